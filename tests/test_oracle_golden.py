@@ -1,0 +1,254 @@
+"""
+Pins the CPU oracle (oracle/*.c) to the reference:
+  * golden vectors produced by the real Cython reference (oracle/gen_golden.py),
+  * the known answers of the reference's own tests
+    (lib/bx/intervals/intersection_tests.py, lib/bx/bitset_tests.py,
+     doctests intersection.pyx:335-376),
+  * op-for-op equality with oracle/_ref (the reference's C compiled in place),
+    when that library is present.
+CPU only.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from bitset_replay import replay
+from bxmi import synth
+from oracle import oracle as O
+
+
+# ---------------------------------------------------------------- intervals --
+def build_tree(case):
+    t = O.OracleIntervalTree()
+    t.insert_many(case["starts"], case["ends"])
+    return t
+
+
+def test_find_matches_reference_vectors(golden_trees):
+    nq = 0
+    for case in golden_trees:
+        t = build_tree(case)
+        assert t.traverse().tolist() == case["order"], (case["mode"], case["n"])
+        for (qs, qe), want in zip(case["queries"], case["hits"]):
+            assert t.find(qs, qe).tolist() == want, (case["mode"], case["n"], qs, qe)
+            nq += 1
+    assert nq > 2000
+
+
+def test_order_key_model(golden_trees):
+    """In-order == sort by (start, end<=start first, -i / +i).
+
+    SURVEY A.1 states the flag as end == start; the reversed-target vectors show it is
+    end <= start (intersection.pyx:112-116 compares `end` with the node's *start*).
+    This is the sort key the device index is built with."""
+    for case in golden_trees:
+        s, e = case["starts"], case["ends"]
+        key = sorted(range(len(s)), key=lambda i: (s[i], 0 if e[i] <= s[i] else 1, -i if e[i] <= s[i] else i))
+        assert key == case["order"], (case["mode"], case["n"])
+
+
+def test_batch_apis_agree_with_find(golden_trees):
+    for case in golden_trees[::5]:
+        t = build_tree(case)
+        q = np.array(case["queries"], dtype=np.int32)
+        counts, total = t.count_batch(q[:, 0], q[:, 1])
+        offs, hits = t.find_batch(q[:, 0], q[:, 1])
+        assert counts.tolist() == [len(h) for h in case["hits"]]
+        assert total == sum(len(h) for h in case["hits"]) == offs[-1]
+        assert hits.tolist() == [x for h in case["hits"] for x in h]
+
+
+def test_neighbours_match_reference_vectors(golden_trees):
+    n = 0
+    for case in golden_trees:
+        if not case["neighbours"]:
+            continue
+        t = build_tree(case)
+        for kind, pos, k, md, want in case["neighbours"]:
+            got = t.left(pos, n=k, max_dist=md) if kind == "before" else t.right(pos, n=k, max_dist=md)
+            assert got == want, (kind, pos, k, md)
+            n += 1
+    assert n > 300
+
+
+def test_reference_known_answers_intervaltree():
+    # intersection_tests.py:158-184 (IntervalTreeTest)
+    t = O.OracleIntervalTree()
+    n = 0
+    for i in range(1, 1000, 80):
+        for a, b in ((i, i + 10), (i + 20, i + 30), (i + 40, i + 50), (i + 60, i + 70)):
+            t.insert(a, b)
+            n += 1
+    assert len(t.find(100, 200)) == 5
+    assert len(t.traverse()) == n
+    # intersection.pyx:345-361 doctests
+    d = O.OracleIntervalTree()
+    for a, b in ((0, 10), (3, 7), (3, 40), (13, 50)):
+        d.insert(a, b)
+    assert d.find(30, 50).tolist() == [2, 3]
+    assert d.find(100, 200).tolist() == []
+    assert d.left(10) == [1]  # before_interval(Interval(10, 20)) -> [Interval(3, 7)]
+    assert d.left(5) == []
+    assert d.left(11) == [0]  # upstream_of_interval(Interval(11, 12))
+    assert d.right(12) == [3]  # ... strand="-"
+    assert d.right(2, n=3) == [1, 2, 3]
+    e = O.OracleIntervalTree()
+    e.insert(0, 10)
+    e.insert(3, 7)
+    assert e.find(2, 5).tolist() == [0, 1]
+    # empty tree (intersection_tests.py:186-195)
+    assert O.OracleIntervalTree().find(100, 300).tolist() == []
+
+
+def test_reference_known_answers_neighbours():
+    # intersection_tests.py:17-54 (NeighborTestCase)
+    t = O.OracleIntervalTree()
+    t.insert(50, 59)
+    for i in range(0, 110, 10):
+        if i != 50:
+            t.insert(i, i + 9)
+    se = lambda idx: [(t.starts[i], t.ends[i]) for i in idx]
+    assert se(t.left(60, n=2)) == [(50, 59), (40, 49)]
+    for i in range(10, 100, 10):
+        assert se(t.left(i, max_dist=10, n=1))[0][1] == i - 1
+    assert len(t.left(60, n=200)) == 6
+    for i in range(10, 100, 10):
+        assert se(t.right(i + 1, n=1))[0][0] == i + 10
+    for i in range(0, 100, 10):
+        assert se(t.right(i - 1, max_dist=10, n=1))[0][0] == i
+
+
+def test_reference_known_answers_lotsa():
+    # intersection_tests.py:104-141 (LotsaTestCase): 100k zero-length + 600 x (0,1)
+    t = O.OracleIntervalTree()
+    t.insert(1, 2)
+    s = np.arange(0, 1000000, 10, dtype=np.int32)
+    t.insert_many(s, s)
+    t.insert_many(np.zeros(600, np.int32), np.ones(600, np.int32))
+    assert len(t.right(1, n=33)) == 33
+    assert len(t.left(1, n=33)) == 1
+    assert len(t.right(1, n=9999)) == 250
+    assert len(t.right(1, n=9999, max_dist=99999)) == 9999
+    assert len(t.right(1, max_dist=0, n=10)) == 0
+    for n, d in enumerate(range(10, 1000, 10)):
+        assert len(t.right(1, max_dist=d, n=10000)) == n + 1
+
+
+def _scale_counts(pt):
+    (ts, te), _ = synth.cfg2(pt["n_targets"], 1)
+    qs, qe = synth.uniform_intervals(pt["n_queries_total"], 202)
+    qs, qe = qs[:: pt["stride"]].copy(), qe[:: pt["stride"]].copy()
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(ts, te)
+    counts, total = t.count_batch(qs, qe)
+    return counts, total
+
+
+def test_scale_1M_hash(golden_scale):
+    pt = golden_scale["1M x 200k"]
+    counts, total = _scale_counts(pt)
+    assert total == pt["total"]
+    assert counts[:16].tolist() == pt["first16"]
+    assert hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"]
+
+
+@pytest.mark.slow
+def test_scale_10M_hash(golden_scale):
+    key = "10M x 1M (cfg2 subsample)"
+    if key not in golden_scale:
+        pytest.skip("10M point not generated")
+    pt = golden_scale[key]
+    counts, total = _scale_counts(pt)
+    assert total == pt["total"]
+    assert hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"]
+
+
+# ------------------------------------------------------------------ bitsets --
+def test_binnedbitset_matches_reference_vectors(golden_bitsets):
+    for case in golden_bitsets["cases"]:
+        replay(case, O.OracleBinnedBitSet)
+
+
+def test_binnedbitset_big_sizes(golden_bitsets):
+    for case in golden_bitsets["big"]:
+        replay(case, O.OracleBinnedBitSet, check_final=False)
+
+
+def test_binnedbitset_ctor_limits(golden_bitsets):
+    assert O.MAX == golden_bitsets["MAX"]
+    for size, want in golden_bitsets["ctor"]:
+        try:
+            got = ["ok", O.OracleBinnedBitSet(size).size]
+        except ValueError as ex:
+            got = ["ValueError", str(ex)]
+        assert got == want
+
+
+def test_reference_known_answers_bitset():
+    # lib/bx/bitset_tests.py:51-108 with the same (size, granularity = size % 11) as :117-119
+    def new():
+        return O.OracleBinnedBitSet(100, 100 % 11)
+
+    b = new()
+    for s, e in ((11, 14), (20, 75), (90, 100)):
+        b.set_range(s, e - s)
+    assert [b.count_range(0, 0), b.count_range(0, 20), b.count_range(25, 25), b.count_range(80, 20), b.count_range(0, 100)] == [0, 3, 25, 10, 68]
+    assert [b.next_set(0), b.next_set(13), b.next_set(15)] == [11, 13, 20]
+    assert [b.next_clear(0), b.next_clear(11), b.next_clear(20), b.next_clear(92)] == [0, 14, 75, 100]
+    with pytest.raises(IndexError):
+        b.set(-5)
+    with pytest.raises(IndexError):
+        b.set(110)
+    with pytest.raises(ValueError):
+        O.OracleBinnedBitSet(4000000000, 4000000000 % 11)
+    x, y = new(), new()
+    x.set_range(20, 40)
+    y.set_range(50, 25)
+    x.iand(y)
+    assert x.unpack().tolist() == [1 if 50 <= i < 60 else 0 for i in range(100)]
+    x, y = new(), new()
+    x.set_range(20, 40)
+    y.set_range(50, 25)
+    x.ior(y)
+    assert x.unpack().tolist() == [1 if 20 <= i < 75 else 0 for i in range(100)]
+    z = new()
+    z.set_range(20, 40)
+    z.invert()
+    assert z.unpack().tolist() == [0 if 20 <= i < 60 else 1 for i in range(100)]
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_restatement_equals_compiled_reference_c():
+    """Random differential run: our binbits.c vs the reference's C files compiled in place."""
+    rng = np.random.default_rng(77)
+    for size, gran in ((100, 1), (997, 7), (5000, 64), (70000, 1024), (1 << 20, 1024), (12345, 10)):
+        mine = [O.OracleBinnedBitSet(size, gran) for _ in range(2)]
+        ref = [O.RefBinnedBitSet(size, gran) for _ in range(2)]
+        assert (mine[0].bin_size, mine[0].nbins) == (ref[0].bin_size, ref[0].nbins)
+        for step in range(400):
+            w = int(rng.integers(0, 2))
+            op = int(rng.integers(0, 10))
+            s = int(rng.integers(0, size))
+            n = int(rng.integers(0, min(size - s, max(2, size // 4)) + 1))
+            if op <= 2:
+                mine[w].set_range(s, n), ref[w].set_range(s, n)
+            elif op == 3:
+                assert mine[w].count_range(s, n) == ref[w].count_range(s, n), (size, gran, step)
+            elif op == 4:
+                assert mine[w].next_set(s) == ref[w].next_set(s), (size, gran, step)
+                assert mine[w].next_clear(s) == ref[w].next_clear(s), (size, gran, step)
+            elif op == 5:
+                mine[w].set(s), ref[w].set(s)
+                mine[1 - w].clear(s), ref[1 - w].clear(s)
+            elif op == 6 and rng.random() < 0.4:
+                mine[w].invert(), ref[w].invert()
+            elif op == 7:
+                mine[w].iand(mine[1 - w]), ref[w].iand(ref[1 - w])
+            elif op == 8:
+                mine[w].ior(mine[1 - w]), ref[w].ior(ref[1 - w])
+            else:
+                assert mine[w][s] == ref[w][s]
+        for w in range(2):
+            assert mine[w].count_range(0, size) == ref[w].count_range(0, size)
+            assert all(mine[w][p] == ref[w][p] for p in range(0, size, max(1, size // 997)))
