@@ -1,0 +1,355 @@
+"""
+bx.intervals.intersection -- drop-in for the reference's Cython module
+lib/bx/intervals/intersection.pyx, served by the MI355X engine
+(bxmi.intervals.IntervalIndex over libbxmi.so).
+
+Same public names and behaviour as the reference:
+  Interval                     intersection.pyx:274-323
+  IntervalNode                 intersection.pyx:61-268
+  IntervalTree / Intersecter   intersection.pyx:325-488
+
+The tree is not a treap here.  ``insert`` queues (start, end, payload); the
+first query uploads the queue and builds the device index (radix sort into the
+treap's in-order + 32-ary search levels); ``find`` is a batch-of-one of the
+batched kernel and returns the stored Python objects in the reference's order.
+Throughput comes from the additive batch methods ``find_batch`` / ``count_batch``.
+Nothing is computed on the CPU: without libbxmi.so and a GPU these classes raise.
+"""
+import operator
+
+import numpy as np
+
+from bx.bitset import _cint
+from bxmi.intervals import IntervalIndex
+
+__all__ = ["Interval", "IntervalNode", "IntervalTree", "Intersecter"]
+
+
+class Interval:
+    """
+    Basic feature, with required integer start and end properties.
+    Also accepts optional strand as +1 or -1 (used for up/downstream queries),
+    a name, and any arbitrary data is sent in on the info keyword argument
+    (intersection.pyx:274-323).
+
+    >>> f1 = Interval(23, 36)
+    >>> f2 = Interval(34, 48, value={'chr': 12, 'anno': 'transposon'})
+    >>> f2
+    Interval(34, 48, value={'chr': 12, 'anno': 'transposon'})
+    """
+
+    __slots__ = ("start", "end", "value", "chrom", "strand")
+
+    def __init__(self, start, end, value=None, chrom=None, strand=None):
+        start, end = _cint(start), _cint(end)
+        assert start <= end, "start must be less than end"
+        self.start = start
+        self.end = end
+        self.value = value
+        self.chrom = chrom
+        self.strand = strand
+
+    def __repr__(self):
+        fstr = "Interval(%d, %d" % (self.start, self.end)
+        if self.value is not None:
+            fstr += ", value=" + str(self.value)
+        fstr += ")"
+        return fstr
+
+    # intersection.pyx:305-323 -- the reference's (deliberately odd) ordering
+    def __lt__(self, other):
+        return self.start < other.start or self.end < other.end
+
+    def __le__(self, other):
+        return self == other or self < other
+
+    def __eq__(self, other):
+        return self.start == other.start and self.end == other.end
+
+    def __ne__(self, other):
+        return self.start != other.start or self.end != other.end
+
+    def __gt__(self, other):
+        return self.start > other.start or self.end > other.end
+
+    def __ge__(self, other):
+        return self == other or self > other
+
+    __hash__ = None
+
+
+class _Core:
+    """Payload list + device index shared by an IntervalTree and its IntervalNode views."""
+
+    def __init__(self):
+        self.index = IntervalIndex()
+        self.values = []
+        self.starts = []
+        self.ends = []
+        self._flushed = 0
+        self._order = None
+
+    def insert(self, start, end, value):
+        self.starts.append(start)
+        self.ends.append(end)
+        self.values.append(value)
+        self._order = None
+
+    def __len__(self):
+        return len(self.values)
+
+    def _flush(self):
+        n = len(self.values)
+        if self._flushed < n:
+            self.index.append(
+                np.array(self.starts[self._flushed:], dtype=np.int32), np.array(self.ends[self._flushed:], dtype=np.int32)
+            )
+            self._flushed = n
+
+    def find(self, start, end):
+        self._flush()
+        _, hits = self.index.find(np.array([start], dtype=np.int32), np.array([end], dtype=np.int32), cap_hint=4096)
+        vals = self.values
+        return [vals[i] for i in hits.tolist()]
+
+    def order(self):
+        if self._order is None:
+            self._flush()
+            self._order = self.index.order().tolist()
+        return self._order
+
+    # intersection.pyx:232-260
+    def left(self, position, n=1, max_dist=2500):
+        n, max_dist = _cint(n), _cint(max_dist)
+        self._flush()
+        cand = self.index.neighbors(_cint(position - 1) + 1, max_dist, -1).tolist()
+        results = [self.values[i] for i in cand]
+        if len(results) == n:
+            return results
+        results.sort(key=operator.attrgetter("end"), reverse=True)
+        return results[:n]
+
+    def right(self, position, n=1, max_dist=2500):
+        n, max_dist = _cint(n), _cint(max_dist)
+        self._flush()
+        cand = self.index.neighbors(_cint(position + 1) - 1, max_dist, +1).tolist()
+        results = [self.values[i] for i in cand]
+        if len(results) == n:
+            return results
+        results.sort(key=operator.attrgetter("start"))
+        return results[:n]
+
+
+class IntervalNode:
+    """
+    A single node of an `IntervalTree` (intersection.pyx:61-268).
+
+    NOTE: Unless you really know what you are doing, you probably should use
+          `IntervalTree` rather than using this directly.
+
+    Here a node is a *view* of a position range of the device index laid out as
+    an implicit balanced search tree; the root view spans everything.
+    """
+
+    def __init__(self, start, end, interval, _core=None, _span=None, _parent=None):
+        if _core is None:
+            _core = _Core()
+            _core.insert(_cint(start), _cint(end), interval)
+        self._core = _core
+        self._span = _span  # None = whole tree (root); else (lo, hi) over the in-order sequence
+        self._parent = _parent
+
+    # ---- the node's own interval -------------------------------------------
+    def _bounds(self):
+        return (0, len(self._core)) if self._span is None else self._span
+
+    def _mid(self):
+        lo, hi = self._bounds()
+        return self._core.order()[(lo + hi) // 2]
+
+    @property
+    def start(self):
+        return self._core.starts[self._mid()]
+
+    @property
+    def end(self):
+        return self._core.ends[self._mid()]
+
+    @property
+    def interval(self):
+        return self._core.values[self._mid()]
+
+    @property
+    def left_node(self):
+        lo, hi = self._bounds()
+        mid = (lo + hi) // 2
+        return IntervalNode(0, 0, None, self._core, (lo, mid), self) if mid > lo else None
+
+    @property
+    def right_node(self):
+        lo, hi = self._bounds()
+        mid = (lo + hi) // 2
+        return IntervalNode(0, 0, None, self._core, (mid + 1, hi), self) if hi > mid + 1 else None
+
+    @property
+    def root_node(self):
+        return self._parent
+
+    def __repr__(self):
+        return "IntervalNode(%i, %i)" % (self.start, self.end)
+
+    # ---- operations ----------------------------------------------------------
+    def insert(self, start, end, interval):
+        """Insert a new interval; returns the (possibly new) root, like intersection.pyx:103-138."""
+        self._core.insert(_cint(start), _cint(end), interval)
+        return self if self._span is None else IntervalNode(0, 0, None, self._core)
+
+    def intersect(self, start, end, sort=True):
+        """given a start and a end, return a list of features falling within that range"""
+        return self._core.find(_cint(start), _cint(end))
+
+    find = intersect
+
+    def left(self, position, n=1, max_dist=2500):
+        return self._core.left(position, n, max_dist)
+
+    def right(self, position, n=1, max_dist=2500):
+        return self._core.right(position, n, max_dist)
+
+    def traverse(self, func):
+        lo, hi = self._bounds()
+        core = self._core
+        order = core.order()
+        for k in range(lo, hi):
+            func(_Leaf(core, order[k]))
+
+
+class _Leaf:
+    """What traverse() hands to the callback: .start/.end/.interval of one stored interval."""
+
+    __slots__ = ("start", "end", "interval")
+
+    def __init__(self, core, i):
+        self.start = core.starts[i]
+        self.end = core.ends[i]
+        self.interval = core.values[i]
+
+    def __repr__(self):
+        return "IntervalNode(%i, %i)" % (self.start, self.end)
+
+
+class IntervalTree:
+    """
+    Data structure for performing window intersect queries on a set of
+    of possibly overlapping 1d intervals (intersection.pyx:325-485).
+
+    >>> intersecter = IntervalTree()
+    >>> intersecter.insert( 0, 10, "food" )
+    >>> intersecter.insert( 3, 7, dict(foo='bar') )
+    >>> intersecter.find( 2, 5 )
+    ['food', {'foo': 'bar'}]
+    """
+
+    def __init__(self):
+        self._core = None
+
+    def _c(self):
+        if self._core is None:
+            self._core = _Core()
+        return self._core
+
+    # ---- Position based interfaces -----------------------------------------
+    def insert(self, start, end, value=None):
+        """Insert the interval [start,end) associated with value `value`."""
+        self._c().insert(_cint(start), _cint(end), value)
+
+    add = insert
+
+    def find(self, start, end):
+        """Return a sorted list of all intervals overlapping [start,end)."""
+        if self._core is None:
+            return []
+        return self._core.find(_cint(start), _cint(end))
+
+    def before(self, position, num_intervals=1, max_dist=2500):
+        """Find `num_intervals` intervals that lie before `position` and are no further than `max_dist` positions away"""
+        if self._core is None:
+            return []
+        return self._core.left(position, num_intervals, max_dist)
+
+    def after(self, position, num_intervals=1, max_dist=2500):
+        """Find `num_intervals` intervals that lie after `position` and are no further than `max_dist` positions away"""
+        if self._core is None:
+            return []
+        return self._core.right(position, num_intervals, max_dist)
+
+    # ---- Interval-like object based interfaces -----------------------------
+    def insert_interval(self, interval):
+        """Insert an "interval" like object (one with at least start and end attributes)"""
+        self.insert(interval.start, interval.end, interval)
+
+    add_interval = insert_interval
+
+    def before_interval(self, interval, num_intervals=1, max_dist=2500):
+        if self._core is None:
+            return []
+        return self._core.left(interval.start, num_intervals, max_dist)
+
+    def after_interval(self, interval, num_intervals=1, max_dist=2500):
+        if self._core is None:
+            return []
+        return self._core.right(interval.end, num_intervals, max_dist)
+
+    def upstream_of_interval(self, interval, num_intervals=1, max_dist=2500):
+        if self._core is None:
+            return []
+        if interval.strand == -1 or interval.strand == "-":
+            return self._core.right(interval.end, num_intervals, max_dist)
+        return self._core.left(interval.start, num_intervals, max_dist)
+
+    def downstream_of_interval(self, interval, num_intervals=1, max_dist=2500):
+        if self._core is None:
+            return []
+        if interval.strand == -1 or interval.strand == "-":
+            return self._core.left(interval.start, num_intervals, max_dist)
+        return self._core.right(interval.end, num_intervals, max_dist)
+
+    def traverse(self, fn):
+        """call fn for each element in the tree"""
+        if self._core is None:
+            return None
+        return IntervalNode(0, 0, None, self._core).traverse(fn)
+
+    # ---- additive batch API (not in the reference) ---------------------------
+    def insert_batch(self, starts, ends, values=None):
+        """insert(starts[i], ends[i], values[i]) for all i (values default to None)."""
+        c = self._c()
+        s = np.asarray(starts).tolist()
+        e = np.asarray(ends).tolist()
+        c.starts.extend(s)
+        c.ends.extend(e)
+        c.values.extend(values if values is not None else [None] * len(s))
+        c._order = None
+
+    def count_batch(self, starts, ends):
+        """len(find(starts[i], ends[i])) for all i -> (int32 array, total)."""
+        if self._core is None:
+            n = len(starts)
+            return np.zeros(n, dtype=np.int32), 0
+        self._core._flush()
+        return self._core.index.count(starts, ends)
+
+    def find_batch(self, starts, ends):
+        """CSR (offsets, payload indices) of find(starts[i], ends[i]); map indices with .values."""
+        if self._core is None:
+            return np.zeros(len(starts) + 1, dtype=np.int64), np.empty(0, dtype=np.int32)
+        self._core._flush()
+        return self._core.index.find(starts, ends)
+
+    @property
+    def values(self):
+        return self._c().values
+
+
+# For backward compatibility
+Intersecter = IntervalTree

@@ -1,0 +1,138 @@
+"""
+Batch interval index on the MI355X -- the engine under
+``bx.intervals.intersection.IntervalTree`` (reference: lib/bx/intervals/intersection.pyx).
+
+``IntervalIndex`` keeps intervals as int32 SoA arrays in HBM and answers whole
+batches of ``find`` queries per kernel launch.  Payloads never leave the host:
+the device returns *insertion indices* in the reference's result order.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import as_i32, call, ptr
+
+
+class IntervalIndex:
+    """SoA interval index; insertion index == payload id.
+
+    append() -> seal() -> count()/find() ; appending again un-seals, the next
+    query re-seals (the index is rebuilt from the device-resident arrays).
+    """
+
+    def __init__(self):
+        _ffi.require_gpu()
+        h = C.c_void_p()
+        call("bxmi_ivl_create", C.byref(h))
+        self._h = h
+        self._n = 0
+        self._sealed = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.load().bxmi_ivl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self._n
+
+    # ---- build -------------------------------------------------------------
+    def append(self, starts, ends):
+        """IntervalTree.insert(start, end, i) for each pair, in order (intersection.pyx:388-395)."""
+        s, e = as_i32(starts), as_i32(ends)
+        if s.shape != e.shape or s.ndim != 1:
+            raise ValueError("starts and ends must be 1-d arrays of equal length")
+        if len(s):
+            call("bxmi_ivl_append", self._h, ptr(s), ptr(e), len(s))
+            self._n += len(s)
+            self._sealed = False
+
+    def append_dev(self, starts_ptr, ends_ptr, n, stream=None):
+        call("bxmi_ivl_append_dev", self._h, starts_ptr, ends_ptr, n, stream)
+        self._n += n
+        self._sealed = False
+
+    def seal(self, stream=None):
+        call("bxmi_ivl_seal", self._h, stream)
+        self._sealed = True
+
+    def _ready(self):
+        if not self._sealed:
+            self.seal()
+
+    @property
+    def has_reversed(self):
+        self._ready()
+        f = C.c_int(0)
+        call("bxmi_ivl_has_reversed", self._h, C.byref(f))
+        return bool(f.value)
+
+    def order(self):
+        """Insertion indices in the treap's in-order (== IntervalTree.traverse order)."""
+        self._ready()
+        out = np.empty(self._n, dtype=np.int32)
+        if self._n:
+            call("bxmi_ivl_order", self._h, ptr(out))
+        return out
+
+    # ---- queries -----------------------------------------------------------
+    def count(self, qs, qe, want_counts=True):
+        """len(find(qs[i], qe[i])) for every i  ->  (int32[nq] or None, int total)."""
+        self._ready()
+        qs, qe = as_i32(qs), as_i32(qe)
+        if qs.shape != qe.shape or qs.ndim != 1:
+            raise ValueError("qs and qe must be 1-d arrays of equal length")
+        counts = np.empty(len(qs), dtype=np.int32) if want_counts else None
+        total = C.c_int64(0)
+        call("bxmi_ivl_count", self._h, ptr(qs), ptr(qe), len(qs), ptr(counts), C.byref(total))
+        return counts, total.value
+
+    def find(self, qs, qe, cap_hint=None):
+        """Batched find(): CSR (offsets int64[nq+1], hits int32[total]) of insertion indices."""
+        self._ready()
+        qs, qe = as_i32(qs), as_i32(qe)
+        if qs.shape != qe.shape or qs.ndim != 1:
+            raise ValueError("qs and qe must be 1-d arrays of equal length")
+        nq = len(qs)
+        offsets = np.zeros(nq + 1, dtype=np.int64)
+        cap = int(cap_hint) if cap_hint is not None else max(1024, 8 * nq)
+        total = C.c_int64(0)
+        for _ in range(2):
+            hits = np.empty(cap, dtype=np.int32)
+            rc = call("bxmi_ivl_find", self._h, ptr(qs), ptr(qe), nq, ptr(offsets), ptr(hits), cap, C.byref(total),
+                      allow=(_ffi.ERANGE,))
+            if rc == _ffi.OK:
+                return offsets, hits[: total.value]
+            cap = total.value
+        raise _ffi.BxmiError(_ffi.ERANGE, "find: hit buffer still too small")
+
+    def count_dev(self, qs_ptr, qe_ptr, nq, counts_ptr, total_ptr, stream=None):
+        """Device-pointer form used by bench.py / the sharded driver (no host sync)."""
+        self._ready()
+        call("bxmi_ivl_count_dev", self._h, qs_ptr, qe_ptr, nq, counts_ptr, total_ptr, stream)
+
+    def find_dev(self, qs_ptr, qe_ptr, nq, offsets_ptr, hits_ptr, cap, stream=None):
+        self._ready()
+        total = C.c_int64(0)
+        rc = call("bxmi_ivl_find_dev", self._h, qs_ptr, qe_ptr, nq, offsets_ptr, hits_ptr, cap, C.byref(total), stream,
+                  allow=(_ffi.ERANGE,))
+        return rc, total.value
+
+    def neighbors(self, position, max_dist, direction, cap=4096):
+        """Candidate list of IntervalNode.left (direction<0) / right (direction>0), intersection.pyx:192-229."""
+        self._ready()
+        n_out = C.c_int64(0)
+        for _ in range(2):
+            out = np.empty(max(cap, 1), dtype=np.int32)
+            call("bxmi_ivl_neighbors", self._h, int(position), int(max_dist), int(direction), ptr(out), len(out), C.byref(n_out))
+            if n_out.value <= len(out):
+                return out[: n_out.value]
+            cap = n_out.value
+        raise _ffi.BxmiError(_ffi.ERANGE, "neighbors: buffer still too small")

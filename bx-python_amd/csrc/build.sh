@@ -1,0 +1,21 @@
+#!/bin/bash
+# Build libbxmi.so for gfx950 (MI355X) in-tree: bx-python_amd/bxmi/libbxmi.so.
+# hipcc cross-compiles without a GPU; the .so travels to the GPU box with gpurun.
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../bxmi/libbxmi.so"
+OBJ="$HERE/_obj"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${BXMI_EXTRA_FLAGS:-}"
+mkdir -p "$OBJ"
+pids=()
+for f in core intervals bitset; do
+  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.hpp" -nt "$OBJ/$f.o" ] \
+     || [ "$HERE/primitives.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/bxmi.h" -nt "$OBJ/$f.o" ]; then
+    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/core.o" "$OBJ/intervals.o" "$OBJ/bitset.o"
+echo "built $OUT"

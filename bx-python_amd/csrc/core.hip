@@ -1,0 +1,134 @@
+// core.hip -- library-level entry points of libbxmi: error text, device
+// selection, raw HBM staging and the tuning knobs.
+#include <mutex>
+
+#include "common.hpp"
+
+namespace bxmi {
+
+std::string &last_error()
+{
+    thread_local std::string e;
+    return e;
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+const DeviceProps &device_props()
+{
+    // refreshed when the current device changes (one process normally owns one GPU)
+    thread_local DeviceProps p;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return p;
+    if (p.device != dev) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+            p.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            p.device = dev;
+        }
+    }
+    return p;
+}
+
+int ivl_set_option(const char *key, int64_t value);
+int bits_set_option(const char *key, int64_t value);
+
+}  // namespace bxmi
+
+using namespace bxmi;
+
+extern "C" int bxmi_version(void) { return 100; }  // 0.1.0
+
+extern "C" const char *bxmi_last_error(void) { return last_error().c_str(); }
+
+extern "C" int bxmi_device_count(int *n)
+{
+    if (!n) return fail(BXMI_EINVAL, "bxmi_device_count: n is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return fail(BXMI_EHIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n = c;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_set_device(int device)
+{
+    BXMI_HIP(hipSetDevice(device));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_get_device(int *device)
+{
+    if (!device) return fail(BXMI_EINVAL, "bxmi_get_device: device is NULL");
+    BXMI_HIP(hipGetDevice(device));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_device_info(int device, char *name, int name_len, int *compute_units, int64_t *hbm_bytes)
+{
+    hipDeviceProp_t prop;
+    BXMI_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_synchronize(void *stream)
+{
+    BXMI_HIP(hipStreamSynchronize(as_stream(stream)));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_malloc(void **dptr, size_t bytes)
+{
+    if (!dptr) return fail(BXMI_EINVAL, "bxmi_malloc: dptr is NULL");
+    *dptr = nullptr;
+    BXMI_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_free(void *dptr)
+{
+    if (dptr) BXMI_HIP(hipFree(dptr));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes) BXMI_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (bytes) BXMI_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_memset(void *dst_dev, int value, size_t bytes)
+{
+    if (bytes) BXMI_HIP(hipMemset(dst_dev, value, bytes));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_set_option(const char *key, int64_t value)
+{
+    if (!key) return fail(BXMI_EINVAL, "bxmi_set_option: key is NULL");
+    if (ivl_set_option(key, value) || bits_set_option(key, value)) return BXMI_OK;
+    return fail(BXMI_EINVAL, "bxmi_set_option: unknown key '%s'", key);
+}

@@ -1,0 +1,885 @@
+// intervals.hip -- the interval index behind IntervalTree/Intersecter.find().
+//
+// Reference algorithm (lib/bx/intervals/intersection.pyx): a randomised treap
+// of Python nodes, find() = pointer-chasing DFS (:180-189) that reports, in
+// in-order, every interval with  end > qs  and  start < qe.
+//
+// MI355X design (not a treap):
+//   * seal(): radix-sort the intervals into the treap's in-order, which is the
+//     sort by (start, end<=start first, -i / +i) (intersection.pyx:112-116);
+//     keep SoA int32 arrays in that order: s_ord, e_ord, idx, plus the prefix
+//     max of e_ord (pm) and the separately sorted ends (e_sorted).
+//   * every rank query goes through a static 32-ary search tree: a node is
+//     32 int32 keys = one 128-byte line; 8 lanes cooperate on a node (one
+//     coalesced 16-byte load each, compare 4 keys, 3 DPP adds).  The top
+//     levels are staged in LDS, the lower ones come from L2 / HBM.  A 10M
+//     index is 5 levels deep: 3 LDS visits + 2 line fetches per rank.
+//   * count = rank_lt(starts, qe) - rank_le(ends, qs) for proper queries on
+//     proper targets; anything else (zero-length / reversed query, reversed
+//     target) takes the exact window scan [first pm>qs, rank_lt(starts,qe)).
+//   * find = the same window, compacted with wave ballots into CSR order.
+// Integer compares and popcounts only: HBM/L2-latency bound, no MFMA.
+#include <climits>
+#include <vector>
+
+#include "primitives.hpp"
+
+namespace bxmi {
+
+constexpr int MAXLEV = 7;          // 32^7 > 2^31
+constexpr int FAN = 32;            // keys per node (128 B)
+constexpr int LDS_TREE_INTS = 18688;  // per tree: 73 KiB, two trees + scratch < 160 KiB
+constexpr int CNT_THREADS = 1024;  // one workgroup per CU, 16 waves
+constexpr int CNT_Q = 4;           // queries in flight per 8-lane group
+
+struct TreeDev {
+    const int32_t *lev[MAXLEV];  // lev[0] = leaves (the sorted array, padded with INT_MAX)
+    int32_t lds_off[MAXLEV];     // offset (ints) of the level inside this tree's LDS region
+    int32_t lev_ints[MAXLEV];    // ints in the level (32 * nodes)
+    int32_t nlev;
+    int32_t lds_from;            // levels >= lds_from live in LDS
+    int32_t lds_ints;            // total ints staged
+};
+
+struct IndexDev {
+    const int32_t *s_ord, *e_ord, *idx, *pm;
+    int32_t n;
+    int32_t has_reversed;
+};
+
+// ---------------------------------------------------------------------------
+// build kernels
+// ---------------------------------------------------------------------------
+// 64-bit sort key: biased start in the high word, then the tie rule of
+// intersection.pyx:112-116 -- on equal starts, intervals with end <= start go
+// LEFT (so they come first, newest first), the others go right (oldest first).
+__global__ void ivl_make_keys_kernel(const int32_t *__restrict__ start, const int32_t *__restrict__ end, int64_t n,
+                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ end_keys,
+                                     unsigned *__restrict__ n_reversed)
+{
+    unsigned rev = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int32_t s = start[i], e = end[i];
+        uint32_t sub = (e <= s) ? (0x7fffffffu - (uint32_t)i) : (0x80000000u | (uint32_t)i);
+        keys[i] = ((unsigned long long)((uint32_t)s ^ 0x80000000u) << 32) | sub;
+        end_keys[i] = (uint32_t)e ^ 0x80000000u;
+        rev += (e < s);
+    }
+    unsigned long long m = __ballot(rev != 0);
+    if (m && lane_id() == (int)__ffsll((long long)m) - 1) {
+        // one atomic per wave is plenty: we only need "zero or not"
+        atomicAdd(n_reversed, 1u);
+    }
+}
+
+__global__ void ivl_unpack_kernel(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ end,
+                                  int64_t n, int64_t n_pad, int32_t *__restrict__ s_ord, int32_t *__restrict__ e_ord,
+                                  int32_t *__restrict__ idx)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_pad; k += (int64_t)gridDim.x * blockDim.x) {
+        if (k < n) {
+            unsigned long long key = keys[k];
+            uint32_t sub = (uint32_t)key;
+            int32_t i = (sub & 0x80000000u) ? (int32_t)(sub & 0x7fffffffu) : (int32_t)(0x7fffffffu - sub);
+            s_ord[k] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
+            idx[k] = i;
+            e_ord[k] = end[i];
+        } else {  // padding up to a whole node
+            s_ord[k] = INT_MAX;
+            e_ord[k] = INT_MIN;
+            idx[k] = -1;
+        }
+    }
+}
+
+__global__ void ivl_unbias_kernel(const uint32_t *__restrict__ in, int64_t n, int64_t n_pad, int32_t *__restrict__ out)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_pad; k += (int64_t)gridDim.x * blockDim.x)
+        out[k] = k < n ? (int32_t)(in[k] ^ 0x80000000u) : INT_MAX;
+}
+
+__global__ void ivl_pad_kernel(int32_t *__restrict__ a, int64_t n, int64_t n_pad, int32_t v)
+{
+    int64_t k = n + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_pad) a[k] = v;
+}
+
+// Level l+1 of a search tree: entry j = last key of child node j, except that
+// the LAST child (and every padding slot) gets INT_MAX, a fence no key is
+// greater than.  With the fence, "number of entries < key" is always a valid
+// child index and no clamping is needed on the way down.
+__global__ void ivl_tree_level_kernel(const int32_t *__restrict__ below, int64_t nodes_below,
+                                      int32_t *__restrict__ out, int64_t out_ints)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < out_ints; j += (int64_t)gridDim.x * blockDim.x)
+        out[j] = (j < nodes_below - 1) ? below[j * FAN + (FAN - 1)] : INT_MAX;
+}
+
+// ---------------------------------------------------------------------------
+// device-side search
+// ---------------------------------------------------------------------------
+template <bool DPP>
+__device__ __forceinline__ int node_count_lt(int4 v, int key)
+{
+    int c = (v.x < key) + (v.y < key) + (v.z < key) + (v.w < key);
+    return DPP ? group8_sum_dpp(c) : group8_sum_shfl(c);
+}
+
+__device__ __forceinline__ void stage_tree(const TreeDev &t, int32_t *lds)
+{
+    for (int l = t.nlev - 1; l >= t.lds_from; --l) {
+        const int4 *src = reinterpret_cast<const int4 *>(t.lev[l]);
+        int4 *dst = reinterpret_cast<int4 *>(lds + t.lds_off[l]);
+        int n4 = t.lev_ints[l] >> 2;
+        for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
+    }
+}
+
+// rank_lt for NQ independent keys at once (ILP): returns #{a[i] < key}.
+template <bool DPP, int NQ>
+__device__ __forceinline__ void tree_rank_lt(const TreeDev &t, const int32_t *lds, const int (&key)[NQ], int (&rank)[NQ],
+                                             int sub)
+{
+#pragma unroll
+    for (int j = 0; j < NQ; j++) rank[j] = 0;
+    for (int l = t.nlev - 1; l >= 0; --l) {
+        int4 v[NQ];
+        if (l >= t.lds_from) {
+            const int32_t *b = lds + t.lds_off[l] + sub * 4;
+#pragma unroll
+            for (int j = 0; j < NQ; j++) v[j] = *reinterpret_cast<const int4 *>(b + rank[j] * FAN);
+        } else {
+            const int32_t *b = t.lev[l] + sub * 4;
+#pragma unroll
+            for (int j = 0; j < NQ; j++) v[j] = *reinterpret_cast<const int4 *>(b + (int64_t)rank[j] * FAN);
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; j++) rank[j] = rank[j] * FAN + node_count_lt<DPP>(v[j], key[j]);
+    }
+}
+
+// Plain lower bound on the monotone prefix-max array: first k with pm[k] > qs.
+__device__ __forceinline__ int first_pm_gt(const int32_t *__restrict__ pm, int n, int qs)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (pm[mid] > qs)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
+// #{k in [lo,hi) : e_ord[k] > qs}, 8 lanes x int4 per 32-element step, aligned.
+template <bool DPP>
+__device__ __forceinline__ int window_count(const int32_t *__restrict__ e_ord, int lo, int hi, int qs, int sub)
+{
+    int c = 0;
+    for (int k0 = lo & ~(FAN - 1); k0 < hi; k0 += FAN) {
+        int kb = k0 + sub * 4;
+        int4 v = *reinterpret_cast<const int4 *>(e_ord + kb);
+        c += (kb + 0 >= lo && kb + 0 < hi && v.x > qs);
+        c += (kb + 1 >= lo && kb + 1 < hi && v.y > qs);
+        c += (kb + 2 >= lo && kb + 2 < hi && v.z > qs);
+        c += (kb + 3 >= lo && kb + 3 < hi && v.w > qs);
+    }
+    return DPP ? group8_sum_dpp(c) : group8_sum_shfl(c);
+}
+
+// ---------------------------------------------------------------------------
+// count kernel (the headline path: 100M queries x 10M targets)
+// ---------------------------------------------------------------------------
+template <bool DPP>
+__global__ __launch_bounds__(CNT_THREADS) void ivl_count_kernel(TreeDev S, TreeDev E, IndexDev ix,
+                                                               const int32_t *__restrict__ qs_arr,
+                                                               const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                               int32_t *__restrict__ counts,
+                                                               unsigned long long *__restrict__ total)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    int32_t *ldsS = lds, *ldsE = lds + S.lds_ints;
+    long long *red = reinterpret_cast<long long *>(lds + S.lds_ints + E.lds_ints);  // 16 slots after the staged levels
+    stage_tree(S, ldsS);
+    stage_tree(E, ldsE);
+    __syncthreads();
+
+    const int sub = threadIdx.x & 7;
+    const int64_t group = (int64_t)blockIdx.x * (CNT_THREADS / 8) + (threadIdx.x >> 3);
+    const int64_t ngroups = (int64_t)gridDim.x * (CNT_THREADS / 8);
+    long long acc = 0;
+
+    for (int64_t q0 = group * CNT_Q; q0 < nq; q0 += ngroups * CNT_Q) {
+        int qs[CNT_Q], qe[CNT_Q];
+        if (q0 + CNT_Q <= nq) {
+            int4 a = *reinterpret_cast<const int4 *>(qs_arr + q0);
+            int4 b = *reinterpret_cast<const int4 *>(qe_arr + q0);
+            qs[0] = a.x, qs[1] = a.y, qs[2] = a.z, qs[3] = a.w;
+            qe[0] = b.x, qe[1] = b.y, qe[2] = b.z, qe[3] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < CNT_Q; j++) {
+                bool ok = q0 + j < nq;
+                qs[j] = ok ? qs_arr[q0 + j] : 0;
+                qe[j] = ok ? qe_arr[q0 + j] : 0;  // (0,0): zero-length, handled below, result discarded
+            }
+        }
+        // rank_lt(starts, qe) and rank_le(ends, qs) = rank_lt(ends, qs+1)
+        int kE[CNT_Q], rS[CNT_Q], rE[CNT_Q];
+#pragma unroll
+        for (int j = 0; j < CNT_Q; j++) kE[j] = qs[j] == INT_MAX ? INT_MAX : qs[j] + 1;
+        tree_rank_lt<DPP, CNT_Q>(S, ldsS, qe, rS, sub);
+        tree_rank_lt<DPP, CNT_Q>(E, ldsE, kE, rE, sub);
+
+        int cnt[CNT_Q];
+#pragma unroll
+        for (int j = 0; j < CNT_Q; j++) {
+            bool regular = (qs[j] < qe[j]) && !ix.has_reversed;
+            if (regular) {
+                cnt[j] = rS[j] - (qs[j] == INT_MAX ? ix.n : rE[j]);
+            } else {
+                // exact predicate over the candidate window (uniform inside the 8-lane group)
+                int lo = first_pm_gt(ix.pm, ix.n, qs[j]);
+                cnt[j] = lo < rS[j] ? window_count<DPP>(ix.e_ord, lo, rS[j], qs[j], sub) : 0;
+            }
+        }
+        if (sub == 0) {
+            if (q0 + CNT_Q <= nq) {
+                if (counts) *reinterpret_cast<int4 *>(counts + q0) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
+                acc += (long long)cnt[0] + cnt[1] + cnt[2] + cnt[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < CNT_Q; j++)
+                    if (q0 + j < nq) {
+                        if (counts) counts[q0 + j] = cnt[j];
+                        acc += cnt[j];
+                    }
+            }
+        }
+    }
+    if (total) block_accumulate_i64(acc, red, total);
+}
+
+// ---------------------------------------------------------------------------
+// find kernels: window + count, then ballot-compacted fill
+// ---------------------------------------------------------------------------
+constexpr int FIND_THREADS = 512;
+constexpr int FIND_Q = 2;
+
+template <bool DPP>
+__global__ __launch_bounds__(FIND_THREADS) void ivl_find_count_kernel(TreeDev S, TreeDev P, IndexDev ix,
+                                                                     const int32_t *__restrict__ qs_arr,
+                                                                     const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                                     int32_t *__restrict__ win_lo,
+                                                                     int32_t *__restrict__ win_hi,
+                                                                     int32_t *__restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    int32_t *ldsS = lds, *ldsP = lds + S.lds_ints;
+    stage_tree(S, ldsS);
+    stage_tree(P, ldsP);
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    const int64_t group = (int64_t)blockIdx.x * (FIND_THREADS / 8) + (threadIdx.x >> 3);
+    const int64_t ngroups = (int64_t)gridDim.x * (FIND_THREADS / 8);
+    for (int64_t q0 = group * FIND_Q; q0 < nq; q0 += ngroups * FIND_Q) {
+        int qs[FIND_Q], qe[FIND_Q], kP[FIND_Q], hi[FIND_Q], lo[FIND_Q];
+#pragma unroll
+        for (int j = 0; j < FIND_Q; j++) {
+            bool ok = q0 + j < nq;
+            qs[j] = ok ? qs_arr[q0 + j] : 0;
+            qe[j] = ok ? qe_arr[q0 + j] : 0;
+            kP[j] = qs[j] == INT_MAX ? INT_MAX : qs[j] + 1;
+        }
+        tree_rank_lt<DPP, FIND_Q>(S, ldsS, qe, hi, sub);  // #{start < qe}
+        tree_rank_lt<DPP, FIND_Q>(P, ldsP, kP, lo, sub);  // #{pm <= qs} = first k with pm[k] > qs
+#pragma unroll
+        for (int j = 0; j < FIND_Q; j++) {
+            if (qs[j] == INT_MAX) lo[j] = ix.n;
+            int c = lo[j] < hi[j] ? window_count<DPP>(ix.e_ord, lo[j], hi[j], qs[j], sub) : 0;
+            if (sub == 0 && q0 + j < nq) {
+                win_lo[q0 + j] = lo[j];
+                win_hi[q0 + j] = hi[j];
+                counts[q0 + j] = c;
+            }
+        }
+    }
+}
+
+// One 8-lane group per query; every 32-element step is compacted with four
+// wave ballots: the byte of this group in ballot j tells which of its lanes
+// hit in slot j, so a lane's output position is a handful of popcounts.
+__global__ __launch_bounds__(FIND_THREADS) void ivl_find_fill_kernel(IndexDev ix, const int32_t *__restrict__ qs_arr,
+                                                                    int64_t nq, const int32_t *__restrict__ win_lo,
+                                                                    const int32_t *__restrict__ win_hi,
+                                                                    const int64_t *__restrict__ offsets,
+                                                                    int32_t *__restrict__ hits)
+{
+    const int lane = lane_id();
+    const int sub = lane & 7, gshift = lane & ~7;
+    const unsigned below = (1u << sub) - 1u;
+    const int64_t group = (int64_t)blockIdx.x * (FIND_THREADS / 8) + (threadIdx.x >> 3);
+    const int64_t ngroups = (int64_t)gridDim.x * (FIND_THREADS / 8);
+    for (int64_t q = group; q < nq; q += ngroups) {
+        int lo = win_lo[q], hi = win_hi[q], qs = qs_arr[q];
+        int64_t base = offsets[q];
+        if (offsets[q + 1] == base) continue;
+        for (int k0 = lo & ~(FAN - 1); k0 < hi; k0 += FAN) {
+            int kb = k0 + sub * 4;
+            int4 v = *reinterpret_cast<const int4 *>(ix.e_ord + kb);
+            bool f0 = kb + 0 >= lo && kb + 0 < hi && v.x > qs;
+            bool f1 = kb + 1 >= lo && kb + 1 < hi && v.y > qs;
+            bool f2 = kb + 2 >= lo && kb + 2 < hi && v.z > qs;
+            bool f3 = kb + 3 >= lo && kb + 3 < hi && v.w > qs;
+            unsigned b0 = (unsigned)(__ballot(f0) >> gshift) & 0xffu;
+            unsigned b1 = (unsigned)(__ballot(f1) >> gshift) & 0xffu;
+            unsigned b2 = (unsigned)(__ballot(f2) >> gshift) & 0xffu;
+            unsigned b3 = (unsigned)(__ballot(f3) >> gshift) & 0xffu;
+            int step = __popc(b0) + __popc(b1) + __popc(b2) + __popc(b3);
+            if (f0 | f1 | f2 | f3) {
+                int64_t pos = base + __popc(b0 & below) + __popc(b1 & below) + __popc(b2 & below) + __popc(b3 & below);
+                int4 id = *reinterpret_cast<const int4 *>(ix.idx + kb);
+                if (f0) hits[pos++] = id.x;
+                if (f1) hits[pos++] = id.y;
+                if (f2) hits[pos++] = id.z;
+                if (f3) hits[pos++] = id.w;
+            }
+            base += step;
+        }
+    }
+}
+
+// before()/after() candidate filter over a window of the in-order arrays
+// (single query, one workgroup): keeps k in [lo,hi) with vlo <= val[k] < vhi.
+__global__ __launch_bounds__(256) void ivl_filter_window_kernel(const int32_t *__restrict__ val,
+                                                               const int32_t *__restrict__ idx, int lo, int hi,
+                                                               long long vlo, long long vhi, int reverse,
+                                                               int32_t *__restrict__ out, int64_t cap,
+                                                               unsigned long long *__restrict__ n_out)
+{
+    __shared__ int wave_tot[4];
+    __shared__ long long run;
+    if (threadIdx.x == 0) run = 0;
+    __syncthreads();
+    int span = hi - lo;
+    for (int b = 0; b < span; b += 256) {
+        int t = b + threadIdx.x;
+        int k = reverse ? hi - 1 - t : lo + t;
+        bool ok = t < span;
+        bool f = false;
+        if (ok) {
+            long long v = val[k];
+            f = v >= vlo && v < vhi;
+        }
+        unsigned long long m = __ballot(f);
+        int w = threadIdx.x >> 6;
+        if (lane_id() == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int i = 0; i < 4; i++) {
+            if (i < w) woff += wave_tot[i];
+            tot += wave_tot[i];
+        }
+        long long pos = run + woff + __popcll(m & lanemask_lt());
+        if (f && pos < cap) out[pos] = idx[k];
+        __syncthreads();
+        if (threadIdx.x == 0) run += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = (unsigned long long)run;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct Tree {
+    DevBuf upper;  // levels 1.. (level 0 is the caller's padded sorted array)
+    TreeDev dev{};
+    int build(const int32_t *leaves, int64_t n, hipStream_t st)
+    {
+        dev = TreeDev{};
+        int64_t nodes[MAXLEV];
+        nodes[0] = n > 0 ? div_up(n, FAN) : 1;
+        int nlev = 1;
+        while (nodes[nlev - 1] > 1) {
+            nodes[nlev] = div_up(nodes[nlev - 1], FAN);
+            nlev++;
+        }
+        int64_t upper_ints = 0;
+        for (int l = 1; l < nlev; l++) upper_ints += nodes[l] * FAN;
+        BXMI_TRY(upper.reserve((size_t)(upper_ints + 4) * sizeof(int32_t)));
+        int32_t *p = upper.as<int32_t>();
+        dev.lev[0] = leaves;
+        dev.lev_ints[0] = (int32_t)(nodes[0] * FAN);
+        for (int l = 1; l < nlev; l++) {
+            int64_t ints = nodes[l] * FAN;
+            hipLaunchKernelGGL(ivl_tree_level_kernel, dim3(stream_grid(ints, 256)), dim3(256), 0, st, dev.lev[l - 1], nodes[l - 1],
+                               p, ints);
+            dev.lev[l] = p;
+            dev.lev_ints[l] = (int32_t)ints;
+            p += ints;
+        }
+        BXMI_LAUNCH_CHECK();
+        dev.nlev = nlev;
+        set_lds_budget(LDS_TREE_INTS);
+        return BXMI_OK;
+    }
+    // Stage as many top levels as fit in `budget` ints.
+    void set_lds_budget(int64_t budget)
+    {
+        int64_t used = 0;
+        int from = dev.nlev;
+        for (int l = dev.nlev - 1; l >= 0; --l) {
+            if (used + dev.lev_ints[l] > budget) break;
+            dev.lds_off[l] = (int32_t)used;
+            used += dev.lev_ints[l];
+            from = l;
+        }
+        dev.lds_from = from;
+        dev.lds_ints = (int32_t)used;
+    }
+};
+
+static int64_t g_opt_group_sum = 0;   // 0 = DPP, 1 = ds_bpermute shuffles
+static int64_t g_opt_lds_ints = LDS_TREE_INTS;
+static int64_t g_opt_count_grid = 0;  // 0 = one workgroup per CU
+
+int ivl_set_option(const char *key, int64_t value)
+{
+    if (!strcmp(key, "ivl.group_sum")) {
+        g_opt_group_sum = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.lds_ints")) {
+        g_opt_lds_ints = value < 0 ? 0 : (value > LDS_TREE_INTS ? LDS_TREE_INTS : value);
+        return 1;
+    }
+    if (!strcmp(key, "ivl.count_grid")) {
+        g_opt_count_grid = value;
+        return 1;
+    }
+    return 0;
+}
+
+}  // namespace bxmi
+
+using namespace bxmi;
+
+struct bxmi_ivl {
+    // host staging of appended intervals (insertion order)
+    std::vector<int32_t> h_start, h_end;
+    // device copies in insertion order
+    DevBuf d_start, d_end;
+    int64_t n_dev = 0;   // intervals resident on device (insertion order)
+    int64_t n = 0;       // intervals in the sealed index
+    bool sealed = false;
+    int has_reversed = 0;
+    // sealed index
+    DevBuf keys_a, keys_b, ekeys_a, ekeys_b;
+    DevBuf s_ord, e_ord, idx, pm, e_sorted, flag;
+    Tree treeS, treeE, treeP;
+    SortScratch sort_scratch;
+    DevBuf scan_scratch;
+    // query scratch
+    DevBuf q_s, q_e, q_cnt, q_lo, q_hi, q_off, q_hits, q_total;
+    hipStream_t stream = nullptr;
+    int device = 0;
+};
+
+static int ivl_stream(bxmi_ivl *h)
+{
+    if (!h->stream) BXMI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_create(bxmi_ivl_t **out)
+{
+    if (!out) return fail(BXMI_EINVAL, "bxmi_ivl_create: out is NULL");
+    int dev = 0;
+    BXMI_HIP(hipGetDevice(&dev));
+    bxmi_ivl *h = new (std::nothrow) bxmi_ivl();
+    if (!h) return fail(BXMI_ENOMEM, "bxmi_ivl_create: host allocation failed");
+    h->device = dev;
+    *out = h;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_destroy(bxmi_ivl_t *h)
+{
+    if (!h) return BXMI_OK;
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_append(bxmi_ivl_t *h, const int32_t *start, const int32_t *end, int64_t n)
+{
+    if (!h || n < 0 || (n > 0 && (!start || !end))) return fail(BXMI_EINVAL, "bxmi_ivl_append: bad arguments");
+    if ((int64_t)h->h_start.size() + h->n_dev + n >= ((int64_t)1 << 31) - 64)
+        return fail(BXMI_EINVAL, "bxmi_ivl_append: more than 2^31 intervals");
+    try {
+        h->h_start.insert(h->h_start.end(), start, start + n);
+        h->h_end.insert(h->h_end.end(), end, end + n);
+    } catch (...) {
+        return fail(BXMI_ENOMEM, "bxmi_ivl_append: host allocation failed");
+    }
+    if (n) h->sealed = false;
+    return BXMI_OK;
+}
+
+// Move host-staged intervals to the device arrays (insertion order preserved).
+static int ivl_flush_host(bxmi_ivl *h, hipStream_t st)
+{
+    int64_t add = (int64_t)h->h_start.size();
+    if (!add) return BXMI_OK;
+    int64_t tot = h->n_dev + add;
+    BXMI_TRY(h->d_start.reserve((size_t)tot * 4, true, st));
+    BXMI_TRY(h->d_end.reserve((size_t)tot * 4, true, st));
+    BXMI_HIP(hipMemcpyAsync(h->d_start.as<int32_t>() + h->n_dev, h->h_start.data(), (size_t)add * 4, hipMemcpyHostToDevice, st));
+    BXMI_HIP(hipMemcpyAsync(h->d_end.as<int32_t>() + h->n_dev, h->h_end.data(), (size_t)add * 4, hipMemcpyHostToDevice, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    h->n_dev = tot;
+    h->h_start.clear();
+    h->h_end.clear();
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_append_dev(bxmi_ivl_t *h, const int32_t *start, const int32_t *end, int64_t n, void *stream)
+{
+    if (!h || n < 0 || (n > 0 && (!start || !end))) return fail(BXMI_EINVAL, "bxmi_ivl_append_dev: bad arguments");
+    hipStream_t st = as_stream(stream);
+    BXMI_TRY(ivl_flush_host(h, st));
+    int64_t tot = h->n_dev + n;
+    if (tot >= ((int64_t)1 << 31) - 64) return fail(BXMI_EINVAL, "bxmi_ivl_append_dev: more than 2^31 intervals");
+    BXMI_TRY(h->d_start.reserve((size_t)tot * 4, true, st));
+    BXMI_TRY(h->d_end.reserve((size_t)tot * 4, true, st));
+    BXMI_HIP(hipMemcpyAsync(h->d_start.as<int32_t>() + h->n_dev, start, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    BXMI_HIP(hipMemcpyAsync(h->d_end.as<int32_t>() + h->n_dev, end, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    h->n_dev = tot;
+    if (n) h->sealed = false;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
+{
+    if (!h) return fail(BXMI_EINVAL, "bxmi_ivl_seal: NULL handle");
+    hipStream_t st = as_stream(stream);
+    BXMI_TRY(ivl_flush_host(h, st));
+    const int64_t n = h->n_dev;
+    const int64_t n_pad = (n > 0 ? div_up(n, FAN) : 1) * FAN;
+    const size_t pad_bytes = (size_t)(n_pad + FAN) * 4;
+
+    BXMI_TRY(h->keys_a.reserve((size_t)(n + 1) * 8));
+    BXMI_TRY(h->keys_b.reserve((size_t)(n + 1) * 8));
+    BXMI_TRY(h->ekeys_a.reserve((size_t)(n + 1) * 4));
+    BXMI_TRY(h->ekeys_b.reserve((size_t)(n + 1) * 4));
+    BXMI_TRY(h->s_ord.reserve(pad_bytes));
+    BXMI_TRY(h->e_ord.reserve(pad_bytes));
+    BXMI_TRY(h->idx.reserve(pad_bytes));
+    BXMI_TRY(h->pm.reserve(pad_bytes));
+    BXMI_TRY(h->e_sorted.reserve(pad_bytes));
+    BXMI_TRY(h->flag.reserve(64));
+
+    unsigned *d_rev = h->flag.as<unsigned>();
+    BXMI_HIP(hipMemsetAsync(d_rev, 0, 4, st));
+    const int g = stream_grid(n_pad, 256 * 4);
+    if (n > 0) {
+        hipLaunchKernelGGL(ivl_make_keys_kernel, dim3(g), dim3(256), 0, st, h->d_start.as<int32_t>(), h->d_end.as<int32_t>(), n,
+                           h->keys_a.as<unsigned long long>(), h->ekeys_a.as<uint32_t>(), d_rev);
+        BXMI_LAUNCH_CHECK();
+    }
+    unsigned long long *sorted_keys = nullptr;
+    uint32_t *sorted_ends = nullptr;
+    BXMI_TRY(radix_sort_keys<unsigned long long>(h->keys_a.as<unsigned long long>(), h->keys_b.as<unsigned long long>(), n,
+                                                 &sorted_keys, h->sort_scratch, st));
+    BXMI_TRY(radix_sort_keys<uint32_t>(h->ekeys_a.as<uint32_t>(), h->ekeys_b.as<uint32_t>(), n, &sorted_ends, h->sort_scratch, st));
+    hipLaunchKernelGGL(ivl_unpack_kernel, dim3(g), dim3(256), 0, st, sorted_keys, h->d_end.as<int32_t>(), n, n_pad,
+                       h->s_ord.as<int32_t>(), h->e_ord.as<int32_t>(), h->idx.as<int32_t>());
+    hipLaunchKernelGGL(ivl_unbias_kernel, dim3(g), dim3(256), 0, st, sorted_ends, n, n_pad, h->e_sorted.as<int32_t>());
+    BXMI_LAUNCH_CHECK();
+    // prefix max of ends in tree order; padding = INT_MAX so the pm tree's leaves stay sorted
+    BXMI_TRY((device_scan<int32_t, int32_t, OpMax, true>(h->e_ord.as<int32_t>(), h->pm.as<int32_t>(), n, INT_MIN, nullptr,
+                                                        h->scan_scratch, st)));
+    if (n_pad > n) {
+        hipLaunchKernelGGL(ivl_pad_kernel, dim3((unsigned)div_up(n_pad - n, 64)), dim3(64), 0, st, h->pm.as<int32_t>(), n, n_pad, INT_MAX);
+        BXMI_LAUNCH_CHECK();
+    }
+    BXMI_TRY(h->treeS.build(h->s_ord.as<int32_t>(), n, st));
+    BXMI_TRY(h->treeE.build(h->e_sorted.as<int32_t>(), n, st));
+    BXMI_TRY(h->treeP.build(h->pm.as<int32_t>(), n, st));
+    unsigned rev = 0;
+    BXMI_HIP(hipMemcpyAsync(&rev, d_rev, 4, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    h->has_reversed = rev != 0;
+    h->n = n;
+    h->sealed = true;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_size(const bxmi_ivl_t *h, int64_t *n)
+{
+    if (!h || !n) return fail(BXMI_EINVAL, "bxmi_ivl_size: bad arguments");
+    *n = h->n_dev + (int64_t)h->h_start.size();
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_has_reversed(const bxmi_ivl_t *h, int *flag)
+{
+    if (!h || !flag) return fail(BXMI_EINVAL, "bxmi_ivl_has_reversed: bad arguments");
+    if (!h->sealed) return fail(BXMI_ESTATE, "bxmi_ivl_has_reversed: index not sealed");
+    *flag = h->has_reversed;
+    return BXMI_OK;
+}
+
+static int need_sealed(const bxmi_ivl *h, const char *who)
+{
+    if (!h) return fail(BXMI_EINVAL, "%s: NULL handle", who);
+    if (!h->sealed) return fail(BXMI_ESTATE, "%s: index not sealed (call bxmi_ivl_seal after appending)", who);
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_order_dev(const bxmi_ivl_t *h, const int32_t **idx_dev, const int32_t **start_dev,
+                                  const int32_t **end_dev)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_order_dev"));
+    if (idx_dev) *idx_dev = h->idx.as<int32_t>();
+    if (start_dev) *start_dev = h->s_ord.as<int32_t>();
+    if (end_dev) *end_dev = h->e_ord.as<int32_t>();
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_order(const bxmi_ivl_t *h, int32_t *idx_out)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_order"));
+    if (h->n && !idx_out) return fail(BXMI_EINVAL, "bxmi_ivl_order: idx_out is NULL");
+    if (h->n) BXMI_HIP(hipMemcpy(idx_out, h->idx.p, (size_t)h->n * 4, hipMemcpyDeviceToHost));
+    return BXMI_OK;
+}
+
+static IndexDev index_dev(const bxmi_ivl *h)
+{
+    IndexDev ix;
+    ix.s_ord = h->s_ord.as<int32_t>();
+    ix.e_ord = h->e_ord.as<int32_t>();
+    ix.idx = h->idx.as<int32_t>();
+    ix.pm = h->pm.as<int32_t>();
+    ix.n = (int32_t)h->n;
+    ix.has_reversed = h->has_reversed;
+    return ix;
+}
+
+template <typename Kern>
+static int allow_big_lds(Kern k, size_t bytes)
+{
+    BXMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
+                                  int64_t *total_dev, void *stream)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_count_dev"));
+    if (nq < 0 || (nq > 0 && (!qs || !qe))) return fail(BXMI_EINVAL, "bxmi_ivl_count_dev: bad arguments");
+    if (nq == 0) return BXMI_OK;
+    if (((uintptr_t)qs | (uintptr_t)qe | (uintptr_t)counts) & 15)
+        return fail(BXMI_EINVAL, "bxmi_ivl_count_dev: query/count arrays must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    TreeDev S = h->treeS.dev, E = h->treeE.dev;
+    Tree tS = Tree(), tE = Tree();
+    if (g_opt_lds_ints != LDS_TREE_INTS) {  // A/B knob: restage fewer levels
+        tS.dev = S, tE.dev = E;
+        tS.set_lds_budget(g_opt_lds_ints), tE.set_lds_budget(g_opt_lds_ints);
+        S = tS.dev, E = tE.dev;
+    }
+    size_t lds_bytes = (size_t)(S.lds_ints + E.lds_ints) * 4 + (CNT_THREADS / 64) * sizeof(long long);
+    int grid = g_opt_count_grid > 0 ? (int)g_opt_count_grid : device_props().cus;
+    int64_t need = div_up(nq, (int64_t)(CNT_THREADS / 8) * CNT_Q);
+    if (need < grid) grid = (int)need;
+    unsigned long long *tot = reinterpret_cast<unsigned long long *>(total_dev);
+    if (g_opt_group_sum == 0) {
+        BXMI_TRY(allow_big_lds(ivl_count_kernel<true>, lds_bytes));
+        hipLaunchKernelGGL(ivl_count_kernel<true>, dim3(grid), dim3(CNT_THREADS), lds_bytes, st, S, E, index_dev(h), qs, qe, nq, counts, tot);
+    } else {
+        BXMI_TRY(allow_big_lds(ivl_count_kernel<false>, lds_bytes));
+        hipLaunchKernelGGL(ivl_count_kernel<false>, dim3(grid), dim3(CNT_THREADS), lds_bytes, st, S, E, index_dev(h), qs, qe, nq, counts, tot);
+    }
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+static int upload_queries(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, hipStream_t st)
+{
+    BXMI_TRY(h->q_s.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->q_e.reserve((size_t)(nq + 4) * 4));
+    BXMI_HIP(hipMemcpyAsync(h->q_s.p, qs, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    BXMI_HIP(hipMemcpyAsync(h->q_e.p, qe, (size_t)nq * 4, hipMemcpyHostToDevice, st));
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_count(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_count"));
+    if (nq < 0 || (nq > 0 && (!qs || !qe))) return fail(BXMI_EINVAL, "bxmi_ivl_count: bad arguments");
+    if (total) *total = 0;
+    if (nq == 0) return BXMI_OK;
+    BXMI_TRY(ivl_stream(h));
+    hipStream_t st = h->stream;
+    BXMI_TRY(upload_queries(h, qs, qe, nq, st));
+    BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->q_total.reserve(64));
+    BXMI_HIP(hipMemsetAsync(h->q_total.p, 0, 8, st));
+    BXMI_TRY(bxmi_ivl_count_dev(h, h->q_s.as<int32_t>(), h->q_e.as<int32_t>(), nq, counts ? h->q_cnt.as<int32_t>() : nullptr,
+                                h->q_total.as<int64_t>(), st));
+    if (counts) BXMI_HIP(hipMemcpyAsync(counts, h->q_cnt.p, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    int64_t t = 0;
+    BXMI_HIP(hipMemcpyAsync(&t, h->q_total.p, 8, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    if (total) *total = t;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,
+                                 int32_t *hits, int64_t cap, int64_t *total_host, void *stream)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_find_dev"));
+    if (nq < 0 || !offsets || (nq > 0 && (!qs || !qe)) || cap < 0 || (cap > 0 && !hits))
+        return fail(BXMI_EINVAL, "bxmi_ivl_find_dev: bad arguments");
+    hipStream_t st = as_stream(stream);
+    if (nq == 0) {
+        BXMI_HIP(hipMemsetAsync(offsets, 0, 8, st));
+        if (total_host) *total_host = 0;
+        return BXMI_OK;
+    }
+    BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->q_lo.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->q_hi.reserve((size_t)(nq + 4) * 4));
+    TreeDev S = h->treeS.dev, P = h->treeP.dev;
+    size_t lds_bytes = (size_t)(S.lds_ints + P.lds_ints) * 4;
+    IndexDev ix = index_dev(h);
+    int grid = device_props().cus * 2;
+    int64_t need = div_up(nq, (int64_t)(FIND_THREADS / 8) * FIND_Q);
+    if (need < grid) grid = (int)need;
+    if (g_opt_group_sum == 0) {
+        BXMI_TRY(allow_big_lds(ivl_find_count_kernel<true>, lds_bytes));
+        hipLaunchKernelGGL(ivl_find_count_kernel<true>, dim3(grid), dim3(FIND_THREADS), lds_bytes, st, S, P, ix, qs, qe, nq,
+                           h->q_lo.as<int32_t>(), h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
+    } else {
+        BXMI_TRY(allow_big_lds(ivl_find_count_kernel<false>, lds_bytes));
+        hipLaunchKernelGGL(ivl_find_count_kernel<false>, dim3(grid), dim3(FIND_THREADS), lds_bytes, st, S, P, ix, qs, qe, nq,
+                           h->q_lo.as<int32_t>(), h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
+    }
+    BXMI_LAUNCH_CHECK();
+    // offsets[0..nq) = exclusive sum of counts, offsets[nq] = total
+    BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
+                                                           reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
+    int64_t total = 0;
+    BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    if (total_host) *total_host = total;
+    if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
+    if (total == 0) return BXMI_OK;
+    int fgrid = stream_grid(nq, FIND_THREADS / 8);
+    hipLaunchKernelGGL(ivl_find_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, ix, qs, nq, h->q_lo.as<int32_t>(),
+                       h->q_hi.as<int32_t>(), offsets, hits);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits,
+                             int64_t cap, int64_t *total)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_find"));
+    if (nq < 0 || !offsets || (nq > 0 && (!qs || !qe)) || cap < 0 || (cap > 0 && !hits))
+        return fail(BXMI_EINVAL, "bxmi_ivl_find: bad arguments");
+    BXMI_TRY(ivl_stream(h));
+    hipStream_t st = h->stream;
+    if (nq == 0) {
+        offsets[0] = 0;
+        if (total) *total = 0;
+        return BXMI_OK;
+    }
+    BXMI_TRY(upload_queries(h, qs, qe, nq, st));
+    BXMI_TRY(h->q_off.reserve((size_t)(nq + 2) * 8));
+    BXMI_TRY(h->q_hits.reserve((size_t)(cap + 4) * 4));
+    int64_t tot = 0;
+    int rc = bxmi_ivl_find_dev(h, h->q_s.as<int32_t>(), h->q_e.as<int32_t>(), nq, h->q_off.as<int64_t>(), h->q_hits.as<int32_t>(), cap,
+                               &tot, st);
+    if (total) *total = tot;
+    if (rc != BXMI_OK && rc != BXMI_ERANGE) return rc;
+    BXMI_HIP(hipMemcpyAsync(offsets, h->q_off.p, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (rc == BXMI_OK && tot > 0) BXMI_HIP(hipMemcpyAsync(hits, h->q_hits.p, (size_t)tot * 4, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    return rc;
+}
+
+// Two lower-bound ranks for the single-position neighbour API:
+// out[t] = #{a_t[k] < x_t}, thresholds in 64 bits so position +/- max_dist cannot overflow.
+__global__ void ivl_two_ranks_kernel(const int32_t *__restrict__ a0, long long x0, const int32_t *__restrict__ a1,
+                                     long long x1, int n, int *out)
+{
+    if (threadIdx.x < 2) {
+        const int32_t *a = threadIdx.x ? a1 : a0;
+        long long x = threadIdx.x ? x1 : x0;
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+            if ((long long)a[mid] < x)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        out[threadIdx.x] = lo;
+    }
+}
+
+extern "C" int bxmi_ivl_neighbors(bxmi_ivl_t *h, int32_t position, int32_t max_dist, int dir, int32_t *out, int64_t cap,
+                                  int64_t *n_out)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_neighbors"));
+    if (!n_out || cap < 0 || (cap > 0 && !out) || dir == 0) return fail(BXMI_EINVAL, "bxmi_ivl_neighbors: bad arguments");
+    *n_out = 0;
+    if (h->n == 0) return BXMI_OK;
+    BXMI_TRY(ivl_stream(h));
+    hipStream_t st = h->stream;
+    BXMI_TRY(h->q_cnt.reserve(64));
+    BXMI_TRY(h->q_total.reserve(64));
+    BXMI_TRY(h->q_hits.reserve((size_t)(cap + 4) * 4));
+    int *d_r = h->q_cnt.as<int>();
+    int r[2] = {0, 0};
+    const int n = (int)h->n;
+    long long vlo, vhi;
+    int lo, hi;
+    if (dir > 0) {
+        // intersection.pyx:213-229,255: p = position + 1, keep 0 <= start - p < max_dist (in-order)
+        long long p = (long long)position + 1;
+        vlo = p, vhi = p + max_dist;
+        hipLaunchKernelGGL(ivl_two_ranks_kernel, dim3(1), dim3(64), 0, st, h->s_ord.as<int32_t>(), vlo, h->s_ord.as<int32_t>(), vhi, n, d_r);
+        BXMI_HIP(hipMemcpyAsync(r, d_r, 8, hipMemcpyDeviceToHost, st));
+        BXMI_HIP(hipStreamSynchronize(st));
+        lo = r[0], hi = r[1];
+        hipLaunchKernelGGL(ivl_filter_window_kernel, dim3(1), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->idx.as<int32_t>(), lo, hi, vlo, vhi,
+                           0, h->q_hits.as<int32_t>(), cap, h->q_total.as<unsigned long long>());
+    } else {
+        // intersection.pyx:192-209,240: p = position - 1, keep 0 <= p - end < max_dist (reverse in-order)
+        // i.e. p - max_dist < end <= p.  Candidates lie in [first k with pm[k] > p-max_dist, #{start <= p}):
+        // the upper bound is the reference's own `minstart > position` prune (:196-197).
+        long long p = (long long)position - 1;
+        vlo = p - max_dist + 1, vhi = p + 1;
+        hipLaunchKernelGGL(ivl_two_ranks_kernel, dim3(1), dim3(64), 0, st, h->pm.as<int32_t>(), vlo, h->s_ord.as<int32_t>(), vhi, n, d_r);
+        BXMI_HIP(hipMemcpyAsync(r, d_r, 8, hipMemcpyDeviceToHost, st));
+        BXMI_HIP(hipStreamSynchronize(st));
+        lo = r[0], hi = r[1];
+        if (hi < lo) hi = lo;
+        hipLaunchKernelGGL(ivl_filter_window_kernel, dim3(1), dim3(256), 0, st, h->e_ord.as<int32_t>(), h->idx.as<int32_t>(), lo, hi, vlo, vhi,
+                           1, h->q_hits.as<int32_t>(), cap, h->q_total.as<unsigned long long>());
+    }
+    BXMI_LAUNCH_CHECK();
+    unsigned long long cnt = 0;
+    BXMI_HIP(hipMemcpyAsync(&cnt, h->q_total.p, 8, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    *n_out = (int64_t)cnt;
+    int64_t ncopy = (int64_t)cnt < cap ? (int64_t)cnt : cap;
+    if (ncopy > 0) BXMI_HIP(hipMemcpy(out, h->q_hits.p, (size_t)ncopy * 4, hipMemcpyDeviceToHost));
+    return BXMI_OK;
+}

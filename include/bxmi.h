@@ -1,0 +1,159 @@
+/*
+ * bxmi.h -- C ABI of libbxmi.so, the MI355X (gfx950) engine behind
+ *   bx.intervals.intersection.IntervalTree / Intersecter   (insert, find)
+ *   bx.bitset.BinnedBitSet                                 (set_range, iand, ior, count_range, ...)
+ *
+ * Plain C, opaque handles, plain pointers and sizes; no torch / Python types.
+ * Every function returns a status (BXMI_OK == 0); bxmi_last_error() gives the
+ * text of the last failure on the calling thread.
+ *
+ * Pointer convention: arguments are HOST pointers unless the function name ends
+ * in `_dev`, in which case every array argument is a DEVICE pointer (HBM) and
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).  Host
+ * variants stage through the library's own stream and return when the result
+ * is in the caller's buffer.
+ *
+ * Reference interfaces replaced (bx-python 0.14.0, paths under the reference):
+ *   src/binBits.h:15-26          the 12 binBits* functions  -> bxmi_bits_*
+ *   lib/bx/bitset.pyx:198-241    BinnedBitSet methods        -> call bxmi_bits_*
+ *   lib/bx/intervals/intersection.pyx:388-406,428-435
+ *                                IntervalTree.insert/find    -> bxmi_ivl_*
+ *   (intersection.pyx has no C ABI of its own: its cdef classes are the
+ *    interface, so the entry points below are what a Cython/ctypes shim of
+ *    those classes binds; see INTEGRATION.md.)
+ */
+#ifndef BXMI_H
+#define BXMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BXMI_OK 0
+#define BXMI_EINVAL 1 /* bad argument (NULL handle, negative count, size > 2^31-1, ...) */
+#define BXMI_ENOMEM 2 /* host or device allocation failed */
+#define BXMI_EHIP 3   /* a HIP runtime call or kernel launch failed */
+#define BXMI_ESTATE 4 /* call not valid in the handle's state (e.g. query before seal) */
+#define BXMI_ERANGE 5 /* caller's output buffer too small; the needed size is reported */
+
+typedef struct bxmi_ivl bxmi_ivl_t;   /* one interval index == one IntervalTree */
+typedef struct bxmi_bits bxmi_bits_t; /* one binned bitset  == one BinnedBitSet */
+
+/* ---- library / device ---------------------------------------------------- */
+int bxmi_version(void);
+const char *bxmi_last_error(void);
+int bxmi_device_count(int *n);
+int bxmi_set_device(int device);
+int bxmi_get_device(int *device);
+int bxmi_device_info(int device, char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+int bxmi_synchronize(void *stream);
+
+/* Raw HBM staging for hosts that do not bring their own allocator. */
+int bxmi_malloc(void **dptr, size_t bytes);
+int bxmi_free(void *dptr);
+int bxmi_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int bxmi_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int bxmi_memset(void *dst_dev, int value, size_t bytes);
+
+/* Tuning knobs (process-wide): key/value, e.g. ("ivl.group_sum", 0=dpp 1=shfl). */
+int bxmi_set_option(const char *key, int64_t value);
+
+/* ---- interval index  (intersection.pyx) ---------------------------------- */
+/* IntervalTree()                                   intersection.pyx:380-382 */
+int bxmi_ivl_create(bxmi_ivl_t **out);
+int bxmi_ivl_destroy(bxmi_ivl_t *h);
+/* IntervalTree.insert(start, end, value) x n, in insertion order; the payload
+ * of interval i is its insertion index (the host keeps the objects).
+ * Any int32 pair is accepted, like the reference (start > end, negatives).
+ *                                                  intersection.pyx:388-397 */
+int bxmi_ivl_append(bxmi_ivl_t *h, const int32_t *start, const int32_t *end, int64_t n);
+int bxmi_ivl_append_dev(bxmi_ivl_t *h, const int32_t *start, const int32_t *end, int64_t n, void *stream);
+/* Build the device index over everything appended so far: radix sort into the
+ * treap's in-order (key start, end<=start first, -i/+i), sorted ends, prefix
+ * max of ends, and the 32-ary search levels.  Re-callable after more appends. */
+int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream);
+int bxmi_ivl_size(const bxmi_ivl_t *h, int64_t *n);
+/* 1 if some stored interval has end < start (forces the general count path). */
+int bxmi_ivl_has_reversed(const bxmi_ivl_t *h, int *flag);
+/* In-order sequence of insertion indices == IntervalTree.traverse order.
+ *                                                  intersection.pyx:262-268 */
+int bxmi_ivl_order(const bxmi_ivl_t *h, int32_t *idx_out);
+int bxmi_ivl_order_dev(const bxmi_ivl_t *h, const int32_t **idx_dev, const int32_t **start_dev, const int32_t **end_dev);
+
+/* len(IntervalTree.find(qs[i], qe[i])) for a batch.  counts (int32[nq]) and
+ * total (sum, int64) are each optional (NULL).  Exact for ANY query/target,
+ * including zero-length, reversed and negative ones.
+ *                                                  intersection.pyx:169-189,400-406 */
+int bxmi_ivl_count(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total);
+/* Device variant: *total_dev (device int64) is ACCUMULATED into (zero it first). */
+int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
+                       int64_t *total_dev, void *stream);
+
+/* IntervalTree.find for a batch, as CSR: offsets[nq+1] (int64) and, for query
+ * i, hits[offsets[i]..offsets[i+1]) = insertion indices in the reference's
+ * result order.  If the hit list needs more than `cap` entries the call
+ * returns BXMI_ERANGE with offsets and *total valid and hits untouched. */
+int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,
+                  int32_t *hits, int64_t cap, int64_t *total);
+int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,
+                      int32_t *hits, int64_t cap, int64_t *total_host, void *stream);
+
+/* IntervalNode.left / right candidate collection for before()/after():
+ * dir < 0: reverse in-order, keep 0 <= (position-1) - end   < max_dist
+ * dir > 0: in-order,         keep 0 <= start - (position+1) < max_dist
+ * Writes up to cap insertion indices; *n_out = number of candidates.
+ *                                                  intersection.pyx:192-260 */
+int bxmi_ivl_neighbors(bxmi_ivl_t *h, int32_t position, int32_t max_dist, int dir, int32_t *out, int64_t cap,
+                       int64_t *n_out);
+
+/* ---- binned bitset  (binBits.h:15-26, bitset.pyx:198-241) ----------------- */
+/* binBitsAlloc(size, granularity): bin_size and nbins use the reference's
+ * float32 arithmetic; size > 2^31-1 or size < 1 -> BXMI_EINVAL.
+ * granularity == 0 creates a FLAT set (bitset.pyx:107-173 BitSet over
+ * kent/bits.h: no bins, so no ALL_ONE arithmetic). */
+int bxmi_bits_create(int64_t size, int64_t granularity, bxmi_bits_t **out);
+int bxmi_bits_destroy(bxmi_bits_t *h); /* binBitsFree */
+int bxmi_bits_info(const bxmi_bits_t *h, int32_t *size, int32_t *bin_size, int32_t *nbins);
+/* Device view: dense LSB-first uint64 words covering [0, nbins*bin_size). */
+int bxmi_bits_words_dev(bxmi_bits_t *h, uint64_t **words_dev, int64_t *nwords);
+/* Per-bin state as the reference would hold it: 0 = ALL_ZERO, 1 = ALL_ONE, 2 = allocated. */
+int bxmi_bits_bin_states(bxmi_bits_t *h, uint8_t *out);
+
+int bxmi_bits_get(bxmi_bits_t *h, int32_t pos, int *bit); /* binBitsReadOne  */
+int bxmi_bits_set(bxmi_bits_t *h, int32_t pos);           /* binBitsSetOne   */
+int bxmi_bits_clear(bxmi_bits_t *h, int32_t pos);         /* binBitsClearOne */
+/* binBitsSetRange x n.  Ranges must satisfy 0 <= start, 0 <= len,
+ * start+len <= size (the wrapper raises bitset.pyx's IndexErrors first). */
+int bxmi_bits_set_ranges(bxmi_bits_t *h, const int32_t *start, const int32_t *len, int64_t n);
+int bxmi_bits_set_ranges_dev(bxmi_bits_t *h, const int32_t *start, const int32_t *len, int64_t n, void *stream);
+/* binBitsCountRange x n (including the reference's ALL_ONE-bin arithmetic). */
+int bxmi_bits_count_ranges(bxmi_bits_t *h, const int32_t *start, const int32_t *len, int64_t n, int32_t *out);
+int bxmi_bits_count_ranges_dev(bxmi_bits_t *h, const int32_t *start, const int32_t *len, int64_t n, int32_t *out,
+                               void *stream);
+/* binBitsCountRange for one (possibly chromosome-long) range, grid-wide reduction. */
+int bxmi_bits_count_range(bxmi_bits_t *h, int32_t start, int32_t len, int32_t *out);
+/* binBitsFindSet (val=1) / binBitsFindClear (val=0): first such bit >= start, else size. */
+int bxmi_bits_next(bxmi_bits_t *h, int32_t start, int val, int32_t *out);
+int bxmi_bits_and(bxmi_bits_t *h, const bxmi_bits_t *other); /* binBitsAnd */
+int bxmi_bits_or(bxmi_bits_t *h, const bxmi_bits_t *other);  /* binBitsOr  */
+int bxmi_bits_not(bxmi_bits_t *h);                           /* binBitsNot */
+int bxmi_bits_xor(bxmi_bits_t *h, const bxmi_bits_t *other); /* bitXor (flat sets only, bits.h:56) */
+/* Fused  h &= other  and  popcount(h[0,size))  in one pass over HBM. */
+int bxmi_bits_and_count(bxmi_bits_t *h, const bxmi_bits_t *other, int64_t *count);
+/* Stream-ordered forms used by the bench (no host sync; *count_dev accumulated). */
+int bxmi_bits_and_dev(bxmi_bits_t *h, const bxmi_bits_t *other, void *stream);
+int bxmi_bits_or_dev(bxmi_bits_t *h, const bxmi_bits_t *other, void *stream);
+int bxmi_bits_and_count_dev(bxmi_bits_t *h, const bxmi_bits_t *other, int64_t *count_dev, void *stream);
+int bxmi_bits_popcount_dev(bxmi_bits_t *h, int64_t *count_dev, void *stream);
+/* Maximal runs of set bits inside [from, size), i.e. the pairs the loop
+ * start=next_set(end); end=next_clear(start) of bed_intersect_basewise.py:32-38
+ * produces.  Writes up to cap pairs; *n_runs = number of runs (BXMI_ERANGE if > cap). */
+int bxmi_bits_runs(bxmi_bits_t *h, int32_t from, int32_t *run_start, int32_t *run_end, int64_t cap, int64_t *n_runs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BXMI_H */

@@ -1,0 +1,252 @@
+"""
+GPU parity tests of the bitset path (run on the MI355X box with -m gpu).
+
+Everything goes through the C ABI (libbxmi.so); the checker is the CPU oracle
+(oracle/binbits.c, itself pinned to the reference) and the committed
+reference-generated op sequences.  Bit-exact.
+"""
+import numpy as np
+import pytest
+
+from bitset_replay import replay
+from bxmi import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def B():
+    import bx.bitset
+
+    return bx.bitset
+
+
+# ------------------------------------------------------------------ golden --
+def test_compat_binnedbitset_matches_reference_vectors(golden_bitsets, B):
+    for case in golden_bitsets["cases"]:
+        replay(case, B.BinnedBitSet)
+
+
+def test_compat_binnedbitset_big_sizes(golden_bitsets, B):
+    for case in golden_bitsets["big"]:
+        replay(case, B.BinnedBitSet, check_final=False)
+
+
+def test_compat_ctor_limits(golden_bitsets, B):
+    assert B.MAX == golden_bitsets["MAX"]
+    for size, want in golden_bitsets["ctor"]:
+        try:
+            got = ["ok", B.BinnedBitSet(size).size]
+        except ValueError as ex:
+            got = ["ValueError", str(ex)]
+        assert got == want
+
+
+@pytest.mark.parametrize("kind", ["BitSet", "BinnedBitSet"])
+def test_reference_known_answers(B, kind):
+    """lib/bx/bitset_tests.py:12-119, both classes."""
+
+    def new(size):
+        return B.BitSet(size) if kind == "BitSet" else B.BinnedBitSet(size, size % 11)
+
+    def bits_of(b):
+        return [b[i] for i in range(b.size)]
+
+    with pytest.raises(ValueError):
+        new(4000000000)
+    b = new(100)
+    with pytest.raises(IndexError):
+        b.set(-5)
+    with pytest.raises(IndexError):
+        b.set(110)
+    want = [0] * 100
+    assert bits_of(b) == want
+    for pos in (11, 14, 70, 16):
+        b.set(pos)
+        want[pos] = 1
+    for pos in (14, 80, 16):
+        b.clear(pos)
+        want[pos] = 0
+    assert bits_of(b) == want
+    b = new(100)
+    want = [0] * 100
+    for s, e in ((11, 14), (20, 75), (90, 99)):
+        b.set_range(s, e - s)
+        want[s:e] = [1] * (e - s)
+    assert bits_of(b) == want
+    b = new(100)
+    for s, e in ((11, 14), (20, 75), (90, 100)):
+        b.set_range(s, e - s)
+    assert [b.count_range(0, 0), b.count_range(0, 20), b.count_range(25, 25), b.count_range(80, 20), b.count_range(0, 100)] == [0, 3, 25, 10, 68]
+    assert [b.next_set(0), b.next_set(13), b.next_set(15)] == [11, 13, 20]
+    assert [b.next_clear(0), b.next_clear(11), b.next_clear(20), b.next_clear(92)] == [0, 14, 75, 100]
+    x, y = new(100), new(100)
+    x.set_range(20, 40), y.set_range(50, 25)
+    x.iand(y)
+    assert bits_of(x) == [1 if 50 <= i < 60 else 0 for i in range(100)]
+    x, y = new(100), new(100)
+    x.set_range(20, 40), y.set_range(50, 25)
+    x.ior(y)
+    assert bits_of(x) == [1 if 20 <= i < 75 else 0 for i in range(100)]
+    z = new(100)
+    z.set_range(20, 40)
+    z.invert()
+    assert bits_of(z) == [0 if 20 <= i < 60 else 1 for i in range(100)]
+
+
+def test_flat_bitset_extras(B):
+    """BitSet-only surface: ixor, clone, count_range defaults, next_set(start, end), operators (bitset.pyx:125-173)."""
+    a, b = B.BitSet(200), B.BitSet(200)
+    a.set_range(10, 50), b.set_range(40, 60)
+    c = a.clone()
+    c.ixor(b)
+    assert [c[i] for i in range(200)] == [1 if (10 <= i < 40 or 60 <= i < 100) else 0 for i in range(200)]
+    assert a.count_range() == 50 and a.count_range(30) == 30
+    assert a.next_set(0, 5) == 5 and a.next_set(0) == 10 and a.next_clear(10, 30) == 30 and a.next_clear(10) == 60
+    a &= b
+    assert a.count_range(0, 200) == 20
+    a |= b
+    assert a.count_range(0, 200) == 60
+    a = ~a
+    assert a.count_range(0, 200) == 140 and a.count_range(40, 60) == 0  # no ALL_ONE arithmetic on a flat set
+    with pytest.raises(IndexError):
+        a.next_set(5, 3)
+    with pytest.raises(TypeError):
+        a.iand(B.BinnedBitSet(200))
+
+
+# ------------------------------------------------------- oracle differential --
+@pytest.mark.parametrize("size,gran", [(100, 1), (997, 7), (5000, 64), (70000, 1024), (1 << 20, 1024), (12345, 10), (4097, 4097), (1 << 22, 3)])
+def test_random_differential_batch(O, size, gran):
+    from bxmi.bitset import DeviceBitSet
+
+    rng = np.random.default_rng(size + gran)
+    dev = [DeviceBitSet(size, gran) for _ in range(2)]
+    ora = [O.OracleBinnedBitSet(size, gran) for _ in range(2)]
+    assert (dev[0].bin_size, dev[0].nbins) == (ora[0].bin_size, ora[0].nbins)
+    for step in range(40):
+        w = int(rng.integers(0, 2))
+        op = int(rng.integers(0, 9))
+        m = int(rng.integers(1, 300))
+        s = rng.integers(0, size, size=m)
+        if step % 5 == 0:  # long ranges too: many words, many bins
+            n = rng.integers(0, size, size=m)
+        else:
+            n = rng.integers(0, max(2, min(size, 3000)), size=m)
+        n = np.minimum(n, size - s)
+        if op <= 2:
+            dev[w].set_ranges(s, n), ora[w].set_ranges(s, n)
+        elif op == 3:
+            assert dev[w].count_ranges(s, n).tolist() == ora[w].count_ranges(s, n).tolist(), (size, gran, step)
+        elif op == 4:
+            for p in s[:6].tolist():
+                assert dev[w].next(p, 1) == ora[w].next_set(p), (size, gran, step, p)
+                assert dev[w].next(p, 0) == ora[w].next_clear(p), (size, gran, step, p)
+        elif op == 5:
+            for p in s[:4].tolist():
+                dev[w].set(p), ora[w].set(p)
+                dev[1 - w].clear(p), ora[1 - w].clear(p)
+                assert dev[w].get(p) == 1 and dev[1 - w].get(p) == 0
+        elif op == 6 and rng.random() < 0.5:
+            dev[w].invert(), ora[w].invert()
+        elif op == 7:
+            dev[w].iand(dev[1 - w]), ora[w].iand(ora[1 - w])
+        elif op == 8:
+            dev[w].ior(dev[1 - w]), ora[w].ior(ora[1 - w])
+        for k in range(2):
+            assert dev[k].count_range(0, size) == ora[k].count_range(0, size), (size, gran, step, k)
+    for k in range(2):
+        assert dev[k].bin_states().tolist() == ora[k].states().tolist()
+        assert np.array_equal(dev[k].to_bits(), ora[k].unpack())
+        rs, re = dev[k].runs()
+        ors, ore = ora[k].runs()
+        assert np.array_equal(rs, ors) and np.array_equal(re, ore)
+        mid = size // 3
+        rs2, re2 = dev[k].runs(mid)
+        keep = ore > mid
+        assert np.array_equal(re2, ore[keep]) and np.array_equal(rs2, np.maximum(ors[keep], mid))
+
+
+def test_and_count_fused(O):
+    from bxmi.bitset import DeviceBitSet
+
+    size = 3_000_001
+    rng = np.random.default_rng(11)
+    a, b = DeviceBitSet(size), DeviceBitSet(size)
+    oa, ob = O.OracleBinnedBitSet(size), O.OracleBinnedBitSet(size)
+    for d, o, seed in ((a, oa, 1), (b, ob, 2)):
+        s = rng.integers(0, size - 2000, size=5000)
+        n = rng.integers(1, 2000, size=5000)
+        d.set_ranges(s, n), o.set_ranges(s, n)
+    b.invert(), ob.invert()  # padding bits of the last bin become ones: they must not be counted
+    got = a.and_count(b)
+    oa.iand(ob)
+    assert got == oa.count_range(0, size)
+    assert np.array_equal(a.to_bits(), oa.unpack())
+
+
+def test_batch_errors_match_reference_messages():
+    from bxmi.bitset import DeviceBitSet
+
+    d = DeviceBitSet(1000, 10)
+    with pytest.raises(IndexError, match=r"Count \(-3\) must be non-negative\."):
+        d.set_ranges([5, 10, 20], [5, -3, 5])
+    assert d.count_range(0, 1000) == 5  # the valid prefix was applied, like a per-line loop would have
+    with pytest.raises(IndexError, match=r"End \(1001\) is larger than the size of this BinnedBitSet \(1000\)\."):
+        d.count_ranges([0, 999], [10, 2])
+    with pytest.raises(IndexError, match=r"1000 is larger than the size of this BitSet \(1000\)\."):
+        d.count_ranges([1000], [0])
+    with pytest.raises(IndexError, match=r"BitSet index \(-1\) must be non-negative\."):
+        d.set_ranges([-1], [1])
+    with pytest.raises(ValueError, match="BitSets must have the same size"):
+        d.iand(DeviceBitSet(999, 10))
+
+
+# --------------------------------------------------------- full-size properties --
+def test_cfg3_genome_scale_properties(O):
+    """BASELINE configs[2]: two hg19-sized (3.1 Gbp, 24 chromosomes) bitsets, iand + count_range.
+    chr21 and chrY are checked bit-for-bit against the oracle, every chromosome through identities."""
+    from bxmi.bitset import DeviceBitSet
+
+    ra = synth.genome_ranges(1_500_000, 301)
+    rb = synth.genome_ranges(1_500_000, 302)
+    tot_a = tot_b = tot_and = tot_or = 0
+    for chrom, size in synth.HG19_SIZES.items():
+        a, b, a2 = DeviceBitSet(size), DeviceBitSet(size), DeviceBitSet(size)
+        a.set_ranges(*ra[chrom]), b.set_ranges(*rb[chrom]), a2.set_ranges(*ra[chrom])
+        ca, cb = a.count_range(0, size), b.count_range(0, size)
+        a2.ior(b)
+        c_or = a2.count_range(0, size)
+        c_and = a.and_count(b)  # fused iand + popcount
+        assert c_and == a.count_range(0, size)
+        assert c_and + c_or == ca + cb  # inclusion-exclusion
+        rs, re = a.runs()
+        assert int((re - rs).sum()) == c_and and (rs[1:] > re[:-1]).all()
+        # per-range counts against the full count: consecutive windows tile the chromosome
+        edges = np.linspace(0, size, 2001).astype(np.int64)
+        win = a.count_ranges(edges[:-1], np.diff(edges))
+        assert int(win.sum()) == c_and
+        a.invert()
+        assert a.count_range(0, size) <= size - c_and  # ALL_ONE first-bin arithmetic can only subtract
+        a.invert()
+        assert a.count_range(0, size) == c_and
+        if chrom in ("chr21", "chrY"):
+            oa, ob = O.OracleBinnedBitSet(size), O.OracleBinnedBitSet(size)
+            oa.set_ranges(*ra[chrom]), ob.set_ranges(*rb[chrom])
+            assert (ca, cb) == (oa.count_range(0, size), ob.count_range(0, size))
+            oa.iand(ob)
+            assert c_and == oa.count_range(0, size)
+            ors, ore = oa.runs()
+            assert np.array_equal(rs, ors) and np.array_equal(re, ore)
+        tot_a, tot_b, tot_and, tot_or = tot_a + ca, tot_b + cb, tot_and + c_and, tot_or + c_or
+        for d in (a, b, a2):
+            d.close()
+    assert tot_and + tot_or == tot_a + tot_b
+    assert 0.30 < tot_a / 3_095_677_412 < 0.45  # ~38 % coverage per set

@@ -1,0 +1,292 @@
+"""
+GPU parity tests of the interval path (run on the MI355X box with -m gpu).
+
+Everything goes through the C ABI (libbxmi.so via bxmi._ffi); the checker is
+the CPU oracle (oracle/ivtree.c) and the committed reference-generated vectors.
+Bit-exact: counts, CSR offsets, hit order.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from bxmi import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def IntervalIndex():
+    from bxmi.intervals import IntervalIndex
+
+    return IntervalIndex
+
+
+def set_opt(key, value):
+    from bxmi import _ffi
+
+    _ffi.call("bxmi_set_option", key.encode(), int(value))
+
+
+def make_index(IntervalIndex, starts, ends):
+    ix = IntervalIndex()
+    ix.append(starts, ends)
+    ix.seal()
+    return ix
+
+
+# ------------------------------------------------------------------ golden --
+def test_order_matches_reference_traverse(golden_trees, IntervalIndex):
+    for case in golden_trees:
+        ix = make_index(IntervalIndex, case["starts"], case["ends"])
+        assert ix.order().tolist() == case["order"], (case["mode"], case["n"])
+
+
+@pytest.mark.parametrize("group_sum", [0, 1])
+def test_count_and_find_match_reference_vectors(golden_trees, IntervalIndex, group_sum):
+    set_opt("ivl.group_sum", group_sum)
+    try:
+        for case in golden_trees:
+            ix = make_index(IntervalIndex, case["starts"], case["ends"])
+            q = np.array(case["queries"], dtype=np.int32)
+            counts, total = ix.count(q[:, 0], q[:, 1])
+            want = [len(h) for h in case["hits"]]
+            assert counts.tolist() == want, (case["mode"], case["n"])
+            assert total == sum(want)
+            offs, hits = ix.find(q[:, 0], q[:, 1])
+            assert offs.tolist() == np.concatenate([[0], np.cumsum(want)]).tolist()
+            assert hits.tolist() == [x for h in case["hits"] for x in h], (case["mode"], case["n"])
+    finally:
+        set_opt("ivl.group_sum", 0)
+
+
+def test_neighbours_match_reference_vectors(golden_trees, IntervalIndex):
+    import operator
+
+    n = 0
+    for case in golden_trees:
+        if not case["neighbours"]:
+            continue
+        ix = make_index(IntervalIndex, case["starts"], case["ends"])
+        s, e = case["starts"], case["ends"]
+        for kind, pos, k, md, want in case["neighbours"]:
+            cand = ix.neighbors(pos, md, -1 if kind == "before" else +1).tolist()
+            if len(cand) != k:  # intersection.pyx:242-245 / :257-260
+                cand = sorted(cand, key=(lambda i: e[i]) if kind == "before" else (lambda i: s[i]), reverse=kind == "before")[:k]
+            assert cand == want, (kind, pos, k, md)
+            n += 1
+    assert n > 300
+
+
+def test_empty_index(IntervalIndex):
+    ix = IntervalIndex()
+    ix.seal()
+    c, t = ix.count([1, 5], [10, 5])
+    assert c.tolist() == [0, 0] and t == 0
+    offs, hits = ix.find([1], [10])
+    assert offs.tolist() == [0, 0] and len(hits) == 0
+    assert ix.order().tolist() == []
+
+
+# ------------------------------------------------------- oracle differential --
+def _random_case(rng, n, span, zero_frac=0.0, rev_frac=0.0, lmax=50):
+    s = rng.integers(-span, span, size=n)
+    ln = rng.integers(1, lmax + 1, size=n)
+    ln[rng.random(n) < zero_frac] = 0
+    e = s + ln
+    flip = rng.random(n) < rev_frac
+    s, e = np.where(flip, e, s), np.where(flip, s, e)
+    return s.astype(np.int32), e.astype(np.int32)
+
+
+@pytest.mark.parametrize(
+    "n,span,zero,rev,lmax",
+    [(1, 10, 0, 0, 5), (31, 40, 0.2, 0, 8), (32, 40, 0, 0, 8), (33, 40, 0, 0.2, 8), (1023, 500, 0.1, 0, 30),
+     (1025, 100, 0.3, 0.1, 10), (40000, 100000, 0.05, 0, 200), (200000, 3000, 0.1, 0, 20), (70000, 10**9, 0, 0, 10**6)],
+)
+def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
+    rng = np.random.default_rng(n * 7 + span)
+    s, e = _random_case(rng, n, span, zero, rev, lmax)
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    ix = make_index(IntervalIndex, s, e)
+    assert ix.has_reversed == bool((e < s).any())
+    assert ix.order().tolist() == t.traverse().tolist()
+    nq = 3000
+    qs, qe = _random_case(rng, nq, span, 0.1, 0.1, lmax * 2)
+    qs[:5] = [-(2**31), 2**31 - 1, -(2**31), 2**31 - 1, 0]  # extreme coordinates
+    qe[:5] = [2**31 - 1, 2**31 - 1, -(2**31), -(2**31), 0]
+    want_c, want_t = t.count_batch(qs, qe)
+    got_c, got_t = ix.count(qs, qe)
+    bad = np.nonzero(got_c != want_c)[0]
+    assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got_c[bad[:5]], want_c[bad[:5]])
+    assert got_t == want_t
+    want_off, want_hits = t.find_batch(qs, qe)
+    got_off, got_hits = ix.find(qs, qe)
+    assert np.array_equal(got_off, want_off)
+    assert np.array_equal(got_hits, want_hits)
+
+
+def test_long_target_spanning_everything(O, IntervalIndex):
+    """One chromosome-long interval inserted first: every later window starts at it."""
+    rng = np.random.default_rng(5)
+    s, e = _random_case(rng, 20000, 10**6, 0, 0, 100)
+    s = np.concatenate([[-(10**6) - 5], s]).astype(np.int32)
+    e = np.concatenate([[10**6 + 500], e]).astype(np.int32)
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    ix = make_index(IntervalIndex, s, e)
+    qs, qe = _random_case(rng, 500, 10**6, 0.1, 0, 300)
+    want_off, want_hits = t.find_batch(qs, qe)
+    got_off, got_hits = ix.find(qs, qe)
+    assert np.array_equal(got_off, want_off) and np.array_equal(got_hits, want_hits)
+    assert ix.count(qs, qe)[0].tolist() == np.diff(want_off).tolist()
+
+
+def test_incremental_append_reseals(O, IntervalIndex):
+    rng = np.random.default_rng(9)
+    s, e = _random_case(rng, 5000, 20000, 0.1, 0, 60)
+    ix = IntervalIndex()
+    t = O.OracleIntervalTree()
+    for lo in range(0, 5000, 1250):
+        ix.append(s[lo:lo + 1250], e[lo:lo + 1250])
+        t.insert_many_arrays(s[lo:lo + 1250], e[lo:lo + 1250])
+        qs, qe = _random_case(rng, 400, 20000, 0, 0, 100)
+        assert ix.count(qs, qe)[0].tolist() == t.count_batch(qs, qe)[0].tolist()
+        assert np.array_equal(ix.find(qs, qe)[1], t.find_batch(qs, qe)[1])
+
+
+# --------------------------------------------------------- scale / golden hash --
+def test_scale_1M_hash(golden_scale, IntervalIndex):
+    pt = golden_scale["1M x 200k"]
+    (ts, te), _ = synth.cfg2(pt["n_targets"], 1)
+    qs, qe = synth.uniform_intervals(pt["n_queries_total"], 202)
+    qs, qe = qs[:: pt["stride"]].copy(), qe[:: pt["stride"]].copy()
+    ix = make_index(IntervalIndex, ts, te)
+    for lds_ints in (18688, 1024, 0):  # 3 / 2 / 0 LDS-resident levels must agree
+        set_opt("ivl.lds_ints", lds_ints)
+        counts, total = ix.count(qs, qe)
+        assert total == pt["total"]
+        assert hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], lds_ints
+    set_opt("ivl.lds_ints", 18688)
+    offs, hits = ix.find(qs, qe)
+    assert offs[-1] == pt["total"] and np.array_equal(np.diff(offs), counts)
+    # every reported hit really overlaps, and hits of one query come in tree order
+    rep = np.repeat(np.arange(len(qs)), counts)
+    assert (te[hits] > qs[rep]).all() and (ts[hits] < qe[rep]).all()
+
+
+def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
+    """BASELINE configs[1]: 100M queries x 10M targets, count-only.  The reference hash pins the
+    1M-query subsample; the rest is checked through size-independent identities."""
+    key = "10M x 1M (cfg2 subsample)"
+    (ts, te), (qs, qe) = synth.cfg2()
+    ix = make_index(IntervalIndex, ts, te)
+    counts, total = ix.count(qs, qe)
+    assert total == int(counts.sum(dtype=np.int64))
+    if key in golden_scale:
+        pt = golden_scale[key]
+        sub = counts[:: pt["stride"]]
+        assert int(sub.sum(dtype=np.int64)) == pt["total"]
+        assert hashlib.sha256(np.ascontiguousarray(sub).tobytes()).hexdigest() == pt["counts_sha256"]
+    # additivity: counting two halves separately gives the same per-query numbers
+    h = len(qs) // 2
+    c2, t2 = ix.count(qs[h:], qe[h:])
+    assert np.array_equal(c2, counts[h:])
+    # a query covering the whole genome sees every target; an empty one sees none
+    c3, _ = ix.count(np.array([-5, 7], np.int32), np.array([2**31 - 1, 7], np.int32))
+    assert c3[0] == len(ts)
+    # monotonicity: widening a query never loses hits
+    wide, _ = ix.count(qs[:1_000_000] - 100, qe[:1_000_000] + 100)
+    assert (wide >= counts[:1_000_000]).all()
+
+
+# -------------------------------------------------------------- compat API --
+def test_compat_intervaltree_known_answers():
+    """lib/bx/intervals/intersection_tests.py:158-201 and the doctests intersection.pyx:335-376."""
+    from bx.intervals.intersection import Intersecter, Interval, IntervalTree
+
+    assert Intersecter is IntervalTree
+    iv = IntervalTree()
+    n = 0
+    for i in range(1, 1000, 80):
+        iv.insert(i, i + 10, {"value": i * i})
+        iv.add(i + 20, i + 30, {"astr": str(i * i)})
+        iv.insert_interval(Interval(i + 40, i + 50, value={"astr": str(i * i)}))
+        iv.add_interval(Interval(i + 60, i + 70, value={"astr": str(i * i)}))
+        n += 4
+    assert len(iv.find(100, 200)) == 5
+    a = []
+    iv.traverse(a.append)
+    assert len(a) == n
+    iv.traverse(lambda node: node.interval)
+    e = IntervalTree()
+    assert e.find(100, 300) == [] and e.after(100) == [] and e.before(100) == []
+    assert e.after_interval(100) == [] and e.before_interval(100) == []
+    assert e.upstream_of_interval(100) == [] and e.downstream_of_interval(100) == []
+    assert e.traverse(lambda x: x.append(1)) is None
+
+    t = IntervalTree()
+    t.insert(0, 10, "food")
+    t.insert(3, 7, dict(foo="bar"))
+    assert t.find(2, 5) == ["food", {"foo": "bar"}]
+    t = IntervalTree()
+    for a_, b_ in ((0, 10), (3, 7), (3, 40), (13, 50)):
+        t.insert_interval(Interval(a_, b_))
+    assert repr(t.find(30, 50)) == "[Interval(3, 40), Interval(13, 50)]"
+    assert t.find(100, 200) == []
+    assert repr(t.before_interval(Interval(10, 20))) == "[Interval(3, 7)]"
+    assert t.before_interval(Interval(5, 20)) == []
+    assert repr(t.upstream_of_interval(Interval(11, 12))) == "[Interval(0, 10)]"
+    assert repr(t.upstream_of_interval(Interval(11, 12, strand="-"))) == "[Interval(13, 50)]"
+    assert repr(t.upstream_of_interval(Interval(1, 2, strand="-"), num_intervals=3)) == "[Interval(3, 7), Interval(3, 40), Interval(13, 50)]"
+    with pytest.raises(OverflowError):
+        t.find(2**31, 2**31 + 5)
+    with pytest.raises(TypeError):
+        t.find("a", 5)
+    assert repr(t.find(2.5, 3.5)) == "[Interval(0, 10), Interval(3, 7), Interval(3, 40)]"
+
+
+def test_compat_intervalnode_neighbours():
+    """intersection_tests.py:17-54 (NeighborTestCase) and :104-141 (LotsaTestCase, reduced to what stays fast)."""
+    from bx.intervals.intersection import Interval, IntervalNode
+
+    iv = IntervalNode(50, 59, Interval(50, 59))
+    for i in range(0, 110, 10):
+        if i == 50:
+            continue
+        f = Interval(i, i + 9)
+        iv = iv.insert(f.start, f.end, f)
+    assert str(iv.left(60, n=2)) == str([Interval(50, 59), Interval(40, 49)])
+    for i in range(10, 100, 10):
+        assert iv.left(i, max_dist=10, n=1)[0].end == i - 1
+    assert len(iv.left(60, n=200)) == 6
+    for i in range(10, 100, 10):
+        r = iv.right(i + 1, n=1)
+        assert len(r) == 1 and r[0].start == i + 10
+    for i in range(0, 100, 10):
+        assert iv.right(i - 1, max_dist=10, n=1)[0].start == i
+
+    big = IntervalNode(1, 2, Interval(1, 2))
+    for i in range(0, 1000000, 10):
+        big = big.insert(i, i, Interval(i, i))
+    for i in range(600):
+        big = big.insert(0, 1, Interval(0, 1))
+    assert len(big.right(1, n=33)) == 33
+    assert len(big.left(1, n=33)) == 1
+    assert len(big.right(1, n=9999)) == 250
+    assert len(big.right(1, n=9999, max_dist=99999)) == 9999
+    assert len(big.right(1, max_dist=0, n=10)) == 0
+    for n, d in enumerate(range(10, 1000, 100)):
+        assert len(big.right(1, max_dist=d, n=10000)) == 10 * n + 1
+    for (qs, qe) in ((1000, 5000), (123456, 130000)):
+        for feat in big.find(qs, qe):
+            assert (qs <= feat.end <= qe) or (qs <= feat.start <= qe)
+    assert repr(big) .startswith("IntervalNode(")
