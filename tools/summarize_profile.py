@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (kernel stats + FETCH_SIZE / WRITE_SIZE passes) into small files:
+   <dir>/summary_kernel_stats.csv, <dir>/summary_pmc.json.   usage: summarize_profile.py gpurun_out"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+
+
+def find(sub, pat):
+    hits = glob.glob(os.path.join(d, sub, "**", pat), recursive=True)
+    return hits[0] if hits else None
+
+
+def short(name):
+    n = name.split("(")[0]
+    for pre in ("void ", "bxmi::"):
+        n = n.replace(pre, "")
+    return n[:90]
+
+
+out = {}
+stats = find("prof_stats", "*kernel_stats.csv")
+if stats:
+    rows = list(csv.DictReader(open(stats)))
+    with open(os.path.join(d, "summary_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct"])
+        for r in rows[:40]:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
+            print("%-70s calls=%-6s avg=%10.1f us  %5s%%" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+trace = find("prof_stats", "*kernel_trace.csv")
+dur = defaultdict(list)
+if trace:
+    for r in csv.DictReader(open(trace)):
+        dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+for tag, counter in (("prof_fetch", "FETCH_SIZE"), ("prof_write", "WRITE_SIZE")):
+    cc = find(tag, "*counter_collection.csv")
+    if not cc:
+        continue
+    acc = defaultdict(list)
+    for r in csv.DictReader(open(cc)):
+        if r.get("Counter_Name") == counter:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        out.setdefault(k, {})[counter] = dict(dispatches=len(v), mean=sum(v) / len(v), min=min(v), max=max(v))
+for k, v in dur.items():
+    if k in out:
+        out[k]["avg_duration_us"] = sum(v) / len(v) / 1e3
+        out[k]["dispatches_traced"] = len(v)
+json.dump(out, open(os.path.join(d, "summary_pmc.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if "ivl_" in k or "bits_" in k}, indent=1))
