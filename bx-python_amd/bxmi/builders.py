@@ -1,0 +1,88 @@
+"""
+BED text -> {chrom: BinnedBitSet}, the batch counterpart of the reference's
+lib/bx/bitset_builders.py:17-54 (``binned_bitsets_from_file``).
+
+Same observable behaviour -- skip rules, first-appearance chromosome order,
+``lens`` lookup, padding arithmetic, the start>end warning, and the exception a
+bad line raises -- but the per-line ``set_range`` calls are collected per
+chromosome and issued as ONE ``set_ranges`` kernel launch each.
+"""
+from warnings import warn
+
+import numpy as np
+
+from bx.bitset import MAX, BinnedBitSet
+
+
+def _check_range(size, start, count):
+    """bitset.pyx:184-189 (bb_check_range_count), evaluated at parse time so errors keep file order."""
+    if start < 0:
+        return IndexError("BitSet index (%d) must be non-negative." % start)
+    if start >= size:
+        return IndexError("%d is larger than the size of this BitSet (%d)." % (start, size))
+    if count < 0:
+        return IndexError("Count (%d) must be non-negative." % count)
+    if start + count > size:
+        return IndexError("End (%d) is larger than the size of this BinnedBitSet (%d)." % (start + count, size))
+    return None
+
+
+def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=5, upstream_pad=0, downstream_pad=0, lens={}):
+    """
+    Read a file into a dictionary of bitsets (same arguments as the reference):
+    - 'f' should be a file like object (or any iterable containing strings)
+    - 'chrom_col', 'start_col', and 'end_col' must exist in each line.
+    - if 'lens' is provided bitset sizes will be looked up from it, otherwise
+      chromosomes will be assumed to be the maximum size
+    """
+    sizes = {}  # chrom -> size, in first-appearance order (drives dict order of the result)
+    starts, counts = {}, {}
+    error = None
+    size = None
+    last_chrom = None
+    for line in f:
+        if line.startswith("#") or line.isspace():  # bitset_builders.py:33-34
+            continue
+        try:
+            fields = line.split()
+            chrom = fields[chrom_col]
+            if chrom != last_chrom:
+                if chrom not in sizes:
+                    size = lens[chrom] if chrom in lens else MAX
+                    if size > 2147483647:
+                        raise ValueError("%d is larger than the maximum BinnedBitSet size of %d." % (size, 2147483647))
+                    sizes[chrom] = size
+                    starts[chrom], counts[chrom] = [], []
+                last_chrom = chrom
+            start, end = int(fields[start_col]), int(fields[end_col])
+            if upstream_pad:
+                start = max(0, start - upstream_pad)
+            if downstream_pad:
+                end = min(size, end + downstream_pad)  # `size` of the most recently created bitset, as in :48-49
+            if start > end:
+                warn("Interval start after end!")
+            if not -2147483648 <= start <= 2147483647:
+                raise OverflowError("value too large to convert to int")
+            error = _check_range(sizes[chrom], start, end - start)
+            if error is not None:
+                break
+            if end > start:
+                starts[chrom].append(start)
+                counts[chrom].append(end - start)
+        except (ValueError, IndexError, OverflowError) as ex:
+            error = ex
+            break
+    bitsets = {}
+    for chrom, sz in sizes.items():
+        b = BinnedBitSet(sz)
+        if starts[chrom]:
+            b.set_ranges(np.array(starts[chrom], dtype=np.int32), np.array(counts[chrom], dtype=np.int32))
+        bitsets[chrom] = b
+    if error is not None:
+        raise error
+    return bitsets
+
+
+def binned_bitsets_from_list(rows):
+    """bitset_builders.py:142-156: rows of (chrom, start, end)."""
+    return binned_bitsets_from_file(("%s\t%s\t%s\n" % (r[0], int(r[1]), int(r[2])) for r in rows))

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""
+Print number of bases covered by all intervals in a bed file (bases covered by
+more than one interval are counted only once). Multiple bed files can be
+provided on the command line or to stdin.
+
+usage: %prog bed files ...
+"""
+# Counterpart of the reference's scripts/bed_coverage.py:19-31: one set_ranges launch and one
+# grid-wide popcount per chromosome.
+import fileinput
+import sys
+
+from bxmi.builders import binned_bitsets_from_file
+
+
+def main(argv=None, out=None, stdin=None):
+    out = out or sys.stdout
+    bed_filenames = sys.argv[1:] if argv is None else argv
+    if bed_filenames:
+        inp = fileinput.input(bed_filenames)
+    else:
+        inp = stdin or sys.stdin
+    bitsets = binned_bitsets_from_file(inp)
+    total = 0
+    for chrom in bitsets:
+        total += bitsets[chrom].count_range(0, bitsets[chrom].size)
+    out.write("%d\n" % total)
+    out.flush()
+
+
+if __name__ == "__main__":
+    main()

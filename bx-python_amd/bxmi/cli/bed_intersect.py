@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""
+Find regions of first bed file that overlap regions in a second bed file. The
+output preserves all fields from the input.
+
+NOTE: -u and -d options are currently not functional!
+
+usage: %prog bed_file_1 bed_file_2
+    -m, --mincols=N: Require this much overlap (default 1bp)
+    -u, --upstream_pad=N: upstream interval padding (default 0bp)
+    -d, --downstream_pad=N: downstream interval padding (default 0bp)
+    -v, --reverse: Print regions that DO NOT overlap
+    -b, --booleans: Just print '1' if interval overlaps or '0' otherwise
+"""
+# Counterpart of the reference's scripts/bed_intersect.py:26-68 -- same flags, same stdout
+# (including the "line\n" + " " quirk of print(line, end=" ")), but every query line of a
+# chromosome is answered by one batched count_ranges launch instead of one call per line.
+import optparse
+import sys
+from warnings import warn
+
+import numpy as np
+
+from bxmi.builders import _check_range, binned_bitsets_from_file
+
+
+def parse_args(argv):
+    p = optparse.OptionParser("%prog bed_file_1 bed_file_2", conflict_handler="resolve")
+    p.add_option("-m", "--mincols", action="store", help="Require this much overlap (default 1bp)")
+    p.add_option("-u", "--upstream_pad", action="store", help="upstream interval padding (default 0bp)")
+    p.add_option("-d", "--downstream_pad", action="store", help="downstream interval padding (default 0bp)")
+    p.add_option("-v", "--reverse", action="store_true", help="Print regions that DO NOT overlap")
+    p.add_option("-b", "--booleans", action="store_true", help="Just print '1' if interval overlaps or '0' otherwise")
+    return p.parse_args(argv)
+
+
+def main(argv=None, out=None):
+    out = out or sys.stdout
+    options, args = parse_args(sys.argv[1:] if argv is None else argv)
+    mincols = 1
+    try:
+        if options.mincols:
+            mincols = int(options.mincols)
+        if options.upstream_pad:
+            int(options.upstream_pad)  # parsed, unused: "not functional" in the reference too
+        if options.downstream_pad:
+            int(options.downstream_pad)
+        reverse = bool(options.reverse)
+        booleans = bool(options.booleans)
+        in_fname, in2_fname = args
+    except Exception:
+        raise SystemExit(__doc__.replace("%prog", sys.argv[0]))
+
+    bitsets = binned_bitsets_from_file(open(in2_fname))
+
+    # Pass 1 (host): parse the query file in order; stop at the first line the reference would die on.
+    lines, per_chrom = [], {}
+    error = None
+    for line in open(in_fname):
+        if line.startswith("#") or line.isspace():
+            continue
+        try:
+            fields = line.split()
+            start, end = int(fields[1]), int(fields[2])
+            if start > end:
+                warn("Bed interval start after end!")
+            chrom = fields[0]
+            if chrom in bitsets:
+                error = _check_range(bitsets[chrom].size, start, end - start)
+                if error is not None:
+                    break
+                s, c, idx = per_chrom.setdefault(chrom, ([], [], []))
+                s.append(start)
+                c.append(end - start)
+                idx.append(len(lines))
+            lines.append(line)
+        except (ValueError, IndexError) as ex:
+            error = ex
+            break
+    # Pass 2 (device): one count_ranges launch per chromosome.
+    hit = np.zeros(len(lines), dtype=bool)
+    for chrom, (s, c, idx) in per_chrom.items():
+        counts = bitsets[chrom].count_ranges(np.array(s, dtype=np.int32), np.array(c, dtype=np.int32))
+        hit[np.array(idx, dtype=np.int64)] = counts >= mincols
+    # Pass 3 (host): emit in file order, exactly as the reference prints.
+    w = out.write
+    for line, h in zip(lines, hit.tolist()):
+        if booleans:
+            w("1\n" if h != reverse else "0\n")
+        elif h != reverse:
+            w(line)
+            w(" ")
+    out.flush()
+    if error is not None:
+        raise error
+
+
+if __name__ == "__main__":
+    main()

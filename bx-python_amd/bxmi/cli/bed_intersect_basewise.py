@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""
+Find regions of first bed file that overlap regions in a second bed file. This
+program performs a base-by-base intersection, so only runs of bases that are
+covered in both of the inputs will be output.
+
+usage: %prog bed_file_1 bed_file_2
+"""
+# Counterpart of the reference's scripts/bed_intersect_basewise.py:14-38: the
+# next_set/next_clear walk becomes one run-extraction pass on the device per chromosome.
+import sys
+
+from bxmi.builders import binned_bitsets_from_file
+
+
+def main(argv=None, out=None):
+    out = out or sys.stdout
+    args = sys.argv[1:] if argv is None else argv
+    try:
+        in_fname, in2_fname = args
+    except ValueError:
+        raise SystemExit(__doc__.replace("%prog", sys.argv[0]))
+    bits1 = binned_bitsets_from_file(open(in_fname))
+    bits2 = binned_bitsets_from_file(open(in2_fname))
+    bitsets = {}
+    for key in bits1:  # first-appearance order of file 1
+        if key in bits2:
+            bits1[key].iand(bits2[key])
+            bitsets[key] = bits1[key]
+    w = out.write
+    for chrom, bits in bitsets.items():
+        starts, ends = bits.runs()
+        for s, e in zip(starts.tolist(), ends.tolist()):
+            w("%s\t%d\t%d\n" % (chrom, s, e))
+        if len(ends) and ends[-1] == bits.size:
+            # the reference's loop would now call next_set(size) and die (bitset.pyx:180-181)
+            out.flush()
+            raise IndexError("%d is larger than the size of this BitSet (%d)." % (bits.size, bits.size))
+    out.flush()
+
+
+if __name__ == "__main__":
+    main()

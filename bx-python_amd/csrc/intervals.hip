@@ -136,23 +136,29 @@ __device__ __forceinline__ void stage_tree(const TreeDev &t, int32_t *lds)
 }
 
 // rank_lt for NQ independent keys at once (ILP): returns #{a[i] < key}.
+// Two separate loops so the staged levels compile to ds_read_b128 and the lower
+// ones to global_load_dwordx4 (one merged loop makes hipcc fall back to flat_load
+// with a full vmcnt+lgkmcnt drain per level).
 template <bool DPP, int NQ>
 __device__ __forceinline__ void tree_rank_lt(const TreeDev &t, const int32_t *lds, const int (&key)[NQ], int (&rank)[NQ],
                                              int sub)
 {
 #pragma unroll
     for (int j = 0; j < NQ; j++) rank[j] = 0;
-    for (int l = t.nlev - 1; l >= 0; --l) {
+    int l = t.nlev - 1;
+    for (; l >= t.lds_from; --l) {
+        const int4 *b = reinterpret_cast<const int4 *>(lds + t.lds_off[l]) + sub;
         int4 v[NQ];
-        if (l >= t.lds_from) {
-            const int32_t *b = lds + t.lds_off[l] + sub * 4;
 #pragma unroll
-            for (int j = 0; j < NQ; j++) v[j] = *reinterpret_cast<const int4 *>(b + rank[j] * FAN);
-        } else {
-            const int32_t *b = t.lev[l] + sub * 4;
+        for (int j = 0; j < NQ; j++) v[j] = b[rank[j] * (FAN / 4)];
 #pragma unroll
-            for (int j = 0; j < NQ; j++) v[j] = *reinterpret_cast<const int4 *>(b + (int64_t)rank[j] * FAN);
-        }
+        for (int j = 0; j < NQ; j++) rank[j] = rank[j] * FAN + node_count_lt<DPP>(v[j], key[j]);
+    }
+    for (; l >= 0; --l) {
+        const int4 *b = reinterpret_cast<const int4 *>(t.lev[l]) + sub;
+        int4 v[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; j++) v[j] = b[(int64_t)rank[j] * (FAN / 4)];
 #pragma unroll
         for (int j = 0; j < NQ; j++) rank[j] = rank[j] * FAN + node_count_lt<DPP>(v[j], key[j]);
     }

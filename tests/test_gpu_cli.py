@@ -1,0 +1,166 @@
+"""
+GPU tests of the CLI counterparts (bxmi.cli.*) against stdout captured from the
+reference's own scripts (tests/golden/cli/expected.json, made by oracle/gen_golden.py),
+plus the per-call drop-in API driven in the call pattern those scripts use.
+Byte-identical stdout, same exit status, same final exception line.
+"""
+import hashlib
+import io
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from bxmi import synth
+from conftest import GOLDEN, PKG, ROOT
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(GOLDEN, "cli")
+
+
+def run_cli(module, args, stdin=None):
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT, PYTHONWARNINGS="ignore")
+    p = subprocess.run([sys.executable, "-m", "bxmi.cli." + module] + args, input=stdin, capture_output=True, text=True, env=env)
+    tail = p.stderr.strip().splitlines()[-1:] if p.returncode else []
+    return dict(stdout=p.stdout, returncode=p.returncode, stderr_tail=tail)
+
+
+def files(tag):
+    return os.path.join(CLI, tag + "_a.bed"), os.path.join(CLI, tag + "_b.bed")
+
+
+def check(got, want, key):
+    assert got["returncode"] == want["returncode"], (key, got)
+    assert got["stdout"] == want["stdout"], key
+    assert got["stderr_tail"] == want["stderr_tail"], key
+
+
+@pytest.mark.parametrize("tag", ["small", "med"])
+def test_bed_intersect_flags(golden_cli, tag):
+    fa, fb = files(tag)
+    for flags in ([], ["-b"], ["-v"], ["-b", "-v"], ["-m", "5"], ["--mincols=50"], ["-m", "5", "-v"]):
+        key = "bed_intersect %s %s" % (tag, " ".join(flags))
+        check(run_cli("bed_intersect", flags + [fa, fb]), golden_cli["cases"][key], key)
+
+
+@pytest.mark.parametrize("tag", ["small", "med"])
+def test_basewise_and_coverage(golden_cli, tag):
+    fa, fb = files(tag)
+    check(run_cli("bed_intersect_basewise", [fa, fb]), golden_cli["cases"]["bed_intersect_basewise %s" % tag], tag)
+    check(run_cli("bed_coverage", [fa]), golden_cli["cases"]["bed_coverage %s a" % tag], tag)
+    check(run_cli("bed_coverage", [fa, fb]), golden_cli["cases"]["bed_coverage %s ab" % tag], tag)
+
+
+def test_coverage_stdin_and_errors(golden_cli):
+    stdin = open(os.path.join(CLI, "small_b.bed")).read()
+    check(run_cli("bed_coverage", [], stdin=stdin), golden_cli["cases"]["bed_coverage small stdin"], "stdin")
+    for name, key in (("bad_reversed", "bed_coverage bad_reversed"), ("bad_toolarge", "bed_coverage bad_toolarge")):
+        check(run_cli("bed_coverage", [os.path.join(CLI, name + ".bed")]), golden_cli["cases"][key], key)
+    key = "bed_intersect bad_toolarge_query"
+    check(run_cli("bed_intersect", [os.path.join(CLI, "bad_toolarge.bed"), os.path.join(CLI, "small_b.bed")]), golden_cli["cases"][key], key)
+
+
+def test_interval_join(golden_cli):
+    check(run_cli("interval_join", [os.path.join(CLI, "join_a.bed"), os.path.join(CLI, "join_b.bed")]),
+          golden_cli["cases"]["interval_join small"], "small")
+    fa, fb = files("med")
+    check(run_cli("interval_join", [fa, fb]), golden_cli["cases"]["interval_join med"], "med")
+
+
+def test_cfg1_10k_x_10k(golden_cli, tmp_path):
+    """BASELINE configs[0]: chr1 10k x 10k synthetic BED, every script, output hashes from the reference run."""
+    (ts, te), (qs, qe) = synth.cfg1()
+    fa, fb = str(tmp_path / "q.bed"), str(tmp_path / "t.bed")
+    open(fa, "w").writelines(synth.bed_lines("chr1", qs, qe, "q"))
+    open(fb, "w").writelines(synth.bed_lines("chr1", ts, te, "t"))
+    runs = {
+        "bed_intersect": ("bed_intersect", [fa, fb]), "bed_intersect -b": ("bed_intersect", ["-b", fa, fb]),
+        "bed_intersect -m 500": ("bed_intersect", ["-m", "500", fa, fb]), "bed_intersect_basewise": ("bed_intersect_basewise", [fa, fb]),
+        "bed_coverage": ("bed_coverage", [fb]), "interval_join": ("interval_join", [fa, fb]),
+    }
+    for key, (mod, args) in runs.items():
+        want = golden_cli["cfg1"][key]
+        got = run_cli(mod, args)
+        assert got["returncode"] == want["returncode"] == 0, key
+        assert len(got["stdout"]) == want["nbytes"] and got["stdout"][:200] == want["head"], key
+        assert hashlib.sha256(got["stdout"].encode()).hexdigest() == want["sha256"], key
+
+
+# ---- the per-call drop-in API, used the way the unmodified scripts use it -----------------
+def per_line_bitsets(path):
+    """One BinnedBitSet per chromosome, one set_range call per BED line (file order)."""
+    import bx.bitset
+
+    sets = {}
+    for line in open(path):
+        if line.startswith("#") or line.isspace():
+            continue
+        f = line.split()
+        if f[0] not in sets:
+            sets[f[0]] = bx.bitset.BinnedBitSet(bx.bitset.MAX)
+        sets[f[0]].set_range(int(f[1]), int(f[2]) - int(f[1]))
+    return sets
+
+
+@pytest.mark.parametrize("tag", ["small", "med"])
+def test_dropin_classes_per_call_pattern(golden_cli, tag):
+    fa, fb = files(tag)
+    # count_range per query line, echoing hits with the trailing-space print quirk
+    sets = per_line_bitsets(fb)
+    out = io.StringIO()
+    for line in open(fa):
+        if line.startswith("#") or line.isspace():
+            continue
+        f = line.split()
+        s, e = int(f[1]), int(f[2])
+        if f[0] in sets and sets[f[0]].count_range(s, e - s) >= 1:
+            print(line, end=" ", file=out)
+    assert out.getvalue() == golden_cli["cases"]["bed_intersect %s " % tag]["stdout"]
+    # iand + the next_set / next_clear walk
+    a, b = per_line_bitsets(fa), per_line_bitsets(fb)
+    out = io.StringIO()
+    for chrom in a:
+        if chrom not in b:
+            continue
+        a[chrom].iand(b[chrom])
+        bits, end = a[chrom], 0
+        while True:
+            start = bits.next_set(end)
+            if start == bits.size:
+                break
+            end = bits.next_clear(start)
+            print("%s\t%d\t%d" % (chrom, start, end), file=out)
+    assert out.getvalue() == golden_cli["cases"]["bed_intersect_basewise %s" % tag]["stdout"]
+    # coverage
+    total = sum(s.count_range(0, s.size) for s in per_line_bitsets(fa).values())
+    assert "%d\n" % total == golden_cli["cases"]["bed_coverage %s a" % tag]["stdout"]
+
+
+def test_dropin_intersecter_join_pattern(golden_cli):
+    """Per-chromosome Intersecter, add_interval per row, find per row -- interval_join's call pattern."""
+    import bx.intervals
+
+    class Row:
+        def __init__(self, line):
+            self.fields = line.rstrip("\r\n").split("\t")
+            self.chrom, self.start, self.end = self.fields[0], int(self.fields[1]), int(self.fields[2])
+
+        def __str__(self):
+            return "\t".join(self.fields)
+
+    fa, fb = files("med")
+    trees = {}
+    for line in open(fb):
+        r = Row(line)
+        if r.chrom not in trees:
+            trees[r.chrom] = bx.intervals.Intersecter()
+        trees[r.chrom].add_interval(r)
+    out = io.StringIO()
+    for line in open(fa):
+        r = Row(line)
+        if r.chrom in trees:
+            for other in trees[r.chrom].find(r.start, r.end):
+                print("\t".join([str(r), str(other)]), file=out)
+    assert out.getvalue() == golden_cli["cases"]["interval_join med"]["stdout"]
