@@ -267,6 +267,425 @@ __global__ __launch_bounds__(CNT_THREADS) void ivl_count_kernel(TreeDev S, TreeD
     if (total) block_accumulate_i64(acc, red, total);
 }
 
+
+// ---------------------------------------------------------------------------
+// partitioned count path (large batches)
+// ---------------------------------------------------------------------------
+// The direct kernel above is instruction-issue bound (rocprof: ~27 wave
+// instructions per query, SIMDs 100 % busy) and pulls ~350 B/query through the
+// fabric because random queries touch random leaves.  For big batches we make
+// the accesses local instead:
+//   1. bucket the queries by coordinate (2048 buckets over the targets' span):
+//      histogram -> scan -> scatter (LDS atomics give the in-tile ranks);
+//   2. one workgroup per (bucket, chunk): the bucket's slice of the sorted
+//      ends/starts (a few thousand keys) is staged in LDS and every lane does
+//      two plain binary searches there -- ~3 wave instructions per query, and
+//      the targets are read from HBM once, coalesced;
+//   3. counts come back in bucket order and are gathered into query order.
+// Everything stays exact: slices are chosen so that ranks outside them are
+// known, and anything that falls outside (very long / reversed queries) takes
+// a per-lane global search.
+constexpr int PT_NB_LOG2 = 11;
+constexpr int PT_NB = 1 << PT_NB_LOG2;      // coordinate buckets
+constexpr int PT_THREADS = 1024;
+constexpr int PT_ITEMS = 16;
+constexpr int PT_TILE = PT_THREADS * PT_ITEMS;  // 16384 queries per partition tile (staged whole in LDS)
+constexpr int PT_CHUNK = 32768;             // queries per search workgroup
+constexpr int PT_LDS_INTS = 19456;          // 76 KiB of slices per workgroup -> two workgroups per CU
+constexpr int PT_SLOTS = 64;                // spread the total over 64 counters (one atomic per workgroup)
+constexpr int PT_ILP = 4;                   // queries in flight per lane in the search kernel
+
+struct PartGeom {
+    int32_t cmin;   // smallest coordinate of the bucket grid
+    int32_t shift;  // bucket width = 1 << shift
+};
+
+struct SliceBound {
+    int32_t eLo, eHi;    // staged slice of the sorted ends    [eLo, eHi)
+    int32_t sLo, sHi;    // staged slice of the sorted starts  [sLo, sHi)
+    int32_t qeLo, qeHi;  // rank_lt(starts, qe) may use the slice iff qeLo <= qe <= qeHi
+    int32_t kE, kS;      // the slices are staged as perfect search trees of 2^k - 1 keys; kE < 0: does not fit in LDS
+};
+
+__device__ __host__ __forceinline__ int pt_skew(int i) { return i + (i >> 5); }
+
+__device__ __forceinline__ int part_bucket(int qs, PartGeom g)
+{
+    if (qs < g.cmin) return 0;
+    unsigned b = ((unsigned)qs - (unsigned)g.cmin) >> g.shift;
+    return b < (unsigned)(PT_NB - 1) ? (int)b : PT_NB - 1;
+}
+
+__global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const int32_t *__restrict__ qs, int64_t nq, PartGeom g,
+                                                               unsigned *__restrict__ hist, int64_t ntiles)
+{
+    __shared__ unsigned cnt[PT_NB];
+    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * PT_TILE;
+    const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
+    if (n == PT_TILE) {
+        // full tile: 4 x 16-byte loads in flight per lane before the first atomic
+        const int4 *q4 = reinterpret_cast<const int4 *>(qs + base);
+        int4 v[PT_ITEMS / 4];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS / 4; j++) v[j] = q4[j * PT_THREADS + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS / 4; j++) {
+            atomicAdd(&cnt[part_bucket(v[j].x, g)], 1u);
+            atomicAdd(&cnt[part_bucket(v[j].y, g)], 1u);
+            atomicAdd(&cnt[part_bucket(v[j].z, g)], 1u);
+            atomicAdd(&cnt[part_bucket(v[j].w, g)], 1u);
+        }
+    } else {
+        for (int j = threadIdx.x; j < n; j += PT_THREADS) atomicAdd(&cnt[part_bucket(qs[base + j], g)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) hist[(int64_t)i * ntiles + blockIdx.x] = cnt[i];
+}
+
+// The scan wants the table bucket-major (all tiles of bucket 0, then bucket 1, ...); the scatter
+// and gather workgroups want THEIR tile's 2048 entries contiguous.  One transpose in between.
+__global__ __launch_bounds__(256) void part_transpose_kernel(const unsigned *__restrict__ bucket_major, int64_t ntiles,
+                                                             unsigned *__restrict__ tile_major)
+{
+    __shared__ unsigned tile[32][33];
+    const int64_t t0 = (int64_t)blockIdx.x * 32;  // 32 tiles x 32 buckets per block
+    const int b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (t0 + tx < ntiles) ? bucket_major[(int64_t)(b0 + r) * ntiles + t0 + tx] : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (t0 + r < ntiles) tile_major[(t0 + r) * PT_NB + b0 + tx] = tile[tx][r];
+}
+
+// One workgroup moves one tile of 16384 queries into bucket order.  A scattered 4-byte store
+// costs a whole L2 request, so the tile is ordered INSIDE LDS first (ranks from LDS atomics,
+// (qs,qe) pairs written to their sorted slot) and then streamed out: consecutive lanes store
+// to consecutive addresses, one request per (tile, bucket) run.  `lpos` remembers, per query in
+// original order, its slot in the tile's sorted order (16 bits) for the gather on the way back.
+__global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
+                                                                  int64_t nq, PartGeom g,
+                                                                  const unsigned *__restrict__ tile_table /* [ntiles][PT_NB] */,
+                                                                  int32_t *__restrict__ qs_out, int32_t *__restrict__ qe_out,
+                                                                  unsigned short *__restrict__ lpos /* may be NULL */)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    int2 *staged = reinterpret_cast<int2 *>(dyn);                       // [PT_TILE] (qs, qe) in bucket order
+    unsigned *cnt = reinterpret_cast<unsigned *>(dyn + 2 * PT_TILE);     // [PT_NB] counts, later (global base - tile offset)
+    unsigned *toff = cnt + PT_NB;                                        // [PT_NB] start of each bucket inside the tile
+    __shared__ unsigned scan_tmp[16];
+    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * PT_TILE;
+    const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
+    int s[PT_ITEMS], e[PT_ITEMS];
+    unsigned br[PT_ITEMS];  // bucket << 16 | rank inside (tile, bucket)
+#pragma unroll
+    for (int j = 0; j < PT_ITEMS; j++) {
+        int k = j * PT_THREADS + threadIdx.x;
+        if (k < n) {
+            s[j] = qs[base + k];
+            e[j] = qe[base + k];
+            unsigned b = (unsigned)part_bucket(s[j], g);
+            br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        unsigned a = cnt[2 * threadIdx.x], b = cnt[2 * threadIdx.x + 1];
+        unsigned tot;
+        unsigned exc = block_exclusive_scan(a + b, OpSum(), 0u, scan_tmp, &tot);
+        toff[2 * threadIdx.x] = exc;
+        toff[2 * threadIdx.x + 1] = exc + a;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = tile_table[(int64_t)blockIdx.x * PT_NB + i] - toff[i];
+#pragma unroll
+    for (int j = 0; j < PT_ITEMS; j++) {
+        int k = j * PT_THREADS + threadIdx.x;
+        if (k < n) {
+            unsigned p = toff[br[j] >> 16] + (br[j] & 0xffffu);
+            staged[p] = make_int2(s[j], e[j]);
+            if (lpos) lpos[base + k] = (unsigned short)p;
+        }
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < n; p += PT_THREADS) {
+        int2 v = staged[p];
+        unsigned d = cnt[part_bucket(v.x, g)] + (unsigned)p;  // global base of the run + offset inside it
+        qs_out[d] = v.x;
+        qe_out[d] = v.y;
+    }
+}
+
+// wg_first[b] = first search workgroup of bucket b (exclusive scan of ceil(n_b / PT_CHUNK)).
+__global__ __launch_bounds__(1024) void part_plan_kernel(const unsigned *__restrict__ scanned_hist, int64_t ntiles, int64_t nq,
+                                                         int32_t *__restrict__ wg_first /* [PT_NB + 1] */)
+{
+    __shared__ int lds[16];
+    int carry = 0;
+    for (int base = 0; base < PT_NB; base += 1024) {
+        int b = base + threadIdx.x;
+        int64_t lo = scanned_hist[(int64_t)b * ntiles];
+        int64_t hi = b + 1 < PT_NB ? (int64_t)scanned_hist[(int64_t)(b + 1) * ntiles] : nq;
+        int chunks = (int)((hi - lo + PT_CHUNK - 1) / PT_CHUNK);
+        int total;
+        int exc = block_exclusive_scan(chunks, OpSum(), 0, lds, &total);
+        wg_first[b] = carry + exc;
+        carry += total;
+    }
+    if (threadIdx.x == 0) wg_first[PT_NB] = carry;
+}
+
+// #{a[i] < key} over a[0..n) held in LDS with a[n] == INT_MAX as a stop; `top` = highest power of two <= n+1.
+__device__ __forceinline__ int lds_rank_lt(const int32_t *a, int n, int top, int key)
+{
+    int pos = 0;
+    for (int s = top; s > 0; s >>= 1) {
+        int p = pos + s;
+        int v = a[(p < n + 1 ? p : n + 1) - 1];
+        pos = v < key ? p : pos;
+    }
+    return pos;
+}
+
+__device__ __forceinline__ int global_rank_lt(const int32_t *__restrict__ a, int lo, int hi, int key)
+{
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
+                                                                const SliceBound *__restrict__ bounds,
+                                                                const int32_t *__restrict__ wg_first,
+                                                                const unsigned *__restrict__ scanned_hist, int64_t ntiles,
+                                                                const int32_t *__restrict__ qs_arr,
+                                                                const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                                int32_t *__restrict__ counts /* bucket order, may be NULL */,
+                                                                unsigned long long *__restrict__ total_slots)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ int s_bucket;
+    __shared__ long long red[PT_THREADS / 64];
+    if (threadIdx.x == 0) s_bucket = -1;
+    __syncthreads();
+    {
+        // every lane tests two buckets: the owner of workgroup w is the bucket with first <= w < next
+        const int w = (int)blockIdx.x;
+#pragma unroll
+        for (int u = 0; u < PT_NB / PT_THREADS; u++) {
+            int b = u * PT_THREADS + threadIdx.x;
+            if (wg_first[b] <= w && w < wg_first[b + 1]) s_bucket = b;
+        }
+    }
+    __syncthreads();
+    const int b = s_bucket;
+    if (b < 0) return;
+    const int64_t q_lo = scanned_hist[(int64_t)b * ntiles];
+    const int64_t q_hi = b + 1 < PT_NB ? (int64_t)scanned_hist[(int64_t)(b + 1) * ntiles] : nq;
+    const int64_t q_begin = q_lo + (int64_t)((int)blockIdx.x - wg_first[b]) * PT_CHUNK;
+    const int64_t q_end = q_begin + PT_CHUNK < q_hi ? q_begin + PT_CHUNK : q_hi;
+    const SliceBound sb = bounds[b];
+    const int nE = sb.eHi - sb.eLo, nS = sb.sHi - sb.sLo;
+    // The two slices are staged as PERFECT binary search trees in breadth-first (Eytzinger)
+    // order, padded with INT_MAX: tree[1] is the root, children of i are 2i and 2i+1.  A search
+    // is "i = 2i + (tree[i] < key)" -- one LDS read and three VALU ops per level -- the probes of
+    // one level fall in one contiguous block (no power-of-two bank pile-up), and after k levels
+    // i - 2^k is exactly the number of keys < key.
+    const bool staged = sb.kE >= 0;
+    int32_t *treeE = lds, *treeS = lds + (staged ? (1 << sb.kE) : 0);
+    if (staged) {
+        const int total = (1 << sb.kE) + (1 << sb.kS);
+        for (int i = threadIdx.x; i < total; i += PT_THREADS) lds[i] = INT_MAX;
+        __syncthreads();
+        for (int r = threadIdx.x; r < nE; r += PT_THREADS) {
+            int tpos = r + 1, z = __ffs(tpos) - 1;  // in-order number and height of the node holding rank r
+            treeE[(tpos >> (z + 1)) + (1 << (sb.kE - 1 - z))] = e_sorted[sb.eLo + r];
+        }
+        for (int r = threadIdx.x; r < nS; r += PT_THREADS) {
+            int tpos = r + 1, z = __ffs(tpos) - 1;
+            treeS[(tpos >> (z + 1)) + (1 << (sb.kS - 1 - z))] = ix.s_ord[sb.sLo + r];
+        }
+    }
+    __syncthreads();
+    long long acc = 0;
+    for (int64_t i0 = q_begin + threadIdx.x; i0 < q_end; i0 += PT_THREADS * PT_ILP) {
+        int qs[PT_ILP], qe[PT_ILP], rS[PT_ILP], rE[PT_ILP];
+        bool live[PT_ILP];
+#pragma unroll
+        for (int j = 0; j < PT_ILP; j++) {
+            int64_t i = i0 + (int64_t)j * PT_THREADS;
+            live[j] = i < q_end;
+            qs[j] = live[j] ? qs_arr[i] : 0;
+            qe[j] = live[j] ? qe_arr[i] : 0;
+            rS[j] = rE[j] = 1;
+        }
+        if (staged) {
+            // PT_ILP x 2 independent descents in lockstep (same trees => same depth)
+            for (int it = 0; it < sb.kS; it++) {
+#pragma unroll
+                for (int j = 0; j < PT_ILP; j++) rS[j] = 2 * rS[j] + (treeS[rS[j]] < qe[j]);  // #{start < qe}
+            }
+            for (int it = 0; it < sb.kE; it++) {
+#pragma unroll
+                for (int j = 0; j < PT_ILP; j++) rE[j] = 2 * rE[j] + (treeE[rE[j]] <= qs[j] && qs[j] != INT_MAX);  // #{end <= qs}
+            }
+#pragma unroll
+            for (int j = 0; j < PT_ILP; j++) {
+                rS[j] -= 1 << sb.kS;
+                rE[j] -= 1 << sb.kE;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PT_ILP; j++) {
+            if (!live[j]) continue;
+            const bool in_slice = qe[j] >= sb.qeLo && qe[j] <= sb.qeHi;
+            int s_rank;
+            if (staged && in_slice)
+                s_rank = sb.sLo + rS[j];
+            else if (in_slice)
+                s_rank = global_rank_lt(ix.s_ord, sb.sLo, sb.sHi, qe[j]);
+            else
+                s_rank = global_rank_lt(ix.s_ord, 0, ix.n, qe[j]);
+            int c;
+            if (qs[j] < qe[j]) {  // regular query (the index has no reversed targets on this path)
+                int e_rank;
+                if (qs[j] == INT_MAX)
+                    e_rank = ix.n;
+                else if (staged)
+                    e_rank = sb.eLo + rE[j];
+                else
+                    e_rank = global_rank_lt(e_sorted, sb.eLo, sb.eHi, qs[j] + 1);
+                c = s_rank - e_rank;
+            } else {  // zero-length / reversed query: exact predicate over the candidate window
+                int lo = first_pm_gt(ix.pm, ix.n, qs[j]);
+                c = 0;
+                for (int k = lo; k < s_rank; k++) c += ix.e_ord[k] > qs[j];
+            }
+            int64_t i = i0 + (int64_t)j * PT_THREADS;
+            if (counts) counts[i] = c;
+            acc += c;
+        }
+    }
+    if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
+}
+
+// Counts come back in bucket order.  One workgroup per partition tile pulls the tile's runs
+// (one per bucket, contiguous in the bucketed array) into LDS in the tile's sorted order, then
+// every query picks its count through the 16-bit slot remembered by the scatter: all global
+// traffic is coalesced, the random access happens in LDS.
+__global__ __launch_bounds__(PT_THREADS) void part_gather_kernel(const int32_t *__restrict__ bucketed,
+                                                                 const unsigned short *__restrict__ lpos,
+                                                                 const unsigned *__restrict__ tile_table /* [ntiles][PT_NB] */,
+                                                                 int64_t ntiles, int64_t nq, int32_t *__restrict__ out)
+{
+    __shared__ int32_t vals[PT_TILE];
+    __shared__ unsigned short toff[PT_NB + 2];
+    __shared__ unsigned gbase[PT_NB];
+    __shared__ unsigned scan_tmp[16];
+    const int64_t base = (int64_t)blockIdx.x * PT_TILE;
+    const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
+    {
+        // Tile counts = distance to the next entry of the (linear, bucket-major) exclusive scan: the next
+        // tile's entry for the same bucket, or -- for the last tile -- tile 0's entry of the next bucket.
+        const bool last_tile = blockIdx.x + 1 == ntiles;
+        const unsigned *row = tile_table + (int64_t)blockIdx.x * PT_NB;
+        const unsigned *next = last_tile ? tile_table : row + PT_NB;
+        unsigned c[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            int b = 2 * threadIdx.x + u;
+            unsigned lo = row[b];
+            unsigned hi = !last_tile ? next[b] : (b + 1 < PT_NB ? next[b + 1] : (unsigned)nq);
+            gbase[b] = lo;
+            c[u] = hi - lo;
+        }
+        unsigned tot;
+        unsigned exc = block_exclusive_scan(c[0] + c[1], OpSum(), 0u, scan_tmp, &tot);
+        toff[2 * threadIdx.x] = (unsigned short)exc;
+        toff[2 * threadIdx.x + 1] = (unsigned short)(exc + c[0]);
+        if (threadIdx.x == 0) toff[PT_NB] = (unsigned short)tot;  // tot == n <= 16384
+    }
+    __syncthreads();
+    // 8 lanes per bucket run (runs average 8 queries): 128 runs in flight per pass over the buckets
+    const int sub = threadIdx.x & 7;
+    for (int b = threadIdx.x >> 3; b < PT_NB; b += PT_THREADS / 8) {
+        unsigned o = toff[b], len = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o, gb = gbase[b];
+        for (unsigned r = sub; r < len; r += 8) vals[o + r] = bucketed[gb + r];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += PT_THREADS) out[base + k] = vals[lpos[base + k]];
+}
+
+__global__ void part_fold_total_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
+{
+    unsigned long long v = threadIdx.x < PT_SLOTS ? slots[threadIdx.x] : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0 && v) atomicAdd(total, v);
+}
+
+// Slice bounds of every bucket; depends only on the sealed index, so it is built once at seal().
+__global__ void part_bounds_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted, int n, PartGeom g,
+                                   SliceBound *__restrict__ out)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= PT_NB) return;
+    const long long W = 1ll << g.shift;
+    const long long lo = b == 0 ? (long long)INT_MIN - 1 : (long long)g.cmin + (long long)b * W;          // qs >= lo
+    const long long hi = b == PT_NB - 1 ? (long long)INT_MAX + 1 : (long long)g.cmin + (long long)(b + 1) * W;  // qs < hi
+    auto rank_lt64 = [n](const int32_t *a, long long x) {
+        int l = 0, h = n;
+        while (l < h) {
+            int mid = (int)(((unsigned)l + (unsigned)h) >> 1);
+            if ((long long)a[mid] < x)
+                l = mid + 1;
+            else
+                h = mid;
+        }
+        return l;
+    };
+    SliceBound sb;
+    // ends: keys qs+1 lie in [lo+1, hi]
+    sb.eLo = rank_lt64(e_sorted, lo + 1);
+    sb.eHi = rank_lt64(e_sorted, hi + 1);
+    // trees: 2^kE slots for the ends, the rest of the LDS budget (a power of two) for the starts
+    const int nE = sb.eHi - sb.eLo;
+    int kE = 0;
+    while (kE < 20 && (1 << kE) - 1 < nE) kE++;
+    int room = PT_LDS_INTS - (1 << kE);
+    // starts: keys qe of ordinary queries lie in [lo, hi + W/8]; shrink to what the tree can hold
+    sb.sLo = rank_lt64(s_ord, lo);
+    long long x = hi + (W >> 3) + 1;
+    int sHi = rank_lt64(s_ord, x);
+    int kS = 0;
+    while ((1 << kS) - 1 < sHi - sb.sLo) kS++;
+    while (kS > 0 && (1 << kS) > room) kS--;
+    if (room < 1) {
+        kE = -1;  // the ends alone overflow LDS: this bucket searches its slices in global memory
+        kS = 0;
+    } else if (sHi - sb.sLo > (1 << kS) - 1) {
+        sHi = sb.sLo + (1 << kS) - 1;
+        x = sHi < n ? (long long)s_ord[sHi] : (long long)INT_MAX + 1;  // every start at index >= sHi is >= x
+    }
+    sb.kE = kE;
+    sb.kS = kS;
+    sb.sHi = sHi;
+    sb.qeLo = lo < INT_MIN ? INT_MIN : (int32_t)lo;
+    sb.qeHi = x > INT_MAX ? INT_MAX : (int32_t)x;
+    out[b] = sb;
+}
+
 // ---------------------------------------------------------------------------
 // find kernels: window + count, then ballot-compacted fill
 // ---------------------------------------------------------------------------
@@ -450,6 +869,8 @@ struct Tree {
 static int64_t g_opt_group_sum = 0;   // 0 = DPP, 1 = ds_bpermute shuffles
 static int64_t g_opt_lds_ints = LDS_TREE_INTS;
 static int64_t g_opt_count_grid = 0;  // 0 = one workgroup per CU
+static int64_t g_opt_partition = -1;  // -1 = auto (large batches), 0 = never, 1 = always
+static int64_t g_opt_partition_min = 4 << 20;  // auto: partition batches of at least this many queries
 
 int ivl_set_option(const char *key, int64_t value)
 {
@@ -463,6 +884,14 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.count_grid")) {
         g_opt_count_grid = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.partition")) {
+        g_opt_partition = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.partition_min")) {
+        g_opt_partition_min = value;
         return 1;
     }
     return 0;
@@ -489,9 +918,67 @@ struct bxmi_ivl {
     DevBuf scan_scratch;
     // query scratch
     DevBuf q_s, q_e, q_cnt, q_lo, q_hi, q_off, q_hits, q_total;
+    // partitioned count path
+    PartGeom geom{0, 0};
+    DevBuf slice_bounds, p_hist, p_table, p_qs, p_qe, p_dest, p_cnt, p_plan, p_slots;
     hipStream_t stream = nullptr;
     int device = 0;
 };
+
+
+static IndexDev index_dev(const bxmi_ivl *h);
+template <typename Kern>
+static int allow_big_lds(Kern k, size_t bytes);
+
+// Large-batch count: bucket the queries, search each bucket against LDS-resident slices, gather back.
+static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
+                                 int64_t *total_dev, hipStream_t st)
+{
+    if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
+    const int64_t ntiles = div_up(nq, PT_TILE);
+    BXMI_TRY(h->p_hist.reserve((size_t)ntiles * PT_NB * sizeof(unsigned)));
+    BXMI_TRY(h->p_qs.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_qe.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_plan.reserve((PT_NB + 1) * sizeof(int32_t)));
+    BXMI_TRY(h->p_slots.reserve(PT_SLOTS * sizeof(unsigned long long)));
+    if (counts) {
+        BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
+        BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
+    }
+    unsigned *hist = h->p_hist.as<unsigned>();
+    hipLaunchKernelGGL(part_hist_kernel, dim3((unsigned)ntiles), dim3(PT_THREADS), 0, st, qs, nq, h->geom, hist, ntiles);
+    BXMI_LAUNCH_CHECK();
+    BXMI_TRY((device_scan<unsigned, unsigned, OpSum, false>(hist, hist, ntiles * PT_NB, 0u, nullptr, h->scan_scratch, st)));
+    BXMI_TRY(h->p_table.reserve((size_t)ntiles * PT_NB * sizeof(unsigned)));
+    unsigned *table = h->p_table.as<unsigned>();
+    hipLaunchKernelGGL(part_transpose_kernel, dim3((unsigned)div_up(ntiles, 32), PT_NB / 32), dim3(256), 0, st, hist, ntiles, table);
+    const size_t scat_lds = (size_t)PT_TILE * 8 + 2 * PT_NB * sizeof(unsigned);
+    BXMI_TRY(allow_big_lds(part_scatter_kernel, scat_lds));
+    hipLaunchKernelGGL(part_scatter_kernel, dim3((unsigned)ntiles), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, table,
+                       h->p_qs.as<int32_t>(), h->p_qe.as<int32_t>(), counts ? h->p_dest.as<unsigned short>() : nullptr);
+    hipLaunchKernelGGL(part_plan_kernel, dim3(1), dim3(1024), 0, st, hist, ntiles, nq, h->p_plan.as<int32_t>());
+    BXMI_LAUNCH_CHECK();
+    if (total_dev) BXMI_HIP(hipMemsetAsync(h->p_slots.p, 0, PT_SLOTS * sizeof(unsigned long long), st));
+    const size_t lds_bytes = (size_t)PT_LDS_INTS * 4;
+    BXMI_TRY(allow_big_lds(part_count_kernel, lds_bytes));
+    const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
+    hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->e_sorted.as<int32_t>(),
+                       h->slice_bounds.as<SliceBound>(), h->p_plan.as<int32_t>(), hist, ntiles, h->p_qs.as<int32_t>(),
+                       h->p_qe.as<int32_t>(), nq, counts ? h->p_cnt.as<int32_t>() : nullptr,
+                       total_dev ? h->p_slots.as<unsigned long long>() : nullptr);
+    BXMI_LAUNCH_CHECK();
+    if (counts) {
+        hipLaunchKernelGGL(part_gather_kernel, dim3((unsigned)ntiles), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>(),
+                           h->p_dest.as<unsigned short>(), table, ntiles, nq, counts);
+        BXMI_LAUNCH_CHECK();
+    }
+    if (total_dev) {
+        hipLaunchKernelGGL(part_fold_total_kernel, dim3(1), dim3(64), 0, st, h->p_slots.as<unsigned long long>(),
+                           reinterpret_cast<unsigned long long *>(total_dev));
+        BXMI_LAUNCH_CHECK();
+    }
+    return BXMI_OK;
+}
 
 static int ivl_stream(bxmi_ivl *h)
 {
@@ -615,10 +1102,29 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
     BXMI_TRY(h->treeE.build(h->e_sorted.as<int32_t>(), n, st));
     BXMI_TRY(h->treeP.build(h->pm.as<int32_t>(), n, st));
     unsigned rev = 0;
+    int32_t cmin = 0, cmax = 0;
     BXMI_HIP(hipMemcpyAsync(&rev, d_rev, 4, hipMemcpyDeviceToHost, st));
+    if (n > 0) {
+        BXMI_HIP(hipMemcpyAsync(&cmin, h->s_ord.as<int32_t>(), 4, hipMemcpyDeviceToHost, st));
+        BXMI_HIP(hipMemcpyAsync(&cmax, h->e_sorted.as<int32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    }
     BXMI_HIP(hipStreamSynchronize(st));
     h->has_reversed = rev != 0;
     h->n = n;
+    // bucket grid of the partitioned count path: PT_NB buckets of width 2^shift over [min start, max end]
+    {
+        int64_t span = (int64_t)cmax - (int64_t)cmin;
+        if (span < 0) span = 0;
+        int shift = 0;
+        while ((span >> shift) >= PT_NB) shift++;
+        h->geom.cmin = cmin;
+        h->geom.shift = shift;
+        BXMI_TRY(h->slice_bounds.reserve(PT_NB * sizeof(SliceBound)));
+        hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)n,
+                           h->geom, h->slice_bounds.as<SliceBound>());
+        BXMI_LAUNCH_CHECK();
+        BXMI_HIP(hipStreamSynchronize(st));
+    }
     h->sealed = true;
     return BXMI_OK;
 }
@@ -691,6 +1197,9 @@ extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_
     if (((uintptr_t)qs | (uintptr_t)qe | (uintptr_t)counts) & 15)
         return fail(BXMI_EINVAL, "bxmi_ivl_count_dev: query/count arrays must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
+    const bool partition = !h->has_reversed && h->n > 0 &&
+                           (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_partition_min && h->n >= 4096));
+    if (partition) return ivl_count_partitioned(h, qs, qe, nq, counts, total_dev, st);
     TreeDev S = h->treeS.dev, E = h->treeE.dev;
     Tree tS = Tree(), tE = Tree();
     if (g_opt_lds_ints != LDS_TREE_INTS) {  // A/B knob: restage fewer levels

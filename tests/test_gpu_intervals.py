@@ -60,6 +60,12 @@ def test_count_and_find_match_reference_vectors(golden_trees, IntervalIndex, gro
             want = [len(h) for h in case["hits"]]
             assert counts.tolist() == want, (case["mode"], case["n"])
             assert total == sum(want)
+            set_opt("ivl.partition", 1)
+            try:
+                counts, total = ix.count(q[:, 0], q[:, 1])
+            finally:
+                set_opt("ivl.partition", -1)
+            assert counts.tolist() == want and total == sum(want), ("partitioned", case["mode"], case["n"])
             offs, hits = ix.find(q[:, 0], q[:, 1])
             assert offs.tolist() == np.concatenate([[0], np.cumsum(want)]).tolist()
             assert hits.tolist() == [x for h in case["hits"] for x in h], (case["mode"], case["n"])
@@ -128,6 +134,15 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     bad = np.nonzero(got_c != want_c)[0]
     assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got_c[bad[:5]], want_c[bad[:5]])
     assert got_t == want_t
+    set_opt("ivl.partition", 1)  # same batch through the bucketed large-batch path
+    try:
+        got_c, got_t = ix.count(qs, qe)
+        tot_only = ix.count(qs, qe, want_counts=False)[1]
+    finally:
+        set_opt("ivl.partition", -1)
+    bad = np.nonzero(got_c != want_c)[0]
+    assert len(bad) == 0, ("partitioned", bad[:5], qs[bad[:5]], qe[bad[:5]], got_c[bad[:5]], want_c[bad[:5]])
+    assert got_t == want_t == tot_only
     want_off, want_hits = t.find_batch(qs, qe)
     got_off, got_hits = ix.find(qs, qe)
     assert np.array_equal(got_off, want_off)
@@ -176,6 +191,12 @@ def test_scale_1M_hash(golden_scale, IntervalIndex):
         assert total == pt["total"]
         assert hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], lds_ints
     set_opt("ivl.lds_ints", 18688)
+    set_opt("ivl.partition", 1)
+    try:
+        counts, total = ix.count(qs, qe)
+    finally:
+        set_opt("ivl.partition", -1)
+    assert total == pt["total"] and hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], "partitioned"
     offs, hits = ix.find(qs, qe)
     assert offs[-1] == pt["total"] and np.array_equal(np.diff(offs), counts)
     # every reported hit really overlaps, and hits of one query come in tree order
@@ -196,6 +217,13 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
         sub = counts[:: pt["stride"]]
         assert int(sub.sum(dtype=np.int64)) == pt["total"]
         assert hashlib.sha256(np.ascontiguousarray(sub).tobytes()).hexdigest() == pt["counts_sha256"]
+    # the direct tree kernel and the bucketed path agree (first 8M queries through the direct kernel)
+    set_opt("ivl.partition", 0)
+    try:
+        direct, _ = ix.count(qs[:8_000_000], qe[:8_000_000])
+    finally:
+        set_opt("ivl.partition", -1)
+    assert np.array_equal(direct, counts[:8_000_000])
     # additivity: counting two halves separately gives the same per-query numbers
     h = len(qs) // 2
     c2, t2 = ix.count(qs[h:], qe[h:])
