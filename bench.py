@@ -121,6 +121,22 @@ def bench_bitsets(torch, steps, warmup):
         for a, b in zip(A, Bs):
             _ffi.call("bxmi_bits_and_count_dev", a._h, b._h, acc.data_ptr(), stream)
 
+    from bxmi.bitset import BitSetGroup
+
+    gA, gB = BitSetGroup(A), BitSetGroup(Bs)
+    per = torch.zeros(len(A), dtype=torch.int64, device="cuda")
+
+    def g_popcount():
+        per.zero_()
+        _ffi.call("bxmi_bits_group_popcount_dev", gA._g, per.data_ptr(), stream)
+
+    def g_iand():
+        _ffi.call("bxmi_bits_group_and_dev", gA._g, gB._g, None, stream)
+
+    def g_fused():
+        per.zero_()
+        _ffi.call("bxmi_bits_group_and_dev", gA._g, gB._g, per.data_ptr(), stream)
+
     pop_before = None
     popcount()
     torch.cuda.synchronize()
@@ -132,7 +148,17 @@ def bench_bitsets(torch, steps, warmup):
     popcount()
     torch.cuda.synchronize()
     assert int(acc.item()) == and_bits, "fused and+count disagrees with a separate popcount"
+    ms_gpop, ms_gand, ms_gfused = timed(g_popcount), timed(g_iand), timed(g_fused)
+    assert int(per.sum().item()) == and_bits, "group and+count disagrees with the per-chromosome launches"
+    group = dict(
+        note="same work as ONE launch over all 24 chromosomes (bxmi_bits_group_*)",
+        popcount_gbps=round(bits / ms_gpop / 1e6, 1), iand_gbps=round(bits / ms_gand / 1e6, 1), iand_count_fused_gbps=round(bits / ms_gfused / 1e6, 1),
+        ms=dict(popcount=round(ms_gpop, 4), iand=round(ms_gand, 4), fused=round(ms_gfused, 4)),
+        roofline_frac=dict(popcount=round(bits / 8 / (ms_gpop * 1e6) / HBM_PEAK_GBS, 4), iand=round(3 * bits / 8 / (ms_gand * 1e6) / HBM_PEAK_GBS, 4),
+                           fused=round(3 * bits / 8 / (ms_gfused * 1e6) / HBM_PEAK_GBS, 4)),
+    )
     out = dict(
+        one_launch_per_genome=group,
         workload="configs[2]: 24 hg19-sized chromosome bitsets (3.096 Gbp), two sets of 1.5M ranges, lens=chrom sizes",
         popcount_gbps=round(bits / ms_pop / 1e6, 1), iand_gbps=round(bits / ms_and / 1e6, 1), iand_count_fused_gbps=round(bits / ms_fused / 1e6, 1),
         ms=dict(popcount=round(ms_pop, 4), iand=round(ms_and, 4), fused=round(ms_fused, 4)),

@@ -76,6 +76,11 @@ _SIGNATURES = {
     "bxmi_bits_and_count_dev": [vp, vp, vp, vp],
     "bxmi_bits_popcount_dev": [vp, vp, vp],
     "bxmi_bits_runs": [vp, i32, vp, vp, i64, _p(i64)],
+    "bxmi_bits_group_create": [_p(vp), C.c_int, _p(vp)],
+    "bxmi_bits_group_destroy": [vp],
+    "bxmi_bits_group_and_dev": [vp, vp, vp, vp],
+    "bxmi_bits_group_or_dev": [vp, vp, vp],
+    "bxmi_bits_group_popcount_dev": [vp, vp, vp],
 }
 _OTHER_RESTYPE = {"bxmi_version": (C.c_int, []), "bxmi_last_error": (C.c_char_p, [])}
 

@@ -196,3 +196,64 @@ class DeviceBitSet:
         w = np.empty(n, dtype=np.uint64)
         call("bxmi_memcpy_d2h", ptr(w), p, n * 8)
         return np.unpackbits(w.view(np.uint8), bitorder="little")[: self.size]
+
+
+class BitSetGroup:
+    """Several bitsets (one per chromosome) operated on in ONE kernel launch.
+
+    The batch form of the per-chromosome loops in the reference's scripts:
+    ``for key in bits1: bits1[key].iand(bits2[key])`` (bed_intersect_basewise.py:25-28) and
+    ``total += bitsets[chrom].count_range(0, size)`` (bed_coverage.py:27-29)."""
+
+    def __init__(self, members):
+        self.members = list(members)
+        if not self.members:
+            raise ValueError("a group needs at least one bitset")
+        n = len(self.members)
+        arr = (C.c_void_p * n)(*[m._h for m in self.members])
+        g = C.c_void_p()
+        call("bxmi_bits_group_create", arr, n, C.byref(g))
+        self._g = g
+        self._counts = _ffi.DeviceArray(8 * n)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            _ffi.load().bxmi_bits_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _pair(self, other):
+        if len(other.members) != len(self.members):
+            raise ValueError("groups must have the same number of members")
+        for a, b in zip(self.members, other.members):
+            a.check_same_size(b)
+            a._same_bins(b)
+
+    def _fetch(self):
+        call("bxmi_synchronize", None)
+        return self._counts.to_numpy(np.int64, len(self.members))
+
+    def iand(self, other, want_counts=False):
+        """member[i] &= other.member[i] for all i; optionally the popcount of every result."""
+        self._pair(other)
+        if want_counts:
+            self._counts.zero()
+        call("bxmi_bits_group_and_dev", self._g, other._g, self._counts.ptr if want_counts else None, None)
+        return self._fetch() if want_counts else call("bxmi_synchronize", None) and None
+
+    def ior(self, other):
+        self._pair(other)
+        call("bxmi_bits_group_or_dev", self._g, other._g, None)
+        call("bxmi_synchronize", None)
+
+    def popcounts(self):
+        """count_range(0, size) of every member (true popcounts: callers on inverted sets beware the
+        reference's ALL_ONE arithmetic only bites when start % bin_size != 0, never here)."""
+        self._counts.zero()
+        call("bxmi_bits_group_popcount_dev", self._g, self._counts.ptr, None)
+        return self._fetch()

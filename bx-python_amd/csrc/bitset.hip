@@ -17,6 +17,7 @@
 #include <climits>
 #include <cmath>
 #include <new>
+#include <vector>
 
 #include "primitives.hpp"
 
@@ -405,6 +406,125 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_runs_fill_kernel(const unsi
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// genome-scale batches: AND / OR / popcount over MANY bitsets in one launch
+// ---------------------------------------------------------------------------
+// bed_intersect_basewise.py:25-28 and bed_coverage.py:27-29 loop over the
+// chromosomes; 24 small launches (16 MB each) leave the GPU mostly idle and pay
+// one contended atomic per workgroup.  A group keeps a device table of its
+// members so the whole genome is one launch: workgroups walk 64 KiB chunks of a
+// flattened chunk space, and per-member counts land on per-member counters.
+constexpr int MB_CHUNK_PAIRS = 4096;  // 16-byte pairs per chunk = 64 KiB
+
+struct GroupSeg {
+    unsigned long long *words;
+    uint8_t *tags;
+    int64_t npairs;
+    int64_t size_bits;
+    int64_t chunk_first;  // first chunk of this member in the flattened chunk space
+    int64_t tag_first;    // first tag of this member in the flattened tag space
+    int64_t ntags;
+};
+
+__device__ __forceinline__ int group_find(const GroupSeg *__restrict__ segs, int nseg, int64_t chunk)
+{
+    int lo = 0, hi = nseg;  // last member whose first chunk is <= chunk
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (segs[mid].chunk_first <= chunk)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// OP: 0 = and, 1 = or, 3 = read-only popcount.  COUNT: accumulate popcount of the result inside [0,size).
+template <int OP, bool COUNT>
+__global__ __launch_bounds__(BITS_THREADS) void bits_group_kernel(const GroupSeg *__restrict__ sa, const GroupSeg *__restrict__ sb,
+                                                                 int nseg, int64_t total_chunks,
+                                                                 unsigned long long *__restrict__ counts)
+{
+    __shared__ long long red[BITS_THREADS / 64];
+    const int64_t per = (total_chunks + gridDim.x - 1) / gridDim.x;
+    int64_t c = (int64_t)blockIdx.x * per;
+    const int64_t c_end = c + per < total_chunks ? c + per : total_chunks;
+    if (c >= c_end) return;
+    int seg = group_find(sa, nseg, c);
+    long long acc = 0;
+    for (; c < c_end; c++) {
+        while (seg + 1 < nseg && sa[seg + 1].chunk_first <= c) {  // next member: flush this one's count
+            if (COUNT) {
+                block_accumulate_i64(acc, red, counts + seg);
+                __syncthreads();
+                acc = 0;
+            }
+            seg++;
+        }
+        const GroupSeg A = sa[seg];
+        ulonglong2 *va = reinterpret_cast<ulonglong2 *>(A.words);
+        const ulonglong2 *vb = OP == 3 ? nullptr : reinterpret_cast<const ulonglong2 *>(sb[seg].words);
+        const int64_t p0 = (c - A.chunk_first) * MB_CHUNK_PAIRS;
+        const int64_t p1 = p0 + MB_CHUNK_PAIRS < A.npairs ? p0 + MB_CHUNK_PAIRS : A.npairs;
+        const int64_t full_words = A.size_bits >> 6;
+        const unsigned long long tail_mask = (A.size_bits & 63) ? ~(~0ull << (A.size_bits & 63)) : 0ull;
+        for (int64_t p = p0 + threadIdx.x; p < p1; p += BITS_THREADS) {
+            ulonglong2 x = va[p];
+            if (OP != 3) {
+                ulonglong2 y = vb[p];
+                if (OP == 0) {
+                    x.x &= y.x;
+                    x.y &= y.y;
+                } else {
+                    x.x |= y.x;
+                    x.y |= y.y;
+                }
+                va[p] = x;
+            }
+            if (COUNT) {
+                int64_t w = p * 2;
+                if (w + 1 < full_words) {
+                    acc += __popcll(x.x) + __popcll(x.y);
+                } else {
+                    acc += w < full_words ? __popcll(x.x) : (w == full_words ? __popcll(x.x & tail_mask) : 0);
+                    acc += (w + 1) < full_words ? __popcll(x.y) : ((w + 1) == full_words ? __popcll(x.y & tail_mask) : 0);
+                }
+            }
+        }
+    }
+    if (COUNT) block_accumulate_i64(acc, red, counts + seg);
+}
+
+// Per-bin state tables of binBitsAnd / binBitsOr over the flattened tag space of a group.
+template <int OP>
+__global__ void tags_group_kernel(const GroupSeg *__restrict__ sa, const GroupSeg *__restrict__ sb, int nseg, int64_t total_tags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_tags; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nseg;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (sa[mid].tag_first <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        int64_t k = i - sa[lo].tag_first;
+        uint8_t *a = sa[lo].tags;
+        const uint8_t *b = sb[lo].tags;
+        uint8_t x = a[k], y = b[k];
+        if (OP == 0) {  // binBits.c:237-256
+            if (x == TAG_ZERO || y == TAG_ONE) continue;
+            if (y == TAG_ZERO) a[k] = TAG_ZERO;
+            else if (x == TAG_ONE) a[k] = TAG_DATA;
+        } else {  // binBits.c:271-290
+            if (x == TAG_ONE || y == TAG_ZERO) continue;
+            if (y == TAG_ONE) a[k] = TAG_ONE;
+            else if (x == TAG_ZERO) a[k] = TAG_DATA;
+        }
+    }
+}
+
 static int64_t g_opt_bits_grid = 0;
 int bits_set_option(const char *key, int64_t value)
 {
@@ -693,7 +813,11 @@ template <int OP, bool COUNT>
 static int bits_binary(bxmi_bits *h, const bxmi_bits *other, unsigned long long *acc_dev, hipStream_t st)
 {
     int64_t npairs = h->nwords >> 1;
-    hipLaunchKernelGGL((bits_binary_kernel<OP, COUNT>), dim3(bits_grid(npairs, BITS_THREADS * 2)), dim3(BITS_THREADS), 0, st,
+    // counting variants end in one atomic per workgroup on a single counter (~12 ns each, serialised):
+    // keep the grid at 2 workgroups per CU for those
+    int grid = bits_grid(npairs, BITS_THREADS * 2);
+    if (COUNT && grid > device_props().cus * 2) grid = device_props().cus * 2;
+    hipLaunchKernelGGL((bits_binary_kernel<OP, COUNT>), dim3(grid), dim3(BITS_THREADS), 0, st,
                        h->words.as<unsigned long long>(), other->words.as<unsigned long long>(), npairs, (int64_t)h->size, acc_dev);
     int64_t nb = div_up(h->total_bits, h->bin_size);
     if (OP == 0 && !h->flat)
@@ -732,7 +856,9 @@ extern "C" int bxmi_bits_popcount_dev(bxmi_bits_t *h, int64_t *count_dev, void *
 {
     if (!h || !count_dev) return fail(BXMI_EINVAL, "bxmi_bits_popcount_dev: bad arguments");
     int64_t npairs = h->nwords >> 1;
-    hipLaunchKernelGGL(bits_popcount_kernel, dim3(bits_grid(npairs, BITS_THREADS * 2)), dim3(BITS_THREADS), 0, as_stream(stream),
+    int grid = bits_grid(npairs, BITS_THREADS * 2);
+    if (grid > device_props().cus * 2) grid = device_props().cus * 2;
+    hipLaunchKernelGGL(bits_popcount_kernel, dim3(grid), dim3(BITS_THREADS), 0, as_stream(stream),
                        h->words.as<unsigned long long>(), npairs, (int64_t)h->size, reinterpret_cast<unsigned long long *>(count_dev));
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
@@ -832,4 +958,100 @@ extern "C" int bxmi_bits_runs(bxmi_bits_t *h, int32_t from, int32_t *run_start, 
     BXMI_HIP(hipMemcpyAsync(run_end, h->run_e.p, (size_t)totals[0] * 4, hipMemcpyDeviceToHost, st));
     BXMI_HIP(hipStreamSynchronize(st));
     return BXMI_OK;
+}
+
+// ---- groups ------------------------------------------------------------------
+struct bxmi_bits_group {
+    std::vector<bxmi_bits *> members;
+    DevBuf table;
+    int64_t total_chunks = 0, total_tags = 0;
+};
+
+extern "C" int bxmi_bits_group_create(bxmi_bits_t *const *members, int n, bxmi_bits_group_t **out)
+{
+    if (!members || !out || n < 1) return fail(BXMI_EINVAL, "bxmi_bits_group_create: bad arguments");
+    bxmi_bits_group *g = new (std::nothrow) bxmi_bits_group();
+    if (!g) return fail(BXMI_ENOMEM, "bxmi_bits_group_create: host allocation failed");
+    std::vector<GroupSeg> segs((size_t)n);
+    for (int i = 0; i < n; i++) {
+        bxmi_bits *m = members[i];
+        if (!m) {
+            delete g;
+            return fail(BXMI_EINVAL, "bxmi_bits_group_create: member %d is NULL", i);
+        }
+        g->members.push_back(m);
+        GroupSeg &s = segs[(size_t)i];
+        s.words = m->words.as<unsigned long long>();
+        s.tags = m->tags.as<uint8_t>();
+        s.npairs = m->nwords >> 1;
+        s.size_bits = m->size;
+        s.chunk_first = g->total_chunks;
+        s.tag_first = g->total_tags;
+        s.ntags = div_up(m->total_bits, m->bin_size);
+        g->total_chunks += div_up(s.npairs, MB_CHUNK_PAIRS);
+        g->total_tags += s.ntags;
+    }
+    int rc = g->table.reserve(segs.size() * sizeof(GroupSeg));
+    if (rc == BXMI_OK && hipMemcpy(g->table.p, segs.data(), segs.size() * sizeof(GroupSeg), hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(BXMI_EHIP, "bxmi_bits_group_create: table upload failed");
+    if (rc != BXMI_OK) {
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_bits_group_destroy(bxmi_bits_group_t *g)
+{
+    delete g;
+    return BXMI_OK;
+}
+
+static int group_pair_check(const bxmi_bits_group *a, const bxmi_bits_group *b, const char *who)
+{
+    if (!a || !b) return fail(BXMI_EINVAL, "%s: NULL group", who);
+    if (a->members.size() != b->members.size()) return fail(BXMI_EINVAL, "%s: groups have different member counts", who);
+    for (size_t i = 0; i < a->members.size(); i++) BXMI_TRY(same_shape(a->members[i], b->members[i], who));
+    return BXMI_OK;
+}
+
+template <int OP, bool COUNT>
+static int group_launch(bxmi_bits_group *a, const bxmi_bits_group *b, int64_t *counts_dev, hipStream_t st)
+{
+    const int n = (int)a->members.size();
+    int grid = (int)(a->total_chunks < (int64_t)device_props().cus * 8 ? a->total_chunks : (int64_t)device_props().cus * 8);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL((bits_group_kernel<OP, COUNT>), dim3(grid), dim3(BITS_THREADS), 0, st, a->table.as<GroupSeg>(),
+                       b ? b->table.as<GroupSeg>() : nullptr, n, a->total_chunks, reinterpret_cast<unsigned long long *>(counts_dev));
+    if (OP == 0 || OP == 1) {
+        hipLaunchKernelGGL((tags_group_kernel<OP>), dim3(stream_grid(a->total_tags, 256)), dim3(256), 0, st, a->table.as<GroupSeg>(),
+                           b->table.as<GroupSeg>(), n, a->total_tags);
+        for (int i = 0; i < n; i++) {
+            bxmi_bits *x = a->members[(size_t)i];
+            const bxmi_bits *y = b->members[(size_t)i];
+            if (!x->flat) x->maybe_one = OP == 0 ? (x->maybe_one && y->maybe_one) : (x->maybe_one || y->maybe_one);
+        }
+    }
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_bits_group_and_dev(bxmi_bits_group_t *g, const bxmi_bits_group_t *other, int64_t *counts_dev, void *stream)
+{
+    BXMI_TRY(group_pair_check(g, other, "bxmi_bits_group_and"));
+    return counts_dev ? group_launch<0, true>(g, other, counts_dev, as_stream(stream))
+                      : group_launch<0, false>(g, other, nullptr, as_stream(stream));
+}
+
+extern "C" int bxmi_bits_group_or_dev(bxmi_bits_group_t *g, const bxmi_bits_group_t *other, void *stream)
+{
+    BXMI_TRY(group_pair_check(g, other, "bxmi_bits_group_or"));
+    return group_launch<1, false>(g, other, nullptr, as_stream(stream));
+}
+
+extern "C" int bxmi_bits_group_popcount_dev(bxmi_bits_group_t *g, int64_t *counts_dev, void *stream)
+{
+    if (!g || !counts_dev) return fail(BXMI_EINVAL, "bxmi_bits_group_popcount_dev: bad arguments");
+    return group_launch<3, true>(g, nullptr, counts_dev, as_stream(stream));
 }

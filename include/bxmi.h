@@ -148,6 +148,17 @@ int bxmi_bits_and_dev(bxmi_bits_t *h, const bxmi_bits_t *other, void *stream);
 int bxmi_bits_or_dev(bxmi_bits_t *h, const bxmi_bits_t *other, void *stream);
 int bxmi_bits_and_count_dev(bxmi_bits_t *h, const bxmi_bits_t *other, int64_t *count_dev, void *stream);
 int bxmi_bits_popcount_dev(bxmi_bits_t *h, int64_t *count_dev, void *stream);
+/* Genome-scale batches: the per-chromosome loops of bed_intersect_basewise.py:25-28
+ * (iand) and bed_coverage.py:27-29 (count_range(0, size)) as ONE launch over all
+ * members.  counts_dev, when given, is int64[n_members] in HBM and is accumulated
+ * into (zero it first): popcount of each member's result inside [0, size). */
+typedef struct bxmi_bits_group bxmi_bits_group_t;
+int bxmi_bits_group_create(bxmi_bits_t *const *members, int n, bxmi_bits_group_t **out);
+int bxmi_bits_group_destroy(bxmi_bits_group_t *g);
+int bxmi_bits_group_and_dev(bxmi_bits_group_t *g, const bxmi_bits_group_t *other, int64_t *counts_dev, void *stream);
+int bxmi_bits_group_or_dev(bxmi_bits_group_t *g, const bxmi_bits_group_t *other, void *stream);
+int bxmi_bits_group_popcount_dev(bxmi_bits_group_t *g, int64_t *counts_dev, void *stream);
+
 /* Maximal runs of set bits inside [from, size), i.e. the pairs the loop
  * start=next_set(end); end=next_clear(start) of bed_intersect_basewise.py:32-38
  * produces.  Writes up to cap pairs; *n_runs = number of runs (BXMI_ERANGE if > cap). */

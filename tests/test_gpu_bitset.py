@@ -192,6 +192,41 @@ def test_and_count_fused(O):
     assert np.array_equal(a.to_bits(), oa.unpack())
 
 
+def test_group_ops_match_per_member_ops(O):
+    """One launch over many bitsets == the per-chromosome loop (sizes chosen to straddle chunk edges)."""
+    from bxmi.bitset import BitSetGroup, DeviceBitSet
+
+    rng = np.random.default_rng(21)
+    sizes = [100, 524288 + 77, 3_000_001, 4096 * 128, 65, 9_999_999]
+    A = [DeviceBitSet(s) for s in sizes]
+    B = [DeviceBitSet(s) for s in sizes]
+    OA = [O.OracleBinnedBitSet(s) for s in sizes]
+    OB = [O.OracleBinnedBitSet(s) for s in sizes]
+    for dev, ora in ((A, OA), (B, OB)):
+        for d, o in zip(dev, ora):
+            m = 400
+            s = rng.integers(0, d.size, size=m)
+            n = np.minimum(rng.integers(0, max(2, d.size // 50), size=m), d.size - s)
+            d.set_ranges(s, n), o.set_ranges(s, n)
+    B[2].invert(), OB[2].invert()  # padding bits + ALL_ONE tags inside one member
+    ga, gb = BitSetGroup(A), BitSetGroup(B)
+    assert ga.popcounts().tolist() == [o.count_range(0, o.size) for o in OA]
+    counts = ga.iand(gb, want_counts=True)
+    for oa, ob in zip(OA, OB):
+        oa.iand(ob)
+    assert counts.tolist() == [o.count_range(0, o.size) for o in OA]
+    for d, o in zip(A, OA):
+        assert d.bin_states().tolist() == o.states().tolist()
+        assert np.array_equal(d.to_bits(), o.unpack())
+    ga.ior(gb)
+    for oa, ob in zip(OA, OB):
+        oa.ior(ob)
+    assert ga.popcounts().tolist() == [int(o.unpack().sum()) for o in OA]
+    for d, o in zip(A, OA):
+        assert d.bin_states().tolist() == o.states().tolist()
+        assert d.count_range(0, d.size) == o.count_range(0, o.size)
+
+
 def test_batch_errors_match_reference_messages():
     from bxmi.bitset import DeviceBitSet
 
