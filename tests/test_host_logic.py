@@ -155,3 +155,19 @@ def test_sharded_count_world_size_2_gloo(tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert p.stdout.count("ok") == 2
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/lib/bx"), reason="reference tree not mounted (build container only)")
+def test_overlay_resolves_next_to_an_installed_bx_python():
+    """PYTHONPATH=bx-python_amd:<bx-python>/lib: our two modules win, everything else comes from bx-python."""
+    code = (
+        "import bx, bx.bitset, bx.intervals, bx.intervals.intersection, bx.bitset_builders, bx.intervals.io, bx.cookbook.doc_optparse\n"
+        "print(bx.bitset.__file__); print(bx.intervals.intersection.__file__)\n"
+        "print(bx.bitset_builders.__file__); print(bx.intervals.io.__file__)\n"
+        "print(bx.bitset_builders.BinnedBitSet is bx.bitset.BinnedBitSet, bx.intervals.Intersecter is bx.intervals.intersection.IntervalTree)\n"
+    )
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "bx-python_amd") + os.pathsep + "/root/reference/lib")
+    out = subprocess.check_output([sys.executable, "-c", code], text=True, env=env).splitlines()
+    assert out[0].endswith("bx-python_amd/bx/bitset.py") and out[1].endswith("bx-python_amd/bx/intervals/intersection.py")
+    assert out[2].startswith("/root/reference/lib/bx/") and out[3].startswith("/root/reference/lib/bx/")
+    assert out[4] == "True True"
