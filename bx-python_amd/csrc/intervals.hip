@@ -316,13 +316,25 @@ __device__ __forceinline__ int part_bucket(int qs, PartGeom g)
     return b < (unsigned)(PT_NB - 1) ? (int)b : PT_NB - 1;
 }
 
+// Workgroup -> tile, XCD-aware.  Workgroup w runs on XCD w % 8 (observed dispatch order; used for
+// speed only).  Giving each XCD a CONTIGUOUS range of tiles means the four (tile, bucket) runs that
+// share one 128-byte line of the bucketed arrays are written / read by the same XCD close in time,
+// so its L2 merges them: measured 1.7x write and 3x read amplification without this.
+__device__ __forceinline__ int64_t part_tile_of_block(int64_t ntiles)
+{
+    const int64_t per_xcd = (ntiles + 7) >> 3;
+    return (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+}
+
 __global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const int32_t *__restrict__ qs, int64_t nq, PartGeom g,
-                                                               unsigned *__restrict__ hist, int64_t ntiles)
+                                                               unsigned *__restrict__ table /* [ntiles][PT_NB] */, int64_t ntiles)
 {
     __shared__ unsigned cnt[PT_NB];
+    const int64_t tile = part_tile_of_block(ntiles);
+    if (tile >= ntiles) return;
     for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * PT_TILE;
+    const int64_t base = tile * PT_TILE;
     const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
     if (n == PT_TILE) {
         // full tile: 4 x 16-byte loads in flight per lane before the first atomic
@@ -341,25 +353,75 @@ __global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const int32_t *__
         for (int j = threadIdx.x; j < n; j += PT_THREADS) atomicAdd(&cnt[part_bucket(qs[base + j], g)], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) hist[(int64_t)i * ntiles + blockIdx.x] = cnt[i];
+    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) table[tile * PT_NB + i] = cnt[i];
 }
 
-// The scan wants the table bucket-major (all tiles of bucket 0, then bucket 1, ...); the scatter
-// and gather workgroups want THEIR tile's 2048 entries contiguous.  One transpose in between.
-__global__ __launch_bounds__(256) void part_transpose_kernel(const unsigned *__restrict__ bucket_major, int64_t ntiles,
-                                                             unsigned *__restrict__ tile_major)
+// The table is tile-major ([tile][bucket], every workgroup reads/writes its own 8 KiB row coalesced).
+// Destination of (tile t, bucket b) = sum of all counts of buckets < b, plus counts of bucket b in
+// tiles < t: a scan DOWN the columns after a scan ACROSS the column totals, in three small kernels.
+__global__ __launch_bounds__(PT_THREADS) void part_colsum_kernel(const unsigned *__restrict__ table, int64_t ntiles, int rows_per_block,
+                                                                 unsigned *__restrict__ partial /* [nblocks][PT_NB] */)
 {
-    __shared__ unsigned tile[32][33];
-    const int64_t t0 = (int64_t)blockIdx.x * 32;  // 32 tiles x 32 buckets per block
-    const int b0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-#pragma unroll
-    for (int r = ty; r < 32; r += 8)
-        tile[r][tx] = (t0 + tx < ntiles) ? bucket_major[(int64_t)(b0 + r) * ntiles + t0 + tx] : 0u;
-    __syncthreads();
-#pragma unroll
-    for (int r = ty; r < 32; r += 8)
-        if (t0 + r < ntiles) tile_major[(t0 + r) * PT_NB + b0 + tx] = tile[tx][r];
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < ntiles ? r0 + rows_per_block : ntiles;
+    unsigned s0 = 0, s1 = 0;
+    for (int64_t r = r0; r < r1; r++) {
+        s0 += table[r * PT_NB + threadIdx.x];
+        s1 += table[r * PT_NB + PT_THREADS + threadIdx.x];
+    }
+    partial[(int64_t)blockIdx.x * PT_NB + threadIdx.x] = s0;
+    partial[(int64_t)blockIdx.x * PT_NB + PT_THREADS + threadIdx.x] = s1;
+}
+
+__global__ __launch_bounds__(PT_THREADS) void part_colbase_kernel(unsigned *__restrict__ partial, int nblocks, int64_t nq,
+                                                                  int32_t *__restrict__ wg_first /* [PT_NB + 1] */)
+{
+    __shared__ unsigned scan_tmp[16];
+    __shared__ int scan_tmp_i[16];
+    // thread t owns the adjacent columns 2t and 2t+1 (so that one block scan orders all 2048 buckets)
+    const int c0 = 2 * threadIdx.x, c1 = c0 + 1;
+    unsigned t0 = 0, t1 = 0;
+#pragma unroll 8
+    for (int r = 0; r < nblocks; r++) {
+        uint2 v = *reinterpret_cast<const uint2 *>(partial + (int64_t)r * PT_NB + c0);
+        t0 += v.x;
+        t1 += v.y;
+    }
+    unsigned tot;
+    unsigned base0 = block_exclusive_scan(t0 + t1, OpSum(), 0u, scan_tmp, &tot);
+    unsigned base1 = base0 + t0;
+    // search-workgroup plan: bucket b gets ceil(n_b / PT_CHUNK) workgroups
+    int ch0 = (int)((t0 + PT_CHUNK - 1) / PT_CHUNK), ch1 = (int)((t1 + PT_CHUNK - 1) / PT_CHUNK);
+    int chtot;
+    int w0 = block_exclusive_scan(ch0 + ch1, OpSum(), 0, scan_tmp_i, &chtot);
+    wg_first[c0] = w0;
+    wg_first[c1] = w0 + ch0;
+    if (threadIdx.x == 0) wg_first[PT_NB] = chtot;
+    unsigned run0 = base0, run1 = base1;
+#pragma unroll 8
+    for (int r = 0; r < nblocks; r++) {
+        uint2 *cell = reinterpret_cast<uint2 *>(partial + (int64_t)r * PT_NB + c0);
+        uint2 v = *cell;
+        *cell = make_uint2(run0, run1);
+        run0 += v.x;
+        run1 += v.y;
+    }
+}
+
+__global__ __launch_bounds__(PT_THREADS) void part_colscan_kernel(unsigned *__restrict__ table, int64_t ntiles, int rows_per_block,
+                                                                  const unsigned *__restrict__ partial)
+{
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < ntiles ? r0 + rows_per_block : ntiles;
+    unsigned run0 = partial[(int64_t)blockIdx.x * PT_NB + threadIdx.x];
+    unsigned run1 = partial[(int64_t)blockIdx.x * PT_NB + PT_THREADS + threadIdx.x];
+    for (int64_t r = r0; r < r1; r++) {
+        unsigned v0 = table[r * PT_NB + threadIdx.x], v1 = table[r * PT_NB + PT_THREADS + threadIdx.x];
+        table[r * PT_NB + threadIdx.x] = run0;
+        table[r * PT_NB + PT_THREADS + threadIdx.x] = run1;
+        run0 += v0;
+        run1 += v1;
+    }
 }
 
 // One workgroup moves one tile of 16384 queries into bucket order.  A scattered 4-byte store
@@ -370,7 +432,8 @@ __global__ __launch_bounds__(256) void part_transpose_kernel(const unsigned *__r
 __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
                                                                   int64_t nq, PartGeom g,
                                                                   const unsigned *__restrict__ tile_table /* [ntiles][PT_NB] */,
-                                                                  int32_t *__restrict__ qs_out, int32_t *__restrict__ qe_out,
+                                                                  int64_t ntiles, int32_t *__restrict__ qs_out,
+                                                                  int32_t *__restrict__ qe_out,
                                                                   unsigned short *__restrict__ lpos /* may be NULL */)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
@@ -378,9 +441,11 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
     unsigned *cnt = reinterpret_cast<unsigned *>(dyn + 2 * PT_TILE);     // [PT_NB] counts, later (global base - tile offset)
     unsigned *toff = cnt + PT_NB;                                        // [PT_NB] start of each bucket inside the tile
     __shared__ unsigned scan_tmp[16];
+    const int64_t tile = part_tile_of_block(ntiles);
+    if (tile >= ntiles) return;
     for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * PT_TILE;
+    const int64_t base = tile * PT_TILE;
     const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
     int s[PT_ITEMS], e[PT_ITEMS];
     unsigned br[PT_ITEMS];  // bucket << 16 | rank inside (tile, bucket)
@@ -403,7 +468,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
         toff[2 * threadIdx.x + 1] = exc + a;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = tile_table[(int64_t)blockIdx.x * PT_NB + i] - toff[i];
+    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = tile_table[tile * PT_NB + i] - toff[i];
 #pragma unroll
     for (int j = 0; j < PT_ITEMS; j++) {
         int k = j * PT_THREADS + threadIdx.x;
@@ -420,25 +485,6 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
         qs_out[d] = v.x;
         qe_out[d] = v.y;
     }
-}
-
-// wg_first[b] = first search workgroup of bucket b (exclusive scan of ceil(n_b / PT_CHUNK)).
-__global__ __launch_bounds__(1024) void part_plan_kernel(const unsigned *__restrict__ scanned_hist, int64_t ntiles, int64_t nq,
-                                                         int32_t *__restrict__ wg_first /* [PT_NB + 1] */)
-{
-    __shared__ int lds[16];
-    int carry = 0;
-    for (int base = 0; base < PT_NB; base += 1024) {
-        int b = base + threadIdx.x;
-        int64_t lo = scanned_hist[(int64_t)b * ntiles];
-        int64_t hi = b + 1 < PT_NB ? (int64_t)scanned_hist[(int64_t)(b + 1) * ntiles] : nq;
-        int chunks = (int)((hi - lo + PT_CHUNK - 1) / PT_CHUNK);
-        int total;
-        int exc = block_exclusive_scan(chunks, OpSum(), 0, lds, &total);
-        wg_first[b] = carry + exc;
-        carry += total;
-    }
-    if (threadIdx.x == 0) wg_first[PT_NB] = carry;
 }
 
 // #{a[i] < key} over a[0..n) held in LDS with a[n] == INT_MAX as a stop; `top` = highest power of two <= n+1.
@@ -468,7 +514,7 @@ __device__ __forceinline__ int global_rank_lt(const int32_t *__restrict__ a, int
 __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
                                                                 const SliceBound *__restrict__ bounds,
                                                                 const int32_t *__restrict__ wg_first,
-                                                                const unsigned *__restrict__ scanned_hist, int64_t ntiles,
+                                                                const unsigned *__restrict__ table /* row 0 = bucket offsets */,
                                                                 const int32_t *__restrict__ qs_arr,
                                                                 const int32_t *__restrict__ qe_arr, int64_t nq,
                                                                 int32_t *__restrict__ counts /* bucket order, may be NULL */,
@@ -491,8 +537,8 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
     __syncthreads();
     const int b = s_bucket;
     if (b < 0) return;
-    const int64_t q_lo = scanned_hist[(int64_t)b * ntiles];
-    const int64_t q_hi = b + 1 < PT_NB ? (int64_t)scanned_hist[(int64_t)(b + 1) * ntiles] : nq;
+    const int64_t q_lo = table[b];
+    const int64_t q_hi = b + 1 < PT_NB ? (int64_t)table[b + 1] : nq;
     const int64_t q_begin = q_lo + (int64_t)((int)blockIdx.x - wg_first[b]) * PT_CHUNK;
     const int64_t q_end = q_begin + PT_CHUNK < q_hi ? q_begin + PT_CHUNK : q_hi;
     const SliceBound sb = bounds[b];
@@ -593,13 +639,15 @@ __global__ __launch_bounds__(PT_THREADS) void part_gather_kernel(const int32_t *
     __shared__ unsigned short toff[PT_NB + 2];
     __shared__ unsigned gbase[PT_NB];
     __shared__ unsigned scan_tmp[16];
-    const int64_t base = (int64_t)blockIdx.x * PT_TILE;
+    const int64_t tile = part_tile_of_block(ntiles);
+    if (tile >= ntiles) return;
+    const int64_t base = tile * PT_TILE;
     const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
     {
         // Tile counts = distance to the next entry of the (linear, bucket-major) exclusive scan: the next
         // tile's entry for the same bucket, or -- for the last tile -- tile 0's entry of the next bucket.
-        const bool last_tile = blockIdx.x + 1 == ntiles;
-        const unsigned *row = tile_table + (int64_t)blockIdx.x * PT_NB;
+        const bool last_tile = tile + 1 == ntiles;
+        const unsigned *row = tile_table + tile * PT_NB;
         const unsigned *next = last_tile ? tile_table : row + PT_NB;
         unsigned c[2];
 #pragma unroll
@@ -936,7 +984,6 @@ static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *
 {
     if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
     const int64_t ntiles = div_up(nq, PT_TILE);
-    BXMI_TRY(h->p_hist.reserve((size_t)ntiles * PT_NB * sizeof(unsigned)));
     BXMI_TRY(h->p_qs.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_qe.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_plan.reserve((PT_NB + 1) * sizeof(int32_t)));
@@ -945,30 +992,33 @@ static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *
         BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
         BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
     }
-    unsigned *hist = h->p_hist.as<unsigned>();
-    hipLaunchKernelGGL(part_hist_kernel, dim3((unsigned)ntiles), dim3(PT_THREADS), 0, st, qs, nq, h->geom, hist, ntiles);
-    BXMI_LAUNCH_CHECK();
-    BXMI_TRY((device_scan<unsigned, unsigned, OpSum, false>(hist, hist, ntiles * PT_NB, 0u, nullptr, h->scan_scratch, st)));
+    const unsigned tgrid = (unsigned)(((ntiles + 7) >> 3) << 3);  // 8 XCD ranges of ceil(ntiles/8) tiles
+    int rows_per_block = (int)div_up(ntiles, 64);  // ~64 row blocks: the serial middle kernel stays short
+    const int nrb = (int)div_up(ntiles, rows_per_block);
     BXMI_TRY(h->p_table.reserve((size_t)ntiles * PT_NB * sizeof(unsigned)));
-    unsigned *table = h->p_table.as<unsigned>();
-    hipLaunchKernelGGL(part_transpose_kernel, dim3((unsigned)div_up(ntiles, 32), PT_NB / 32), dim3(256), 0, st, hist, ntiles, table);
+    BXMI_TRY(h->p_hist.reserve((size_t)nrb * PT_NB * sizeof(unsigned)));
+    unsigned *table = h->p_table.as<unsigned>(), *partial = h->p_hist.as<unsigned>();
+    hipLaunchKernelGGL(part_hist_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, qs, nq, h->geom, table, ntiles);
+    hipLaunchKernelGGL(part_colsum_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
+    hipLaunchKernelGGL(part_colbase_kernel, dim3(1), dim3(PT_THREADS), 0, st, partial, nrb, nq, h->p_plan.as<int32_t>());
+    hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
+    BXMI_LAUNCH_CHECK();
     const size_t scat_lds = (size_t)PT_TILE * 8 + 2 * PT_NB * sizeof(unsigned);
     BXMI_TRY(allow_big_lds(part_scatter_kernel, scat_lds));
-    hipLaunchKernelGGL(part_scatter_kernel, dim3((unsigned)ntiles), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, table,
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, table, ntiles,
                        h->p_qs.as<int32_t>(), h->p_qe.as<int32_t>(), counts ? h->p_dest.as<unsigned short>() : nullptr);
-    hipLaunchKernelGGL(part_plan_kernel, dim3(1), dim3(1024), 0, st, hist, ntiles, nq, h->p_plan.as<int32_t>());
     BXMI_LAUNCH_CHECK();
     if (total_dev) BXMI_HIP(hipMemsetAsync(h->p_slots.p, 0, PT_SLOTS * sizeof(unsigned long long), st));
     const size_t lds_bytes = (size_t)PT_LDS_INTS * 4;
     BXMI_TRY(allow_big_lds(part_count_kernel, lds_bytes));
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
     hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->e_sorted.as<int32_t>(),
-                       h->slice_bounds.as<SliceBound>(), h->p_plan.as<int32_t>(), hist, ntiles, h->p_qs.as<int32_t>(),
+                       h->slice_bounds.as<SliceBound>(), h->p_plan.as<int32_t>(), table, h->p_qs.as<int32_t>(),
                        h->p_qe.as<int32_t>(), nq, counts ? h->p_cnt.as<int32_t>() : nullptr,
                        total_dev ? h->p_slots.as<unsigned long long>() : nullptr);
     BXMI_LAUNCH_CHECK();
     if (counts) {
-        hipLaunchKernelGGL(part_gather_kernel, dim3((unsigned)ntiles), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>(),
+        hipLaunchKernelGGL(part_gather_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>(),
                            h->p_dest.as<unsigned short>(), table, ntiles, nq, counts);
         BXMI_LAUNCH_CHECK();
     }

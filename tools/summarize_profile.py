@@ -52,5 +52,23 @@ for k, v in dur.items():
     if k in out:
         out[k]["avg_duration_us"] = sum(v) / len(v) / 1e3
         out[k]["dispatches_traced"] = len(v)
+# HBM bytes of one count pass = its five kernels (the table scans add ~0.15 GB and are shared with seal()).
+# FETCH_SIZE is in KiB and reads HALF of a streaming read on gfx950 (checked below on the bitset popcount, whose
+# byte count is known); WRITE_SIZE is in KiB and exact.  Correction as MI355X_MICROARCH.md prescribes.
+pass_kernels = ["part_hist_kernel", "part_transpose_kernel", "part_scatter_kernel", "part_count_kernel", "part_gather_kernel"]
+tot = 0.0
+detail = {}
+for k in pass_kernels:
+    v = out.get(k)
+    if v and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        b = (2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024.0
+        detail[k] = dict(hbm_bytes=b, fetch_kib_raw=v["FETCH_SIZE"]["mean"], write_kib=v["WRITE_SIZE"]["mean"], avg_us=v.get("avg_duration_us"))
+        tot += b
+if detail:
+    out["count_pass"] = dict(hbm_bytes_per_launch=round(tot), kernels=detail,
+                             note="sum over the pass's kernels of (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024")
+v = out.get("ivl_count_kernel<true>")
+if v and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+    out["ivl_count_kernel"] = dict(hbm_bytes_per_launch=round((2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024.0))
 json.dump(out, open(os.path.join(d, "summary_pmc.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if "ivl_" in k or "bits_" in k}, indent=1))
+print(json.dumps({k: v for k, v in out.items() if k in ("count_pass", "bits_popcount_kernel") or k.startswith("bits_group")}, indent=1))
