@@ -236,6 +236,48 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
     assert (wide >= counts[:1_000_000]).all()
 
 
+def test_genome_sharded_count_single_rank():
+    """configs[3] shape at reduced size: 24 chromosomes, per-chromosome indexes, counts summed (world size 1 here;
+    the 2-rank gloo run of the same driver is tests/test_host_logic.py)."""
+    from bxmi import shard
+
+    rng = np.random.default_rng(404)
+    targets, queries = {}, {}
+    for chrom, size in synth.HG19_SIZES.items():
+        nt, nq = max(50, size // 20000), max(50, size // 5000)
+        s = rng.integers(0, size - 1000, size=nt).astype(np.int32)
+        targets[chrom] = (s, (s + rng.integers(1, 1001, size=nt)).astype(np.int32))
+        q = rng.integers(0, size - 1000, size=nq).astype(np.int32)
+        queries[chrom] = (q, (q + rng.integers(1, 1001, size=nq)).astype(np.int32))
+    totals, per_query = shard.count_genome(targets, queries, rank=0, world=1)
+    for chrom in synth.HG19_SIZES:
+        ts, te = targets[chrom]
+        qs, qe = queries[chrom]
+        want = np.searchsorted(np.sort(ts), qe, "left") - np.searchsorted(np.sort(te), qs, "right")  # proper intervals only
+        assert np.array_equal(per_query[chrom], want.astype(np.int32)), chrom
+        assert totals[chrom] == int(want.sum())
+
+
+def test_find_join_scale_properties(IntervalIndex):
+    """configs[4] shape at 4M x 4M (the 50M x 50M run is tools/bench_find.py): CSR consistency, every hit overlaps,
+    hits of a query in tree order, and agreement with the count path."""
+    (ts, te), (qs, qe) = synth.cfg5(4_000_000, 4_000_000)
+    ix = make_index(IntervalIndex, ts, te)
+    offs, hits = ix.find(qs, qe, cap_hint=8 * len(qs))
+    counts, total = ix.count(qs, qe)
+    assert offs[-1] == total == len(hits) and np.array_equal(np.diff(offs).astype(np.int32), counts)
+    rep = np.repeat(np.arange(len(qs)), counts)
+    assert (te[hits] > qs[rep]).all() and (ts[hits] < qe[rep]).all()
+    key = ts[hits].astype(np.int64) * (1 << 31) + hits
+    same = rep[1:] == rep[:-1]
+    assert (key[1:][same] >= key[:-1][same]).all()
+    # brute-force spot check of 200 queries
+    for i in np.random.default_rng(1).integers(0, len(qs), size=200):
+        want = np.nonzero((te > qs[i]) & (ts < qe[i]))[0]
+        got = hits[offs[i]:offs[i + 1]]
+        assert sorted(got.tolist()) == want.tolist()
+
+
 # -------------------------------------------------------------- compat API --
 def test_compat_intervaltree_known_answers():
     """lib/bx/intervals/intersection_tests.py:158-201 and the doctests intersection.pyx:335-376."""

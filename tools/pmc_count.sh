@@ -29,11 +29,12 @@ for l in open('gpurun_out/pmc/index.txt'):
     acc = collections.defaultdict(list)
     if f:
         for r in csv.DictReader(open(f[0])):
-            if 'ivl_count_kernel' in r['Kernel_Name']:
-                acc[r['Counter_Name']].append(float(r['Counter_Value']))
+            kn = r['Kernel_Name']
+            if any(f in kn for f in os.environ.get('KFILTER', 'ivl_count_kernel').split(',')):
+                acc[kn.split('(')[0].replace('bxmi::','')[:24] + ' ' + r['Counter_Name']].append(float(r['Counter_Value']))
     out.write(l.strip() + '\n')
-    for k, v in acc.items():
-        out.write('    %-34s mean=%.6g n=%d\n' % (k, sum(v) / len(v), len(v)))
+    for k, v in sorted(acc.items()):
+        out.write('    %-52s mean=%.6g n=%d\n' % (k, sum(v) / len(v), len(v)))
     if not f:
         out.write('    (no counter file) ' + open('gpurun_out/pmc/%s.log' % run).read()[-300:].replace('\n', ' | ') + '\n')
 out.close()
