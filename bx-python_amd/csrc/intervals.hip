@@ -288,7 +288,10 @@ __global__ __launch_bounds__(CNT_THREADS) void ivl_count_kernel(TreeDev S, TreeD
 constexpr int PT_NB_LOG2 = 11;
 constexpr int PT_NB = 1 << PT_NB_LOG2;      // coordinate buckets
 constexpr int PT_THREADS = 1024;
-constexpr int PT_ITEMS = 16;
+#ifndef BXMI_PT_ITEMS
+#define BXMI_PT_ITEMS 16
+#endif
+constexpr int PT_ITEMS = BXMI_PT_ITEMS;
 constexpr int PT_TILE = PT_THREADS * PT_ITEMS;  // 16384 queries per partition tile (staged whole in LDS)
 constexpr int PT_CHUNK = 32768;             // queries per search workgroup
 constexpr int PT_LDS_INTS = 19456;          // 76 KiB of slices per workgroup -> two workgroups per CU
@@ -436,11 +439,14 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
                                                                   int32_t *__restrict__ qe_out,
                                                                   unsigned short *__restrict__ lpos /* may be NULL */)
 {
+    // LDS: half a tile of (qs, qe) pairs (64 KiB) + two 2048-entry tables (16 KiB) = 80 KiB, so TWO workgroups
+    // share a CU and one streams out while the other loads; the tile goes through the staging area in two halves.
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    int2 *staged = reinterpret_cast<int2 *>(dyn);                       // [PT_TILE] (qs, qe) in bucket order
-    unsigned *cnt = reinterpret_cast<unsigned *>(dyn + 2 * PT_TILE);     // [PT_NB] counts, later (global base - tile offset)
-    unsigned *toff = cnt + PT_NB;                                        // [PT_NB] start of each bucket inside the tile
-    __shared__ unsigned scan_tmp[16];
+    constexpr int HALF = PT_TILE / 2;
+    int2 *staged = reinterpret_cast<int2 *>(dyn);                    // [HALF] (qs, qe) in bucket order
+    unsigned *cnt = reinterpret_cast<unsigned *>(dyn + 2 * HALF);     // [PT_NB] counts, later (global base - tile offset)
+    unsigned *toff = cnt + PT_NB;                                     // [PT_NB] start of each bucket inside the tile
+    unsigned *scan_tmp = reinterpret_cast<unsigned *>(dyn);           // the staging area is idle during the scan
     const int64_t tile = part_tile_of_block(ntiles);
     if (tile >= ntiles) return;
     for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = 0;
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
     const int64_t base = tile * PT_TILE;
     const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
     int s[PT_ITEMS], e[PT_ITEMS];
-    unsigned br[PT_ITEMS];  // bucket << 16 | rank inside (tile, bucket)
+    unsigned br[PT_ITEMS];  // bucket << 16 | rank inside (tile, bucket); later the slot in the tile's sorted order
 #pragma unroll
     for (int j = 0; j < PT_ITEMS; j++) {
         int k = j * PT_THREADS + threadIdx.x;
@@ -473,17 +479,26 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
     for (int j = 0; j < PT_ITEMS; j++) {
         int k = j * PT_THREADS + threadIdx.x;
         if (k < n) {
-            unsigned p = toff[br[j] >> 16] + (br[j] & 0xffffu);
-            staged[p] = make_int2(s[j], e[j]);
-            if (lpos) lpos[base + k] = (unsigned short)p;
+            br[j] = toff[br[j] >> 16] + (br[j] & 0xffffu);
+            if (lpos) lpos[base + k] = (unsigned short)br[j];
         }
     }
-    __syncthreads();
-    for (int p = threadIdx.x; p < n; p += PT_THREADS) {
-        int2 v = staged[p];
-        unsigned d = cnt[part_bucket(v.x, g)] + (unsigned)p;  // global base of the run + offset inside it
-        qs_out[d] = v.x;
-        qe_out[d] = v.y;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        __syncthreads();  // tables ready (half 0) / previous half streamed out (half 1)
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            int k = j * PT_THREADS + threadIdx.x;
+            if (k < n && (int)(br[j] / HALF) == half) staged[br[j] & (HALF - 1)] = make_int2(s[j], e[j]);
+        }
+        __syncthreads();
+        const int m = n - half * HALF < HALF ? n - half * HALF : HALF;
+        for (int p = threadIdx.x; p < m; p += PT_THREADS) {
+            int2 v = staged[p];
+            unsigned d = cnt[part_bucket(v.x, g)] + (unsigned)(p + half * HALF);  // global base of the run + offset inside it
+            qs_out[d] = v.x;
+            qe_out[d] = v.y;
+        }
     }
 }
 
@@ -919,6 +934,8 @@ static int64_t g_opt_lds_ints = LDS_TREE_INTS;
 static int64_t g_opt_count_grid = 0;  // 0 = one workgroup per CU
 static int64_t g_opt_partition = -1;  // -1 = auto (large batches), 0 = never, 1 = always
 static int64_t g_opt_partition_min = 4 << 20;  // auto: partition batches of at least this many queries
+static int64_t g_opt_pipeline = 1;    // sub-batches on forked streams; measured: no gain (2: -2 %, 4: +10 %), so off by default
+constexpr int PT_MAX_SUB = 8;
 
 int ivl_set_option(const char *key, int64_t value)
 {
@@ -936,6 +953,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.partition")) {
         g_opt_partition = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.pipeline")) {
+        g_opt_pipeline = value < 1 ? 1 : value;
         return 1;
     }
     if (!strcmp(key, "ivl.partition_min")) {
@@ -969,6 +990,8 @@ struct bxmi_ivl {
     // partitioned count path
     PartGeom geom{0, 0};
     DevBuf slice_bounds, p_hist, p_table, p_qs, p_qe, p_dest, p_cnt, p_plan, p_slots;
+    hipStream_t sub_stream[PT_MAX_SUB] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[PT_MAX_SUB] = {};
     hipStream_t stream = nullptr;
     int device = 0;
 };
@@ -979,53 +1002,88 @@ template <typename Kern>
 static int allow_big_lds(Kern k, size_t bytes);
 
 // Large-batch count: bucket the queries, search each bucket against LDS-resident slices, gather back.
+// One sub-batch of the partitioned path, all on stream `st`; scratch regions are addressed by query offset q0.
+static int ivl_count_part_sub(bxmi_ivl *h, int sub, int64_t q0, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
+                              int64_t *total_dev, hipStream_t st)
+{
+    const int64_t ntiles = div_up(nq, PT_TILE);
+    const int64_t tile0 = q0 / PT_TILE;                           // sub-batches start on tile boundaries
+    const unsigned tgrid = (unsigned)(((ntiles + 7) >> 3) << 3);  // 8 XCD ranges of ceil(ntiles/8) tiles
+    const int rows_per_block = (int)div_up(ntiles, 64);           // ~64 row blocks: the serial middle kernel stays short
+    const int nrb = (int)div_up(ntiles, rows_per_block);
+    unsigned *table = h->p_table.as<unsigned>() + tile0 * PT_NB;
+    unsigned *partial = h->p_hist.as<unsigned>() + (int64_t)sub * 80 * PT_NB;
+    int32_t *plan = h->p_plan.as<int32_t>() + (int64_t)sub * (PT_NB + 8);
+    unsigned long long *slots = h->p_slots.as<unsigned long long>() + (int64_t)sub * PT_SLOTS;
+    int32_t *bqs = h->p_qs.as<int32_t>() + q0, *bqe = h->p_qe.as<int32_t>() + q0;
+    hipLaunchKernelGGL(part_hist_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, qs, nq, h->geom, table, ntiles);
+    hipLaunchKernelGGL(part_colsum_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
+    hipLaunchKernelGGL(part_colbase_kernel, dim3(1), dim3(PT_THREADS), 0, st, partial, nrb, nq, plan);
+    hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
+    BXMI_LAUNCH_CHECK();
+    const size_t scat_lds = (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned);
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, table, ntiles, bqs, bqe,
+                       counts ? h->p_dest.as<unsigned short>() + q0 : nullptr);
+    BXMI_LAUNCH_CHECK();
+    if (total_dev) BXMI_HIP(hipMemsetAsync(slots, 0, PT_SLOTS * sizeof(unsigned long long), st));
+    const size_t lds_bytes = (size_t)PT_LDS_INTS * 4;
+    const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
+    hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->e_sorted.as<int32_t>(),
+                       h->slice_bounds.as<SliceBound>(), plan, table, bqs, bqe, nq, counts ? h->p_cnt.as<int32_t>() + q0 : nullptr,
+                       total_dev ? slots : nullptr);
+    BXMI_LAUNCH_CHECK();
+    if (counts) {
+        hipLaunchKernelGGL(part_gather_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>() + q0,
+                           h->p_dest.as<unsigned short>() + q0, table, ntiles, nq, counts);
+        BXMI_LAUNCH_CHECK();
+    }
+    if (total_dev) {
+        hipLaunchKernelGGL(part_fold_total_kernel, dim3(1), dim3(64), 0, st, slots, reinterpret_cast<unsigned long long *>(total_dev));
+        BXMI_LAUNCH_CHECK();
+    }
+    return BXMI_OK;
+}
+
+// Large-batch count: bucket the queries, search each bucket against LDS-resident slices, gather back.
+// Big batches are cut into sub-batches on forked streams: the passes are bound by different units
+// (LDS atomics, the store path, VALU issue, latency), so sub-batch k's search overlaps k+1's scatter.
 static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
                                  int64_t *total_dev, hipStream_t st)
 {
     if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
-    const int64_t ntiles = div_up(nq, PT_TILE);
+    int nsub = 1;
+    if (g_opt_pipeline > 1 && nq >= (int64_t)g_opt_pipeline * (8 << 20)) nsub = (int)(g_opt_pipeline > PT_MAX_SUB ? PT_MAX_SUB : g_opt_pipeline);
+    const int64_t per = div_up(div_up(nq, nsub), PT_TILE) * PT_TILE;
     BXMI_TRY(h->p_qs.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_qe.reserve((size_t)(nq + 4) * 4));
-    BXMI_TRY(h->p_plan.reserve((PT_NB + 1) * sizeof(int32_t)));
-    BXMI_TRY(h->p_slots.reserve(PT_SLOTS * sizeof(unsigned long long)));
+    BXMI_TRY(h->p_plan.reserve((size_t)PT_MAX_SUB * (PT_NB + 8) * sizeof(int32_t)));
+    BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOTS * sizeof(unsigned long long)));
+    BXMI_TRY(h->p_table.reserve((size_t)(div_up(nq, PT_TILE) + PT_MAX_SUB) * PT_NB * sizeof(unsigned)));
+    BXMI_TRY(h->p_hist.reserve((size_t)PT_MAX_SUB * 80 * PT_NB * sizeof(unsigned)));
     if (counts) {
         BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
         BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
     }
-    const unsigned tgrid = (unsigned)(((ntiles + 7) >> 3) << 3);  // 8 XCD ranges of ceil(ntiles/8) tiles
-    int rows_per_block = (int)div_up(ntiles, 64);  // ~64 row blocks: the serial middle kernel stays short
-    const int nrb = (int)div_up(ntiles, rows_per_block);
-    BXMI_TRY(h->p_table.reserve((size_t)ntiles * PT_NB * sizeof(unsigned)));
-    BXMI_TRY(h->p_hist.reserve((size_t)nrb * PT_NB * sizeof(unsigned)));
-    unsigned *table = h->p_table.as<unsigned>(), *partial = h->p_hist.as<unsigned>();
-    hipLaunchKernelGGL(part_hist_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, qs, nq, h->geom, table, ntiles);
-    hipLaunchKernelGGL(part_colsum_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
-    hipLaunchKernelGGL(part_colbase_kernel, dim3(1), dim3(PT_THREADS), 0, st, partial, nrb, nq, h->p_plan.as<int32_t>());
-    hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
-    BXMI_LAUNCH_CHECK();
-    const size_t scat_lds = (size_t)PT_TILE * 8 + 2 * PT_NB * sizeof(unsigned);
-    BXMI_TRY(allow_big_lds(part_scatter_kernel, scat_lds));
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, table, ntiles,
-                       h->p_qs.as<int32_t>(), h->p_qe.as<int32_t>(), counts ? h->p_dest.as<unsigned short>() : nullptr);
-    BXMI_LAUNCH_CHECK();
-    if (total_dev) BXMI_HIP(hipMemsetAsync(h->p_slots.p, 0, PT_SLOTS * sizeof(unsigned long long), st));
-    const size_t lds_bytes = (size_t)PT_LDS_INTS * 4;
-    BXMI_TRY(allow_big_lds(part_count_kernel, lds_bytes));
-    const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
-    hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->e_sorted.as<int32_t>(),
-                       h->slice_bounds.as<SliceBound>(), h->p_plan.as<int32_t>(), table, h->p_qs.as<int32_t>(),
-                       h->p_qe.as<int32_t>(), nq, counts ? h->p_cnt.as<int32_t>() : nullptr,
-                       total_dev ? h->p_slots.as<unsigned long long>() : nullptr);
-    BXMI_LAUNCH_CHECK();
-    if (counts) {
-        hipLaunchKernelGGL(part_gather_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>(),
-                           h->p_dest.as<unsigned short>(), table, ntiles, nq, counts);
-        BXMI_LAUNCH_CHECK();
+    BXMI_TRY(allow_big_lds(part_scatter_kernel, (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned)));
+    BXMI_TRY(allow_big_lds(part_count_kernel, (size_t)PT_LDS_INTS * 4));
+    if (nsub == 1) return ivl_count_part_sub(h, 0, 0, qs, qe, nq, counts, total_dev, st);
+    // fork: side streams wait for everything already queued on the caller's stream
+    if (!h->ev_fork) {
+        BXMI_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < PT_MAX_SUB; i++) {
+            BXMI_HIP(hipStreamCreateWithFlags(&h->sub_stream[i], hipStreamNonBlocking));
+            BXMI_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
     }
-    if (total_dev) {
-        hipLaunchKernelGGL(part_fold_total_kernel, dim3(1), dim3(64), 0, st, h->p_slots.as<unsigned long long>(),
-                           reinterpret_cast<unsigned long long *>(total_dev));
-        BXMI_LAUNCH_CHECK();
+    BXMI_HIP(hipEventRecord(h->ev_fork, st));
+    for (int s = 0; s < nsub; s++) {
+        const int64_t q0 = (int64_t)s * per;
+        if (q0 >= nq) break;
+        const int64_t n = nq - q0 < per ? nq - q0 : per;
+        BXMI_HIP(hipStreamWaitEvent(h->sub_stream[s], h->ev_fork, 0));
+        BXMI_TRY(ivl_count_part_sub(h, s, q0, qs + q0, qe + q0, n, counts ? counts + q0 : nullptr, total_dev, h->sub_stream[s]));
+        BXMI_HIP(hipEventRecord(h->ev_join[s], h->sub_stream[s]));
+        BXMI_HIP(hipStreamWaitEvent(st, h->ev_join[s], 0));  // join: the caller's stream continues after every sub-batch
     }
     return BXMI_OK;
 }
@@ -1052,6 +1110,13 @@ extern "C" int bxmi_ivl_destroy(bxmi_ivl_t *h)
 {
     if (!h) return BXMI_OK;
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->ev_fork) {
+        (void)hipEventDestroy(h->ev_fork);
+        for (int i = 0; i < PT_MAX_SUB; i++) {
+            (void)hipStreamDestroy(h->sub_stream[i]);
+            (void)hipEventDestroy(h->ev_join[i]);
+        }
+    }
     delete h;
     return BXMI_OK;
 }
