@@ -27,10 +27,9 @@ __all__ = ["Interval", "IntervalNode", "IntervalTree", "Intersecter"]
 
 class Interval:
     """
-    Basic feature, with required integer start and end properties.
-    Also accepts optional strand as +1 or -1 (used for up/downstream queries),
-    a name, and any arbitrary data is sent in on the info keyword argument
-    (intersection.pyx:274-323).
+    A stored feature: integer ``start``/``end`` plus free-form ``value``, ``chrom`` and ``strand``
+    (``-1`` or ``"-"`` flips the up/downstream queries).  Same constructor, repr and comparison
+    rules as the reference class (intersection.pyx:274-323).
 
     >>> f1 = Interval(23, 36)
     >>> f2 = Interval(34, 48, value={'chr': 12, 'anno': 'transposon'})
@@ -142,13 +141,9 @@ class _Core:
 
 class IntervalNode:
     """
-    A single node of an `IntervalTree` (intersection.pyx:61-268).
-
-    NOTE: Unless you really know what you are doing, you probably should use
-          `IntervalTree` rather than using this directly.
-
-    Here a node is a *view* of a position range of the device index laid out as
-    an implicit balanced search tree; the root view spans everything.
+    Node-level API of the reference (intersection.pyx:61-268), kept for code and tests that drive
+    the tree through its root node.  Here a node is a *view* of a position range of the device
+    index laid out as an implicit balanced search tree; the root view spans everything.
     """
 
     def __init__(self, start, end, interval, _core=None, _span=None, _parent=None):
@@ -205,7 +200,7 @@ class IntervalNode:
         return self if self._span is None else IntervalNode(0, 0, None, self._core)
 
     def intersect(self, start, end, sort=True):
-        """given a start and a end, return a list of features falling within that range"""
+        """Same as IntervalTree.find (the `sort` argument is accepted and ignored, as in the reference)."""
         return self._core.find(_cint(start), _cint(end))
 
     find = intersect
@@ -240,8 +235,8 @@ class _Leaf:
 
 class IntervalTree:
     """
-    Data structure for performing window intersect queries on a set of
-    of possibly overlapping 1d intervals (intersection.pyx:325-485).
+    Window-overlap queries over a set of 1-d half-open intervals; same public methods and
+    results as the reference class (intersection.pyx:325-485), served from the device index.
 
     >>> intersecter = IntervalTree()
     >>> intersecter.insert( 0, 10, "food" )
@@ -260,32 +255,32 @@ class IntervalTree:
 
     # ---- Position based interfaces -----------------------------------------
     def insert(self, start, end, value=None):
-        """Insert the interval [start,end) associated with value `value`."""
+        """Store [start, end) with payload `value` (any int32 pair is accepted, like the reference)."""
         self._c().insert(_cint(start), _cint(end), value)
 
     add = insert
 
     def find(self, start, end):
-        """Return a sorted list of all intervals overlapping [start,end)."""
+        """Payloads of every stored interval with end > start_q and start < end_q, in tree order."""
         if self._core is None:
             return []
         return self._core.find(_cint(start), _cint(end))
 
     def before(self, position, num_intervals=1, max_dist=2500):
-        """Find `num_intervals` intervals that lie before `position` and are no further than `max_dist` positions away"""
+        """Up to `num_intervals` nearest intervals ending before `position`, within `max_dist`."""
         if self._core is None:
             return []
         return self._core.left(position, num_intervals, max_dist)
 
     def after(self, position, num_intervals=1, max_dist=2500):
-        """Find `num_intervals` intervals that lie after `position` and are no further than `max_dist` positions away"""
+        """Up to `num_intervals` nearest intervals starting after `position`, within `max_dist`."""
         if self._core is None:
             return []
         return self._core.right(position, num_intervals, max_dist)
 
     # ---- Interval-like object based interfaces -----------------------------
     def insert_interval(self, interval):
-        """Insert an "interval" like object (one with at least start and end attributes)"""
+        """insert(obj.start, obj.end, obj) for any object with those two attributes."""
         self.insert(interval.start, interval.end, interval)
 
     add_interval = insert_interval
@@ -315,7 +310,7 @@ class IntervalTree:
         return self._core.right(interval.end, num_intervals, max_dist)
 
     def traverse(self, fn):
-        """call fn for each element in the tree"""
+        """fn(node) for every stored interval, in tree order (node has .start/.end/.interval)."""
         if self._core is None:
             return None
         return IntervalNode(0, 0, None, self._core).traverse(fn)
