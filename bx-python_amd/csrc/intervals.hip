@@ -307,7 +307,8 @@ struct SliceBound {
     int32_t eLo, eHi;    // staged slice of the sorted ends    [eLo, eHi)
     int32_t sLo, sHi;    // staged slice of the sorted starts  [sLo, sHi)
     int32_t qeLo, qeHi;  // rank_lt(starts, qe) may use the slice iff qeLo <= qe <= qeHi
-    int32_t kE, kS;      // the slices are staged as perfect search trees of 2^k - 1 keys; kE < 0: does not fit in LDS
+    int32_t kE, kS;      // the slices are staged as perfect search trees of 2^k - 1 keys ...
+    int32_t strideE, strideS;  // ... over every stride-th key (stride 1 = all of them: the tree alone gives the rank)
 };
 
 __device__ __host__ __forceinline__ int pt_skew(int i) { return i + (i >> 5); }
@@ -563,19 +564,22 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
     // is "i = 2i + (tree[i] < key)" -- one LDS read and three VALU ops per level -- the probes of
     // one level fall in one contiguous block (no power-of-two bank pile-up), and after k levels
     // i - 2^k is exactly the number of keys < key.
-    const bool staged = sb.kE >= 0;
-    int32_t *treeE = lds, *treeS = lds + (staged ? (1 << sb.kE) : 0);
-    if (staged) {
+    // A slice too long for LDS (dense region, or a 50M-target index) is staged SAMPLED: the tree holds the last key
+    // of every group of `stride` keys, the descent yields the group, and a 1-3 step search inside that group (global
+    // memory, but the bucket's own few lines) finishes the rank.
+    int32_t *treeE = lds, *treeS = lds + (1 << sb.kE);
+    {
         const int total = (1 << sb.kE) + (1 << sb.kS);
         for (int i = threadIdx.x; i < total; i += PT_THREADS) lds[i] = INT_MAX;
         __syncthreads();
-        for (int r = threadIdx.x; r < nE; r += PT_THREADS) {
-            int tpos = r + 1, z = __ffs(tpos) - 1;  // in-order number and height of the node holding rank r
-            treeE[(tpos >> (z + 1)) + (1 << (sb.kE - 1 - z))] = e_sorted[sb.eLo + r];
+        const int mE = nE / sb.strideE, mS = nS / sb.strideS;  // complete groups
+        for (int r = threadIdx.x; r < mE; r += PT_THREADS) {
+            int tpos = r + 1, z = __ffs(tpos) - 1;  // in-order number and height of the node holding sample r
+            treeE[(tpos >> (z + 1)) + (1 << (sb.kE - 1 - z))] = e_sorted[sb.eLo + (r + 1) * sb.strideE - 1];
         }
-        for (int r = threadIdx.x; r < nS; r += PT_THREADS) {
+        for (int r = threadIdx.x; r < mS; r += PT_THREADS) {
             int tpos = r + 1, z = __ffs(tpos) - 1;
-            treeS[(tpos >> (z + 1)) + (1 << (sb.kS - 1 - z))] = ix.s_ord[sb.sLo + r];
+            treeS[(tpos >> (z + 1)) + (1 << (sb.kS - 1 - z))] = ix.s_ord[sb.sLo + (r + 1) * sb.strideS - 1];
         }
     }
     __syncthreads();
@@ -591,42 +595,42 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
             qe[j] = live[j] ? qe_arr[i] : 0;
             rS[j] = rE[j] = 1;
         }
-        if (staged) {
-            // PT_ILP x 2 independent descents in lockstep (same trees => same depth)
-            for (int it = 0; it < sb.kS; it++) {
+        // PT_ILP x 2 independent descents in lockstep (same trees => same depth)
+        for (int it = 0; it < sb.kS; it++) {
 #pragma unroll
-                for (int j = 0; j < PT_ILP; j++) rS[j] = 2 * rS[j] + (treeS[rS[j]] < qe[j]);  // #{start < qe}
-            }
-            for (int it = 0; it < sb.kE; it++) {
+            for (int j = 0; j < PT_ILP; j++) rS[j] = 2 * rS[j] + (treeS[rS[j]] < qe[j]);  // #{start samples < qe}
+        }
+        for (int it = 0; it < sb.kE; it++) {
 #pragma unroll
-                for (int j = 0; j < PT_ILP; j++) rE[j] = 2 * rE[j] + (treeE[rE[j]] <= qs[j] && qs[j] != INT_MAX);  // #{end <= qs}
-            }
+            for (int j = 0; j < PT_ILP; j++) rE[j] = 2 * rE[j] + (treeE[rE[j]] <= qs[j] && qs[j] != INT_MAX);  // #{end samples <= qs}
+        }
+#pragma unroll
+        for (int j = 0; j < PT_ILP; j++) {
+            rS[j] = (rS[j] - (1 << sb.kS)) * sb.strideS;
+            rE[j] = (rE[j] - (1 << sb.kE)) * sb.strideE;
+        }
+        if (sb.strideS > 1) {
 #pragma unroll
             for (int j = 0; j < PT_ILP; j++) {
-                rS[j] -= 1 << sb.kS;
-                rE[j] -= 1 << sb.kE;
+                int hi = rS[j] + sb.strideS < nS ? rS[j] + sb.strideS : nS;
+                rS[j] = global_rank_lt(ix.s_ord + sb.sLo, rS[j], hi, qe[j]);
+            }
+        }
+        if (sb.strideE > 1) {
+#pragma unroll
+            for (int j = 0; j < PT_ILP; j++) {
+                int hi = rE[j] + sb.strideE < nE ? rE[j] + sb.strideE : nE;
+                rE[j] = qs[j] == INT_MAX ? 0 : global_rank_lt(e_sorted + sb.eLo, rE[j], hi, qs[j] + 1);
             }
         }
 #pragma unroll
         for (int j = 0; j < PT_ILP; j++) {
             if (!live[j]) continue;
             const bool in_slice = qe[j] >= sb.qeLo && qe[j] <= sb.qeHi;
-            int s_rank;
-            if (staged && in_slice)
-                s_rank = sb.sLo + rS[j];
-            else if (in_slice)
-                s_rank = global_rank_lt(ix.s_ord, sb.sLo, sb.sHi, qe[j]);
-            else
-                s_rank = global_rank_lt(ix.s_ord, 0, ix.n, qe[j]);
+            const int s_rank = in_slice ? sb.sLo + rS[j] : global_rank_lt(ix.s_ord, 0, ix.n, qe[j]);
             int c;
             if (qs[j] < qe[j]) {  // regular query (the index has no reversed targets on this path)
-                int e_rank;
-                if (qs[j] == INT_MAX)
-                    e_rank = ix.n;
-                else if (staged)
-                    e_rank = sb.eLo + rE[j];
-                else
-                    e_rank = global_rank_lt(e_sorted, sb.eLo, sb.eHi, qs[j] + 1);
+                const int e_rank = qs[j] == INT_MAX ? ix.n : sb.eLo + rE[j];
                 c = s_rank - e_rank;
             } else {  // zero-length / reversed query: exact predicate over the candidate window
                 int lo = first_pm_gt(ix.pm, ix.n, qs[j]);
@@ -722,28 +726,21 @@ __global__ void part_bounds_kernel(const int32_t *__restrict__ s_ord, const int3
     // ends: keys qs+1 lie in [lo+1, hi]
     sb.eLo = rank_lt64(e_sorted, lo + 1);
     sb.eHi = rank_lt64(e_sorted, hi + 1);
-    // trees: 2^kE slots for the ends, the rest of the LDS budget (a power of two) for the starts
+    // Each slice becomes a perfect tree of at most 2^13 - 1 keys (two trees = 64 KiB of LDS, two workgroups per
+    // CU); a longer slice is sampled with the smallest stride that fits.
     const int nE = sb.eHi - sb.eLo;
-    int kE = 0;
-    while (kE < 20 && (1 << kE) - 1 < nE) kE++;
-    int room = PT_LDS_INTS - (1 << kE);
-    // starts: keys qe of ordinary queries lie in [lo, hi + W/8]; shrink to what the tree can hold
     sb.sLo = rank_lt64(s_ord, lo);
-    long long x = hi + (W >> 3) + 1;
-    int sHi = rank_lt64(s_ord, x);
-    int kS = 0;
-    while ((1 << kS) - 1 < sHi - sb.sLo) kS++;
-    while (kS > 0 && (1 << kS) > room) kS--;
-    if (room < 1) {
-        kE = -1;  // the ends alone overflow LDS: this bucket searches its slices in global memory
-        kS = 0;
-    } else if (sHi - sb.sLo > (1 << kS) - 1) {
-        sHi = sb.sLo + (1 << kS) - 1;
-        x = sHi < n ? (long long)s_ord[sHi] : (long long)INT_MAX + 1;  // every start at index >= sHi is >= x
-    }
+    long long x = hi + (W >> 3) + 1;  // starts: keys qe of ordinary queries lie in [lo, hi + W/8]
+    sb.sHi = rank_lt64(s_ord, x);
+    const int nS = sb.sHi - sb.sLo;
+    constexpr int TREE_KEYS = (1 << 13) - 1;
+    sb.strideE = nE / TREE_KEYS + 1;
+    sb.strideS = nS / TREE_KEYS + 1;
+    int kE = 0, kS = 0;
+    while ((1 << kE) - 1 < nE / sb.strideE) kE++;
+    while ((1 << kS) - 1 < nS / sb.strideS) kS++;
     sb.kE = kE;
     sb.kS = kS;
-    sb.sHi = sHi;
     sb.qeLo = lo < INT_MIN ? INT_MIN : (int32_t)lo;
     sb.qeHi = x > INT_MAX ? INT_MAX : (int32_t)x;
     out[b] = sb;

@@ -149,6 +149,32 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     assert np.array_equal(got_hits, want_hits)
 
 
+def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
+    """250k of 300k targets sit inside one coordinate bucket: its slices exceed LDS and are staged sampled
+    (every stride-th key) with a short finishing search -- counts must still be exact."""
+    rng = np.random.default_rng(77)
+    s = np.concatenate([rng.integers(0, 10_000_000, size=50_000), rng.integers(5_000_000, 5_004_000, size=250_000)])
+    ln = rng.integers(0, 300, size=len(s))
+    s, e = s.astype(np.int32), (s + ln).astype(np.int32)
+    qs = np.concatenate([rng.integers(0, 10_000_000, size=20_000), rng.integers(4_999_000, 5_005_000, size=40_000)])
+    qe = qs + rng.integers(0, 2000, size=len(qs))
+    qe[::97] = qs[::97] - 5            # a few reversed queries
+    qe[::89] += 3_000_000              # and some far longer than a bucket (leave the staged slice)
+    qs, qe = qs.astype(np.int32), qe.astype(np.int32)
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    want, want_total = t.count_batch(qs, qe)
+    ix = make_index(IntervalIndex, s, e)
+    set_opt("ivl.partition", 1)
+    try:
+        got, got_total = ix.count(qs, qe)
+    finally:
+        set_opt("ivl.partition", -1)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got[bad[:5]], want[bad[:5]])
+    assert got_total == want_total
+
+
 def test_long_target_spanning_everything(O, IntervalIndex):
     """One chromosome-long interval inserted first: every later window starts at it."""
     rng = np.random.default_rng(5)
