@@ -7,6 +7,7 @@ Same observable behaviour -- skip rules, first-appearance chromosome order,
 bad line raises -- but the per-line ``set_range`` calls are collected per
 chromosome and issued as ONE ``set_ranges`` kernel launch each.
 """
+import re
 from warnings import warn
 
 import numpy as np
@@ -27,7 +28,8 @@ def _check_range(size, start, count):
     return None
 
 
-def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=5, upstream_pad=0, downstream_pad=0, lens={}):
+def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=5, upstream_pad=0, downstream_pad=0, lens={},
+                             _bed_track_lines=False):
     """
     Read a file into a dictionary of bitsets (same arguments as the reference):
     - 'f' should be a file like object (or any iterable containing strings)
@@ -40,9 +42,18 @@ def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=
     error = None
     size = None
     last_chrom = None
+    offset = 0
     for line in f:
         if line.startswith("#") or line.isspace():  # bitset_builders.py:33-34
             continue
+        if _bed_track_lines:  # bitset_builders.py:77-85: browser lines ignored, track lines may carry offset=N
+            if line.startswith("browser"):
+                continue
+            if line.startswith("track"):
+                m = re.search(r"offset=(\d+)", line)
+                if m and m.group(1):
+                    offset = int(m.group(1))
+                continue
         try:
             fields = line.split()
             chrom = fields[chrom_col]
@@ -54,7 +65,7 @@ def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=
                     sizes[chrom] = size
                     starts[chrom], counts[chrom] = [], []
                 last_chrom = chrom
-            start, end = int(fields[start_col]), int(fields[end_col])
+            start, end = int(fields[start_col]) + offset, int(fields[end_col]) + offset
             if upstream_pad:
                 start = max(0, start - upstream_pad)
             if downstream_pad:
@@ -81,6 +92,30 @@ def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=
     if error is not None:
         raise error
     return bitsets
+
+
+def binned_bitsets_from_bed_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=5, upstream_pad=0, downstream_pad=0, lens={}):
+    """bitset_builders.py:57-104: like binned_bitsets_from_file, but `browser` lines are skipped and
+    `track ... offset=N` lines shift every following interval by N."""
+    return binned_bitsets_from_file(f, chrom_col, start_col, end_col, strand_col, upstream_pad, downstream_pad, lens,
+                                    _bed_track_lines=True)
+
+
+def write_runs(out, chrom, bits, clip=None):
+    """The `start = next_set(end); end = next_clear(start)` walk of the basewise scripts as one
+    device run extraction.  Raises where the reference's loop would (a run reaching `size` makes
+    it call next_set(size), bitset.pyx:180-181).  `clip` = bed_complement.py's chromosome length."""
+    starts, ends = bits.runs()
+    w = out.write
+    for s, e in zip(starts.tolist(), ends.tolist()):
+        if clip is not None and e > clip:
+            e = clip
+        w("%s\t%d\t%d\n" % (chrom, s, e))
+        if clip is not None and e == clip:
+            return
+    if len(ends) and ends[-1] == bits.size:
+        out.flush()
+        raise IndexError("%d is larger than the size of this BitSet (%d)." % (bits.size, bits.size))
 
 
 def binned_bitsets_from_list(rows):

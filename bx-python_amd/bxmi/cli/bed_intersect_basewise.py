@@ -10,7 +10,7 @@ usage: %prog bed_file_1 bed_file_2
 # next_set/next_clear walk becomes one run-extraction pass on the device per chromosome.
 import sys
 
-from bxmi.builders import binned_bitsets_from_file
+from bxmi.builders import binned_bitsets_from_file, write_runs
 
 
 def main(argv=None, out=None):
@@ -27,15 +27,8 @@ def main(argv=None, out=None):
         if key in bits2:
             bits1[key].iand(bits2[key])
             bitsets[key] = bits1[key]
-    w = out.write
     for chrom, bits in bitsets.items():
-        starts, ends = bits.runs()
-        for s, e in zip(starts.tolist(), ends.tolist()):
-            w("%s\t%d\t%d\n" % (chrom, s, e))
-        if len(ends) and ends[-1] == bits.size:
-            # the reference's loop would now call next_set(size) and die (bitset.pyx:180-181)
-            out.flush()
-            raise IndexError("%d is larger than the size of this BitSet (%d)." % (bits.size, bits.size))
+        write_runs(out, chrom, bits)
     out.flush()
 
 

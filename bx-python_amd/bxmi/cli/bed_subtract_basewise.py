@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""
+Find continuous regions that are covered by the first bed file (`bed_file_1`)
+but not by the second bed file (`bed_file_2`)
+
+usage: %prog bed_file_1 bed_file_2
+"""
+# Counterpart of the reference's scripts/bed_subtract_basewise.py:22-43: invert + iand on the device,
+# then one run extraction per chromosome instead of the next_set/next_clear walk.
+import sys
+
+from bxmi.builders import binned_bitsets_from_file, write_runs
+
+
+def main(argv=None, out=None):
+    out = out or sys.stdout
+    args = sys.argv[1:] if argv is None else argv
+    try:
+        in_fname, in2_fname = args
+    except ValueError:
+        raise SystemExit(__doc__.replace("%prog", sys.argv[0]))
+    bitsets1 = binned_bitsets_from_file(open(in_fname))
+    bitsets2 = binned_bitsets_from_file(open(in2_fname))
+    for chrom, bits1 in bitsets1.items():
+        if chrom in bitsets2:
+            bits2 = bitsets2[chrom]
+            bits2.invert()
+            bits1.iand(bits2)
+        write_runs(out, chrom, bits1)
+    out.flush()
+
+
+if __name__ == "__main__":
+    main()

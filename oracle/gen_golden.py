@@ -286,6 +286,36 @@ def gen_cli():
     dump("cli/expected.json", dict(source="reference scripts/*.py run with the reference build", cases=exp, cfg1=cfg1))
 
 
+def gen_cli_siblings():
+    """the sibling scripts that use only the hot-path API."""
+    d = os.path.join(GOLD, "cli")
+    small_a, small_b = os.path.join(d, "small_a.bed"), os.path.join(d, "small_b.bed")
+    med_a, med_b = os.path.join(d, "med_a.bed"), os.path.join(d, "med_b.bed")
+    lens = os.path.join(d, "chrom.len")
+    open(lens, "w").write("chr1\t1000\nchr2\t400\nchr5\t77\nchrX\t100500\nchr3\t500\n")
+    track = os.path.join(d, "track_offset.bed")
+    open(track, "w").write("browser position chr1:1-100\ntrack name=x offset=100\nchr1\t10\t20\nchr1\t15\t30\n# c\n"
+                           "track name=y offset=1000\nchr2\t0\t5\nchr1\t5\t9\nchr2\t3\t8\n")
+    plain = os.path.join(d, "plain_a.bed")  # no comment/blank lines: some siblings do not skip them
+    open(plain, "w").writelines([l for l in open(small_a) if not l.startswith("#") and l.strip()])
+    exp = {}
+    for tag, (fa, fb) in dict(small=(small_a, small_b), med=(med_a, med_b)).items():
+        exp["bed_subtract_basewise %s" % tag] = run_script("bed_subtract_basewise.py", [fa, fb])
+        exp["bed_subtract_basewise %s rev" % tag] = run_script("bed_subtract_basewise.py", [fb, fa])
+        exp["bed_complement %s" % tag] = run_script("bed_complement.py", [fa, lens])
+        exp["bed_merge_overlapping %s" % tag] = run_script("bed_merge_overlapping.py", [fa, fb])
+        exp["bed_diff_basewise_summary %s" % tag] = run_script("bed_diff_basewise_summary.py", [fa, fb])
+    exp["bed_merge_overlapping track"] = run_script("bed_merge_overlapping.py", [track])
+    exp["bed_merge_overlapping stdin"] = run_script("bed_merge_overlapping.py", [], stdin=open(small_b).read())
+    for tag, fa, fb in (("small", plain, small_b), ("med", med_a, med_b)):
+        exp["bed_coverage_by_interval %s" % tag] = run_script("bed_coverage_by_interval.py", [fa, fb])
+        exp["bed_coverage_by_interval %s mask" % tag] = run_script("bed_coverage_by_interval.py", [fa, fb, fa if tag == "med" else small_b])
+        exp["bed_count_overlapping %s" % tag] = run_script("bed_count_overlapping.py", [fa, fb])
+        exp["bed_count_by_interval %s" % tag] = run_script("bed_count_by_interval.py", [fa, fb])
+        exp["interval_count_intersections %s" % tag] = run_script("interval_count_intersections.py", [fb, fa])
+    dump("cli/expected_siblings.json", dict(source="reference scripts/*.py run with the reference build", cases=exp))
+
+
 # --------------------------------------------------------------------------- #
 # 4. Scale points of cfg 2 through the real treap (hashes only)
 # --------------------------------------------------------------------------- #
@@ -329,5 +359,8 @@ if __name__ == "__main__":
         gen_bitsets()
     if "cli" in todo:
         gen_cli()
+        gen_cli_siblings()
+    if "siblings" in todo:
+        gen_cli_siblings()
     if "scale" in todo:
         gen_scale(a.scale)

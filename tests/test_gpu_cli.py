@@ -88,6 +88,48 @@ def test_cfg1_10k_x_10k(golden_cli, tmp_path):
         assert hashlib.sha256(got["stdout"].encode()).hexdigest() == want["sha256"], key
 
 
+# ---- sibling scripts that use only the hot-path API ----------------------
+@pytest.fixture(scope="module")
+def golden_siblings():
+    from conftest import load_golden
+
+    return load_golden("cli/expected_siblings.json")["cases"]
+
+
+def check_sibling(golden_siblings, key, module, args, stdin=None):
+    want = dict(golden_siblings[key])
+    # the goldens were captured with files under /root/repo/tests/golden/cli; two scripts echo the file names
+    want["stdout"] = want["stdout"].replace("/root/repo/tests/golden/cli", CLI)
+    check(run_cli(module, args, stdin=stdin), want, key)
+
+
+@pytest.mark.parametrize("tag", ["small", "med"])
+def test_sibling_bitset_scripts(golden_siblings, tag):
+    fa, fb = files(tag)
+    lens = os.path.join(CLI, "chrom.len")
+    check_sibling(golden_siblings, "bed_subtract_basewise %s" % tag, "bed_subtract_basewise", [fa, fb])
+    check_sibling(golden_siblings, "bed_subtract_basewise %s rev" % tag, "bed_subtract_basewise", [fb, fa])
+    check_sibling(golden_siblings, "bed_complement %s" % tag, "bed_complement", [fa, lens])
+    check_sibling(golden_siblings, "bed_merge_overlapping %s" % tag, "bed_merge_overlapping", [fa, fb])
+    check_sibling(golden_siblings, "bed_diff_basewise_summary %s" % tag, "bed_diff_basewise_summary", [fa, fb])
+
+
+def test_sibling_merge_track_offsets_and_stdin(golden_siblings):
+    check_sibling(golden_siblings, "bed_merge_overlapping track", "bed_merge_overlapping", [os.path.join(CLI, "track_offset.bed")])
+    check_sibling(golden_siblings, "bed_merge_overlapping stdin", "bed_merge_overlapping", [], stdin=open(os.path.join(CLI, "small_b.bed")).read())
+
+
+@pytest.mark.parametrize("tag", ["small", "med"])
+def test_sibling_interval_scripts(golden_siblings, tag):
+    fa, fb = (os.path.join(CLI, "plain_a.bed"), os.path.join(CLI, "small_b.bed")) if tag == "small" else files("med")
+    check_sibling(golden_siblings, "bed_coverage_by_interval %s" % tag, "bed_coverage_by_interval", [fa, fb])
+    check_sibling(golden_siblings, "bed_coverage_by_interval %s mask" % tag, "bed_coverage_by_interval",
+                  [fa, fb, fa if tag == "med" else os.path.join(CLI, "small_b.bed")])
+    check_sibling(golden_siblings, "bed_count_overlapping %s" % tag, "bed_count_overlapping", [fa, fb])
+    check_sibling(golden_siblings, "bed_count_by_interval %s" % tag, "bed_count_by_interval", [fa, fb])
+    check_sibling(golden_siblings, "interval_count_intersections %s" % tag, "interval_count_intersections", [fb, fa])
+
+
 # ---- the per-call drop-in API, used the way the unmodified scripts use it -----------------
 def per_line_bitsets(path):
     """One BinnedBitSet per chromosome, one set_range call per BED line (file order)."""
