@@ -284,7 +284,7 @@ __global__ __launch_bounds__(CNT_THREADS) void ivl_count_kernel(TreeDev S, TreeD
 //   3. counts come back in bucket order and are gathered into query order.
 // Everything stays exact: slices are chosen so that ranks outside them are
 // known, and anything that falls outside (very long / reversed queries) takes
-// a per-lane global search.
+// a per-lane global search.  rocprofv3 numbers for each step: DESIGN.md 3.1.
 constexpr int PT_NB_LOG2 = 11;
 constexpr int PT_NB = 1 << PT_NB_LOG2;      // coordinate buckets
 constexpr int PT_THREADS = 1024;
@@ -310,8 +310,6 @@ struct SliceBound {
     int32_t kE, kS;      // the slices are staged as perfect search trees of 2^k - 1 keys ...
     int32_t strideE, strideS;  // ... over every stride-th key (stride 1 = all of them: the tree alone gives the rank)
 };
-
-__device__ __host__ __forceinline__ int pt_skew(int i) { return i + (i >> 5); }
 
 __device__ __forceinline__ int part_bucket(int qs, PartGeom g)
 {
@@ -501,18 +499,6 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
             qe_out[d] = v.y;
         }
     }
-}
-
-// #{a[i] < key} over a[0..n) held in LDS with a[n] == INT_MAX as a stop; `top` = highest power of two <= n+1.
-__device__ __forceinline__ int lds_rank_lt(const int32_t *a, int n, int top, int key)
-{
-    int pos = 0;
-    for (int s = top; s > 0; s >>= 1) {
-        int p = pos + s;
-        int v = a[(p < n + 1 ? p : n + 1) - 1];
-        pos = v < key ? p : pos;
-    }
-    return pos;
 }
 
 __device__ __forceinline__ int global_rank_lt(const int32_t *__restrict__ a, int lo, int hi, int key)
