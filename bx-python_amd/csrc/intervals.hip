@@ -31,6 +31,8 @@ constexpr int FAN = 32;            // keys per node (128 B)
 constexpr int LDS_TREE_INTS = 18688;  // per tree: 73 KiB, two trees + scratch < 160 KiB
 constexpr int CNT_THREADS = 1024;  // one workgroup per CU, 16 waves
 constexpr int CNT_Q = 4;           // queries in flight per 8-lane group
+constexpr int FIND_THREADS = 512;
+constexpr int FIND_Q = 2;
 
 struct TreeDev {
     const int32_t *lev[MAXLEV];  // lev[0] = leaves (the sorted array, padded with INT_MAX)
@@ -309,6 +311,7 @@ struct SliceBound {
     int32_t qeLo, qeHi;  // rank_lt(starts, qe) may use the slice iff qeLo <= qe <= qeHi
     int32_t kE, kS;      // the slices are staged as perfect search trees of 2^k - 1 keys ...
     int32_t strideE, strideS;  // ... over every stride-th key (stride 1 = all of them: the tree alone gives the rank)
+    int32_t pLo, pHi, kP, strideP;  // same for the prefix-max array (window start of find): ranks of pm <= qs
 };
 
 __device__ __forceinline__ int part_bucket(int qs, PartGeom g)
@@ -680,6 +683,237 @@ __global__ __launch_bounds__(PT_THREADS) void part_gather_kernel(const int32_t *
     for (int k = threadIdx.x; k < n; k += PT_THREADS) out[base + k] = vals[lpos[base + k]];
 }
 
+
+// ---- partitioned find: window + count per query in bucket order, offsets carried to bucket order ----
+// Which bucket / which queries does this search workgroup own?  (shared prologue of the count and window kernels)
+__device__ __forceinline__ bool part_chunk_of_block(const int32_t *__restrict__ wg_first, const unsigned *__restrict__ table,
+                                                    int64_t nq, int *s_bucket, int &b, int64_t &q_begin, int64_t &q_end)
+{
+    if (threadIdx.x == 0) *s_bucket = -1;
+    __syncthreads();
+    const int w = (int)blockIdx.x;
+#pragma unroll
+    for (int u = 0; u < PT_NB / PT_THREADS; u++) {
+        int c = u * PT_THREADS + threadIdx.x;
+        if (wg_first[c] <= w && w < wg_first[c + 1]) *s_bucket = c;
+    }
+    __syncthreads();
+    b = *s_bucket;
+    if (b < 0) return false;
+    const int64_t q_lo = table[b];
+    const int64_t q_hi = b + 1 < PT_NB ? (int64_t)table[b + 1] : nq;
+    q_begin = q_lo + (int64_t)(w - wg_first[b]) * PT_CHUNK;
+    q_end = q_begin + PT_CHUNK < q_hi ? q_begin + PT_CHUNK : q_hi;
+    return true;
+}
+
+// Stage `m = n / stride` samples of a sorted slice as a perfect Eytzinger tree of 2^k slots (slot 0 unused).
+__device__ __forceinline__ void part_stage_tree(int32_t *tree, int k, const int32_t *__restrict__ src, int n, int stride)
+{
+    const int m = n / stride;
+    for (int r = threadIdx.x; r < m; r += PT_THREADS) {
+        int tpos = r + 1, z = __ffs(tpos) - 1;  // in-order number and height of the node holding sample r
+        tree[(tpos >> (z + 1)) + (1 << (k - 1 - z))] = src[(r + 1) * stride - 1];
+    }
+}
+
+// For every bucketed query: hi = #{start < qe}, lo = #{prefix-max <= qs} and the number of hits in the window
+// [lo, hi) of the tree-ordered arrays.  Ranks come from LDS trees one lane per query; the window is then scanned
+// by 8 lanes per query with 16-byte loads (a per-lane serial scan would issue 8 scattered requests per query).
+__global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, const SliceBound *__restrict__ bounds,
+                                                                 const int32_t *__restrict__ wg_first,
+                                                                 const unsigned *__restrict__ table,
+                                                                 const int32_t *__restrict__ qs_arr,
+                                                                 const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                                 int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
+                                                                 int32_t *__restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ int s_bucket;
+    int b;
+    int64_t q_begin, q_end;
+    if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end)) return;
+    const SliceBound sb = bounds[b];
+    const int nS = sb.sHi - sb.sLo, nP = sb.pHi - sb.pLo;
+    int32_t *treeP = lds, *treeS = lds + (1 << sb.kP);
+    {
+        const int total = (1 << sb.kP) + (1 << sb.kS);
+        for (int i = threadIdx.x; i < total; i += PT_THREADS) lds[i] = INT_MAX;
+        __syncthreads();
+        part_stage_tree(treeP, sb.kP, ix.pm + sb.pLo, nP, sb.strideP);
+        part_stage_tree(treeS, sb.kS, ix.s_ord + sb.sLo, nS, sb.strideS);
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7, gbase = lane_id() & ~7;
+    for (int64_t i0 = q_begin + threadIdx.x; i0 - threadIdx.x < q_end; i0 += PT_THREADS) {
+        const bool live = i0 < q_end;
+        const int qs = live ? qs_arr[i0] : 0, qe = live ? qe_arr[i0] : 0;
+        int rS = 1, rP = 1;
+        for (int it = 0; it < sb.kS; it++) rS = 2 * rS + (treeS[rS] < qe);
+        for (int it = 0; it < sb.kP; it++) rP = 2 * rP + (treeP[rP] <= qs && qs != INT_MAX);
+        rS = (rS - (1 << sb.kS)) * sb.strideS;
+        rP = (rP - (1 << sb.kP)) * sb.strideP;
+        if (sb.strideS > 1) rS = global_rank_lt(ix.s_ord + sb.sLo, rS, rS + sb.strideS < nS ? rS + sb.strideS : nS, qe);
+        if (sb.strideP > 1 && qs != INT_MAX)
+            rP = global_rank_lt(ix.pm + sb.pLo, rP, rP + sb.strideP < nP ? rP + sb.strideP : nP, qs + 1);
+        const bool in_slice = qe >= sb.qeLo && qe <= sb.qeHi;
+        int hi = in_slice ? sb.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe);
+        int lo = qs == INT_MAX ? ix.n : sb.pLo + rP;
+        if (!live) lo = hi = 0;
+        // cooperative window scan: the 8 lanes of a group take their 8 queries one after the other; the first
+        // 32-candidate step of all 8 windows is loaded up front (one dependent round trip instead of eight)
+        int wl[8], wh[8], wk[8];
+        int4 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            wl[r] = __shfl(lo, gbase + r, 64);
+            wh[r] = __shfl(hi, gbase + r, 64);
+            wk[r] = __shfl(qs, gbase + r, 64);
+            v[r] = wl[r] < wh[r] ? *reinterpret_cast<const int4 *>(ix.e_ord + (wl[r] & ~(FAN - 1)) + sub * 4) : make_int4(0, 0, 0, 0);
+        }
+        int mine = 0;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            int c = 0;
+            if (wl[r] < wh[r]) {
+                const int k0 = wl[r] & ~(FAN - 1), kb = k0 + sub * 4;
+                c += (kb + 0 >= wl[r] && kb + 0 < wh[r] && v[r].x > wk[r]);
+                c += (kb + 1 >= wl[r] && kb + 1 < wh[r] && v[r].y > wk[r]);
+                c += (kb + 2 >= wl[r] && kb + 2 < wh[r] && v[r].z > wk[r]);
+                c += (kb + 3 >= wl[r] && kb + 3 < wh[r] && v[r].w > wk[r]);
+                c = group8_sum_dpp(c);
+                if (k0 + FAN < wh[r]) c += window_count<true>(ix.e_ord, k0 + FAN, wh[r], wk[r], sub);  // long window: the rest
+            }
+            if (sub == r) mine = c;
+        }
+        if (live) {
+            win_lo[i0] = lo;
+            win_hi[i0] = hi;
+            counts[i0] = mine;
+        }
+    }
+}
+
+// Values in query order -> bucket order (the inverse of part_gather_kernel): a workgroup drops its tile's
+// values into LDS at the slots the scatter recorded, then streams the tile's runs out, one per bucket.
+__global__ __launch_bounds__(PT_THREADS) void part_permute_i64_kernel(const long long *__restrict__ values,
+                                                                      const unsigned short *__restrict__ lpos,
+                                                                      const unsigned *__restrict__ tile_table, int64_t ntiles,
+                                                                      int64_t nq, long long *__restrict__ bucketed)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    long long *vals = reinterpret_cast<long long *>(dyn);                           // [PT_TILE]
+    unsigned short *toff = reinterpret_cast<unsigned short *>(vals + PT_TILE);      // [PT_NB + 2]
+    unsigned *gbase = reinterpret_cast<unsigned *>(toff + PT_NB + 2);               // [PT_NB]
+    __shared__ unsigned scan_tmp[16];
+    const int64_t tile = part_tile_of_block(ntiles);
+    if (tile >= ntiles) return;
+    const int64_t base = tile * PT_TILE;
+    const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
+    {
+        const bool last_tile = tile + 1 == ntiles;
+        const unsigned *row = tile_table + tile * PT_NB;
+        const unsigned *next = last_tile ? tile_table : row + PT_NB;
+        unsigned c[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            int b = 2 * threadIdx.x + u;
+            unsigned lo = row[b];
+            unsigned hi = !last_tile ? next[b] : (b + 1 < PT_NB ? next[b + 1] : (unsigned)nq);
+            gbase[b] = lo;
+            c[u] = hi - lo;
+        }
+        unsigned tot;
+        unsigned exc = block_exclusive_scan(c[0] + c[1], OpSum(), 0u, scan_tmp, &tot);
+        toff[2 * threadIdx.x] = (unsigned short)exc;
+        toff[2 * threadIdx.x + 1] = (unsigned short)(exc + c[0]);
+    }
+    for (int k = threadIdx.x; k < n; k += PT_THREADS) vals[lpos[base + k]] = values[base + k];
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    for (int b = threadIdx.x >> 3; b < PT_NB; b += PT_THREADS / 8) {
+        unsigned o = toff[b], len = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o, gb = gbase[b];
+        for (unsigned r = sub; r < len; r += 8) bucketed[gb + r] = vals[o + r];
+    }
+}
+
+// One 32-candidate step of a window: compact the hits of this step behind `base` (CSR order = tree order).
+__device__ __forceinline__ int fill_step(int4 v, int4 id, int kb, int lo, int hi, int qs, int64_t base, int32_t *__restrict__ hits,
+                                         int gshift, unsigned below)
+{
+    bool f0 = kb + 0 >= lo && kb + 0 < hi && v.x > qs;
+    bool f1 = kb + 1 >= lo && kb + 1 < hi && v.y > qs;
+    bool f2 = kb + 2 >= lo && kb + 2 < hi && v.z > qs;
+    bool f3 = kb + 3 >= lo && kb + 3 < hi && v.w > qs;
+    unsigned b0 = (unsigned)(__ballot(f0) >> gshift) & 0xffu;
+    unsigned b1 = (unsigned)(__ballot(f1) >> gshift) & 0xffu;
+    unsigned b2 = (unsigned)(__ballot(f2) >> gshift) & 0xffu;
+    unsigned b3 = (unsigned)(__ballot(f3) >> gshift) & 0xffu;
+    if (f0 | f1 | f2 | f3) {
+        int64_t pos = base + __popc(b0 & below) + __popc(b1 & below) + __popc(b2 & below) + __popc(b3 & below);
+        if (f0) hits[pos++] = id.x;
+        if (f1) hits[pos++] = id.y;
+        if (f2) hits[pos++] = id.z;
+        if (f3) hits[pos++] = id.w;
+    }
+    return __popc(b0) + __popc(b1) + __popc(b2) + __popc(b3);
+}
+
+// Fill pass in bucket order: the window reads stay inside the bucket's lines (L2) instead of touching two random
+// lines per query, and each 8-lane group keeps FILL_Q queries in flight (metadata and the first step of every
+// window are loaded before any of them is compacted: the chain load-meta -> load-window -> store is latency bound).
+constexpr int FILL_Q = 4;
+__global__ __launch_bounds__(FIND_THREADS) void part_fill_kernel(IndexDev ix, const int32_t *__restrict__ qs_arr, int64_t nq,
+                                                                const int32_t *__restrict__ win_lo,
+                                                                const int32_t *__restrict__ win_hi,
+                                                                const int32_t *__restrict__ cnt,
+                                                                const long long *__restrict__ boffs,
+                                                                int32_t *__restrict__ hits)
+{
+    const int lane = lane_id();
+    const int sub = lane & 7, gshift = lane & ~7;
+    const unsigned below = (1u << sub) - 1u;
+    // contiguous block of queries per workgroup, XCD-aware: neighbours in bucket order share lines
+    const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
+    const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
+    for (int64_t qb = q0 + (int64_t)(threadIdx.x >> 3) * FILL_Q; qb < q1; qb += (FIND_THREADS / 8) * FILL_Q) {
+        int lo[FILL_Q], hi[FILL_Q], qs[FILL_Q];
+        int64_t base[FILL_Q];
+#pragma unroll
+        for (int j = 0; j < FILL_Q; j++) {
+            const int64_t q = qb + j;
+            const bool live = q < q1 && cnt[q] != 0;
+            lo[j] = live ? win_lo[q] : 0;
+            hi[j] = live ? win_hi[q] : 0;
+            qs[j] = live ? qs_arr[q] : 0;
+            base[j] = live ? boffs[q] : 0;
+        }
+        int4 ve[FILL_Q], vi[FILL_Q];
+#pragma unroll
+        for (int j = 0; j < FILL_Q; j++) {
+            const int kb = (lo[j] & ~(FAN - 1)) + sub * 4;
+            if (lo[j] < hi[j]) {
+                ve[j] = *reinterpret_cast<const int4 *>(ix.e_ord + kb);
+                vi[j] = *reinterpret_cast<const int4 *>(ix.idx + kb);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FILL_Q; j++) {
+            if (lo[j] >= hi[j]) continue;
+            int k0 = lo[j] & ~(FAN - 1);
+            base[j] += fill_step(ve[j], vi[j], k0 + sub * 4, lo[j], hi[j], qs[j], base[j], hits, gshift, below);
+            for (k0 += FAN; k0 < hi[j]; k0 += FAN) {
+                const int kb = k0 + sub * 4;
+                int4 v = *reinterpret_cast<const int4 *>(ix.e_ord + kb);
+                int4 id = *reinterpret_cast<const int4 *>(ix.idx + kb);
+                base[j] += fill_step(v, id, kb, lo[j], hi[j], qs[j], base[j], hits, gshift, below);
+            }
+        }
+    }
+}
+
 __global__ void part_fold_total_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
 {
     unsigned long long v = threadIdx.x < PT_SLOTS ? slots[threadIdx.x] : 0ull;
@@ -689,8 +923,8 @@ __global__ void part_fold_total_kernel(unsigned long long *__restrict__ slots, u
 }
 
 // Slice bounds of every bucket; depends only on the sealed index, so it is built once at seal().
-__global__ void part_bounds_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted, int n, PartGeom g,
-                                   SliceBound *__restrict__ out)
+__global__ void part_bounds_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted,
+                                   const int32_t *__restrict__ pm, int n, PartGeom g, SliceBound *__restrict__ out)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= PT_NB) return;
@@ -727,6 +961,14 @@ __global__ void part_bounds_kernel(const int32_t *__restrict__ s_ord, const int3
     while ((1 << kS) - 1 < nS / sb.strideS) kS++;
     sb.kE = kE;
     sb.kS = kS;
+    // prefix max of ends in tree order (monotone): #{pm <= qs} for qs in [lo, hi) lies in [#{pm < lo}, #{pm < hi}]
+    sb.pLo = rank_lt64(pm, lo);
+    sb.pHi = rank_lt64(pm, hi);
+    const int nP = sb.pHi - sb.pLo;
+    sb.strideP = nP / TREE_KEYS + 1;
+    int kP = 0;
+    while ((1 << kP) - 1 < nP / sb.strideP) kP++;
+    sb.kP = kP;
     sb.qeLo = lo < INT_MIN ? INT_MIN : (int32_t)lo;
     sb.qeHi = x > INT_MAX ? INT_MAX : (int32_t)x;
     out[b] = sb;
@@ -735,8 +977,6 @@ __global__ void part_bounds_kernel(const int32_t *__restrict__ s_ord, const int3
 // ---------------------------------------------------------------------------
 // find kernels: window + count, then ballot-compacted fill
 // ---------------------------------------------------------------------------
-constexpr int FIND_THREADS = 512;
-constexpr int FIND_Q = 2;
 
 template <bool DPP>
 __global__ __launch_bounds__(FIND_THREADS) void ivl_find_count_kernel(TreeDev S, TreeDev P, IndexDev ix,
@@ -972,7 +1212,7 @@ struct bxmi_ivl {
     DevBuf q_s, q_e, q_cnt, q_lo, q_hi, q_off, q_hits, q_total;
     // partitioned count path
     PartGeom geom{0, 0};
-    DevBuf slice_bounds, p_hist, p_table, p_qs, p_qe, p_dest, p_cnt, p_plan, p_slots;
+    DevBuf slice_bounds, p_hist, p_table, p_qs, p_qe, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
     hipStream_t sub_stream[PT_MAX_SUB] = {};
     hipEvent_t ev_fork = nullptr, ev_join[PT_MAX_SUB] = {};
     hipStream_t stream = nullptr;
@@ -1068,6 +1308,68 @@ static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *
         BXMI_HIP(hipEventRecord(h->ev_join[s], h->sub_stream[s]));
         BXMI_HIP(hipStreamWaitEvent(st, h->ev_join[s], 0));  // join: the caller's stream continues after every sub-batch
     }
+    return BXMI_OK;
+}
+
+
+// Partitioned find(): same bucketing as the count path, then window+count per query in bucket order, counts gathered
+// back for the CSR offsets, offsets carried to bucket order, hits written from bucket order.
+static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits,
+                                int64_t cap, int64_t *total_host, hipStream_t st)
+{
+    if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_find: more than 2^31 queries in one batch");
+    const int64_t ntiles = div_up(nq, PT_TILE);
+    const unsigned tgrid = (unsigned)(((ntiles + 7) >> 3) << 3);
+    const int rows_per_block = (int)div_up(ntiles, 64);
+    const int nrb = (int)div_up(ntiles, rows_per_block);
+    BXMI_TRY(h->p_qs.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_qe.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
+    BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_lo.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_hi.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_boffs.reserve((size_t)(nq + 4) * 8));
+    BXMI_TRY(h->p_plan.reserve((size_t)PT_MAX_SUB * (PT_NB + 8) * sizeof(int32_t)));
+    BXMI_TRY(h->p_table.reserve((size_t)(ntiles + PT_MAX_SUB) * PT_NB * sizeof(unsigned)));
+    BXMI_TRY(h->p_hist.reserve((size_t)PT_MAX_SUB * 80 * PT_NB * sizeof(unsigned)));
+    unsigned *table = h->p_table.as<unsigned>(), *partial = h->p_hist.as<unsigned>();
+    int32_t *plan = h->p_plan.as<int32_t>();
+    int32_t *bqs = h->p_qs.as<int32_t>(), *bqe = h->p_qe.as<int32_t>();
+    unsigned short *lpos = h->p_dest.as<unsigned short>();
+    hipLaunchKernelGGL(part_hist_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, qs, nq, h->geom, table, ntiles);
+    hipLaunchKernelGGL(part_colsum_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
+    hipLaunchKernelGGL(part_colbase_kernel, dim3(1), dim3(PT_THREADS), 0, st, partial, nrb, nq, plan);
+    hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
+    BXMI_LAUNCH_CHECK();
+    const size_t scat_lds = (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned);
+    BXMI_TRY(allow_big_lds(part_scatter_kernel, scat_lds));
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, table, ntiles, bqs, bqe, lpos);
+    BXMI_LAUNCH_CHECK();
+    const size_t lds_bytes = (size_t)PT_LDS_INTS * 4;
+    BXMI_TRY(allow_big_lds(part_window_kernel, lds_bytes));
+    const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
+    hipLaunchKernelGGL(part_window_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->slice_bounds.as<SliceBound>(), plan,
+                       table, bqs, bqe, nq, h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->p_cnt.as<int32_t>());
+    hipLaunchKernelGGL(part_gather_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>(), lpos, table, ntiles, nq,
+                       h->q_cnt.as<int32_t>());
+    BXMI_LAUNCH_CHECK();
+    BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
+                                                           reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
+    int64_t total = 0;
+    BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    if (total_host) *total_host = total;
+    if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
+    if (total == 0) return BXMI_OK;
+    const size_t perm_lds = (size_t)PT_TILE * 8 + (PT_NB + 2) * 2 + PT_NB * 4 + 64;
+    BXMI_TRY(allow_big_lds(part_permute_i64_kernel, perm_lds));
+    hipLaunchKernelGGL(part_permute_i64_kernel, dim3(tgrid), dim3(PT_THREADS), perm_lds, st, reinterpret_cast<const long long *>(offsets), lpos,
+                       table, ntiles, nq, h->p_boffs.as<long long>());
+    int fgrid = device_props().cus * 8;
+    hipLaunchKernelGGL(part_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), bqs, nq, h->p_lo.as<int32_t>(),
+                       h->p_hi.as<int32_t>(), h->p_cnt.as<int32_t>(), h->p_boffs.as<long long>(), hits);
+    BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
@@ -1218,8 +1520,8 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         h->geom.cmin = cmin;
         h->geom.shift = shift;
         BXMI_TRY(h->slice_bounds.reserve(PT_NB * sizeof(SliceBound)));
-        hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)n,
-                           h->geom, h->slice_bounds.as<SliceBound>());
+        hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
+                           h->pm.as<int32_t>(), (int)n, h->geom, h->slice_bounds.as<SliceBound>());
         BXMI_LAUNCH_CHECK();
         BXMI_HIP(hipStreamSynchronize(st));
     }
@@ -1364,6 +1666,8 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
         if (total_host) *total_host = 0;
         return BXMI_OK;
     }
+    if (!h->has_reversed && h->n > 0 && (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_partition_min && h->n >= 4096)))
+        return ivl_find_partitioned(h, qs, qe, nq, offsets, hits, cap, total_host, st);
     BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_lo.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_hi.reserve((size_t)(nq + 4) * 4));

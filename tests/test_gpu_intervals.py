@@ -63,9 +63,12 @@ def test_count_and_find_match_reference_vectors(golden_trees, IntervalIndex, gro
             set_opt("ivl.partition", 1)
             try:
                 counts, total = ix.count(q[:, 0], q[:, 1])
+                p_offs, p_hits = ix.find(q[:, 0], q[:, 1])
             finally:
                 set_opt("ivl.partition", -1)
             assert counts.tolist() == want and total == sum(want), ("partitioned", case["mode"], case["n"])
+            assert p_hits.tolist() == [x for h in case["hits"] for x in h], ("partitioned find", case["mode"], case["n"])
+            assert p_offs.tolist() == np.concatenate([[0], np.cumsum(want)]).tolist()
             offs, hits = ix.find(q[:, 0], q[:, 1])
             assert offs.tolist() == np.concatenate([[0], np.cumsum(want)]).tolist()
             assert hits.tolist() == [x for h in case["hits"] for x in h], (case["mode"], case["n"])
@@ -138,8 +141,13 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     try:
         got_c, got_t = ix.count(qs, qe)
         tot_only = ix.count(qs, qe, want_counts=False)[1]
+        if not ix.has_reversed:
+            p_off, p_hits = ix.find(qs, qe)
     finally:
         set_opt("ivl.partition", -1)
+    if not ix.has_reversed:
+        w_off, w_hits = t.find_batch(qs, qe)
+        assert np.array_equal(p_off, w_off) and np.array_equal(p_hits, w_hits), "partitioned find"
     bad = np.nonzero(got_c != want_c)[0]
     assert len(bad) == 0, ("partitioned", bad[:5], qs[bad[:5]], qe[bad[:5]], got_c[bad[:5]], want_c[bad[:5]])
     assert got_t == want_t == tot_only
@@ -168,11 +176,14 @@ def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
     set_opt("ivl.partition", 1)
     try:
         got, got_total = ix.count(qs, qe)
+        p_off, p_hits = ix.find(qs[:20000], qe[:20000])
     finally:
         set_opt("ivl.partition", -1)
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got[bad[:5]], want[bad[:5]])
     assert got_total == want_total
+    w_off, w_hits = t.find_batch(qs[:20000], qe[:20000])
+    assert np.array_equal(p_off, w_off) and np.array_equal(p_hits, w_hits)
 
 
 def test_long_target_spanning_everything(O, IntervalIndex):
@@ -289,7 +300,16 @@ def test_find_join_scale_properties(IntervalIndex):
     hits of a query in tree order, and agreement with the count path."""
     (ts, te), (qs, qe) = synth.cfg5(4_000_000, 4_000_000)
     ix = make_index(IntervalIndex, ts, te)
-    offs, hits = ix.find(qs, qe, cap_hint=8 * len(qs))
+    set_opt("ivl.partition", 0)
+    try:
+        d_offs, d_hits = ix.find(qs, qe, cap_hint=8 * len(qs))  # direct tree kernels
+    finally:
+        set_opt("ivl.partition", 1)
+    try:
+        offs, hits = ix.find(qs, qe, cap_hint=8 * len(qs))      # bucketed path
+    finally:
+        set_opt("ivl.partition", -1)
+    assert np.array_equal(d_offs, offs) and np.array_equal(d_hits, hits)
     counts, total = ix.count(qs, qe)
     assert offs[-1] == total == len(hits) and np.array_equal(np.diff(offs).astype(np.int32), counts)
     rep = np.repeat(np.arange(len(qs)), counts)
