@@ -107,9 +107,8 @@ class _Core:
 
     def find(self, start, end):
         self._flush()
-        _, hits = self.index.find(np.array([start], dtype=np.int32), np.array([end], dtype=np.int32), cap_hint=4096)
         vals = self.values
-        return [vals[i] for i in hits.tolist()]
+        return [vals[i] for i in self.index.find_one(start, end).tolist()]
 
     def order(self):
         if self._order is None:

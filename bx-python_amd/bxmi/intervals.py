@@ -28,6 +28,7 @@ class IntervalIndex:
         self._h = h
         self._n = 0
         self._sealed = False
+        self._one_buf = np.empty(4096, dtype=np.int32)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -112,6 +113,17 @@ class IntervalIndex:
                 return offsets, hits[: total.value]
             cap = total.value
         raise _ffi.BxmiError(_ffi.ERANGE, "find: hit buffer still too small")
+
+    def find_one(self, qs, qe):
+        """find() for one query -> int32 array of insertion indices (one launch + one sync)."""
+        self._ready()
+        n = C.c_int64(0)
+        buf = self._one_buf
+        rc = call("bxmi_ivl_find_one", self._h, int(qs), int(qe), ptr(buf), len(buf), C.byref(n), allow=(_ffi.ERANGE,))
+        if rc == _ffi.ERANGE:
+            buf = self._one_buf = np.empty(int(n.value) * 2, dtype=np.int32)
+            call("bxmi_ivl_find_one", self._h, int(qs), int(qe), ptr(buf), len(buf), C.byref(n))
+        return buf[: n.value]
 
     def count_dev(self, qs_ptr, qe_ptr, nq, counts_ptr, total_ptr, stream=None):
         """Device-pointer form used by bench.py / the sharded driver (no host sync)."""

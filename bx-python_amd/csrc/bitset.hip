@@ -135,6 +135,34 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_count_ranges_kernel(const u
     }
 }
 
+
+// One (short) range, one launch: the latency path behind the per-call count_range() of the drop-in class.
+// Arguments travel as kernel arguments and the answer lands in host-visible memory: launch + one stream sync.
+__global__ __launch_bounds__(BITS_THREADS) void bits_count_one_kernel(const unsigned long long *__restrict__ words,
+                                                                     const uint8_t *__restrict__ tags, int bin_size, int64_t s,
+                                                                     int64_t e, long long *__restrict__ out_host)
+{
+    __shared__ long long red[BITS_THREADS / 64];
+    __shared__ unsigned long long total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const int64_t w0 = s >> 6, w1 = (e - 1) >> 6;
+    long long c = 0;
+    for (int64_t w = w0 + threadIdx.x; w <= w1; w += BITS_THREADS) {
+        unsigned long long x = words[w];
+        if (w == w0) x &= mask_from((int)(s & 63));
+        if (w == w1) x &= mask_upto((int)((e - 1) & 63));
+        c += __popcll(x);
+    }
+    block_accumulate_i64(c, red, &total);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long r = (long long)total;
+        if (tags && tags[s / bin_size] == TAG_ONE) r -= s % bin_size;  // binBits.c:155,161
+        *out_host = r;
+    }
+}
+
 // One long range, whole grid: popcount of words [w0, w1] with edge masks.
 __global__ __launch_bounds__(BITS_THREADS) void bits_popcount_span_kernel(const unsigned long long *__restrict__ words,
                                                                          int64_t w0, int64_t w1, unsigned long long m0,
@@ -556,6 +584,7 @@ struct bxmi_bits {
     bool maybe_one = false;  // some bin may be ALL_ONE (only after invert / ior with such a set)
     bool flat = false;       // plain BitSet (bitset.pyx:107-173): no bins, no tri-state quirks
     DevBuf q_a, q_b, q_out, acc, tiles_s, tiles_l, run_s, run_e, scan_tmp;
+    long long *one_buf = nullptr;  // host-visible result of the one-range latency path
     hipStream_t stream = nullptr;
 };
 
@@ -608,6 +637,7 @@ extern "C" int bxmi_bits_destroy(bxmi_bits_t *h)
 {
     if (!h) return BXMI_OK;
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->one_buf) (void)hipHostFree(h->one_buf);
     delete h;
     return BXMI_OK;
 }
@@ -750,7 +780,16 @@ extern "C" int bxmi_bits_count_range(bxmi_bits_t *h, int32_t start, int32_t len,
     BXMI_TRY(validate_ranges(h, &start, &len, 1, "bxmi_bits_count_range"));
     *out = 0;
     if (len == 0) return BXMI_OK;
-    if (len < (1 << 16)) return bxmi_bits_count_ranges(h, &start, &len, 1, out);
+    if (len < (1 << 20)) {  // up to 16 Ki words: one workgroup, result straight into host-visible memory
+        BXMI_TRY(bits_stream(h));
+        if (!h->one_buf) BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->one_buf), 64, hipHostMallocDefault));
+        hipLaunchKernelGGL(bits_count_one_kernel, dim3(1), dim3(BITS_THREADS), 0, h->stream, h->words.as<unsigned long long>(),
+                           h->maybe_one ? h->tags.as<uint8_t>() : nullptr, h->bin_size, (int64_t)start, (int64_t)start + len, h->one_buf);
+        BXMI_LAUNCH_CHECK();
+        BXMI_HIP(hipStreamSynchronize(h->stream));
+        *out = (int32_t)*reinterpret_cast<volatile long long *>(h->one_buf);
+        return BXMI_OK;
+    }
     // chromosome-scale range: every CU takes part
     BXMI_TRY(bits_stream(h));
     BXMI_TRY(h->acc.reserve(64));

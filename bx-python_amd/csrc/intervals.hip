@@ -497,7 +497,11 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
         const int m = n - half * HALF < HALF ? n - half * HALF : HALF;
         for (int p = threadIdx.x; p < m; p += PT_THREADS) {
             int2 v = staged[p];
+#ifdef BXMI_DEBUG_LINEAR_SCATTER  // timing experiment only (wrong results): how much do the run-scattered stores cost?
+            unsigned d = (unsigned)(base + p + half * HALF);
+#else
             unsigned d = cnt[part_bucket(v.x, g)] + (unsigned)(p + half * HALF);  // global base of the run + offset inside it
+#endif
             qs_out[d] = v.x;
             qe_out[d] = v.y;
         }
@@ -1061,6 +1065,49 @@ __global__ __launch_bounds__(FIND_THREADS) void ivl_find_fill_kernel(IndexDev ix
     }
 }
 
+
+// ---- one query, one launch: the latency path behind the per-call find() of the drop-in classes ----
+// A single workgroup: 8 lanes walk the two search trees (all levels from L2), then the whole workgroup scans the
+// window and compacts the hits with wave ballots straight into host-visible memory: launch + one stream sync.
+constexpr int ONE_THREADS = 256;
+__global__ __launch_bounds__(ONE_THREADS) void ivl_find_one_kernel(TreeDev S, TreeDev P, IndexDev ix, int qs, int qe,
+                                                                  int32_t *__restrict__ out /* [0] = n (64-bit), hits from [2] */,
+                                                                  int cap)
+{
+    __shared__ int s_lo, s_hi;
+    __shared__ int wave_tot[ONE_THREADS / 64];
+    if (threadIdx.x < 8) {
+        int key_s[1] = {qe}, key_p[1] = {qs == INT_MAX ? INT_MAX : qs + 1}, r_s[1], r_p[1];
+        tree_rank_lt<true, 1>(S, nullptr, key_s, r_s, (int)threadIdx.x);
+        tree_rank_lt<true, 1>(P, nullptr, key_p, r_p, (int)threadIdx.x);
+        if (threadIdx.x == 0) {
+            s_hi = r_s[0];
+            s_lo = qs == INT_MAX ? ix.n : r_p[0];
+        }
+    }
+    __syncthreads();
+    const int lo = s_lo, hi = s_hi;
+    long long run = 0;
+    for (int b = lo; b < hi; b += ONE_THREADS) {
+        const int k = b + (int)threadIdx.x;
+        const bool f = k < hi && ix.e_ord[k] > qs;
+        const unsigned long long m = __ballot(f);
+        const int w = threadIdx.x >> 6;
+        if (lane_id() == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int i = 0; i < ONE_THREADS / 64; i++) {
+            if (i < w) woff += wave_tot[i];
+            tot += wave_tot[i];
+        }
+        const long long pos = run + woff + __popcll(m & lanemask_lt());
+        if (f && pos < cap) out[2 + pos] = ix.idx[k];
+        run += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *reinterpret_cast<long long *>(out) = run;
+}
+
 // before()/after() candidate filter over a window of the in-order arrays
 // (single query, one workgroup): keeps k in [lo,hi) with vlo <= val[k] < vhi.
 __global__ __launch_bounds__(256) void ivl_filter_window_kernel(const int32_t *__restrict__ val,
@@ -1213,6 +1260,7 @@ struct bxmi_ivl {
     // partitioned count path
     PartGeom geom{0, 0};
     DevBuf slice_bounds, p_hist, p_table, p_qs, p_qe, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
+    int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][hits...]
     hipStream_t sub_stream[PT_MAX_SUB] = {};
     hipEvent_t ev_fork = nullptr, ev_join[PT_MAX_SUB] = {};
     hipStream_t stream = nullptr;
@@ -1395,6 +1443,7 @@ extern "C" int bxmi_ivl_destroy(bxmi_ivl_t *h)
 {
     if (!h) return BXMI_OK;
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->one_buf) (void)hipHostFree(h->one_buf);
     if (h->ev_fork) {
         (void)hipEventDestroy(h->ev_fork);
         for (int i = 0; i < PT_MAX_SUB; i++) {
@@ -1728,6 +1777,36 @@ extern "C" int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe
     if (rc == BXMI_OK && tot > 0) BXMI_HIP(hipMemcpyAsync(hits, h->q_hits.p, (size_t)tot * 4, hipMemcpyDeviceToHost, st));
     BXMI_HIP(hipStreamSynchronize(st));
     return rc;
+}
+
+
+constexpr int ONE_CAP = 4096 - 2;  // hits that fit the 16 KiB host-visible result buffer
+
+// IntervalTree.find(start, end) for ONE query (intersection.pyx:400-406): one kernel launch, one stream sync.
+extern "C" int bxmi_ivl_find_one(bxmi_ivl_t *h, int32_t qs, int32_t qe, int32_t *hits, int64_t cap, int64_t *n_hits)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_find_one"));
+    if (!n_hits || cap < 0 || (cap > 0 && !hits)) return fail(BXMI_EINVAL, "bxmi_ivl_find_one: bad arguments");
+    *n_hits = 0;
+    if (h->n == 0) return BXMI_OK;
+    BXMI_TRY(ivl_stream(h));
+    if (!h->one_buf) BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->one_buf), 4096 * sizeof(int32_t), hipHostMallocDefault));
+    Tree tS = Tree(), tP = Tree();
+    tS.dev = h->treeS.dev, tP.dev = h->treeP.dev;
+    tS.set_lds_budget(0), tP.set_lds_budget(0);  // every level from global memory (L2): nothing to stage for one query
+    hipLaunchKernelGGL(ivl_find_one_kernel, dim3(1), dim3(ONE_THREADS), 0, h->stream, tS.dev, tP.dev, index_dev(h), qs, qe, h->one_buf, ONE_CAP);
+    BXMI_LAUNCH_CHECK();
+    BXMI_HIP(hipStreamSynchronize(h->stream));
+    const int64_t n = *reinterpret_cast<volatile long long *>(h->one_buf);
+    *n_hits = n;
+    if (n > ONE_CAP) {  // a very popular region: take the batched path once
+        if (n > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find_one: %lld hits need a larger buffer than cap=%lld", (long long)n, (long long)cap);
+        int64_t offs[2], total = 0;
+        return bxmi_ivl_find(h, &qs, &qe, 1, offs, hits, cap, &total);
+    }
+    if (n > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find_one: %lld hits need a larger buffer than cap=%lld", (long long)n, (long long)cap);
+    if (n > 0) memcpy(hits, h->one_buf + 2, (size_t)n * sizeof(int32_t));
+    return BXMI_OK;
 }
 
 // Two lower-bound ranks for the single-position neighbour API:

@@ -101,6 +101,10 @@ int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t n
 int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,
                       int32_t *hits, int64_t cap, int64_t *total_host, void *stream);
 
+/* IntervalTree.find for ONE query: one launch + one stream sync (the latency path of the per-call
+ * drop-in API).  *n_hits = number of hits; BXMI_ERANGE if it exceeds cap. */
+int bxmi_ivl_find_one(bxmi_ivl_t *h, int32_t qs, int32_t qe, int32_t *hits, int64_t cap, int64_t *n_hits);
+
 /* IntervalNode.left / right candidate collection for before()/after():
  * dir < 0: reverse in-order, keep 0 <= (position-1) - end   < max_dist
  * dir > 0: in-order,         keep 0 <= start - (position+1) < max_dist

@@ -94,9 +94,20 @@ def test_neighbours_match_reference_vectors(golden_trees, IntervalIndex):
     assert n > 300
 
 
+def test_find_one_beyond_its_buffer(IntervalIndex):
+    """More hits than the 16 KiB host-visible result buffer holds: falls over to the batched path."""
+    n = 10000
+    s = np.arange(n, dtype=np.int32)
+    ix = make_index(IntervalIndex, s, s + 100000)
+    assert ix.find_one(50, 60).tolist() == list(range(60))
+    assert ix.find_one(0, 200000).tolist() == list(range(n))
+    assert ix.find_one(5, 5).tolist() == list(range(5)) and ix.find_one(7, 3).tolist() == list(range(3))
+
+
 def test_empty_index(IntervalIndex):
     ix = IntervalIndex()
     ix.seal()
+    assert ix.find_one(1, 10).tolist() == []
     c, t = ix.count([1, 5], [10, 5])
     assert c.tolist() == [0, 0] and t == 0
     offs, hits = ix.find([1], [10])
@@ -155,6 +166,8 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     got_off, got_hits = ix.find(qs, qe)
     assert np.array_equal(got_off, want_off)
     assert np.array_equal(got_hits, want_hits)
+    for i in list(range(8)) + list(range(100, 160)):  # the one-query latency path (per-call find() of the drop-in)
+        assert ix.find_one(int(qs[i]), int(qe[i])).tolist() == want_hits[want_off[i]:want_off[i + 1]].tolist(), i
 
 
 def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
