@@ -508,6 +508,10 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
     }
 }
 
+// Finish a sampled-tree rank inside one group of `stride` keys: short groups are counted with independent loads
+// (one round trip, usually one line); long ones fall back to a binary search.
+__device__ __forceinline__ int group_rank_lt(const int32_t *__restrict__ a, int lo, int hi, int key);
+
 __device__ __forceinline__ int global_rank_lt(const int32_t *__restrict__ a, int lo, int hi, int key)
 {
     while (lo < hi) {
@@ -518,6 +522,47 @@ __device__ __forceinline__ int global_rank_lt(const int32_t *__restrict__ a, int
             hi = mid;
     }
     return lo;
+}
+
+// Which bucket / which queries does this search workgroup own?  (shared prologue of the count and window kernels)
+__device__ __forceinline__ bool part_chunk_of_block(const int32_t *__restrict__ wg_first, const unsigned *__restrict__ table,
+                                                    int64_t nq, int *s_bucket, int &b, int64_t &q_begin, int64_t &q_end)
+{
+    if (threadIdx.x == 0) *s_bucket = -1;
+    __syncthreads();
+    const int w = (int)blockIdx.x;
+#pragma unroll
+    for (int u = 0; u < PT_NB / PT_THREADS; u++) {
+        int c = u * PT_THREADS + threadIdx.x;
+        if (wg_first[c] <= w && w < wg_first[c + 1]) *s_bucket = c;
+    }
+    __syncthreads();
+    b = *s_bucket;
+    if (b < 0) return false;
+    const int64_t q_lo = table[b];
+    const int64_t q_hi = b + 1 < PT_NB ? (int64_t)table[b + 1] : nq;
+    q_begin = q_lo + (int64_t)(w - wg_first[b]) * PT_CHUNK;
+    q_end = q_begin + PT_CHUNK < q_hi ? q_begin + PT_CHUNK : q_hi;
+    return true;
+}
+
+// Stage `m = n / stride` samples of a sorted slice as a perfect Eytzinger tree of 2^k slots (slot 0 unused).
+__device__ __forceinline__ void part_stage_tree(int32_t *tree, int k, const int32_t *__restrict__ src, int n, int stride)
+{
+    const int m = n / stride;
+    for (int r = threadIdx.x; r < m; r += PT_THREADS) {
+        int tpos = r + 1, z = __ffs(tpos) - 1;  // in-order number and height of the node holding sample r
+        tree[(tpos >> (z + 1)) + (1 << (k - 1 - z))] = src[(r + 1) * stride - 1];
+    }
+}
+
+__device__ __forceinline__ int group_rank_lt(const int32_t *__restrict__ a, int lo, int hi, int key)
+{
+    if (hi - lo > 8) return global_rank_lt(a, lo, hi, key);
+    int c = lo;
+#pragma unroll
+    for (int u = 0; u < 8; u++) c += (lo + u < hi) && a[lo + u < hi ? lo + u : lo] < key;
+    return c;
 }
 
 __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
@@ -532,24 +577,9 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ int s_bucket;
     __shared__ long long red[PT_THREADS / 64];
-    if (threadIdx.x == 0) s_bucket = -1;
-    __syncthreads();
-    {
-        // every lane tests two buckets: the owner of workgroup w is the bucket with first <= w < next
-        const int w = (int)blockIdx.x;
-#pragma unroll
-        for (int u = 0; u < PT_NB / PT_THREADS; u++) {
-            int b = u * PT_THREADS + threadIdx.x;
-            if (wg_first[b] <= w && w < wg_first[b + 1]) s_bucket = b;
-        }
-    }
-    __syncthreads();
-    const int b = s_bucket;
-    if (b < 0) return;
-    const int64_t q_lo = table[b];
-    const int64_t q_hi = b + 1 < PT_NB ? (int64_t)table[b + 1] : nq;
-    const int64_t q_begin = q_lo + (int64_t)((int)blockIdx.x - wg_first[b]) * PT_CHUNK;
-    const int64_t q_end = q_begin + PT_CHUNK < q_hi ? q_begin + PT_CHUNK : q_hi;
+    int b;
+    int64_t q_begin, q_end;
+    if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end)) return;
     const SliceBound sb = bounds[b];
     const int nE = sb.eHi - sb.eLo, nS = sb.sHi - sb.sLo;
     // The two slices are staged as PERFECT binary search trees in breadth-first (Eytzinger)
@@ -565,15 +595,8 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
         const int total = (1 << sb.kE) + (1 << sb.kS);
         for (int i = threadIdx.x; i < total; i += PT_THREADS) lds[i] = INT_MAX;
         __syncthreads();
-        const int mE = nE / sb.strideE, mS = nS / sb.strideS;  // complete groups
-        for (int r = threadIdx.x; r < mE; r += PT_THREADS) {
-            int tpos = r + 1, z = __ffs(tpos) - 1;  // in-order number and height of the node holding sample r
-            treeE[(tpos >> (z + 1)) + (1 << (sb.kE - 1 - z))] = e_sorted[sb.eLo + (r + 1) * sb.strideE - 1];
-        }
-        for (int r = threadIdx.x; r < mS; r += PT_THREADS) {
-            int tpos = r + 1, z = __ffs(tpos) - 1;
-            treeS[(tpos >> (z + 1)) + (1 << (sb.kS - 1 - z))] = ix.s_ord[sb.sLo + (r + 1) * sb.strideS - 1];
-        }
+        part_stage_tree(treeE, sb.kE, e_sorted + sb.eLo, nE, sb.strideE);
+        part_stage_tree(treeS, sb.kS, ix.s_ord + sb.sLo, nS, sb.strideS);
     }
     __syncthreads();
     long long acc = 0;
@@ -606,14 +629,14 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
 #pragma unroll
             for (int j = 0; j < PT_ILP; j++) {
                 int hi = rS[j] + sb.strideS < nS ? rS[j] + sb.strideS : nS;
-                rS[j] = global_rank_lt(ix.s_ord + sb.sLo, rS[j], hi, qe[j]);
+                rS[j] = group_rank_lt(ix.s_ord + sb.sLo, rS[j], hi, qe[j]);
             }
         }
         if (sb.strideE > 1) {
 #pragma unroll
             for (int j = 0; j < PT_ILP; j++) {
                 int hi = rE[j] + sb.strideE < nE ? rE[j] + sb.strideE : nE;
-                rE[j] = qs[j] == INT_MAX ? 0 : global_rank_lt(e_sorted + sb.eLo, rE[j], hi, qs[j] + 1);
+                rE[j] = qs[j] == INT_MAX ? 0 : group_rank_lt(e_sorted + sb.eLo, rE[j], hi, qs[j] + 1);
             }
         }
 #pragma unroll
@@ -689,38 +712,6 @@ __global__ __launch_bounds__(PT_THREADS) void part_gather_kernel(const int32_t *
 
 
 // ---- partitioned find: window + count per query in bucket order, offsets carried to bucket order ----
-// Which bucket / which queries does this search workgroup own?  (shared prologue of the count and window kernels)
-__device__ __forceinline__ bool part_chunk_of_block(const int32_t *__restrict__ wg_first, const unsigned *__restrict__ table,
-                                                    int64_t nq, int *s_bucket, int &b, int64_t &q_begin, int64_t &q_end)
-{
-    if (threadIdx.x == 0) *s_bucket = -1;
-    __syncthreads();
-    const int w = (int)blockIdx.x;
-#pragma unroll
-    for (int u = 0; u < PT_NB / PT_THREADS; u++) {
-        int c = u * PT_THREADS + threadIdx.x;
-        if (wg_first[c] <= w && w < wg_first[c + 1]) *s_bucket = c;
-    }
-    __syncthreads();
-    b = *s_bucket;
-    if (b < 0) return false;
-    const int64_t q_lo = table[b];
-    const int64_t q_hi = b + 1 < PT_NB ? (int64_t)table[b + 1] : nq;
-    q_begin = q_lo + (int64_t)(w - wg_first[b]) * PT_CHUNK;
-    q_end = q_begin + PT_CHUNK < q_hi ? q_begin + PT_CHUNK : q_hi;
-    return true;
-}
-
-// Stage `m = n / stride` samples of a sorted slice as a perfect Eytzinger tree of 2^k slots (slot 0 unused).
-__device__ __forceinline__ void part_stage_tree(int32_t *tree, int k, const int32_t *__restrict__ src, int n, int stride)
-{
-    const int m = n / stride;
-    for (int r = threadIdx.x; r < m; r += PT_THREADS) {
-        int tpos = r + 1, z = __ffs(tpos) - 1;  // in-order number and height of the node holding sample r
-        tree[(tpos >> (z + 1)) + (1 << (k - 1 - z))] = src[(r + 1) * stride - 1];
-    }
-}
-
 // For every bucketed query: hi = #{start < qe}, lo = #{prefix-max <= qs} and the number of hits in the window
 // [lo, hi) of the tree-ordered arrays.  Ranks come from LDS trees one lane per query; the window is then scanned
 // by 8 lanes per query with 16-byte loads (a per-lane serial scan would issue 8 scattered requests per query).
@@ -757,9 +748,9 @@ __global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, co
         for (int it = 0; it < sb.kP; it++) rP = 2 * rP + (treeP[rP] <= qs && qs != INT_MAX);
         rS = (rS - (1 << sb.kS)) * sb.strideS;
         rP = (rP - (1 << sb.kP)) * sb.strideP;
-        if (sb.strideS > 1) rS = global_rank_lt(ix.s_ord + sb.sLo, rS, rS + sb.strideS < nS ? rS + sb.strideS : nS, qe);
+        if (sb.strideS > 1) rS = group_rank_lt(ix.s_ord + sb.sLo, rS, rS + sb.strideS < nS ? rS + sb.strideS : nS, qe);
         if (sb.strideP > 1 && qs != INT_MAX)
-            rP = global_rank_lt(ix.pm + sb.pLo, rP, rP + sb.strideP < nP ? rP + sb.strideP : nP, qs + 1);
+            rP = group_rank_lt(ix.pm + sb.pLo, rP, rP + sb.strideP < nP ? rP + sb.strideP : nP, qs + 1);
         const bool in_slice = qe >= sb.qeLo && qe <= sb.qeHi;
         int hi = in_slice ? sb.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe);
         int lo = qs == INT_MAX ? ix.n : sb.pLo + rP;
@@ -1272,40 +1263,76 @@ static IndexDev index_dev(const bxmi_ivl *h);
 template <typename Kern>
 static int allow_big_lds(Kern k, size_t bytes);
 
-// Large-batch count: bucket the queries, search each bucket against LDS-resident slices, gather back.
-// One sub-batch of the partitioned path, all on stream `st`; scratch regions are addressed by query offset q0.
+// Everything a bucketed pass needs to know about one (sub-)batch.
+struct PartPlan {
+    int64_t ntiles;
+    unsigned tgrid;        // tile-kernel grid: 8 XCD ranges of ceil(ntiles/8) tiles
+    unsigned *table;       // [ntiles][PT_NB] destination of every (tile, bucket) run; row 0 = bucket offsets
+    int32_t *plan;         // first search workgroup of every bucket
+    int32_t *bqs, *bqe;    // the queries in bucket order
+    unsigned short *lpos;  // per query (original order): slot inside its tile's sorted order
+};
+
+// Bucket the batch: histogram, column scan of the tile-major table, LDS-ordered scatter.  `sub`/`q0` select the
+// scratch regions of a sub-batch (regions are addressed by query offset; sub-batches start on tile boundaries).
+static int part_prepare(bxmi_ivl *h, int sub, int64_t q0, const int32_t *qs, const int32_t *qe, int64_t nq, bool want_lpos, hipStream_t st,
+                        PartPlan *pp)
+{
+    pp->ntiles = div_up(nq, PT_TILE);
+    pp->tgrid = (unsigned)(((pp->ntiles + 7) >> 3) << 3);
+    const int rows_per_block = (int)div_up(pp->ntiles, 64);  // ~64 row blocks: the serial middle kernel stays short
+    const int nrb = (int)div_up(pp->ntiles, rows_per_block);
+    pp->table = h->p_table.as<unsigned>() + (q0 / PT_TILE) * PT_NB;
+    unsigned *partial = h->p_hist.as<unsigned>() + (int64_t)sub * 80 * PT_NB;
+    pp->plan = h->p_plan.as<int32_t>() + (int64_t)sub * (PT_NB + 8);
+    pp->bqs = h->p_qs.as<int32_t>() + q0;
+    pp->bqe = h->p_qe.as<int32_t>() + q0;
+    pp->lpos = want_lpos ? h->p_dest.as<unsigned short>() + q0 : nullptr;
+    hipLaunchKernelGGL(part_hist_kernel, dim3(pp->tgrid), dim3(PT_THREADS), 0, st, qs, nq, h->geom, pp->table, pp->ntiles);
+    hipLaunchKernelGGL(part_colsum_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, pp->table, pp->ntiles, rows_per_block, partial);
+    hipLaunchKernelGGL(part_colbase_kernel, dim3(1), dim3(PT_THREADS), 0, st, partial, nrb, nq, pp->plan);
+    hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, pp->table, pp->ntiles, rows_per_block, partial);
+    BXMI_LAUNCH_CHECK();
+    const size_t scat_lds = (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned);
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(pp->tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, pp->table, pp->ntiles, pp->bqs,
+                       pp->bqe, pp->lpos);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+// Scratch for bucketing a batch of nq queries (grow-only).
+static int part_reserve(bxmi_ivl *h, int64_t nq, bool want_lpos)
+{
+    BXMI_TRY(h->p_qs.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_qe.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_plan.reserve((size_t)PT_MAX_SUB * (PT_NB + 8) * sizeof(int32_t)));
+    BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOTS * sizeof(unsigned long long)));
+    BXMI_TRY(h->p_table.reserve((size_t)(div_up(nq, PT_TILE) + PT_MAX_SUB) * PT_NB * sizeof(unsigned)));
+    BXMI_TRY(h->p_hist.reserve((size_t)PT_MAX_SUB * 80 * PT_NB * sizeof(unsigned)));
+    if (want_lpos) {
+        BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
+        BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
+    }
+    BXMI_TRY(allow_big_lds(part_scatter_kernel, (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned)));
+    return BXMI_OK;
+}
+
+// One sub-batch of the partitioned count, all on stream `st`.
 static int ivl_count_part_sub(bxmi_ivl *h, int sub, int64_t q0, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
                               int64_t *total_dev, hipStream_t st)
 {
-    const int64_t ntiles = div_up(nq, PT_TILE);
-    const int64_t tile0 = q0 / PT_TILE;                           // sub-batches start on tile boundaries
-    const unsigned tgrid = (unsigned)(((ntiles + 7) >> 3) << 3);  // 8 XCD ranges of ceil(ntiles/8) tiles
-    const int rows_per_block = (int)div_up(ntiles, 64);           // ~64 row blocks: the serial middle kernel stays short
-    const int nrb = (int)div_up(ntiles, rows_per_block);
-    unsigned *table = h->p_table.as<unsigned>() + tile0 * PT_NB;
-    unsigned *partial = h->p_hist.as<unsigned>() + (int64_t)sub * 80 * PT_NB;
-    int32_t *plan = h->p_plan.as<int32_t>() + (int64_t)sub * (PT_NB + 8);
+    PartPlan pp;
+    BXMI_TRY(part_prepare(h, sub, q0, qs, qe, nq, counts != nullptr, st, &pp));
     unsigned long long *slots = h->p_slots.as<unsigned long long>() + (int64_t)sub * PT_SLOTS;
-    int32_t *bqs = h->p_qs.as<int32_t>() + q0, *bqe = h->p_qe.as<int32_t>() + q0;
-    hipLaunchKernelGGL(part_hist_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, qs, nq, h->geom, table, ntiles);
-    hipLaunchKernelGGL(part_colsum_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
-    hipLaunchKernelGGL(part_colbase_kernel, dim3(1), dim3(PT_THREADS), 0, st, partial, nrb, nq, plan);
-    hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
-    BXMI_LAUNCH_CHECK();
-    const size_t scat_lds = (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned);
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, table, ntiles, bqs, bqe,
-                       counts ? h->p_dest.as<unsigned short>() + q0 : nullptr);
-    BXMI_LAUNCH_CHECK();
     if (total_dev) BXMI_HIP(hipMemsetAsync(slots, 0, PT_SLOTS * sizeof(unsigned long long), st));
-    const size_t lds_bytes = (size_t)PT_LDS_INTS * 4;
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
-    hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->e_sorted.as<int32_t>(),
-                       h->slice_bounds.as<SliceBound>(), plan, table, bqs, bqe, nq, counts ? h->p_cnt.as<int32_t>() + q0 : nullptr,
+    hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h), h->e_sorted.as<int32_t>(),
+                       h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bqs, pp.bqe, nq, counts ? h->p_cnt.as<int32_t>() + q0 : nullptr,
                        total_dev ? slots : nullptr);
     BXMI_LAUNCH_CHECK();
     if (counts) {
-        hipLaunchKernelGGL(part_gather_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>() + q0,
-                           h->p_dest.as<unsigned short>() + q0, table, ntiles, nq, counts);
+        hipLaunchKernelGGL(part_gather_kernel, dim3(pp.tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>() + q0, pp.lpos, pp.table, pp.ntiles,
+                           nq, counts);
         BXMI_LAUNCH_CHECK();
     }
     if (total_dev) {
@@ -1325,17 +1352,7 @@ static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *
     int nsub = 1;
     if (g_opt_pipeline > 1 && nq >= (int64_t)g_opt_pipeline * (8 << 20)) nsub = (int)(g_opt_pipeline > PT_MAX_SUB ? PT_MAX_SUB : g_opt_pipeline);
     const int64_t per = div_up(div_up(nq, nsub), PT_TILE) * PT_TILE;
-    BXMI_TRY(h->p_qs.reserve((size_t)(nq + 4) * 4));
-    BXMI_TRY(h->p_qe.reserve((size_t)(nq + 4) * 4));
-    BXMI_TRY(h->p_plan.reserve((size_t)PT_MAX_SUB * (PT_NB + 8) * sizeof(int32_t)));
-    BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOTS * sizeof(unsigned long long)));
-    BXMI_TRY(h->p_table.reserve((size_t)(div_up(nq, PT_TILE) + PT_MAX_SUB) * PT_NB * sizeof(unsigned)));
-    BXMI_TRY(h->p_hist.reserve((size_t)PT_MAX_SUB * 80 * PT_NB * sizeof(unsigned)));
-    if (counts) {
-        BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
-        BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
-    }
-    BXMI_TRY(allow_big_lds(part_scatter_kernel, (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned)));
+    BXMI_TRY(part_reserve(h, nq, counts != nullptr));
     BXMI_TRY(allow_big_lds(part_count_kernel, (size_t)PT_LDS_INTS * 4));
     if (nsub == 1) return ivl_count_part_sub(h, 0, 0, qs, qe, nq, counts, total_dev, st);
     // fork: side streams wait for everything already queued on the caller's stream
@@ -1366,39 +1383,23 @@ static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *q
                                 int64_t cap, int64_t *total_host, hipStream_t st)
 {
     if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_find: more than 2^31 queries in one batch");
-    const int64_t ntiles = div_up(nq, PT_TILE);
-    const unsigned tgrid = (unsigned)(((ntiles + 7) >> 3) << 3);
-    const int rows_per_block = (int)div_up(ntiles, 64);
-    const int nrb = (int)div_up(ntiles, rows_per_block);
-    BXMI_TRY(h->p_qs.reserve((size_t)(nq + 4) * 4));
-    BXMI_TRY(h->p_qe.reserve((size_t)(nq + 4) * 4));
-    BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
-    BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(part_reserve(h, nq, true));
     BXMI_TRY(h->p_lo.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_hi.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_boffs.reserve((size_t)(nq + 4) * 8));
-    BXMI_TRY(h->p_plan.reserve((size_t)PT_MAX_SUB * (PT_NB + 8) * sizeof(int32_t)));
-    BXMI_TRY(h->p_table.reserve((size_t)(ntiles + PT_MAX_SUB) * PT_NB * sizeof(unsigned)));
-    BXMI_TRY(h->p_hist.reserve((size_t)PT_MAX_SUB * 80 * PT_NB * sizeof(unsigned)));
-    unsigned *table = h->p_table.as<unsigned>(), *partial = h->p_hist.as<unsigned>();
-    int32_t *plan = h->p_plan.as<int32_t>();
-    int32_t *bqs = h->p_qs.as<int32_t>(), *bqe = h->p_qe.as<int32_t>();
-    unsigned short *lpos = h->p_dest.as<unsigned short>();
-    hipLaunchKernelGGL(part_hist_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, qs, nq, h->geom, table, ntiles);
-    hipLaunchKernelGGL(part_colsum_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
-    hipLaunchKernelGGL(part_colbase_kernel, dim3(1), dim3(PT_THREADS), 0, st, partial, nrb, nq, plan);
-    hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, table, ntiles, rows_per_block, partial);
-    BXMI_LAUNCH_CHECK();
-    const size_t scat_lds = (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned);
-    BXMI_TRY(allow_big_lds(part_scatter_kernel, scat_lds));
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, table, ntiles, bqs, bqe, lpos);
-    BXMI_LAUNCH_CHECK();
+    PartPlan pp;
+    BXMI_TRY(part_prepare(h, 0, 0, qs, qe, nq, true, st, &pp));
+    const int64_t ntiles = pp.ntiles;
+    const unsigned tgrid = pp.tgrid;
+    unsigned *table = pp.table;
+    int32_t *bqs = pp.bqs;
+    unsigned short *lpos = pp.lpos;
     const size_t lds_bytes = (size_t)PT_LDS_INTS * 4;
     BXMI_TRY(allow_big_lds(part_window_kernel, lds_bytes));
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
-    hipLaunchKernelGGL(part_window_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->slice_bounds.as<SliceBound>(), plan,
-                       table, bqs, bqe, nq, h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->p_cnt.as<int32_t>());
+    hipLaunchKernelGGL(part_window_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->slice_bounds.as<SliceBound>(), pp.plan,
+                       table, bqs, pp.bqe, nq, h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->p_cnt.as<int32_t>());
     hipLaunchKernelGGL(part_gather_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>(), lpos, table, ntiles, nq,
                        h->q_cnt.as<int32_t>());
     BXMI_LAUNCH_CHECK();
