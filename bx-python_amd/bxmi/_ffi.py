@@ -77,13 +77,19 @@ _SIGNATURES = {
     "bxmi_bits_and_count_dev": [vp, vp, vp, vp],
     "bxmi_bits_popcount_dev": [vp, vp, vp],
     "bxmi_bits_runs": [vp, i32, vp, vp, i64, _p(i64)],
+    "bxmi_bed_parse": [vp, i64, C.c_int, C.c_int, C.c_int, _p(vp)],
+    "bxmi_bed_destroy": [vp],
+    "bxmi_bed_info": [vp, _p(i64), _p(i32), _p(i64), _p(i64), _p(i64)],
+    "bxmi_bed_columns": [vp, _p(vp), _p(vp), _p(vp), _p(vp), _p(vp)],
+    "bxmi_bed_emit_lines": [vp, vp, vp, C.c_char_p, C.c_int],
     "bxmi_bits_group_create": [_p(vp), C.c_int, _p(vp)],
     "bxmi_bits_group_destroy": [vp],
     "bxmi_bits_group_and_dev": [vp, vp, vp, vp],
     "bxmi_bits_group_or_dev": [vp, vp, vp],
     "bxmi_bits_group_popcount_dev": [vp, vp, vp],
 }
-_OTHER_RESTYPE = {"bxmi_version": (C.c_int, []), "bxmi_last_error": (C.c_char_p, [])}
+_OTHER_RESTYPE = {"bxmi_version": (C.c_int, []), "bxmi_last_error": (C.c_char_p, []),
+                  "bxmi_bed_chrom_name": (C.c_char_p, [vp, i32])}
 
 EXPORTED = sorted(list(_SIGNATURES) + list(_OTHER_RESTYPE))
 

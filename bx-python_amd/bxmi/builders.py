@@ -28,6 +28,40 @@ def _check_range(size, start, count):
     return None
 
 
+def _bulk_prefix(f, chrom_col, start_col, end_col, lens, sizes, parts):
+    """Fast path: parse a real file in C++ and queue every row up to the first one the reference would
+    reject; returns the text lines that still have to go through the per-line loop."""
+    from . import bedio
+
+    data = bedio.file_bytes(f) if bedio.enabled() else None
+    if data is None:
+        return f
+    bed = bedio.ParsedBed(data, chrom_col, start_col, end_col)
+    try:
+        size_of = np.array([lens[c] if c in lens else MAX for c in bed.names] or [MAX], dtype=np.int64)
+        sz = size_of[bed.chrom] if bed.n else np.empty(0, np.int64)
+        s, e = bed.start, bed.end
+        bad = (sz > 2147483647) | (s < 0) | (s >= sz) | (e < s) | (e > sz)  # includes start beyond int32
+        k = int(np.argmax(bad)) if bad.any() else bed.n
+        ids = bed.chrom[:k]
+        order = np.argsort(ids, kind="stable")
+        bounds = np.searchsorted(ids[order], np.arange(len(bed.names) + 1))
+        first_row = np.full(len(bed.names), bed.n, dtype=np.int64)
+        if k:
+            np.minimum.at(first_row, ids, np.arange(k))
+        for c in np.argsort(first_row, kind="stable").tolist():  # chromosomes in first-appearance order
+            if first_row[c] >= k:
+                break
+            rows = order[bounds[c]:bounds[c + 1]]
+            name = bed.names[c]
+            sizes[name] = int(size_of[c])
+            keep = rows[e[rows] > s[rows]]
+            parts[name] = [(s[keep].astype(np.int32), (e[keep] - s[keep]).astype(np.int32))]
+        return bed.rest_lines(k if k < bed.n else None)
+    finally:
+        bed.close()
+
+
 def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=5, upstream_pad=0, downstream_pad=0, lens={},
                              _bed_track_lines=False):
     """
@@ -38,11 +72,18 @@ def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=
       chromosomes will be assumed to be the maximum size
     """
     sizes = {}  # chrom -> size, in first-appearance order (drives dict order of the result)
+    parts = {}  # chrom -> [(starts, counts) arrays] queued by the bulk prefix
     starts, counts = {}, {}
     error = None
     size = None
     last_chrom = None
     offset = 0
+    if not (upstream_pad or downstream_pad or _bed_track_lines):
+        f = _bulk_prefix(f, chrom_col, start_col, end_col, lens, sizes, parts)
+        for chrom in sizes:
+            starts[chrom], counts[chrom] = [], []
+        if sizes:
+            size = sizes[next(reversed(sizes))]
     for line in f:
         if line.startswith("#") or line.isspace():  # bitset_builders.py:33-34
             continue
@@ -86,6 +127,9 @@ def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=
     bitsets = {}
     for chrom, sz in sizes.items():
         b = BinnedBitSet(sz)
+        for s, c in parts.get(chrom, ()):
+            if len(s):
+                b.set_ranges(s, c)
         if starts[chrom]:
             b.set_ranges(np.array(starts[chrom], dtype=np.int32), np.array(counts[chrom], dtype=np.int32))
         bitsets[chrom] = b

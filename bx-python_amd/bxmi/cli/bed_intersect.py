@@ -52,11 +52,70 @@ def main(argv=None, out=None):
         raise SystemExit(__doc__.replace("%prog", sys.argv[0]))
 
     bitsets = binned_bitsets_from_file(open(in2_fname))
+    query = open(in_fname)
+    rest = _bulk_prefix(query, bitsets, mincols, reverse, booleans, out)
+    _per_line(rest, bitsets, mincols, reverse, booleans, out)
 
-    # Pass 1 (host): parse the query file in order; stop at the first line the reference would die on.
+
+def _bulk_prefix(query, bitsets, mincols, reverse, booleans, out):
+    """Fast path: the query file is parsed in C++ (bxmi.bedio), every chromosome's rows are answered by one
+    count_ranges launch and the selected lines are written straight from the file buffer.  Stops at the first
+    row the reference would reject (or the parser is unsure about) and returns the remaining lines."""
+    from bxmi import bedio
+
+    data = bedio.file_bytes(query) if bedio.enabled() else None
+    if data is None:
+        return query
+    bed = bedio.ParsedBed(data)
+    try:
+        known = np.array([name in bitsets for name in bed.names] or [False])
+        size_of = np.array([bitsets[name].size if name in bitsets else 0 for name in bed.names] or [0], dtype=np.int64)
+        has = known[bed.chrom] if bed.n else np.empty(0, bool)
+        sz = size_of[bed.chrom] if bed.n else np.empty(0, np.int64)
+        s, e = bed.start, bed.end
+        bad = has & ((s < 0) | (s >= sz) | (e < s) | (e > sz))
+        k = int(np.argmax(bad)) if bad.any() else bed.n
+        if (s[:k] > e[:k]).any():
+            warn("Bed interval start after end!")
+        hit = np.zeros(bed.n, dtype=bool)
+        ids = bed.chrom[:k]
+        order = np.argsort(ids, kind="stable")
+        bounds = np.searchsorted(ids[order], np.arange(len(bed.names) + 1))
+        for c, name in enumerate(bed.names):
+            rows = order[bounds[c]:bounds[c + 1]]
+            if known[c] and len(rows):
+                counts = bitsets[name].count_ranges(s[rows].astype(np.int32), (e[rows] - s[rows]).astype(np.int32))
+                hit[rows] = counts >= mincols
+        sel = hit != reverse
+        sel[k:] = False
+        out.flush()
+        if booleans:
+            text = np.where(sel[:k], ord("1"), ord("0")).astype(np.uint8)
+            both = np.empty((k, 2), dtype=np.uint8)
+            both[:, 0], both[:, 1] = text, ord("\n")
+            out.write(both.tobytes().decode("ascii"))
+        else:
+            try:
+                fd = out.fileno()
+            except (AttributeError, OSError, ValueError):
+                fd = None
+            if fd is not None:
+                bed.emit(sel, b" ", fd)
+            else:
+                for i in np.nonzero(sel)[0].tolist():
+                    o = int(bed.line_off[i])
+                    out.write(data[o:o + int(bed.line_len[i])].decode("utf-8") + " ")
+        out.flush()
+        return bed.rest_lines(k if k < bed.n else None)
+    finally:
+        bed.close()
+
+
+def _per_line(lines_in, bitsets, mincols, reverse, booleans, out):
+    # Pass 1 (host): parse the query lines in order; stop at the first line the reference would die on.
     lines, per_chrom = [], {}
     error = None
-    for line in open(in_fname):
+    for line in lines_in:
         if line.startswith("#") or line.isspace():
             continue
         try:

@@ -9,13 +9,14 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 ${BXMI_DEFS:-} -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${BXMI_EXTRA_FLAGS:-}"
 mkdir -p "$OBJ"
 pids=()
-for f in core intervals bitset; do
-  if [ ! -f "$OBJ/$f.o" ] || [ "$HERE/$f.hip" -nt "$OBJ/$f.o" ] || [ "$HERE/common.hpp" -nt "$OBJ/$f.o" ] \
+for f in core intervals bitset bedparse; do
+  src="$HERE/$f.hip"; [ -f "$src" ] || src="$HERE/$f.cpp"
+  if [ ! -f "$OBJ/$f.o" ] || [ "$src" -nt "$OBJ/$f.o" ] || [ "$HERE/common.hpp" -nt "$OBJ/$f.o" ] \
      || [ "$HERE/primitives.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/bxmi.h" -nt "$OBJ/$f.o" ]; then
-    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$OBJ/$f.o" &
+    $HIPCC $FLAGS -c "$src" -o "$OBJ/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/core.o" "$OBJ/intervals.o" "$OBJ/bitset.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/core.o" "$OBJ/intervals.o" "$OBJ/bitset.o" "$OBJ/bedparse.o"
 echo "built $OUT"

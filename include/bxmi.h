@@ -168,6 +168,25 @@ int bxmi_bits_group_popcount_dev(bxmi_bits_group_t *g, int64_t *counts_dev, void
  * produces.  Writes up to cap pairs; *n_runs = number of runs (BXMI_ERANGE if > cap). */
 int bxmi_bits_runs(bxmi_bits_t *h, int32_t from, int32_t *run_start, int32_t *run_end, int64_t cap, int64_t *n_runs);
 
+/* ---- BED text -> SoA columns on the host (the step before the hot path) ------
+ * Strict single-pass parser for what lib/bx/bitset_builders.py:33-46 and
+ * scripts/bed_intersect.py:46-50 do per line in Python: skip '#' and blank lines,
+ * split on whitespace runs, int() the start/end columns.  It STOPS at the first line
+ * that is not plain ASCII BED (stop_line/stop_off), so the caller can hand the rest to
+ * the reference's own semantics; it never reinterprets or repairs input. */
+typedef struct bxmi_bed bxmi_bed_t;
+int bxmi_bed_parse(const char *data, int64_t len, int chrom_col, int start_col, int end_col, bxmi_bed_t **out);
+int bxmi_bed_destroy(bxmi_bed_t *b);
+int bxmi_bed_info(const bxmi_bed_t *b, int64_t *n_rows, int32_t *n_chroms, int64_t *stop_line, int64_t *stop_off,
+                  int64_t *lines_seen);
+/* Borrowed views, valid until bxmi_bed_destroy: chromosome id (first-appearance order), start, end,
+ * and each row's line as (offset, length incl. newline) into the parsed buffer. */
+int bxmi_bed_columns(const bxmi_bed_t *b, const int32_t **chrom_id, const int64_t **start, const int64_t **end,
+                     const int64_t **line_off, const int32_t **line_len);
+const char *bxmi_bed_chrom_name(const bxmi_bed_t *b, int32_t id);
+/* Write the lines with mask[row] != 0, each followed by `suffix`, to file descriptor fd. */
+int bxmi_bed_emit_lines(const bxmi_bed_t *b, const char *data, const uint8_t *mask, const char *suffix, int fd);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,6 +130,46 @@ def test_sibling_interval_scripts(golden_siblings, tag):
     check_sibling(golden_siblings, "interval_count_intersections %s" % tag, "interval_count_intersections", [fb, fa])
 
 
+# ---- native BED ingest: bulk path == per-line path, byte for byte --------
+def test_fast_ingest_equals_per_line_path(tmp_path):
+    rng = np.random.default_rng(808)
+
+    def make(path, n, tag, oddities):
+        ch = rng.choice(["chr1", "chr2", "chr10", "chrUn_x"], size=n, p=[0.4, 0.3, 0.2, 0.1])
+        s = rng.integers(0, 5_000_000, size=n)
+        e = s + rng.integers(0, 900, size=n)
+        with open(path, "w") as f:
+            for i in range(n):
+                if oddities and i % 5003 == 0:
+                    f.write("# comment\n\n   \n")
+                if oddities and i == n // 2:
+                    f.write("chr2\t1_000\t2_000\tunderscores_are_valid_python_ints\n")  # parser hands over here
+                f.write("%s\t%d\t%d\t%s%d\t0\t+\n" % (ch[i], s[i], e[i], tag, i))
+
+    fa, fb = str(tmp_path / "a.bed"), str(tmp_path / "b.bed")
+    make(fa, 60_000, "a", True)
+    make(fb, 60_000, "b", True)
+    slow_env = {"BXMI_NO_FASTPARSE": "1"}
+
+    def run(module, args, extra=None):
+        env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + ROOT, PYTHONWARNINGS="ignore", **(extra or {}))
+        p = subprocess.run([sys.executable, "-m", "bxmi.cli." + module] + args, capture_output=True, text=True, env=env)
+        return p.returncode, p.stdout, p.stderr.strip().splitlines()[-1:] if p.returncode else []
+
+    for module, args in (("bed_intersect", [fa, fb]), ("bed_intersect", ["-v", fa, fb]), ("bed_intersect", ["-b", "-m", "300", fa, fb]),
+                         ("bed_coverage", [fa, fb]), ("bed_intersect_basewise", [fa, fb]), ("bed_subtract_basewise", [fa, fb])):
+        fast, slow = run(module, args), run(module, args, slow_env)
+        assert fast == slow and fast[0] == 0 and len(fast[1]) > 0, (module, args)
+    # an invalid row in the middle: same output before it, same exception
+    bad = str(tmp_path / "bad.bed")
+    lines = open(fa).read().splitlines(keepends=True)
+    lines.insert(40_000, "chr1\t600000000\t600000010\tbeyond_MAX\n")
+    open(bad, "w").writelines(lines)
+    for module, args in (("bed_intersect", [bad, fb]), ("bed_coverage", [bad])):
+        fast, slow = run(module, args), run(module, args, slow_env)
+        assert fast == slow and fast[0] == 1 and "IndexError" in fast[2][0], (module, fast[2])
+
+
 # ---- the per-call drop-in API, used the way the unmodified scripts use it -----------------
 def per_line_bitsets(path):
     """One BinnedBitSet per chromosome, one set_range call per BED line (file order)."""

@@ -171,3 +171,74 @@ def test_overlay_resolves_next_to_an_installed_bx_python():
     assert out[0].endswith("bx-python_amd/bx/bitset.py") and out[1].endswith("bx-python_amd/bx/intervals/intersection.py")
     assert out[2].startswith("/root/reference/lib/bx/") and out[3].startswith("/root/reference/lib/bx/")
     assert out[4] == "True True"
+
+
+def _python_parse(text, chrom_col=0, start_col=1, end_col=2):
+    """What the reference's per-line code accepts, restated: returns (rows, index of the first line the strict
+    native parser must refuse or None)."""
+    import re
+
+    rows, stop = [], None
+    plain_int = re.compile(r"[+-]?[0-9]{1,18}\Z")
+    for ln, line in enumerate(text.splitlines(keepends=True)):
+        body = line[:-1] if line.endswith("\n") else line
+        if any(ord(ch) >= 0x80 for ch in body) or "\r" in body:
+            stop = ln
+            break
+        if line.startswith("#") or line.isspace():
+            continue
+        f = line.split()
+        need = max(chrom_col, start_col, end_col) + 1
+        if len(f) < need or not plain_int.match(f[start_col]) or not plain_int.match(f[end_col]):
+            stop = ln
+            break
+        rows.append((f[chrom_col], int(f[start_col]), int(f[end_col]), line))
+    return rows, stop
+
+
+def test_native_bed_parser_matches_per_line_semantics():
+    """csrc/bedparse.cpp (host-only code in libbxmi.so): consumes exactly the plain lines, in order, and stops where
+    the per-line Python path has to take over."""
+    from bxmi import bedio
+
+    rng = np.random.default_rng(5)
+    body = []
+    for i in range(3000):
+        ch = "chr%d" % rng.integers(1, 5)
+        s = int(rng.integers(0, 10**6))
+        sep = ["\t", " ", "  \t "][int(rng.integers(0, 3))]
+        body.append("%s%s%d%s%d%sname%d\n" % (ch, sep, s, sep, s + int(rng.integers(0, 500)), sep, i))
+        if i % 97 == 0:
+            body.append("# comment %d\n" % i)
+        if i % 131 == 0:
+            body.append(["\n", "   \n", "\t\n", "\x1c\x1d \n"][i % 4])
+    cases = {
+        "clean": "".join(body),
+        "no trailing newline": "".join(body)[:-1],
+        "signs and zeros": "chr1\t+5\t-3\nchr1\t0007\t09\n  chr2   1   2   \n",
+        "leading space then hash is data": " #x\t1\t2\n",
+        "underscore int": "chr1\t1\t2\nchr1\t1_0\t20\nchr1\t3\t4\n",
+        "float": "chr1\t1\t2\nchr1\t1.5\t2\n",
+        "too few columns": "chr1\t1\t2\nchr1\t5\n",
+        "crlf": "chr1\t1\t2\r\nchr1\t3\t4\r\n",
+        "non ascii": "chr1\t1\t2\nchré\t3\t4\n",
+        "huge literal": "chr1\t1\t2\nchr1\t1234567890123456789012\t5\n",
+        "empty": "",
+        "only comments": "# a\n#b\n\n",
+    }
+    for name, text in cases.items():
+        data = text.encode("utf-8")
+        want, stop = _python_parse(text)
+        bed = bedio.ParsedBed(data)
+        got = [(bed.names[c], int(s), int(e), data[int(o):int(o) + int(n)].decode("utf-8"))
+               for c, s, e, o, n in zip(bed.chrom.tolist(), bed.start.tolist(), bed.end.tolist(), bed.line_off.tolist(), bed.line_len.tolist())]
+        assert got == want, name
+        lines = text.splitlines(keepends=True)
+        assert bed.rest_lines() == (lines[stop:] if stop is not None else []), name
+        # chromosome ids are handed out in first-appearance order
+        seen = []
+        for ch, _, _, _ in want:
+            if ch not in seen:
+                seen.append(ch)
+        assert bed.names == seen, name
+        bed.close()
