@@ -28,38 +28,130 @@ def _check_range(size, start, count):
     return None
 
 
-def _bulk_prefix(f, chrom_col, start_col, end_col, lens, sizes, parts):
-    """Fast path: parse a real file in C++ and queue every row up to the first one the reference would
-    reject; returns the text lines that still have to go through the per-line loop."""
-    from . import bedio
+class BitsetAccumulator:
+    """State of one `binned_bitsets_from_file` run, so that several files can be fed in sequence
+    (what fileinput does for bed_coverage.py / bed_merge_overlapping.py).  feed() queues ranges per chromosome,
+    finish() creates the bitsets in first-appearance order, issues one set_ranges launch per queued block and
+    re-raises the first error the reference would have hit."""
 
-    data = bedio.file_bytes(f) if bedio.enabled() else None
-    if data is None:
-        return f
-    bed = bedio.ParsedBed(data, chrom_col, start_col, end_col)
-    try:
-        size_of = np.array([lens[c] if c in lens else MAX for c in bed.names] or [MAX], dtype=np.int64)
-        sz = size_of[bed.chrom] if bed.n else np.empty(0, np.int64)
-        s, e = bed.start, bed.end
-        bad = (sz > 2147483647) | (s < 0) | (s >= sz) | (e < s) | (e > sz)  # includes start beyond int32
-        k = int(np.argmax(bad)) if bad.any() else bed.n
-        ids = bed.chrom[:k]
-        order = np.argsort(ids, kind="stable")
-        bounds = np.searchsorted(ids[order], np.arange(len(bed.names) + 1))
-        first_row = np.full(len(bed.names), bed.n, dtype=np.int64)
-        if k:
-            np.minimum.at(first_row, ids, np.arange(k))
-        for c in np.argsort(first_row, kind="stable").tolist():  # chromosomes in first-appearance order
-            if first_row[c] >= k:
+    def __init__(self, chrom_col=0, start_col=1, end_col=2, upstream_pad=0, downstream_pad=0, lens={}, bed_track_lines=False):
+        self.cols = (chrom_col, start_col, end_col)
+        self.upstream_pad, self.downstream_pad, self.lens, self.track = upstream_pad, downstream_pad, lens, bed_track_lines
+        self.sizes = {}   # chrom -> size, in first-appearance order (drives dict order of the result)
+        self.blocks = {}  # chrom -> [(starts, counts) int32 arrays] in file order
+        self.starts, self.counts = {}, {}  # per-line rows not yet turned into a block
+        self.error = None
+        self.size = None  # `size` of the most recently created bitset (the padding code of the reference uses it)
+        self.last_chrom = None
+        self.offset = 0
+
+    def _new_chrom(self, chrom, size):
+        self.sizes[chrom] = size
+        self.blocks[chrom] = []
+        self.starts[chrom], self.counts[chrom] = [], []
+
+    def _close_lists(self, chrom):
+        if self.starts[chrom]:
+            self.blocks[chrom].append((np.array(self.starts[chrom], dtype=np.int32), np.array(self.counts[chrom], dtype=np.int32)))
+            self.starts[chrom], self.counts[chrom] = [], []
+
+    def _bulk_prefix(self, f):
+        """Fast path: parse a real file in C++ and queue every row up to the first one the reference would
+        reject; returns the text lines that still have to go through the per-line loop."""
+        from . import bedio
+
+        data = bedio.file_bytes(f) if bedio.enabled() else None
+        if data is None:
+            return f
+        bed = bedio.ParsedBed(data, *self.cols)
+        try:
+            size_of = np.array([self.sizes.get(c, self.lens[c] if c in self.lens else MAX) for c in bed.names] or [MAX], dtype=np.int64)
+            sz = size_of[bed.chrom] if bed.n else np.empty(0, np.int64)
+            s, e = bed.start, bed.end
+            bad = (sz > 2147483647) | (s < 0) | (s >= sz) | (e < s) | (e > sz)  # includes start beyond int32
+            k = int(np.argmax(bad)) if bad.any() else bed.n
+            ids = bed.chrom[:k]
+            order = np.argsort(ids, kind="stable")
+            bounds = np.searchsorted(ids[order], np.arange(len(bed.names) + 1))
+            first_row = np.full(len(bed.names), bed.n, dtype=np.int64)
+            if k:
+                np.minimum.at(first_row, ids, np.arange(k))
+            for c in np.argsort(first_row, kind="stable").tolist():  # chromosomes in first-appearance order
+                if first_row[c] >= k:
+                    break
+                rows = order[bounds[c]:bounds[c + 1]]
+                name = bed.names[c]
+                if name not in self.sizes:
+                    self._new_chrom(name, int(size_of[c]))
+                    self.size = int(size_of[c])
+                self._close_lists(name)
+                keep = rows[e[rows] > s[rows]]
+                self.blocks[name].append((s[keep].astype(np.int32), (e[keep] - s[keep]).astype(np.int32)))
+            self.last_chrom = None
+            return bed.rest_lines(k if k < bed.n else None)
+        finally:
+            bed.close()
+
+    def feed(self, f):
+        if self.error is not None:
+            return self
+        chrom_col, start_col, end_col = self.cols
+        if not (self.upstream_pad or self.downstream_pad or self.track):
+            f = self._bulk_prefix(f)
+        for line in f:
+            if line.startswith("#") or line.isspace():  # bitset_builders.py:33-34
+                continue
+            if self.track:  # bitset_builders.py:77-85: browser lines ignored, track lines may carry offset=N
+                if line.startswith("browser"):
+                    continue
+                if line.startswith("track"):
+                    m = re.search(r"offset=(\d+)", line)
+                    if m and m.group(1):
+                        self.offset = int(m.group(1))
+                    continue
+            try:
+                fields = line.split()
+                chrom = fields[chrom_col]
+                if chrom != self.last_chrom:
+                    if chrom not in self.sizes:
+                        size = self.lens[chrom] if chrom in self.lens else MAX
+                        if size > 2147483647:
+                            raise ValueError("%d is larger than the maximum BinnedBitSet size of %d." % (size, 2147483647))
+                        self._new_chrom(chrom, size)
+                        self.size = size
+                    self.last_chrom = chrom
+                start, end = int(fields[start_col]) + self.offset, int(fields[end_col]) + self.offset
+                if self.upstream_pad:
+                    start = max(0, start - self.upstream_pad)
+                if self.downstream_pad:
+                    end = min(self.size, end + self.downstream_pad)  # `size` of the newest bitset, as in :48-49
+                if start > end:
+                    warn("Interval start after end!")
+                if not -2147483648 <= start <= 2147483647:
+                    raise OverflowError("value too large to convert to int")
+                self.error = _check_range(self.sizes[chrom], start, end - start)
+                if self.error is not None:
+                    break
+                if end > start:
+                    self.starts[chrom].append(start)
+                    self.counts[chrom].append(end - start)
+            except (ValueError, IndexError, OverflowError) as ex:
+                self.error = ex
                 break
-            rows = order[bounds[c]:bounds[c + 1]]
-            name = bed.names[c]
-            sizes[name] = int(size_of[c])
-            keep = rows[e[rows] > s[rows]]
-            parts[name] = [(s[keep].astype(np.int32), (e[keep] - s[keep]).astype(np.int32))]
-        return bed.rest_lines(k if k < bed.n else None)
-    finally:
-        bed.close()
+        return self
+
+    def finish(self):
+        bitsets = {}
+        for chrom, sz in self.sizes.items():
+            self._close_lists(chrom)
+            b = BinnedBitSet(sz)
+            for s, c in self.blocks[chrom]:
+                if len(s):
+                    b.set_ranges(s, c)
+            bitsets[chrom] = b
+        if self.error is not None:
+            raise self.error
+        return bitsets
 
 
 def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=5, upstream_pad=0, downstream_pad=0, lens={},
@@ -71,71 +163,16 @@ def binned_bitsets_from_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=
     - if 'lens' is provided bitset sizes will be looked up from it, otherwise
       chromosomes will be assumed to be the maximum size
     """
-    sizes = {}  # chrom -> size, in first-appearance order (drives dict order of the result)
-    parts = {}  # chrom -> [(starts, counts) arrays] queued by the bulk prefix
-    starts, counts = {}, {}
-    error = None
-    size = None
-    last_chrom = None
-    offset = 0
-    if not (upstream_pad or downstream_pad or _bed_track_lines):
-        f = _bulk_prefix(f, chrom_col, start_col, end_col, lens, sizes, parts)
-        for chrom in sizes:
-            starts[chrom], counts[chrom] = [], []
-        if sizes:
-            size = sizes[next(reversed(sizes))]
-    for line in f:
-        if line.startswith("#") or line.isspace():  # bitset_builders.py:33-34
-            continue
-        if _bed_track_lines:  # bitset_builders.py:77-85: browser lines ignored, track lines may carry offset=N
-            if line.startswith("browser"):
-                continue
-            if line.startswith("track"):
-                m = re.search(r"offset=(\d+)", line)
-                if m and m.group(1):
-                    offset = int(m.group(1))
-                continue
-        try:
-            fields = line.split()
-            chrom = fields[chrom_col]
-            if chrom != last_chrom:
-                if chrom not in sizes:
-                    size = lens[chrom] if chrom in lens else MAX
-                    if size > 2147483647:
-                        raise ValueError("%d is larger than the maximum BinnedBitSet size of %d." % (size, 2147483647))
-                    sizes[chrom] = size
-                    starts[chrom], counts[chrom] = [], []
-                last_chrom = chrom
-            start, end = int(fields[start_col]) + offset, int(fields[end_col]) + offset
-            if upstream_pad:
-                start = max(0, start - upstream_pad)
-            if downstream_pad:
-                end = min(size, end + downstream_pad)  # `size` of the most recently created bitset, as in :48-49
-            if start > end:
-                warn("Interval start after end!")
-            if not -2147483648 <= start <= 2147483647:
-                raise OverflowError("value too large to convert to int")
-            error = _check_range(sizes[chrom], start, end - start)
-            if error is not None:
-                break
-            if end > start:
-                starts[chrom].append(start)
-                counts[chrom].append(end - start)
-        except (ValueError, IndexError, OverflowError) as ex:
-            error = ex
-            break
-    bitsets = {}
-    for chrom, sz in sizes.items():
-        b = BinnedBitSet(sz)
-        for s, c in parts.get(chrom, ()):
-            if len(s):
-                b.set_ranges(s, c)
-        if starts[chrom]:
-            b.set_ranges(np.array(starts[chrom], dtype=np.int32), np.array(counts[chrom], dtype=np.int32))
-        bitsets[chrom] = b
-    if error is not None:
-        raise error
-    return bitsets
+    return BitsetAccumulator(chrom_col, start_col, end_col, upstream_pad, downstream_pad, lens, _bed_track_lines).feed(f).finish()
+
+
+def binned_bitsets_from_paths(paths, bed_track_lines=False):
+    """`binned_bitsets_from_file(fileinput.input(paths))` with every file going through the bulk ingest."""
+    acc = BitsetAccumulator(bed_track_lines=bed_track_lines)
+    for path in paths:
+        with open(path) as f:
+            acc.feed(f)
+    return acc.finish()
 
 
 def binned_bitsets_from_bed_file(f, chrom_col=0, start_col=1, end_col=2, strand_col=5, upstream_pad=0, downstream_pad=0, lens={}):

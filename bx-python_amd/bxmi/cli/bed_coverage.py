@@ -11,17 +11,16 @@ usage: %prog bed files ...
 import fileinput
 import sys
 
-from bxmi.builders import binned_bitsets_from_file
+from bxmi.builders import binned_bitsets_from_file, binned_bitsets_from_paths
 
 
 def main(argv=None, out=None, stdin=None):
     out = out or sys.stdout
     bed_filenames = sys.argv[1:] if argv is None else argv
-    if bed_filenames:
-        inp = fileinput.input(bed_filenames)
+    if bed_filenames and "-" not in bed_filenames:
+        bitsets = binned_bitsets_from_paths(bed_filenames)  # what fileinput would chain, each file ingested in bulk
     else:
-        inp = stdin or sys.stdin
-    bitsets = binned_bitsets_from_file(inp)
+        bitsets = binned_bitsets_from_file(fileinput.input(bed_filenames) if bed_filenames else (stdin or sys.stdin))
     total = 0
     for chrom in bitsets:
         total += bitsets[chrom].count_range(0, bitsets[chrom].size)
