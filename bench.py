@@ -192,6 +192,30 @@ def bench_bitsets(torch, steps, warmup):
         out["cpu_reference_error"] = repr(ex)
     for d in A + Bs:
         d.close()
+    # the same two sets with the reference's DEFAULT sizes (no lens: 24 x 512 Mi bits = 1.5 GiB per set)
+    try:
+        from bxmi.bitset import MAX
+
+        A2, B2 = [], []
+        for chrom in synth.HG19_SIZES:
+            a, b = DeviceBitSet(MAX), DeviceBitSet(MAX)
+            a.set_ranges(*ra[chrom])
+            b.set_ranges(*rb[chrom])
+            A2.append(a)
+            B2.append(b)
+        g2a, g2b = BitSetGroup(A2), BitSetGroup(B2)
+        bits2 = MAX * len(A2)
+        ms_p2 = timed(lambda: (per.zero_(), _ffi.call("bxmi_bits_group_popcount_dev", g2a._g, per.data_ptr(), stream)))
+        ms_f2 = timed(lambda: (per.zero_(), _ffi.call("bxmi_bits_group_and_dev", g2a._g, g2b._g, per.data_ptr(), stream)))
+        assert int(per.sum().item()) == and_bits, "MAX-sized sets disagree with the lens-sized ones"
+        out["default_MAX_sizes"] = dict(
+            workload="same ranges, every chromosome a BinnedBitSet(MAX): 24 x 512 Mi bits", popcount_gbps=round(bits2 / ms_p2 / 1e6, 1),
+            iand_count_fused_gbps=round(bits2 / ms_f2 / 1e6, 1), ms=dict(popcount=round(ms_p2, 4), fused=round(ms_f2, 4)),
+            roofline_frac=dict(popcount=round(bits2 / 8 / (ms_p2 * 1e6) / HBM_PEAK_GBS, 4), fused=round(3 * bits2 / 8 / (ms_f2 * 1e6) / HBM_PEAK_GBS, 4)))
+        for d in A2 + B2:
+            d.close()
+    except Exception as ex:
+        out["default_MAX_sizes"] = {"error": repr(ex)}
     return out
 
 
@@ -202,7 +226,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--queries", type=int, default=100_000_000)
     ap.add_argument("--targets", type=int, default=10_000_000)
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bitset", action="store_true")
     ap.add_argument("--allreduce-total", type=int, default=1, help="all-reduce the int64 overlap total each step when --gpus > 1")

@@ -129,7 +129,8 @@ def _random_case(rng, n, span, zero_frac=0.0, rev_frac=0.0, lmax=50):
 @pytest.mark.parametrize(
     "n,span,zero,rev,lmax",
     [(1, 10, 0, 0, 5), (31, 40, 0.2, 0, 8), (32, 40, 0, 0, 8), (33, 40, 0, 0.2, 8), (1023, 500, 0.1, 0, 30),
-     (1025, 100, 0.3, 0.1, 10), (40000, 100000, 0.05, 0, 200), (200000, 3000, 0.1, 0, 20), (70000, 10**9, 0, 0, 10**6)],
+     (1025, 100, 0.3, 0.1, 10), (40000, 100000, 0.05, 0, 200), (200000, 3000, 0.1, 0, 20), (70000, 10**9, 0, 0, 10**6),
+     (5000, 2**31 - 1100, 0.05, 0, 1000), (3000, 5, 0.5, 0, 2)],  # the whole int32 line; everything piled on 10 coordinates
 )
 def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     rng = np.random.default_rng(n * 7 + span)
