@@ -468,6 +468,14 @@ __device__ __forceinline__ int group_find(const GroupSeg *__restrict__ segs, int
     return lo;
 }
 
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+// 16-byte non-temporal store: the result of a streaming AND/OR is not read again by this kernel
+__device__ __forceinline__ void store_pair_nt(ulonglong2 *dst, ulonglong2 v)
+{
+    u64x2 t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<u64x2 *>(dst));
+}
+
 // OP: 0 = and, 1 = or, 3 = read-only popcount.  COUNT: accumulate popcount of the result inside [0,size).
 template <int OP, bool COUNT>
 __global__ __launch_bounds__(BITS_THREADS) void bits_group_kernel(const GroupSeg *__restrict__ sa, const GroupSeg *__restrict__ sb,
@@ -497,26 +505,38 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_group_kernel(const GroupSeg
         const int64_t p1 = p0 + MB_CHUNK_PAIRS < A.npairs ? p0 + MB_CHUNK_PAIRS : A.npairs;
         const int64_t full_words = A.size_bits >> 6;
         const unsigned long long tail_mask = (A.size_bits & 63) ? ~(~0ull << (A.size_bits & 63)) : 0ull;
-        for (int64_t p = p0 + threadIdx.x; p < p1; p += BITS_THREADS) {
-            ulonglong2 x = va[p];
-            if (OP != 3) {
-                ulonglong2 y = vb[p];
-                if (OP == 0) {
-                    x.x &= y.x;
-                    x.y &= y.y;
-                } else {
-                    x.x |= y.x;
-                    x.y |= y.y;
-                }
-                va[p] = x;
+        // 4 x 16-byte loads per operand in flight per lane before the first store (a chunk is 16 pairs per lane)
+        constexpr int U = 4;
+        for (int64_t pb = p0 + threadIdx.x; pb < p1; pb += (int64_t)BITS_THREADS * U) {
+            ulonglong2 x[U], y[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t p = pb + (int64_t)u * BITS_THREADS;
+                x[u] = p < p1 ? va[p] : make_ulonglong2(0, 0);
+                if (OP != 3) y[u] = p < p1 ? vb[p] : make_ulonglong2(0, 0);
             }
-            if (COUNT) {
-                int64_t w = p * 2;
-                if (w + 1 < full_words) {
-                    acc += __popcll(x.x) + __popcll(x.y);
-                } else {
-                    acc += w < full_words ? __popcll(x.x) : (w == full_words ? __popcll(x.x & tail_mask) : 0);
-                    acc += (w + 1) < full_words ? __popcll(x.y) : ((w + 1) == full_words ? __popcll(x.y & tail_mask) : 0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t p = pb + (int64_t)u * BITS_THREADS;
+                if (p >= p1) break;
+                if (OP != 3) {
+                    if (OP == 0) {
+                        x[u].x &= y[u].x;
+                        x[u].y &= y[u].y;
+                    } else {
+                        x[u].x |= y[u].x;
+                        x[u].y |= y[u].y;
+                    }
+                    store_pair_nt(va + p, x[u]);
+                }
+                if (COUNT) {
+                    int64_t w = p * 2;
+                    if (w + 1 < full_words) {
+                        acc += __popcll(x[u].x) + __popcll(x[u].y);
+                    } else {
+                        acc += w < full_words ? __popcll(x[u].x) : (w == full_words ? __popcll(x[u].x & tail_mask) : 0);
+                        acc += (w + 1) < full_words ? __popcll(x[u].y) : ((w + 1) == full_words ? __popcll(x[u].y & tail_mask) : 0);
+                    }
                 }
             }
         }
