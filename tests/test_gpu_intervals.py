@@ -171,6 +171,49 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
         assert ix.find_one(int(qs[i]), int(qe[i])).tolist() == want_hits[want_off[i]:want_off[i + 1]].tolist(), i
 
 
+@pytest.mark.parametrize("n,nq,span,lmax", [(5000, 40000, 200000, 300), (300000, 100000, 3_000_000, 2000), (300000, 50000, 2**31 - 3_000_000, 10**6),
+                                            (40, 33000, 1000, 50)])
+def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
+    """Queries whose starts are non-decreasing take the one-pass local kernel (detected on the device); a single
+    descent sends the same batch down the bucketed path.  Both must equal the reference, as must the direct kernel."""
+    rng = np.random.default_rng(n + nq)
+    s, e = _random_case(rng, n, span, 0.05, 0, lmax)
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    ix = make_index(IntervalIndex, s, e)
+    qs, qe = _random_case(rng, nq, span, 0.1, 0.05, lmax * 2)
+    order = np.argsort(qs, kind="stable")
+    qs, qe = qs[order].copy(), qe[order].copy()
+    qe[::101] = 2**31 - 1   # far-away ends leave the staged slice
+    qe[::103] = -(2**31)
+    qs[-3:] = 2**31 - 1     # still sorted; INT_MAX starts
+    qe[-3:] = [2**31 - 1, 0, -(2**31)]
+    want_c, want_t = t.count_batch(qs, qe)
+    set_opt("ivl.partition", 1)
+    try:
+        got_c, got_t = ix.count(qs, qe)
+        tot_only = ix.count(qs, qe, want_counts=False)[1]
+        f_off, f_hits = ix.find(qs, qe)  # bucketed find of a sorted batch (wave-aggregated ranks in the scatter)
+        set_opt("ivl.sorted_path", 0)  # same batch, bucketed
+        b_c, b_t = ix.count(qs, qe)
+        set_opt("ivl.sorted_path", 1)
+        qs2, qe2 = qs.copy(), qe.copy()  # one descent in the middle: not sorted any more
+        m = nq // 2
+        qs2[m], qs2[m + 1] = qs[m + 1] + 1, qs[m] - 1
+        u_c, u_t = ix.count(qs2, qe2)
+    finally:
+        set_opt("ivl.sorted_path", 1)
+        set_opt("ivl.partition", -1)
+    bad = np.nonzero(got_c != want_c)[0]
+    assert len(bad) == 0, ("sorted path", bad[:5], qs[bad[:5]], qe[bad[:5]], got_c[bad[:5]], want_c[bad[:5]])
+    assert got_t == want_t == tot_only
+    assert np.array_equal(b_c, want_c) and b_t == want_t
+    w_off, w_hits = t.find_batch(qs, qe)
+    assert np.array_equal(f_off, w_off) and np.array_equal(f_hits, w_hits), "find on a sorted batch"
+    want2_c, want2_t = t.count_batch(qs2, qe2)
+    assert np.array_equal(u_c, want2_c) and u_t == want2_t
+
+
 def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
     """250k of 300k targets sit inside one coordinate bucket: its slices exceed LDS and are staged sampled
     (every stride-th key) with a short finishing search -- counts must still be exact."""

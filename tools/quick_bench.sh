@@ -5,6 +5,7 @@ mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_intervals.py -m gpu -q -x --timeout 600 -p no:cacheprovider > gpurun_out/test_intervals.log 2>&1; echo "intervals rc=$?"
 tail -15 gpurun_out/test_intervals.log
 for opts in "ivl.partition=0" "ivl.partition=1"; do echo -n "$opts  "; BXMI_OPTS=$opts REPS=5 python tools/count_only.py 2>&1 | tail -1; done
+for opts in "ivl.sorted_path=0" "ivl.sorted_path=1"; do echo -n "$opts  "; MODE=sorted BXMI_OPTS=$opts REPS=5 python tools/count_only.py 2>&1 | tail -1; done
 cd /tmp; export TMPDIR=/tmp
 BXMI_OPTS=ivl.partition=1 REPS=3 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_part -o part --output-format csv -- python /root/repo/tools/count_only.py > /dev/null 2>&1
 python - <<'PY'
