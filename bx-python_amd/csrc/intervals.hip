@@ -472,8 +472,10 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
                                                                   const unsigned *__restrict__ unsorted /* part_hist's flag or NULL */,
                                                                   int skip_sorted /* 1: a sorted batch is answered elsewhere */)
 {
-    // LDS: half a tile of (qs, qe) pairs (64 KiB) + two 2048-entry tables (16 KiB) = 80 KiB, so TWO workgroups
-    // share a CU and one streams out while the other loads; the tile goes through the staging area in two halves.
+    // LDS: half a tile of (qs, qe) pairs (64 KiB) + two 2048-entry tables (16 KiB) = 80 KiB; the tile goes through the
+    // staging area in two halves.  The tile's pairs and slots live in registers (102 VGPRs), so in practice ONE
+    // workgroup runs per CU; keeping only the slots and re-reading the pairs when they are staged (58 VGPRs, two
+    // workgroups per CU) measured 0.93 ms against 0.64 ms, and forcing 64 VGPRs spills 32 of them.
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     constexpr int HALF = PT_TILE / 2;
     int2 *staged = reinterpret_cast<int2 *>(dyn);                    // [HALF] (qs, qe) in bucket order
@@ -589,10 +591,11 @@ __device__ __forceinline__ bool part_chunk_of_block(const int32_t *__restrict__ 
 }
 
 // Stage `m = n / stride` samples of a sorted slice as a perfect Eytzinger tree of 2^k slots (slot 0 unused).
+template <int THREADS>
 __device__ __forceinline__ void part_stage_tree(int32_t *tree, int k, const int32_t *__restrict__ src, int n, int stride)
 {
     const int m = n / stride;
-    for (int r = threadIdx.x; r < m; r += blockDim.x) {
+    for (int r = threadIdx.x; r < m; r += THREADS) {
         int tpos = r + 1, z = __ffs(tpos) - 1;  // in-order number and height of the node holding sample r
         tree[(tpos >> (z + 1)) + (1 << (k - 1 - z))] = src[(r + 1) * stride - 1];
     }
@@ -639,8 +642,8 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
         const int total = (1 << sb.kE) + (1 << sb.kS);
         for (int i = threadIdx.x; i < total; i += PT_THREADS) lds[i] = INT_MAX;
         __syncthreads();
-        part_stage_tree(treeE, sb.kE, e_sorted + sb.eLo, nE, sb.strideE);
-        part_stage_tree(treeS, sb.kS, ix.s_ord + sb.sLo, nS, sb.strideS);
+        part_stage_tree<PT_THREADS>(treeE, sb.kE, e_sorted + sb.eLo, nE, sb.strideE);
+        part_stage_tree<PT_THREADS>(treeS, sb.kS, ix.s_ord + sb.sLo, nS, sb.strideS);
     }
     __syncthreads();
     long long acc = 0;
@@ -810,8 +813,8 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
         const int total = (1 << kE) + (1 << kS);
         for (int i = threadIdx.x; i < total; i += LC_THREADS) lds[i] = INT_MAX;
         __syncthreads();
-        part_stage_tree(treeE, kE, e_sorted + eLo, nE, strideE);
-        part_stage_tree(treeS, kS, ix.s_ord + sLo, nS, strideS);
+        part_stage_tree<LC_THREADS>(treeE, kE, e_sorted + eLo, nE, strideE);
+        part_stage_tree<LC_THREADS>(treeS, kS, ix.s_ord + sLo, nS, strideS);
     }
     __syncthreads();
 #pragma unroll
@@ -921,48 +924,48 @@ __global__ __launch_bounds__(PT_THREADS) void part_gather_kernel(const int32_t *
 
 
 // ---- partitioned find: window + count per query in bucket order, offsets carried to bucket order ----
-// For every bucketed query: hi = #{start < qe}, lo = #{prefix-max <= qs} and the number of hits in the window
-// [lo, hi) of the tree-ordered arrays.  Ranks come from LDS trees one lane per query; the window is then scanned
-// by 8 lanes per query with 16-byte loads (a per-lane serial scan would issue 8 scattered requests per query).
-__global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, const SliceBound *__restrict__ bounds,
-                                                                 const int32_t *__restrict__ wg_first,
-                                                                 const unsigned *__restrict__ table,
-                                                                 const int32_t *__restrict__ qs_arr,
-                                                                 const int32_t *__restrict__ qe_arr, int64_t nq,
-                                                                 int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
-                                                                 int32_t *__restrict__ counts)
+// For every query of [q_begin, q_end): hi = #{start < qe}, lo = #{prefix-max <= qs} and the number of hits in the
+// window [lo, hi) of the tree-ordered arrays.  Ranks come from LDS trees one lane per query; the window is then
+// scanned by 8 lanes per query with 16-byte loads (a per-lane serial scan would issue 8 scattered requests per query).
+struct WindowSlices {
+    int sLo, nS, kS, strideS;  // staged slice of the starts (tree order)
+    int pLo, nP, kP, strideP;  // staged slice of the prefix-max array
+    int qeLo, qeHi;            // rank_lt(starts, qe) may use the slice iff qeLo <= qe <= qeHi
+};
+
+template <int THREADS>
+__device__ __forceinline__ void window_stage(const IndexDev &ix, const WindowSlices &w, int32_t *lds, int32_t *&treeP, int32_t *&treeS)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    __shared__ int s_bucket;
-    int b;
-    int64_t q_begin, q_end;
-    if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end)) return;
-    const SliceBound sb = bounds[b];
-    const int nS = sb.sHi - sb.sLo, nP = sb.pHi - sb.pLo;
-    int32_t *treeP = lds, *treeS = lds + (1 << sb.kP);
-    {
-        const int total = (1 << sb.kP) + (1 << sb.kS);
-        for (int i = threadIdx.x; i < total; i += PT_THREADS) lds[i] = INT_MAX;
-        __syncthreads();
-        part_stage_tree(treeP, sb.kP, ix.pm + sb.pLo, nP, sb.strideP);
-        part_stage_tree(treeS, sb.kS, ix.s_ord + sb.sLo, nS, sb.strideS);
-    }
+    treeP = lds, treeS = lds + (1 << w.kP);
+    const int total = (1 << w.kP) + (1 << w.kS);
+    for (int i = threadIdx.x; i < total; i += THREADS) lds[i] = INT_MAX;
     __syncthreads();
+    part_stage_tree<THREADS>(treeP, w.kP, ix.pm + w.pLo, w.nP, w.strideP);
+    part_stage_tree<THREADS>(treeS, w.kS, ix.s_ord + w.sLo, w.nS, w.strideS);
+    __syncthreads();
+}
+
+template <int THREADS>
+__device__ __forceinline__ void window_queries(const IndexDev &ix, const WindowSlices &w, const int32_t *treeP, const int32_t *treeS,
+                                               int64_t q_begin, int64_t q_end, const int32_t *__restrict__ qs_arr,
+                                               const int32_t *__restrict__ qe_arr, int32_t *__restrict__ win_lo,
+                                               int32_t *__restrict__ win_hi, int32_t *__restrict__ counts)
+{
     const int sub = threadIdx.x & 7, gbase = lane_id() & ~7;
-    for (int64_t i0 = q_begin + threadIdx.x; i0 - threadIdx.x < q_end; i0 += PT_THREADS) {
+    for (int64_t i0 = q_begin + threadIdx.x; i0 - threadIdx.x < q_end; i0 += THREADS) {
         const bool live = i0 < q_end;
         const int qs = live ? qs_arr[i0] : 0, qe = live ? qe_arr[i0] : 0;
         int rS = 1, rP = 1;
-        for (int it = 0; it < sb.kS; it++) rS = 2 * rS + (treeS[rS] < qe);
-        for (int it = 0; it < sb.kP; it++) rP = 2 * rP + (treeP[rP] <= qs && qs != INT_MAX);
-        rS = (rS - (1 << sb.kS)) * sb.strideS;
-        rP = (rP - (1 << sb.kP)) * sb.strideP;
-        if (sb.strideS > 1) rS = group_rank_lt(ix.s_ord + sb.sLo, rS, rS + sb.strideS < nS ? rS + sb.strideS : nS, qe);
-        if (sb.strideP > 1 && qs != INT_MAX)
-            rP = group_rank_lt(ix.pm + sb.pLo, rP, rP + sb.strideP < nP ? rP + sb.strideP : nP, qs + 1);
-        const bool in_slice = qe >= sb.qeLo && qe <= sb.qeHi;
-        int hi = in_slice ? sb.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe);
-        int lo = qs == INT_MAX ? ix.n : sb.pLo + rP;
+        for (int it = 0; it < w.kS; it++) rS = 2 * rS + (treeS[rS] < qe);
+        for (int it = 0; it < w.kP; it++) rP = 2 * rP + (treeP[rP] <= qs && qs != INT_MAX);
+        rS = (rS - (1 << w.kS)) * w.strideS;
+        rP = (rP - (1 << w.kP)) * w.strideP;
+        if (w.strideS > 1) rS = group_rank_lt(ix.s_ord + w.sLo, rS, rS + w.strideS < w.nS ? rS + w.strideS : w.nS, qe);
+        if (w.strideP > 1 && qs != INT_MAX)
+            rP = group_rank_lt(ix.pm + w.pLo, rP, rP + w.strideP < w.nP ? rP + w.strideP : w.nP, qs + 1);
+        const bool in_slice = qe >= w.qeLo && qe <= w.qeHi;
+        int hi = in_slice ? w.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe);
+        int lo = qs == INT_MAX ? ix.n : w.pLo + rP;
         if (!live) lo = hi = 0;
         // cooperative window scan: the 8 lanes of a group take their 8 queries one after the other; the first
         // 32-candidate step of all 8 windows is loaded up front (one dependent round trip instead of eight)
@@ -996,6 +999,98 @@ __global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, co
             counts[i0] = mine;
         }
     }
+}
+
+__global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, const SliceBound *__restrict__ bounds,
+                                                                 const int32_t *__restrict__ wg_first,
+                                                                 const unsigned *__restrict__ table,
+                                                                 const int32_t *__restrict__ qs_arr,
+                                                                 const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                                 int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
+                                                                 int32_t *__restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ int s_bucket;
+    int b;
+    int64_t q_begin, q_end;
+    if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end)) return;
+    const SliceBound sb = bounds[b];
+    const WindowSlices w = {sb.sLo, sb.sHi - sb.sLo, sb.kS, sb.strideS, sb.pLo, sb.pHi - sb.pLo, sb.kP, sb.strideP, sb.qeLo, sb.qeHi};
+    int32_t *treeP, *treeS;
+    window_stage<PT_THREADS>(ix, w, lds, treeP, treeS);
+    window_queries<PT_THREADS>(ix, w, treeP, treeS, q_begin, q_end, qs_arr, qe_arr, win_lo, win_hi, counts);
+}
+
+// find() on a batch whose starts are already sorted: the windows of 4096 consecutive queries as they lie (same idea
+// as ivl_local_count_kernel); lo / hi / counts come out in query order, so the CSR offsets are one scan away and the
+// fill pass writes neighbouring queries' hits to neighbouring addresses.
+__global__ __launch_bounds__(LC_THREADS) void ivl_local_window_kernel(TreeDev S, TreeDev P, IndexDev ix,
+                                                                      const int32_t *__restrict__ qs_arr,
+                                                                      const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                                      int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
+                                                                      int32_t *__restrict__ counts)
+{
+    __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
+    __shared__ int s_mm[3][LC_THREADS / 64];
+    __shared__ int s_slice[6];  // pLo, pHi, sLo, sHi, qeLo, qeHi
+    const int64_t base = (int64_t)blockIdx.x * LC_CHUNK;
+    const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
+    int mn = INT_MAX, mx = INT_MIN, emx = INT_MIN;
+    for (int k = threadIdx.x; k < n; k += LC_THREADS) {
+        int s = qs_arr[base + k], e = qe_arr[base + k];
+        mn = s < mn ? s : mn;
+        mx = s > mx ? s : mx;
+        emx = e > emx ? e : emx;
+    }
+    mn = wave_min_i32(mn), mx = wave_max_i32(mx), emx = wave_max_i32(emx);
+    if (lane_id() == 0) s_mm[0][threadIdx.x >> 6] = mn, s_mm[1][threadIdx.x >> 6] = mx, s_mm[2][threadIdx.x >> 6] = emx;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int a = INT_MAX, b = INT_MIN, c = INT_MIN;
+#pragma unroll
+        for (int i = 0; i < LC_THREADS / 64; i++) {
+            a = s_mm[0][i] < a ? s_mm[0][i] : a;
+            b = s_mm[1][i] > b ? s_mm[1][i] : b;
+            c = s_mm[2][i] > c ? s_mm[2][i] : c;
+        }
+        long long cap = (long long)b + 4 * ((long long)b - (long long)a) + 65536;  // see ivl_local_count_kernel
+        if (cap > INT_MAX) cap = INT_MAX;
+        int s_hi_key = (long long)c < cap ? c : (int)cap;
+        if (s_hi_key < a) s_hi_key = a;
+        const int sub = threadIdx.x & 7, upper = (threadIdx.x >> 3) & 1;
+        const int qs_key = upper ? b : a;
+        int keyP[1] = {qs_key == INT_MAX ? INT_MAX : qs_key + 1};  // #{pm <= qs}
+        int keyS[1] = {upper ? s_hi_key : a};
+        int rP[1], rS[1];
+        tree_rank_lt<true, 1>(P, lds, keyP, rP, sub);
+        tree_rank_lt<true, 1>(S, lds, keyS, rS, sub);
+        if (qs_key == INT_MAX || rP[0] > ix.n) rP[0] = ix.n;
+        if (sub == 0 && threadIdx.x < 16) {
+            s_slice[0 + upper] = rP[0];
+            s_slice[2 + upper] = rS[0];
+            s_slice[4 + upper] = upper ? s_hi_key : a;
+        }
+    }
+    __syncthreads();
+    WindowSlices w;
+    w.pLo = s_slice[0], w.nP = s_slice[1] - s_slice[0], w.sLo = s_slice[2], w.nS = s_slice[3] - s_slice[2];
+    w.qeLo = s_slice[4], w.qeHi = s_slice[5];
+    w.strideP = w.nP / LC_TREE_KEYS + 1, w.strideS = w.nS / LC_TREE_KEYS + 1;
+    w.kP = w.kS = 0;
+    while ((1 << w.kP) - 1 < w.nP / w.strideP) w.kP++;
+    while ((1 << w.kS) - 1 < w.nS / w.strideS) w.kS++;
+    int32_t *treeP, *treeS;
+    window_stage<LC_THREADS>(ix, w, lds, treeP, treeS);
+    window_queries<LC_THREADS>(ix, w, treeP, treeS, base, base + n, qs_arr, qe_arr, win_lo, win_hi, counts);
+}
+
+// Are the starts non-decreasing?  (find path: decided on the host before anything else is launched)
+__global__ void ivl_sorted_check_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ unsorted)
+{
+    bool descent = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < nq; i += (int64_t)gridDim.x * blockDim.x)
+        descent |= qs[i] > qs[i + 1];
+    if (__ballot(descent) && lane_id() == 0 && *unsorted == 0) *unsorted = 1;
 }
 
 // Values in query order -> bucket order (the inverse of part_gather_kernel): a workgroup drops its tile's
@@ -1604,6 +1699,33 @@ static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *
 }
 
 
+// find() on a batch with sorted starts: windows in query order -> scan -> fill, no bucketing.
+static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits, int64_t cap,
+                          int64_t *total_host, hipStream_t st)
+{
+    BXMI_TRY(h->p_lo.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_hi.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
+    TreeDev S = h->treeS.dev, P = h->treeP.dev;
+    S.lds_from = S.nlev, S.lds_ints = 0, P.lds_from = P.nlev, P.lds_ints = 0;  // walk the global levels only
+    hipLaunchKernelGGL(ivl_local_window_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, P, index_dev(h), qs, qe, nq,
+                       h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
+    BXMI_LAUNCH_CHECK();
+    BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
+                                                           reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
+    int64_t total = 0;
+    BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    if (total_host) *total_host = total;
+    if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
+    if (total == 0) return BXMI_OK;
+    int fgrid = device_props().cus * 8;
+    hipLaunchKernelGGL(part_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, nq, h->p_lo.as<int32_t>(),
+                       h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
 // Partitioned find(): same bucketing as the count path, then window+count per query in bucket order, counts gathered
 // back for the CSR offsets, offsets carried to bucket order, hits written from bucket order.
 static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits,
@@ -1946,7 +2068,20 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
         return BXMI_OK;
     }
     if (!h->has_reversed && h->n > 0 && (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_partition_min && h->n >= 4096)))
+    {
+        if (g_opt_sorted_path) {
+            // one cheap look at the starts decides the path on the host (find() synchronises for the total anyway)
+            BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOT_STRIDE * sizeof(unsigned long long)));
+            unsigned *flag = reinterpret_cast<unsigned *>(h->p_slots.as<unsigned long long>() + PT_SLOTS);
+            unsigned unsorted = 1;
+            BXMI_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+            hipLaunchKernelGGL(ivl_sorted_check_kernel, dim3(stream_grid(nq, 256)), dim3(256), 0, st, qs, nq, flag);
+            BXMI_HIP(hipMemcpyAsync(&unsorted, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            BXMI_HIP(hipStreamSynchronize(st));
+            if (!unsorted) return ivl_find_local(h, qs, qe, nq, offsets, hits, cap, total_host, st);
+        }
         return ivl_find_partitioned(h, qs, qe, nq, offsets, hits, cap, total_host, st);
+    }
     BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_lo.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_hi.reserve((size_t)(nq + 4) * 4));

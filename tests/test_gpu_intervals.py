@@ -193,9 +193,10 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
     try:
         got_c, got_t = ix.count(qs, qe)
         tot_only = ix.count(qs, qe, want_counts=False)[1]
-        f_off, f_hits = ix.find(qs, qe)  # bucketed find of a sorted batch (wave-aggregated ranks in the scatter)
+        f_off, f_hits = ix.find(qs, qe)  # windows in query order, no bucketing
         set_opt("ivl.sorted_path", 0)  # same batch, bucketed
         b_c, b_t = ix.count(qs, qe)
+        g_off, g_hits = ix.find(qs, qe)  # bucketed find of a sorted batch (wave-aggregated ranks in the scatter)
         set_opt("ivl.sorted_path", 1)
         qs2, qe2 = qs.copy(), qe.copy()  # one descent in the middle: not sorted any more
         m = nq // 2
@@ -210,6 +211,7 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
     assert np.array_equal(b_c, want_c) and b_t == want_t
     w_off, w_hits = t.find_batch(qs, qe)
     assert np.array_equal(f_off, w_off) and np.array_equal(f_hits, w_hits), "find on a sorted batch"
+    assert np.array_equal(g_off, w_off) and np.array_equal(g_hits, w_hits), "bucketed find on a sorted batch"
     want2_c, want2_t = t.count_batch(qs2, qe2)
     assert np.array_equal(u_c, want2_c) and u_t == want2_t
 

@@ -18,6 +18,10 @@ from bxmi.intervals import IntervalIndex
 NT = int(os.environ.get("NT", 50_000_000))
 NQ = int(os.environ.get("NQ", 50_000_000))
 (ts, te), (qs_h, qe_h) = synth.cfg5(NT, NQ)
+MODE = os.environ.get("MODE", "random")  # sorted: the queries ordered by start, as a sorted BED file would give them
+if MODE == "sorted":
+    o = np.argsort(qs_h, kind="stable")
+    qs_h, qe_h = qs_h[o], qe_h[o]
 t0 = time.perf_counter()
 ix = IntervalIndex()
 ix.append(ts, te)
@@ -54,7 +58,7 @@ key = d_ts[h].long() * (1 << 31) + h
 same = rep[1:] == rep[:-1]
 ok_order = bool((key[1:][same] >= key[:-1][same]).all().item())
 alg = NQ * 16 + total * 4 + NT * 8
-print(json.dumps(dict(workload="configs[4]: %d x %d join, G=2e9, len U[1,200], CSR in HBM" % (NQ, NT), ms=round(ms, 3),
+print(json.dumps(dict(workload="configs[4]: %d x %d join, G=2e9, len U[1,200], CSR in HBM, query order: %s" % (NQ, NT, MODE), ms=round(ms, 3),
                       mqueries_per_s=round(NQ / ms / 1e3, 1), mhits_per_s=round(total / ms / 1e3, 1), hits=total,
                       algorithmic_bytes=alg, achieved_gbs=round(alg / ms / 1e6, 1), frac_of_8tbs=round(alg / ms / 1e6 / 8000, 4),
                       index_build_s=round(build_s, 2), every_hit_overlaps=ok_overlap, counts_match_count_path=ok_counts,
