@@ -331,11 +331,17 @@ __device__ __forceinline__ int64_t part_tile_of_block(int64_t ntiles)
     return (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
 }
 
+// Histogram pass.  The LDS atomics that count a tile's buckets also hand every query its rank inside its (tile,
+// bucket) run, and after one block scan the workgroup knows where each bucket starts inside the tile -- so the
+// query's slot in the tile's sorted order (`lpos`, 16 bits) is written right here and the scatter needs no atomics
+// of its own (LDS atomics run at ~1 lane/clk/CU: 0.16 ms per 100M, paid once instead of twice).
 __global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const int32_t *__restrict__ qs, int64_t nq, PartGeom g,
                                                                unsigned *__restrict__ table /* [ntiles][PT_NB] */, int64_t ntiles,
-                                                               unsigned *__restrict__ unsorted /* may be NULL */)
+                                                               unsigned short *__restrict__ lpos, unsigned *__restrict__ unsorted /* may be NULL */)
 {
     __shared__ unsigned cnt[PT_NB];
+    __shared__ unsigned short toff[PT_NB];
+    __shared__ unsigned scan_tmp[16];
     const int64_t tile = part_tile_of_block(ntiles);
     if (tile >= ntiles) return;
     for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = 0;
@@ -345,6 +351,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const int32_t *__
     // While the starts stream by, notice whether they are already non-decreasing (a sorted BED file): such a batch
     // needs no bucketing at all and is answered by ivl_local_count_kernel instead (see there).
     bool descent = false;
+    unsigned br[PT_ITEMS];  // bucket << 16 | rank inside the (tile, bucket) run
     if (n == PT_TILE) {
         // full tile: 4 x 16-byte loads in flight per lane before the first atomic
         const int4 *q4 = reinterpret_cast<const int4 *>(qs + base);
@@ -359,29 +366,63 @@ __global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const int32_t *__
 #pragma unroll
         for (int j = 0; j < PT_ITEMS / 4; j++) {
             descent |= v[j].x > v[j].y || v[j].y > v[j].z || v[j].z > v[j].w || v[j].w > nxt[j];
-            const int bx = part_bucket(v[j].x, g), by = part_bucket(v[j].y, g), bz = part_bucket(v[j].z, g), bw = part_bucket(v[j].w, g);
+            const unsigned bx = part_bucket(v[j].x, g), by = part_bucket(v[j].y, g), bz = part_bucket(v[j].z, g), bw = part_bucket(v[j].w, g);
             // Sorted input puts the wave's 256 consecutive queries in one bucket, and 256 same-address LDS atomics
             // serialize (measured 4.4x on a sorted batch): one lane adds for the whole wave then.
-            const int b0 = __builtin_amdgcn_readfirstlane(bx);
+            const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bx);
             if (__all(bx == b0 && by == b0 && bz == b0 && bw == b0)) {
-                if (lane_id() == 0) atomicAdd(&cnt[b0], 256u);
+                unsigned r0 = 0;
+                if (lane_id() == 0) r0 = atomicAdd(&cnt[b0], 256u);
+                r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)r0) + 4u * (unsigned)lane_id();
+                br[4 * j + 0] = (b0 << 16) | (r0 + 0);
+                br[4 * j + 1] = (b0 << 16) | (r0 + 1);
+                br[4 * j + 2] = (b0 << 16) | (r0 + 2);
+                br[4 * j + 3] = (b0 << 16) | (r0 + 3);
             } else {
-                atomicAdd(&cnt[bx], 1u);
-                atomicAdd(&cnt[by], 1u);
-                atomicAdd(&cnt[bz], 1u);
-                atomicAdd(&cnt[bw], 1u);
+                br[4 * j + 0] = (bx << 16) | atomicAdd(&cnt[bx], 1u);
+                br[4 * j + 1] = (by << 16) | atomicAdd(&cnt[by], 1u);
+                br[4 * j + 2] = (bz << 16) | atomicAdd(&cnt[bz], 1u);
+                br[4 * j + 3] = (bw << 16) | atomicAdd(&cnt[bw], 1u);
             }
         }
     } else {
-        for (int j = threadIdx.x; j < n; j += PT_THREADS) {
-            int a = qs[base + j];
-            descent |= base + j + 1 < nq && a > qs[base + j + 1];
-            atomicAdd(&cnt[part_bucket(a, g)], 1u);
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            const int k = j * PT_THREADS + threadIdx.x;
+            if (k < n) {
+                int a = qs[base + k];
+                descent |= base + k + 1 < nq && a > qs[base + k + 1];
+                unsigned b = (unsigned)part_bucket(a, g);
+                br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
+            }
         }
     }
     if (unsorted && __ballot(descent) && lane_id() == 0 && *unsorted == 0) *unsorted = 1;
     __syncthreads();
-    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) table[tile * PT_NB + i] = cnt[i];
+    {
+        unsigned a = cnt[2 * threadIdx.x], b = cnt[2 * threadIdx.x + 1];
+        unsigned tot;
+        unsigned exc = block_exclusive_scan(a + b, OpSum(), 0u, scan_tmp, &tot);
+        toff[2 * threadIdx.x] = (unsigned short)exc;
+        toff[2 * threadIdx.x + 1] = (unsigned short)(exc + a);
+        *reinterpret_cast<uint2 *>(table + tile * PT_NB + 2 * threadIdx.x) = make_uint2(a, b);
+    }
+    __syncthreads();
+    if (n == PT_TILE) {
+        uint2 *l4 = reinterpret_cast<uint2 *>(lpos + base);  // four 16-bit slots per 8-byte store
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS / 4; j++) {
+            unsigned s0 = toff[br[4 * j + 0] >> 16] + (br[4 * j + 0] & 0xffffu), s1 = toff[br[4 * j + 1] >> 16] + (br[4 * j + 1] & 0xffffu);
+            unsigned s2 = toff[br[4 * j + 2] >> 16] + (br[4 * j + 2] & 0xffffu), s3 = toff[br[4 * j + 3] >> 16] + (br[4 * j + 3] & 0xffffu);
+            l4[j * PT_THREADS + threadIdx.x] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS; j++) {
+            const int k = j * PT_THREADS + threadIdx.x;
+            if (k < n) lpos[base + k] = (unsigned short)(toff[br[j] >> 16] + (br[j] & 0xffffu));
+        }
+    }
 }
 
 // The table is tile-major ([tile][bucket], every workgroup reads/writes its own 8 KiB row coalesced).
@@ -459,93 +500,75 @@ __global__ __launch_bounds__(PT_THREADS) void part_colscan_kernel(unsigned *__re
 }
 
 // One workgroup moves one tile of 16384 queries into bucket order.  A scattered 4-byte store
-// costs a whole L2 request, so the tile is ordered INSIDE LDS first (ranks from LDS atomics,
-// (qs,qe) pairs written to their sorted slot) and then streamed out: consecutive lanes store
-// to consecutive addresses, one request per (tile, bucket) run.  `lpos` remembers, per query in
-// original order, its slot in the tile's sorted order (16 bits) for the gather on the way back.
+// costs a whole L2 request, so the tile is ordered INSIDE LDS first ((qs,qe) pairs written to the
+// slot of the tile's sorted order that the histogram pass recorded in `lpos`) and then streamed
+// out: consecutive lanes store to consecutive addresses, one request per (tile, bucket) run.
 __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
                                                                   int64_t nq, PartGeom g,
                                                                   const unsigned *__restrict__ tile_table /* [ntiles][PT_NB] */,
                                                                   int64_t ntiles, int32_t *__restrict__ qs_out,
                                                                   int32_t *__restrict__ qe_out,
-                                                                  unsigned short *__restrict__ lpos /* may be NULL */,
-                                                                  const unsigned *__restrict__ unsorted /* part_hist's flag or NULL */,
-                                                                  int skip_sorted /* 1: a sorted batch is answered elsewhere */)
+                                                                  const unsigned short *__restrict__ lpos,
+                                                                  const unsigned *__restrict__ gate)
 {
-    // LDS: half a tile of (qs, qe) pairs (64 KiB) + two 2048-entry tables (16 KiB) = 80 KiB; the tile goes through the
-    // staging area in two halves.  The tile's pairs and slots live in registers (102 VGPRs), so in practice ONE
-    // workgroup runs per CU; keeping only the slots and re-reading the pairs when they are staged (58 VGPRs, two
-    // workgroups per CU) measured 0.93 ms against 0.64 ms, and forcing 64 VGPRs spills 32 of them.
+    // LDS: half a tile of (qs, qe) pairs (64 KiB) + one 2048-entry table (8 KiB); the tile goes through the staging
+    // area in two halves.  The tile's pairs and slots live in registers, so in practice ONE workgroup runs per CU;
+    // keeping only the slots and re-reading the pairs when they are staged (58 VGPRs, two workgroups per CU) measured
+    // 0.93 ms against 0.64 ms, and forcing 64 VGPRs spills 32 of them.
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     constexpr int HALF = PT_TILE / 2;
     int2 *staged = reinterpret_cast<int2 *>(dyn);                    // [HALF] (qs, qe) in bucket order
-    unsigned *cnt = reinterpret_cast<unsigned *>(dyn + 2 * HALF);     // [PT_NB] counts, later (global base - tile offset)
-    unsigned *toff = cnt + PT_NB;                                     // [PT_NB] start of each bucket inside the tile
+    unsigned *delta = reinterpret_cast<unsigned *>(dyn + 2 * HALF);   // [PT_NB] global base of the (tile, bucket) run - its offset in the tile
     unsigned *scan_tmp = reinterpret_cast<unsigned *>(dyn);           // the staging area is idle during the scan
     const int64_t tile = part_tile_of_block(ntiles);
     if (tile >= ntiles) return;
-    const bool is_sorted = unsorted && *unsorted == 0;  // (the load overlaps the clearing)
-    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = 0;
-    __syncthreads();
-    if (is_sorted && skip_sorted) return;
+    const unsigned go = gate ? *gate : 1u;  // 0 = sorted batch, answered elsewhere
     const int64_t base = tile * PT_TILE;
     const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
     int s[PT_ITEMS], e[PT_ITEMS];
-    unsigned br[PT_ITEMS];  // bucket << 16 | rank inside (tile, bucket); later the slot in the tile's sorted order
+    unsigned slot[PT_ITEMS];
+    if (go == 0) return;
 #pragma unroll
     for (int j = 0; j < PT_ITEMS; j++) {
         int k = j * PT_THREADS + threadIdx.x;
         if (k < n) {
             s[j] = qs[base + k];
             e[j] = qe[base + k];
-        }
-        unsigned b = k < n ? (unsigned)part_bucket(s[j], g) : ~0u;
-        const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
-        // Sorted batch (find path): the wave's 64 consecutive queries mostly share a bucket and 64 same-address LDS
-        // atomics serialise -- one lane adds for the wave, ranks by lane.  Not even tested for on unsorted batches.
-        if (is_sorted && __all(b == b0) && b0 != ~0u) {
-            unsigned r0 = 0;
-            if (lane_id() == 0) r0 = atomicAdd(&cnt[b0], 64u);
-            br[j] = (b0 << 16) | ((unsigned)__builtin_amdgcn_readfirstlane((int)r0) + (unsigned)lane_id());
-        } else if (k < n) {
-            br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
+            slot[j] = lpos[base + k];
         }
     }
-    __syncthreads();
     {
-        unsigned a = cnt[2 * threadIdx.x], b = cnt[2 * threadIdx.x + 1];
-        unsigned tot;
-        unsigned exc = block_exclusive_scan(a + b, OpSum(), 0u, scan_tmp, &tot);
-        toff[2 * threadIdx.x] = exc;
-        toff[2 * threadIdx.x + 1] = exc + a;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = tile_table[tile * PT_NB + i] - toff[i];
+        // Tile counts = distance to the next entry of the (linear, bucket-major) exclusive scan: the next
+        // tile's entry for the same bucket, or -- for the last tile -- tile 0's entry of the next bucket.
+        const bool last_tile = tile + 1 == ntiles;
+        const unsigned *row = tile_table + tile * PT_NB;
+        const unsigned *next = last_tile ? tile_table : row + PT_NB;
+        unsigned c[2], lo[2];
 #pragma unroll
-    for (int j = 0; j < PT_ITEMS; j++) {
-        int k = j * PT_THREADS + threadIdx.x;
-        if (k < n) {
-            br[j] = toff[br[j] >> 16] + (br[j] & 0xffffu);
-            if (lpos) lpos[base + k] = (unsigned short)br[j];
+        for (int u = 0; u < 2; u++) {
+            int b = 2 * threadIdx.x + u;
+            lo[u] = row[b];
+            unsigned hi = !last_tile ? next[b] : (b + 1 < PT_NB ? next[b + 1] : (unsigned)nq);
+            c[u] = hi - lo[u];
         }
+        unsigned tot;
+        unsigned exc = block_exclusive_scan(c[0] + c[1], OpSum(), 0u, scan_tmp, &tot);
+        delta[2 * threadIdx.x] = lo[0] - exc;
+        delta[2 * threadIdx.x + 1] = lo[1] - (exc + c[0]);
     }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        __syncthreads();  // tables ready (half 0) / previous half streamed out (half 1)
+        __syncthreads();  // table ready, scan scratch free (half 0) / previous half streamed out (half 1)
 #pragma unroll
         for (int j = 0; j < PT_ITEMS; j++) {
             int k = j * PT_THREADS + threadIdx.x;
-            if (k < n && (int)(br[j] / HALF) == half) staged[br[j] & (HALF - 1)] = make_int2(s[j], e[j]);
+            if (k < n && (int)(slot[j] / HALF) == half) staged[slot[j] & (HALF - 1)] = make_int2(s[j], e[j]);
         }
         __syncthreads();
         const int m = n - half * HALF < HALF ? n - half * HALF : HALF;
         for (int p = threadIdx.x; p < m; p += PT_THREADS) {
             int2 v = staged[p];
-#ifdef BXMI_DEBUG_LINEAR_SCATTER  // timing experiment only (wrong results): how much do the run-scattered stores cost?
-            unsigned d = (unsigned)(base + p + half * HALF);
-#else
-            unsigned d = cnt[part_bucket(v.x, g)] + (unsigned)(p + half * HALF);  // global base of the run + offset inside it
-#endif
+            unsigned d = delta[part_bucket(v.x, g)] + (unsigned)(p + half * HALF);  // global base of the run + offset inside it
             qs_out[d] = v.x;
             qe_out[d] = v.y;
         }
@@ -1599,16 +1622,16 @@ static int part_prepare(bxmi_ivl *h, int sub, int64_t q0, const int32_t *qs, con
     pp->plan = h->p_plan.as<int32_t>() + (int64_t)sub * (PT_NB + 8);
     pp->bqs = h->p_qs.as<int32_t>() + q0;
     pp->bqe = h->p_qe.as<int32_t>() + q0;
-    pp->lpos = want_lpos ? h->p_dest.as<unsigned short>() + q0 : nullptr;
+    pp->lpos = h->p_dest.as<unsigned short>() + q0;  // written by the histogram pass, read by the scatter (and the gather)
     hipLaunchKernelGGL(part_hist_kernel, dim3(pp->tgrid), dim3(PT_THREADS), 0, st, qs, nq, h->geom, pp->table, pp->ntiles,
-                       unsorted);
+                       pp->lpos, unsorted);
     hipLaunchKernelGGL(part_colsum_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, pp->table, pp->ntiles, rows_per_block, partial, gate);
     hipLaunchKernelGGL(part_colbase_kernel, dim3(1), dim3(PT_THREADS), 0, st, partial, nrb, nq, pp->plan, gate);
     hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, pp->table, pp->ntiles, rows_per_block, partial, gate);
     BXMI_LAUNCH_CHECK();
-    const size_t scat_lds = (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned);
+    const size_t scat_lds = (size_t)(PT_TILE / 2) * 8 + PT_NB * sizeof(unsigned);
     hipLaunchKernelGGL(part_scatter_kernel, dim3(pp->tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, pp->table, pp->ntiles, pp->bqs,
-                       pp->bqe, pp->lpos, unsorted, skip_sorted ? 1 : 0);
+                       pp->bqe, pp->lpos, gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -1622,11 +1645,9 @@ static int part_reserve(bxmi_ivl *h, int64_t nq, bool want_lpos)
     BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOT_STRIDE * sizeof(unsigned long long)));
     BXMI_TRY(h->p_table.reserve((size_t)(div_up(nq, PT_TILE) + PT_MAX_SUB) * PT_NB * sizeof(unsigned)));
     BXMI_TRY(h->p_hist.reserve((size_t)PT_MAX_SUB * 80 * PT_NB * sizeof(unsigned)));
-    if (want_lpos) {
-        BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
-        BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
-    }
-    BXMI_TRY(allow_big_lds(part_scatter_kernel, (size_t)(PT_TILE / 2) * 8 + 2 * PT_NB * sizeof(unsigned)));
+    BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
+    if (want_lpos) BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(allow_big_lds(part_scatter_kernel, (size_t)(PT_TILE / 2) * 8 + PT_NB * sizeof(unsigned)));
     return BXMI_OK;
 }
 
