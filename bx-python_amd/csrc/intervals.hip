@@ -295,7 +295,10 @@ constexpr int PT_THREADS = 1024;
 #endif
 constexpr int PT_ITEMS = BXMI_PT_ITEMS;
 constexpr int PT_TILE = PT_THREADS * PT_ITEMS;  // 16384 queries per partition tile (staged whole in LDS)
-constexpr int PT_CHUNK = 32768;             // queries per search workgroup
+#ifndef BXMI_PT_CHUNK
+#define BXMI_PT_CHUNK 32768
+#endif
+constexpr int PT_CHUNK = BXMI_PT_CHUNK;     // queries per search workgroup
 constexpr int PT_LDS_INTS = 19456;          // 76 KiB of slices per workgroup -> two workgroups per CU
 constexpr int PT_SLOTS = 64;                // spread the total over 64 counters (one atomic per workgroup)
 constexpr int PT_ILP = 4;                   // queries in flight per lane in the search kernel
@@ -731,14 +734,6 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
     if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
 }
 
-// ---- sorted batches: no bucketing at all ----
-// When the query starts are already non-decreasing (the usual BED file), 16384 consecutive queries touch one short
-// stretch of the sorted ends / starts.  One workgroup takes such a chunk as it lies: min/max of its keys (block
-// reduction), the four slice boundaries (8-lane walks of the index's 32-ary trees by the first wave), the slices
-// staged as LDS search trees exactly as in part_count_kernel, counts stored straight back in query order: 8 B read
-// and 4 B written per query, no scratch.  Nothing in here relies on the order for correctness -- an unsorted chunk
-// would just get long (sampled) slices and be slow -- the flag computed by part_hist_kernel only decides which of
-// the two paths does the work.
 __device__ __forceinline__ int wave_min_i32(int v)
 {
 #pragma unroll
@@ -758,6 +753,201 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return v;
 }
 
+// ---- the same search with direct addressing instead of trees (default) ----
+// Inside one bucket the keys are close to uniform, so most of a binary search is wasted: the bucket's coordinate
+// range is cut into 4096 (+512 for the starts, whose keys reach W/8 past the bucket) equal cells, `cs[c]` = number of
+// slice keys whose cell is below c (16 bits), and a rank is  cs[cell(key)] + (a 2-4 step search among the cell's
+// own keys)  -- the step count is the bit length of the fullest cell, found while staging, so dense or clumped
+// buckets just take more steps and stay exact.  cell() is monotone (clamped), hence keys in lower cells are smaller
+// and keys in higher cells larger than the probe whatever the clamping does.  ~20 lane-instructions per rank
+// instead of ~52 for the 13-level tree.
+constexpr int PC_CELLS_LOG2 = 12;
+constexpr int PC_NC = (1 << PC_CELLS_LOG2) + (1 << (PC_CELLS_LOG2 - 3));  // 4608
+constexpr int PC_CS_INTS = (PC_NC + 2) / 2;                                // one 16-bit table, in ints
+#ifndef BXMI_PC_ILP
+#define BXMI_PC_ILP 4
+#endif
+constexpr int PC_ILP = BXMI_PC_ILP;  // queries in flight per lane
+constexpr int PC_PAD = 64;                                                 // INT_MAX fence after each slice: searches of <= 6 steps need no bound check
+constexpr int PC_KEYS = (PT_LDS_INTS - 2 * PC_CS_INTS - 2 * PC_PAD) / 2;  // keys (or samples) per staged slice: 7 359
+
+struct CellMap {
+    int lo;      // coordinate of cell 0
+    int cshift;  // cell width = 1 << cshift
+};
+__device__ __forceinline__ int cell_of(int x, CellMap m)
+{
+    unsigned d = ((unsigned)x - (unsigned)m.lo) >> m.cshift;
+    d = d < (unsigned)(PC_NC - 1) ? d : (unsigned)(PC_NC - 1);
+    return x < m.lo ? 0 : (int)d;
+}
+
+// Stage m = n / stride samples of a sorted slice linearly (arr[m] = INT_MAX fence) and build its cell table.
+// Returns the number of search steps: the bit length of the fullest cell.
+__device__ __forceinline__ int cells_stage(int32_t *arr, unsigned short *cs, const int32_t *__restrict__ src, int n, int stride, CellMap cm,
+                                           int *s_red /* [16] */)
+{
+    const int m = n / stride;
+    for (int r = threadIdx.x; r < m; r += PT_THREADS) arr[r] = src[(r + 1) * stride - 1];
+    if (threadIdx.x < PC_PAD) arr[m + threadIdx.x] = INT_MAX;
+    __syncthreads();
+    // element r opens every cell in (cell(arr[r-1]), cell(arr[r])]; the virtual element m closes the table
+    for (int r = threadIdx.x; r <= m; r += PT_THREADS) {
+        const int cp = r == 0 ? -1 : cell_of(arr[r - 1], cm);
+        const int cr = r == m ? PC_NC - 1 : cell_of(arr[r], cm);
+        for (int c = cp + 1; c <= cr; c++) cs[c] = (unsigned short)r;
+    }
+    __syncthreads();
+    int pop = 0;
+    for (int c = threadIdx.x; c < PC_NC; c += PT_THREADS) {
+        int p = (c + 1 < PC_NC ? (int)cs[c + 1] : m) - (int)cs[c];
+        pop = p > pop ? p : pop;
+    }
+    pop = wave_max_i32(pop);
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = pop;
+    __syncthreads();
+    pop = 0;
+#pragma unroll
+    for (int i = 0; i < PT_THREADS / 64; i++) pop = s_red[i] > pop ? s_red[i] : pop;
+    __syncthreads();
+    return 32 - __clz(pop);  // 0 for an empty slice
+}
+
+__global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
+                                                                      const SliceBound *__restrict__ bounds,
+                                                                      const int32_t *__restrict__ wg_first,
+                                                                      const unsigned *__restrict__ table /* row 0 = bucket offsets */,
+                                                                      const int32_t *__restrict__ qs_arr,
+                                                                      const int32_t *__restrict__ qe_arr, int64_t nq, PartGeom g,
+                                                                      int32_t *__restrict__ counts /* bucket order, may be NULL */,
+                                                                      unsigned long long *__restrict__ total_slots,
+                                                                      const unsigned *__restrict__ gate)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ int s_bucket;
+    __shared__ int s_red[PT_THREADS / 64];
+    __shared__ long long red[PT_THREADS / 64];
+    int b;
+    int64_t q_begin, q_end;
+    const unsigned go = gate ? *gate : 1u;  // 0 = sorted batch, answered by ivl_local_count_kernel
+    if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end) || go == 0) return;
+    const SliceBound sb = bounds[b];
+    const int nE = sb.eHi - sb.eLo, nS = sb.sHi - sb.sLo;
+    // strides chosen for the tree kernel may be finer than this layout holds: widen if needed
+    const int strideE = nE / sb.strideE > PC_KEYS ? nE / PC_KEYS + 1 : sb.strideE;
+    const int strideS = nS / sb.strideS > PC_KEYS ? nS / PC_KEYS + 1 : sb.strideS;
+    const int mE = nE / strideE, mS = nS / strideS;
+    CellMap cm;
+    {
+        long long lo = (long long)g.cmin + ((long long)b << g.shift);
+        cm.lo = lo > INT_MAX ? INT_MAX : (int)lo;
+        cm.cshift = g.shift > PC_CELLS_LOG2 ? g.shift - PC_CELLS_LOG2 : 0;
+    }
+    unsigned short *csE = reinterpret_cast<unsigned short *>(lds), *csS = reinterpret_cast<unsigned short *>(lds + PC_CS_INTS);
+    int32_t *arrE = lds + 2 * PC_CS_INTS, *arrS = arrE + mE + PC_PAD;
+    const int stepsE = cells_stage(arrE, csE, e_sorted + sb.eLo, nE, strideE, cm, s_red);
+    const int stepsS = cells_stage(arrS, csS, ix.s_ord + sb.sLo, nS, strideS, cm, s_red);
+    // positions are kept as LDS byte offsets of "the last key known to be below the probe" (one add + one read per step)
+    const char *ldsb = reinterpret_cast<const char *>(lds);
+    const int baseE = (2 * PC_CS_INTS) * 4, baseS = baseE + (mE + PC_PAD) * 4, endE = baseE + mE * 4, endS = baseS + mS * 4;
+    const bool fenced = stepsE <= 6 && stepsS <= 6;  // every probe stays inside the INT_MAX fence
+    const bool inner = b > 0 && b < PT_NB - 1;        // the bucket's own starts need no clamping
+    // The common case -- an ordinary query (qs < qe, qe inside the staged slice) against unsampled slices -- is kept
+    // lean: 32-bit offsets from the chunk's base, count = (pS - pE) / 4 + constant, one test for "anything unusual".
+    const unsigned nch = (unsigned)(q_end - q_begin);
+    const int32_t *__restrict__ qsb = qs_arr + q_begin;
+    const int32_t *__restrict__ qeb = qe_arr + q_begin;
+    int32_t *__restrict__ cb = counts ? counts + q_begin : nullptr;
+    const bool unsampled = strideS == 1 && strideE == 1;
+    const int cconst = (sb.sLo - sb.eLo) - ((baseS - baseE) >> 2);
+    long long acc = 0;
+    for (unsigned u0 = threadIdx.x; u0 < nch; u0 += PT_THREADS * PC_ILP) {
+        int qs[PC_ILP], qe[PC_ILP], pS[PC_ILP], pE[PC_ILP];
+#pragma unroll
+        for (int j = 0; j < PC_ILP; j++) {
+            unsigned u = u0 + (unsigned)j * PT_THREADS;
+            u = u < nch ? u : nch - 1;  // a valid address: no branch around the loads
+            qs[j] = qsb[u];
+            qe[j] = qeb[u];
+        }
+#pragma unroll
+        for (int j = 0; j < PC_ILP; j++) {
+            const int cE = inner ? (int)(((unsigned)qs[j] - (unsigned)cm.lo) >> cm.cshift) : cell_of(qs[j], cm);
+            pS[j] = baseS + (int)csS[cell_of(qe[j], cm)] * 4 - 4;
+            pE[j] = baseE + (int)csE[cE] * 4 - 4;
+        }
+        // only keys of the probe's own cell can still qualify, everything in later cells is larger, the fence stops the walk
+        if (fenced) {
+            for (int st = stepsS - 1; st >= 0; st--) {
+#pragma unroll
+                for (int j = 0; j < PC_ILP; j++) {
+                    const int t = pS[j] + (4 << st);
+                    pS[j] = *reinterpret_cast<const int32_t *>(ldsb + t) < qe[j] ? t : pS[j];
+                }
+            }
+            for (int st = stepsE - 1; st >= 0; st--) {
+#pragma unroll
+                for (int j = 0; j < PC_ILP; j++) {
+                    const int t = pE[j] + (4 << st);
+                    pE[j] = *reinterpret_cast<const int32_t *>(ldsb + t) <= qs[j] ? t : pE[j];  // (qs == INT_MAX passes the fence: handled below)
+                }
+            }
+        } else {
+            for (int st = stepsS - 1; st >= 0; st--) {
+#pragma unroll
+                for (int j = 0; j < PC_ILP; j++) {
+                    int t = pS[j] + (4 << st);
+                    t = t < endS ? t : endS;
+                    pS[j] = *reinterpret_cast<const int32_t *>(ldsb + t) < qe[j] ? t : pS[j];
+                }
+            }
+            for (int st = stepsE - 1; st >= 0; st--) {
+#pragma unroll
+                for (int j = 0; j < PC_ILP; j++) {
+                    int t = pE[j] + (4 << st);
+                    t = t < endE ? t : endE;
+                    pE[j] = *reinterpret_cast<const int32_t *>(ldsb + t) <= qs[j] ? t : pE[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PC_ILP; j++) {
+            const unsigned u = u0 + (unsigned)j * PT_THREADS;
+            int c = ((pS[j] - pE[j]) >> 2) + cconst;  // (sLo + #starts < qe) - (eLo + #ends <= qs)
+            const bool ordinary = unsampled && qs[j] < qe[j] && qe[j] >= sb.qeLo && qe[j] <= sb.qeHi;
+            if (!ordinary) {
+                // sampled slices: finish each rank inside its group; qe outside the slice: global search;
+                // zero-length / reversed query: exact predicate over the candidate window
+                int rS = (((pS[j] - baseS) >> 2) + 1) * strideS, rE = (((pE[j] - baseE) >> 2) + 1) * strideE;
+                if (strideS > 1) rS = group_rank_lt(ix.s_ord + sb.sLo, rS, rS + strideS < nS ? rS + strideS : nS, qe[j]);
+                if (strideE > 1 && qs[j] != INT_MAX) rE = group_rank_lt(e_sorted + sb.eLo, rE, rE + strideE < nE ? rE + strideE : nE, qs[j] + 1);
+                const bool in_slice = qe[j] >= sb.qeLo && qe[j] <= sb.qeHi;
+                const int s_rank = in_slice ? sb.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe[j]);
+                if (qs[j] < qe[j]) {
+                    c = s_rank - (sb.eLo + rE);  // (qs < qe rules out qs == INT_MAX)
+                } else {
+                    int lo = first_pm_gt(ix.pm, ix.n, qs[j]);
+                    c = 0;
+                    for (int k = lo; k < s_rank; k++) c += ix.e_ord[k] > qs[j];
+                }
+            }
+            if (u < nch) {
+                if (cb) cb[u] = c;
+                acc += c;
+            }
+        }
+    }
+    if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
+}
+
+// ---- sorted batches: no bucketing at all ----
+// When the query starts are already non-decreasing (the usual BED file), 16384 consecutive queries touch one short
+// stretch of the sorted ends / starts.  One workgroup takes such a chunk as it lies: min/max of its keys (block
+// reduction), the four slice boundaries (8-lane walks of the index's 32-ary trees by the first wave), the slices
+// staged as LDS search trees exactly as in part_count_kernel, counts stored straight back in query order: 8 B read
+// and 4 B written per query, no scratch.  Nothing in here relies on the order for correctness -- an unsorted chunk
+// would just get long (sampled) slices and be slow -- the flag computed by part_hist_kernel only decides which of
+// the two paths does the work.
 constexpr int LC_THREADS = 512;
 constexpr int LC_ITEMS = 8;
 constexpr int LC_CHUNK = LC_THREADS * LC_ITEMS;  // 4096 consecutive queries per workgroup
@@ -1525,6 +1715,7 @@ static int64_t g_opt_partition_min = 4 << 20;  // auto: partition batches of at 
 static int64_t g_opt_pipeline = 1;    // sub-batches on forked streams; measured: no gain (2: -2 %, 4: +10 %), so off by default
 constexpr int PT_MAX_SUB = 8;
 constexpr int PT_SLOT_STRIDE = PT_SLOTS + 8;  // per sub-batch: the partial totals, then the "unsorted" flag
+static int64_t g_opt_count_cells = 1;  // 1 = direct-addressed cells in the bucket search, 0 = LDS search trees
 static int64_t g_opt_sorted_path = 1;  // 1 = batches whose starts are already sorted skip the bucketing (detected on the device)
 
 int ivl_set_option(const char *key, int64_t value)
@@ -1547,6 +1738,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.pipeline")) {
         g_opt_pipeline = value < 1 ? 1 : value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.count_cells")) {
+        g_opt_count_cells = value != 0;
         return 1;
     }
     if (!strcmp(key, "ivl.sorted_path")) {
@@ -1669,9 +1864,14 @@ static int ivl_count_part_sub(bxmi_ivl *h, int sub, int64_t q0, const int32_t *q
                            h->e_sorted.as<int32_t>(), qs, qe, nq, counts, total_dev ? slots : nullptr, unsorted);
     }
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
-    hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h), h->e_sorted.as<int32_t>(),
-                       h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bqs, pp.bqe, nq, counts ? h->p_cnt.as<int32_t>() + q0 : nullptr,
-                       total_dev ? slots : nullptr, unsorted);
+    if (g_opt_count_cells)
+        hipLaunchKernelGGL(part_count_cells_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
+                           h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bqs, pp.bqe, nq, h->geom,
+                           counts ? h->p_cnt.as<int32_t>() + q0 : nullptr, total_dev ? slots : nullptr, unsorted);
+    else
+        hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h), h->e_sorted.as<int32_t>(),
+                           h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bqs, pp.bqe, nq, counts ? h->p_cnt.as<int32_t>() + q0 : nullptr,
+                           total_dev ? slots : nullptr, unsorted);
     BXMI_LAUNCH_CHECK();
     if (counts) {
         hipLaunchKernelGGL(part_gather_kernel, dim3(pp.tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>() + q0, pp.lpos, pp.table, pp.ntiles,
@@ -1697,6 +1897,7 @@ static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *
     const int64_t per = div_up(div_up(nq, nsub), PT_TILE) * PT_TILE;
     BXMI_TRY(part_reserve(h, nq, counts != nullptr));
     BXMI_TRY(allow_big_lds(part_count_kernel, (size_t)PT_LDS_INTS * 4));
+    BXMI_TRY(allow_big_lds(part_count_cells_kernel, (size_t)PT_LDS_INTS * 4));
     if (nsub == 1) return ivl_count_part_sub(h, 0, 0, qs, qe, nq, counts, total_dev, st);
     // fork: side streams wait for everything already queued on the caller's stream
     if (!h->ev_fork) {

@@ -153,10 +153,15 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     try:
         got_c, got_t = ix.count(qs, qe)
         tot_only = ix.count(qs, qe, want_counts=False)[1]
+        set_opt("ivl.count_cells", 0)  # the LDS-search-tree variant of the bucket search
+        tree_c, tree_t = ix.count(qs, qe)
+        set_opt("ivl.count_cells", 1)
         if not ix.has_reversed:
             p_off, p_hits = ix.find(qs, qe)
     finally:
+        set_opt("ivl.count_cells", 1)
         set_opt("ivl.partition", -1)
+    assert np.array_equal(tree_c, want_c) and tree_t == want_t, "partitioned, tree variant"
     if not ix.has_reversed:
         w_off, w_hits = t.find_batch(qs, qe)
         assert np.array_equal(p_off, w_off) and np.array_equal(p_hits, w_hits), "partitioned find"
@@ -235,9 +240,14 @@ def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
     set_opt("ivl.partition", 1)
     try:
         got, got_total = ix.count(qs, qe)
+        set_opt("ivl.count_cells", 0)
+        tree, tree_total = ix.count(qs, qe)
+        set_opt("ivl.count_cells", 1)
         p_off, p_hits = ix.find(qs[:20000], qe[:20000])
     finally:
+        set_opt("ivl.count_cells", 1)
         set_opt("ivl.partition", -1)
+    assert np.array_equal(tree, want) and tree_total == want_total, "tree variant"
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got[bad[:5]], want[bad[:5]])
     assert got_total == want_total
