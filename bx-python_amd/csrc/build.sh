@@ -8,6 +8,8 @@ OBJ="$HERE/_obj"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 ${BXMI_DEFS:-} -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${BXMI_EXTRA_FLAGS:-}"
 mkdir -p "$OBJ"
+# a change of flags (BXMI_DEFS experiments) must rebuild everything
+if [ "$(cat "$OBJ/.flags" 2>/dev/null)" != "$FLAGS" ]; then rm -f "$OBJ"/*.o; echo "$FLAGS" > "$OBJ/.flags"; fi
 pids=()
 for f in core intervals bitset bedparse; do
   src="$HERE/$f.hip"; [ -f "$src" ] || src="$HERE/$f.cpp"

@@ -296,7 +296,7 @@ constexpr int PT_THREADS = 1024;
 constexpr int PT_ITEMS = BXMI_PT_ITEMS;
 constexpr int PT_TILE = PT_THREADS * PT_ITEMS;  // 16384 queries per partition tile (staged whole in LDS)
 #ifndef BXMI_PT_CHUNK
-#define BXMI_PT_CHUNK 32768
+#define BXMI_PT_CHUNK 65536
 #endif
 constexpr int PT_CHUNK = BXMI_PT_CHUNK;     // queries per search workgroup
 constexpr int PT_LDS_INTS = 19456;          // 76 KiB of slices per workgroup -> two workgroups per CU
