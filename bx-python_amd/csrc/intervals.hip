@@ -509,15 +509,15 @@ __global__ __launch_bounds__(PT_THREADS) void part_colscan_kernel(unsigned *__re
 __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
                                                                   int64_t nq, PartGeom g,
                                                                   const unsigned *__restrict__ tile_table /* [ntiles][PT_NB] */,
-                                                                  int64_t ntiles, int32_t *__restrict__ qs_out,
-                                                                  int32_t *__restrict__ qe_out,
+                                                                  int64_t ntiles, int2 *__restrict__ pairs_out /* (qs, qe) in bucket order */,
                                                                   const unsigned short *__restrict__ lpos,
                                                                   const unsigned *__restrict__ gate)
 {
     // LDS: half a tile of (qs, qe) pairs (64 KiB) + one 2048-entry table (8 KiB); the tile goes through the staging
     // area in two halves.  The tile's pairs and slots live in registers, so in practice ONE workgroup runs per CU;
-    // keeping only the slots and re-reading the pairs when they are staged (58 VGPRs, two workgroups per CU) measured
-    // 0.93 ms against 0.64 ms, and forcing 64 VGPRs spills 32 of them.
+    // keeping only the slots and re-reading the pairs for each half (64 VGPRs, two workgroups per CU) measured 0.61 ms
+    // against 0.46 ms even with all loads of a group issued up front -- more tiles in flight spread the four runs that
+    // share a 128-byte line further apart in time.
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     constexpr int HALF = PT_TILE / 2;
     int2 *staged = reinterpret_cast<int2 *>(dyn);                    // [HALF] (qs, qe) in bucket order
@@ -572,8 +572,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
         for (int p = threadIdx.x; p < m; p += PT_THREADS) {
             int2 v = staged[p];
             unsigned d = delta[part_bucket(v.x, g)] + (unsigned)(p + half * HALF);  // global base of the run + offset inside it
-            qs_out[d] = v.x;
-            qe_out[d] = v.y;
+            pairs_out[d] = v;  // one 8-byte store: a (tile, bucket) run is 64 contiguous bytes
         }
     }
 }
@@ -640,8 +639,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
                                                                 const SliceBound *__restrict__ bounds,
                                                                 const int32_t *__restrict__ wg_first,
                                                                 const unsigned *__restrict__ table /* row 0 = bucket offsets */,
-                                                                const int32_t *__restrict__ qs_arr,
-                                                                const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                                const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
                                                                 int32_t *__restrict__ counts /* bucket order, may be NULL */,
                                                                 unsigned long long *__restrict__ total_slots,
                                                                 const unsigned *__restrict__ gate)
@@ -680,8 +678,9 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
         for (int j = 0; j < PT_ILP; j++) {
             int64_t i = i0 + (int64_t)j * PT_THREADS;
             live[j] = i < q_end;
-            qs[j] = live[j] ? qs_arr[i] : 0;
-            qe[j] = live[j] ? qe_arr[i] : 0;
+            const int2 v = live[j] ? pairs[i] : make_int2(0, 0);
+            qs[j] = v.x;
+            qe[j] = v.y;
             rS[j] = rE[j] = 1;
         }
         // PT_ILP x 2 independent descents in lockstep (same trees => same depth)
@@ -817,8 +816,8 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
                                                                       const SliceBound *__restrict__ bounds,
                                                                       const int32_t *__restrict__ wg_first,
                                                                       const unsigned *__restrict__ table /* row 0 = bucket offsets */,
-                                                                      const int32_t *__restrict__ qs_arr,
-                                                                      const int32_t *__restrict__ qe_arr, int64_t nq, PartGeom g,
+                                                                      const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
+                                                                      PartGeom g,
                                                                       int32_t *__restrict__ counts /* bucket order, may be NULL */,
                                                                       unsigned long long *__restrict__ total_slots,
                                                                       const unsigned *__restrict__ gate)
@@ -855,8 +854,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
     // The common case -- an ordinary query (qs < qe, qe inside the staged slice) against unsampled slices -- is kept
     // lean: 32-bit offsets from the chunk's base, count = (pS - pE) / 4 + constant, one test for "anything unusual".
     const unsigned nch = (unsigned)(q_end - q_begin);
-    const int32_t *__restrict__ qsb = qs_arr + q_begin;
-    const int32_t *__restrict__ qeb = qe_arr + q_begin;
+    const int2 *__restrict__ qb = pairs + q_begin;
     int32_t *__restrict__ cb = counts ? counts + q_begin : nullptr;
     const bool unsampled = strideS == 1 && strideE == 1;
     const int cconst = (sb.sLo - sb.eLo) - ((baseS - baseE) >> 2);
@@ -867,8 +865,9 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
         for (int j = 0; j < PC_ILP; j++) {
             unsigned u = u0 + (unsigned)j * PT_THREADS;
             u = u < nch ? u : nch - 1;  // a valid address: no branch around the loads
-            qs[j] = qsb[u];
-            qe[j] = qeb[u];
+            const int2 v = qb[u];
+            qs[j] = v.x;
+            qe[j] = v.y;
         }
 #pragma unroll
         for (int j = 0; j < PC_ILP; j++) {
@@ -1089,7 +1088,7 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
 // (one per bucket, contiguous in the bucketed array) into LDS in the tile's sorted order, then
 // every query picks its count through the 16-bit slot remembered by the scatter: all global
 // traffic is coalesced, the random access happens in LDS.
-__global__ __launch_bounds__(PT_THREADS) void part_gather_kernel(const int32_t *__restrict__ bucketed,
+__global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void part_gather_kernel(const int32_t *__restrict__ bucketed,
                                                                  const unsigned short *__restrict__ lpos,
                                                                  const unsigned *__restrict__ tile_table /* [ntiles][PT_NB] */,
                                                                  int64_t ntiles, int64_t nq, int32_t *__restrict__ out,
@@ -1125,14 +1124,56 @@ __global__ __launch_bounds__(PT_THREADS) void part_gather_kernel(const int32_t *
         if (threadIdx.x == 0) toff[PT_NB] = (unsigned short)tot;  // tot == n <= 16384
     }
     __syncthreads();
-    // 8 lanes per bucket run (runs average 8 queries): 128 runs in flight per pass over the buckets
-    const int sub = threadIdx.x & 7;
-    for (int b = threadIdx.x >> 3; b < PT_NB; b += PT_THREADS / 8) {
-        unsigned o = toff[b], len = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o, gb = gbase[b];
-        for (unsigned r = sub; r < len; r += 8) vals[o + r] = bucketed[gb + r];
+    // 8 lanes per bucket run (runs average 8 queries).  A lane's 16 runs are handled eight at a time with all loads
+    // of a round issued before the first LDS write: the loop "per run: load, store" is one dependent round trip per
+    // run (measured 29 us per tile, nearly all of it latency).
+    const unsigned sub = threadIdx.x & 7;
+    constexpr int RUNS = PT_NB / (PT_THREADS / 8);  // 16 runs per lane
+#pragma unroll
+    for (int g0 = 0; g0 < RUNS; g0 += 8) {
+        unsigned o[8], len[8], gb[8];
+        int v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int b = (int)(threadIdx.x >> 3) + (g0 + i) * (PT_THREADS / 8);
+            o[i] = toff[b];
+            len[i] = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o[i];
+            gb[i] = gbase[b];
+        }
+#pragma unroll
+        for (int round = 0; round < 2; round++) {  // elements sub and sub + 8 of every run
+            const unsigned r = sub + 8u * round;
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = r < len[i] ? bucketed[gb[i] + r] : 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (r < len[i]) vals[o[i] + r] = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {  // runs longer than 16 (rare; the whole tile for a sorted batch): the whole wave copies them
+            unsigned long long m = __ballot(sub == 0 && len[i] > 16);
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const unsigned oo = __shfl(o[i], src, 64), ll = __shfl(len[i], src, 64), gg = __shfl(gb[i], src, 64);
+                for (unsigned r = 16 + lane_id(); r < ll; r += 64) vals[oo + r] = bucketed[gg + r];
+            }
+        }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < n; k += PT_THREADS) out[base + k] = vals[lpos[base + k]];
+    if (n == PT_TILE) {
+        // a lane takes 4 consecutive queries: 8-byte loads of the slots, 16-byte stores of the counts, all loads first
+        const uint2 *l4 = reinterpret_cast<const uint2 *>(lpos + base);
+        int4 *o4 = reinterpret_cast<int4 *>(out + base);
+        uint2 sl[PT_ITEMS / 4];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS / 4; j++) sl[j] = l4[j * PT_THREADS + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < PT_ITEMS / 4; j++)
+            o4[j * PT_THREADS + threadIdx.x] = make_int4(vals[sl[j].x & 0xffffu], vals[sl[j].x >> 16], vals[sl[j].y & 0xffffu], vals[sl[j].y >> 16]);
+    } else {
+        for (int k = threadIdx.x; k < n; k += PT_THREADS) out[base + k] = vals[lpos[base + k]];
+    }
 }
 
 
@@ -1158,7 +1199,7 @@ __device__ __forceinline__ void window_stage(const IndexDev &ix, const WindowSli
     __syncthreads();
 }
 
-template <int THREADS>
+template <int THREADS, bool PAIRS /* qs_arr is an array of (qs, qe) pairs, qe_arr unused */>
 __device__ __forceinline__ void window_queries(const IndexDev &ix, const WindowSlices &w, const int32_t *treeP, const int32_t *treeS,
                                                int64_t q_begin, int64_t q_end, const int32_t *__restrict__ qs_arr,
                                                const int32_t *__restrict__ qe_arr, int32_t *__restrict__ win_lo,
@@ -1167,7 +1208,13 @@ __device__ __forceinline__ void window_queries(const IndexDev &ix, const WindowS
     const int sub = threadIdx.x & 7, gbase = lane_id() & ~7;
     for (int64_t i0 = q_begin + threadIdx.x; i0 - threadIdx.x < q_end; i0 += THREADS) {
         const bool live = i0 < q_end;
-        const int qs = live ? qs_arr[i0] : 0, qe = live ? qe_arr[i0] : 0;
+        int qs = 0, qe = 0;
+        if (PAIRS) {
+            const int2 v = live ? reinterpret_cast<const int2 *>(qs_arr)[i0] : make_int2(0, 0);
+            qs = v.x, qe = v.y;
+        } else if (live) {
+            qs = qs_arr[i0], qe = qe_arr[i0];
+        }
         int rS = 1, rP = 1;
         for (int it = 0; it < w.kS; it++) rS = 2 * rS + (treeS[rS] < qe);
         for (int it = 0; it < w.kP; it++) rP = 2 * rP + (treeP[rP] <= qs && qs != INT_MAX);
@@ -1217,8 +1264,7 @@ __device__ __forceinline__ void window_queries(const IndexDev &ix, const WindowS
 __global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, const SliceBound *__restrict__ bounds,
                                                                  const int32_t *__restrict__ wg_first,
                                                                  const unsigned *__restrict__ table,
-                                                                 const int32_t *__restrict__ qs_arr,
-                                                                 const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                                 const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
                                                                  int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
                                                                  int32_t *__restrict__ counts)
 {
@@ -1231,7 +1277,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, co
     const WindowSlices w = {sb.sLo, sb.sHi - sb.sLo, sb.kS, sb.strideS, sb.pLo, sb.pHi - sb.pLo, sb.kP, sb.strideP, sb.qeLo, sb.qeHi};
     int32_t *treeP, *treeS;
     window_stage<PT_THREADS>(ix, w, lds, treeP, treeS);
-    window_queries<PT_THREADS>(ix, w, treeP, treeS, q_begin, q_end, qs_arr, qe_arr, win_lo, win_hi, counts);
+    window_queries<PT_THREADS, true>(ix, w, treeP, treeS, q_begin, q_end, reinterpret_cast<const int32_t *>(pairs), nullptr, win_lo, win_hi, counts);
 }
 
 // find() on a batch whose starts are already sorted: the windows of 4096 consecutive queries as they lie (same idea
@@ -1294,7 +1340,7 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_window_kernel(TreeDev S,
     while ((1 << w.kS) - 1 < w.nS / w.strideS) w.kS++;
     int32_t *treeP, *treeS;
     window_stage<LC_THREADS>(ix, w, lds, treeP, treeS);
-    window_queries<LC_THREADS>(ix, w, treeP, treeS, base, base + n, qs_arr, qe_arr, win_lo, win_hi, counts);
+    window_queries<LC_THREADS, false>(ix, w, treeP, treeS, base, base + n, qs_arr, qe_arr, win_lo, win_hi, counts);
 }
 
 // Are the starts non-decreasing?  (find path: decided on the host before anything else is launched)
@@ -1375,7 +1421,8 @@ __device__ __forceinline__ int fill_step(int4 v, int4 id, int kb, int lo, int hi
 // lines per query, and each 8-lane group keeps FILL_Q queries in flight (metadata and the first step of every
 // window are loaded before any of them is compacted: the chain load-meta -> load-window -> store is latency bound).
 constexpr int FILL_Q = 4;
-__global__ __launch_bounds__(FIND_THREADS) void part_fill_kernel(IndexDev ix, const int32_t *__restrict__ qs_arr, int64_t nq,
+__global__ __launch_bounds__(FIND_THREADS) void part_fill_kernel(IndexDev ix, const int32_t *__restrict__ qs_arr, int qs_stride /* 2: (qs, qe) pairs */,
+                                                                int64_t nq,
                                                                 const int32_t *__restrict__ win_lo,
                                                                 const int32_t *__restrict__ win_hi,
                                                                 const int32_t *__restrict__ cnt,
@@ -1399,7 +1446,7 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_kernel(IndexDev ix, co
             const bool live = q < q1 && cnt[q] != 0;
             lo[j] = live ? win_lo[q] : 0;
             hi[j] = live ? win_hi[q] : 0;
-            qs[j] = live ? qs_arr[q] : 0;
+            qs[j] = live ? qs_arr[q * qs_stride] : 0;
             base[j] = live ? boffs[q] : 0;
         }
         int4 ve[FILL_Q], vi[FILL_Q];
@@ -1778,7 +1825,7 @@ struct bxmi_ivl {
     DevBuf q_s, q_e, q_cnt, q_lo, q_hi, q_off, q_hits, q_total;
     // partitioned count path
     PartGeom geom{0, 0};
-    DevBuf slice_bounds, p_hist, p_table, p_qs, p_qe, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
+    DevBuf slice_bounds, p_hist, p_table, p_pairs, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][hits...]
     hipStream_t sub_stream[PT_MAX_SUB] = {};
     hipEvent_t ev_fork = nullptr, ev_join[PT_MAX_SUB] = {};
@@ -1797,7 +1844,7 @@ struct PartPlan {
     unsigned tgrid;        // tile-kernel grid: 8 XCD ranges of ceil(ntiles/8) tiles
     unsigned *table;       // [ntiles][PT_NB] destination of every (tile, bucket) run; row 0 = bucket offsets
     int32_t *plan;         // first search workgroup of every bucket
-    int32_t *bqs, *bqe;    // the queries in bucket order
+    int2 *bq;              // the queries in bucket order, (qs, qe) pairs
     unsigned short *lpos;  // per query (original order): slot inside its tile's sorted order
 };
 
@@ -1815,8 +1862,7 @@ static int part_prepare(bxmi_ivl *h, int sub, int64_t q0, const int32_t *qs, con
     pp->table = h->p_table.as<unsigned>() + (q0 / PT_TILE) * PT_NB;
     unsigned *partial = h->p_hist.as<unsigned>() + (int64_t)sub * 80 * PT_NB;
     pp->plan = h->p_plan.as<int32_t>() + (int64_t)sub * (PT_NB + 8);
-    pp->bqs = h->p_qs.as<int32_t>() + q0;
-    pp->bqe = h->p_qe.as<int32_t>() + q0;
+    pp->bq = h->p_pairs.as<int2>() + q0;
     pp->lpos = h->p_dest.as<unsigned short>() + q0;  // written by the histogram pass, read by the scatter (and the gather)
     hipLaunchKernelGGL(part_hist_kernel, dim3(pp->tgrid), dim3(PT_THREADS), 0, st, qs, nq, h->geom, pp->table, pp->ntiles,
                        pp->lpos, unsorted);
@@ -1825,8 +1871,8 @@ static int part_prepare(bxmi_ivl *h, int sub, int64_t q0, const int32_t *qs, con
     hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, pp->table, pp->ntiles, rows_per_block, partial, gate);
     BXMI_LAUNCH_CHECK();
     const size_t scat_lds = (size_t)(PT_TILE / 2) * 8 + PT_NB * sizeof(unsigned);
-    hipLaunchKernelGGL(part_scatter_kernel, dim3(pp->tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, pp->table, pp->ntiles, pp->bqs,
-                       pp->bqe, pp->lpos, gate);
+    hipLaunchKernelGGL(part_scatter_kernel, dim3(pp->tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, pp->table, pp->ntiles, pp->bq,
+                       pp->lpos, gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -1834,8 +1880,7 @@ static int part_prepare(bxmi_ivl *h, int sub, int64_t q0, const int32_t *qs, con
 // Scratch for bucketing a batch of nq queries (grow-only).
 static int part_reserve(bxmi_ivl *h, int64_t nq, bool want_lpos)
 {
-    BXMI_TRY(h->p_qs.reserve((size_t)(nq + 4) * 4));
-    BXMI_TRY(h->p_qe.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->p_pairs.reserve((size_t)(nq + 4) * 8));
     BXMI_TRY(h->p_plan.reserve((size_t)PT_MAX_SUB * (PT_NB + 8) * sizeof(int32_t)));
     BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOT_STRIDE * sizeof(unsigned long long)));
     BXMI_TRY(h->p_table.reserve((size_t)(div_up(nq, PT_TILE) + PT_MAX_SUB) * PT_NB * sizeof(unsigned)));
@@ -1866,11 +1911,11 @@ static int ivl_count_part_sub(bxmi_ivl *h, int sub, int64_t q0, const int32_t *q
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
     if (g_opt_count_cells)
         hipLaunchKernelGGL(part_count_cells_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
-                           h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bqs, pp.bqe, nq, h->geom,
+                           h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bq, nq, h->geom,
                            counts ? h->p_cnt.as<int32_t>() + q0 : nullptr, total_dev ? slots : nullptr, unsorted);
     else
         hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h), h->e_sorted.as<int32_t>(),
-                           h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bqs, pp.bqe, nq, counts ? h->p_cnt.as<int32_t>() + q0 : nullptr,
+                           h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bq, nq, counts ? h->p_cnt.as<int32_t>() + q0 : nullptr,
                            total_dev ? slots : nullptr, unsorted);
     BXMI_LAUNCH_CHECK();
     if (counts) {
@@ -1942,7 +1987,7 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     if (total == 0) return BXMI_OK;
     int fgrid = device_props().cus * 8;
-    hipLaunchKernelGGL(part_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, nq, h->p_lo.as<int32_t>(),
+    hipLaunchKernelGGL(part_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->p_lo.as<int32_t>(),
                        h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
@@ -1966,13 +2011,12 @@ static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *q
     const int64_t ntiles = pp.ntiles;
     const unsigned tgrid = pp.tgrid;
     unsigned *table = pp.table;
-    int32_t *bqs = pp.bqs;
     unsigned short *lpos = pp.lpos;
     const size_t lds_bytes = (size_t)PT_LDS_INTS * 4;
     BXMI_TRY(allow_big_lds(part_window_kernel, lds_bytes));
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
     hipLaunchKernelGGL(part_window_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->slice_bounds.as<SliceBound>(), pp.plan,
-                       table, bqs, pp.bqe, nq, h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->p_cnt.as<int32_t>());
+                       table, pp.bq, nq, h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->p_cnt.as<int32_t>());
     hipLaunchKernelGGL(part_gather_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>(), lpos, table, ntiles, nq,
                        h->q_cnt.as<int32_t>(), (const unsigned *)nullptr);
     BXMI_LAUNCH_CHECK();
@@ -1989,7 +2033,8 @@ static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *q
     hipLaunchKernelGGL(part_permute_i64_kernel, dim3(tgrid), dim3(PT_THREADS), perm_lds, st, reinterpret_cast<const long long *>(offsets), lpos,
                        table, ntiles, nq, h->p_boffs.as<long long>());
     int fgrid = device_props().cus * 8;
-    hipLaunchKernelGGL(part_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), bqs, nq, h->p_lo.as<int32_t>(),
+    hipLaunchKernelGGL(part_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), reinterpret_cast<const int32_t *>(pp.bq), 2, nq,
+                       h->p_lo.as<int32_t>(),
                        h->p_hi.as<int32_t>(), h->p_cnt.as<int32_t>(), h->p_boffs.as<long long>(), hits);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
