@@ -771,15 +771,17 @@ constexpr int PC_PAD = 64;                                                 // IN
 constexpr int PC_KEYS = (PT_LDS_INTS - 2 * PC_CS_INTS - 2 * PC_PAD) / 2;  // keys (or samples) per staged slice: 7 359
 
 struct CellMap {
-    int lo;      // coordinate of cell 0
+    int lo, hi;  // coordinates of the first cell's first and the last cell's last position
     int cshift;  // cell width = 1 << cshift
 };
 __device__ __forceinline__ int cell_of(int x, CellMap m)
 {
-    unsigned d = ((unsigned)x - (unsigned)m.lo) >> m.cshift;
-    d = d < (unsigned)(PC_NC - 1) ? d : (unsigned)(PC_NC - 1);
-    return x < m.lo ? 0 : (int)d;
+    x = x < m.lo ? m.lo : x;  // (a v_med3_i32)
+    x = x > m.hi ? m.hi : x;
+    return (int)(((unsigned)x - (unsigned)m.lo) >> m.cshift);
 }
+typedef __attribute__((address_space(3))) const int32_t *lds_i32p;
+typedef __attribute__((address_space(3))) const unsigned short *lds_u16p;
 
 // Stage m = n / stride samples of a sorted slice linearly (arr[m] = INT_MAX fence) and build its cell table.
 // Returns the number of search steps: the bit length of the fullest cell.
@@ -841,26 +843,29 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
         long long lo = (long long)g.cmin + ((long long)b << g.shift);
         cm.lo = lo > INT_MAX ? INT_MAX : (int)lo;
         cm.cshift = g.shift > PC_CELLS_LOG2 ? g.shift - PC_CELLS_LOG2 : 0;
+        long long hi = (long long)cm.lo + ((long long)PC_NC << cm.cshift) - 1;
+        cm.hi = hi > INT_MAX ? INT_MAX : (int)hi;
     }
     unsigned short *csE = reinterpret_cast<unsigned short *>(lds), *csS = reinterpret_cast<unsigned short *>(lds + PC_CS_INTS);
     int32_t *arrE = lds + 2 * PC_CS_INTS, *arrS = arrE + mE + PC_PAD;
     const int stepsE = cells_stage(arrE, csE, e_sorted + sb.eLo, nE, strideE, cm, s_red);
     const int stepsS = cells_stage(arrS, csS, ix.s_ord + sb.sLo, nS, strideS, cm, s_red);
-    // positions are kept as LDS byte offsets of "the last key known to be below the probe" (one add + one read per step)
-    const char *ldsb = reinterpret_cast<const char *>(lds);
-    const int baseE = (2 * PC_CS_INTS) * 4, baseS = baseE + (mE + PC_PAD) * 4, endE = baseE + mE * 4, endS = baseS + mS * 4;
+    // positions are LDS pointers to "the last key known to be below the probe" (one add + one read per step)
+    const lds_i32p aE = (lds_i32p)arrE, aS = (lds_i32p)arrS;
+    const lds_u16p cE = (lds_u16p)csE, cS = (lds_u16p)csS;
     const bool fenced = stepsE <= 6 && stepsS <= 6;  // every probe stays inside the INT_MAX fence
-    const bool inner = b > 0 && b < PT_NB - 1;        // the bucket's own starts need no clamping
     // The common case -- an ordinary query (qs < qe, qe inside the staged slice) against unsampled slices -- is kept
-    // lean: 32-bit offsets from the chunk's base, count = (pS - pE) / 4 + constant, one test for "anything unusual".
+    // lean: 32-bit offsets from the chunk's base, count = (pS - pE) + constant, one test per round for "anything unusual".
     const unsigned nch = (unsigned)(q_end - q_begin);
     const int2 *__restrict__ qb = pairs + q_begin;
     int32_t *__restrict__ cb = counts ? counts + q_begin : nullptr;
     const bool unsampled = strideS == 1 && strideE == 1;
-    const int cconst = (sb.sLo - sb.eLo) - ((baseS - baseE) >> 2);
+    const int cconst = (sb.sLo - sb.eLo) - (int)(aS - aE);
+    const unsigned qe_span = (unsigned)sb.qeHi - (unsigned)sb.qeLo;
     long long acc = 0;
     for (unsigned u0 = threadIdx.x; u0 < nch; u0 += PT_THREADS * PC_ILP) {
-        int qs[PC_ILP], qe[PC_ILP], pS[PC_ILP], pE[PC_ILP];
+        int qs[PC_ILP], qe[PC_ILP];
+        lds_i32p pS[PC_ILP], pE[PC_ILP];
 #pragma unroll
         for (int j = 0; j < PC_ILP; j++) {
             unsigned u = u0 + (unsigned)j * PT_THREADS;
@@ -871,68 +876,78 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
         }
 #pragma unroll
         for (int j = 0; j < PC_ILP; j++) {
-            const int cE = inner ? (int)(((unsigned)qs[j] - (unsigned)cm.lo) >> cm.cshift) : cell_of(qs[j], cm);
-            pS[j] = baseS + (int)csS[cell_of(qe[j], cm)] * 4 - 4;
-            pE[j] = baseE + (int)csE[cE] * 4 - 4;
+            pS[j] = aS + cS[cell_of(qe[j], cm)] - 1;
+            pE[j] = aE + cE[cell_of(qs[j], cm)] - 1;
         }
         // only keys of the probe's own cell can still qualify, everything in later cells is larger, the fence stops the walk
         if (fenced) {
             for (int st = stepsS - 1; st >= 0; st--) {
 #pragma unroll
                 for (int j = 0; j < PC_ILP; j++) {
-                    const int t = pS[j] + (4 << st);
-                    pS[j] = *reinterpret_cast<const int32_t *>(ldsb + t) < qe[j] ? t : pS[j];
+                    const lds_i32p t = pS[j] + (1 << st);
+                    pS[j] = *t < qe[j] ? t : pS[j];
                 }
             }
             for (int st = stepsE - 1; st >= 0; st--) {
 #pragma unroll
                 for (int j = 0; j < PC_ILP; j++) {
-                    const int t = pE[j] + (4 << st);
-                    pE[j] = *reinterpret_cast<const int32_t *>(ldsb + t) <= qs[j] ? t : pE[j];  // (qs == INT_MAX passes the fence: handled below)
+                    const lds_i32p t = pE[j] + (1 << st);
+                    pE[j] = *t <= qs[j] ? t : pE[j];  // (qs == INT_MAX passes the fence: handled below)
                 }
             }
         } else {
+            const lds_i32p endS = aS + mS, endE = aE + mE;
             for (int st = stepsS - 1; st >= 0; st--) {
 #pragma unroll
                 for (int j = 0; j < PC_ILP; j++) {
-                    int t = pS[j] + (4 << st);
+                    lds_i32p t = pS[j] + (1 << st);
                     t = t < endS ? t : endS;
-                    pS[j] = *reinterpret_cast<const int32_t *>(ldsb + t) < qe[j] ? t : pS[j];
+                    pS[j] = *t < qe[j] ? t : pS[j];
                 }
             }
             for (int st = stepsE - 1; st >= 0; st--) {
 #pragma unroll
                 for (int j = 0; j < PC_ILP; j++) {
-                    int t = pE[j] + (4 << st);
+                    lds_i32p t = pE[j] + (1 << st);
                     t = t < endE ? t : endE;
-                    pE[j] = *reinterpret_cast<const int32_t *>(ldsb + t) <= qs[j] ? t : pE[j];
+                    pE[j] = *t <= qs[j] ? t : pE[j];
+                }
+            }
+        }
+        int c[PC_ILP];
+        bool odd = !unsampled;
+#pragma unroll
+        for (int j = 0; j < PC_ILP; j++) {
+            c[j] = (int)(pS[j] - pE[j]) + cconst;  // (sLo + #starts < qe) - (eLo + #ends <= qs)
+            odd |= !(qs[j] < qe[j]) | ((unsigned)qe[j] - (unsigned)sb.qeLo > qe_span);
+        }
+        if (odd) {
+#pragma unroll
+            for (int j = 0; j < PC_ILP; j++) {
+                const bool in_slice = (unsigned)qe[j] - (unsigned)sb.qeLo <= qe_span;
+                if (unsampled && qs[j] < qe[j] && in_slice) continue;
+                // sampled slices: finish each rank inside its group; qe outside the slice: global search;
+                // zero-length / reversed query: exact predicate over the candidate window
+                int rS = ((int)(pS[j] - aS) + 1) * strideS, rE = ((int)(pE[j] - aE) + 1) * strideE;
+                if (strideS > 1) rS = group_rank_lt(ix.s_ord + sb.sLo, rS, rS + strideS < nS ? rS + strideS : nS, qe[j]);
+                if (strideE > 1 && qs[j] != INT_MAX) rE = group_rank_lt(e_sorted + sb.eLo, rE, rE + strideE < nE ? rE + strideE : nE, qs[j] + 1);
+                const int s_rank = in_slice ? sb.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe[j]);
+                if (qs[j] < qe[j]) {
+                    c[j] = s_rank - (sb.eLo + rE);  // (qs < qe rules out qs == INT_MAX)
+                } else {
+                    int lo = first_pm_gt(ix.pm, ix.n, qs[j]);
+                    int cc = 0;
+                    for (int k = lo; k < s_rank; k++) cc += ix.e_ord[k] > qs[j];
+                    c[j] = cc;
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < PC_ILP; j++) {
             const unsigned u = u0 + (unsigned)j * PT_THREADS;
-            int c = ((pS[j] - pE[j]) >> 2) + cconst;  // (sLo + #starts < qe) - (eLo + #ends <= qs)
-            const bool ordinary = unsampled && qs[j] < qe[j] && qe[j] >= sb.qeLo && qe[j] <= sb.qeHi;
-            if (!ordinary) {
-                // sampled slices: finish each rank inside its group; qe outside the slice: global search;
-                // zero-length / reversed query: exact predicate over the candidate window
-                int rS = (((pS[j] - baseS) >> 2) + 1) * strideS, rE = (((pE[j] - baseE) >> 2) + 1) * strideE;
-                if (strideS > 1) rS = group_rank_lt(ix.s_ord + sb.sLo, rS, rS + strideS < nS ? rS + strideS : nS, qe[j]);
-                if (strideE > 1 && qs[j] != INT_MAX) rE = group_rank_lt(e_sorted + sb.eLo, rE, rE + strideE < nE ? rE + strideE : nE, qs[j] + 1);
-                const bool in_slice = qe[j] >= sb.qeLo && qe[j] <= sb.qeHi;
-                const int s_rank = in_slice ? sb.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe[j]);
-                if (qs[j] < qe[j]) {
-                    c = s_rank - (sb.eLo + rE);  // (qs < qe rules out qs == INT_MAX)
-                } else {
-                    int lo = first_pm_gt(ix.pm, ix.n, qs[j]);
-                    c = 0;
-                    for (int k = lo; k < s_rank; k++) c += ix.e_ord[k] > qs[j];
-                }
-            }
             if (u < nch) {
-                if (cb) cb[u] = c;
-                acc += c;
+                if (cb) cb[u] = c[j];
+                acc += c[j];
             }
         }
     }
