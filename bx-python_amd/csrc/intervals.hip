@@ -439,7 +439,18 @@ __global__ __launch_bounds__(PT_THREADS) void part_colsum_kernel(const unsigned 
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < ntiles ? r0 + rows_per_block : ntiles;
     unsigned s0 = 0, s1 = 0;
-    for (int64_t r = r0; r < r1; r++) {
+    int64_t r = r0;
+    for (; r + 16 <= r1; r += 16) {  // 32 loads in flight: the kernel is a chain of round trips otherwise
+        unsigned v0[16], v1[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            v0[i] = table[(r + i) * PT_NB + threadIdx.x];
+            v1[i] = table[(r + i) * PT_NB + PT_THREADS + threadIdx.x];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) s0 += v0[i], s1 += v1[i];
+    }
+    for (; r < r1; r++) {
         s0 += table[r * PT_NB + threadIdx.x];
         s1 += table[r * PT_NB + PT_THREADS + threadIdx.x];
     }
@@ -457,11 +468,20 @@ __global__ __launch_bounds__(PT_THREADS) void part_colbase_kernel(unsigned *__re
     // thread t owns the adjacent columns 2t and 2t+1 (so that one block scan orders all 2048 buckets)
     const int c0 = 2 * threadIdx.x, c1 = c0 + 1;
     unsigned t0 = 0, t1 = 0;
-#pragma unroll 8
-    for (int r = 0; r < nblocks; r++) {
-        uint2 v = *reinterpret_cast<const uint2 *>(partial + (int64_t)r * PT_NB + c0);
-        t0 += v.x;
-        t1 += v.y;
+    {
+        int r = 0;
+        for (; r + 16 <= nblocks; r += 16) {
+            uint2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = *reinterpret_cast<const uint2 *>(partial + (int64_t)(r + i) * PT_NB + c0);
+#pragma unroll
+            for (int i = 0; i < 16; i++) t0 += v[i].x, t1 += v[i].y;
+        }
+        for (; r < nblocks; r++) {
+            uint2 v = *reinterpret_cast<const uint2 *>(partial + (int64_t)r * PT_NB + c0);
+            t0 += v.x;
+            t1 += v.y;
+        }
     }
     unsigned tot;
     unsigned base0 = block_exclusive_scan(t0 + t1, OpSum(), 0u, scan_tmp, &tot);
@@ -474,13 +494,26 @@ __global__ __launch_bounds__(PT_THREADS) void part_colbase_kernel(unsigned *__re
     wg_first[c1] = w0 + ch0;
     if (threadIdx.x == 0) wg_first[PT_NB] = chtot;
     unsigned run0 = base0, run1 = base1;
-#pragma unroll 8
-    for (int r = 0; r < nblocks; r++) {
-        uint2 *cell = reinterpret_cast<uint2 *>(partial + (int64_t)r * PT_NB + c0);
-        uint2 v = *cell;
-        *cell = make_uint2(run0, run1);
-        run0 += v.x;
-        run1 += v.y;
+    {
+        int r = 0;
+        for (; r + 16 <= nblocks; r += 16) {
+            uint2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) v[i] = *reinterpret_cast<const uint2 *>(partial + (int64_t)(r + i) * PT_NB + c0);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                *reinterpret_cast<uint2 *>(partial + (int64_t)(r + i) * PT_NB + c0) = make_uint2(run0, run1);
+                run0 += v[i].x;
+                run1 += v[i].y;
+            }
+        }
+        for (; r < nblocks; r++) {
+            uint2 *cell = reinterpret_cast<uint2 *>(partial + (int64_t)r * PT_NB + c0);
+            uint2 v = *cell;
+            *cell = make_uint2(run0, run1);
+            run0 += v.x;
+            run1 += v.y;
+        }
     }
 }
 
@@ -493,7 +526,23 @@ __global__ __launch_bounds__(PT_THREADS) void part_colscan_kernel(unsigned *__re
     const int64_t r1 = r0 + rows_per_block < ntiles ? r0 + rows_per_block : ntiles;
     unsigned run0 = partial[(int64_t)blockIdx.x * PT_NB + threadIdx.x];
     unsigned run1 = partial[(int64_t)blockIdx.x * PT_NB + PT_THREADS + threadIdx.x];
-    for (int64_t r = r0; r < r1; r++) {
+    int64_t r = r0;
+    for (; r + 16 <= r1; r += 16) {
+        unsigned v0[16], v1[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            v0[i] = table[(r + i) * PT_NB + threadIdx.x];
+            v1[i] = table[(r + i) * PT_NB + PT_THREADS + threadIdx.x];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            table[(r + i) * PT_NB + threadIdx.x] = run0;
+            table[(r + i) * PT_NB + PT_THREADS + threadIdx.x] = run1;
+            run0 += v0[i];
+            run1 += v1[i];
+        }
+    }
+    for (; r < r1; r++) {
         unsigned v0 = table[r * PT_NB + threadIdx.x], v1 = table[r * PT_NB + PT_THREADS + threadIdx.x];
         table[r * PT_NB + threadIdx.x] = run0;
         table[r * PT_NB + PT_THREADS + threadIdx.x] = run1;
