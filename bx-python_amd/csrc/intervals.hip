@@ -655,7 +655,7 @@ __device__ __forceinline__ bool part_chunk_of_block(const int32_t *__restrict__ 
         if (wg_first[c] <= w && w < wg_first[c + 1]) *s_bucket = c;
     }
     __syncthreads();
-    b = *s_bucket;
+    b = __builtin_amdgcn_readfirstlane(*s_bucket);  // uniform: everything derived from it lives in SGPRs
     if (b < 0) return false;
     const int64_t q_lo = table[b];
     const int64_t q_hi = b + 1 < PT_NB ? (int64_t)table[b + 1] : nq;
@@ -829,6 +829,16 @@ __device__ __forceinline__ int cell_of(int x, CellMap m)
     x = x > m.hi ? m.hi : x;
     return (int)(((unsigned)x - (unsigned)m.lo) >> m.cshift);
 }
+__device__ __forceinline__ CellMap cell_map_of(int b, PartGeom g)
+{
+    CellMap cm;
+    long long lo = (long long)g.cmin + ((long long)b << g.shift);
+    cm.lo = lo > INT_MAX ? INT_MAX : (int)lo;
+    cm.cshift = g.shift > PC_CELLS_LOG2 ? g.shift - PC_CELLS_LOG2 : 0;
+    long long hi = (long long)cm.lo + ((long long)PC_NC << cm.cshift) - 1;
+    cm.hi = hi > INT_MAX ? INT_MAX : (int)hi;
+    return cm;
+}
 typedef __attribute__((address_space(3))) const int32_t *lds_i32p;
 typedef __attribute__((address_space(3))) const unsigned short *lds_u16p;
 
@@ -863,8 +873,47 @@ __device__ __forceinline__ int cells_stage(int32_t *arr, unsigned short *cs, con
     return 32 - __clz(pop);  // 0 for an empty slice
 }
 
+// What a search workgroup needs of its bucket, ready to be copied into LDS: [csE][csS][arrE + fence][arrS + fence].
+// It depends only on the sealed index, so seal() builds it once per bucket (part_cells_image_kernel) and the search
+// kernel starts with one streaming copy instead of two gathers, two table builds and eight barriers (measured ~25 us
+// per workgroup, a quarter of the kernel).
+struct CellsMeta {
+    int mE, mS;            // staged keys (or samples) of the ends / starts slice
+    int strideE, strideS;  // 1 = every key
+    int stepsE, stepsS;    // search steps inside a cell
+    int used_ints;         // ints of the image in use
+    int pad;
+};
+
+__global__ __launch_bounds__(PT_THREADS) void part_cells_image_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
+                                                                      const SliceBound *__restrict__ bounds, PartGeom g,
+                                                                      int32_t *__restrict__ images /* [PT_NB][PT_LDS_INTS] */,
+                                                                      CellsMeta *__restrict__ meta)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ int s_red[PT_THREADS / 64];
+    const int b = blockIdx.x;
+    const SliceBound sb = bounds[b];
+    const int nE = sb.eHi - sb.eLo, nS = sb.sHi - sb.sLo;
+    // strides chosen for the tree kernel may be finer than this layout holds: widen if needed
+    const int strideE = nE / sb.strideE > PC_KEYS ? nE / PC_KEYS + 1 : sb.strideE;
+    const int strideS = nS / sb.strideS > PC_KEYS ? nS / PC_KEYS + 1 : sb.strideS;
+    const int mE = nE / strideE, mS = nS / strideS;
+    const CellMap cm = cell_map_of(b, g);
+    unsigned short *csE = reinterpret_cast<unsigned short *>(lds), *csS = reinterpret_cast<unsigned short *>(lds + PC_CS_INTS);
+    int32_t *arrE = lds + 2 * PC_CS_INTS, *arrS = arrE + mE + PC_PAD;
+    const int stepsE = cells_stage(arrE, csE, e_sorted + sb.eLo, nE, strideE, cm, s_red);
+    const int stepsS = cells_stage(arrS, csS, ix.s_ord + sb.sLo, nS, strideS, cm, s_red);
+    const int used = ((2 * PC_CS_INTS + mE + mS + 2 * PC_PAD) + 3) & ~3;
+    __syncthreads();
+    int4 *dst = reinterpret_cast<int4 *>(images + (int64_t)b * PT_LDS_INTS);
+    for (int i = threadIdx.x; i < used / 4; i += PT_THREADS) dst[i] = reinterpret_cast<const int4 *>(lds)[i];
+    if (threadIdx.x == 0) meta[b] = CellsMeta{mE, mS, strideE, strideS, stepsE, stepsS, used, 0};
+}
+
 __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
                                                                       const SliceBound *__restrict__ bounds,
+                                                                      const int32_t *__restrict__ images, const CellsMeta *__restrict__ meta,
                                                                       const int32_t *__restrict__ wg_first,
                                                                       const unsigned *__restrict__ table /* row 0 = bucket offsets */,
                                                                       const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
@@ -875,30 +924,24 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
 {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     __shared__ int s_bucket;
-    __shared__ int s_red[PT_THREADS / 64];
     __shared__ long long red[PT_THREADS / 64];
     int b;
     int64_t q_begin, q_end;
     const unsigned go = gate ? *gate : 1u;  // 0 = sorted batch, answered by ivl_local_count_kernel
     if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end) || go == 0) return;
     const SliceBound sb = bounds[b];
+    const CellsMeta cmeta = meta[b];
     const int nE = sb.eHi - sb.eLo, nS = sb.sHi - sb.sLo;
-    // strides chosen for the tree kernel may be finer than this layout holds: widen if needed
-    const int strideE = nE / sb.strideE > PC_KEYS ? nE / PC_KEYS + 1 : sb.strideE;
-    const int strideS = nS / sb.strideS > PC_KEYS ? nS / PC_KEYS + 1 : sb.strideS;
-    const int mE = nE / strideE, mS = nS / strideS;
-    CellMap cm;
+    const int strideE = cmeta.strideE, strideS = cmeta.strideS, mE = cmeta.mE, mS = cmeta.mS;
+    const int stepsE = cmeta.stepsE, stepsS = cmeta.stepsS;
+    const CellMap cm = cell_map_of(b, g);
     {
-        long long lo = (long long)g.cmin + ((long long)b << g.shift);
-        cm.lo = lo > INT_MAX ? INT_MAX : (int)lo;
-        cm.cshift = g.shift > PC_CELLS_LOG2 ? g.shift - PC_CELLS_LOG2 : 0;
-        long long hi = (long long)cm.lo + ((long long)PC_NC << cm.cshift) - 1;
-        cm.hi = hi > INT_MAX ? INT_MAX : (int)hi;
+        const int4 *src = reinterpret_cast<const int4 *>(images + (int64_t)b * PT_LDS_INTS);
+        for (int i = threadIdx.x; i < cmeta.used_ints / 4; i += PT_THREADS) reinterpret_cast<int4 *>(lds)[i] = src[i];
     }
+    __syncthreads();
     unsigned short *csE = reinterpret_cast<unsigned short *>(lds), *csS = reinterpret_cast<unsigned short *>(lds + PC_CS_INTS);
     int32_t *arrE = lds + 2 * PC_CS_INTS, *arrS = arrE + mE + PC_PAD;
-    const int stepsE = cells_stage(arrE, csE, e_sorted + sb.eLo, nE, strideE, cm, s_red);
-    const int stepsS = cells_stage(arrS, csS, ix.s_ord + sb.sLo, nS, strideS, cm, s_red);
     // positions are LDS pointers to "the last key known to be below the probe" (one add + one read per step)
     const lds_i32p aE = (lds_i32p)arrE, aS = (lds_i32p)arrS;
     const lds_u16p cE = (lds_u16p)csE, cS = (lds_u16p)csS;
@@ -1889,7 +1932,7 @@ struct bxmi_ivl {
     DevBuf q_s, q_e, q_cnt, q_lo, q_hi, q_off, q_hits, q_total;
     // partitioned count path
     PartGeom geom{0, 0};
-    DevBuf slice_bounds, p_hist, p_table, p_pairs, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
+    DevBuf slice_bounds, cell_images, cell_meta, p_hist, p_table, p_pairs, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][hits...]
     hipStream_t sub_stream[PT_MAX_SUB] = {};
     hipEvent_t ev_fork = nullptr, ev_join[PT_MAX_SUB] = {};
@@ -1975,7 +2018,8 @@ static int ivl_count_part_sub(bxmi_ivl *h, int sub, int64_t q0, const int32_t *q
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
     if (g_opt_count_cells)
         hipLaunchKernelGGL(part_count_cells_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
-                           h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bq, nq, h->geom,
+                           h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), h->cell_images.as<int32_t>(),
+                           h->cell_meta.as<CellsMeta>(), pp.plan, pp.table, pp.bq, nq, h->geom,
                            counts ? h->p_cnt.as<int32_t>() + q0 : nullptr, total_dev ? slots : nullptr, unsorted);
     else
         hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h), h->e_sorted.as<int32_t>(),
@@ -2255,6 +2299,15 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
                            h->pm.as<int32_t>(), (int)n, h->geom, h->slice_bounds.as<SliceBound>());
         BXMI_LAUNCH_CHECK();
+        if (!h->has_reversed && n > 0) {  // LDS images of every bucket for the large-batch search (159 MB)
+            BXMI_TRY(h->cell_images.reserve((size_t)PT_NB * PT_LDS_INTS * sizeof(int32_t)));
+            BXMI_TRY(h->cell_meta.reserve(PT_NB * sizeof(CellsMeta)));
+            BXMI_TRY(allow_big_lds(part_cells_image_kernel, (size_t)PT_LDS_INTS * 4));
+            hipLaunchKernelGGL(part_cells_image_kernel, dim3(PT_NB), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
+                               h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), h->geom, h->cell_images.as<int32_t>(),
+                               h->cell_meta.as<CellsMeta>());
+            BXMI_LAUNCH_CHECK();
+        }
         BXMI_HIP(hipStreamSynchronize(st));
     }
     h->sealed = true;
