@@ -1237,34 +1237,34 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const unsigned sub = threadIdx.x & 7;
     constexpr int RUNS = PT_NB / (PT_THREADS / 8);  // 16 runs per lane
 #pragma unroll
-    for (int g0 = 0; g0 < RUNS; g0 += 8) {
-        unsigned o[8], len[8], gb[8];
-        int v[8];
+    for (int round = 0; round < 2; round++) {  // elements sub and sub + 8 of all 16 runs: two round trips in all
+        const unsigned r = sub + 8u * round;
+        int v[RUNS];
+        unsigned short at[RUNS];
+        unsigned live = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int b = (int)(threadIdx.x >> 3) + (g0 + i) * (PT_THREADS / 8);
-            o[i] = toff[b];
-            len[i] = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o[i];
-            gb[i] = gbase[b];
+        for (int i = 0; i < RUNS; i++) {
+            const int b = (int)(threadIdx.x >> 3) + i * (PT_THREADS / 8);
+            const unsigned o = toff[b], len = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o;
+            const bool ok = r < len;
+            live |= (unsigned)ok << i;
+            at[i] = (unsigned short)(o + r);
+            v[i] = ok ? bucketed[gbase[b] + r] : 0;
         }
 #pragma unroll
-        for (int round = 0; round < 2; round++) {  // elements sub and sub + 8 of every run
-            const unsigned r = sub + 8u * round;
-#pragma unroll
-            for (int i = 0; i < 8; i++) v[i] = r < len[i] ? bucketed[gb[i] + r] : 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (r < len[i]) vals[o[i] + r] = v[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {  // runs longer than 16 (rare; the whole tile for a sorted batch): the whole wave copies them
-            unsigned long long m = __ballot(sub == 0 && len[i] > 16);
-            while (m) {
-                const int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const unsigned oo = __shfl(o[i], src, 64), ll = __shfl(len[i], src, 64), gg = __shfl(gb[i], src, 64);
-                for (unsigned r = 16 + lane_id(); r < ll; r += 64) vals[oo + r] = bucketed[gg + r];
-            }
+        for (int i = 0; i < RUNS; i++)
+            if (live >> i & 1) vals[at[i]] = v[i];
+    }
+#pragma unroll 1
+    for (int i = 0; i < RUNS; i++) {  // runs longer than 16 (rare; the whole tile for a sorted batch): the whole wave copies them
+        const int b = (int)(threadIdx.x >> 3) + i * (PT_THREADS / 8);
+        const unsigned o = toff[b], len = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o, gb = gbase[b];
+        unsigned long long m = __ballot(sub == 0 && len > 16);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const unsigned oo = __shfl(o, src, 64), ll = __shfl(len, src, 64), gg = __shfl(gb, src, 64);
+            for (unsigned q = 16 + lane_id(); q < ll; q += 64) vals[oo + q] = bucketed[gg + q];
         }
     }
     __syncthreads();
