@@ -52,10 +52,11 @@ for k, v in dur.items():
     if k in out:
         out[k]["avg_duration_us"] = sum(v) / len(v) / 1e3
         out[k]["dispatches_traced"] = len(v)
-# HBM bytes of one count pass = its five kernels (the table scans add ~0.15 GB and are shared with seal()).
+# HBM bytes of one count pass = its seven kernels.
 # FETCH_SIZE is in KiB and reads HALF of a streaming read on gfx950 (checked below on the bitset popcount, whose
 # byte count is known); WRITE_SIZE is in KiB and exact.  Correction as MI355X_MICROARCH.md prescribes.
-pass_kernels = ["part_hist_kernel", "part_transpose_kernel", "part_scatter_kernel", "part_count_kernel", "part_gather_kernel"]
+pass_kernels = ["part_hist_kernel", "part_colsum_kernel", "part_colbase_kernel", "part_colscan_kernel", "part_scatter_kernel",
+                "part_count_cells_kernel", "part_gather_kernel"]
 tot = 0.0
 detail = {}
 for k in pass_kernels:
