@@ -58,7 +58,16 @@ int bxmi_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int bxmi_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int bxmi_memset(void *dst_dev, int value, size_t bytes);
 
-/* Tuning knobs (process-wide): key/value, e.g. ("ivl.group_sum", 0=dpp 1=shfl). */
+/* Tuning / A-B knobs (process-wide), key -> value.  Results never depend on them (the GPU tests run both sides).
+ *   ivl.partition      -1 auto (batches >= ivl.partition_min queries take the bucketed path), 0 never, 1 always
+ *   ivl.partition_min  threshold of the auto mode (default 4 Mi queries)
+ *   ivl.sorted_path    1 (default): a batch whose starts are already non-decreasing skips the bucketing
+ *   ivl.count_cells    1 (default): bucket search by direct-addressed cells; 0: LDS search trees
+ *   ivl.pipeline       sub-batches on forked streams (default 1 = off; measured no gain)
+ *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search
+ *   ivl.lds_ints, ivl.count_grid   staging budget / grid of the direct count kernel
+ *   bits.grid          grid of the per-bitset kernels
+ * Unknown keys return BXMI_EINVAL. */
 int bxmi_set_option(const char *key, int64_t value);
 
 /* ---- interval index  (intersection.pyx) ---------------------------------- */
