@@ -563,15 +563,14 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
                                                                   const unsigned short *__restrict__ lpos,
                                                                   const unsigned *__restrict__ gate)
 {
-    // LDS: half a tile of (qs, qe) pairs (64 KiB) + one 2048-entry table (8 KiB); the tile goes through the staging
-    // area in two halves.  The tile's pairs and slots live in registers, so in practice ONE workgroup runs per CU;
-    // keeping only the slots and re-reading the pairs for each half (64 VGPRs, two workgroups per CU) measured 0.61 ms
-    // against 0.46 ms even with all loads of a group issued up front -- more tiles in flight spread the four runs that
-    // share a 128-byte line further apart in time.
+    // LDS: the whole tile of (qs, qe) pairs (128 KiB) + one 2048-entry table (8 KiB).  The tile's pairs and slots live
+    // in registers (102 VGPRs), so ONE workgroup runs per CU whatever the LDS footprint; staging half a tile at a time
+    // (80 KiB) measured 4 % slower, and keeping only the slots in registers and re-reading the pairs (64 VGPRs, two
+    // workgroups per CU) measured 0.61 ms against 0.46 ms -- more tiles in flight spread the runs that share a
+    // 128-byte line further apart in time.
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    constexpr int HALF = PT_TILE / 2;
-    int2 *staged = reinterpret_cast<int2 *>(dyn);                    // [HALF] (qs, qe) in bucket order
-    unsigned *delta = reinterpret_cast<unsigned *>(dyn + 2 * HALF);   // [PT_NB] global base of the (tile, bucket) run - its offset in the tile
+    int2 *staged = reinterpret_cast<int2 *>(dyn);                    // [PT_TILE] (qs, qe) in bucket order
+    unsigned *delta = reinterpret_cast<unsigned *>(dyn + 2 * PT_TILE);   // [PT_NB] global base of the (tile, bucket) run - its offset in the tile
     unsigned *scan_tmp = reinterpret_cast<unsigned *>(dyn);           // the staging area is idle during the scan
     const int64_t tile = part_tile_of_block(ntiles);
     if (tile >= ntiles) return;
@@ -609,21 +608,18 @@ __global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t 
         delta[2 * threadIdx.x] = lo[0] - exc;
         delta[2 * threadIdx.x + 1] = lo[1] - (exc + c[0]);
     }
+    __syncthreads();  // table ready, scan scratch free
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        __syncthreads();  // table ready, scan scratch free (half 0) / previous half streamed out (half 1)
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS; j++) {
-            int k = j * PT_THREADS + threadIdx.x;
-            if (k < n && (int)(slot[j] / HALF) == half) staged[slot[j] & (HALF - 1)] = make_int2(s[j], e[j]);
-        }
-        __syncthreads();
-        const int m = n - half * HALF < HALF ? n - half * HALF : HALF;
-        for (int p = threadIdx.x; p < m; p += PT_THREADS) {
-            int2 v = staged[p];
-            unsigned d = delta[part_bucket(v.x, g)] + (unsigned)(p + half * HALF);  // global base of the run + offset inside it
-            pairs_out[d] = v;  // one 8-byte store: a (tile, bucket) run is 64 contiguous bytes
-        }
+    for (int j = 0; j < PT_ITEMS; j++) {
+        int k = j * PT_THREADS + threadIdx.x;
+        if (k < n) staged[slot[j]] = make_int2(s[j], e[j]);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = threadIdx.x; p < n; p += PT_THREADS) {
+        int2 v = staged[p];
+        unsigned d = delta[part_bucket(v.x, g)] + (unsigned)p;  // global base of the run + offset inside it
+        pairs_out[d] = v;  // one 8-byte store: a (tile, bucket) run is 64 contiguous bytes
     }
 }
 
@@ -2048,7 +2044,7 @@ static int part_prepare(bxmi_ivl *h, int sub, int64_t q0, const int32_t *qs, con
     hipLaunchKernelGGL(part_colbase_kernel, dim3(1), dim3(PT_THREADS), 0, st, partial, nrb, nq, pp->plan, gate);
     hipLaunchKernelGGL(part_colscan_kernel, dim3(nrb), dim3(PT_THREADS), 0, st, pp->table, pp->ntiles, rows_per_block, partial, gate);
     BXMI_LAUNCH_CHECK();
-    const size_t scat_lds = (size_t)(PT_TILE / 2) * 8 + PT_NB * sizeof(unsigned);
+    const size_t scat_lds = (size_t)PT_TILE * 8 + PT_NB * sizeof(unsigned);
     hipLaunchKernelGGL(part_scatter_kernel, dim3(pp->tgrid), dim3(PT_THREADS), scat_lds, st, qs, qe, nq, h->geom, pp->table, pp->ntiles, pp->bq,
                        pp->lpos, gate);
     BXMI_LAUNCH_CHECK();
@@ -2065,7 +2061,7 @@ static int part_reserve(bxmi_ivl *h, int64_t nq, bool want_lpos)
     BXMI_TRY(h->p_hist.reserve((size_t)PT_MAX_SUB * 80 * PT_NB * sizeof(unsigned)));
     BXMI_TRY(h->p_dest.reserve((size_t)(nq + 8) * 2));
     if (want_lpos) BXMI_TRY(h->p_cnt.reserve((size_t)(nq + 4) * 4));
-    BXMI_TRY(allow_big_lds(part_scatter_kernel, (size_t)(PT_TILE / 2) * 8 + PT_NB * sizeof(unsigned)));
+    BXMI_TRY(allow_big_lds(part_scatter_kernel, (size_t)PT_TILE * 8 + PT_NB * sizeof(unsigned)));
     return BXMI_OK;
 }
 
