@@ -873,7 +873,7 @@ __device__ __forceinline__ int cells_stage(int32_t *arr, unsigned short *cs, con
 }
 
 // What a search workgroup needs of its bucket, ready to be copied into LDS: [csE][csS][arrE + fence][arrS + fence].
-// It depends only on the sealed index, so seal() builds it once per bucket (part_cells_image_kernel) and the search
+// It depends only on the sealed index, so it is built once per bucket (part_cells_image_kernel, on the first large batch) and the search
 // kernel starts with one streaming copy instead of two gathers, two table builds and eight barriers (measured ~25 us
 // per workgroup, a quarter of the kernel).
 struct CellsMeta {
@@ -1935,8 +1935,7 @@ static int64_t g_opt_lds_ints = LDS_TREE_INTS;
 static int64_t g_opt_count_grid = 0;  // 0 = one workgroup per CU
 static int64_t g_opt_partition = -1;  // -1 = auto (large batches), 0 = never, 1 = always
 static int64_t g_opt_partition_min = 4 << 20;  // auto: partition batches of at least this many queries
-static int64_t g_opt_pipeline = 1;    // sub-batches on forked streams; measured: no gain (2: -2 %, 4: +10 %), so off by default
-constexpr int PT_MAX_SUB = 8;
+constexpr int PT_MAX_SUB = 1;  // scratch regions are addressed per sub-batch; one region since sub-batch pipelining was dropped
 constexpr int PT_SLOT_STRIDE = PT_SLOTS + 8;  // per sub-batch: the partial totals, then the "unsorted" flag
 static int64_t g_opt_count_cells = 1;  // 1 = direct-addressed cells in the bucket search, 0 = LDS search trees
 static int64_t g_opt_sorted_path = 1;  // 1 = batches whose starts are already sorted skip the bucketing (detected on the device)
@@ -1957,10 +1956,6 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.partition")) {
         g_opt_partition = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.pipeline")) {
-        g_opt_pipeline = value < 1 ? 1 : value;
         return 1;
     }
     if (!strcmp(key, "ivl.count_cells")) {
@@ -2001,10 +1996,9 @@ struct bxmi_ivl {
     DevBuf q_s, q_e, q_cnt, q_lo, q_hi, q_off, q_hits, q_total;
     // partitioned count path
     PartGeom geom{0, 0};
+    bool images_ready = false;
     DevBuf slice_bounds, cell_images, cell_meta, p_hist, p_table, p_pairs, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][hits...]
-    hipStream_t sub_stream[PT_MAX_SUB] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[PT_MAX_SUB] = {};
     hipStream_t stream = nullptr;
     int device = 0;
 };
@@ -2108,38 +2102,28 @@ static int ivl_count_part_sub(bxmi_ivl *h, int sub, int64_t q0, const int32_t *q
 }
 
 // Large-batch count: bucket the queries, search each bucket against LDS-resident slices, gather back.
-// Big batches are cut into sub-batches on forked streams: the passes are bound by different units
-// (LDS atomics, the store path, VALU issue, latency), so sub-batch k's search overlaps k+1's scatter.
+// (Cutting the batch into sub-batches on forked streams, so that one sub-batch's search overlaps the next one's scatter,
+// measured -2 % at depth 2 and +10 % at depth 4 and was removed.)
 static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
                                  int64_t *total_dev, hipStream_t st)
 {
     if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
-    int nsub = 1;
-    if (g_opt_pipeline > 1 && nq >= (int64_t)g_opt_pipeline * (8 << 20)) nsub = (int)(g_opt_pipeline > PT_MAX_SUB ? PT_MAX_SUB : g_opt_pipeline);
-    const int64_t per = div_up(div_up(nq, nsub), PT_TILE) * PT_TILE;
     BXMI_TRY(part_reserve(h, nq, counts != nullptr));
     BXMI_TRY(allow_big_lds(part_count_kernel, (size_t)PT_LDS_INTS * 4));
     BXMI_TRY(allow_big_lds(part_count_cells_kernel, (size_t)PT_LDS_INTS * 4));
-    if (nsub == 1) return ivl_count_part_sub(h, 0, 0, qs, qe, nq, counts, total_dev, st);
-    // fork: side streams wait for everything already queued on the caller's stream
-    if (!h->ev_fork) {
-        BXMI_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < PT_MAX_SUB; i++) {
-            BXMI_HIP(hipStreamCreateWithFlags(&h->sub_stream[i], hipStreamNonBlocking));
-            BXMI_HIP(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
-        }
+    if (g_opt_count_cells && !h->images_ready) {
+        // LDS images of every bucket for the search (159 MB, a property of the sealed index): built by the first large
+        // batch, so the many small per-chromosome trees of the drop-in classes never pay for them
+        BXMI_TRY(h->cell_images.reserve((size_t)PT_NB * PT_LDS_INTS * sizeof(int32_t)));
+        BXMI_TRY(h->cell_meta.reserve(PT_NB * sizeof(CellsMeta)));
+        BXMI_TRY(allow_big_lds(part_cells_image_kernel, (size_t)PT_LDS_INTS * 4));
+        hipLaunchKernelGGL(part_cells_image_kernel, dim3(PT_NB), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
+                           h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), h->geom, h->cell_images.as<int32_t>(),
+                           h->cell_meta.as<CellsMeta>());
+        BXMI_LAUNCH_CHECK();
+        h->images_ready = true;
     }
-    BXMI_HIP(hipEventRecord(h->ev_fork, st));
-    for (int s = 0; s < nsub; s++) {
-        const int64_t q0 = (int64_t)s * per;
-        if (q0 >= nq) break;
-        const int64_t n = nq - q0 < per ? nq - q0 : per;
-        BXMI_HIP(hipStreamWaitEvent(h->sub_stream[s], h->ev_fork, 0));
-        BXMI_TRY(ivl_count_part_sub(h, s, q0, qs + q0, qe + q0, n, counts ? counts + q0 : nullptr, total_dev, h->sub_stream[s]));
-        BXMI_HIP(hipEventRecord(h->ev_join[s], h->sub_stream[s]));
-        BXMI_HIP(hipStreamWaitEvent(st, h->ev_join[s], 0));  // join: the caller's stream continues after every sub-batch
-    }
-    return BXMI_OK;
+    return ivl_count_part_sub(h, 0, 0, qs, qe, nq, counts, total_dev, st);
 }
 
 
@@ -2240,13 +2224,6 @@ extern "C" int bxmi_ivl_destroy(bxmi_ivl_t *h)
     if (!h) return BXMI_OK;
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->one_buf) (void)hipHostFree(h->one_buf);
-    if (h->ev_fork) {
-        (void)hipEventDestroy(h->ev_fork);
-        for (int i = 0; i < PT_MAX_SUB; i++) {
-            (void)hipStreamDestroy(h->sub_stream[i]);
-            (void)hipEventDestroy(h->ev_join[i]);
-        }
-    }
     delete h;
     return BXMI_OK;
 }
@@ -2368,15 +2345,7 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
                            h->pm.as<int32_t>(), (int)n, h->geom, h->slice_bounds.as<SliceBound>());
         BXMI_LAUNCH_CHECK();
-        if (!h->has_reversed && n > 0) {  // LDS images of every bucket for the large-batch search (159 MB)
-            BXMI_TRY(h->cell_images.reserve((size_t)PT_NB * PT_LDS_INTS * sizeof(int32_t)));
-            BXMI_TRY(h->cell_meta.reserve(PT_NB * sizeof(CellsMeta)));
-            BXMI_TRY(allow_big_lds(part_cells_image_kernel, (size_t)PT_LDS_INTS * 4));
-            hipLaunchKernelGGL(part_cells_image_kernel, dim3(PT_NB), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
-                               h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), h->geom, h->cell_images.as<int32_t>(),
-                               h->cell_meta.as<CellsMeta>());
-            BXMI_LAUNCH_CHECK();
-        }
+        h->images_ready = false;  // built by the first large batch that needs them
         BXMI_HIP(hipStreamSynchronize(st));
     }
     h->sealed = true;

@@ -63,7 +63,6 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *   ivl.partition_min  threshold of the auto mode (default 4 Mi queries)
  *   ivl.sorted_path    1 (default): a batch whose starts are already non-decreasing skips the bucketing
  *   ivl.count_cells    1 (default): bucket search by direct-addressed cells; 0: LDS search trees
- *   ivl.pipeline       sub-batches on forked streams (default 1 = off; measured no gain)
  *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search
  *   ivl.lds_ints, ivl.count_grid   staging budget / grid of the direct count kernel
  *   bits.grid          grid of the per-bitset kernels
