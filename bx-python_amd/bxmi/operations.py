@@ -1,0 +1,410 @@
+"""
+The Galaxy-level interval operations on the MI355X engine.
+
+Counterparts of lib/bx/intervals/operations/{__init__,intersect,subtract,coverage,merge,complement,
+base_coverage}.py: same call signatures, the same sequence of yielded objects (Header / Comment /
+GenomicInterval / field lists), the same skip bookkeeping on the readers.  What changes is the shape of
+the work.  The reference walks the primary file row by row and asks the bitset three or more questions
+per row (`count_range`, then `next_set` / `next_clear` in a loop).  Here the primary is read once, and per
+chromosome the engine answers all rows together:
+
+  * covered bases of every row        -> one `bxmi_bits_count_ranges` launch,
+  * the set runs of the secondary set -> one `bxmi_bits_runs` scan,
+  * which runs each row overlaps      -> one batched `find` on an interval index over the runs,
+
+and the pieces are clipped from those answers.  Consequences a caller can see: the primary reader is
+drained on the first `next()` (the reference drains it lazily), and the skips an operation itself records
+on the primary appear then -- interleaved with the reader's own skips in file order, as in the reference.
+
+The per-call generators `bits_set_in_range` / `bits_clear_in_range` are kept for callers that use them
+directly (operations/__init__.py:10-33).
+"""
+from warnings import warn
+
+import numpy as np
+
+from bx.bitset import MAX
+
+from .genomic import BitsetSafeReaderWrapper, Comment, GenomicInterval, Header
+from .intervals import IntervalIndex
+
+BED_DEFAULT_COLS = 0, 1, 2, 5
+MAX_END = 512 * 1024 * 1024
+
+
+# ------------------------------------------------------------------ per-call generators --
+def bits_set_in_range(bits, range_start, range_end):
+    """(start, end) of every span of set bits inside [range_start, range_end) (operations/__init__.py:10-20).
+    Like the reference it raises IndexError when the scan runs off the end of the bitset."""
+    pos = range_start
+    while True:
+        first = bits.next_set(pos)
+        pos = min(bits.next_clear(first), range_end)
+        if first >= pos:
+            return
+        yield first, pos
+
+
+def bits_clear_in_range(bits, range_start, range_end):
+    """(start, end) of every span of clear bits inside [range_start, range_end) (operations/__init__.py:23-33)."""
+    pos = range_start
+    while True:
+        first = bits.next_clear(pos)
+        if first >= range_end:
+            return
+        pos = min(bits.next_set(first), range_end)
+        yield first, pos
+
+
+# ------------------------------------------------------------------ batched answers --
+def _past_end_message(size):
+    # what next_set(size) / next_clear(size) raise (bitset.pyx:176-180)
+    return "%d is larger than the size of this BitSet (%d)." % (size, size)
+
+
+class _RunTable:
+    """Set runs of one bitset (one device scan) and a device interval index over them."""
+
+    def __init__(self, bits):
+        rs, re = bits.runs(0)
+        self.rs = np.asarray(rs, dtype=np.int64)
+        self.re = np.asarray(re, dtype=np.int64)
+        self.size = bits.size
+        self.index = None
+        if len(self.rs):
+            self.index = IntervalIndex()
+            self.index.append(self.rs.astype(np.int32), np.minimum(self.re, 2**31 - 1).astype(np.int32))
+            self.index.seal()
+
+    def overlaps(self, a, b):
+        """CSR (offsets, run ids) of the runs overlapping each [a_i, b_i); rows with a_i >= b_i get none."""
+        n = len(a)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        proper = np.nonzero(a < b)[0]
+        if self.index is None or len(proper) == 0:
+            return offsets, np.empty(0, dtype=np.int64)
+        off, hits = self.index.find(a[proper].astype(np.int32), np.minimum(b[proper], 2**31 - 1).astype(np.int32))
+        counts = np.zeros(n, dtype=np.int64)
+        counts[proper] = np.diff(off)
+        offsets[1:] = np.cumsum(counts)
+        return offsets, hits.astype(np.int64)
+
+    def set_pieces(self, a, b):
+        """Per row: the pieces bits_set_in_range would yield, and whether it would then run off the end
+        (no set bit after the last piece: `next_set` answers `size`, `next_clear(size)` raises)."""
+        offsets, ids = self.overlaps(a, b)
+        row = np.repeat(np.arange(len(a)), np.diff(offsets))
+        ps = np.maximum(self.rs[ids], a[row])
+        pe = np.minimum(self.re[ids], b[row])
+        nruns = len(self.rs)
+        n = np.diff(offsets)
+        last_set = self.re[-1] if nruns else 0
+        off_end = np.empty(len(a), dtype=bool)
+        none = n == 0
+        off_end[none] = (a[none] >= last_set) if nruns else True  # nothing set at or after a
+        some = ~none
+        if some.any():
+            last = ids[offsets[1:][some] - 1]
+            off_end[some] = (last == nruns - 1) & (self.re[last] <= b[some])
+        return offsets, ps, pe, off_end
+
+    def clear_pieces(self, a, b):
+        """Per row: the pieces bits_clear_in_range would yield, and whether it would then call next_clear(size)."""
+        offsets, ids = self.overlaps(a, b)
+        n = np.diff(offsets)
+        row = np.repeat(np.arange(len(a)), n)
+        cs = np.maximum(self.rs[ids], a[row])
+        ce = np.minimum(self.re[ids], b[row])
+        # candidate gaps of row i: [a, cs_0), [ce_0, cs_1), ..., [ce_last, b)  -> n_i + 1 of them
+        goff = np.zeros(len(a) + 1, dtype=np.int64)
+        goff[1:] = np.cumsum(n + 1)
+        total = int(goff[-1])
+        gs = np.empty(total, dtype=np.int64)
+        ge = np.empty(total, dtype=np.int64)
+        first = goff[:-1]
+        lastp = goff[1:] - 1
+        gs[first] = a
+        ge[lastp] = b
+        inner = np.arange(len(ids)) + row  # run k of row i sits between candidate k and k + 1 of that row
+        ge[inner] = cs
+        gs[inner + 1] = ce
+        keep = gs < ge
+        grow = np.repeat(np.arange(len(a)), n + 1)[keep]
+        poff = np.zeros(len(a) + 1, dtype=np.int64)
+        poff[1:] = np.cumsum(np.bincount(grow, minlength=len(a)))
+        tail_clear = len(self.rs) == 0 or self.re[-1] < self.size
+        off_end = (a < b) & (b == self.size) & tail_clear
+        return poff, gs[keep], ge[keep], off_end
+
+
+class _Primary:
+    """The primary reader, drained: items in order with the line bookkeeping the reference would have seen."""
+
+    def __init__(self, reader):
+        self.reader = reader
+        self.tracks = hasattr(reader, "skip_log") and hasattr(reader, "delivered")
+        self.log_from = len(reader.skip_log) if self.tracks else 0
+        self.skipped0 = getattr(reader, "skipped", None)
+        self.lines0 = list(getattr(reader, "skipped_lines", []) or [])
+        self.base = reader.delivered if self.tracks else 0
+        self.items, self.where = [], []
+        for item in reader:
+            self.items.append(item)
+            self.where.append((getattr(reader, "linenum", None), getattr(reader, "current_line", None)))
+        self.own = []  # (item index, message)
+
+    def skip(self, i, message):
+        self.own.append((i, message))
+
+    def settle(self):
+        """Replay the operation's own skips into the reader in file order
+        (`primary.skipped += 1; if primary.skipped < 10: primary.skipped_lines.append(...)`, e.g. intersect.py:52-61)."""
+        r = self.reader
+        if not self.own or self.skipped0 is None or not hasattr(r, "skipped_lines"):
+            return
+        self.own.sort(key=lambda t: t[0])
+        events = [(self.base + i + 0.25, (self.where[i][0], self.where[i][1], msg)) for i, msg in self.own]
+        if self.tracks:
+            events += [(d - 0.5, entry) for d, entry in r.skip_log[self.log_from:]]
+        events.sort(key=lambda t: t[0])
+        skipped, lines = self.skipped0, list(self.lines0)
+        for _, entry in events:
+            skipped += 1
+            if skipped < 10:
+                lines.append(entry)
+        r.skipped = skipped
+        r.skipped_lines[:] = lines
+        if self.tracks:
+            r.skip_log[self.log_from:] = [(int(t + 0.75), e) for t, e in events]
+
+
+def _first_safe_bitsets(reader, lens, **kw):
+    safe = BitsetSafeReaderWrapper(reader, lens=lens)
+    return safe, safe.binned_bitsets(lens=lens, **kw)
+
+
+def _range_error(bits, start, end):
+    """The IndexError text count_range(start, end - start) would raise, or None (bitset.pyx:176-189)."""
+    try:
+        bits._d.check_range_count(start, end - start)
+    except IndexError as e:
+        return str(e)
+    return None
+
+
+def _rows_by_chrom(primary, bitsets, start_after_end):
+    """Valid interval rows grouped by chromosome: {chrom: (item indices, starts, ends)}; invalid ones are logged."""
+    groups = {}
+    for i, item in enumerate(primary.items):
+        if not isinstance(item, GenomicInterval):
+            continue
+        chrom = item.chrom
+        if chrom not in bitsets:
+            continue
+        start, end = int(item.start), int(item.end)
+        if start > end and start_after_end == "skip":
+            primary.skip(i, "Interval start after end!")
+            continue
+        if start > end and start_after_end == "warn":
+            warn("Interval start after end!")
+        err = _range_error(bitsets[chrom], start, end)
+        if err is not None:
+            primary.skip(i, err)
+            continue
+        g = groups.setdefault(chrom, ([], [], []))
+        g[0].append(i), g[1].append(start), g[2].append(end)
+    return {c: (np.array(g[0], dtype=np.int64), np.array(g[1], dtype=np.int64), np.array(g[2], dtype=np.int64))
+            for c, g in groups.items()}
+
+
+def _covered(bits, starts, ends):
+    return np.asarray(bits.count_ranges(starts.astype(np.int32), (ends - starts).astype(np.int32)), dtype=np.int64)
+
+
+def _emit(primary, comments, per_item, passthrough=None):
+    """Yield in primary order: headers, comments, and for interval rows whatever `per_item` holds."""
+    for i, item in enumerate(primary.items):
+        if isinstance(item, Header):
+            yield item
+        if isinstance(item, Comment) and comments:
+            yield item
+        elif isinstance(item, GenomicInterval):
+            if passthrough is not None and passthrough(item):
+                yield item
+                continue
+            for start, end in per_item.get(i, ()):
+                piece = item.copy()
+                piece.start = start
+                piece.end = end
+                yield piece
+
+
+def _pieces_or_whole(primary, bitsets, groups, mincols, pieces, want_set):
+    """intersect (want_set) / subtract: per item index the list of (start, end) to emit."""
+    out = {}
+    for chrom, (idx, starts, ends) in groups.items():
+        bits = bitsets[chrom]
+        covered = _covered(bits, starts, ends)
+        enough = covered >= mincols
+        if want_set:
+            cut = enough if pieces else np.zeros(len(idx), dtype=bool)
+            whole = enough & ~cut
+        else:
+            cut = enough if pieces else np.zeros(len(idx), dtype=bool)
+            whole = ~enough  # subtract.py:59-63: too little overlap -> the row survives whole; enough and not pieces -> nothing
+        for k in np.nonzero(whole)[0]:
+            out[int(idx[k])] = [(int(starts[k]), int(ends[k]))]
+        sel = np.nonzero(cut)[0]
+        if len(sel):
+            table = _RunTable(bits)
+            fn = table.set_pieces if want_set else table.clear_pieces
+            off, ps, pe, off_end = fn(starts[sel], ends[sel])
+            for j, k in enumerate(sel):
+                lo, hi = int(off[j]), int(off[j + 1])
+                out[int(idx[k])] = list(zip(ps[lo:hi].tolist(), pe[lo:hi].tolist()))
+                if off_end[j]:
+                    primary.skip(int(idx[k]), _past_end_message(bits.size))
+    return out
+
+
+# ------------------------------------------------------------------ the operations --
+def intersect(readers, mincols=1, upstream_pad=0, downstream_pad=0, pieces=True, lens={}, comments=True):
+    """operations/intersect.py:21-83.  readers[0] is kept, restricted to what the AND of readers[1:] covers."""
+    primary = readers[0]
+    _, bitsets = _first_safe_bitsets(readers[1], lens, upstream_pad=upstream_pad, downstream_pad=downstream_pad)
+    for other in readers[2:]:
+        more = other.binned_bitsets(upstream_pad=upstream_pad, downstream_pad=downstream_pad, lens=lens)
+        for chrom in bitsets:
+            if chrom in more:
+                bitsets[chrom].iand(more[chrom])
+    p = _Primary(primary)
+    groups = _rows_by_chrom(p, bitsets, "skip")
+    out = _pieces_or_whole(p, bitsets, groups, mincols, pieces, want_set=True)
+    p.settle()
+    yield from _emit(p, comments, out)
+
+
+def subtract(readers, mincols=1, upstream_pad=0, downstream_pad=0, pieces=True, lens={}, comments=True):
+    """operations/subtract.py:22-77.  readers[0] minus the OR of readers[1:]."""
+    primary = readers[0]
+    _, bitsets = _first_safe_bitsets(readers[1], lens, upstream_pad=upstream_pad, downstream_pad=downstream_pad)
+    for other in readers[2:]:
+        more = other.binned_bitsets(upstream_pad=upstream_pad, downstream_pad=downstream_pad, lens=lens)
+        for chrom in more:
+            if chrom not in bitsets:
+                bitsets[chrom] = more[chrom]
+            else:
+                bitsets[chrom].ior(more[chrom])
+    p = _Primary(primary)
+    groups = _rows_by_chrom(p, bitsets, "warn")
+    out = _pieces_or_whole(p, bitsets, groups, mincols, pieces, want_set=False)
+    p.settle()
+    yield from _emit(p, comments, out, passthrough=lambda item: item.chrom not in bitsets)
+
+
+def coverage(readers, comments=True):
+    """operations/coverage.py:17-77.  Appends 'bases covered' and 'fraction covered' to every row of readers[0]."""
+    primary = readers[0]
+    _, bitsets = _first_safe_bitsets(readers[1], {})
+    for other in readers[2:]:
+        more = other.binned_bitsets()
+        for chrom in bitsets:
+            if chrom in more:
+                bitsets[chrom].ior(more[chrom])
+    p = _Primary(primary)
+    covered_of = {}
+    pending = {}
+    for i, item in enumerate(p.items):
+        if not isinstance(item, GenomicInterval):
+            continue
+        start, end = int(item.start), int(item.end)
+        if start > end:
+            p.skip(i, "Interval start after end!")
+            continue
+        if item.chrom not in bitsets:
+            covered_of[i] = (0, 0.0)
+            continue
+        err = _range_error(bitsets[item.chrom], start, end)
+        if err is not None:
+            p.skip(i, err)
+            continue
+        g = pending.setdefault(item.chrom, ([], [], []))
+        g[0].append(i), g[1].append(start), g[2].append(end)
+    for chrom, (idx, starts, ends) in pending.items():
+        starts, ends = np.array(starts, dtype=np.int64), np.array(ends, dtype=np.int64)
+        covered = _covered(bitsets[chrom], starts, ends)
+        for i, c, length in zip(idx, covered.tolist(), (ends - starts).tolist()):
+            covered_of[i] = (c, 0 if length == 0 else float(c) / float(length))
+    p.settle()
+    for i, item in enumerate(p.items):
+        if isinstance(item, Header):
+            yield item
+        if isinstance(item, Comment) and comments:
+            yield item
+        elif isinstance(item, GenomicInterval) and i in covered_of:
+            bases, fraction = covered_of[i]
+            item.fields.append(str(bases))
+            item.fields.append(str(fraction))
+            yield item
+
+
+def _note_reader_skip(reader, message):
+    # merge.py:27-35 / complement.py:50-57: `reader.skipped += 1; if reader.skipped < 10: skipped_lines.append(...)`
+    try:
+        reader.note_skip(reader.linenum, reader.current_line, message)
+    except Exception:
+        pass
+
+
+def merge(interval, mincols=1):
+    """operations/merge.py:13-37.  One row per run of the union, as a list of column strings; like the reference the
+    SAME list object is yielded again and again for a chromosome, and every chromosome ends with a logged skip
+    (the scan always runs off the end of the bitset)."""
+    reader = BitsetSafeReaderWrapper(interval, lens={})
+    bitsets = reader.binned_bitsets()
+    if reader.header:
+        yield reader.header
+    width = max(reader.chrom_col, reader.start_col, reader.end_col) + 1
+    for chrom, bits in bitsets.items():
+        row = ["."] * width
+        row[reader.chrom_col] = chrom
+        rs, re = bits.runs(0)
+        for start, end in zip(np.asarray(rs).tolist(), np.asarray(re).tolist()):
+            row[reader.start_col] = str(start)
+            row[reader.end_col] = str(min(end, MAX_END))
+            yield row
+        _note_reader_skip(reader, _past_end_message(bits.size))
+
+
+def complement(reader, lens):
+    """operations/complement.py:13-57.  The uncovered stretches of every chromosome seen, up to lens[chrom] (or MAX)."""
+    safe, bitsets = _first_safe_bitsets(reader, lens, upstream_pad=0, downstream_pad=0)
+    for bits in bitsets.values():
+        bits.invert()
+    width = max(safe.chrom_col, safe.start_col, safe.end_col) + 1
+    for chrom, bits in bitsets.items():
+        limit = lens.get(chrom, MAX)
+        rs, re = bits.runs(0)
+        for start, end in zip(np.asarray(rs).tolist(), np.asarray(re).tolist()):
+            if start >= limit:
+                break
+            fields = ["."] * width
+            if 0 <= safe.strand_col < len(fields):
+                fields[safe.strand_col] = "+"
+            fields[safe.chrom_col] = chrom
+            fields[safe.start_col] = start
+            fields[safe.end_col] = min(end, limit)
+            yield GenomicInterval(safe, fields, safe.chrom_col, safe.start_col, safe.end_col, safe.strand_col, "+")
+
+
+def base_coverage(reader):
+    """operations/base_coverage.py:10-23.  Number of bases covered by the reader's intervals."""
+    safe, bitsets = _first_safe_bitsets(reader, {})
+    total = 0
+    for bits in bitsets.values():
+        err = _range_error(bits, 0, MAX_END)
+        if err is not None:
+            _note_reader_skip(safe, err)
+            continue
+        total += bits.count_range(0, MAX_END)
+    return total

@@ -1,0 +1,116 @@
+"""
+GPU parity tests of the operations layer, `-m gpu`.
+
+bxmi.operations + bxmi.genomic against tests/golden/operations.json, which oracle/gen_golden_ops.py
+captured from the reference's bx.intervals.operations running on the reference's own readers:
+every yielded object (type, fields, chrom/start/end/strand), what escapes as an exception, the warnings,
+and the skip bookkeeping left on the primary reader -- all must be identical.
+"""
+import json
+import os
+import warnings
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "operations.json")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(GOLDEN) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from bxmi import genomic, operations
+
+    return genomic, operations
+
+
+def _tell(genomic, item):
+    if isinstance(item, genomic.Header):
+        return ["header", str(item)]
+    if isinstance(item, genomic.Comment):
+        return ["comment", str(item)]
+    if isinstance(item, list):
+        return ["list", list(item)]
+    return ["interval", [str(f) for f in item.fields], item.chrom, int(item.start), int(item.end), item.strand]
+
+
+def _run(genomic, operations, case, inputs):
+    make = {"nice": genomic.NiceReaderWrapper, "plain": genomic.GenomicIntervalReader}
+    readers = [make[k](list(inputs[key])) for k, key in zip(case["readers"], case["inputs"])]
+    op, params = case["op"], dict(case["params"])
+    if op == "base_coverage":
+        return readers, operations.base_coverage(readers[0]), None, []
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        try:
+            if op in ("intersect", "subtract", "coverage"):
+                it = getattr(operations, op)(readers, **params)
+            elif op == "merge":
+                it = operations.merge(readers[0])
+            else:
+                it = operations.complement(readers[0], params["lens"])
+            out, err = [_tell(genomic, x) for x in it], None
+        except Exception as e:
+            out, err = None, [type(e).__name__, str(e)]
+    return readers, out, err, [str(x.message) for x in w]
+
+
+def test_operations_match_the_reference(golden, mods):
+    genomic, operations = mods
+    inputs = golden["inputs"]
+    assert len(golden["cases"]) >= 40
+    for case in golden["cases"]:
+        readers, out, err, warns = _run(genomic, operations, case, inputs)
+        name = case["name"]
+        if case["op"] == "base_coverage":
+            assert out == case["value"], name
+            continue
+        assert err == case["error"], (name, err, case["error"])
+        if out is not None:
+            assert len(out) == len(case["output"]), (name, len(out), len(case["output"]))
+            for k, (got, want) in enumerate(zip(out, case["output"])):
+                assert got == want, (name, k, got, want)
+        assert warns == case["warnings"], (name, warns, case["warnings"])
+        if case["primary"] is not None:
+            p = readers[0]
+            assert p.skipped == case["primary"]["skipped"], (name, p.skipped, case["primary"]["skipped"])
+            assert [list(t) for t in p.skipped_lines] == case["primary"]["skipped_lines"], (name, p.skipped_lines)
+
+
+def test_range_generators_match_the_batched_pieces(mods):
+    """bits_set_in_range / bits_clear_in_range (per-call, on the drop-in BinnedBitSet) give the pieces the batched
+    path computes from the run list -- including whether the scan runs off the end of the bitset."""
+    import numpy as np
+
+    from bx.bitset import BinnedBitSet
+
+    _, operations = mods
+    rng = np.random.default_rng(5)
+    for size, nr in ((1000, 12), (4096, 40), (777, 0), (500, 3)):
+        bits = BinnedBitSet(size)
+        for _ in range(nr):
+            s = int(rng.integers(0, size))
+            bits.set_range(s, int(rng.integers(0, min(60, size - s) + 1)))
+        if nr == 3:
+            bits.set_range(size - 7, 7)  # a run reaching the very end
+        table = operations._RunTable(bits)
+        a = rng.integers(0, size, size=300)
+        b = np.minimum(a + rng.integers(0, 200, size=300), size)
+        a[:3], b[:3] = [0, size - 1, size // 2], [size, size, size]
+        for fn, gen in ((table.set_pieces, operations.bits_set_in_range), (table.clear_pieces, operations.bits_clear_in_range)):
+            off, ps, pe, off_end = fn(a.astype(np.int64), b.astype(np.int64))
+            for i in range(len(a)):
+                want, raised = [], False
+                try:
+                    for piece in gen(bits, int(a[i]), int(b[i])):
+                        want.append(piece)
+                except IndexError:
+                    raised = True
+                got = list(zip(ps[off[i]:off[i + 1]].tolist(), pe[off[i]:off[i + 1]].tolist()))
+                assert got == want and bool(off_end[i]) == raised, (size, nr, fn.__name__, int(a[i]), int(b[i]), got, want, raised)

@@ -242,3 +242,31 @@ def test_native_bed_parser_matches_per_line_semantics():
                 seen.append(ch)
         assert bed.names == seen, name
         bed.close()
+
+
+def test_interval_readers_follow_the_reference_docstring_examples():
+    """The known-answer examples of lib/bx/intervals/io.py:111-137,220-229 (reader protocol, field write-back,
+    NiceReaderWrapper bookkeeping), on bxmi.genomic -- host-only text handling, no GPU involved."""
+    from bxmi.genomic import Comment, GenomicInterval, GenomicIntervalReader, Header, NiceReaderWrapper
+
+    lines = ["#chrom\tname\tstart\tend\textra", "chr1\tfoo\t1\t100\txxx", "chr2\tbar\t20\t300\txxx", "#I am a comment",
+             "chr2\tbar\t20\t300\txxx"]
+    r = GenomicIntervalReader(lines, start_col=2, end_col=3)
+    elements = list(r)
+    assert isinstance(elements[0], Header) and str(elements[0]) == "#chrom\tname\tstart\tend\textra"
+    assert isinstance(elements[1], GenomicInterval) and (elements[1].start, elements[1].end) == (1, 100)
+    assert str(elements[1]) == "chr1\tfoo\t1\t100\txxx"
+    elements[1].start = 30
+    assert (elements[1].start, elements[1].end) == (30, 100) and str(elements[1]) == "chr1\tfoo\t30\t100\txxx"
+    assert isinstance(elements[2], GenomicInterval) and isinstance(elements[3], Comment) and isinstance(elements[4], GenomicInterval)
+    assert elements[1]["name"] == "foo" and elements[1][0] == "chr1"
+
+    n = NiceReaderWrapper(lines + ["chr1\tbaz\tx\t5", "chr1\tq\t9\t3"], start_col=2, end_col=3)
+    assert isinstance(next(n), Header) and n.current_line == lines[0]
+    assert len(list(n)) == 4
+    assert n.skipped == 2 and [t[0] for t in n.skipped_lines] == [6, 7]
+    assert n.skipped_lines[0][2] == "Could not parse start_col: invalid literal for int() with base 10: 'x' on line 6, integer expected"
+    assert n.skipped_lines[1][2] == "Start is greater than End. Interval length is < 1. on line 7"
+    # construction normalises the fields it parsed (whitespace, sign, strand '.')
+    row = GenomicInterval(None, [" chr7 ", "+5", "9", "x", "0", "."], 0, 1, 2, 5, "-")
+    assert row.fields == ["chr7", "5", "9", "x", "0", "-"] and row.copy().fields == row.fields

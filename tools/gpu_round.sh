@@ -13,5 +13,8 @@ timeout 1500 python -m pytest tests/test_gpu_bitset.py -m gpu -q --timeout 900 -
 if [ -f tests/test_gpu_cli.py ]; then
 timeout 900 python -m pytest tests/test_gpu_cli.py -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/test_cli.log 2>&1; echo "cli rc=$?" >> gpurun_out/smoke.log
 fi
+if [ -f tests/test_gpu_operations.py ]; then
+timeout 900 python -m pytest tests/test_gpu_operations.py -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/test_operations.log 2>&1; echo "operations rc=$?" >> gpurun_out/smoke.log
+fi
 timeout 900 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?" >> gpurun_out/smoke.log
-tail -5 gpurun_out/smoke.log; tail -3 gpurun_out/test_intervals.log; tail -3 gpurun_out/test_bitset.log; cat gpurun_out/bench.json
+tail -6 gpurun_out/smoke.log; tail -3 gpurun_out/test_intervals.log; tail -3 gpurun_out/test_bitset.log; cat gpurun_out/bench.json
