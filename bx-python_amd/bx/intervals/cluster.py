@@ -1,0 +1,68 @@
+"""
+Drop-in `bx.intervals.cluster` on the MI355X engine (reference: lib/bx/intervals/cluster.pyx, src/cluster.c).
+
+`ClusterTree(mincols, minregions)` groups intervals that lie within `mincols` of each other.  The
+reference keeps a self-balancing tree of clusters and merges on every insert; here inserts are
+collected and the clusters of the whole set are computed in one go on the device the first time
+they are asked for (sort by start, running maximum of the ends, a boundary wherever
+`start - mincols > largest end so far`) -- for mincols >= 0 the reference's outcome does not
+depend on the insertion order, so the results are identical.  A negative `mincols` makes the
+reference's result depend on insertion order; that is not reproduced (ValueError on query).
+"""
+from bxmi.intervals import IntervalIndex
+
+__all__ = ["ClusterTree"]
+
+_INT_MIN, _INT_MAX = -(2**31), 2**31 - 1
+
+
+def _cint(x):
+    # the C signature takes ints: anything else overflows or fails the way Cython's coercion does
+    v = int(x)
+    if v < _INT_MIN or v > _INT_MAX:
+        raise OverflowError("value too large to convert to int")
+    return v
+
+
+class ClusterTree:
+    """cluster.pyx:57-121"""
+
+    def __init__(self, mincols, minregions):
+        self.mincols = _cint(mincols)
+        self.minregions = _cint(minregions)
+        self._s, self._e, self._ids = [], [], []
+        self._regions = None
+
+    def insert(self, s, e, id):
+        """Insert an interval with start, end, id as parameters (cluster.pyx:69-72)."""
+        if s > e:
+            raise ValueError("Interval start must be before end")
+        s, e, id = _cint(s), _cint(e), _cint(id)
+        self._s.append(s), self._e.append(e), self._ids.append(id)
+        self._regions = None
+
+    def _compute(self):
+        if self._regions is None:
+            regions = []
+            if self._s:
+                if self.mincols < 0:
+                    raise ValueError("ClusterTree with a negative distance depends on the insertion order in the reference; not supported")
+                ix = IntervalIndex()
+                ix.append(self._s, self._e)
+                starts, ends, offsets, members = ix.clusters(self.mincols, self._ids)
+                members = members.tolist()
+                for c, (a, b) in enumerate(zip(starts.tolist(), ends.tolist())):
+                    lo, hi = int(offsets[c]), int(offsets[c + 1])
+                    if hi - lo >= self.minregions:  # src/cluster.c:190 (num_ivals >= min_intervals)
+                        regions.append((a, b, members[lo:hi]))
+                ix.close()
+            self._regions = regions
+        return self._regions
+
+    def getregions(self):
+        """Clusters in ascending order of start: (start, end, [sorted ids]) (cluster.pyx:74-98)."""
+        return [(a, b, list(ids)) for a, b, ids in self._compute()]
+
+    def getlines(self):
+        """The ids of all clustered intervals, cluster by cluster (cluster.pyx:100-121)."""
+        return [i for _, _, ids in self._compute() for i in ids]

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "bxmi_ivl_find_dev": [vp, vp, vp, i64, vp, vp, i64, _p(i64), vp],
     "bxmi_ivl_find_one": [vp, i32, i32, vp, i64, _p(i64)],
     "bxmi_ivl_neighbors": [vp, i32, i32, C.c_int, vp, i64, _p(i64)],
+    "bxmi_ivl_clusters": [vp, vp, i32, _p(i64), vp, vp, vp, vp],
     "bxmi_bits_create": [i64, i64, _p(vp)],
     "bxmi_bits_destroy": [vp],
     "bxmi_bits_info": [vp, _p(i32), _p(i32), _p(i32)],

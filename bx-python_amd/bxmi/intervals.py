@@ -148,3 +148,23 @@ class IntervalIndex:
                 return out[: n_out.value]
             cap = n_out.value
         raise _ffi.BxmiError(_ffi.ERANGE, "neighbors: buffer still too small")
+
+    def clusters(self, max_dist, ids=None):
+        """ClusterTree's grouping (cluster.pyx:57-121): intervals chained by gaps <= max_dist.
+        -> (starts int32[c], ends int32[c], offsets int64[c+1], members int32[n]); members of a cluster are ids in
+        ascending order (ids[insertion index], or the insertion index when ids is None)."""
+        self._ready()
+        n = self._n
+        starts = np.empty(max(n, 1), dtype=np.int32)
+        ends = np.empty(max(n, 1), dtype=np.int32)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        members = np.empty(max(n, 1), dtype=np.int32)
+        nc = C.c_int64(0)
+        if ids is not None:
+            ids = as_i32(ids)
+            if len(ids) != n:
+                raise ValueError("ids must have one entry per interval")
+        call("bxmi_ivl_clusters", self._h, ptr(ids) if ids is not None else None, int(max_dist), C.byref(nc), ptr(starts), ptr(ends),
+             ptr(offsets), ptr(members))
+        c = nc.value
+        return starts[:c], ends[:c], offsets[: c + 1], members[:n]

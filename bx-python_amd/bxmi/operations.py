@@ -349,9 +349,15 @@ def coverage(readers, comments=True):
 
 
 def _note_reader_skip(reader, message):
-    # merge.py:27-35 / complement.py:50-57: `reader.skipped += 1; if reader.skipped < 10: skipped_lines.append(...)`
+    # merge.py:27-35 / complement.py:50-57 / find_clusters.py:33-40:
+    # `reader.skipped += 1; if reader.skipped < 10: skipped_lines.append((linenum, current_line, message))`, errors ignored
     try:
-        reader.note_skip(reader.linenum, reader.current_line, message)
+        if hasattr(reader, "note_skip"):
+            reader.note_skip(reader.linenum, reader.current_line, message)
+        else:
+            reader.skipped += 1
+            if reader.skipped < 10:
+                reader.skipped_lines.append((reader.linenum, reader.current_line, message))
     except Exception:
         pass
 
@@ -395,6 +401,26 @@ def complement(reader, lens):
             fields[safe.start_col] = start
             fields[safe.end_col] = min(end, limit)
             yield GenomicInterval(safe, fields, safe.chrom_col, safe.start_col, safe.end_col, safe.strand_col, "+")
+
+
+def find_clusters(reader, mincols=1, minregions=2):
+    """operations/find_clusters.py:20-41: one ClusterTree per chromosome keyed by 0-based item number; everything that is
+    not an interval row is returned in `extra`.  The trees answer on the device when asked."""
+    from bx.intervals.cluster import ClusterTree
+
+    extra, chroms = {}, {}
+    for linenum, item in enumerate(reader):
+        if not isinstance(item, GenomicInterval):
+            extra[linenum] = item
+            continue
+        tree = chroms.get(item.chrom)
+        if tree is None:
+            tree = chroms[item.chrom] = ClusterTree(mincols, minregions)
+        try:
+            tree.insert(item.start, item.end, linenum)
+        except OverflowError as e:
+            _note_reader_skip(reader, str(e))
+    return chroms, extra
 
 
 def base_coverage(reader):

@@ -121,6 +121,15 @@ int bxmi_ivl_find_one(bxmi_ivl_t *h, int32_t qs, int32_t qe, int32_t *hits, int6
 int bxmi_ivl_neighbors(bxmi_ivl_t *h, int32_t position, int32_t max_dist, int dir, int32_t *out, int64_t cap,
                        int64_t *n_out);
 
+/* ClusterTree (lib/bx/intervals/cluster.pyx:57-121, src/cluster.c:112-260): groups of intervals chained by gaps of at
+ * most max_dist (>= 0).  All clusters in ascending start order: starts[c], ends[c], and members[offsets[c] ..
+ * offsets[c+1]) = the member ids in ascending order, where an interval's id is ids[insertion index] (or the insertion
+ * index itself when ids is NULL).  starts/ends/members need n entries, offsets n + 1 (n = bxmi_ivl_size).  The caller
+ * applies ClusterTree's min_intervals filter.  max_dist < 0 -> BXMI_EINVAL (the reference's result then depends on
+ * the insertion order). */
+int bxmi_ivl_clusters(bxmi_ivl_t *h, const int32_t *ids, int32_t max_dist, int64_t *n_clusters, int32_t *starts, int32_t *ends,
+                      int64_t *offsets, int32_t *members);
+
 /* ---- binned bitset  (binBits.h:15-26, bitset.pyx:198-241) ----------------- */
 /* binBitsAlloc(size, granularity): bin_size and nbins use the reference's
  * float32 arithmetic; size > 2^31-1 or size < 1 -> BXMI_EINVAL.

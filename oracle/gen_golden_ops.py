@@ -27,6 +27,8 @@ from bx.intervals.operations.coverage import coverage  # noqa: E402
 from bx.intervals.operations.intersect import intersect  # noqa: E402
 from bx.intervals.operations.merge import merge  # noqa: E402
 from bx.intervals.operations.subtract import subtract  # noqa: E402
+from bx.intervals.cluster import ClusterTree  # noqa: E402  (the reference's extension: cluster.pyx + src/cluster.c)
+from bx.intervals.operations.find_clusters import find_clusters  # noqa: E402
 from bx.tabular.io import Comment, Header  # noqa: E402
 
 assert "bxref" in sys.modules["bx.intervals.operations.intersect"].__file__ or PYREF in sys.modules["bx.intervals.operations.intersect"].__file__
@@ -155,6 +157,51 @@ OPS = dict(intersect=intersect, subtract=subtract, coverage=coverage, merge=merg
 MAKE = dict(nice=nice, plain=plain)
 
 
+def cluster_cases():
+    """ClusterTree vectors: the reference's own test inputs (cluster_tests.py:15-130) and seeded random trees."""
+    fixed = [
+        (0, 0, [(3, 4, 0), (6, 7, 1), (9, 10, 2), (1, 2, 3), (3, 8, 4)]),
+        (0, 0, [(1, 4, 0), (4, 5, 1)]),
+        (0, 0, [(1, 2, 0), (4, 5, 1), (2, 4, 2)]),
+        (0, 0, [(1, 2, 0), (8, 9, 1), (3, 4, 2), (5, 6, 3), (7, 8, 4), (1, 10, 5)]),
+        (0, 0, [(1, 1, 0), (1, 2, 1), (3, 4, 2), (3, 4, 3), (1, 4, 4)]),
+        (0, 2, [(3, 4, 0), (6, 7, 1), (9, 10, 2), (1, 2, 3), (3, 8, 4)]),
+        (1, 0, [(3, 4, 0), (6, 7, 1), (9, 10, 2), (1, 2, 3), (3, 8, 4)]),
+        (0, 0, [(6, 7, 1), (1, 2, 3), (9, 10, 2), (3, 4, 0), (3, 8, 4)]),
+        (0, 0, [(3, 4, 1), (13, 14, 6), (21, 22, 14), (5, 6, 2), (4, 10, 11), (1, 2, 0), (11, 12, 5), (1, 3, 10), (7, 8, 3),
+                (15, 16, 7), (15, 20, 13), (19, 20, 9), (10, 15, 12), (17, 18, 8), (9, 10, 4)]),
+        (0, 0, []),
+    ]
+    rng = np.random.default_rng(77)
+    for n, span, lmax in ((50, 400, 20), (300, 4000, 40), (300, 100000, 300), (600, 10**9, 10**6), (500, 30, 5)):
+        for md in (0, 1, 7, 1000):
+            s = rng.integers(-span, span, size=n)
+            e = s + rng.integers(0, lmax, size=n)
+            ids = rng.integers(-1000, 100000, size=n)
+            fixed.append((md, int(rng.integers(0, 4)), [(int(a), int(b), int(i)) for a, b, i in zip(s, e, ids)]))
+    out = []
+    for md, mn, triples in fixed:
+        t = ClusterTree(md, mn)
+        for a, b, i in triples:
+            t.insert(a, b, i)
+        out.append(dict(max_dist=md, min_intervals=mn, triples=triples, regions=[[a, b, ids] for a, b, ids in t.getregions()],
+                        lines=t.getlines()))
+    return out
+
+
+def find_clusters_cases():
+    out = []
+    for name, lines, kind, params in (("messy", PRIMARY_MESSY, "nice", dict(mincols=1, minregions=2)),
+                                      ("messy_wide", PRIMARY_MESSY, "nice", dict(mincols=200, minregions=1)),
+                                      ("random", RAND_P, "plain", dict(mincols=10, minregions=2))):
+        reader = MAKE[kind](lines)
+        chroms, extra = find_clusters(reader, **params)
+        out.append(dict(name=name, input=name, reader=kind, params=params,
+                        chroms={c: dict(regions=[[a, b, ids] for a, b, ids in t.getregions()], lines=t.getlines()) for c, t in chroms.items()},
+                        chrom_order=list(chroms), extra={str(k): tell(v) for k, v in extra.items()}, primary=skips(reader)))
+    return out
+
+
 def main():
     out = []
     for c in CASES:
@@ -182,7 +229,9 @@ def main():
         print("%-40s %s" % (c["name"], "items=%s err=%s" % (len(rec["output"]) if rec["output"] is not None else rec.get("value"), rec["error"])))
     path = os.path.join(ROOT, "tests", "golden", "operations.json")
     with open(path, "w") as f:
-        json.dump(dict(generator="oracle/gen_golden_ops.py", inputs=INPUTS, cases=out), f, separators=(",", ":"))
+        json.dump(dict(generator="oracle/gen_golden_ops.py", inputs=INPUTS, cases=out, clusters=cluster_cases(),
+                       find_clusters=find_clusters_cases(), find_clusters_inputs=dict(messy=PRIMARY_MESSY, messy_wide=PRIMARY_MESSY, random=RAND_P)),
+                  f, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")
 
 

@@ -18,6 +18,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 _REF = os.path.join(_HERE, "_ref", "libbinbits_ref.so")
+_REF_CLUSTER = os.path.join(_HERE, "_ref", "libcluster_ref.so")
 
 MAX_INT = 2147483647  # bitset.pyx:105
 MAX = 512 * 1024 * 1024  # bitset.pyx:196
@@ -29,11 +30,11 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 def build(force=False):
     """Compile liboracle.so (and _ref when the reference tree is mounted)."""
-    srcs = [os.path.join(_HERE, f) for f in ("ivtree.c", "binbits.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("ivtree.c", "binbits.c", "cluster.c")]
     stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF)):
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF) or not os.path.exists(_REF_CLUSTER)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -90,6 +91,8 @@ def lib():
         L.obb_runs.restype = C.c_int64
         L.obb_runs.argtypes = [vp, vp, vp, C.c_int64]
         L.obb_unpack.argtypes = [vp, _u8p]
+        L.oracle_clusters.restype = C.c_int64
+        L.oracle_clusters.argtypes = [_i32p, _i32p, vp, C.c_int64, C.c_int32, _i32p, _i32p, _i64p, _i32p]
         _lib = L
     return _lib
 
@@ -383,3 +386,86 @@ class RefBinnedBitSet(_BinBitsBase):
 
     def invert(self):
         ref_lib().binBitsNot(self._p)
+
+
+# ---------------------------------------------------------------- ClusterTree (src/cluster.c, cluster.pyx) --
+def cluster_regions(starts, ends, ids, max_dist, min_intervals=0):
+    """getregions() of a ClusterTree(max_dist, min_intervals) holding the given intervals (oracle/cluster.c)."""
+    s, e = _i32(starts), _i32(ends)
+    n = len(s)
+    idv = _i32(ids) if ids is not None else None
+    c_start, c_end = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.int32)
+    c_off, members = np.zeros(n + 1, np.int64), np.empty(max(n, 1), np.int32)
+    nc = lib().oracle_clusters(s, e, idv.ctypes.data if idv is not None else None, n, int(max_dist), c_start, c_end, c_off, members)
+    if nc < 0:
+        raise ValueError("oracle_clusters: bad input (negative max_dist is insertion-order dependent in the reference)")
+    out = []
+    for c in range(nc):
+        lo, hi = int(c_off[c]), int(c_off[c + 1])
+        if hi - lo >= min_intervals:
+            out.append((int(c_start[c]), int(c_end[c]), members[lo:hi].tolist()))
+    return out
+
+
+class _RefInterval(C.Structure):  # src/cluster.h: struct_interval
+    pass
+
+
+_RefInterval._fields_ = [("start", C.c_int), ("end", C.c_int), ("id", C.c_int), ("next", C.POINTER(_RefInterval))]
+
+
+class _RefClusterNode(C.Structure):  # src/cluster.h: struct_clusternode (leading fields)
+    _fields_ = [("start", C.c_int), ("end", C.c_int), ("priority", C.c_int), ("interval_head", C.POINTER(_RefInterval)),
+                ("interval_tail", C.POINTER(_RefInterval)), ("num_ivals", C.c_int)]
+
+
+class _RefClusterTree(C.Structure):  # src/cluster.h: struct_clustertree
+    _fields_ = [("max_dist", C.c_int), ("min_intervals", C.c_int), ("root", C.c_void_p)]
+
+
+class _RefTreeItr(C.Structure):
+    pass
+
+
+_RefTreeItr._fields_ = [("next", C.POINTER(_RefTreeItr)), ("node", C.POINTER(_RefClusterNode))]
+
+_ref_cluster = None
+
+
+def have_ref_cluster():
+    return os.path.exists(_REF_CLUSTER)
+
+
+def ref_cluster_regions(triples, max_dist, min_intervals):
+    """cluster.pyx's getregions() re-hosted on the reference's compiled src/cluster.c: inserts in the given order."""
+    global _ref_cluster
+    if _ref_cluster is None:
+        R = C.CDLL(_REF_CLUSTER)
+        R.create_clustertree.restype = C.POINTER(_RefClusterTree)
+        R.create_clustertree.argtypes = [C.c_int, C.c_int]
+        R.clusternode_insert.restype = C.c_void_p
+        R.clusternode_insert.argtypes = [C.POINTER(_RefClusterTree), C.c_void_p, C.c_int, C.c_int, C.c_int]
+        R.clusteritr.restype = C.POINTER(_RefTreeItr)
+        R.clusteritr.argtypes = [C.POINTER(_RefClusterTree)]
+        R.freeclusteritr.argtypes = [C.POINTER(_RefTreeItr)]
+        R.free_tree.argtypes = [C.POINTER(_RefClusterTree)]
+        _ref_cluster = R
+    R = _ref_cluster
+    tree = R.create_clustertree(int(max_dist), int(min_intervals))
+    for s, e, i in triples:
+        tree.contents.root = R.clusternode_insert(tree, tree.contents.root, int(s), int(e), int(i))
+    out = []
+    itr = R.clusteritr(tree)
+    head = itr
+    while itr:
+        node = itr.contents.node.contents
+        ids, iv = [], node.interval_head
+        while iv:
+            ids.append(iv.contents.id)
+            iv = iv.contents.next
+        out.append((node.start, node.end, sorted(ids)))
+        itr = itr.contents.next
+    if head:
+        R.freeclusteritr(head)
+    R.free_tree(tree)
+    return out

@@ -114,3 +114,62 @@ def test_range_generators_match_the_batched_pieces(mods):
                     raised = True
                 got = list(zip(ps[off[i]:off[i + 1]].tolist(), pe[off[i]:off[i + 1]].tolist()))
                 assert got == want and bool(off_end[i]) == raised, (size, nr, fn.__name__, int(a[i]), int(b[i]), got, want, raised)
+
+
+# ------------------------------------------------------------------ ClusterTree / find_clusters (rank 4) --
+def test_clustertree_matches_reference_vectors(golden):
+    """The drop-in bx.intervals.cluster.ClusterTree (device clustering through bxmi_ivl_clusters) against
+    getregions()/getlines() of the reference's extension on 30 trees, and against the CPU oracle on a big one."""
+    import numpy as np
+
+    from bx.intervals.cluster import ClusterTree
+    from oracle import oracle as O
+
+    for c in golden["clusters"]:
+        t = ClusterTree(c["max_dist"], c["min_intervals"])
+        for a, b, i in c["triples"]:
+            t.insert(a, b, i)
+        assert [[a, b, ids] for a, b, ids in t.getregions()] == c["regions"], (c["max_dist"], c["min_intervals"], len(c["triples"]))
+        assert t.getlines() == c["lines"]
+        t.insert(10**8, 10**8 + 1, 7)  # inserting after a query invalidates the cached answer
+        if c["min_intervals"] <= 1:
+            assert t.getlines().count(7) == c["lines"].count(7) + 1
+    t = ClusterTree(0, 0)
+    with pytest.raises(ValueError, match="Interval start must be before end"):
+        t.insert(4, 2, 0)
+    with pytest.raises(OverflowError):
+        t.insert(0, 2**31, 0)
+    assert t.getregions() == [] and t.getlines() == []
+    # 2M intervals, three distances: device result == CPU restatement
+    rng = np.random.default_rng(4)
+    n = 2_000_000
+    s = rng.integers(0, 2_000_000_000, size=n).astype(np.int32)
+    e = (s.astype(np.int64) + rng.integers(0, 400, size=n)).clip(max=2**31 - 1).astype(np.int32)
+    ids = rng.integers(-(2**31), 2**31 - 1, size=n).astype(np.int32)
+    from bxmi.intervals import IntervalIndex
+
+    ix = IntervalIndex()
+    ix.append(s, e)
+    for md in (0, 300, 5000):
+        cs, ce, off, mem = ix.clusters(md, ids)
+        want = O.cluster_regions(s, e, ids, md, 0)
+        assert len(cs) == len(want)
+        assert cs.tolist() == [w[0] for w in want] and ce.tolist() == [w[1] for w in want]
+        assert mem.tolist() == [i for w in want for i in w[2]]
+        assert off.tolist() == np.concatenate([[0], np.cumsum([len(w[2]) for w in want])]).tolist()
+
+
+def test_find_clusters_matches_the_reference(golden, mods):
+    genomic, operations = mods
+    make = {"nice": genomic.NiceReaderWrapper, "plain": genomic.GenomicIntervalReader}
+    for c in golden["find_clusters"]:
+        reader = make[c["reader"]](list(golden["find_clusters_inputs"][c["input"]]))
+        chroms, extra = operations.find_clusters(reader, **c["params"])
+        assert list(chroms) == c["chrom_order"], c["name"]
+        for chrom, want in c["chroms"].items():
+            assert [[a, b, ids] for a, b, ids in chroms[chrom].getregions()] == want["regions"], (c["name"], chrom)
+            assert chroms[chrom].getlines() == want["lines"], (c["name"], chrom)
+        assert {str(k): _tell(genomic, v) for k, v in extra.items()} == c["extra"], c["name"]
+        if c["primary"] is not None:
+            assert reader.skipped == c["primary"]["skipped"]
+            assert [list(t) for t in reader.skipped_lines] == c["primary"]["skipped_lines"]

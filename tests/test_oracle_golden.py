@@ -252,3 +252,58 @@ def test_restatement_equals_compiled_reference_c():
         for w in range(2):
             assert mine[w].count_range(0, size) == ref[w].count_range(0, size)
             assert all(mine[w][p] == ref[w][p] for p in range(0, size, max(1, size // 997)))
+
+
+# ------------------------------------------------------------------ ClusterTree --
+def _cluster_golden():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "operations.json")) as f:
+        return json.load(f)["clusters"]
+
+
+def test_cluster_restatement_matches_reference_vectors():
+    """oracle/cluster.c against getregions()/getlines() of the reference's extension (30 trees: the inputs of the
+    reference's own cluster_tests.py plus seeded random ones; oracle/gen_golden_ops.py)."""
+    cases = _cluster_golden()
+    assert len(cases) >= 30
+    for c in cases:
+        t = c["triples"]
+        got = O.cluster_regions([x[0] for x in t], [x[1] for x in t], [x[2] for x in t], c["max_dist"], c["min_intervals"])
+        assert [[a, b, ids] for a, b, ids in got] == c["regions"], (c["max_dist"], c["min_intervals"], len(t))
+        assert [i for _, _, ids in got for i in ids] == c["lines"]
+
+
+def test_reference_known_answers_cluster():
+    """cluster_tests.py:15-61 as literals."""
+    def regions(pairs, md=0, mn=0):
+        return O.cluster_regions([p[0] for p in pairs], [p[1] for p in pairs], list(range(len(pairs))), md, mn)
+
+    assert regions([(3, 4), (6, 7), (9, 10), (1, 2), (3, 8)]) == [(1, 2, [3]), (3, 8, [0, 1, 4]), (9, 10, [2])]
+    assert regions([(1, 4), (4, 5)]) == [(1, 5, [0, 1])]
+    assert regions([(1, 2), (4, 5), (2, 4)]) == [(1, 5, [0, 1, 2])]
+    assert regions([(1, 2), (8, 9), (3, 4), (5, 6), (7, 8), (1, 10)]) == [(1, 10, [0, 1, 2, 3, 4, 5])]
+    assert regions([(1, 1), (1, 2), (3, 4), (3, 4), (1, 4)]) == [(1, 4, [0, 1, 2, 3, 4])]
+    assert regions([(3, 4), (6, 7), (9, 10), (1, 2), (3, 8)], mn=2) == [(3, 8, [0, 1, 4])]
+    assert regions([(3, 4), (6, 7), (9, 10), (1, 2), (3, 8)], md=1) == [(1, 10, [0, 1, 2, 3, 4])]
+    upto = 100000
+    pairs = [(2 * i + 1, 2 * i + 2) for i in range(upto)] + [(0, upto * 3)]
+    assert regions(pairs) == [(0, upto * 3, list(range(upto + 1)))]
+
+
+@pytest.mark.skipif(not O.have_ref_cluster(), reason="oracle/_ref/libcluster_ref.so is built only where /root/reference exists")
+def test_cluster_restatement_equals_compiled_reference_c():
+    """oracle/cluster.c vs the reference's own src/cluster.c compiled in place, inserted in random orders."""
+    rng = np.random.default_rng(9)
+    for trial in range(400):
+        n = int(rng.integers(1, 80))
+        md, mn = int(rng.integers(0, 25)), int(rng.integers(0, 4))
+        span = int(rng.choice([40, 300, 10**6]))
+        s = rng.integers(-span, span, size=n)
+        e = s + rng.integers(0, 30, size=n)
+        ids = rng.integers(-50, 5000, size=n)
+        order = rng.permutation(n)
+        want = O.ref_cluster_regions([(int(s[i]), int(e[i]), int(ids[i])) for i in order], md, mn)
+        got = O.cluster_regions(s, e, ids, md, mn)
+        assert got == want, (trial, md, mn, n)
