@@ -219,6 +219,56 @@ def bench_bitsets(torch, steps, warmup):
     return out
 
 
+def bench_find(torch, reps=3):
+    """configs[4] (BASELINE.json: 50M x 50M overlap join, CSR hit list kept in HBM) -- a side measurement, never `value`.
+    Generated order and the same queries sorted by start; size-independent checks on the full result."""
+    from bxmi import synth
+    from bxmi.intervals import IntervalIndex
+
+    nt = nq = 50_000_000
+    (ts, te), (qs_h, qe_h) = synth.cfg5(nt, nq)
+    ix = IntervalIndex()
+    ix.append(ts, te)
+    ix.seal()
+    cap = nq * 8
+    offs = torch.empty(nq + 1, dtype=torch.int64, device="cuda")
+    hits = torch.empty(cap, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {"workload": "configs[4]: %d x %d join, G=2e9, len U[1,200], CSR (int64 offsets, int32 hits) in HBM" % (nq, nt)}
+    d_ts, d_te = torch.from_numpy(ts).cuda(), torch.from_numpy(te).cuda()
+    qs, qe = torch.from_numpy(qs_h).cuda(), torch.from_numpy(qe_h).cuda()
+    for label in ("generated_order", "sorted_by_start"):
+        if label == "sorted_by_start":
+            o = torch.argsort(qs, stable=True)
+            qs, qe = qs[o].contiguous(), qe[o].contiguous()
+            del o
+        rc, total = ix.find_dev(qs.data_ptr(), qe.data_ptr(), nq, offs.data_ptr(), hits.data_ptr(), cap, stream)
+        if rc != 0:
+            return {"error": "find_dev rc=%d" % rc}
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ix.find_dev(qs.data_ptr(), qe.data_ptr(), nq, offs.data_ptr(), hits.data_ptr(), cap, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        h = hits[:total].long()
+        rep = torch.repeat_interleave(torch.arange(nq, device="cuda"), offs[1:] - offs[:-1])
+        every_hit_overlaps = bool(((d_te[h] > qs[rep]) & (d_ts[h] < qe[rep])).all().item())
+        counts = torch.empty(nq, dtype=torch.int32, device="cuda")
+        tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+        ix.count_dev(qs.data_ptr(), qe.data_ptr(), nq, counts.data_ptr(), tot.data_ptr(), stream)
+        torch.cuda.synchronize()
+        counts_match = bool(torch.equal((offs[1:] - offs[:-1]).int(), counts)) and int(tot.item()) == total
+        alg = nq * 16 + total * 4 + nt * 8
+        out[label] = dict(ms=round(ms, 3), m_queries_per_s=round(nq / ms / 1e3, 1), m_hits_per_s=round(total / ms / 1e3, 1), hits=int(total),
+                          frac_of_hbm_peak=round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), every_hit_overlaps=every_hit_overlaps,
+                          counts_match_count_path=counts_match)
+        del h, rep, counts
+    return out
+
+
 def alg_bytes_of(nq, nt):
     """8 B in + 4 B out per query, the sorted starts + ends read once."""
     return nq * 12 + nt * 8
@@ -234,6 +284,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bitset", action="store_true")
+    ap.add_argument("--no-find", action="store_true", help="skip the configs[4] CSR-join side measurement")
     ap.add_argument("--no-sorted", action="store_true", help="skip the sorted-queries side measurement (profiling runs: its launches "
                     "dismiss the bucketed kernels at once and would halve their average durations)")
     ap.add_argument("--allreduce-total", type=int, default=1, help="all-reduce the int64 overlap total each step when --gpus > 1")
@@ -429,6 +480,12 @@ def main():
             line["bitset"] = bench_bitsets(torch, max(5, args.steps), args.warmup)
         except Exception as ex:
             line["bitset"] = {"error": repr(ex)}
+    if world == 1 and not args.no_find:
+        try:
+            torch.cuda.empty_cache()
+            line["find_csr"] = bench_find(torch)
+        except Exception as ex:
+            line["find_csr"] = {"error": repr(ex)}
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
