@@ -423,6 +423,70 @@ def find_clusters(reader, mincols=1, minregions=2):
     return chroms, extra
 
 
+def join(leftSet, rightSet, mincols=1, leftfill=True, rightfill=True):
+    """operations/join.py:14-75: every left row is paired with the right rows it overlaps by at least `mincols`
+    (left fields + right fields); unmatched rows are padded with "." when the fill flags ask for it.
+
+    The reference reports the matches of one left row in the pre-order of a treap with RANDOM priorities
+    (quicksect.py:39-44,113-119), i.e. in no reproducible order; here they come in the index's order (by start).
+    Everything else -- which rows, the overlap arithmetic with its inclusive-range quirks (:36-50), the fill rows and
+    the final in-order list of never-matched right rows (ties: later line first, quicksect.py:50-63) -- is identical.
+    One batched `find` per chromosome replaces the per-row tree walks."""
+    right = {}  # chrom -> (starts, ends, fields lists), in file order
+    rightlen = 0
+    for item in rightSet:
+        if isinstance(item, GenomicInterval):
+            g = right.setdefault(item.chrom, ([], [], []))
+            g[0].append(item.start), g[1].append(item.end), g[2].append(item.fields)
+            if rightlen == 0:
+                rightlen = item.nfields
+    left = list(leftSet)
+    leftlen = 0
+    by_chrom = {}
+    for i, item in enumerate(left):
+        if isinstance(item, GenomicInterval):
+            if leftlen == 0:
+                leftlen = item.nfields
+            if item.chrom in right:
+                by_chrom.setdefault(item.chrom, []).append(i)
+    matches = {}  # left item index -> list of (chrom, right row number)
+    for chrom, rows in by_chrom.items():
+        rs, re, _ = right[chrom]
+        index = IntervalIndex()
+        index.append(np.array(rs, dtype=np.int64).astype(np.int32), np.array(re, dtype=np.int64).astype(np.int32))
+        qs = np.array([left[i].start for i in rows], dtype=np.int64)
+        qe = np.array([left[i].end for i in rows], dtype=np.int64)
+        off, hits = index.find(qs.astype(np.int32), qe.astype(np.int32))
+        index.close()
+        hs, he = np.array(rs, dtype=np.int64)[hits], np.array(re, dtype=np.int64)[hits]
+        row = np.repeat(np.arange(len(rows)), np.diff(off))
+        a, b = qs[row], qe[row]
+        s_in = (hs >= a) & (hs <= b)  # `item.start in range(interval.start, interval.end + 1)`
+        e_in = (he >= a) & (he <= b)
+        overlap = np.where(s_in & ~e_in, b - hs, np.where(e_in & ~s_in, he - a, np.where(s_in & e_in, he - hs, b - a)))
+        ok = overlap >= mincols
+        for k, i in enumerate(rows):
+            lo, hi = int(off[k]), int(off[k + 1])
+            matches[i] = (chrom, hits[lo:hi][ok[lo:hi]].tolist(), hi - lo)
+    visited = {chrom: set() for chrom in right}
+    for i, item in enumerate(left):
+        if not isinstance(item, GenomicInterval):
+            yield item
+            continue
+        chrom, good, found = matches.get(i, (item.chrom, [], 0))
+        for j in good:
+            visited[chrom].add(j)
+            yield list(item) + list(right[chrom][2][j])
+        if not good and rightfill:  # nothing found, or nothing met mincols
+            yield list(item) + ["."] * rightlen
+    if leftfill:
+        for chrom, (rs, _, fields) in right.items():
+            order = sorted(range(len(rs)), key=lambda j: (rs[j], -j))  # in-order of the reference's tree
+            for j in order:
+                if j not in visited[chrom]:
+                    yield ["."] * leftlen + list(fields[j])
+
+
 def base_coverage(reader):
     """operations/base_coverage.py:10-23.  Number of bases covered by the reader's intervals."""
     safe, bitsets = _first_safe_bitsets(reader, {})

@@ -29,6 +29,7 @@ from bx.intervals.operations.merge import merge  # noqa: E402
 from bx.intervals.operations.subtract import subtract  # noqa: E402
 from bx.intervals.cluster import ClusterTree  # noqa: E402  (the reference's extension: cluster.pyx + src/cluster.c)
 from bx.intervals.operations.find_clusters import find_clusters  # noqa: E402
+from bx.intervals.operations.join import join  # noqa: E402
 from bx.tabular.io import Comment, Header  # noqa: E402
 
 assert "bxref" in sys.modules["bx.intervals.operations.intersect"].__file__ or PYREF in sys.modules["bx.intervals.operations.intersect"].__file__
@@ -202,6 +203,25 @@ def find_clusters_cases():
     return out
 
 
+def join_cases():
+    """join: the match order inside one left row is random in the reference (treap priorities); the test canonicalises it."""
+    import random
+
+    out = []
+    small_l = bed([("chr1", 10, 50), ("chr1", 40, 45), ("chr1", 100, 100), ("chr2", 5, 500), ("chrX", 1, 9), ("chr1", 30, 31), ("chr1", 10, 50)])
+    small_r = ["#r\n"] + bed([("chr1", 20, 30), ("chr1", 25, 44), ("chr1", 44, 60), ("chr1", 10, 50), ("chr1", 50, 70), ("chr1", 20, 30),
+                              ("chr2", 100, 200), ("chr3", 0, 10), ("chr1", 0, 10)], extra=False)
+    inputs = dict(small_l=["#l\n", "# c\n"] + small_l, small_r=small_r, rand_l=RAND_P, rand_r=RAND_A)
+    for name, lkey, rkey, params in (("small", "small_l", "small_r", dict()), ("small_m5", "small_l", "small_r", dict(mincols=5)),
+                                     ("small_nofill", "small_l", "small_r", dict(leftfill=False, rightfill=False)),
+                                     ("small_m0", "small_l", "small_r", dict(mincols=0, rightfill=False)),
+                                     ("random", "rand_l", "rand_r", dict(mincols=3)), ("random_m40", "rand_l", "rand_r", dict(mincols=40, leftfill=False))):
+        random.seed(5)
+        items = [tell(x) for x in join(nice(inputs[lkey]), plain(inputs[rkey]), **params)]
+        out.append(dict(name=name, left=lkey, right=rkey, params=params, output=items))
+    return dict(inputs=inputs, cases=out)
+
+
 def main():
     out = []
     for c in CASES:
@@ -230,7 +250,7 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "operations.json")
     with open(path, "w") as f:
         json.dump(dict(generator="oracle/gen_golden_ops.py", inputs=INPUTS, cases=out, clusters=cluster_cases(),
-                       find_clusters=find_clusters_cases(), find_clusters_inputs=dict(messy=PRIMARY_MESSY, messy_wide=PRIMARY_MESSY, random=RAND_P)),
+                       join=join_cases(), find_clusters=find_clusters_cases(), find_clusters_inputs=dict(messy=PRIMARY_MESSY, messy_wide=PRIMARY_MESSY, random=RAND_P)),
                   f, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")
 

@@ -173,3 +173,33 @@ def test_find_clusters_matches_the_reference(golden, mods):
         if c["primary"] is not None:
             assert reader.skipped == c["primary"]["skipped"]
             assert [list(t) for t in reader.skipped_lines] == c["primary"]["skipped_lines"]
+
+
+def test_join_matches_the_reference(golden, mods):
+    """operations.join against the reference's (captured with a seeded RNG).  The reference lists the matches of one
+    left row in the pre-order of a randomly balanced tree, so rows sharing a left row are compared as a sorted group;
+    headers, fill rows and the trailing never-matched right rows must be in the reference's exact order."""
+    genomic, operations = mods
+    g = golden["join"]
+
+    def canon(items, leftlen=6):
+        out, run, prev = [], [], None
+        for it in items:
+            key = tuple(it[1][:leftlen]) if it[0] == "list" else None
+            if key is None or key != prev:
+                out.extend(sorted(run))
+                run = []
+            if key is None:
+                out.append(it)
+            else:
+                run.append(it)
+            prev = key
+        return out + sorted(run)
+
+    assert len(g["cases"]) >= 6
+    for c in g["cases"]:
+        left = genomic.NiceReaderWrapper(list(g["inputs"][c["left"]]))
+        right = genomic.GenomicIntervalReader(list(g["inputs"][c["right"]]))
+        got = [_tell(genomic, x) for x in operations.join(left, right, **c["params"])]
+        assert len(got) == len(c["output"]), (c["name"], len(got), len(c["output"]))
+        assert canon(got) == canon(c["output"]), c["name"]
