@@ -1,0 +1,151 @@
+"""
+CPU tests (-m "not gpu") of the HOST logic of bxmi.operations / bxmi.genomic: the device engine is replaced by the
+CPU oracle (test infrastructure, oracle/) behind the two seams the operations use -- `bx.bitset.BinnedBitSet` and
+`bxmi.operations.IntervalIndex` -- and everything is compared with the vectors captured from the reference
+(tests/golden/operations.json).  This pins the readers, the batching arithmetic (piece clipping, gap building,
+run-off-the-end rule, skip replay) and join/find_clusters without a GPU; tests/test_gpu_operations.py runs the same
+comparison on the real engine.
+"""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "operations.json")
+
+
+class _OracleBits(O.OracleBinnedBitSet):
+    """OracleBinnedBitSet with the extra surface of the drop-in class that bxmi.operations touches."""
+
+    @property
+    def _d(self):
+        return self
+
+    def check_range_count(self, start, count):
+        self._check_range_count(start, count)
+
+    def runs(self, start=0):
+        return O.OracleBinnedBitSet.runs(self)
+
+
+class _OracleIndex:
+    """IntervalIndex look-alike on the oracle treap (find in tree order -> insertion indices)."""
+
+    def __init__(self):
+        self._s, self._e = [], []
+
+    def append(self, starts, ends):
+        self._s.extend(np.asarray(starts).tolist())
+        self._e.extend(np.asarray(ends).tolist())
+
+    def seal(self):
+        pass
+
+    def close(self):
+        pass
+
+    def _tree(self):
+        t = O.OracleIntervalTree()
+        t.insert_many_arrays(np.array(self._s, dtype=np.int32), np.array(self._e, dtype=np.int32))
+        return t
+
+    def find(self, qs, qe):
+        return self._tree().find_batch(np.asarray(qs, dtype=np.int32), np.asarray(qe, dtype=np.int32))
+
+    def clusters(self, max_dist, ids=None):
+        regs = O.cluster_regions(self._s, self._e, ids, max_dist, 0)
+        off = np.concatenate([[0], np.cumsum([len(r[2]) for r in regs])]).astype(np.int64)
+        return (np.array([r[0] for r in regs], np.int32), np.array([r[1] for r in regs], np.int32), off,
+                np.array([i for r in regs for i in r[2]], np.int32))
+
+
+@pytest.fixture()
+def mods(monkeypatch):
+    import bx.bitset
+    import bx.intervals.cluster as cluster_mod
+    from bxmi import genomic, operations
+
+    monkeypatch.setattr(bx.bitset, "BinnedBitSet", _OracleBits)
+    monkeypatch.setattr(operations, "IntervalIndex", _OracleIndex)
+    monkeypatch.setattr(cluster_mod, "IntervalIndex", _OracleIndex)
+    return genomic, operations
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(GOLDEN) as f:
+        return json.load(f)
+
+
+def _tell(genomic, item):
+    if isinstance(item, genomic.Header):
+        return ["header", str(item)]
+    if isinstance(item, genomic.Comment):
+        return ["comment", str(item)]
+    if isinstance(item, list):
+        return ["list", list(item)]
+    return ["interval", [str(f) for f in item.fields], item.chrom, int(item.start), int(item.end), item.strand]
+
+
+def test_operations_host_logic_matches_the_reference(golden, mods):
+    genomic, operations = mods
+    make = {"nice": genomic.NiceReaderWrapper, "plain": genomic.GenomicIntervalReader}
+    for case in golden["cases"]:
+        readers = [make[k](list(golden["inputs"][key])) for k, key in zip(case["readers"], case["inputs"])]
+        op, params, name = case["op"], dict(case["params"]), case["name"]
+        if op == "base_coverage":
+            assert operations.base_coverage(readers[0]) == case["value"], name
+            continue
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            try:
+                if op in ("intersect", "subtract", "coverage"):
+                    it = getattr(operations, op)(readers, **params)
+                elif op == "merge":
+                    it = operations.merge(readers[0])
+                else:
+                    it = operations.complement(readers[0], params["lens"])
+                out, err = [_tell(genomic, x) for x in it], None
+            except Exception as e:
+                out, err = None, [type(e).__name__, str(e)]
+        assert err == case["error"], (name, err)
+        assert out == case["output"], name
+        assert [str(x.message) for x in w] == case["warnings"], name
+        if case["primary"] is not None:
+            assert readers[0].skipped == case["primary"]["skipped"], name
+            assert [list(t) for t in readers[0].skipped_lines] == case["primary"]["skipped_lines"], name
+
+
+def test_join_and_find_clusters_host_logic(golden, mods):
+    genomic, operations = mods
+    g = golden["join"]
+
+    def canon(items, leftlen=6):
+        out, run, prev = [], [], None
+        for it in items:
+            key = tuple(it[1][:leftlen]) if it[0] == "list" else None
+            if key is None or key != prev:
+                out.extend(sorted(run))
+                run = []
+            (out if key is None else run).append(it)
+            prev = key
+        return out + sorted(run)
+
+    for c in g["cases"]:
+        left = genomic.NiceReaderWrapper(list(g["inputs"][c["left"]]))
+        right = genomic.GenomicIntervalReader(list(g["inputs"][c["right"]]))
+        got = [_tell(genomic, x) for x in operations.join(left, right, **c["params"])]
+        assert canon(got) == canon(c["output"]), c["name"]
+    make = {"nice": genomic.NiceReaderWrapper, "plain": genomic.GenomicIntervalReader}
+    for c in golden["find_clusters"]:
+        reader = make[c["reader"]](list(golden["find_clusters_inputs"][c["input"]]))
+        chroms, extra = operations.find_clusters(reader, **c["params"])
+        assert list(chroms) == c["chrom_order"]
+        for chrom, want in c["chroms"].items():
+            assert [[a, b, ids] for a, b, ids in chroms[chrom].getregions()] == want["regions"], (c["name"], chrom)
+            assert chroms[chrom].getlines() == want["lines"]
+        assert {str(k): _tell(genomic, v) for k, v in extra.items()} == c["extra"]
