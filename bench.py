@@ -327,19 +327,23 @@ def main():
     qs = torch.from_numpy(qs_h).cuda()
     qe = torch.from_numpy(qe_h).cuda()
     counts = torch.empty(args.queries, dtype=torch.int32, device="cuda")
-    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    # bxmi_ivl_count_dev ADDS the pass's overlap total to *total: every step gets its own zeroed slot
+    totals = torch.zeros(args.steps + args.warmup + 8, dtype=torch.int64, device="cuda")
+    total = totals[-1:]
     stream = torch.cuda.current_stream().cuda_stream
     nq = args.queries
+    step_no = [0]
 
     def step(ev=None):
-        total.zero_()
+        slot = totals[step_no[0]:step_no[0] + 1]
+        step_no[0] += 1
         if ev:
             ev[0].record()
-        ix.count_dev(qs.data_ptr(), qe.data_ptr(), nq, counts.data_ptr(), total.data_ptr(), stream)
+        ix.count_dev(qs.data_ptr(), qe.data_ptr(), nq, counts.data_ptr(), slot.data_ptr(), stream)
         if ev:
             ev[1].record()
         if world > 1 and args.allreduce_total:
-            dist.all_reduce(total)  # RCCL over xGMI: 8 bytes, the path's only collective
+            dist.all_reduce(slot)  # RCCL over xGMI: 8 bytes, the path's only collective
 
     for _ in range(args.warmup):
         step()
@@ -367,6 +371,8 @@ def main():
     local_total = int(total.item())
     sum_ok = local_total == int(counts.sum(dtype=torch.int64).item())
     parity = "sum-of-counts == total: %s" % sum_ok
+    if world == 1:
+        parity += "; every timed step produced that total: %s" % bool((totals[: args.steps + args.warmup] == local_total).all().item())
     golden_path = os.path.join(ROOT, "tests", "golden", "scale.json")
     if rank == 0 and args.queries == 100_000_000 and args.targets == 10_000_000 and os.path.exists(golden_path):
         pt = json.load(open(golden_path))["points"].get("10M x 1M (cfg2 subsample)")
