@@ -641,6 +641,19 @@ __device__ __forceinline__ int global_rank_lt(const int32_t *__restrict__ a, int
     return lo;
 }
 
+// Counts travel back to query order as 16 bits when they fit: 0xFFFF says "ask again" and the gather recomputes
+// that query from the index (exact; only pile-ups of >= 65535 overlapping targets ever take it).  Halves the bytes of
+// the counts' round trip (0.4 GB of the pass at 100M queries).
+constexpr unsigned COUNT_ESCAPE = 0xFFFFu;
+__device__ __forceinline__ void store_count(int32_t *p, int64_t i, int c) { p[i] = c; }
+__device__ __forceinline__ void store_count(unsigned short *p, int64_t i, int c)
+{
+    p[i] = (unsigned short)((unsigned)c < COUNT_ESCAPE ? (unsigned)c : COUNT_ESCAPE);
+}
+
+// One query straight from the sealed index (global binary searches): the escape path of the 16-bit counts.
+__device__ __forceinline__ int count_one_global(const IndexDev &ix, const int32_t *__restrict__ e_sorted, int qs, int qe);
+
 // Which bucket / which queries does this search workgroup own?  (shared prologue of the count and window kernels)
 __device__ __forceinline__ bool part_chunk_of_block(const int32_t *__restrict__ wg_first, const unsigned *__restrict__ table,
                                                     int64_t nq, int *s_bucket, int &b, int64_t &q_begin, int64_t &q_end)
@@ -683,12 +696,13 @@ __device__ __forceinline__ int group_rank_lt(const int32_t *__restrict__ a, int 
     return c;
 }
 
+template <typename CT>
 __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
                                                                 const SliceBound *__restrict__ bounds,
                                                                 const int32_t *__restrict__ wg_first,
                                                                 const unsigned *__restrict__ table /* row 0 = bucket offsets */,
                                                                 const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
-                                                                int32_t *__restrict__ counts /* bucket order, may be NULL */,
+                                                                CT *__restrict__ counts /* bucket order, may be NULL */,
                                                                 unsigned long long *__restrict__ total_slots,
                                                                 const unsigned *__restrict__ gate)
 {
@@ -774,7 +788,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, con
                 for (int k = lo; k < s_rank; k++) c += ix.e_ord[k] > qs[j];
             }
             int64_t i = i0 + (int64_t)j * PT_THREADS;
-            if (counts) counts[i] = c;
+            if (counts) store_count(counts, i, c);
             acc += c;
         }
     }
@@ -910,6 +924,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_cells_image_kernel(IndexDev i
     if (threadIdx.x == 0) meta[b] = CellsMeta{mE, mS, strideE, strideS, stepsE, stepsS, used, 0};
 }
 
+template <typename CT>
 __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
                                                                       const SliceBound *__restrict__ bounds,
                                                                       const int32_t *__restrict__ images, const CellsMeta *__restrict__ meta,
@@ -917,7 +932,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
                                                                       const unsigned *__restrict__ table /* row 0 = bucket offsets */,
                                                                       const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
                                                                       PartGeom g,
-                                                                      int32_t *__restrict__ counts /* bucket order, may be NULL */,
+                                                                      CT *__restrict__ counts /* bucket order, may be NULL */,
                                                                       unsigned long long *__restrict__ total_slots,
                                                                       const unsigned *__restrict__ gate)
 {
@@ -949,7 +964,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
     // lean: 32-bit offsets from the chunk's base, count = (pS - pE) + constant, one test per round for "anything unusual".
     const unsigned nch = (unsigned)(q_end - q_begin);
     const int2 *__restrict__ qb = pairs + q_begin;
-    int32_t *__restrict__ cb = counts ? counts + q_begin : nullptr;
+    CT *__restrict__ cb = counts ? counts + q_begin : nullptr;
     const bool unsampled = strideS == 1 && strideE == 1;
     const int cconst = (sb.sLo - sb.eLo) - (int)(aS - aE);
     const unsigned qe_span = (unsigned)sb.qeHi - (unsigned)sb.qeLo;
@@ -1037,7 +1052,7 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
         for (int j = 0; j < PC_ILP; j++) {
             const unsigned u = u0 + (unsigned)j * PT_THREADS;
             if (u < nch) {
-                if (cb) cb[u] = c[j];
+                if (cb) store_count(cb, (int64_t)u, c[j]);
                 acc += c[j];
             }
         }
@@ -1194,13 +1209,16 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
 // (one per bucket, contiguous in the bucketed array) into LDS in the tile's sorted order, then
 // every query picks its count through the 16-bit slot remembered by the scatter: all global
 // traffic is coalesced, the random access happens in LDS.
-__global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void part_gather_kernel(const int32_t *__restrict__ bucketed,
+template <typename CT /* int32_t, or unsigned short with COUNT_ESCAPE */>
+__global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void part_gather_kernel(const CT *__restrict__ bucketed,
                                                                  const unsigned short *__restrict__ lpos,
                                                                  const unsigned *__restrict__ tile_table /* [ntiles][PT_NB] */,
                                                                  int64_t ntiles, int64_t nq, int32_t *__restrict__ out,
-                                                                 const unsigned *__restrict__ gate)
+                                                                 const unsigned *__restrict__ gate, IndexDev ix,
+                                                                 const int32_t *__restrict__ e_sorted, const int32_t *__restrict__ qs_arr,
+                                                                 const int32_t *__restrict__ qe_arr /* the four: escape path only */)
 {
-    __shared__ int32_t vals[PT_TILE];
+    __shared__ CT vals[PT_TILE];
     __shared__ unsigned short toff[PT_NB + 2];
     __shared__ unsigned gbase[PT_NB];
     __shared__ unsigned scan_tmp[16];
@@ -1238,7 +1256,7 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 #pragma unroll
     for (int round = 0; round < 2; round++) {  // elements sub and sub + 8 of all 16 runs: two round trips in all
         const unsigned r = sub + 8u * round;
-        int v[RUNS];
+        CT v[RUNS];
         unsigned short at[RUNS];
         unsigned live = 0;
 #pragma unroll
@@ -1248,7 +1266,7 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             const bool ok = r < len;
             live |= (unsigned)ok << i;
             at[i] = (unsigned short)(o + r);
-            v[i] = ok ? bucketed[gbase[b] + r] : 0;
+            v[i] = ok ? bucketed[gbase[b] + r] : (CT)0;
         }
 #pragma unroll
         for (int i = 0; i < RUNS; i++)
@@ -1267,6 +1285,7 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         }
     }
     __syncthreads();
+    constexpr bool ESC = sizeof(CT) == 2;
     if (n == PT_TILE) {
         // a lane takes 4 consecutive queries: 8-byte loads of the slots, 16-byte stores of the counts, all loads first
         const uint2 *l4 = reinterpret_cast<const uint2 *>(lpos + base);
@@ -1275,13 +1294,35 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 #pragma unroll
         for (int j = 0; j < PT_ITEMS / 4; j++) sl[j] = l4[j * PT_THREADS + threadIdx.x];
 #pragma unroll
-        for (int j = 0; j < PT_ITEMS / 4; j++)
-            o4[j * PT_THREADS + threadIdx.x] = make_int4(vals[sl[j].x & 0xffffu], vals[sl[j].x >> 16], vals[sl[j].y & 0xffffu], vals[sl[j].y >> 16]);
+        for (int j = 0; j < PT_ITEMS / 4; j++) {
+            int c[4] = {(int)vals[sl[j].x & 0xffffu], (int)vals[sl[j].x >> 16], (int)vals[sl[j].y & 0xffffu], (int)vals[sl[j].y >> 16]};
+            if (ESC && ((unsigned)c[0] == COUNT_ESCAPE || (unsigned)c[1] == COUNT_ESCAPE || (unsigned)c[2] == COUNT_ESCAPE ||
+                        (unsigned)c[3] == COUNT_ESCAPE)) {
+                const int64_t k0 = base + 4 * (int64_t)(j * PT_THREADS + threadIdx.x);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if ((unsigned)c[u] == COUNT_ESCAPE) c[u] = count_one_global(ix, e_sorted, qs_arr[k0 + u], qe_arr[k0 + u]);
+            }
+            o4[j * PT_THREADS + threadIdx.x] = make_int4(c[0], c[1], c[2], c[3]);
+        }
     } else {
-        for (int k = threadIdx.x; k < n; k += PT_THREADS) out[base + k] = vals[lpos[base + k]];
+        for (int k = threadIdx.x; k < n; k += PT_THREADS) {
+            int c = (int)vals[lpos[base + k]];
+            if (ESC && (unsigned)c == COUNT_ESCAPE) c = count_one_global(ix, e_sorted, qs_arr[base + k], qe_arr[base + k]);
+            out[base + k] = c;
+        }
     }
 }
 
+__device__ __forceinline__ int count_one_global(const IndexDev &ix, const int32_t *__restrict__ e_sorted, int qs, int qe)
+{
+    const int s_rank = global_rank_lt(ix.s_ord, 0, ix.n, qe);
+    if (qs < qe) return s_rank - global_rank_lt(e_sorted, 0, ix.n, qs + 1);  // (qs < qe rules out qs == INT_MAX)
+    const int lo = first_pm_gt(ix.pm, ix.n, qs);  // zero-length / reversed query: exact predicate over the candidate window
+    int c = 0;
+    for (int k = lo; k < s_rank; k++) c += ix.e_ord[k] > qs;
+    return c;
+}
 
 // ---- partitioned find: window + count per query in bucket order, offsets carried to bucket order ----
 // For every query of [q_begin, q_end): hi = #{start < qe}, lo = #{prefix-max <= qs} and the number of hits in the
@@ -2127,19 +2168,19 @@ static int ivl_count_part_sub(bxmi_ivl *h, int sub, int64_t q0, const int32_t *q
                            h->e_sorted.as<int32_t>(), qs, qe, nq, counts, total_dev ? slots : nullptr, unsorted);
     }
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
+    unsigned short *cnt16 = counts ? h->p_cnt.as<unsigned short>() + q0 : nullptr;  // counts in bucket order, 16 bits + escape
     if (g_opt_count_cells)
-        hipLaunchKernelGGL(part_count_cells_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
+        hipLaunchKernelGGL(part_count_cells_kernel<unsigned short>, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
                            h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), h->cell_images.as<int32_t>(),
-                           h->cell_meta.as<CellsMeta>(), pp.plan, pp.table, pp.bq, nq, h->geom,
-                           counts ? h->p_cnt.as<int32_t>() + q0 : nullptr, total_dev ? slots : nullptr, unsorted);
+                           h->cell_meta.as<CellsMeta>(), pp.plan, pp.table, pp.bq, nq, h->geom, cnt16, total_dev ? slots : nullptr, unsorted);
     else
-        hipLaunchKernelGGL(part_count_kernel, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h), h->e_sorted.as<int32_t>(),
-                           h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bq, nq, counts ? h->p_cnt.as<int32_t>() + q0 : nullptr,
+        hipLaunchKernelGGL(part_count_kernel<unsigned short>, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
+                           h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bq, nq, cnt16,
                            total_dev ? slots : nullptr, unsorted);
     BXMI_LAUNCH_CHECK();
     if (counts) {
-        hipLaunchKernelGGL(part_gather_kernel, dim3(pp.tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>() + q0, pp.lpos, pp.table, pp.ntiles,
-                           nq, counts, unsorted);
+        hipLaunchKernelGGL(part_gather_kernel<unsigned short>, dim3(pp.tgrid), dim3(PT_THREADS), 0, st, cnt16, pp.lpos, pp.table, pp.ntiles, nq,
+                           counts, unsorted, index_dev(h), h->e_sorted.as<int32_t>(), qs, qe);
         BXMI_LAUNCH_CHECK();
     }
     if (total_dev) {
@@ -2157,8 +2198,8 @@ static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *
 {
     if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
     BXMI_TRY(part_reserve(h, nq, counts != nullptr));
-    BXMI_TRY(allow_big_lds(part_count_kernel, (size_t)PT_LDS_INTS * 4));
-    BXMI_TRY(allow_big_lds(part_count_cells_kernel, (size_t)PT_LDS_INTS * 4));
+    BXMI_TRY(allow_big_lds(part_count_kernel<unsigned short>, (size_t)PT_LDS_INTS * 4));
+    BXMI_TRY(allow_big_lds(part_count_cells_kernel<unsigned short>, (size_t)PT_LDS_INTS * 4));
     if (g_opt_count_cells && !h->images_ready) {
         // LDS images of every bucket for the search (159 MB, a property of the sealed index): built by the first large
         // batch, so the many small per-chromosome trees of the drop-in classes never pay for them
@@ -2226,8 +2267,9 @@ static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *q
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
     hipLaunchKernelGGL(part_window_kernel, dim3(grid), dim3(PT_THREADS), lds_bytes, st, index_dev(h), h->slice_bounds.as<SliceBound>(), pp.plan,
                        table, pp.bq, nq, h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->p_cnt.as<int32_t>());
-    hipLaunchKernelGGL(part_gather_kernel, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>(), lpos, table, ntiles, nq,
-                       h->q_cnt.as<int32_t>(), (const unsigned *)nullptr);
+    hipLaunchKernelGGL(part_gather_kernel<int32_t>, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_cnt.as<int32_t>(), lpos, table, ntiles, nq,
+                       h->q_cnt.as<int32_t>(), (const unsigned *)nullptr, index_dev(h), (const int32_t *)nullptr, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr);
     BXMI_LAUNCH_CHECK();
     BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
                                                            reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));

