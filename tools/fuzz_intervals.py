@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""One-off randomized differential run of the interval engine against the CPU oracle (not part of the test suite):
+many target / query distributions, both large-batch variants forced on, sorted and unsorted batches, count and find.
+ROUNDS env (default 20).  Prints the first disagreement and exits 1, or a summary line.
+The CPU oracle dominates the run time and its cost grows with the number of HITS: every round is sized so that the
+expected overlaps stay below ~20 M (an unbounded version of this script once spent a whole GPU allowance waiting for
+the oracle) -- run it under `timeout` all the same."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "bx-python_amd"))
+import numpy as np
+
+from bxmi import _ffi
+from bxmi.intervals import IntervalIndex
+from oracle import oracle as O
+
+
+def opt(k, v):
+    _ffi.call("bxmi_set_option", k.encode(), int(v))
+
+
+rng = np.random.default_rng(int(os.environ.get("SEED", 12345)))
+rounds = int(os.environ.get("ROUNDS", 20))
+MAX_HITS = 20_000_000
+checked = 0
+for r in range(rounds):
+    n = int(rng.choice([5000, 20000, 100000, 400000]))
+    nq = int(rng.choice([3000, 20000, 70000]))
+    span = int(rng.choice([2000, 10**5, 10**7, 2 * 10**9]))
+    lmax = int(rng.choice([1, 5, 200, 5000, 10**6]))
+    # expected overlaps per query ~ n * (target length + query length) / span: shrink the lengths until the round is affordable
+    while n * nq * (1.5 * lmax + 1) / span > MAX_HITS and lmax > 1:
+        lmax //= 2
+    if n * nq * (1.5 * lmax + 1) / span > MAX_HITS:
+        nq = max(1000, int(MAX_HITS * span / (n * (1.5 * lmax + 1))))
+    clump = rng.random() < 0.3 and n * nq / 2 * 0.5 < MAX_HITS * 50
+    s = rng.integers(-span // 2, span // 2, size=n)
+    if clump:  # a tenth of the targets piled on a small stretch (queries there see all of them)
+        s[: n // 10] = rng.integers(0, max(span // 1000, 2), size=n // 10)
+    ln = rng.integers(0, lmax + 1, size=n)
+    e = np.minimum(s + ln, 2**31 - 1)
+    qs = rng.integers(-span // 2 - 10, span // 2 + 10, size=nq)
+    qe = np.minimum(qs + rng.integers(0, 2 * lmax + 2, size=nq), 2**31 - 1)
+    flip = rng.random(nq) < 0.03
+    qs, qe = np.where(flip, qe, qs), np.where(flip, qs, qe)
+    if rng.random() < 0.4:
+        o = np.argsort(qs, kind="stable")
+        qs, qe = qs[o], qe[o]
+    s, e, qs, qe = (a.astype(np.int32) for a in (s, e, qs, qe))
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    want_c, want_t = t.count_batch(qs, qe)
+    ix = IntervalIndex()
+    ix.append(s, e)
+    for part, cells in ((0, 1), (1, 1), (1, 0)):
+        opt("ivl.partition", part)
+        opt("ivl.count_cells", cells)
+        got_c, got_t = ix.count(qs, qe)
+        if not np.array_equal(got_c, want_c) or got_t != want_t:
+            bad = np.nonzero(got_c != want_c)[0][:5]
+            print("MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells), bad, qs[bad], qe[bad], got_c[bad], want_c[bad])
+            sys.exit(1)
+    opt("ivl.count_cells", 1)
+    m = min(nq, 20000)
+    w_off, w_hits = t.find_batch(qs[:m], qe[:m])
+    for part in (0, 1):
+        opt("ivl.partition", part)
+        off, hits = ix.find(qs[:m], qe[:m])
+        if not (np.array_equal(off, w_off) and np.array_equal(hits, w_hits)):
+            print("FIND MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part))
+            sys.exit(1)
+    opt("ivl.partition", -1)
+    checked += 1
+    ix.close()
+print("fuzz: %d rounds, all counts and hit lists equal the oracle" % checked)
