@@ -222,6 +222,35 @@ def join_cases():
     return dict(inputs=inputs, cases=out)
 
 
+def reader_cases():
+    """Plain iteration of the reference's readers over every input: items, escaping error, skip bookkeeping, header."""
+    out = []
+    extra_inputs = dict(
+        spaces=["chr1 10 20 a 0 +\n", "chr1\t30\t40\n", "chr2  5   9\n"],
+        crlf=["#h1\th2\th3\r\n", "chr1\t1\t2\r\n", "\r\n", "chr1\t3\t4\n"],
+        noheader=["chr1\t1\t2\n", "#late comment\n", "track x\n", "chr1\t2\t9\tname\t0\t-\n", "chr1\t2\t9\tname\t0\t.\n"],
+    )
+    everything = dict(INPUTS)
+    everything.update(extra_inputs)
+    variants = [("nice", {}), ("plain", {}), ("nice", dict(return_header=False, return_comments=False)),
+                ("nice", dict(allow_spaces=True)), ("nice", dict(fix_strand=True, default_strand="-")),
+                ("nice", dict(chrom_col=0, start_col=1, end_col=2, strand_col=3))]
+    for key, lines in everything.items():
+        if len(lines) > 60:  # the random files add bulk, not cases
+            continue
+        for kind, kw in variants:
+            r = MAKE[kind](lines, **kw)
+            items, err = [], None
+            try:
+                for x in r:
+                    items.append(tell(x))
+            except Exception as e:
+                err = [type(e).__name__, str(e)]
+            out.append(dict(input=key, reader=kind, kwargs=kw, items=items, error=err, skips=skips(r), linenum=r.linenum,
+                            header=str(r.header) if r.header is not None else None))
+    return dict(inputs=extra_inputs, cases=out)
+
+
 def main():
     out = []
     for c in CASES:
@@ -250,7 +279,7 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "operations.json")
     with open(path, "w") as f:
         json.dump(dict(generator="oracle/gen_golden_ops.py", inputs=INPUTS, cases=out, clusters=cluster_cases(),
-                       join=join_cases(), find_clusters=find_clusters_cases(), find_clusters_inputs=dict(messy=PRIMARY_MESSY, messy_wide=PRIMARY_MESSY, random=RAND_P)),
+                       join=join_cases(), readers=reader_cases(), find_clusters=find_clusters_cases(), find_clusters_inputs=dict(messy=PRIMARY_MESSY, messy_wide=PRIMARY_MESSY, random=RAND_P)),
                   f, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")
 

@@ -149,3 +149,32 @@ def test_join_and_find_clusters_host_logic(golden, mods):
             assert [[a, b, ids] for a, b, ids in chroms[chrom].getregions()] == want["regions"], (c["name"], chrom)
             assert chroms[chrom].getlines() == want["lines"]
         assert {str(k): _tell(genomic, v) for k, v in extra.items()} == c["extra"]
+
+
+def test_readers_iterate_like_the_reference(golden):
+    """bxmi.genomic readers against plain iteration of the reference's (items, escaping ParseError, skip log, final
+    line number, header) over every input of the suite plus space-separated, CRLF and header-less files, in six
+    reader configurations.  No engine involved."""
+    from bxmi import genomic
+
+    make = {"nice": genomic.NiceReaderWrapper, "plain": genomic.GenomicIntervalReader}
+    g = golden["readers"]
+    inputs = dict(golden["inputs"])
+    inputs.update(g["inputs"])
+    assert len(g["cases"]) >= 30
+    for c in g["cases"]:
+        r = make[c["reader"]](list(inputs[c["input"]]), **c["kwargs"])
+        items, err = [], None
+        try:
+            for x in r:
+                items.append(_tell(genomic, x))
+        except Exception as e:
+            err = [type(e).__name__, str(e)]
+        tag = (c["input"], c["reader"], c["kwargs"])
+        assert err == c["error"], (tag, err, c["error"])
+        assert items == c["items"], tag
+        assert r.linenum == c["linenum"], tag
+        assert (str(r.header) if r.header is not None else None) == c["header"], tag
+        if c["skips"] is not None:
+            assert r.skipped == c["skips"]["skipped"], tag
+            assert [list(t) for t in r.skipped_lines] == c["skips"]["skipped_lines"], tag
