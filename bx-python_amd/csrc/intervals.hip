@@ -18,7 +18,17 @@
 //     proper targets; anything else (zero-length / reversed query, reversed
 //     target) takes the exact window scan [first pm>qs, rank_lt(starts,qe)).
 //   * find = the same window, compacted with wave ballots into CSR order.
-// Integer compares and popcounts only: HBM/L2-latency bound, no MFMA.
+//   * batches of >= 4 Mi queries leave the trees: the queries are bucketed by coordinate (histogram
+//     + LDS-ordered scatter, "part_*" kernels), every bucket is searched against its slice of the
+//     sorted arrays held in LDS by direct addressing, and the counts are gathered back; a batch
+//     whose starts are already sorted skips the bucketing ("ivl_local_*" kernels).
+//   * clusters (ClusterTree) fall out of s_ord and pm: a boundary wherever start - d > pm[i-1].
+// Integer compares and popcounts only: HBM / LDS bound, no MFMA.
+//
+// Map of the file: build kernels and tree search helpers; direct count kernel; partitioned count
+// path (histogram, column scans, scatter, tree and cell searches, sorted-batch kernel, gather);
+// partitioned / sorted find (window, permute, fill kernels); cluster kernels; host structs and the
+// extern "C" entry points (bxmi_ivl_*), DESIGN.md 3 has the measurements.
 #include <climits>
 #include <vector>
 
