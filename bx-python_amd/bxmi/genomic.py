@@ -115,22 +115,32 @@ class GenomicInterval(TableRow):
     Assigning one of the four attributes rewrites the field it came from."""
 
     def __init__(self, reader, fields, chrom_col, start_col, end_col, strand_col, default_strand, fix_strand=False):
-        TableRow.__init__(self, reader, fields)
-        self.chrom_col, self.start_col, self.end_col, self.strand_col = chrom_col, start_col, end_col, strand_col
-        self.nfields = nfields = len(fields)
-        # every assignment below goes through __setattr__, i.e. NORMALISES the field it was read from
-        # (" chr1 " -> "chr1", "+5" -> "5", strand "." -> the default): str(row) shows it, as in the reference
+        # Written against __dict__ directly: this constructor runs once per line of every file, and routing its ten
+        # assignments through __setattr__ was half of the readers' time.  The effect is what assignment through
+        # __setattr__ gives in the reference: each parsed value is written back, NORMALISED, into the field it came
+        # from (" chr1 " -> "chr1", "+5" -> "5", strand "." -> the default); str(row) shows it.
+        d = self.__dict__
+        d["reader"], d["fields"] = reader, fields
+        d["chrom_col"], d["start_col"], d["end_col"], d["strand_col"] = chrom_col, start_col, end_col, strand_col
+        d["nfields"] = nfields = len(fields)
         if chrom_col >= nfields:
             raise MissingFieldError("No field for chrom_col (%d)" % chrom_col)
-        self.chrom = fields[chrom_col].strip()
-        for name, col in (("start", start_col), ("end", end_col)):
-            if col >= nfields:
-                raise MissingFieldError("No field for %s_col (%d)" % (name, col))
-            try:
-                setattr(self, name, int(fields[col]))
-            except ValueError as e:
-                raise FieldFormatError("Could not parse %s_col: %s" % (name, e), expected="integer")
-        if self.end < self.start:
+        d["chrom"] = fields[chrom_col] = fields[chrom_col].strip()
+        if start_col >= nfields:
+            raise MissingFieldError("No field for start_col (%d)" % start_col)
+        try:
+            start = int(fields[start_col])
+        except ValueError as e:
+            raise FieldFormatError("Could not parse start_col: " + str(e), expected="integer")
+        d["start"], fields[start_col] = start, str(start)
+        if end_col >= nfields:
+            raise MissingFieldError("No field for end_col (%d)" % end_col)
+        try:
+            end = int(fields[end_col])
+        except ValueError as e:
+            raise FieldFormatError("Could not parse end_col: " + str(e), expected="integer")
+        d["end"], fields[end_col] = end, str(end)
+        if end < start:
             raise ParseError("Start is greater than End. Interval length is < 1.")
         strand = default_strand
         if 0 <= strand_col < nfields:
@@ -141,7 +151,8 @@ class GenomicInterval(TableRow):
                 if not fix_strand:
                     raise StrandFormatError("Strand must be either '+' or '-'")
                 strand = "+"
-        self.strand = strand
+            fields[strand_col] = str(strand)
+        d["strand"] = strand
 
     def __setattr__(self, name, value):
         col_attr = _SYNCED.get(name)
@@ -154,6 +165,17 @@ class GenomicInterval(TableRow):
     def copy(self):
         return GenomicInterval(self.reader, list(self.fields), self.chrom_col, self.start_col, self.end_col, self.strand_col,
                                self.strand)
+
+    def _piece(self, start, end):
+        """A copy with new start / end, for rows that come straight from a reader (fields and attributes agree):
+        what copy() followed by the two assignments produces, without parsing the fields again."""
+        new = object.__new__(GenomicInterval)
+        d = new.__dict__
+        d.update(self.__dict__)
+        fields = d["fields"] = list(self.fields)
+        d["start"], d["end"] = start, end
+        fields[self.start_col], fields[self.end_col] = str(start), str(end)
+        return new
 
 
 class TableReader:
@@ -186,7 +208,7 @@ class TableReader:
                 if self.return_header:
                     return self.header
                 continue
-            if any(line.startswith(p) for p in self.comment_lines_startswith):
+            if line.startswith(tuple(self.comment_lines_startswith)):
                 if first and self.header is None:
                     self.header = self.parse_header(line)
                     if self.return_header:

@@ -233,10 +233,14 @@ def _emit(primary, comments, per_item, passthrough=None):
                 yield item
                 continue
             for start, end in per_item.get(i, ()):
-                piece = item.copy()
-                piece.start = start
-                piece.end = end
-                yield piece
+                yield item._piece(start, end) if type(item) is GenomicInterval else _copy_with(item, start, end)
+
+
+def _copy_with(item, start, end):
+    piece = item.copy()  # any other row class: the reference's three steps (intersect.py:69-72)
+    piece.start = start
+    piece.end = end
+    return piece
 
 
 def _pieces_or_whole(primary, bitsets, groups, mincols, pieces, want_set):
