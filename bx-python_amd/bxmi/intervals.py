@@ -75,6 +75,13 @@ class IntervalIndex:
         call("bxmi_ivl_has_reversed", self._h, C.byref(f))
         return bool(f.value)
 
+    def bitmap_state(self):
+        """(state, hard_cells) of the large-batch count pass: 1 = bitmap-cell pass, -1 = bucketed search, 0 = undecided."""
+        self._ready()
+        st, hc = C.c_int(0), C.c_int64(0)
+        call("bxmi_ivl_bitmap_state", self._h, C.byref(st), C.byref(hc))
+        return st.value, hc.value
+
     def order(self):
         """Insertion indices in the treap's in-order (== IntervalTree.traverse order)."""
         self._ready()

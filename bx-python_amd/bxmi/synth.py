@@ -45,6 +45,30 @@ def cfg5(n_targets=50_000_000, n_queries=50_000_000):
     )
 
 
+def cfg4_sizes(n_total, sizes=None):
+    """Intervals per chromosome for a set of n_total placed proportionally to chromosome length (rounded per chromosome)."""
+    sizes = sizes or HG19_SIZES
+    total = sum(sizes.values())
+    return {chrom: int(round(n_total * size / total)) for chrom, size in sizes.items()}
+
+
+def cfg4_chrom(chrom, n_targets=10_000_000, n_queries=100_000_000, sizes=None):
+    """SURVEY 8(d) "cfg 4" (BASELINE configs[3]): the cfg-2 distributions (len U[1,1000]) on one of the 24 hg19
+    chromosomes, N and Q proportional to its length; targets seed (401, i), queries seed (402, i) with i the
+    chromosome's position in HG19_SIZES -- per-chromosome seeds, so a rank generates only what it owns.
+    -> ((target_start, target_end), (query_start, query_end)) int32."""
+    sizes = sizes or HG19_SIZES
+    i = list(sizes).index(chrom)
+    nt, nq = cfg4_sizes(n_targets, sizes)[chrom], cfg4_sizes(n_queries, sizes)[chrom]
+    return uniform_intervals(nt, [401, i], genome=sizes[chrom]), uniform_intervals(nq, [402, i], genome=sizes[chrom])
+
+
+def cfg4(n_targets=10_000_000, n_queries=100_000_000, chroms=None, sizes=None):
+    """{chrom: cfg4_chrom(chrom)} for `chroms` (default: all 24)."""
+    sizes = sizes or HG19_SIZES
+    return {c: cfg4_chrom(c, n_targets, n_queries, sizes) for c in (chroms or list(sizes))}
+
+
 def genome_ranges(n_total, seed, sizes=None, max_len=2000):
     """cfg 3/4: ranges placed proportionally to chromosome length.
 

@@ -1334,6 +1334,10 @@ __device__ __forceinline__ int count_one_global(const IndexDev &ix, const int32_
     return c;
 }
 
+}  // namespace bxmi
+#include "count_bitmap.hpp"
+namespace bxmi {
+
 // ---- partitioned find: window + count per query in bucket order, offsets carried to bucket order ----
 // For every query of [q_begin, q_end): hi = #{start < qe}, lo = #{prefix-max <= qs} and the number of hits in the
 // window [lo, hi) of the tree-ordered arrays.  Ranks come from LDS trees one lane per query; the window is then
@@ -2038,6 +2042,12 @@ constexpr int PT_MAX_SUB = 1;  // scratch regions are addressed per sub-batch; o
 constexpr int PT_SLOT_STRIDE = PT_SLOTS + 8;  // per sub-batch: the partial totals, then the "unsorted" flag
 static int64_t g_opt_count_cells = 1;  // 1 = direct-addressed cells in the bucket search, 0 = LDS search trees
 static int64_t g_opt_sorted_path = 1;  // 1 = batches whose starts are already sorted skip the bucketing (detected on the device)
+static int64_t g_opt_bitmap = -1;      // second-generation count pass (count_bitmap.hpp): -1 = when the index qualifies, 0 = never, 1 = same as -1
+static int64_t g_opt_bm_variant = 0;   // tile kernel shape: 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
+static int64_t g_opt_bm_u = 4;         // tile runs in flight per 8-lane group of the search kernel (2, 4 or 8)
+static int64_t g_opt_bm_pair = 0;      // 1 = a search workgroup holds two neighbouring buckets (one workgroup per CU, runs twice as long)
+static int64_t g_opt_bm_exp = 0;       // diagnostics only (wrong results): price the pieces of the search kernel, see count_bitmap.hpp
+static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
 
 int ivl_set_option(const char *key, int64_t value)
 {
@@ -2069,6 +2079,30 @@ int ivl_set_option(const char *key, int64_t value)
         g_opt_partition_min = value;
         return 1;
     }
+    if (!strcmp(key, "ivl.bitmap")) {
+        g_opt_bitmap = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bm_variant")) {
+        g_opt_bm_variant = value < 0 || value > 2 ? 0 : value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bm_u")) {
+        g_opt_bm_u = value == 2 || value == 8 ? value : 4;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bm_pair")) {
+        g_opt_bm_pair = value != 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bm_exp")) {
+        g_opt_bm_exp = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bm_hard_ppm")) {
+        g_opt_bm_hard_ppm = value;
+        return 1;
+    }
     return 0;
 }
 
@@ -2097,6 +2131,12 @@ struct bxmi_ivl {
     PartGeom geom{0, 0};
     bool images_ready = false;
     DevBuf slice_bounds, cell_images, cell_meta, p_hist, p_table, p_pairs, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
+    // second-generation count pass (count_bitmap.hpp)
+    int32_t cmax = 0;            // largest end of the sealed index
+    int bm_state = 0;            // 0 = not decided yet, 1 = images built and the index qualifies, -1 = it does not
+    int64_t bm_hard_cells = 0;   // what bm_image_kernel reported
+    BmGeom bm_geom{0, 0, 0, 0, 0, 0};
+    DevBuf bm_images, bm_meta, bm_stats, bm_recs, bm_slots, bm_tbl, bm_runT, bm_grpcnt, bm_items;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][hits...]
     hipStream_t stream = nullptr;
     int device = 0;
@@ -2301,6 +2341,147 @@ static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *q
     return BXMI_OK;
 }
 
+// ---- second-generation count pass (count_bitmap.hpp) ----
+// Decide once per sealed index whether it qualifies, and build the bucket images if it does.
+static int bm_prepare_index(bxmi_ivl *h, hipStream_t st)
+{
+    h->bm_state = -1;
+    const int shift = h->geom.shift;
+    if (h->has_reversed || h->n < 4096 || shift > BM_MAX_SHIFT || shift < BM_MIN_SHIFT) return BXMI_OK;
+    const int64_t W = (int64_t)1 << shift;
+    BmGeom g;
+    g.cmin = h->geom.cmin;
+    g.cmax = h->cmax;
+    g.shift = shift;
+    g.nce = (int32_t)(W >> 5) + 2;
+    g.ncs = (int32_t)((W + BM_MARGIN) >> 5) + 1;
+    g.stride = (g.nce + g.ncs + 1) & ~1;
+    BXMI_TRY(h->bm_images.reserve((size_t)BM_NB * g.stride * sizeof(uint2)));
+    BXMI_TRY(h->bm_meta.reserve(BM_NB * sizeof(BmBucket)));
+    BXMI_TRY(h->bm_stats.reserve(64));
+    BXMI_HIP(hipMemsetAsync(h->bm_stats.p, 0, 64, st));
+    const size_t lds = (size_t)5 * g.ncs * sizeof(int32_t);
+    BXMI_TRY(allow_big_lds(bm_image_kernel, lds));
+    hipLaunchKernelGGL(bm_image_kernel, dim3(BM_NB), dim3(1024), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n, g,
+                       h->bm_images.as<uint2>(), h->bm_meta.as<BmBucket>(), h->bm_stats.as<unsigned>());
+    BXMI_LAUNCH_CHECK();
+    unsigned stats[2] = {0, 0};
+    BXMI_HIP(hipMemcpyAsync(stats, h->bm_stats.p, sizeof(stats), hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    h->bm_geom = g;
+    h->bm_hard_cells = stats[0];
+    // cells that queries can land in: the span of the index, twice (ends and starts)
+    const int64_t cells = 2 * ((((int64_t)h->cmax - (int64_t)h->geom.cmin) >> 5) + 1);
+    if (stats[1] == 0 && (int64_t)stats[0] * 1000000 <= cells * g_opt_bm_hard_ppm) h->bm_state = 1;
+    return BXMI_OK;
+}
+
+template <int THREADS, int ITEMS>
+static int bm_launch_tiles(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t ntiles, hipStream_t st)
+{
+    constexpr int TILE = THREADS * ITEMS;
+    const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64;
+    BXMI_TRY(allow_big_lds(bm_tile_sort_kernel<THREADS, ITEMS>, lds));
+    hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS>), dim3((unsigned)ntiles), dim3(THREADS), lds, st, qs, qe, nq, h->bm_geom,
+                       h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>());
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+template <bool PAIR, int U, int EXP = 0>
+static int bm_launch_search(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, hipStream_t st)
+{
+    const size_t lds = (size_t)(PAIR ? 2 : 1) * h->bm_geom.stride * sizeof(uint2);
+    BXMI_TRY(allow_big_lds((bm_search_kernel<PAIR, U, EXP>), lds));
+    hipLaunchKernelGGL((bm_search_kernel<PAIR, U, EXP>), dim3(grid), dim3(BM_SEARCH_THREADS), lds, st, h->bm_images.as<uint2>(), h->bm_geom,
+                       h->bm_meta.as<BmBucket>(), h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), ntp,
+                       h->bm_recs.as<unsigned>(), tile_log2, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>());
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+template <bool PAIR>
+static int bm_launch_search_u(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, hipStream_t st)
+{
+    if (g_opt_bm_exp == 1) return bm_launch_search<PAIR, 4, 1>(h, grid, ntp, tile_log2, st);
+    if (g_opt_bm_exp == 2) return bm_launch_search<PAIR, 4, 2>(h, grid, ntp, tile_log2, st);
+    if (g_opt_bm_exp == 3) return bm_launch_search<PAIR, 4, 3>(h, grid, ntp, tile_log2, st);
+    if (g_opt_bm_exp == 4) return bm_launch_search<PAIR, 4, 4>(h, grid, ntp, tile_log2, st);
+    if (g_opt_bm_exp == 5) return bm_launch_search<PAIR, 4, 5>(h, grid, ntp, tile_log2, st);
+    if (g_opt_bm_exp == 6) return bm_launch_search<PAIR, 4, 6>(h, grid, ntp, tile_log2, st);
+    if (g_opt_bm_exp == 7) return bm_launch_search<PAIR, 4, 7>(h, grid, ntp, tile_log2, st);
+    if (g_opt_bm_u == 2) return bm_launch_search<PAIR, 2>(h, grid, ntp, tile_log2, st);
+    if (g_opt_bm_u == 8) return bm_launch_search<PAIR, 8>(h, grid, ntp, tile_log2, st);
+    return bm_launch_search<PAIR, 4>(h, grid, ntp, tile_log2, st);
+}
+
+template <int THREADS, int ITEMS>
+static int bm_launch_unpermute(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t ntiles, int32_t *counts,
+                               unsigned long long *slots, hipStream_t st)
+{
+    const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);
+    BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS>), lds));
+    hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)ntiles), dim3(THREADS), lds, st, h->bm_recs.as<unsigned>(),
+                       h->bm_slots.as<unsigned short>(), nq, counts, slots, index_dev(h), h->e_sorted.as<int32_t>(), h->bm_geom, qs, qe);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+// tile sort -> run table + plan -> search -> un-permute, all on `st`; counts must not be NULL
+static int ivl_count_bitmap(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total_dev, hipStream_t st)
+{
+    if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
+    const int variant = (int)g_opt_bm_variant;
+    const int tile_log2 = variant == 2 ? 15 : 14;
+    const int64_t tile = (int64_t)1 << tile_log2;
+    const int64_t ntiles = div_up(nq, tile);
+    const int ngroups = (int)div_up(ntiles, BM_GROUP_TILES);
+    const int64_t ntp = (int64_t)ngroups * BM_GROUP_TILES;
+    // PAIR: a search workgroup holds the images of two neighbouring buckets (needs both in one CU's LDS)
+    const bool pair = g_opt_bm_pair != 0 && (size_t)2 * h->bm_geom.stride * sizeof(uint2) + 8192 <= 160 * 1024;
+    const int chunk = pair ? 2 * BM_CHUNK : BM_CHUNK;
+    const int64_t max_items = (pair ? BM_NB / 2 : BM_NB) + 2 * (nq / chunk) + 2;
+    BXMI_TRY(h->bm_recs.reserve((size_t)ntiles * tile * 4));
+    BXMI_TRY(h->bm_slots.reserve((size_t)ntiles * tile * 2));
+    BXMI_TRY(h->bm_tbl.reserve((size_t)ntp * BM_NB * 2));
+    BXMI_TRY(h->bm_runT.reserve((size_t)ntp * BM_NB * 4));
+    BXMI_TRY(h->bm_grpcnt.reserve((size_t)ngroups * BM_NB * 4));
+    BXMI_TRY(h->bm_items.reserve((size_t)(BM_NB + 2 * (nq / BM_CHUNK) + 4) * sizeof(int4)));  // [0] = the item count, items from [1]
+    BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOT_STRIDE * sizeof(unsigned long long)));
+    unsigned long long *slots = h->p_slots.as<unsigned long long>();
+    if (total_dev) BXMI_HIP(hipMemsetAsync(slots, 0, PT_SLOTS * sizeof(unsigned long long), st));
+    if (variant == 2)
+        BXMI_TRY((bm_launch_tiles<1024, 32>(h, qs, qe, nq, ntiles, st)));
+    else if (variant == 1)
+        BXMI_TRY((bm_launch_tiles<1024, 16>(h, qs, qe, nq, ntiles, st)));
+    else
+        BXMI_TRY((bm_launch_tiles<512, 32>(h, qs, qe, nq, ntiles, st)));
+    hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), ntiles, nq, tile_log2,
+                       h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>());
+    if (pair)
+        hipLaunchKernelGGL(bm_plan_kernel<1>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, ntiles, chunk,
+                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>());
+    else
+        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, ntiles, chunk,
+                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>());
+    BXMI_LAUNCH_CHECK();
+    const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
+    if (pair)
+        BXMI_TRY(bm_launch_search_u<true>(h, sgrid, ntp, tile_log2, st));
+    else
+        BXMI_TRY(bm_launch_search_u<false>(h, sgrid, ntp, tile_log2, st));
+    unsigned long long *tslots = total_dev ? slots : nullptr;
+    if (variant == 2)
+        BXMI_TRY((bm_launch_unpermute<1024, 32>(h, qs, qe, nq, ntiles, counts, tslots, st)));
+    else
+        BXMI_TRY((bm_launch_unpermute<1024, 16>(h, qs, qe, nq, ntiles, counts, tslots, st)));
+    if (total_dev) {
+        hipLaunchKernelGGL(part_fold_total_kernel, dim3(1), dim3(64), 0, st, slots, reinterpret_cast<unsigned long long *>(total_dev));
+        BXMI_LAUNCH_CHECK();
+    }
+    return BXMI_OK;
+}
+
 static int ivl_stream(bxmi_ivl *h)
 {
     if (!h->stream) BXMI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -2441,6 +2622,8 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         while ((span >> shift) >= PT_NB) shift++;
         h->geom.cmin = cmin;
         h->geom.shift = shift;
+        h->cmax = cmax;
+        h->bm_state = 0;
         BXMI_TRY(h->slice_bounds.reserve(PT_NB * sizeof(SliceBound)));
         hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
                            h->pm.as<int32_t>(), (int)n, h->geom, h->slice_bounds.as<SliceBound>());
@@ -2471,6 +2654,14 @@ static int need_sealed(const bxmi_ivl *h, const char *who)
 {
     if (!h) return fail(BXMI_EINVAL, "%s: NULL handle", who);
     if (!h->sealed) return fail(BXMI_ESTATE, "%s: index not sealed (call bxmi_ivl_seal after appending)", who);
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_bitmap_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_bitmap_state"));
+    if (state) *state = h->bm_state;
+    if (hard_cells) *hard_cells = h->bm_hard_cells;
     return BXMI_OK;
 }
 
@@ -2522,6 +2713,10 @@ extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_
     hipStream_t st = as_stream(stream);
     const bool partition = !h->has_reversed && h->n > 0 &&
                            (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_partition_min && h->n >= 4096));
+    if (partition && counts && g_opt_bitmap != 0) {
+        if (h->bm_state == 0) BXMI_TRY(bm_prepare_index(h, st));
+        if (h->bm_state == 1) return ivl_count_bitmap(h, qs, qe, nq, counts, total_dev, st);
+    }
     if (partition) return ivl_count_partitioned(h, qs, qe, nq, counts, total_dev, st);
     TreeDev S = h->treeS.dev, E = h->treeE.dev;
     Tree tS = Tree(), tE = Tree();

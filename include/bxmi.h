@@ -63,6 +63,8 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *   ivl.partition_min  threshold of the auto mode (default 4 Mi queries)
  *   ivl.sorted_path    1 (default): a batch whose starts are already non-decreasing skips the bucketing
  *   ivl.count_cells    1 (default): bucket search by direct-addressed cells; 0: LDS search trees
+ *   ivl.bitmap         -1 (default): large batches with per-query counts take the bitmap-cell pass when the index qualifies; 0 never
+ *   ivl.bm_variant, ivl.bm_u, ivl.bm_hard_ppm   tile shape / runs in flight / qualification threshold of that pass
  *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search
  *   ivl.lds_ints, ivl.count_grid   staging budget / grid of the direct count kernel
  *   bits.grid          grid of the per-bitset kernels
@@ -99,6 +101,10 @@ int bxmi_ivl_count(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t 
 /* Device variant: *total_dev (device int64) is ACCUMULATED into (zero it first). */
 int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
                        int64_t *total_dev, void *stream);
+/* Which large-batch count pass serves this sealed index: *state = 0 not decided yet (no large batch so far), 1 = the
+ * bitmap-cell pass (count_bitmap.hpp: its per-bucket images are built), -1 = the bucketed search pass (span wider than
+ * 2^28, reversed targets, or too many coordinates carrying duplicates: *hard_cells of them).  Introspection only. */
+int bxmi_ivl_bitmap_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
 
 /* IntervalTree.find for a batch, as CSR: offsets[nq+1] (int64) and, for query
  * i, hits[offsets[i]..offsets[i+1]) = insertion indices in the reference's

@@ -11,6 +11,9 @@ Only inputs + expected outputs are written (data, never reference source).
 
 --scale additionally runs the 10M-target / 1M-query-subsample point of cfg 2
 through the reference treap (about 5 minutes, ~2 GB) and records its hash.
+--only genome | join | calibration add, to tests/golden/scale.json, the per-chromosome
+hashes of configs[3] (synth.cfg4), the hit-list hash of configs[4] at 50M targets
+(~10 GB, ~30 min) and the reference-vs-port timing BASELINE.md 4 asks for.
 """
 import argparse
 import hashlib
@@ -333,6 +336,115 @@ def scale_point(n_targets, n_queries_total, stride):
                 counts_sha256=sha(counts), total=int(counts.sum(dtype=np.int64)), first16=counts[:16].tolist())
 
 
+def _ref_tree(ts, te):
+    tree = ri.IntervalTree()
+    ins = tree.insert
+    for i, (s, e) in enumerate(zip(ts.tolist(), te.tolist())):
+        ins(s, e, i)
+    return tree
+
+
+def genome_point(stride=100):
+    """BASELINE configs[3] (synth.cfg4): per chromosome the reference treap over that chromosome's targets, queried with
+    every stride-th of its queries."""
+    out = {}
+    for chrom in synth.HG19_SIZES:
+        (ts, te), (qs, qe) = synth.cfg4_chrom(chrom)
+        qs, qe = qs[::stride], qe[::stride]
+        find = _ref_tree(ts, te).find
+        counts = np.fromiter((len(find(a, b)) for a, b in zip(qs.tolist(), qe.tolist())), dtype=np.int32, count=len(qs))
+        out[chrom] = dict(n_targets=len(ts), n_queries_total=len(synth.cfg4_chrom(chrom)[1][0]), n_queries=len(qs), counts_sha256=sha(counts),
+                          total=int(counts.sum(dtype=np.int64)))
+        print(chrom, out[chrom], flush=True)
+    return dict(stride=stride, workload="synth.cfg4_chrom(chrom): targets seed (401,i), queries seed (402,i); queries[::stride]", chroms=out)
+
+
+def join_point(n_targets=50_000_000, n_queries=50_000_000, stride=500):
+    """BASELINE configs[4] (synth.cfg5) at full target count: the hit LISTS (payload = insertion index, the reference's
+    order) of every stride-th query against the 50M-target reference treap (about 10 GB of Python objects)."""
+    import time
+
+    (ts, te), (qs, qe) = synth.cfg5(n_targets, n_queries)
+    qs, qe = qs[::stride], qe[::stride]
+    t0 = time.perf_counter()
+    tree = _ref_tree(ts, te)
+    t_ins = time.perf_counter() - t0
+    find = tree.find
+    t0 = time.perf_counter()
+    res = [find(a, b) for a, b in zip(qs.tolist(), qe.tolist())]
+    t_find = time.perf_counter() - t0
+    counts = np.array([len(r) for r in res], dtype=np.int32)
+    hits = np.array([x for r in res for x in r], dtype=np.int32)
+    return dict(n_targets=n_targets, n_queries_total=n_queries, stride=stride, n_queries=len(qs), counts_sha256=sha(counts), hits_sha256=sha(hits),
+                total=int(counts.sum(dtype=np.int64)), first_hits=hits[:16].tolist(), reference_insert_s=round(t_ins, 1), reference_find_s=round(t_find, 3))
+
+
+def calibration_point(n_targets=10_000_000, n_queries_total=100_000_000, stride=100):
+    """SURVEY 8(d) / BASELINE.md 4 step 1: the reference's IntervalTree.find and the C restatement (oracle/ivtree.c) timed
+    on the same machine and the same inputs -- the 10M-target treap, the 1M-query subsample of cfg 2; single thread,
+    best of 3 for the queries.  bench.py turns its port timing on the GPU box into "x reference" with this ratio."""
+    import platform
+    import time
+
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+
+    (ts, te), _ = synth.cfg2(n_targets, 1)
+    q = synth.uniform_intervals(n_queries_total, 202)
+    qs, qe = q[0][::stride].copy(), q[1][::stride].copy()
+    t0 = time.perf_counter()
+    tree = _ref_tree(ts, te)
+    ref_ins = time.perf_counter() - t0
+    find = tree.find
+    ql, el = qs.tolist(), qe.tolist()
+    ref_find, counts = None, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        counts = np.fromiter((len(find(a, b)) for a, b in zip(ql, el)), dtype=np.int32, count=len(ql))
+        dt = time.perf_counter() - t0
+        ref_find = dt if ref_find is None or dt < ref_find else ref_find
+    del tree
+    t0 = time.perf_counter()
+    ot = O.OracleIntervalTree()
+    ot.insert_many_arrays(ts, te)
+    port_ins = time.perf_counter() - t0
+    port_find = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pc, _ = ot.count_batch(qs, qe)
+        dt = time.perf_counter() - t0
+        port_find = dt if port_find is None or dt < port_find else port_find
+    assert np.array_equal(pc, counts)
+    cpu = ""
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu = platform.processor()
+    return dict(n_targets=n_targets, n_queries=len(qs), stride=stride, cpu=cpu, threads=1,
+                reference_insert_s=round(ref_ins, 2), reference_find_s=round(ref_find, 3), reference_mq_per_s=round(len(qs) / ref_find / 1e6, 5),
+                port_insert_s=round(port_ins, 2), port_find_s=round(port_find, 3), port_mq_per_s=round(len(qs) / port_find / 1e6, 5),
+                port_over_reference=round(ref_find / port_find, 3), counts_sha256=sha(counts),
+                note="reference = len(IntervalTree.find(qs, qe)) per query through the Cython extension (a Python-level loop, as "
+                     "its callers use it); port = oracle/ivtree.c count_batch; same arrays, same machine, one thread")
+
+
+def gen_extra(which):
+    path = os.path.join(GOLD, "scale.json")
+    doc = json.load(open(path))
+    if which == "genome":
+        doc["cfg4_genome"] = genome_point()
+    elif which == "join":
+        doc["cfg5_join"] = join_point()
+    elif which == "calibration":
+        doc["calibration"] = calibration_point()
+    # another generator may have rewritten the file meanwhile: merge on the freshest copy
+    fresh = json.load(open(path))
+    for k in ("cfg4_genome", "cfg5_join", "calibration"):
+        if k in doc and (k == {"genome": "cfg4_genome", "join": "cfg5_join", "calibration": "calibration"}[which]):
+            fresh[k] = doc[k]
+    dump("scale.json", fresh)
+
+
 def gen_scale(full):
     path = os.path.join(GOLD, "scale.json")
     old = json.load(open(path)) if os.path.exists(path) else {}
@@ -364,3 +476,6 @@ if __name__ == "__main__":
         gen_cli_siblings()
     if "scale" in todo:
         gen_scale(a.scale)
+    for which in ("genome", "join", "calibration"):  # --only genome | join | calibration: long-running extras of scale.json
+        if which in todo and a.only:
+            gen_extra(which)

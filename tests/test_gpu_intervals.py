@@ -35,6 +35,15 @@ def set_opt(key, value):
     _ffi.call("bxmi_set_option", key.encode(), int(value))
 
 
+DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": 0, "ivl.bm_u": 4,
+                "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 0}
+
+
+def reset_opts():
+    for k, v in DEFAULT_OPTS.items():
+        set_opt(k, v)
+
+
 def make_index(IntervalIndex, starts, ends):
     ix = IntervalIndex()
     ix.append(starts, ends)
@@ -149,8 +158,10 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     bad = np.nonzero(got_c != want_c)[0]
     assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got_c[bad[:5]], want_c[bad[:5]])
     assert got_t == want_t
-    set_opt("ivl.partition", 1)  # same batch through the bucketed large-batch path
+    set_opt("ivl.partition", 1)  # same batch through the large-batch paths
     try:
+        bm_c, bm_t = ix.count(qs, qe)  # bitmap-cell pass where the index qualifies (else identical to the next line)
+        set_opt("ivl.bitmap", 0)       # the bucketed search pass
         got_c, got_t = ix.count(qs, qe)
         tot_only = ix.count(qs, qe, want_counts=False)[1]
         set_opt("ivl.count_cells", 0)  # the LDS-search-tree variant of the bucket search
@@ -159,8 +170,9 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
         if not ix.has_reversed:
             p_off, p_hits = ix.find(qs, qe)
     finally:
-        set_opt("ivl.count_cells", 1)
-        set_opt("ivl.partition", -1)
+        reset_opts()
+    bad = np.nonzero(bm_c != want_c)[0]
+    assert len(bad) == 0 and bm_t == want_t, ("bitmap pass", ix.bitmap_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
     assert np.array_equal(tree_c, want_c) and tree_t == want_t, "partitioned, tree variant"
     if not ix.has_reversed:
         w_off, w_hits = t.find_batch(qs, qe)
@@ -196,6 +208,8 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
     want_c, want_t = t.count_batch(qs, qe)
     set_opt("ivl.partition", 1)
     try:
+        bm_c, bm_t = ix.count(qs, qe)  # bitmap-cell pass (where the index qualifies): long runs, one bucket per tile
+        set_opt("ivl.bitmap", 0)
         got_c, got_t = ix.count(qs, qe)
         tot_only = ix.count(qs, qe, want_counts=False)[1]
         f_off, f_hits = ix.find(qs, qe)  # windows in query order, no bucketing
@@ -208,8 +222,9 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
         qs2[m], qs2[m + 1] = qs[m + 1] + 1, qs[m] - 1
         u_c, u_t = ix.count(qs2, qe2)
     finally:
-        set_opt("ivl.sorted_path", 1)
-        set_opt("ivl.partition", -1)
+        reset_opts()
+    bad = np.nonzero(bm_c != want_c)[0]
+    assert len(bad) == 0 and bm_t == want_t, ("bitmap pass", ix.bitmap_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
     bad = np.nonzero(got_c != want_c)[0]
     assert len(bad) == 0, ("sorted path", bad[:5], qs[bad[:5]], qe[bad[:5]], got_c[bad[:5]], want_c[bad[:5]])
     assert got_t == want_t == tot_only
@@ -239,17 +254,21 @@ def test_partitioned_counts_beyond_16_bits(O, IntervalIndex):
     t = O.OracleIntervalTree()
     t.insert_many_arrays(s, e)
     want, want_total = t.count_batch(qs, qe)
-    assert want.max() >= 65535 and (want == 65535).sum() == 0 or True
     ix = make_index(IntervalIndex, s, e)
     set_opt("ivl.partition", 1)
     try:
+        bm, bm_total = ix.count(qs, qe)  # bitmap-cell pass: the pile is one hard cell per array, its counts escape
+        state = ix.bitmap_state()
+        set_opt("ivl.bitmap", 0)
         got, got_total = ix.count(qs, qe)
         set_opt("ivl.count_cells", 0)
         tree, tree_total = ix.count(qs, qe)
     finally:
-        set_opt("ivl.count_cells", 1)
-        set_opt("ivl.partition", -1)
+        reset_opts()
     assert int(want.max()) >= pile
+    assert state[0] == 1 and state[1] >= 2, state
+    bad = np.nonzero(bm != want)[0]
+    assert len(bad) == 0 and bm_total == want_total, ("bitmap pass", bad[:5], qs[bad[:5]], qe[bad[:5]], bm[bad[:5]], want[bad[:5]])
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got[bad[:5]], want[bad[:5]])
     assert got_total == want_total == tree_total and np.array_equal(tree, want)
@@ -273,14 +292,20 @@ def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
     ix = make_index(IntervalIndex, s, e)
     set_opt("ivl.partition", 1)
     try:
+        set_opt("ivl.bm_hard_ppm", 10**6)  # keep the bitmap-cell pass although the dense stretch is all hard cells
+        bm, bm_total = ix.count(qs, qe)
+        state = ix.bitmap_state()
+        set_opt("ivl.bitmap", 0)
         got, got_total = ix.count(qs, qe)
         set_opt("ivl.count_cells", 0)
         tree, tree_total = ix.count(qs, qe)
         set_opt("ivl.count_cells", 1)
         p_off, p_hits = ix.find(qs[:20000], qe[:20000])
     finally:
-        set_opt("ivl.count_cells", 1)
-        set_opt("ivl.partition", -1)
+        reset_opts()
+    assert state[0] == 1 and state[1] > 100, state
+    bad = np.nonzero(bm != want)[0]
+    assert len(bad) == 0 and bm_total == want_total, ("bitmap pass, hard cells", bad[:5], qs[bad[:5]], qe[bad[:5]], bm[bad[:5]], want[bad[:5]])
     assert np.array_equal(tree, want) and tree_total == want_total, "tree variant"
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got[bad[:5]], want[bad[:5]])
@@ -318,6 +343,93 @@ def test_incremental_append_reseals(O, IntervalIndex):
         assert np.array_equal(ix.find(qs, qe)[1], t.find_batch(qs, qe)[1])
 
 
+@pytest.mark.parametrize("shape", ["uniform", "sorted", "one_bucket", "messy", "ragged_tail", "dups"])
+def test_bitmap_pass_differential(O, IntervalIndex, shape):
+    """The bitmap-cell count pass (count_bitmap.hpp) against the oracle treap: shuffled, sorted and clumped batches,
+    zero-length / reversed / off-grid / very long queries (escapes), tiles that are not full, targets whose coordinates
+    carry duplicates (duplicate descriptors and hard cells), all tile shapes and unroll depths."""
+    rng = np.random.default_rng(7 + ["uniform", "sorted", "one_bucket", "messy", "ragged_tail", "dups"].index(shape))
+    n, span = 120_000, 40_000_000  # bucket width 2^15
+    s = rng.integers(1000, span, size=n)
+    if shape == "dups":
+        s[: n // 2] = rng.choice(s[n // 2:], size=n // 2)          # half of the starts repeat another one
+        s[:2000] = rng.integers(5_000_000, 5_000_064, size=2000)   # and two cells' worth of piled-up coordinates
+    e = s + rng.integers(0, 1500, size=n)
+    nq = {"ragged_tail": 16384 * 3 + 17}.get(shape, 70_000)
+    qs = rng.integers(0, span + 2000, size=nq)
+    qe = qs + rng.integers(1, 3000, size=nq)
+    if shape == "sorted":
+        o = np.argsort(qs, kind="stable")
+        qs, qe = qs[o], qe[o]
+    elif shape == "one_bucket":
+        qs = rng.integers(20_000_000, 20_030_000, size=nq)
+        qe = qs + rng.integers(1, 3000, size=nq)
+    elif shape == "messy":
+        k = nq // 10
+        qe[:k] = qs[:k]                                       # zero-length
+        qe[k:2 * k] = qs[k:2 * k] - rng.integers(1, 50, size=k)   # reversed
+        qe[2 * k:3 * k] = qs[2 * k:3 * k] + rng.integers(32766, 5_000_000, size=k)  # longer than a record holds
+        qs[3 * k:4 * k] = rng.integers(-(2**31), 1000, size=k)    # left of the grid
+        qe[3 * k:4 * k] = qs[3 * k:4 * k] + rng.integers(1, 2000, size=k)
+        qs[4 * k:5 * k] = rng.integers(span + 2000, 2**31 - 5000, size=k)  # right of it
+        qe[4 * k:5 * k] = qs[4 * k:5 * k] + rng.integers(1, 2000, size=k)
+        qs[5 * k:5 * k + 4] = [-(2**31), 2**31 - 1, 900, 999]
+        qe[5 * k:5 * k + 4] = [2**31 - 1, 2**31 - 1, 1001, 1000]
+        p = rng.permutation(nq)
+        qs, qe = qs[p], qe[p]
+    s, e, qs, qe = (np.clip(a, -(2**31), 2**31 - 1).astype(np.int32) for a in (s, e, qs, qe))
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    want, want_total = t.count_batch(qs, qe)
+    ix = make_index(IntervalIndex, s, e)
+    set_opt("ivl.partition", 1)
+    try:
+        for variant, u, pair in ((0, 4, 0), (1, 2, 1), (2, 8, 0), (0, 4, 1)):
+            set_opt("ivl.bm_variant", variant)
+            set_opt("ivl.bm_u", u)
+            set_opt("ivl.bm_pair", pair)  # one bucket per search workgroup, or two neighbours
+            got, got_total = ix.count(qs, qe)
+            state = ix.bitmap_state()
+            assert state[0] == 1, state
+            bad = np.nonzero(got != want)[0]
+            assert len(bad) == 0, (shape, variant, u, pair, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+            assert got_total == want_total
+        if shape == "dups":
+            assert state[1] > 0  # the pile made hard cells
+    finally:
+        reset_opts()
+
+
+def test_bitmap_pass_is_refused_where_it_does_not_fit(O, IntervalIndex):
+    """Spans beyond 2^28, reversed targets and heavily duplicated coordinates keep the bucketed search pass."""
+    rng = np.random.default_rng(9)
+    cases = {}
+    s = rng.integers(0, 2**30, size=50_000)
+    cases["wide"] = (s, s + rng.integers(0, 500, size=50_000))
+    s = rng.integers(0, 10_000_000, size=50_000)
+    e = s + rng.integers(0, 500, size=50_000)
+    e[7] = s[7] - 3
+    cases["reversed"] = (s, e)
+    s = rng.integers(0, 12_500, size=50_000) * 8  # four occupied coordinates per cell, each several times over: all cells hard
+    cases["duplicates"] = (s, s + 8 * rng.integers(0, 10, size=50_000))
+    qs = rng.integers(0, 10_000_000, size=20_000).astype(np.int32)
+    qe = (qs + rng.integers(1, 800, size=20_000)).astype(np.int32)
+    set_opt("ivl.partition", 1)
+    try:
+        for name, (s, e) in cases.items():
+            s, e = s.astype(np.int32), e.astype(np.int32)
+            t = O.OracleIntervalTree()
+            t.insert_many_arrays(s, e)
+            want, want_total = t.count_batch(qs, qe)
+            ix = make_index(IntervalIndex, s, e)
+            assert ix.bitmap_state()[0] == 0
+            got, got_total = ix.count(qs, qe)
+            assert np.array_equal(got, want) and got_total == want_total, name
+            assert ix.bitmap_state()[0] == (0 if name == "reversed" else -1), (name, ix.bitmap_state())
+    finally:
+        reset_opts()
+
+
 # --------------------------------------------------------- scale / golden hash --
 def test_scale_1M_hash(golden_scale, IntervalIndex):
     pt = golden_scale["1M x 200k"]
@@ -333,9 +445,16 @@ def test_scale_1M_hash(golden_scale, IntervalIndex):
     set_opt("ivl.lds_ints", 18688)
     set_opt("ivl.partition", 1)
     try:
+        for variant in (0, 1, 2, 3):  # the bitmap-cell pass: all three tile shapes, then bucket pairs
+            set_opt("ivl.bm_variant", variant % 3)
+            set_opt("ivl.bm_pair", variant == 3)
+            counts, total = ix.count(qs, qe)
+            assert ix.bitmap_state()[0] == 1
+            assert total == pt["total"] and hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], ("bitmap pass", variant)
+        set_opt("ivl.bitmap", 0)
         counts, total = ix.count(qs, qe)
     finally:
-        set_opt("ivl.partition", -1)
+        reset_opts()
     assert total == pt["total"] and hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], "partitioned"
     offs, hits = ix.find(qs, qe)
     assert offs[-1] == pt["total"] and np.array_equal(np.diff(offs), counts)
@@ -357,13 +476,19 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
         sub = counts[:: pt["stride"]]
         assert int(sub.sum(dtype=np.int64)) == pt["total"]
         assert hashlib.sha256(np.ascontiguousarray(sub).tobytes()).hexdigest() == pt["counts_sha256"]
-    # the direct tree kernel and the bucketed path agree (first 8M queries through the direct kernel)
+    assert ix.bitmap_state()[0] == 1  # the full batch above went through the bitmap-cell pass
+    # the direct tree kernel and the large-batch passes agree (first 8M queries through the direct kernel)
     set_opt("ivl.partition", 0)
     try:
         direct, _ = ix.count(qs[:8_000_000], qe[:8_000_000])
-    finally:
         set_opt("ivl.partition", -1)
+        set_opt("ivl.bitmap", 0)  # the bucketed search pass on the whole batch
+        old, old_total = ix.count(qs, qe)
+    finally:
+        reset_opts()
     assert np.array_equal(direct, counts[:8_000_000])
+    assert np.array_equal(old, counts) and old_total == total
+    del old
     # additivity: counting two halves separately gives the same per-query numbers
     h = len(qs) // 2
     c2, t2 = ix.count(qs[h:], qe[h:])
