@@ -163,6 +163,39 @@ __global__ __launch_bounds__(1024) void bm_image_kernel(const int32_t *__restric
 }
 
 // ---------------------------------------------------------------------------
+// pass 0: is the batch already sorted by start?
+// ---------------------------------------------------------------------------
+// BED files usually arrive sorted, and a sorted batch needs no exchange at all (ivl_local_count_kernel answers it as it
+// lies).  Every kernel of this pass reads the flag this one leaves: 1 = a descent was seen, go on; 0 = sorted, stand
+// down.  A workgroup that sees the flag already raised leaves at once, so a shuffled batch costs a few microseconds
+// (every workgroup finds a descent in its first 4096 starts) and a sorted one a single read of the starts.
+// The flag is read and written with ORDINARY accesses on purpose: raising it with device-scope (write-through) stores
+// from 2048 workgroups serialises them at the memory side (measured: 76 us for a shuffled batch); ordinary stores of the
+// same value meet in each XCD's L2 and are written back at the kernel boundary, which is all the next kernel needs.
+__global__ __launch_bounds__(256) void bm_sorted_check_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ unsorted)
+{
+    constexpr int CH = 256 * 16;
+    for (int64_t c = blockIdx.x; c * CH < nq; c += gridDim.x) {
+        if (__hip_atomic_load(unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
+        const int64_t base = c * CH + 16 * (int64_t)threadIdx.x;
+        bool descent = false;
+        if (base + 17 <= nq) {
+            const int4 *p = reinterpret_cast<const int4 *>(qs + base);
+            const int4 a = p[0], b = p[1], d = p[2], e = p[3];
+            const int nxt = qs[base + 16];
+            descent = a.x > a.y || a.y > a.z || a.z > a.w || a.w > b.x || b.x > b.y || b.y > b.z || b.z > b.w || b.w > d.x || d.x > d.y ||
+                      d.y > d.z || d.z > d.w || d.w > e.x || e.x > e.y || e.y > e.z || e.z > e.w || e.w > nxt;
+        } else {
+            for (int64_t i = base; i + 1 < nq && i < base + 16; i++) descent |= qs[i] > qs[i + 1];
+        }
+        if (__syncthreads_or(descent)) {
+            if (threadIdx.x == 0) __hip_atomic_store(unsorted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // pass 1: order a tile by bucket inside LDS
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned bm_bucket_of(int qs, const BmGeom &g)
@@ -185,9 +218,11 @@ template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const int32_t *__restrict__ qs, const int32_t *__restrict__ qe, int64_t nq,
                                                                BmGeom g, unsigned *__restrict__ recs /* [ntiles][TILE], tile-sorted */,
                                                                unsigned short *__restrict__ slots /* [nq] slot of every query in its tile */,
-                                                               unsigned short *__restrict__ tbl /* [ntiles][BM_NB] first slot of every bucket */)
+                                                               unsigned short *__restrict__ tbl /* [ntiles][BM_NB] first slot of every bucket */,
+                                                               const unsigned *__restrict__ gate /* NULL, or 0 = sorted batch: stand down */)
 {
     constexpr int TILE = THREADS * ITEMS;
+    if (gate && *gate == 0) return;
     constexpr int BPT = BM_NB / THREADS;  // buckets per thread in the scan
     static_assert(BM_NB % THREADS == 0 && (BPT == 2 || BPT == 4), "2 or 4 buckets per thread");
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
@@ -299,9 +334,10 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const int32_t *__
 // grpcnt[group][bucket] = queries of the bucket in the 64 tiles of the group.
 __global__ __launch_bounds__(256) void bm_transpose_kernel(const unsigned short *__restrict__ tbl, int64_t ntiles, int64_t nq, int tile_log2,
                                                            unsigned *__restrict__ runT /* [BM_NB][ntp] */, int64_t ntp,
-                                                           unsigned *__restrict__ grpcnt /* [ngroups][BM_NB] */)
+                                                           unsigned *__restrict__ grpcnt /* [ngroups][BM_NB] */, const unsigned *__restrict__ gate)
 {
     __shared__ unsigned short t[BM_GROUP_TILES][66];
+    if (gate && *gate == 0) return;
     const int grp = blockIdx.x, b0 = blockIdx.y * 64;
     {
         const int r = threadIdx.x >> 2, q = threadIdx.x & 3;  // 4 threads per tile row, 16 buckets each
@@ -391,9 +427,10 @@ __device__ __forceinline__ void bm_plan_walk(const unsigned *__restrict__ grpcnt
 
 template <int UNITS>
 __global__ __launch_bounds__(1024) void bm_plan_kernel(const unsigned *__restrict__ grpcnt, int ngroups, int64_t ntiles, int chunk,
-                                                       int4 *__restrict__ items, int *__restrict__ n_items)
+                                                       int4 *__restrict__ items, int *__restrict__ n_items, const unsigned *__restrict__ gate)
 {
     __shared__ int scan_tmp[16];
+    if (gate && *gate == 0) return;
     const int b0 = 2 * threadIdx.x;
     int cnt[2], again[2];
     bm_plan_walk<false, UNITS>(grpcnt, ngroups, ntiles, b0, chunk, cnt, nullptr, 0, 0);
@@ -469,9 +506,11 @@ __global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_kernel(const uint
                                                                       const int4 *__restrict__ items, const int *__restrict__ n_items,
                                                                       const unsigned *__restrict__ runT, int64_t ntp,
                                                                       unsigned *__restrict__ recs /* records in, counts out */, int tile_log2,
-                                                                      const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted)
+                                                                      const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted,
+                                                                      const unsigned *__restrict__ gate)
 {
     constexpr int L = PAIR ? 16 : 8;
+    if (gate && *gate == 0) return;
     constexpr int NG = BM_SEARCH_THREADS / L;
     constexpr unsigned LONG_RUN = 4 * L;  // longer runs go to the cooperative finish
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
@@ -608,6 +647,185 @@ __global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_kernel(const uint
     if ((EXP & 1) && sink == 0x12345678u) recs[0] = 1;  // keeps the work of the store-less variant alive
 }
 
+// The same walk, software-pipelined: a wave that loads, then computes, then stores leaves the memory pipe idle while
+// it computes and its SIMD idle while it waits -- with every wave slot of the CU taken (the images fill the LDS) the
+// kernel time was the SUM of the two (measured: compute 120 us + record loads 140 us + count stores 240 us).  Here
+// the records of round r + 1 are requested before round r is computed; all loads of a round, the first leftover pass
+// included, are issued together and without branches so that the waits can count instead of draining.
+typedef int bm_v4i __attribute__((ext_vector_type(4)));
+
+template <int U>
+struct BmRound {
+    unsigned first[U];  // first record of each of the group's runs
+    unsigned lens[U];   // records of the item's first bucket | all records << 16
+    unsigned rec[U];    // this lane's record of the first pass
+    unsigned lf_at;     // this lane's record of the first leftover pass (absolute index), ~0u = none
+    unsigned lf_rec;
+    unsigned lf_total;  // leftover records of the whole group
+    unsigned listed;    // bit u: run u is long and waits in the workgroup's list (its leftovers are not the group's)
+    bool lf_second;     // that record belongs to the item's second bucket
+};
+
+template <bool PAIR, int U, bool NT /* image loads non-temporal: they stream through L2 once */>
+__global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_pipe_kernel(const uint2 *__restrict__ images, BmGeom g,
+                                                                           const BmBucket *__restrict__ bmeta, const int4 *__restrict__ items,
+                                                                           const int *__restrict__ n_items, const unsigned *__restrict__ runT,
+                                                                           int64_t ntp, unsigned *__restrict__ recs /* records in, counts out */,
+                                                                           int tile_log2, const int32_t *__restrict__ s_ord,
+                                                                           const int32_t *__restrict__ e_sorted, const unsigned *__restrict__ gate)
+{
+    constexpr int L = PAIR ? 16 : 8;
+    if (gate && *gate == 0) return;
+    constexpr int NG = BM_SEARCH_THREADS / L;
+    constexpr unsigned LONG_RUN = 4 * L;
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ uint2 s_long[BM_LONG_CAP];
+    __shared__ int s_nlong;
+    const int nit = *n_items;
+    const int per_xcd = (nit + 7) >> 3;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int it = (int)(blockIdx.x & 7) * per_xcd + slot;
+    if (slot >= per_xcd || it >= nit) return;
+    const int4 item = items[it];
+    const int b = item.x, t0 = item.y, t1 = item.z;
+    const unsigned *__restrict__ runs0 = runT + (int64_t)b * ntp;
+    const unsigned *__restrict__ runs1 = runs0 + ntp;  // PAIR only
+    const int gid = threadIdx.x / L, sub = threadIdx.x % L;
+    unsigned run[U], run2[U];
+    auto load_runs = [&](int tb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tb + u * NG + gid;
+            const int tc = t < t1 ? t : t0;  // a valid address: no branch around the load
+            const unsigned a = runs0[tc], c = PAIR ? runs1[tc] : 0u;
+            run[u] = t < t1 ? a : 0u;
+            run2[u] = t < t1 ? c : 0u;
+        }
+    };
+    load_runs(t0);
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(images + (size_t)b * g.stride);
+        const int n4 = (PAIR ? 2 : 1) * (g.stride >> 1);
+        constexpr int SWEEPS = 5;
+        for (int i0 = 0; i0 < n4; i0 += SWEEPS * BM_SEARCH_THREADS) {
+            int4 v[SWEEPS];
+#pragma unroll
+            for (int k = 0; k < SWEEPS; k++) {
+                const int i = i0 + k * BM_SEARCH_THREADS + (int)threadIdx.x;
+                if (NT) {
+                    const bm_v4i w = __builtin_nontemporal_load(reinterpret_cast<const bm_v4i *>(src) + (i < n4 ? i : n4 - 1));
+                    v[k] = make_int4(w.x, w.y, w.z, w.w);
+                } else {
+                    v[k] = src[i < n4 ? i : n4 - 1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < SWEEPS; k++) {
+                const int i = i0 + k * BM_SEARCH_THREADS + (int)threadIdx.x;
+                if (i < n4) reinterpret_cast<int4 *>(dyn)[i] = v[k];
+            }
+        }
+    }
+    const lds_cell_p cE0 = (lds_cell_p) reinterpret_cast<unsigned long long *>(dyn), cS0 = cE0 + g.nce;
+    const int cells1 = PAIR ? g.stride : 0;
+    const BmBucket bk0 = bmeta[b], bk1 = bmeta[PAIR ? b + 1 : b];
+    const long long lo0 = (long long)g.cmin + ((long long)b << g.shift), lo1 = lo0 + (PAIR ? (long long)1 << g.shift : 0ll);
+    if (threadIdx.x == 0) s_nlong = 0;
+    __syncthreads();
+    auto answer = [&](unsigned at, bool second, unsigned rec) {
+        const int shift_cells = second ? cells1 : 0;
+        recs[(size_t)at] = bm_count_record(cE0 + shift_cells, cS0 + shift_cells, second ? bk1.eLo : bk0.eLo, second ? bk1.sLo : bk0.sLo,
+                                           second ? lo1 : lo0, rec, s_ord, e_sorted);
+    };
+    // round `tb`: addresses from the runs in run[] / run2[], every load of the round issued
+    auto prep = [&](BmRound<U> &R, int tb) {
+        unsigned cum = 0, lf_at = ~0u, listed_mask = 0;
+        bool lf_second = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tb + u * NG + gid;
+            const unsigned first = ((unsigned)t << tile_log2) + (run[u] & 0xffffu);
+            const unsigned len0 = run[u] >> 16, len = len0 + (PAIR ? run2[u] >> 16 : 0u);
+            R.first[u] = first;
+            R.lens[u] = len0 | (len << 16);
+            R.rec[u] = recs[(size_t)((unsigned)sub < len ? first + (unsigned)sub : 0u)];
+            unsigned rem = len > (unsigned)L ? len - (unsigned)L : 0u;
+            if (len > LONG_RUN) {  // left to the whole workgroup (see bm_search_kernel)
+                bool listed = false;
+                if (sub == 0) {
+                    const int k = atomicAdd(&s_nlong, 1);
+                    if (k < BM_LONG_CAP) {
+                        s_long[k] = make_uint2(first, len | (len0 << 16));
+                        listed = true;
+                    }
+                }
+                listed = __shfl(listed, (int)(threadIdx.x & 63) - sub, 64);
+                if (listed) {
+                    rem = 0;
+                    listed_mask |= 1u << u;
+                }
+            }
+            const unsigned i = (unsigned)sub - cum;  // position among this run's leftovers, if it is this lane's turn
+            if ((unsigned)sub >= cum && i < rem) {
+                lf_at = first + (unsigned)L + i;
+                lf_second = PAIR && (unsigned)L + i >= len0;
+            }
+            cum += rem;
+        }
+        R.lf_total = cum;
+        R.listed = listed_mask;
+        R.lf_at = lf_at;
+        R.lf_second = lf_second;
+        R.lf_rec = recs[(size_t)(lf_at != ~0u ? lf_at : 0u)];
+    };
+    auto finish = [&](BmRound<U> &R) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned len0 = R.lens[u] & 0xffffu, len = R.lens[u] >> 16;
+            if ((unsigned)sub < len) answer(R.first[u] + (unsigned)sub, PAIR && (unsigned)sub >= len0, R.rec[u]);
+        }
+        if (R.lf_at != ~0u) answer(R.lf_at, R.lf_second, R.lf_rec);
+        for (unsigned base = L; __any(base < R.lf_total); base += L) {  // further leftover passes: rare
+            const unsigned i = base + (unsigned)sub;
+            unsigned cum = 0, at = ~0u;
+            bool second = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned len0 = R.lens[u] & 0xffffu, len = R.lens[u] >> 16;
+                const unsigned rem = len > (unsigned)L && !((R.listed >> u) & 1u) ? len - (unsigned)L : 0u;
+                const unsigned j = i - cum;
+                if (i >= cum && j < rem) {
+                    at = R.first[u] + (unsigned)L + j;
+                    second = PAIR && (unsigned)L + j >= len0;
+                }
+                cum += rem;
+            }
+            if (at != ~0u) answer(at, second, recs[(size_t)at]);
+        }
+    };
+    BmRound<U> A, B;
+    prep(A, t0);
+    load_runs(t0 + NG * U);
+    for (int tb = t0; tb < t1; tb += 2 * NG * U) {
+        prep(B, tb + NG * U);
+        load_runs(tb + 2 * NG * U);
+        finish(A);
+        prep(A, tb + 2 * NG * U);
+        load_runs(tb + 3 * NG * U);
+        finish(B);
+    }
+    __syncthreads();
+    {
+        const int nl = s_nlong < BM_LONG_CAP ? s_nlong : BM_LONG_CAP;
+        for (int k = 0; k < nl; k++) {
+            const uint2 e = s_long[k];
+            const unsigned ll = e.y & 0xffffu, l0 = e.y >> 16;
+            for (unsigned p = (unsigned)L + threadIdx.x; p < ll; p += BM_SEARCH_THREADS)
+                answer(e.x + p, PAIR && p >= l0, recs[(size_t)e.x + p]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // pass 4: counts back into query order
 // ---------------------------------------------------------------------------
@@ -624,10 +842,11 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
                                                                const unsigned short *__restrict__ slots, int64_t nq, int32_t *__restrict__ out,
                                                                unsigned long long *__restrict__ total_slots, IndexDev ix,
                                                                const int32_t *__restrict__ e_sorted, BmGeom g, const int32_t *__restrict__ qs_arr,
-                                                               const int32_t *__restrict__ qe_arr)
+                                                               const int32_t *__restrict__ qe_arr, const unsigned *__restrict__ gate)
 {
     constexpr int TILE = THREADS * ITEMS;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    if (gate && *gate == 0) return;
     unsigned *vals = reinterpret_cast<unsigned *>(dyn);  // [TILE]
     __shared__ long long red[THREADS / 64];
     const int64_t tile = blockIdx.x;

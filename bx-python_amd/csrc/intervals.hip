@@ -2043,9 +2043,11 @@ constexpr int PT_SLOT_STRIDE = PT_SLOTS + 8;  // per sub-batch: the partial tota
 static int64_t g_opt_count_cells = 1;  // 1 = direct-addressed cells in the bucket search, 0 = LDS search trees
 static int64_t g_opt_sorted_path = 1;  // 1 = batches whose starts are already sorted skip the bucketing (detected on the device)
 static int64_t g_opt_bitmap = -1;      // second-generation count pass (count_bitmap.hpp): -1 = when the index qualifies, 0 = never, 1 = same as -1
-static int64_t g_opt_bm_variant = 0;   // tile kernel shape: 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
-static int64_t g_opt_bm_u = 4;         // tile runs in flight per 8-lane group of the search kernel (2, 4 or 8)
-static int64_t g_opt_bm_pair = 0;      // 1 = a search workgroup holds two neighbouring buckets (one workgroup per CU, runs twice as long)
+static int64_t g_opt_bm_variant = -1;  // tile kernel shape: -1 = by batch size, 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
+static int64_t g_opt_bm_u = 2;         // tile runs in flight per 8-lane group of the search kernel (2, 4 or 8)
+static int64_t g_opt_bm_pair = 1;      // 1 = a search workgroup holds two neighbouring buckets (one workgroup per CU, runs twice as long)
+static int64_t g_opt_bm_nt = 0;        // 1 = non-temporal image loads in the pipelined search kernel
+static int64_t g_opt_bm_pipe = 1;      // 1 = the software-pipelined search kernel
 static int64_t g_opt_bm_exp = 0;       // diagnostics only (wrong results): price the pieces of the search kernel, see count_bitmap.hpp
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
 
@@ -2084,15 +2086,23 @@ int ivl_set_option(const char *key, int64_t value)
         return 1;
     }
     if (!strcmp(key, "ivl.bm_variant")) {
-        g_opt_bm_variant = value < 0 || value > 2 ? 0 : value;
+        g_opt_bm_variant = value < 0 || value > 2 ? -1 : value;
         return 1;
     }
     if (!strcmp(key, "ivl.bm_u")) {
-        g_opt_bm_u = value == 2 || value == 8 ? value : 4;
+        g_opt_bm_u = value == 4 || value == 8 ? value : 2;
         return 1;
     }
     if (!strcmp(key, "ivl.bm_pair")) {
         g_opt_bm_pair = value != 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bm_nt")) {
+        g_opt_bm_nt = value != 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bm_pipe")) {
+        g_opt_bm_pipe = value != 0;
         return 1;
     }
     if (!strcmp(key, "ivl.bm_exp")) {
@@ -2377,61 +2387,84 @@ static int bm_prepare_index(bxmi_ivl *h, hipStream_t st)
 }
 
 template <int THREADS, int ITEMS>
-static int bm_launch_tiles(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t ntiles, hipStream_t st)
+static int bm_launch_tiles(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t ntiles, const unsigned *gate, hipStream_t st)
 {
     constexpr int TILE = THREADS * ITEMS;
     const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64;
     BXMI_TRY(allow_big_lds(bm_tile_sort_kernel<THREADS, ITEMS>, lds));
     hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS>), dim3((unsigned)ntiles), dim3(THREADS), lds, st, qs, qe, nq, h->bm_geom,
-                       h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>());
+                       h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
 template <bool PAIR, int U, int EXP = 0>
-static int bm_launch_search(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, hipStream_t st)
+static int bm_launch_search(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, const unsigned *gate, hipStream_t st)
 {
     const size_t lds = (size_t)(PAIR ? 2 : 1) * h->bm_geom.stride * sizeof(uint2);
     BXMI_TRY(allow_big_lds((bm_search_kernel<PAIR, U, EXP>), lds));
     hipLaunchKernelGGL((bm_search_kernel<PAIR, U, EXP>), dim3(grid), dim3(BM_SEARCH_THREADS), lds, st, h->bm_images.as<uint2>(), h->bm_geom,
                        h->bm_meta.as<BmBucket>(), h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), ntp,
-                       h->bm_recs.as<unsigned>(), tile_log2, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>());
+                       h->bm_recs.as<unsigned>(), tile_log2, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), gate);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+template <bool PAIR, int U, bool NT>
+static int bm_launch_search_pipe(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, const unsigned *gate, hipStream_t st)
+{
+    const size_t lds = (size_t)(PAIR ? 2 : 1) * h->bm_geom.stride * sizeof(uint2);
+    BXMI_TRY(allow_big_lds((bm_search_pipe_kernel<PAIR, U, NT>), lds));
+    hipLaunchKernelGGL((bm_search_pipe_kernel<PAIR, U, NT>), dim3(grid), dim3(BM_SEARCH_THREADS), lds, st, h->bm_images.as<uint2>(), h->bm_geom,
+                       h->bm_meta.as<BmBucket>(), h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), ntp,
+                       h->bm_recs.as<unsigned>(), tile_log2, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
 template <bool PAIR>
-static int bm_launch_search_u(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, hipStream_t st)
+static int bm_launch_search_u(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, const unsigned *gate, hipStream_t st)
 {
-    if (g_opt_bm_exp == 1) return bm_launch_search<PAIR, 4, 1>(h, grid, ntp, tile_log2, st);
-    if (g_opt_bm_exp == 2) return bm_launch_search<PAIR, 4, 2>(h, grid, ntp, tile_log2, st);
-    if (g_opt_bm_exp == 3) return bm_launch_search<PAIR, 4, 3>(h, grid, ntp, tile_log2, st);
-    if (g_opt_bm_exp == 4) return bm_launch_search<PAIR, 4, 4>(h, grid, ntp, tile_log2, st);
-    if (g_opt_bm_exp == 5) return bm_launch_search<PAIR, 4, 5>(h, grid, ntp, tile_log2, st);
-    if (g_opt_bm_exp == 6) return bm_launch_search<PAIR, 4, 6>(h, grid, ntp, tile_log2, st);
-    if (g_opt_bm_exp == 7) return bm_launch_search<PAIR, 4, 7>(h, grid, ntp, tile_log2, st);
-    if (g_opt_bm_u == 2) return bm_launch_search<PAIR, 2>(h, grid, ntp, tile_log2, st);
-    if (g_opt_bm_u == 8) return bm_launch_search<PAIR, 8>(h, grid, ntp, tile_log2, st);
-    return bm_launch_search<PAIR, 4>(h, grid, ntp, tile_log2, st);
+    if (g_opt_bm_pipe && g_opt_bm_exp == 0) {
+        if (g_opt_bm_nt) {
+            if (g_opt_bm_u == 2) return bm_launch_search_pipe<PAIR, 2, true>(h, grid, ntp, tile_log2, gate, st);
+            return bm_launch_search_pipe<PAIR, 4, true>(h, grid, ntp, tile_log2, gate, st);
+        }
+        if (g_opt_bm_u == 2) return bm_launch_search_pipe<PAIR, 2, false>(h, grid, ntp, tile_log2, gate, st);
+        return bm_launch_search_pipe<PAIR, 4, false>(h, grid, ntp, tile_log2, gate, st);
+    }
+    if (g_opt_bm_exp == 1) return bm_launch_search<PAIR, 4, 1>(h, grid, ntp, tile_log2, gate, st);
+    if (g_opt_bm_exp == 2) return bm_launch_search<PAIR, 4, 2>(h, grid, ntp, tile_log2, gate, st);
+    if (g_opt_bm_exp == 3) return bm_launch_search<PAIR, 4, 3>(h, grid, ntp, tile_log2, gate, st);
+    if (g_opt_bm_exp == 4) return bm_launch_search<PAIR, 4, 4>(h, grid, ntp, tile_log2, gate, st);
+    if (g_opt_bm_exp == 5) return bm_launch_search<PAIR, 4, 5>(h, grid, ntp, tile_log2, gate, st);
+    if (g_opt_bm_exp == 6) return bm_launch_search<PAIR, 4, 6>(h, grid, ntp, tile_log2, gate, st);
+    if (g_opt_bm_exp == 7) return bm_launch_search<PAIR, 4, 7>(h, grid, ntp, tile_log2, gate, st);
+    if (g_opt_bm_u == 2) return bm_launch_search<PAIR, 2>(h, grid, ntp, tile_log2, gate, st);
+    if (g_opt_bm_u == 8) return bm_launch_search<PAIR, 8>(h, grid, ntp, tile_log2, gate, st);
+    return bm_launch_search<PAIR, 4>(h, grid, ntp, tile_log2, gate, st);
 }
 
 template <int THREADS, int ITEMS>
 static int bm_launch_unpermute(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t ntiles, int32_t *counts,
-                               unsigned long long *slots, hipStream_t st)
+                               unsigned long long *slots, const unsigned *gate, hipStream_t st)
 {
     const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);
     BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS>), lds));
     hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)ntiles), dim3(THREADS), lds, st, h->bm_recs.as<unsigned>(),
-                       h->bm_slots.as<unsigned short>(), nq, counts, slots, index_dev(h), h->e_sorted.as<int32_t>(), h->bm_geom, qs, qe);
+                       h->bm_slots.as<unsigned short>(), nq, counts, slots, index_dev(h), h->e_sorted.as<int32_t>(), h->bm_geom, qs, qe, gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
-// tile sort -> run table + plan -> search -> un-permute, all on `st`; counts must not be NULL
+// sorted check -> tile sort -> run table + plan -> search -> un-permute (or, sorted batch: the one-pass local kernel),
+// all on `st`; counts must not be NULL
 static int ivl_count_bitmap(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total_dev, hipStream_t st)
 {
     if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
-    const int variant = (int)g_opt_bm_variant;
+    // tile shape: 32768-query tiles halve the number of (tile, bucket) runs the search has to fetch, but their sort
+    // kernel runs one workgroup per CU and wants a grid of several hundred tiles
+    const int variant = g_opt_bm_variant >= 0 ? (int)g_opt_bm_variant : (nq >= ((int64_t)32 << 20) ? 2 : 0);
     const int tile_log2 = variant == 2 ? 15 : 14;
     const int64_t tile = (int64_t)1 << tile_log2;
     const int64_t ntiles = div_up(nq, tile);
@@ -2448,33 +2481,44 @@ static int ivl_count_bitmap(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, i
     BXMI_TRY(h->bm_grpcnt.reserve((size_t)ngroups * BM_NB * 4));
     BXMI_TRY(h->bm_items.reserve((size_t)(BM_NB + 2 * (nq / BM_CHUNK) + 4) * sizeof(int4)));  // [0] = the item count, items from [1]
     BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOT_STRIDE * sizeof(unsigned long long)));
+    // [PT_SLOTS partial totals][flag: 1 = the starts are NOT sorted], zeroed together
     unsigned long long *slots = h->p_slots.as<unsigned long long>();
-    if (total_dev) BXMI_HIP(hipMemsetAsync(slots, 0, PT_SLOTS * sizeof(unsigned long long), st));
+    unsigned *unsorted = g_opt_sorted_path ? reinterpret_cast<unsigned *>(slots + PT_SLOTS) : nullptr;
+    BXMI_HIP(hipMemsetAsync(slots, 0, PT_SLOT_STRIDE * sizeof(unsigned long long), st));
+    unsigned long long *tslots = total_dev ? slots : nullptr;
+    if (unsorted) {
+        hipLaunchKernelGGL(bm_sorted_check_kernel, dim3(2048), dim3(256), 0, st, qs, nq, unsorted);
+        // sorted batch: one pass over the queries as they lie (exits at once otherwise)
+        TreeDev S = h->treeS.dev, E = h->treeE.dev;
+        S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
+        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
+                           h->e_sorted.as<int32_t>(), qs, qe, nq, counts, tslots, unsorted);
+        BXMI_LAUNCH_CHECK();
+    }
     if (variant == 2)
-        BXMI_TRY((bm_launch_tiles<1024, 32>(h, qs, qe, nq, ntiles, st)));
+        BXMI_TRY((bm_launch_tiles<1024, 32>(h, qs, qe, nq, ntiles, unsorted, st)));
     else if (variant == 1)
-        BXMI_TRY((bm_launch_tiles<1024, 16>(h, qs, qe, nq, ntiles, st)));
+        BXMI_TRY((bm_launch_tiles<1024, 16>(h, qs, qe, nq, ntiles, unsorted, st)));
     else
-        BXMI_TRY((bm_launch_tiles<512, 32>(h, qs, qe, nq, ntiles, st)));
+        BXMI_TRY((bm_launch_tiles<512, 32>(h, qs, qe, nq, ntiles, unsorted, st)));
     hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), ntiles, nq, tile_log2,
-                       h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>());
+                       h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
     if (pair)
         hipLaunchKernelGGL(bm_plan_kernel<1>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, ntiles, chunk,
-                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>());
+                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     else
         hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, ntiles, chunk,
-                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>());
+                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     BXMI_LAUNCH_CHECK();
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
     if (pair)
-        BXMI_TRY(bm_launch_search_u<true>(h, sgrid, ntp, tile_log2, st));
+        BXMI_TRY(bm_launch_search_u<true>(h, sgrid, ntp, tile_log2, unsorted, st));
     else
-        BXMI_TRY(bm_launch_search_u<false>(h, sgrid, ntp, tile_log2, st));
-    unsigned long long *tslots = total_dev ? slots : nullptr;
+        BXMI_TRY(bm_launch_search_u<false>(h, sgrid, ntp, tile_log2, unsorted, st));
     if (variant == 2)
-        BXMI_TRY((bm_launch_unpermute<1024, 32>(h, qs, qe, nq, ntiles, counts, tslots, st)));
+        BXMI_TRY((bm_launch_unpermute<1024, 32>(h, qs, qe, nq, ntiles, counts, tslots, unsorted, st)));
     else
-        BXMI_TRY((bm_launch_unpermute<1024, 16>(h, qs, qe, nq, ntiles, counts, tslots, st)));
+        BXMI_TRY((bm_launch_unpermute<1024, 16>(h, qs, qe, nq, ntiles, counts, tslots, unsorted, st)));
     if (total_dev) {
         hipLaunchKernelGGL(part_fold_total_kernel, dim3(1), dim3(64), 0, st, slots, reinterpret_cast<unsigned long long *>(total_dev));
         BXMI_LAUNCH_CHECK();

@@ -35,8 +35,8 @@ def set_opt(key, value):
     _ffi.call("bxmi_set_option", key.encode(), int(value))
 
 
-DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": 0, "ivl.bm_u": 4,
-                "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 0}
+DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
+                "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 0, "ivl.bm_exp": 0}
 
 
 def reset_opts():
@@ -208,7 +208,10 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
     want_c, want_t = t.count_batch(qs, qe)
     set_opt("ivl.partition", 1)
     try:
+        loc_c, loc_t = ix.count(qs, qe)  # the order check of the bitmap-cell pass hands a sorted batch to the local kernel
+        set_opt("ivl.sorted_path", 0)
         bm_c, bm_t = ix.count(qs, qe)  # bitmap-cell pass (where the index qualifies): long runs, one bucket per tile
+        set_opt("ivl.sorted_path", 1)
         set_opt("ivl.bitmap", 0)
         got_c, got_t = ix.count(qs, qe)
         tot_only = ix.count(qs, qe, want_counts=False)[1]
@@ -225,6 +228,7 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
         reset_opts()
     bad = np.nonzero(bm_c != want_c)[0]
     assert len(bad) == 0 and bm_t == want_t, ("bitmap pass", ix.bitmap_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
+    assert np.array_equal(loc_c, want_c) and loc_t == want_t, "sorted batch behind the bitmap pass's order check"
     bad = np.nonzero(got_c != want_c)[0]
     assert len(bad) == 0, ("sorted path", bad[:5], qs[bad[:5]], qe[bad[:5]], got_c[bad[:5]], want_c[bad[:5]])
     assert got_t == want_t == tot_only
@@ -384,15 +388,18 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape):
     ix = make_index(IntervalIndex, s, e)
     set_opt("ivl.partition", 1)
     try:
-        for variant, u, pair in ((0, 4, 0), (1, 2, 1), (2, 8, 0), (0, 4, 1)):
+        for k, (variant, u, pair, pipe) in enumerate(((0, 4, 0, 0), (1, 2, 1, 0), (2, 8, 0, 0), (0, 4, 1, 0), (0, 2, 0, 1), (0, 4, 0, 1), (2, 2, 1, 1),
+                                                      (1, 4, 1, 1), (-1, 2, 1, 1))):
+            set_opt("ivl.sorted_path", k % 2)  # off: a sorted batch goes through the exchange too (long runs, one bucket per tile)
             set_opt("ivl.bm_variant", variant)
             set_opt("ivl.bm_u", u)
             set_opt("ivl.bm_pair", pair)  # one bucket per search workgroup, or two neighbours
+            set_opt("ivl.bm_pipe", pipe)  # the software-pipelined search kernel
             got, got_total = ix.count(qs, qe)
             state = ix.bitmap_state()
             assert state[0] == 1, state
             bad = np.nonzero(got != want)[0]
-            assert len(bad) == 0, (shape, variant, u, pair, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+            assert len(bad) == 0, (shape, variant, u, pair, pipe, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
             assert got_total == want_total
         if shape == "dups":
             assert state[1] > 0  # the pile made hard cells

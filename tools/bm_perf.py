@@ -51,8 +51,8 @@ def timed(qs, qe, out):
 
 
 ORDERS = os.environ.get("ORDERS", "generated,sorted").split(",")
-# variant:u:pair
-CONFIGS = [tuple(int(x) for x in c.split(":")) for c in os.environ.get("CONFIGS", "0:4:0,0:4:1,0:2:1,0:8:1,1:4:1,2:4:1").split(",")]
+# variant:u:pair:pipe
+CONFIGS = [tuple(int(x) for x in c.split(":")) for c in os.environ.get("CONFIGS", "-1:2:1:1,0:2:1:1,2:2:1:1,2:4:1:1,0:4:0:0").split(",")]
 EXP_PAIR = int(os.environ.get("EXP_PAIR", "1"))
 EXPS = [int(x) for x in os.environ.get("EXPS", "").split(",") if x]
 for order in ORDERS:
@@ -73,22 +73,25 @@ for order in ORDERS:
         opt("ivl.bm_exp", exp)
         print(json.dumps(dict(order=order, path="bitmap", exp=exp, ms=round(timed(qs, qe, counts), 4))), flush=True)
     opt("ivl.bm_exp", 0)
-    for variant, u, pair in CONFIGS:
+    for variant, u, pair, pipe in CONFIGS:
         if True:
             opt("ivl.bm_variant", variant)
             opt("ivl.bm_u", u)
             opt("ivl.bm_pair", pair)
+            opt("ivl.bm_pipe", pipe & 1)
+            opt("ivl.bm_nt", pipe >> 1)
             ms = timed(qs, qe, counts)
             run(qs, qe, counts)
             torch.cuda.synchronize()
             same = bool(torch.equal(counts, ref)) and int(total.item()) == want_total
-            print(json.dumps(dict(order=order, path="bitmap", variant=variant, u=u, pair=pair, ms=round(ms, 4), same_as_bucketed=same,
+            print(json.dumps(dict(order=order, path="bitmap", variant=variant, u=u, pair=pair, pipe=pipe, ms=round(ms, 4), same_as_bucketed=same,
                                   state=ix.bitmap_state())), flush=True)
             if not same:
                 bad = torch.nonzero(counts != ref).flatten()
                 print(json.dumps(dict(mismatches=int(bad.numel()), first=bad[:8].tolist(), got=counts[bad[:8]].tolist(),
                                       want=ref[bad[:8]].tolist(), qs=qs[bad[:8]].tolist(), qe=qe[bad[:8]].tolist())), flush=True)
-    opt("ivl.bm_variant", 0)
-    opt("ivl.bm_u", 4)
-    opt("ivl.bm_pair", 0)
+    opt("ivl.bm_variant", -1)
+    opt("ivl.bm_u", 2)
+    opt("ivl.bm_pair", 1)
+    opt("ivl.bm_pipe", 1)
     del qs, qe
