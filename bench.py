@@ -269,6 +269,136 @@ def bench_find(torch, reps=3):
     return out
 
 
+def genome_golden_check(chrom, counts_np, golden):
+    """Owner-side parity of one chromosome: the strided subsample against the reference treap's hash (tests/golden/scale.json)."""
+    pt = golden["chroms"].get(chrom) if golden else None
+    if not pt:
+        return None
+    sub = np.ascontiguousarray(counts_np[:: golden["stride"]])
+    return hashlib.sha256(sub.tobytes()).hexdigest() == pt["counts_sha256"] and int(sub.sum(dtype=np.int64)) == pt["total"]
+
+
+def bench_genome(torch, dist, rank, world, steps, warmup, n_targets, n_queries, single_gpu_reference=True):
+    """BASELINE configs[3]: the 24 hg19 chromosomes (synth.cfg4: 10M targets x 100M queries spread by length), one
+    interval index per chromosome, chromosomes dealt to the ranks by LPT (bxmi.shard), every rank counts its own
+    chromosomes, the 24 per-chromosome totals are all-reduced (int64, RCCL).  STRONG scaling: the whole job is the
+    same genome whatever the number of GPUs; the time of a step is the slowest rank's.  Returns a dict (rank 0) or None."""
+    from bxmi import shard, synth
+    from bxmi.intervals import IntervalIndex
+
+    chroms = list(synth.HG19_SIZES)
+    tsz, qsz = synth.cfg4_sizes(n_targets), synth.cfg4_sizes(n_queries)
+    weights = {c: tsz[c] + qsz[c] for c in chroms}
+    assign = shard.lpt_assign(weights, world)
+    golden = None
+    gpath = os.path.join(ROOT, "tests", "golden", "scale.json")
+    if n_targets == 10_000_000 and n_queries == 100_000_000 and os.path.exists(gpath):
+        golden = json.load(open(gpath)).get("cfg4_genome")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    class Shard:
+        def __init__(self, owned):
+            self.owned = owned
+            self.ix, self.q, self.counts = {}, {}, {}
+            for c in owned:
+                (ts, te), (qs, qe) = synth.cfg4_chrom(c, n_targets, n_queries)
+                ix = IntervalIndex()
+                ix.append(ts, te)
+                ix.seal()
+                self.ix[c] = ix
+                self.q[c] = (torch.from_numpy(qs).cuda(), torch.from_numpy(qe).cuda())
+                self.counts[c] = torch.empty(len(qs), dtype=torch.int32, device="cuda")
+
+        def step(self, row):
+            for c in self.owned:
+                qs, qe = self.q[c]
+                self.ix[c].count_dev(qs.data_ptr(), qe.data_ptr(), qs.numel(), self.counts[c].data_ptr(), row[chroms.index(c):].data_ptr(), stream)
+
+    def timed(sh, k_steps, k_warm, collective):
+        rows = torch.zeros((k_steps + k_warm + 1, len(chroms)), dtype=torch.int64, device="cuda")
+        for k in range(k_warm):
+            sh.step(rows[k])
+            if collective:
+                dist.all_reduce(rows[k])
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k_steps)]
+        if collective:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(k_steps):
+            ev[k][0].record()
+            sh.step(rows[k_warm + k])
+            ev[k][1].record()
+            if collective:
+                dist.all_reduce(rows[k_warm + k])  # RCCL over xGMI: 24 x int64, the path's only collective
+        torch.cuda.synchronize()
+        if collective:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return elapsed, kernel_ms, rows[k_warm:k_warm + k_steps]
+
+    t0 = time.perf_counter()
+    mine = Shard(assign[rank])
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    collective = world > 1
+    elapsed, kernel_ms, rows = timed(mine, steps, warmup, collective)
+    if collective:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0].item()), float(t[1].item())
+    # parity on what was just measured: owner-side golden hashes, and the reduced totals against the owners' counts
+    ok_hash, ok_sum = [], []
+    own_tot = torch.zeros(len(chroms), dtype=torch.int64, device="cuda")
+    for c in mine.owned:
+        cn = mine.counts[c].cpu().numpy()
+        g = genome_golden_check(c, cn, golden)
+        if g is not None:
+            ok_hash.append(bool(g))
+        own_tot[chroms.index(c)] = int(cn.sum(dtype=np.int64))
+    if collective:
+        dist.all_reduce(own_tot)
+    same_every_step = bool((rows == own_tot.unsqueeze(0)).all().item())
+    flags = torch.tensor([int(all(ok_hash)) if ok_hash else 1, int(same_every_step), len(ok_hash)], dtype=torch.int64, device="cuda")
+    if collective:
+        red = flags.clone()
+        dist.all_reduce(red, op=dist.ReduceOp.MIN)
+        cnt = flags[2:].clone()
+        dist.all_reduce(cnt)
+        flags = torch.tensor([int(red[0]), int(red[1]), int(cnt[0])], device="cuda")
+    total_q = sum(qsz.values())
+    value = total_q * steps / elapsed / 1e6
+    out = None
+    if rank == 0:
+        loads = [sum(weights[c] for c in part) for part in assign]
+        out = dict(
+            workload="configs[3]: 24 hg19 chromosomes, synth.cfg4 (%d targets x %d queries spread by chromosome length, len U[1,1000], seeds (401,i)/(402,i)); "
+                     "one index per chromosome, chromosomes dealt to the ranks by LPT, per-chromosome int64 totals all-reduced" % (sum(tsz.values()), total_q),
+            value=round(value, 2), unit="M queries/s", n_gpus=world, scaling="strong", ms_per_step=round(elapsed / steps * 1e3, 4),
+            kernel_ms_slowest_rank=round(kernel_ms, 4),
+            roofline_frac=round(alg_bytes_of(total_q, sum(tsz.values())) / (kernel_ms * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+            lpt=dict(balance_max_over_mean=round(shard.balance(weights, assign), 4), speedup_bound=round(world / shard.balance(weights, assign), 3),
+                     heaviest_rank_intervals=max(loads), chromosomes_per_rank=[len(p) for p in assign]),
+            collective=("all_reduce(int64[24]) per step, backend %s" % dist.get_backend()) if collective else "none (one rank)",
+            parity=dict(golden_subsample_hashes_ok=bool(flags[0].item()), chromosomes_hashed=int(flags[2].item()),
+                        reduced_totals_equal_sum_of_owner_counts_every_step=bool(flags[1].item()),
+                        overlaps_per_step=int(own_tot.sum().item())),
+            build_s=round(build_s, 2))
+    # the same genome on ONE GPU, in the same run (rank 0 alone; the others wait): what the speed-up is measured against
+    if collective and single_gpu_reference:
+        if rank == 0:
+            rest = Shard([c for c in chroms if c not in assign[0]])
+            rest.owned = chroms
+            for d in ("ix", "q", "counts"):
+                getattr(rest, d).update(getattr(mine, d))
+            e1, k1, _ = timed(rest, steps, warmup, False)
+            out["single_gpu_same_run"] = dict(value=round(total_q * steps / e1 / 1e6, 2), ms_per_step=round(e1 / steps * 1e3, 4), kernel_ms=round(k1, 4))
+            out["speedup_vs_1gpu"] = round(value / out["single_gpu_same_run"]["value"], 3)
+        dist.barrier()
+    return out
+
+
 def alg_bytes_of(nq, nt):
     """8 B in + 4 B out per query, the sorted starts + ends read once."""
     return nq * 12 + nt * 8
@@ -288,6 +418,12 @@ def main():
     ap.add_argument("--no-sorted", action="store_true", help="skip the sorted-queries side measurement (profiling runs: its launches "
                     "dismiss the bucketed kernels at once and would halve their average durations)")
     ap.add_argument("--allreduce-total", type=int, default=1, help="all-reduce the int64 overlap total each step when --gpus > 1")
+    ap.add_argument("--workload", choices=["auto", "count", "genome"], default="auto",
+                    help="count = configs[1] (100M x 10M, one chromosome); genome = configs[3] (24 chromosomes sharded by LPT, strong scaling); "
+                         "auto = count on one GPU (with the genome as a side measurement), genome on several")
+    ap.add_argument("--weak", action="store_true", help="with --workload count on several GPUs: every rank its own 100M queries against a replica "
+                    "of the index (weak scaling, round 1's multi-GPU mode)")
+    ap.add_argument("--no-genome", action="store_true", help="skip the configs[3] side measurement of the one-GPU line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -309,6 +445,41 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    workload = args.workload if args.workload != "auto" else ("count" if world == 1 else "genome")
+    if workload == "count" and world > 1 and not args.weak:
+        log("note: --workload count on %d GPUs is the weak-scaling mode (every rank its own 100M queries); say --weak to silence this" % world)
+    if workload == "genome":
+        g = bench_genome(torch, dist, rank, world, args.steps, args.warmup, args.targets, args.queries)
+        if rank == 0:
+            name = _ffi.C.create_string_buffer(128)
+            _ffi.call("bxmi_device_info", local_rank, name, 128, None, None)
+            total_q = sum(synth.cfg4_sizes(args.queries).values())
+            alg = alg_bytes_of(total_q, sum(synth.cfg4_sizes(args.targets).values()))
+            achieved = alg / (g["kernel_ms_slowest_rank"] * 1e-3) / 1e9
+            line = {
+                "metric": "M overlap-queries/s, whole-genome intersect: 24 chromosomes, 100M x 10M intervals (count-only)",
+                "value": g["value"], "unit": "M queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": g["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32",
+                "data": "synthetic",
+                "config": {"workload": g["workload"], "sharding": "chromosomes dealt to the ranks by LPT (largest first, to the least loaded rank); "
+                           "no data-path collective, per-chromosome int64 totals all-reduced (RCCL) every step", "lpt": g["lpt"]},
+                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                             "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None,
+                             "kernel": "per chromosome: the count pass of bxmi_ivl_count_dev (bitmap-cell pass for batches >= 2 Mi queries, "
+                                       "ivl_count_kernel below); slowest rank", "kernel_ms": g["kernel_ms_slowest_rank"],
+                             "algorithmic_bytes_per_launch": alg, "peak_note": "n_gpus x 8 TB/s",
+                             "timed_with": "HIP events on the launch stream around every rank's chromosomes; the slowest rank's mean"},
+                "collective": g["collective"], "parity": g["parity"], "index_build_s": g["build_s"], "device": name.value.decode(),
+            }
+            for k in ("single_gpu_same_run", "speedup_vs_1gpu"):
+                if k in g:
+                    line[k] = g[k]
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     (ts, te), _ = synth.cfg2(args.targets, 1)
     baseline = None
@@ -413,7 +584,7 @@ def main():
         same = int(scounts.sum(dtype=torch.int64).item()) == local_total
         sorted_q = dict(value=round(nq / s_ms / 1e3, 1), unit="M queries/s", ms_per_pass=round(s_ms, 4),
                         frac_of_hbm_peak=round(alg_bytes_of(nq, args.targets) / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        same_total_as_unsorted=bool(same), kernel="part_hist (detects the order) + ivl_local_count_kernel")
+                        same_total_as_unsorted=bool(same), kernel="bm_sorted_check (detects the order) + ivl_local_count_kernel")
         del sqs, sqe, scounts
 
     if rank != 0:
@@ -426,7 +597,7 @@ def main():
     value = world * nq * args.steps / elapsed / 1e6
     alg_bytes = alg_bytes_of(nq, args.targets)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    partitioned = nq >= (4 << 20)  # libbxmi's default switch-over to the bucketed large-batch path
+    partitioned = nq >= (2 << 20)  # libbxmi's default switch-over to the large-batch (bitmap-cell) pass
     name = _ffi.C.create_string_buffer(128)
     cus = _ffi.C.c_int(0)
     _ffi.call("bxmi_device_info", local_rank, name, 128, _ffi.C.byref(cus), None)
@@ -452,8 +623,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
-            "kernel": ("count pass = part_hist + column scan + part_scatter + part_count_cells + part_gather (dominant: part_scatter_kernel)"
-                       if partitioned else "ivl_count_kernel"),
+            "kernel": ("count pass = bm_sorted_check + bm_tile_sort + bm_transpose + bm_plan + bm_search_pipe + bm_unpermute "
+                       "(dominant: bm_search_pipe_kernel)" if partitioned else "ivl_count_kernel"),
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
             "timed_with": "HIP events on the launch stream around every bxmi_ivl_count_dev call of the timed region",
         },
@@ -492,6 +663,12 @@ def main():
             line["find_csr"] = bench_find(torch)
         except Exception as ex:
             line["find_csr"] = {"error": repr(ex)}
+    if world == 1 and not args.no_genome:
+        try:
+            torch.cuda.empty_cache()
+            line["genome"] = bench_genome(torch, dist, 0, 1, max(5, args.steps), args.warmup, args.targets, args.queries)
+        except Exception as ex:
+            line["genome"] = {"error": repr(ex)}
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -66,11 +66,13 @@ def gather_concat(arr, rank_order_key=None):
     return np.concatenate(parts) if parts else a
 
 
-def count_genome(targets, queries, rank=0, world=1, device=None, counter=None):
+def count_genome(targets, queries, rank=0, world=1, device=None, counter=None, weights=None):
     """Whole-genome overlap count, sharded by chromosome.
 
     targets / queries: {chrom: (start int32[], end int32[])}.  `counter(ts, te, qs, qe) -> (counts, total)`
     defaults to the MI355X engine (IntervalIndex.count); tests inject a stand-in.
+    `weights` ({chrom: cost}) overrides the default cost targets + queries -- a rank that generated only its own
+    chromosomes passes the planned sizes so that every rank deals the chromosomes identically.
     Returns ({chrom: total overlaps}, {chrom: per-query int32 counts} for the chromosomes this rank owns)."""
     if counter is None:
         from .intervals import IntervalIndex
@@ -83,8 +85,9 @@ def count_genome(targets, queries, rank=0, world=1, device=None, counter=None):
             return out
 
     chroms = [c for c in queries if c in targets]
-    weights = {c: len(targets[c][0]) + len(queries[c][0]) for c in chroms}
-    mine = lpt_assign(weights, world)[rank]
+    if weights is None:
+        weights = {c: len(targets[c][0]) + len(queries[c][0]) for c in chroms}
+    mine = lpt_assign({c: weights[c] for c in chroms}, world)[rank]
     totals, per_query = {}, {}
     for c in mine:
         counts, total = counter(targets[c][0], targets[c][1], queries[c][0], queries[c][1])

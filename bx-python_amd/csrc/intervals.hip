@@ -2043,6 +2043,7 @@ constexpr int PT_SLOT_STRIDE = PT_SLOTS + 8;  // per sub-batch: the partial tota
 static int64_t g_opt_count_cells = 1;  // 1 = direct-addressed cells in the bucket search, 0 = LDS search trees
 static int64_t g_opt_sorted_path = 1;  // 1 = batches whose starts are already sorted skip the bucketing (detected on the device)
 static int64_t g_opt_bitmap = -1;      // second-generation count pass (count_bitmap.hpp): -1 = when the index qualifies, 0 = never, 1 = same as -1
+static int64_t g_opt_bitmap_min = 2 << 20;  // auto: batches of at least this many queries take it (when the index qualifies)
 static int64_t g_opt_bm_variant = -1;  // tile kernel shape: -1 = by batch size, 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
 static int64_t g_opt_bm_u = 2;         // tile runs in flight per 8-lane group of the search kernel (2, 4 or 8)
 static int64_t g_opt_bm_pair = 1;      // 1 = a search workgroup holds two neighbouring buckets (one workgroup per CU, runs twice as long)
@@ -2079,6 +2080,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.partition_min")) {
         g_opt_partition_min = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bitmap_min")) {
+        g_opt_bitmap_min = value;
         return 1;
     }
     if (!strcmp(key, "ivl.bitmap")) {
@@ -2757,7 +2762,10 @@ extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_
     hipStream_t st = as_stream(stream);
     const bool partition = !h->has_reversed && h->n > 0 &&
                            (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_partition_min && h->n >= 4096));
-    if (partition && counts && g_opt_bitmap != 0) {
+    // the bitmap-cell pass pays off earlier than the bucketed one (its fixed cost is one read of the bucket images)
+    const bool bitmap = counts && g_opt_bitmap != 0 && !h->has_reversed && h->n >= 4096 &&
+                        (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_bitmap_min));
+    if (bitmap) {
         if (h->bm_state == 0) BXMI_TRY(bm_prepare_index(h, st));
         if (h->bm_state == 1) return ivl_count_bitmap(h, qs, qe, nq, counts, total_dev, st);
     }

@@ -43,6 +43,11 @@ def golden_scale():
     return load_golden("scale.json")["points"]
 
 
+@pytest.fixture(scope="session")
+def golden_scale_doc():
+    return load_golden("scale.json")
+
+
 def has_gpu():
     try:
         import torch

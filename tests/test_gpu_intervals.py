@@ -530,6 +530,84 @@ def test_genome_sharded_count_single_rank():
         assert totals[chrom] == int(want.sum())
 
 
+def test_genome_cfg4_full_size_golden(golden_scale_doc, IntervalIndex):
+    """BASELINE configs[3] at full size on one GPU: synth.cfg4 (24 chromosomes, 10M targets x 100M queries by chromosome
+    length), one index per chromosome.  Every 100th count of every chromosome against the reference treap's hash
+    (tests/golden/scale.json "cfg4_genome", made by oracle/gen_golden.py --only genome), totals = sums."""
+    g = golden_scale_doc.get("cfg4_genome")
+    assert g, "tests/golden/scale.json lacks cfg4_genome"
+    paths = set()
+    grand = 0
+    for chrom, pt in g["chroms"].items():
+        (ts, te), (qs, qe) = synth.cfg4_chrom(chrom)
+        assert len(ts) == pt["n_targets"] and len(qs) == pt["n_queries_total"]
+        ix = make_index(IntervalIndex, ts, te)
+        counts, total = ix.count(qs, qe)
+        assert total == int(counts.sum(dtype=np.int64)), chrom
+        sub = np.ascontiguousarray(counts[:: g["stride"]])
+        assert int(sub.sum(dtype=np.int64)) == pt["total"], chrom
+        assert hashlib.sha256(sub.tobytes()).hexdigest() == pt["counts_sha256"], chrom
+        paths.add(ix.bitmap_state()[0])
+        grand += total
+        ix.close()
+    assert paths == {0, 1}  # big chromosomes through the bitmap-cell pass, small ones (< 2 Mi queries) through the direct kernel
+    assert grand > 0
+
+
+GENOME_WORKER = r"""
+import os, sys, json, hashlib
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "bx-python_amd"))
+import numpy as np, torch, torch.distributed as dist
+from bxmi import shard, synth, _ffi
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")     # the collective of this test; both ranks drive the SAME GPU through libbxmi
+_ffi.call("bxmi_set_device", 0)
+scale = int(sys.argv[2])
+g = json.load(open(os.path.join(sys.argv[1], "tests", "golden", "scale.json")))["cfg4_genome"]
+chroms = list(synth.HG19_SIZES)
+weights = {c: synth.cfg4_sizes(10_000_000 // scale)[c] + synth.cfg4_sizes(100_000_000 // scale)[c] for c in chroms}
+mine = shard.lpt_assign(weights, world)[rank]
+tg = {c: synth.cfg4_chrom(c, 10_000_000 // scale, 100_000_000 // scale)[0] for c in mine}
+qr = {c: synth.cfg4_chrom(c, 10_000_000 // scale, 100_000_000 // scale)[1] for c in mine}
+# every rank passes only what it owns; count_genome deals by the same LPT rule, so ownership must agree
+tg_all = {c: tg.get(c, (np.zeros(0, np.int32),) * 2) for c in chroms}
+qr_all = {c: qr.get(c, (np.zeros(0, np.int32),) * 2) for c in chroms}
+totals, per_query = shard.count_genome(tg_all, qr_all, rank, world, weights=weights)
+assert sorted(per_query) == sorted(mine)
+for c in mine:
+    ts, te = tg[c]; qs, qe = qr[c]
+    want = (np.searchsorted(np.sort(ts), qe, "left") - np.searchsorted(np.sort(te), qs, "right")).astype(np.int32)   # proper intervals
+    assert np.array_equal(per_query[c], want), c
+    if scale == 1:
+        sub = np.ascontiguousarray(per_query[c][:: g["stride"]])
+        assert hashlib.sha256(sub.tobytes()).hexdigest() == g["chroms"][c]["counts_sha256"], c
+# the reduced vector holds every chromosome's total on every rank
+obj = [None] * world
+dist.all_gather_object(obj, {c: int(per_query[c].sum(dtype=np.int64)) for c in mine})
+full = {}
+for d in obj: full.update(d)
+assert totals == {c: full[c] for c in chroms}, (rank, totals, full)
+dist.barrier(); dist.destroy_process_group()
+sys.stdout.write("rank%d-ok %d chromosomes %d overlaps\n" % (rank, len(mine), sum(totals.values())))
+"""
+
+
+def test_genome_two_ranks_real_engine(tmp_path):
+    """configs[3]'s multi-GPU shape with the REAL engine: two processes (world size 2, gloo all-reduce), both on cuda:0,
+    each builds and queries the chromosomes LPT deals it (1/4 of the full genome size), totals reduced across ranks."""
+    import subprocess
+    import sys as _sys
+
+    script = tmp_path / "genome_worker.py"
+    script.write_text(GENOME_WORKER)
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           str(script), root, "4"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "rank0-ok" in p.stdout and "rank1-ok" in p.stdout, p.stdout[-2000:]
+
+
 def test_find_join_scale_properties(IntervalIndex):
     """configs[4] shape at 4M x 4M (the 50M x 50M run is tools/bench_find.py): CSR consistency, every hit overlaps,
     hits of a query in tree order, and agreement with the count path."""
