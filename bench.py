@@ -399,6 +399,19 @@ def bench_genome(torch, dist, rank, world, steps, warmup, n_targets, n_queries, 
     return out
 
 
+def source_stamps():
+    """Hashes that tie a profile to the code it measured: sha256 of bench.py and of the kernel sources, first 16 hex digits."""
+    def sha(paths):
+        h = hashlib.sha256()
+        for q in paths:
+            h.update(open(q, "rb").read())
+        return h.hexdigest()[:16]
+
+    csrc = os.path.join(ROOT, "bx-python_amd", "csrc")
+    kernels = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".cpp")))
+    return dict(bench_sha16=sha([os.path.join(ROOT, "bench.py")]), kernel_sha16=sha(kernels + [os.path.join(ROOT, "include", "bxmi.h")]))
+
+
 def alg_bytes_of(nq, nt):
     """8 B in + 4 B out per query, the sorted starts + ends read once."""
     return nq * 12 + nt * 8
@@ -635,12 +648,24 @@ def main():
         "overlaps_per_step_rank0": local_total,
         "device": name.value.decode(),
     }
+    # HBM bytes per launch from the PMC counters: taken in their own rocprofv3 runs (tools/profile.sh), so this run can only
+    # quote them -- and only if they were taken on THIS code (the file carries the hashes of bench.py and the kernel sources)
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    line["roofline"]["traffic_source"] = "none: profiles/pmc_latest.json missing"
     if os.path.exists(pmc):
         try:
-            line["roofline"]["traffic"] = json.load(open(pmc)).get("count_pass", {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
+            doc = json.load(open(pmc))
+            have, want = doc.get("stamps", {}), source_stamps()
+            if all(have.get(k) == want[k] for k in want):
+                line["roofline"]["traffic"] = doc.get("count_pass", {}).get("hbm_bytes_per_launch")
+                line["roofline"]["traffic_source"] = ("profiles/pmc_latest.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` on %s, "
+                                                      "bench_sha16=%s kernel_sha16=%s head=%s" % (have.get("command"), have.get("date"), have.get("bench_sha16"),
+                                                                                                  have.get("kernel_sha16"), have.get("head")))
+            else:
+                line["roofline"]["traffic_source"] = "stale: profiles/pmc_latest.json was taken on other code (%s), not quoted" % ", ".join(
+                    "%s %s != %s" % (k, have.get(k), want[k]) for k in want if have.get(k) != want[k])
+        except Exception as ex:
+            line["roofline"]["traffic_source"] = "unreadable: %r" % ex
     if baseline is not None:
         res = baseline.measure(qs_h, qe_h, args.cpu_sample)
         if res is None:
@@ -649,6 +674,19 @@ def main():
             cb, ocounts = res
             cb["agrees_with_gpu"] = bool(np.array_equal(ocounts, counts[: args.cpu_sample].cpu().numpy()))
             cb["gpu_over_cpu"] = round(value / cb["value"], 1)
+            # the reference itself cannot run here, so its speed on THIS box's cores is the port's speed here
+            # divided by how much faster the port ran than the reference where both could be timed (oracle/gen_golden.py
+            # --only calibration: same machine, same 10M-target treap, same 1M queries, one thread)
+            try:
+                cal = json.load(open(golden_path)).get("calibration")
+                if cal:
+                    cb["port_over_reference"] = cal["port_over_reference"]
+                    cb["reference_equivalent_mq_per_s"] = round(cb["value"] / cal["port_over_reference"], 5)
+                    cb["x_reference"] = round(value / (cb["value"] / cal["port_over_reference"]), 1)
+                    cb["calibration"] = ("tests/golden/scale.json: reference IntervalTree.find %.5f Mq/s vs oracle/ivtree.c %.5f Mq/s on %s, 1 thread"
+                                         % (cal["reference_mq_per_s"], cal["port_mq_per_s"], cal["cpu"]))
+            except Exception as ex:
+                cb["calibration_error"] = repr(ex)
             line["cpu_baseline"] = cb
     if world == 1 and not args.no_bitset:
         try:

@@ -20,6 +20,7 @@ import operator
 import numpy as np
 
 from bx.bitset import _cint
+from bxmi._ffi import as_i32 as _ffi_as_i32
 from bxmi.intervals import IntervalIndex
 
 __all__ = ["Interval", "IntervalNode", "IntervalTree", "Intersecter"]
@@ -37,13 +38,17 @@ class Interval:
     Interval(34, 48, value={'chr': 12, 'anno': 'transposon'})
     """
 
-    __slots__ = ("start", "end", "value", "chrom", "strand")
+    __slots__ = ("_start", "_end", "value", "chrom", "strand")
+
+    # `cdef public int start, end` (intersection.pyx:276): every assignment is coerced to a C int, later ones too
+    start = property(lambda self: self._start, lambda self, v: setattr(self, "_start", _cint(v)))
+    end = property(lambda self: self._end, lambda self, v: setattr(self, "_end", _cint(v)))
 
     def __init__(self, start, end, value=None, chrom=None, strand=None):
         start, end = _cint(start), _cint(end)
         assert start <= end, "start must be less than end"
-        self.start = start
-        self.end = end
+        self._start = start
+        self._end = end
         self.value = value
         self.chrom = chrom
         self.strand = strand
@@ -318,8 +323,10 @@ class IntervalTree:
     def insert_batch(self, starts, ends, values=None):
         """insert(starts[i], ends[i], values[i]) for all i (values default to None)."""
         c = self._c()
-        s = np.asarray(starts).tolist()
-        e = np.asarray(ends).tolist()
+        s = _ffi_as_i32(starts).tolist()  # same range check as insert(): OverflowError beyond a C int
+        e = _ffi_as_i32(ends).tolist()
+        if len(s) != len(e) or (values is not None and len(values) != len(s)):
+            raise ValueError("insert_batch: starts, ends and values must have the same length")
         c.starts.extend(s)
         c.ends.extend(e)
         c.values.extend(values if values is not None else [None] * len(s))

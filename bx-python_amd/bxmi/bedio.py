@@ -21,16 +21,31 @@ def enabled():
 
 def file_bytes(f):
     """Remaining bytes of a text-mode file object opened on a real file, or None if `f` is something else
-    (stdin pipe wrappers, fileinput, lists of lines...)."""
+    (stdin pipe wrappers, fileinput, lists of lines...) or holds a carriage return anywhere: universal-newline
+    translation turns '\\r\\n' and lone '\\r' into '\\n' in what `for line in f` yields, which the byte-level fast path
+    could only imitate, so such files take the per-line path from the first line on (the file is rewound for it)."""
     buf = getattr(f, "buffer", None)
-    if buf is None or not hasattr(buf, "read") or getattr(f, "newlines", None) not in (None, "\n"):
+    if buf is None or not hasattr(buf, "read"):
         return None
     try:
         if f.tell() != 0:  # somebody already consumed text: the decoder may hold read-ahead
             return None
+        data = buf.read()
+        if b"\r" in data:
+            f.seek(0)
+            return None
     except (OSError, ValueError):
         return None
-    return buf.read()
+    return data
+
+
+def text_lines(f, data):
+    """What `for line in f` would yield for the bytes `data` of file object `f`: same codec, same error policy,
+    universal newlines (str.splitlines would also break at \\x0b, \\x0c, \\x1c-\\x1e, \\x85, \\u2028, \\u2029)."""
+    import io
+
+    return list(io.TextIOWrapper(io.BytesIO(data), encoding=getattr(f, "encoding", None) or "utf-8", errors=getattr(f, "errors", None) or "strict",
+                                 newline=None))
 
 
 class ParsedBed:
@@ -60,13 +75,14 @@ class ParsedBed:
         lib = _ffi.load()
         self.names = [lib.bxmi_bed_chrom_name(h, i).decode("ascii") for i in range(nc.value)]
 
-    def rest_lines(self, first_row=None):
+    def rest_lines(self, first_row=None, f=None):
         """Text lines (with line ends) from row `first_row` of the consumed prefix, or -- if None -- from
-        where the parser stopped; [] when everything was consumed."""
+        where the parser stopped; [] when everything was consumed.  `f` = the file object the bytes came from
+        (its codec and error policy decode the rest, as iterating it would have)."""
         off = int(self.line_off[first_row]) if first_row is not None else self.stop_off
         if off < 0:
             return []
-        return self.data[off:].decode("utf-8").splitlines(keepends=True)
+        return text_lines(f, self.data[off:])
 
     def emit(self, mask, suffix, fd):
         m = np.ascontiguousarray(mask, dtype=np.uint8)

@@ -88,7 +88,7 @@ class BitsetAccumulator:
                 keep = rows[e[rows] > s[rows]]
                 self.blocks[name].append((s[keep].astype(np.int32), (e[keep] - s[keep]).astype(np.int32)))
             self.last_chrom = None
-            return bed.rest_lines(k if k < bed.n else None)
+            return bed.rest_lines(k if k < bed.n else None, f)
         finally:
             bed.close()
 

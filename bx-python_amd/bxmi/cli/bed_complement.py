@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """
-Complement the regions of a bed file. Requires a file that maps source names
-to sizes. This should be in the simple LEN file format (each line contains
-a source name followed by a size, separated by whitespace).
+Print what a BED file leaves uncovered: for every chromosome named in the length table (whitespace-separated
+`name size` lines), the gaps between the file's regions.
 
 usage: %prog bed_file chrom_length_file
 """
@@ -14,12 +13,12 @@ from bxmi.builders import binned_bitsets_from_file, write_runs
 
 
 def read_len(f):
-    """'LEN' file -> {chromosome: length} (bed_complement.py:13-19)."""
-    mapping = {}
-    for line in f:
-        fields = line.split()
-        mapping[fields[0]] = int(fields[1])
-    return mapping
+    """Length table -> {chromosome: length}, in file order (what scripts/bed_complement.py:13-19 reads; a line with fewer
+    than two fields raises IndexError there and here)."""
+    table = {}
+    for fields in map(str.split, f):
+        table[fields[0]] = int(fields[1])
+    return table
 
 
 def main(argv=None, out=None):

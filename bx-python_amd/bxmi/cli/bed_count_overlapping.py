@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """
-For each interval in `bed1` count the number of intersecting regions in `bed2`.
+One number per line of `bed1`: how many regions of `bed2` it overlaps.
 
 usage: %prog bed1 bed2
 """

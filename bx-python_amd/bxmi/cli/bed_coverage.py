@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """
-Print number of bases covered by all intervals in a bed file (bases covered by
-more than one interval are counted only once). Multiple bed files can be
-provided on the command line or to stdin.
+Total bases covered by the BED input (files named on the command line, else stdin); a base under several
+intervals counts once.
 
 usage: %prog bed files ...
 """

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """
-For each interval in `bed1` print the fraction of bases covered by `bed2`.
+For every line of `bed1`, the covered fraction: bases of that interval that `bed2` touches, divided by its length.
 
 usage: %prog bed1 bed2 [mask]
 """

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """
-Given two bed files print the number of bases covered 1) by both, 2) only by
-the first, and 3) only by the second.
+Three base counts for a pair of BED files: covered by both, by the first only, by the second only.
 
 usage: %prog bed_file_1 bed_file_2
 """

@@ -1,9 +1,8 @@
 #!/usr/bin/env python
 """
-Find regions of first bed file that overlap regions in a second bed file. The
-output preserves all fields from the input.
+Echo the lines of the first BED file that overlap something in the second one, every column kept as it was.
 
-NOTE: -u and -d options are currently not functional!
+The padding options -u / -d are parsed and ignored, as in the script this mirrors.
 
 usage: %prog bed_file_1 bed_file_2
     -m, --mincols=N: Require this much overlap (default 1bp)
@@ -106,7 +105,7 @@ def _bulk_prefix(query, bitsets, mincols, reverse, booleans, out):
                     o = int(bed.line_off[i])
                     out.write(data[o:o + int(bed.line_len[i])].decode("utf-8") + " ")
         out.flush()
-        return bed.rest_lines(k if k < bed.n else None)
+        return bed.rest_lines(k if k < bed.n else None, query)
     finally:
         bed.close()
 

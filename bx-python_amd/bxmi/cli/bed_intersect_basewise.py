@@ -1,8 +1,6 @@
 #!/usr/bin/env python
 """
-Find regions of first bed file that overlap regions in a second bed file. This
-program performs a base-by-base intersection, so only runs of bases that are
-covered in both of the inputs will be output.
+Base-level AND of two BED files: prints each maximal stretch of bases that both inputs cover.
 
 usage: %prog bed_file_1 bed_file_2
 """

@@ -1,8 +1,7 @@
 #!/usr/bin/env python
 """
-Merge any overlapping regions of bed files. Bed files can be provided on the
-command line or on stdin. Merged regions are always reported on the '+'
-strand, and any fields beyond chrom/start/stop are lost.
+Union of BED input (command line or stdin): overlapping or touching regions come out as one, on the '+' strand,
+with only chrom / start / end kept.
 
 usage: %prog bed files ...
 """

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """
-Find continuous regions that are covered by the first bed file (`bed_file_1`)
-but not by the second bed file (`bed_file_2`)
+Base-level difference: the maximal stretches `bed_file_1` covers and `bed_file_2` does not.
 
 usage: %prog bed_file_1 bed_file_2
 """

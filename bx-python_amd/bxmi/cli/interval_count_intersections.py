@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """
-Read two lists of intervals (with chromosomes) and count the number of entries
-in the second set that intersect any entry in the first set.
+Two interval files with chromosome columns: counts how many entries of the second overlap at least one entry of the
+first.
 
 usage: %prog bed1 bed2 > out
 """

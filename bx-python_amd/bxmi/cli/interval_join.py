@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """
-Match up intersecting intervals from two files. This performs a "full join",
-any pair of intervals with any basewise overlap will be printed side-by-side.
+Side-by-side listing of every overlapping pair between two interval files (a full join on base overlap).
 
 usage: %prog bed1 bed2
 """

@@ -130,7 +130,7 @@ class IntervalIndex:
         if rc == _ffi.ERANGE:
             buf = self._one_buf = np.empty(int(n.value) * 2, dtype=np.int32)
             call("bxmi_ivl_find_one", self._h, int(qs), int(qe), ptr(buf), len(buf), C.byref(n))
-        return buf[: n.value]
+        return buf[: n.value].copy()  # the buffer is reused by the next call
 
     def count_dev(self, qs_ptr, qe_ptr, nq, counts_ptr, total_ptr, stream=None):
         """Device-pointer form used by bench.py / the sharded driver (no host sync)."""

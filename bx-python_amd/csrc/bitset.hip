@@ -198,11 +198,43 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_popcount_span_kernel(const 
 // iand / ior / invert (binBits.c:230-317) on the dense words
 // ---------------------------------------------------------------------------
 // OP: 0 = and, 1 = or, 2 = xor.  COUNT: also accumulate popcount of the result inside [0, size).
+// One launch per call of the drop-in classes (bed_intersect_basewise.py:25-28 does one iand per chromosome), so the
+// launch itself is most of the cost: the per-bin tags are updated by the LAST workgroup of the same launch instead of
+// a second kernel, a lane keeps four 16-byte loads per operand in flight, and the counting variants run at most one
+// workgroup per CU (their single atomic per workgroup serialises on one counter, ~12 ns each).
+constexpr int BITS_UNROLL = 4;
+
+__device__ __forceinline__ long long pair_popcount(ulonglong2 x, int64_t w, int64_t full_words, unsigned long long tail_mask)
+{
+    if (w + 1 < full_words) return __popcll(x.x) + __popcll(x.y);
+    long long c = w < full_words ? __popcll(x.x) : (w == full_words ? __popcll(x.x & tail_mask) : 0);
+    return c + ((w + 1) < full_words ? __popcll(x.y) : ((w + 1) == full_words ? __popcll(x.y & tail_mask) : 0));
+}
+
+__device__ __forceinline__ void tags_binary(int op, uint8_t *__restrict__ ta, const uint8_t *__restrict__ tb, int64_t nbins)
+{
+    for (int64_t i = threadIdx.x; i < nbins; i += BITS_THREADS) {
+        const uint8_t x = ta[i], y = tb[i];
+        if (op == 0) {                                 // binBitsAnd, binBits.c:237-256
+            if (x == TAG_ZERO) continue;
+            if (y == TAG_ZERO) ta[i] = TAG_ZERO;
+            else if (y == TAG_ONE) continue;
+            else if (x == TAG_ONE) ta[i] = TAG_DATA;   // clone of other
+        } else {                                       // binBitsOr, binBits.c:271-290
+            if (x == TAG_ONE) continue;
+            if (y == TAG_ONE) ta[i] = TAG_ONE;
+            else if (y == TAG_ZERO) continue;
+            else if (x == TAG_ZERO) ta[i] = TAG_DATA;  // clone of other
+        }
+    }
+}
+
 template <int OP, bool COUNT>
 __global__ __launch_bounds__(BITS_THREADS) void bits_binary_kernel(unsigned long long *__restrict__ a,
                                                                   const unsigned long long *__restrict__ b,
                                                                   int64_t npairs /* 16-byte pairs */, int64_t size_bits,
-                                                                  unsigned long long *__restrict__ acc)
+                                                                  unsigned long long *__restrict__ acc, uint8_t *__restrict__ ta,
+                                                                  const uint8_t *__restrict__ tb, int64_t nbins /* 0: no tags (flat set) */)
 {
     __shared__ long long red[BITS_THREADS / 64];
     ulonglong2 *va = reinterpret_cast<ulonglong2 *>(a);
@@ -210,30 +242,30 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_binary_kernel(unsigned long
     const int64_t full_words = size_bits >> 6;  // words entirely inside [0,size)
     const unsigned long long tail_mask = (size_bits & 63) ? ~(~0ull << (size_bits & 63)) : 0ull;
     long long c = 0;
-    int64_t nth = (int64_t)gridDim.x * BITS_THREADS;
-    for (int64_t p = (int64_t)blockIdx.x * BITS_THREADS + threadIdx.x; p < npairs; p += nth) {
-        ulonglong2 x = va[p], y = vb[p];
-        if (OP == 0) {
-            x.x &= y.x;
-            x.y &= y.y;
-        } else if (OP == 1) {
-            x.x |= y.x;
-            x.y |= y.y;
-        } else {
-            x.x ^= y.x;
-            x.y ^= y.y;
-        }
-        va[p] = x;
-        if (COUNT) {
-            int64_t w = p * 2;
-            if (w + 1 < full_words) {
-                c += __popcll(x.x) + __popcll(x.y);
-            } else {
-                c += w < full_words ? __popcll(x.x) : (w == full_words ? __popcll(x.x & tail_mask) : 0);
-                c += (w + 1) < full_words ? __popcll(x.y) : ((w + 1) == full_words ? __popcll(x.y & tail_mask) : 0);
-            }
+    const int64_t nth = (int64_t)gridDim.x * BITS_THREADS;
+    int64_t p = (int64_t)blockIdx.x * BITS_THREADS + threadIdx.x;
+    for (; p + (BITS_UNROLL - 1) * nth < npairs; p += BITS_UNROLL * nth) {
+        ulonglong2 x[BITS_UNROLL], y[BITS_UNROLL];
+#pragma unroll
+        for (int k = 0; k < BITS_UNROLL; k++) x[k] = va[p + k * nth], y[k] = vb[p + k * nth];
+#pragma unroll
+        for (int k = 0; k < BITS_UNROLL; k++) {
+            if (OP == 0) x[k].x &= y[k].x, x[k].y &= y[k].y;
+            else if (OP == 1) x[k].x |= y[k].x, x[k].y |= y[k].y;
+            else x[k].x ^= y[k].x, x[k].y ^= y[k].y;
+            va[p + k * nth] = x[k];
+            if (COUNT) c += pair_popcount(x[k], (p + k * nth) * 2, full_words, tail_mask);
         }
     }
+    for (; p < npairs; p += nth) {
+        ulonglong2 x = va[p], y = vb[p];
+        if (OP == 0) x.x &= y.x, x.y &= y.y;
+        else if (OP == 1) x.x |= y.x, x.y |= y.y;
+        else x.x ^= y.x, x.y ^= y.y;
+        va[p] = x;
+        if (COUNT) c += pair_popcount(x, p * 2, full_words, tail_mask);
+    }
+    if (nbins > 0 && blockIdx.x == gridDim.x - 1) tags_binary(OP, ta, tb, nbins);  // (tags and words are independent arrays)
     if (COUNT) block_accumulate_i64(c, red, acc);
 }
 
@@ -245,17 +277,16 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_popcount_kernel(const unsig
     const int64_t full_words = size_bits >> 6;
     const unsigned long long tail_mask = (size_bits & 63) ? ~(~0ull << (size_bits & 63)) : 0ull;
     long long c = 0;
-    int64_t nth = (int64_t)gridDim.x * BITS_THREADS;
-    for (int64_t p = (int64_t)blockIdx.x * BITS_THREADS + threadIdx.x; p < npairs; p += nth) {
-        ulonglong2 x = va[p];
-        int64_t w = p * 2;
-        if (w + 1 < full_words) {
-            c += __popcll(x.x) + __popcll(x.y);
-        } else {
-            c += w < full_words ? __popcll(x.x) : (w == full_words ? __popcll(x.x & tail_mask) : 0);
-            c += (w + 1) < full_words ? __popcll(x.y) : ((w + 1) == full_words ? __popcll(x.y & tail_mask) : 0);
-        }
+    const int64_t nth = (int64_t)gridDim.x * BITS_THREADS;
+    int64_t p = (int64_t)blockIdx.x * BITS_THREADS + threadIdx.x;
+    for (; p + (BITS_UNROLL - 1) * nth < npairs; p += BITS_UNROLL * nth) {
+        ulonglong2 x[BITS_UNROLL];
+#pragma unroll
+        for (int k = 0; k < BITS_UNROLL; k++) x[k] = va[p + k * nth];
+#pragma unroll
+        for (int k = 0; k < BITS_UNROLL; k++) c += pair_popcount(x[k], (p + k * nth) * 2, full_words, tail_mask);
     }
+    for (; p < npairs; p += nth) c += pair_popcount(va[p], p * 2, full_words, tail_mask);
     block_accumulate_i64(c, red, acc);
 }
 
@@ -273,28 +304,6 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_not_kernel(unsigned long lo
 }
 
 // Per-bin state tables of binBitsAnd / binBitsOr / binBitsNot.
-__global__ void tags_and_kernel(uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int64_t nbins)
-{
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbins; i += (int64_t)gridDim.x * blockDim.x) {
-        uint8_t x = a[i], y = b[i];
-        if (x == TAG_ZERO) continue;                 // binBits.c:237-240
-        if (y == TAG_ZERO) a[i] = TAG_ZERO;          // :241-248
-        else if (y == TAG_ONE) continue;             // :249-252
-        else if (x == TAG_ONE) a[i] = TAG_DATA;      // :253-256 clone of other
-    }
-}
-
-__global__ void tags_or_kernel(uint8_t *__restrict__ a, const uint8_t *__restrict__ b, int64_t nbins)
-{
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbins; i += (int64_t)gridDim.x * blockDim.x) {
-        uint8_t x = a[i], y = b[i];
-        if (x == TAG_ONE) continue;                  // binBits.c:271-274
-        if (y == TAG_ONE) a[i] = TAG_ONE;            // :275-282
-        else if (y == TAG_ZERO) continue;            // :283-286
-        else if (x == TAG_ZERO) a[i] = TAG_DATA;     // :287-290 clone of other
-    }
-}
-
 __global__ void tags_not_kernel(uint8_t *__restrict__ a, int64_t nbins)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbins; i += (int64_t)gridDim.x * blockDim.x) {
@@ -872,17 +881,13 @@ template <int OP, bool COUNT>
 static int bits_binary(bxmi_bits *h, const bxmi_bits *other, unsigned long long *acc_dev, hipStream_t st)
 {
     int64_t npairs = h->nwords >> 1;
-    // counting variants end in one atomic per workgroup on a single counter (~12 ns each, serialised):
-    // keep the grid at 2 workgroups per CU for those
-    int grid = bits_grid(npairs, BITS_THREADS * 2);
-    if (COUNT && grid > device_props().cus * 2) grid = device_props().cus * 2;
+    // a workgroup moves BITS_UNROLL x 4 KiB per operand and sweep; counting variants stay at one workgroup per CU
+    int grid = bits_grid(npairs, BITS_THREADS * BITS_UNROLL);
+    if (COUNT && grid > device_props().cus) grid = device_props().cus;
+    const int64_t nb = h->flat || OP == 2 ? 0 : div_up(h->total_bits, h->bin_size);
     hipLaunchKernelGGL((bits_binary_kernel<OP, COUNT>), dim3(grid), dim3(BITS_THREADS), 0, st,
-                       h->words.as<unsigned long long>(), other->words.as<unsigned long long>(), npairs, (int64_t)h->size, acc_dev);
-    int64_t nb = div_up(h->total_bits, h->bin_size);
-    if (OP == 0 && !h->flat)
-        hipLaunchKernelGGL(tags_and_kernel, dim3(stream_grid(nb, 256)), dim3(256), 0, st, h->tags.as<uint8_t>(), other->tags.as<uint8_t>(), nb);
-    else if (OP == 1 && !h->flat)
-        hipLaunchKernelGGL(tags_or_kernel, dim3(stream_grid(nb, 256)), dim3(256), 0, st, h->tags.as<uint8_t>(), other->tags.as<uint8_t>(), nb);
+                       h->words.as<unsigned long long>(), other->words.as<unsigned long long>(), npairs, (int64_t)h->size, acc_dev,
+                       h->tags.as<uint8_t>(), other->tags.as<uint8_t>(), nb);
     BXMI_LAUNCH_CHECK();
     if (h->flat) return BXMI_OK;
     if (OP == 0)
@@ -915,8 +920,8 @@ extern "C" int bxmi_bits_popcount_dev(bxmi_bits_t *h, int64_t *count_dev, void *
 {
     if (!h || !count_dev) return fail(BXMI_EINVAL, "bxmi_bits_popcount_dev: bad arguments");
     int64_t npairs = h->nwords >> 1;
-    int grid = bits_grid(npairs, BITS_THREADS * 2);
-    if (grid > device_props().cus * 2) grid = device_props().cus * 2;
+    int grid = bits_grid(npairs, BITS_THREADS * BITS_UNROLL);
+    if (grid > device_props().cus) grid = device_props().cus;
     hipLaunchKernelGGL(bits_popcount_kernel, dim3(grid), dim3(BITS_THREADS), 0, as_stream(stream),
                        h->words.as<unsigned long long>(), npairs, (int64_t)h->size, reinterpret_cast<unsigned long long *>(count_dev));
     BXMI_LAUNCH_CHECK();

@@ -3050,6 +3050,10 @@ extern "C" int bxmi_ivl_neighbors(bxmi_ivl_t *h, int32_t position, int32_t max_d
         // intersection.pyx:192-209,240: p = position - 1, keep 0 <= p - end < max_dist (reverse in-order)
         // i.e. p - max_dist < end <= p.  Candidates lie in [first k with pm[k] > p-max_dist, #{start <= p}):
         // the upper bound is the reference's own `minstart > position` prune (:196-197).
+        // (With stored intervals whose start exceeds their end -- IntervalTree.insert accepts them -- the reference prunes by
+        // subtree, so whether such an interval with start > position is still reported there depends on the treap's random
+        // shape; the cut at #{start <= p} used here always leaves it out.  Appendix A.3 of SURVEY.md pins before/after for
+        // proper intervals only, for that reason.)
         long long p = (long long)position - 1;
         vlo = p - max_dist + 1, vhi = p + 1;
         hipLaunchKernelGGL(ivl_two_ranks_kernel, dim3(1), dim3(64), 0, st, h->pm.as<int32_t>(), vlo, h->s_ord.as<int32_t>(), vhi, n, d_r);

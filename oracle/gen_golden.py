@@ -289,6 +289,29 @@ def gen_cli():
     dump("cli/expected.json", dict(source="reference scripts/*.py run with the reference build", cases=exp, cfg1=cfg1))
 
 
+def gen_cli_crlf():
+    """Carriage returns: the reference reads its inputs in text mode, so '\\r\\n' reaches it as '\\n' (and a lone '\\r' ends a
+    line).  CRLF copies of the small pair, plus a file with a form feed and a vertical tab inside a field (no line break
+    for file iteration, one for str.splitlines)."""
+    d = os.path.join(GOLD, "cli")
+    exp = {}
+    for name in ("small_a", "small_b"):
+        text = open(os.path.join(d, name + ".bed")).read()
+        open(os.path.join(d, name + "_crlf.bed"), "w", newline="").write(text.replace("\n", "\r\n"))
+    odd = os.path.join(d, "odd_separators.bed")
+    open(odd, "w", newline="").write("chr1\t10\t20\tx\x0cy\t0\t+\nchr1\t15\t40\tv\x0bw\t0\t-\rchr2\t5\t9\tz\t0\t+\n")
+    a, b = os.path.join(d, "small_a_crlf.bed"), os.path.join(d, "small_b_crlf.bed")
+    la, lb = os.path.join(d, "small_a.bed"), os.path.join(d, "small_b.bed")
+    for flags in ([], ["-b"], ["-v"], ["-m", "5"]):
+        exp["bed_intersect crlf_query %s" % " ".join(flags)] = run_script("bed_intersect.py", flags + [a, lb])
+        exp["bed_intersect crlf_both %s" % " ".join(flags)] = run_script("bed_intersect.py", flags + [a, b])
+    exp["bed_intersect odd_query"] = run_script("bed_intersect.py", [odd, lb])
+    exp["bed_intersect_basewise crlf"] = run_script("bed_intersect_basewise.py", [a, b])
+    exp["bed_coverage crlf"] = run_script("bed_coverage.py", [a, b])
+    exp["bed_coverage odd"] = run_script("bed_coverage.py", [odd])
+    dump("cli/expected_crlf.json", dict(source="reference scripts/*.py run with the reference build", cases=exp))
+
+
 def gen_cli_siblings():
     """the sibling scripts that use only the hot-path API."""
     d = os.path.join(GOLD, "cli")
@@ -474,6 +497,8 @@ if __name__ == "__main__":
         gen_cli_siblings()
     if "siblings" in todo:
         gen_cli_siblings()
+    if "crlf" in todo and a.only:
+        gen_cli_crlf()
     if "scale" in todo:
         gen_scale(a.scale)
     for which in ("genome", "join", "calibration"):  # --only genome | join | calibration: long-running extras of scale.json

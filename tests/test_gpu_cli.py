@@ -53,6 +53,26 @@ def test_basewise_and_coverage(golden_cli, tag):
     check(run_cli("bed_coverage", [fa, fb]), golden_cli["cases"]["bed_coverage %s ab" % tag], tag)
 
 
+def test_carriage_returns_and_odd_separators():
+    """Inputs with '\\r\\n' line ends (query only, and both files), a lone '\\r' as a line end, and a form feed / vertical tab
+    inside a field: the reference sees them through text-mode universal newlines, and so must the fast ingest path
+    (which used to hand back '\\r\\n' lines and to split fields at \\x0b / \\x0c)."""
+    import json
+
+    want = json.load(open(os.path.join(CLI, "expected_crlf.json")))["cases"]
+    a, b = os.path.join(CLI, "small_a_crlf.bed"), os.path.join(CLI, "small_b_crlf.bed")
+    lb, odd = os.path.join(CLI, "small_b.bed"), os.path.join(CLI, "odd_separators.bed")
+    assert b"\r\n" in open(a, "rb").read() and b"\x0c" in open(odd, "rb").read()
+    for flags in ([], ["-b"], ["-v"], ["-m", "5"]):
+        for tag, fb in (("crlf_query", lb), ("crlf_both", b)):
+            key = "bed_intersect %s %s" % (tag, " ".join(flags))
+            check(run_cli("bed_intersect", flags + [a, fb]), want[key], key)
+    check(run_cli("bed_intersect", [odd, lb]), want["bed_intersect odd_query"], "odd_query")
+    check(run_cli("bed_intersect_basewise", [a, b]), want["bed_intersect_basewise crlf"], "basewise crlf")
+    check(run_cli("bed_coverage", [a, b]), want["bed_coverage crlf"], "coverage crlf")
+    check(run_cli("bed_coverage", [odd]), want["bed_coverage odd"], "coverage odd")
+
+
 def test_coverage_stdin_and_errors(golden_cli):
     stdin = open(os.path.join(CLI, "small_b.bed")).read()
     check(run_cli("bed_coverage", [], stdin=stdin), golden_cli["cases"]["bed_coverage small stdin"], "stdin")

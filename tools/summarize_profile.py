@@ -55,8 +55,10 @@ for k, v in dur.items():
 # HBM bytes of one count pass = its seven kernels.
 # FETCH_SIZE is in KiB and reads HALF of a streaming read on gfx950 (checked below on the bitset popcount, whose
 # byte count is known); WRITE_SIZE is in KiB and exact.  Correction as MI355X_MICROARCH.md prescribes.
-pass_kernels = ["part_hist_kernel", "part_colsum_kernel", "part_colbase_kernel", "part_colscan_kernel", "part_scatter_kernel",
-                "part_count_cells_kernel<unsigned short>", "part_gather_kernel<unsigned short>"]
+# the bitmap-cell pass (count_bitmap.hpp); whatever template arguments the run used
+pass_prefixes = ["bm_sorted_check_kernel", "ivl_local_count_kernel", "bm_tile_sort_kernel", "bm_transpose_kernel", "bm_plan_kernel", "bm_search_pipe_kernel",
+                 "bm_search_kernel", "bm_unpermute_kernel", "part_fold_total_kernel"]
+pass_kernels = [k for k in out if any(k.startswith(pre) for pre in pass_prefixes)]
 tot = 0.0
 detail = {}
 for k in pass_kernels:
@@ -71,5 +73,17 @@ if detail:
 v = out.get("ivl_count_kernel<true>")
 if v and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
     out["ivl_count_kernel"] = dict(hbm_bytes_per_launch=round((2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024.0))
+# what code this was measured on (bench.py quotes count_pass.hbm_bytes_per_launch only when these match its own)
+try:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import datetime
+
+    import bench
+
+    out["stamps"] = dict(bench.source_stamps(), date=datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+                         command=os.environ.get("PROFILE_CMD", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-sorted --no-find --no-bitset --no-genome"),
+                         head=os.environ.get("PROFILE_HEAD", "(stamped when copied into profiles/)"))
+except Exception as ex:
+    out["stamps"] = {"error": repr(ex)}
 json.dump(out, open(os.path.join(d, "summary_pmc.json"), "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k in ("count_pass", "bits_popcount_kernel") or k.startswith("bits_group")}, indent=1))
+print(json.dumps({k: v for k, v in out.items() if k in ("count_pass", "bits_popcount_kernel", "stamps") or k.startswith("bits_group")}, indent=1))
