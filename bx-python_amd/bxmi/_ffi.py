@@ -49,6 +49,7 @@ _SIGNATURES = {
     "bxmi_ivl_order_dev": [vp, _p(vp), _p(vp), _p(vp)],
     "bxmi_ivl_count": [vp, vp, vp, i64, vp, _p(i64)],
     "bxmi_ivl_count_dev": [vp, vp, vp, i64, vp, vp, vp],
+    "bxmi_ivl_count_multi_dev": [vp, C.c_int, vp, vp, vp, vp, vp, vp],
     "bxmi_ivl_bitmap_state": [vp, _p(C.c_int), _p(i64)],
     "bxmi_ivl_find": [vp, vp, vp, i64, vp, vp, i64, _p(i64)],
     "bxmi_ivl_find_dev": [vp, vp, vp, i64, vp, vp, i64, _p(i64), vp],

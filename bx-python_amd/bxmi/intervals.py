@@ -137,6 +137,21 @@ class IntervalIndex:
         self._ready()
         call("bxmi_ivl_count_dev", self._h, qs_ptr, qe_ptr, nq, counts_ptr, total_ptr, stream)
 
+    @staticmethod
+    def count_multi_dev(indexes, qs_ptrs, qe_ptrs, nqs, counts_ptrs, total_ptrs=None, stream=None):
+        """count_dev for several indexes at once (one per chromosome): same results, one fused pass for those that qualify.
+        All arguments are per-index lists (device pointers as ints, total_ptrs entries may be None)."""
+        n = len(indexes)
+        for ix in indexes:
+            ix._ready()
+        H = (C.c_void_p * n)(*[ix._h for ix in indexes])
+        Q = (C.c_void_p * n)(*qs_ptrs)
+        E = (C.c_void_p * n)(*qe_ptrs)
+        N = (C.c_int64 * n)(*nqs)
+        K = (C.c_void_p * n)(*counts_ptrs)
+        T = (C.c_void_p * n)(*total_ptrs) if total_ptrs is not None else None
+        call("bxmi_ivl_count_multi_dev", H, n, Q, E, N, K, T, stream)
+
     def find_dev(self, qs_ptr, qe_ptr, nq, offsets_ptr, hits_ptr, cap, stream=None):
         self._ready()
         total = C.c_int64(0)

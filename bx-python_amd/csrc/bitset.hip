@@ -199,7 +199,7 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_popcount_span_kernel(const 
 // ---------------------------------------------------------------------------
 // OP: 0 = and, 1 = or, 2 = xor.  COUNT: also accumulate popcount of the result inside [0, size).
 // One launch per call of the drop-in classes (bed_intersect_basewise.py:25-28 does one iand per chromosome), so the
-// launch itself is most of the cost: the per-bin tags are updated by the LAST workgroup of the same launch instead of
+// launch itself is most of the cost: the per-bin tags are updated by the FIRST workgroup of the same launch instead of
 // a second kernel, a lane keeps four 16-byte loads per operand in flight, and the counting variants run at most one
 // workgroup per CU (their single atomic per workgroup serialises on one counter, ~12 ns each).
 constexpr int BITS_UNROLL = 4;
@@ -242,6 +242,9 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_binary_kernel(unsigned long
     const int64_t full_words = size_bits >> 6;  // words entirely inside [0,size)
     const unsigned long long tail_mask = (size_bits & 63) ? ~(~0ull << (size_bits & 63)) : 0ull;
     long long c = 0;
+    // the per-bin tags (an array of their own): by the FIRST workgroup, before its share of the words, so that the three
+    // dependent round trips hide behind everybody else's streaming instead of trailing the launch
+    if (nbins > 0 && blockIdx.x == 0) tags_binary(OP, ta, tb, nbins);
     const int64_t nth = (int64_t)gridDim.x * BITS_THREADS;
     int64_t p = (int64_t)blockIdx.x * BITS_THREADS + threadIdx.x;
     for (; p + (BITS_UNROLL - 1) * nth < npairs; p += BITS_UNROLL * nth) {
@@ -265,7 +268,6 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_binary_kernel(unsigned long
         va[p] = x;
         if (COUNT) c += pair_popcount(x, p * 2, full_words, tail_mask);
     }
-    if (nbins > 0 && blockIdx.x == gridDim.x - 1) tags_binary(OP, ta, tb, nbins);  // (tags and words are independent arrays)
     if (COUNT) block_accumulate_i64(c, red, acc);
 }
 

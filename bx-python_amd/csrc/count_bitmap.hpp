@@ -58,6 +58,43 @@ struct BmBucket {
     int32_t sLo;  // #{starts < bucket's first coordinate}
 };
 
+// One batch may cover several sealed indexes at once (a genome: one index per chromosome, bxmi_ivl_count_multi_dev):
+// every index with its queries is a SEGMENT.  Tiles are numbered across the whole batch, a segment owns a range of
+// them that starts on a plan-group boundary, and every kernel below finds its geometry, arrays and images through the
+// segment of the tile (or work item) it is looking at.  A plain bxmi_ivl_count_dev call is a batch of one segment.
+struct BmSeg {
+    BmGeom g;
+    const int32_t *qs, *qe;   // the segment's queries
+    int32_t *counts;          // and where their counts go
+    int64_t nq;
+    int64_t tile0, ntiles;    // first tile of the segment in the batch's numbering, tiles that hold queries
+    int64_t tile_end;         // first tile of the next segment (tile0 + ntiles rounded up to a plan group)
+    const uint2 *images;
+    const BmBucket *bmeta;
+    IndexDev ix;              // the sealed index (escapes, hard cells)
+    const int32_t *e_sorted;
+};
+
+// The batch's parameter block is written by a kernel from its own arguments (stream-ordered, no host staging that a
+// following batch could overwrite while this one is still queued): up to BM_PAR_CHUNK segments per launch.
+constexpr int BM_PAR_CHUNK = 16;
+struct BmSegChunk {
+    BmSeg seg[BM_PAR_CHUNK];
+    unsigned long long *total[BM_PAR_CHUNK];  // where each segment's overlap total is accumulated (may be NULL)
+};
+
+__global__ __launch_bounds__(256) void bm_params_kernel(BmSegChunk c, int first, BmSeg *__restrict__ segs, unsigned long long **__restrict__ totals,
+                                                        unsigned short *__restrict__ tile_seg)
+{
+    const BmSeg &sg = c.seg[blockIdx.x];
+    const int id = first + (int)blockIdx.x;
+    if (threadIdx.x == 0) {
+        segs[id] = sg;
+        totals[id] = c.total[blockIdx.x];
+    }
+    for (int64_t t = sg.tile0 + threadIdx.x; t < sg.tile_end; t += 256) tile_seg[t] = (unsigned short)id;
+}
+
 struct OpMin {
     template <typename T>
     __device__ __forceinline__ T operator()(T a, T b) const
@@ -215,8 +252,8 @@ __device__ __forceinline__ unsigned bm_record_of(int qs, int qe, const BmGeom &g
 }
 
 template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const int32_t *__restrict__ qs, const int32_t *__restrict__ qe, int64_t nq,
-                                                               BmGeom g, unsigned *__restrict__ recs /* [ntiles][TILE], tile-sorted */,
+__global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
+                                                               unsigned *__restrict__ recs /* [ntiles][TILE], tile-sorted */,
                                                                unsigned short *__restrict__ slots /* [nq] slot of every query in its tile */,
                                                                unsigned short *__restrict__ tbl /* [ntiles][BM_NB] first slot of every bucket */,
                                                                const unsigned *__restrict__ gate /* NULL, or 0 = sorted batch: stand down */)
@@ -231,8 +268,15 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const int32_t *__
     unsigned short *toff = reinterpret_cast<unsigned short *>(cnt + BM_NB);        // [BM_NB]
     unsigned *scan_tmp = reinterpret_cast<unsigned *>(toff + BM_NB);               // [16]
     const int64_t tile = blockIdx.x;
-    const int64_t base = tile * TILE;
-    const int n = (int)(nq - base < TILE ? nq - base : TILE);
+    const BmSeg &sg = segs[tile_seg[tile]];
+    const int64_t ltile = tile - sg.tile0;
+    if (ltile >= sg.ntiles) return;  // padding up to the next plan group
+    const BmGeom g = sg.g;
+    const int32_t *__restrict__ qs = sg.qs + ltile * TILE, *__restrict__ qe = sg.qe + ltile * TILE;  // this tile's queries
+    const int64_t nq = sg.nq - ltile * TILE;
+    recs += tile * TILE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
+    const int64_t base = 0;
+    const int n = (int)(nq < TILE ? nq : TILE);
     for (int i = threadIdx.x; i < BM_NB; i += THREADS) cnt[i] = 0;
     __syncthreads();
     unsigned br[ITEMS];  // bucket << 16 | rank inside the (tile, bucket) run
@@ -332,7 +376,8 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const int32_t *__
 // ---------------------------------------------------------------------------
 // tbl[tile][bucket] (16-bit first slots) -> runT[bucket][tile] = first slot | length << 16, a 64 x 64 patch per workgroup;
 // grpcnt[group][bucket] = queries of the bucket in the 64 tiles of the group.
-__global__ __launch_bounds__(256) void bm_transpose_kernel(const unsigned short *__restrict__ tbl, int64_t ntiles, int64_t nq, int tile_log2,
+__global__ __launch_bounds__(256) void bm_transpose_kernel(const unsigned short *__restrict__ tbl, const BmSeg *__restrict__ segs,
+                                                           const unsigned short *__restrict__ tile_seg, int tile_log2,
                                                            unsigned *__restrict__ runT /* [BM_NB][ntp] */, int64_t ntp,
                                                            unsigned *__restrict__ grpcnt /* [ngroups][BM_NB] */, const unsigned *__restrict__ gate)
 {
@@ -342,8 +387,9 @@ __global__ __launch_bounds__(256) void bm_transpose_kernel(const unsigned short 
     {
         const int r = threadIdx.x >> 2, q = threadIdx.x & 3;  // 4 threads per tile row, 16 buckets each
         const int64_t tile = (int64_t)grp * BM_GROUP_TILES + r;
-        const bool live = tile < ntiles;
-        const int64_t left = nq - (tile << tile_log2);
+        const BmSeg &sg = segs[tile_seg[tile]];  // (a plan group never straddles two segments)
+        const bool live = tile - sg.tile0 < sg.ntiles;
+        const int64_t left = sg.nq - ((tile - sg.tile0) << tile_log2);
         const unsigned ntile = !live ? 0u : (left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2);
         const unsigned short *row = tbl + tile * BM_NB + b0 + 16 * q;
         uint4 a = make_uint4(0, 0, 0, 0), c = a;
@@ -387,57 +433,73 @@ __global__ __launch_bounds__(256) void bm_transpose_kernel(const unsigned short 
 constexpr int BM_PLAN_BATCH = 16;
 // UNITS = what one work item searches: 2 = a thread walks two buckets, each its own unit (one bucket per search
 // workgroup); 1 = the two buckets form ONE unit (the search workgroup holds both images, see bm_search_kernel<PAIR>).
+// An item never crosses from one segment (index) into the next.  items[i] = {bucket | segment << 16, first tile,
+// last tile + 1, queries}.
 template <bool EMIT, int UNITS>
-__device__ __forceinline__ void bm_plan_walk(const unsigned *__restrict__ grpcnt, int ngroups, int64_t ntiles, int b0, int chunk, int (&cnt)[2],
-                                             int4 *__restrict__ items, int out0, int out1)
+__device__ __forceinline__ void bm_plan_walk(const unsigned *__restrict__ grpcnt, int ngroups, const BmSeg *__restrict__ segs,
+                                             const unsigned short *__restrict__ tile_seg, int b0, int chunk, int (&cnt)[2], int4 *__restrict__ items,
+                                             int out0, int out1)
 {
     unsigned acc[2] = {0, 0};
     int g_first[2] = {0, 0};
     int out[2] = {out0, out1};
+    int seg = tile_seg[0];
     cnt[0] = cnt[1] = 0;
+    auto close = [&](int u, int g_end) {  // the item of unit u that ends before group g_end (same segment as `seg`)
+        if (EMIT) {
+            const int64_t t_last = segs[seg].tile0 + segs[seg].ntiles, t_end = (int64_t)g_end * BM_GROUP_TILES;
+            items[out[u]++] = make_int4((b0 + u) | (seg << 16), g_first[u] * BM_GROUP_TILES, (int)(t_end < t_last ? t_end : t_last), (int)acc[u]);
+        }
+        cnt[u]++;
+        acc[u] = 0;
+    };
     for (int g0 = 0; g0 < ngroups; g0 += BM_PLAN_BATCH) {
         uint2 v[BM_PLAN_BATCH];
-#pragma unroll
-        for (int i = 0; i < BM_PLAN_BATCH; i++)
-            v[i] = g0 + i < ngroups ? *reinterpret_cast<const uint2 *>(grpcnt + (int64_t)(g0 + i) * BM_NB + b0) : make_uint2(0, 0);
+        int sg[BM_PLAN_BATCH];
 #pragma unroll
         for (int i = 0; i < BM_PLAN_BATCH; i++) {
-            const int gi = g0 + i;  // (groups past the end carry zeros: they change nothing)
+            const int gi = g0 + i < ngroups ? g0 + i : ngroups - 1;  // a valid address: no branch around the loads
+            v[i] = *reinterpret_cast<const uint2 *>(grpcnt + (int64_t)gi * BM_NB + b0);
+            sg[i] = tile_seg[(int64_t)gi * BM_GROUP_TILES];
+        }
+#pragma unroll
+        for (int i = 0; i < BM_PLAN_BATCH; i++) {
+            const int gi = g0 + i;
+            if (gi >= ngroups) break;
             const unsigned cc[2] = {UNITS == 1 ? v[i].x + v[i].y : v[i].x, v[i].y};
+            if (sg[i] != seg) {  // the next index starts here
+#pragma unroll
+                for (int u = 0; u < UNITS; u++)
+                    if (acc[u] > 0) close(u, gi);
+                seg = sg[i];
+            }
 #pragma unroll
             for (int u = 0; u < UNITS; u++) {
-                if (acc[u] > 0 && acc[u] + cc[u] > (unsigned)chunk) {
-                    if (EMIT) items[out[u]++] = make_int4(b0 + u, g_first[u] * BM_GROUP_TILES, gi * BM_GROUP_TILES, (int)acc[u]);
-                    cnt[u]++;
-                    acc[u] = 0;
-                }
+                if (acc[u] > 0 && acc[u] + cc[u] > (unsigned)chunk) close(u, gi);
                 if (acc[u] == 0) g_first[u] = gi;
                 acc[u] += cc[u];
             }
         }
     }
-    const int64_t t_end = (int64_t)ngroups * BM_GROUP_TILES;
 #pragma unroll
     for (int u = 0; u < UNITS; u++)
-        if (acc[u] > 0) {
-            if (EMIT) items[out[u]++] = make_int4(b0 + u, g_first[u] * BM_GROUP_TILES, (int)(t_end < ntiles ? t_end : ntiles), (int)acc[u]);
-            cnt[u]++;
-        }
+        if (acc[u] > 0) close(u, ngroups);
 }
 
 template <int UNITS>
-__global__ __launch_bounds__(1024) void bm_plan_kernel(const unsigned *__restrict__ grpcnt, int ngroups, int64_t ntiles, int chunk,
-                                                       int4 *__restrict__ items, int *__restrict__ n_items, const unsigned *__restrict__ gate)
+__global__ __launch_bounds__(1024) void bm_plan_kernel(const unsigned *__restrict__ grpcnt, int ngroups, const BmSeg *__restrict__ segs,
+                                                       const unsigned short *__restrict__ tile_seg, int chunk, int4 *__restrict__ items,
+                                                       int *__restrict__ n_items, const unsigned *__restrict__ gate)
 {
     __shared__ int scan_tmp[16];
     if (gate && *gate == 0) return;
     const int b0 = 2 * threadIdx.x;
     int cnt[2], again[2];
-    bm_plan_walk<false, UNITS>(grpcnt, ngroups, ntiles, b0, chunk, cnt, nullptr, 0, 0);
+    bm_plan_walk<false, UNITS>(grpcnt, ngroups, segs, tile_seg, b0, chunk, cnt, nullptr, 0, 0);
     int tot;
     const int at = block_exclusive_scan(cnt[0] + cnt[1], OpSum(), 0, scan_tmp, &tot);
     if (threadIdx.x == 0) n_items[0] = tot;
-    bm_plan_walk<true, UNITS>(grpcnt, ngroups, ntiles, b0, chunk, again, items, at, at + cnt[0]);  // bucket b0's items, then bucket b0 + 1's
+    bm_plan_walk<true, UNITS>(grpcnt, ngroups, segs, tile_seg, b0, chunk, again, items, at, at + cnt[0]);  // bucket b0's items, then bucket b0 + 1's
 }
 
 // ---------------------------------------------------------------------------
@@ -502,11 +564,9 @@ __device__ __forceinline__ unsigned bm_count_record(lds_cell_p cE, lds_cell_p cS
 // EXP (diagnostics, ivl.bm_exp): 0 = the real thing; 1 = no count stores, 2 = no record loads, 3 = neither (results are
 // wrong then: the timing matrix of tools/bm_perf.py uses them to price the pieces of this kernel).
 template <bool PAIR, int U /* tile runs in flight per lane group */, int EXP = 0>
-__global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_kernel(const uint2 *__restrict__ images, BmGeom g, const BmBucket *__restrict__ bmeta,
-                                                                      const int4 *__restrict__ items, const int *__restrict__ n_items,
-                                                                      const unsigned *__restrict__ runT, int64_t ntp,
+__global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
+                                                                      const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
                                                                       unsigned *__restrict__ recs /* records in, counts out */, int tile_log2,
-                                                                      const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted,
                                                                       const unsigned *__restrict__ gate)
 {
     constexpr int L = PAIR ? 16 : 8;
@@ -525,7 +585,12 @@ __global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_kernel(const uint
     const int it = (int)(blockIdx.x & 7) * per_xcd + slot;
     if (slot >= per_xcd || it >= nit) return;
     const int4 item = items[it];
-    const int b = item.x, t0 = item.y, t1 = item.z;
+    const int b = item.x & 0xffff, t0 = item.y, t1 = item.z;
+    const BmSeg &sg = segs[item.x >> 16];
+    const BmGeom g = sg.g;
+    const uint2 *__restrict__ images = sg.images;
+    const BmBucket *__restrict__ bmeta = sg.bmeta;
+    const int32_t *__restrict__ s_ord = sg.ix.s_ord, *__restrict__ e_sorted = sg.e_sorted;
     const unsigned *__restrict__ runs0 = runT + (int64_t)b * ntp;
     const unsigned *__restrict__ runs1 = runs0 + ntp;  // PAIR only
     const int gid = threadIdx.x / L, sub = threadIdx.x % L;
@@ -667,12 +732,10 @@ struct BmRound {
 };
 
 template <bool PAIR, int U, bool NT /* image loads non-temporal: they stream through L2 once */>
-__global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_pipe_kernel(const uint2 *__restrict__ images, BmGeom g,
-                                                                           const BmBucket *__restrict__ bmeta, const int4 *__restrict__ items,
+__global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                            const int *__restrict__ n_items, const unsigned *__restrict__ runT,
                                                                            int64_t ntp, unsigned *__restrict__ recs /* records in, counts out */,
-                                                                           int tile_log2, const int32_t *__restrict__ s_ord,
-                                                                           const int32_t *__restrict__ e_sorted, const unsigned *__restrict__ gate)
+                                                                           int tile_log2, const unsigned *__restrict__ gate)
 {
     constexpr int L = PAIR ? 16 : 8;
     if (gate && *gate == 0) return;
@@ -687,7 +750,12 @@ __global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_pipe_kernel(const
     const int it = (int)(blockIdx.x & 7) * per_xcd + slot;
     if (slot >= per_xcd || it >= nit) return;
     const int4 item = items[it];
-    const int b = item.x, t0 = item.y, t1 = item.z;
+    const int b = item.x & 0xffff, t0 = item.y, t1 = item.z;
+    const BmSeg &sg = segs[item.x >> 16];
+    const BmGeom g = sg.g;
+    const uint2 *__restrict__ images = sg.images;
+    const BmBucket *__restrict__ bmeta = sg.bmeta;
+    const int32_t *__restrict__ s_ord = sg.ix.s_ord, *__restrict__ e_sorted = sg.e_sorted;
     const unsigned *__restrict__ runs0 = runT + (int64_t)b * ntp;
     const unsigned *__restrict__ runs1 = runs0 + ntp;  // PAIR only
     const int gid = threadIdx.x / L, sub = threadIdx.x % L;
@@ -839,10 +907,10 @@ __device__ __forceinline__ int bm_escape_count(const IndexDev &ix, const int32_t
 
 template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *__restrict__ cnt /* tile-sorted: the records array after the search */,
-                                                               const unsigned short *__restrict__ slots, int64_t nq, int32_t *__restrict__ out,
-                                                               unsigned long long *__restrict__ total_slots, IndexDev ix,
-                                                               const int32_t *__restrict__ e_sorted, BmGeom g, const int32_t *__restrict__ qs_arr,
-                                                               const int32_t *__restrict__ qe_arr, const unsigned *__restrict__ gate)
+                                                               const unsigned short *__restrict__ slots, const BmSeg *__restrict__ segs,
+                                                               const unsigned short *__restrict__ tile_seg,
+                                                               unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS], may be NULL */,
+                                                               const unsigned *__restrict__ gate)
 {
     constexpr int TILE = THREADS * ITEMS;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
@@ -850,8 +918,19 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
     unsigned *vals = reinterpret_cast<unsigned *>(dyn);  // [TILE]
     __shared__ long long red[THREADS / 64];
     const int64_t tile = blockIdx.x;
-    const int64_t base = tile * TILE;
-    const int n = (int)(nq - base < TILE ? nq - base : TILE);
+    const int seg_id = tile_seg[tile];
+    const BmSeg &sg = segs[seg_id];
+    const int64_t ltile = tile - sg.tile0;
+    if (ltile >= sg.ntiles) return;  // padding up to the next plan group
+    const IndexDev ix = sg.ix;
+    const BmGeom g = sg.g;
+    const int32_t *__restrict__ e_sorted = sg.e_sorted;
+    const int32_t *__restrict__ qs_arr = sg.qs + ltile * TILE, *__restrict__ qe_arr = sg.qe + ltile * TILE;  // escapes only
+    int32_t *__restrict__ out = sg.counts + ltile * TILE;
+    cnt += tile * TILE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
+    const int64_t nq = sg.nq - ltile * TILE;
+    const int64_t base = 0;
+    const int n = (int)(nq < TILE ? nq : TILE);
     {
         const int4 *src = reinterpret_cast<const int4 *>(cnt + base);
         if (n == TILE) {
@@ -893,7 +972,17 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
             acc += c;
         }
     }
-    if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
+    if (total_slots) block_accumulate_i64(acc, red, total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)));
+}
+
+// the segments' partial totals, folded into the caller's int64 per segment (accumulated, like bxmi_ivl_count_dev's total)
+__global__ void bm_fold_totals_kernel(const unsigned long long *__restrict__ slots /* [segments][PT_SLOTS] */,
+                                      unsigned long long *const *__restrict__ totals /* [segments] */)
+{
+    unsigned long long v = threadIdx.x < PT_SLOTS ? slots[(int64_t)blockIdx.x * PT_SLOTS + threadIdx.x] : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0 && v && totals[blockIdx.x]) atomicAdd(totals[blockIdx.x], v);
 }
 
 }  // namespace bxmi

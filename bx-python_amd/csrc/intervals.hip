@@ -2151,7 +2151,7 @@ struct bxmi_ivl {
     int bm_state = 0;            // 0 = not decided yet, 1 = images built and the index qualifies, -1 = it does not
     int64_t bm_hard_cells = 0;   // what bm_image_kernel reported
     BmGeom bm_geom{0, 0, 0, 0, 0, 0};
-    DevBuf bm_images, bm_meta, bm_stats, bm_recs, bm_slots, bm_tbl, bm_runT, bm_grpcnt, bm_items;
+    DevBuf bm_images, bm_meta, bm_stats, bm_recs, bm_slots, bm_tbl, bm_runT, bm_grpcnt, bm_items, bm_params;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][hits...]
     hipStream_t stream = nullptr;
     int device = 0;
@@ -2391,144 +2391,211 @@ static int bm_prepare_index(bxmi_ivl *h, hipStream_t st)
     return BXMI_OK;
 }
 
+// Everything the kernels of one batch need, as they are handed to every launch.
+struct BmLaunch {
+    const BmSeg *segs;             // device: the batch's segments
+    const unsigned short *tile_seg;  // device: segment of every tile (padded numbering)
+    bxmi_ivl *owner;               // whose scratch the batch uses
+    int64_t ntp;                   // tiles in the padded numbering (a multiple of BM_GROUP_TILES)
+    int ngroups, tile_log2;
+    size_t search_lds;
+    const unsigned *gate;
+};
+
 template <int THREADS, int ITEMS>
-static int bm_launch_tiles(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t ntiles, const unsigned *gate, hipStream_t st)
+static int bm_launch_tiles(const BmLaunch &L, hipStream_t st)
 {
     constexpr int TILE = THREADS * ITEMS;
     const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64;
     BXMI_TRY(allow_big_lds(bm_tile_sort_kernel<THREADS, ITEMS>, lds));
-    hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS>), dim3((unsigned)ntiles), dim3(THREADS), lds, st, qs, qe, nq, h->bm_geom,
-                       h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), gate);
+    hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
+                       L.owner->bm_recs.as<unsigned>(), L.owner->bm_slots.as<unsigned short>(), L.owner->bm_tbl.as<unsigned short>(), L.gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
 template <bool PAIR, int U, int EXP = 0>
-static int bm_launch_search(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, const unsigned *gate, hipStream_t st)
+static int bm_launch_search(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
-    const size_t lds = (size_t)(PAIR ? 2 : 1) * h->bm_geom.stride * sizeof(uint2);
-    BXMI_TRY(allow_big_lds((bm_search_kernel<PAIR, U, EXP>), lds));
-    hipLaunchKernelGGL((bm_search_kernel<PAIR, U, EXP>), dim3(grid), dim3(BM_SEARCH_THREADS), lds, st, h->bm_images.as<uint2>(), h->bm_geom,
-                       h->bm_meta.as<BmBucket>(), h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), ntp,
-                       h->bm_recs.as<unsigned>(), tile_log2, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), gate);
+    bxmi_ivl *h = L.owner;
+    BXMI_TRY(allow_big_lds((bm_search_kernel<PAIR, U, EXP>), L.search_lds));
+    hipLaunchKernelGGL((bm_search_kernel<PAIR, U, EXP>), dim3(grid), dim3(BM_SEARCH_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+                       h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), L.tile_log2, L.gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
 template <bool PAIR, int U, bool NT>
-static int bm_launch_search_pipe(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, const unsigned *gate, hipStream_t st)
+static int bm_launch_search_pipe(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
-    const size_t lds = (size_t)(PAIR ? 2 : 1) * h->bm_geom.stride * sizeof(uint2);
-    BXMI_TRY(allow_big_lds((bm_search_pipe_kernel<PAIR, U, NT>), lds));
-    hipLaunchKernelGGL((bm_search_pipe_kernel<PAIR, U, NT>), dim3(grid), dim3(BM_SEARCH_THREADS), lds, st, h->bm_images.as<uint2>(), h->bm_geom,
-                       h->bm_meta.as<BmBucket>(), h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), ntp,
-                       h->bm_recs.as<unsigned>(), tile_log2, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), gate);
+    bxmi_ivl *h = L.owner;
+    BXMI_TRY(allow_big_lds((bm_search_pipe_kernel<PAIR, U, NT>), L.search_lds));
+    hipLaunchKernelGGL((bm_search_pipe_kernel<PAIR, U, NT>), dim3(grid), dim3(BM_SEARCH_THREADS), L.search_lds, st, L.segs,
+                       h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), L.tile_log2,
+                       L.gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
 template <bool PAIR>
-static int bm_launch_search_u(bxmi_ivl *h, unsigned grid, int64_t ntp, int tile_log2, const unsigned *gate, hipStream_t st)
+static int bm_launch_search_u(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
     if (g_opt_bm_pipe && g_opt_bm_exp == 0) {
         if (g_opt_bm_nt) {
-            if (g_opt_bm_u == 2) return bm_launch_search_pipe<PAIR, 2, true>(h, grid, ntp, tile_log2, gate, st);
-            return bm_launch_search_pipe<PAIR, 4, true>(h, grid, ntp, tile_log2, gate, st);
+            if (g_opt_bm_u == 2) return bm_launch_search_pipe<PAIR, 2, true>(L, grid, st);
+            return bm_launch_search_pipe<PAIR, 4, true>(L, grid, st);
         }
-        if (g_opt_bm_u == 2) return bm_launch_search_pipe<PAIR, 2, false>(h, grid, ntp, tile_log2, gate, st);
-        return bm_launch_search_pipe<PAIR, 4, false>(h, grid, ntp, tile_log2, gate, st);
+        if (g_opt_bm_u == 2) return bm_launch_search_pipe<PAIR, 2, false>(L, grid, st);
+        return bm_launch_search_pipe<PAIR, 4, false>(L, grid, st);
     }
-    if (g_opt_bm_exp == 1) return bm_launch_search<PAIR, 4, 1>(h, grid, ntp, tile_log2, gate, st);
-    if (g_opt_bm_exp == 2) return bm_launch_search<PAIR, 4, 2>(h, grid, ntp, tile_log2, gate, st);
-    if (g_opt_bm_exp == 3) return bm_launch_search<PAIR, 4, 3>(h, grid, ntp, tile_log2, gate, st);
-    if (g_opt_bm_exp == 4) return bm_launch_search<PAIR, 4, 4>(h, grid, ntp, tile_log2, gate, st);
-    if (g_opt_bm_exp == 5) return bm_launch_search<PAIR, 4, 5>(h, grid, ntp, tile_log2, gate, st);
-    if (g_opt_bm_exp == 6) return bm_launch_search<PAIR, 4, 6>(h, grid, ntp, tile_log2, gate, st);
-    if (g_opt_bm_exp == 7) return bm_launch_search<PAIR, 4, 7>(h, grid, ntp, tile_log2, gate, st);
-    if (g_opt_bm_u == 2) return bm_launch_search<PAIR, 2>(h, grid, ntp, tile_log2, gate, st);
-    if (g_opt_bm_u == 8) return bm_launch_search<PAIR, 8>(h, grid, ntp, tile_log2, gate, st);
-    return bm_launch_search<PAIR, 4>(h, grid, ntp, tile_log2, gate, st);
+    if (g_opt_bm_exp == 1) return bm_launch_search<PAIR, 4, 1>(L, grid, st);
+    if (g_opt_bm_exp == 2) return bm_launch_search<PAIR, 4, 2>(L, grid, st);
+    if (g_opt_bm_exp == 3) return bm_launch_search<PAIR, 4, 3>(L, grid, st);
+    if (g_opt_bm_exp == 4) return bm_launch_search<PAIR, 4, 4>(L, grid, st);
+    if (g_opt_bm_exp == 5) return bm_launch_search<PAIR, 4, 5>(L, grid, st);
+    if (g_opt_bm_exp == 6) return bm_launch_search<PAIR, 4, 6>(L, grid, st);
+    if (g_opt_bm_exp == 7) return bm_launch_search<PAIR, 4, 7>(L, grid, st);
+    if (g_opt_bm_u == 2) return bm_launch_search<PAIR, 2>(L, grid, st);
+    if (g_opt_bm_u == 8) return bm_launch_search<PAIR, 8>(L, grid, st);
+    return bm_launch_search<PAIR, 4>(L, grid, st);
 }
 
 template <int THREADS, int ITEMS>
-static int bm_launch_unpermute(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t ntiles, int32_t *counts,
-                               unsigned long long *slots, const unsigned *gate, hipStream_t st)
+static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st)
 {
+    bxmi_ivl *h = L.owner;
     const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);
     BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS>), lds));
-    hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)ntiles), dim3(THREADS), lds, st, h->bm_recs.as<unsigned>(),
-                       h->bm_slots.as<unsigned short>(), nq, counts, slots, index_dev(h), h->e_sorted.as<int32_t>(), h->bm_geom, qs, qe, gate);
+    hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bm_recs.as<unsigned>(),
+                       h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
-// sorted check -> tile sort -> run table + plan -> search -> un-permute (or, sorted batch: the one-pass local kernel),
-// all on `st`; counts must not be NULL
-static int ivl_count_bitmap(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total_dev, hipStream_t st)
+// The bitmap-cell pass over a batch of n segments (n sealed, qualifying indexes with their queries): [order check ->]
+// tile sort -> run table + plan -> search -> un-permute -> totals, all on `st`, six launches whatever n is.
+// counts[i] must not be NULL; totals_dev[i] may be.  The scratch of hs[0] serves the whole batch.
+static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
+                             int32_t *const *counts, int64_t *const *totals_dev, hipStream_t st)
 {
-    if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
+    bxmi_ivl *h = hs[0];
+    int64_t nq_all = 0;
+    for (int i = 0; i < n; i++) nq_all += nq[i];
+    if (nq_all >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
+    if (n > 4096) return fail(BXMI_EINVAL, "bxmi_ivl_count_multi: more than 4096 indexes in one batch");
     // tile shape: 32768-query tiles halve the number of (tile, bucket) runs the search has to fetch, but their sort
-    // kernel runs one workgroup per CU and wants a grid of several hundred tiles
-    const int variant = g_opt_bm_variant >= 0 ? (int)g_opt_bm_variant : (nq >= ((int64_t)32 << 20) ? 2 : 0);
+    // kernel runs one workgroup per CU and wants a grid of several hundred full tiles
+    const int variant = g_opt_bm_variant >= 0 ? (int)g_opt_bm_variant : (n == 1 && nq_all >= ((int64_t)32 << 20) ? 2 : 0);
     const int tile_log2 = variant == 2 ? 15 : 14;
     const int64_t tile = (int64_t)1 << tile_log2;
-    const int64_t ntiles = div_up(nq, tile);
-    const int ngroups = (int)div_up(ntiles, BM_GROUP_TILES);
-    const int64_t ntp = (int64_t)ngroups * BM_GROUP_TILES;
+    // the batch's tile numbering: every segment starts on a plan-group boundary
+    std::vector<BmSeg> segs((size_t)n);
+    int64_t ntp = 0;
+    size_t max_stride = 0;
+    bool any_total = false;
+    for (int i = 0; i < n; i++) {
+        BmSeg &sg = segs[(size_t)i];
+        sg.g = hs[i]->bm_geom;
+        sg.qs = qs[i], sg.qe = qe[i], sg.counts = counts[i];
+        sg.nq = nq[i];
+        sg.tile0 = ntp;
+        sg.ntiles = div_up(nq[i], tile);
+        sg.images = hs[i]->bm_images.as<uint2>();
+        sg.bmeta = hs[i]->bm_meta.as<BmBucket>();
+        sg.ix = index_dev(hs[i]);
+        sg.e_sorted = hs[i]->e_sorted.as<int32_t>();
+        ntp += div_up(sg.ntiles, BM_GROUP_TILES) * BM_GROUP_TILES;
+        sg.tile_end = ntp;
+        if ((size_t)sg.g.stride > max_stride) max_stride = (size_t)sg.g.stride;
+        any_total |= totals_dev && totals_dev[i];
+    }
+    if (ntp == 0) return BXMI_OK;
+    const int ngroups = (int)(ntp / BM_GROUP_TILES);
     // PAIR: a search workgroup holds the images of two neighbouring buckets (needs both in one CU's LDS)
-    const bool pair = g_opt_bm_pair != 0 && (size_t)2 * h->bm_geom.stride * sizeof(uint2) + 8192 <= 160 * 1024;
+    const bool pair = g_opt_bm_pair != 0 && 2 * max_stride * sizeof(uint2) + 8192 <= 160 * 1024;
     const int chunk = pair ? 2 * BM_CHUNK : BM_CHUNK;
-    const int64_t max_items = (pair ? BM_NB / 2 : BM_NB) + 2 * (nq / chunk) + 2;
-    BXMI_TRY(h->bm_recs.reserve((size_t)ntiles * tile * 4));
-    BXMI_TRY(h->bm_slots.reserve((size_t)ntiles * tile * 2));
+    const int64_t max_items = (int64_t)n * ((pair ? BM_NB / 2 : BM_NB) + 2) + 2 * (nq_all / chunk) + 2;
+    BXMI_TRY(h->bm_recs.reserve((size_t)ntp * tile * 4));
+    BXMI_TRY(h->bm_slots.reserve((size_t)ntp * tile * 2));
     BXMI_TRY(h->bm_tbl.reserve((size_t)ntp * BM_NB * 2));
     BXMI_TRY(h->bm_runT.reserve((size_t)ntp * BM_NB * 4));
     BXMI_TRY(h->bm_grpcnt.reserve((size_t)ngroups * BM_NB * 4));
-    BXMI_TRY(h->bm_items.reserve((size_t)(BM_NB + 2 * (nq / BM_CHUNK) + 4) * sizeof(int4)));  // [0] = the item count, items from [1]
-    BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOT_STRIDE * sizeof(unsigned long long)));
-    // [PT_SLOTS partial totals][flag: 1 = the starts are NOT sorted], zeroed together
+    BXMI_TRY(h->bm_items.reserve((size_t)(max_items + 2) * sizeof(int4)));  // [0] = the item count, items from [1]
+    // parameter block in HBM: [segments][totals pointers][tile -> segment], written by bm_params_kernel from its arguments
+    const size_t seg_bytes = (size_t)n * sizeof(BmSeg), tot_bytes = (size_t)n * sizeof(void *);
+    const size_t tile_off = (seg_bytes + tot_bytes + 15) & ~(size_t)15, par_bytes = tile_off + (size_t)ntp * sizeof(unsigned short);
+    BXMI_TRY(h->bm_params.reserve(par_bytes));
+    for (int first = 0; first < n; first += BM_PAR_CHUNK) {
+        BmSegChunk c;
+        memset(&c, 0, sizeof(c));
+        const int cnt = n - first < BM_PAR_CHUNK ? n - first : BM_PAR_CHUNK;
+        for (int i = 0; i < cnt; i++) {
+            c.seg[i] = segs[(size_t)(first + i)];
+            c.total[i] = totals_dev ? reinterpret_cast<unsigned long long *>(totals_dev[first + i]) : nullptr;
+        }
+        hipLaunchKernelGGL(bm_params_kernel, dim3((unsigned)cnt), dim3(256), 0, st, c, first, h->bm_params.as<BmSeg>(),
+                           reinterpret_cast<unsigned long long **>(h->bm_params.as<unsigned char>() + seg_bytes),
+                           reinterpret_cast<unsigned short *>(h->bm_params.as<unsigned char>() + tile_off));
+    }
+    BXMI_LAUNCH_CHECK();
+    // [segments][PT_SLOTS partial totals], then the flag: 1 = the starts are NOT sorted
+    BXMI_TRY(h->p_slots.reserve(((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long)));
     unsigned long long *slots = h->p_slots.as<unsigned long long>();
-    unsigned *unsorted = g_opt_sorted_path ? reinterpret_cast<unsigned *>(slots + PT_SLOTS) : nullptr;
-    BXMI_HIP(hipMemsetAsync(slots, 0, PT_SLOT_STRIDE * sizeof(unsigned long long), st));
-    unsigned long long *tslots = total_dev ? slots : nullptr;
+    unsigned *unsorted = g_opt_sorted_path && n == 1 ? reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS) : nullptr;
+    BXMI_HIP(hipMemsetAsync(slots, 0, ((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long), st));
+    unsigned long long *tslots = any_total ? slots : nullptr;
+    BmLaunch L;
+    L.segs = h->bm_params.as<BmSeg>();
+    L.tile_seg = reinterpret_cast<const unsigned short *>(h->bm_params.as<unsigned char>() + tile_off);
+    L.owner = h;
+    L.ntp = ntp, L.ngroups = ngroups, L.tile_log2 = tile_log2;
+    L.search_lds = (size_t)(pair ? 2 : 1) * max_stride * sizeof(uint2);
+    L.gate = unsorted;
     if (unsorted) {
-        hipLaunchKernelGGL(bm_sorted_check_kernel, dim3(2048), dim3(256), 0, st, qs, nq, unsorted);
-        // sorted batch: one pass over the queries as they lie (exits at once otherwise)
+        // one index, its batch possibly sorted by start already: one pass over the queries as they lie then, and every
+        // kernel below stands down (the local kernel exits at once otherwise)
+        hipLaunchKernelGGL(bm_sorted_check_kernel, dim3(2048), dim3(256), 0, st, qs[0], nq[0], unsorted);
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
-        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
-                           h->e_sorted.as<int32_t>(), qs, qe, nq, counts, tslots, unsorted);
+        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)div_up(nq[0], LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
+                           h->e_sorted.as<int32_t>(), qs[0], qe[0], nq[0], counts[0], tslots, unsorted);
         BXMI_LAUNCH_CHECK();
     }
     if (variant == 2)
-        BXMI_TRY((bm_launch_tiles<1024, 32>(h, qs, qe, nq, ntiles, unsorted, st)));
+        BXMI_TRY((bm_launch_tiles<1024, 32>(L, st)));
     else if (variant == 1)
-        BXMI_TRY((bm_launch_tiles<1024, 16>(h, qs, qe, nq, ntiles, unsorted, st)));
+        BXMI_TRY((bm_launch_tiles<1024, 16>(L, st)));
     else
-        BXMI_TRY((bm_launch_tiles<512, 32>(h, qs, qe, nq, ntiles, unsorted, st)));
-    hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), ntiles, nq, tile_log2,
-                       h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
+        BXMI_TRY((bm_launch_tiles<512, 32>(L, st)));
+    hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
+                       tile_log2, h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
     if (pair)
-        hipLaunchKernelGGL(bm_plan_kernel<1>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, ntiles, chunk,
+        hipLaunchKernelGGL(bm_plan_kernel<1>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
                            h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     else
-        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, ntiles, chunk,
+        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
                            h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     BXMI_LAUNCH_CHECK();
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
     if (pair)
-        BXMI_TRY(bm_launch_search_u<true>(h, sgrid, ntp, tile_log2, unsorted, st));
+        BXMI_TRY(bm_launch_search_u<true>(L, sgrid, st));
     else
-        BXMI_TRY(bm_launch_search_u<false>(h, sgrid, ntp, tile_log2, unsorted, st));
+        BXMI_TRY(bm_launch_search_u<false>(L, sgrid, st));
     if (variant == 2)
-        BXMI_TRY((bm_launch_unpermute<1024, 32>(h, qs, qe, nq, ntiles, counts, tslots, unsorted, st)));
+        BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st)));
     else
-        BXMI_TRY((bm_launch_unpermute<1024, 16>(h, qs, qe, nq, ntiles, counts, tslots, unsorted, st)));
-    if (total_dev) {
-        hipLaunchKernelGGL(part_fold_total_kernel, dim3(1), dim3(64), 0, st, slots, reinterpret_cast<unsigned long long *>(total_dev));
+        BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st)));
+    if (any_total) {
+        hipLaunchKernelGGL(bm_fold_totals_kernel, dim3((unsigned)n), dim3(64), 0, st, slots,
+                           reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes));
         BXMI_LAUNCH_CHECK();
     }
     return BXMI_OK;
+}
+
+static int ivl_count_bitmap(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total_dev, hipStream_t st)
+{
+    return bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &total_dev, st);
 }
 
 static int ivl_stream(bxmi_ivl *h)
@@ -2790,6 +2857,45 @@ extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_
         hipLaunchKernelGGL(ivl_count_kernel<false>, dim3(grid), dim3(CNT_THREADS), lds_bytes, st, S, E, index_dev(h), qs, qe, nq, counts, tot);
     }
     BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
+                                        int32_t *const *counts, int64_t *const *totals_dev, void *stream)
+{
+    if (n < 0 || (n > 0 && (!hs || !qs || !qe || !nq))) return fail(BXMI_EINVAL, "bxmi_ivl_count_multi_dev: bad arguments");
+    hipStream_t st = as_stream(stream);
+    // indexes whose batch can ride the bitmap-cell pass are answered together (one pass, six launches); the others one by one
+    std::vector<bxmi_ivl *> fh;
+    std::vector<const int32_t *> fqs, fqe;
+    std::vector<int64_t> fnq;
+    std::vector<int32_t *> fc;
+    std::vector<int64_t *> ft;
+    std::vector<int> rest;
+    int64_t nq_all = 0;
+    for (int i = 0; i < n; i++) {
+        BXMI_TRY(need_sealed(hs[i], "bxmi_ivl_count_multi_dev"));
+        if (nq[i] < 0 || (nq[i] > 0 && (!qs[i] || !qe[i]))) return fail(BXMI_EINVAL, "bxmi_ivl_count_multi_dev: bad arguments for index %d", i);
+        if (((uintptr_t)qs[i] | (uintptr_t)qe[i] | (uintptr_t)(counts ? counts[i] : nullptr)) & 15)
+            return fail(BXMI_EINVAL, "bxmi_ivl_count_multi_dev: query/count arrays must be 16-byte aligned");
+        nq_all += nq[i];
+    }
+    const bool fused = g_opt_bitmap != 0 && counts && (g_opt_partition == 1 || (g_opt_partition < 0 && nq_all >= g_opt_bitmap_min));
+    for (int i = 0; i < n; i++) {
+        bxmi_ivl *h = hs[i];
+        if (nq[i] == 0) continue;
+        bool ok = fused && counts[i] && !h->has_reversed && h->n >= 4096;
+        if (ok && h->bm_state == 0) BXMI_TRY(bm_prepare_index(h, st));
+        if (ok && h->bm_state == 1) {
+            fh.push_back(h), fqs.push_back(qs[i]), fqe.push_back(qe[i]), fnq.push_back(nq[i]), fc.push_back(counts[i]);
+            ft.push_back(totals_dev ? totals_dev[i] : nullptr);
+        } else {
+            rest.push_back(i);
+        }
+    }
+    if (!fh.empty()) BXMI_TRY(bm_count_segments(fh.data(), (int)fh.size(), fqs.data(), fqe.data(), fnq.data(), fc.data(), ft.data(), st));
+    for (int i : rest)
+        BXMI_TRY(bxmi_ivl_count_dev(hs[i], qs[i], qe[i], nq[i], counts ? counts[i] : nullptr, totals_dev ? totals_dev[i] : nullptr, stream));
     return BXMI_OK;
 }
 

@@ -101,6 +101,12 @@ int bxmi_ivl_count(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t 
 /* Device variant: *total_dev (device int64) is ACCUMULATED into (zero it first). */
 int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
                        int64_t *total_dev, void *stream);
+/* A dict of per-chromosome trees queried in one go (scripts/interval_join.py:21-28 keeps {chrom: Intersecter}; a genome-wide
+ * batch asks every tree with its own chromosome's queries): exactly n calls of bxmi_ivl_count_dev -- hs[i] with
+ * qs[i][0..nq[i]), counts[i] and totals_dev[i] (each optional / accumulated as there) -- but the indexes that qualify for
+ * the bitmap-cell pass share ONE pass: a fixed handful of launches for the whole genome instead of one set per chromosome. */
+int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
+                             int32_t *const *counts, int64_t *const *totals_dev, void *stream);
 /* Which large-batch count pass serves this sealed index: *state = 0 not decided yet (no large batch so far), 1 = the
  * bitmap-cell pass (count_bitmap.hpp: its per-bucket images are built), -1 = the bucketed search pass (span wider than
  * 2^28, reversed targets, or too many coordinates carrying duplicates: *hard_cells of them).  Introspection only. */

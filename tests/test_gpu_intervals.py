@@ -530,6 +530,53 @@ def test_genome_sharded_count_single_rank():
         assert totals[chrom] == int(want.sum())
 
 
+def test_count_multi_equals_one_index_at_a_time(O, IntervalIndex):
+    """bxmi_ivl_count_multi_dev (one fused bitmap-cell pass over several indexes = a dict of per-chromosome trees) against
+    the oracle and against per-index calls: indexes of different spans (bucket widths 2^10 .. 2^17), one with reversed
+    targets and one too wide for the bitmap cells (both answered by the per-index path inside the same call), ragged
+    batch sizes incl. an empty one, escapes."""
+    from bxmi import _ffi
+
+    rng = np.random.default_rng(31)
+    specs = [(60_000, 2_000_000, 300_001), (9_000, 250_000_000, 70_000), (200_000, 40_000_000, 16384 * 5), (5_000, 900_000, 0),
+             (30_000, 2**30, 50_000), (20_000, 5_000_000, 40_000)]
+    ixs, dev, want = [], [], []
+    for k, (n, span, nq) in enumerate(specs):
+        s = rng.integers(0, span, size=n)
+        e = s + rng.integers(0, 2000, size=n)
+        if k == 5:
+            e[3] = s[3] - 7  # reversed target: this index stays on the direct kernel
+        qs = rng.integers(-1000, span + 3000, size=nq)
+        qe = qs + rng.integers(0, 4000, size=nq)
+        if nq:
+            qe[::97] = qs[::97] + 40_000  # longer than a record holds
+            qe[::89] = qs[::89] - 3       # reversed
+        s, e, qs, qe = (a.astype(np.int32) for a in (s, e, qs, qe))
+        t = O.OracleIntervalTree()
+        t.insert_many_arrays(s, e)
+        want.append(t.count_batch(qs, qe))
+        ixs.append(make_index(IntervalIndex, s, e))
+        dev.append((_ffi.DeviceArray.from_numpy(qs), _ffi.DeviceArray.from_numpy(qe), _ffi.DeviceArray(4 * max(nq, 4)), nq))
+    totals = _ffi.DeviceArray(8 * len(specs))
+    set_opt("ivl.partition", 1)
+    try:
+        for pair, variant in ((1, -1), (0, 0), (1, 2)):
+            set_opt("ivl.bm_pair", pair)
+            set_opt("ivl.bm_variant", variant)
+            totals.zero()
+            IntervalIndex.count_multi_dev(ixs, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [d[3] for d in dev], [d[2].ptr for d in dev],
+                                          [totals.ptr + 8 * i for i in range(len(specs))], None)
+            _ffi.call("bxmi_synchronize", None)
+            tot = totals.to_numpy(np.int64, len(specs))
+            for k, (wc, wt) in enumerate(want):
+                got = dev[k][2].to_numpy(np.int32, dev[k][3])
+                bad = np.nonzero(got != wc)[0]
+                assert len(bad) == 0 and int(tot[k]) == wt, (pair, variant, k, ixs[k].bitmap_state(), bad[:5], got[bad[:5]], wc[bad[:5]], int(tot[k]), wt)
+        assert [ix.bitmap_state()[0] for ix in ixs] == [1, 1, 1, 0, -1, 0]  # empty batch: never looked at; too wide; reversed targets
+    finally:
+        reset_opts()
+
+
 def test_genome_cfg4_full_size_golden(golden_scale_doc, IntervalIndex):
     """BASELINE configs[3] at full size on one GPU: synth.cfg4 (24 chromosomes, 10M targets x 100M queries by chromosome
     length), one index per chromosome.  Every 100th count of every chromosome against the reference treap's hash
