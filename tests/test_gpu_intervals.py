@@ -684,6 +684,39 @@ def test_find_join_scale_properties(IntervalIndex):
         assert sorted(got.tolist()) == want.tolist()
 
 
+def test_find_join_cfg5_full_size_golden(golden_scale_doc, IntervalIndex):
+    """BASELINE configs[4] at full size: 50M x 50M (synth.cfg5), CSR hit lists.  Every 500th query's hit LIST (insertion
+    indices in the reference's order) against the reference treap over all 50M targets (tests/golden/scale.json
+    "cfg5_join", made by oracle/gen_golden.py --only join), both for the batch as generated (bucketed find) and sorted by
+    start (local find); the whole result against the count pass."""
+    g = golden_scale_doc.get("cfg5_join")
+    if not g:
+        pytest.skip("tests/golden/scale.json has no cfg5_join point")
+    (ts, te), (qs, qe) = synth.cfg5(g["n_targets"], g["n_queries_total"])
+    ix = make_index(IntervalIndex, ts, te)
+    offs, hits = ix.find(qs, qe, cap_hint=6 * len(qs))
+    lens = np.diff(offs)
+    st = g["stride"]
+    sub = np.arange(0, len(qs), st)
+    assert len(sub) == g["n_queries"]
+    sub_counts = lens[sub].astype(np.int32)
+    assert int(sub_counts.sum(dtype=np.int64)) == g["total"]
+    assert hashlib.sha256(np.ascontiguousarray(sub_counts).tobytes()).hexdigest() == g["counts_sha256"]
+    sub_hits = np.concatenate([hits[offs[i]:offs[i + 1]] for i in sub.tolist()]).astype(np.int32)
+    assert sub_hits[:16].tolist() == g["first_hits"]
+    assert hashlib.sha256(np.ascontiguousarray(sub_hits).tobytes()).hexdigest() == g["hits_sha256"], "hit lists differ from the reference's"
+    counts, total = ix.count(qs, qe)
+    assert total == offs[-1] == len(hits) and np.array_equal(counts, lens.astype(np.int32))
+    # the same queries sorted by start: every query must get the same list
+    order = np.argsort(qs, kind="stable")
+    s_offs, s_hits = ix.find(qs[order], qe[order], cap_hint=6 * len(qs))
+    assert np.array_equal(np.diff(s_offs), lens[order])
+    inv = np.empty(len(order), dtype=np.int64)
+    inv[order] = np.arange(len(order))
+    s_sub = np.concatenate([s_hits[s_offs[j]:s_offs[j + 1]] for j in inv[sub].tolist()]).astype(np.int32)
+    assert np.array_equal(s_sub, sub_hits)
+
+
 # -------------------------------------------------------------- compat API --
 def test_compat_intervaltree_known_answers():
     """lib/bx/intervals/intersection_tests.py:158-201 and the doctests intersection.pyx:335-376."""
