@@ -611,6 +611,8 @@ struct bxmi_bits {
     int32_t size = 0, bin_size = 0, nbins = 0;
     int64_t total_bits = 0;  // bins cover [0, nbins*bin_size) >= size
     int64_t nwords = 0;      // even, so the words can be read as 16-byte pairs
+    int64_t cap_words = 0;   // words actually allocated: [0, cap_words) hold bits, everything beyond is zero (see bits_need)
+    bool bounded_call = false;  // a host entry point has already sized / clamped for the `_dev` form it is about to call
     DevBuf words, tags;
     bool maybe_one = false;  // some bin may be ALL_ONE (only after invert / ior with such a set)
     bool flat = false;       // plain BitSet (bitset.pyx:107-173): no bins, no tri-state quirks
@@ -622,6 +624,45 @@ struct bxmi_bits {
 static int bits_stream(bxmi_bits *h)
 {
     if (!h->stream) BXMI_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    return BXMI_OK;
+}
+
+// The reference allocates a bin (64 KiB at the default granularity) the first time a bit in it is set
+// (binBits.c:98-128), which is what lets bitset_builders.py create one MAX-sized set per sequence name of a
+// scaffold-level assembly.  Here the words are one dense array, allocated LAZILY up to the highest bit any operation has
+// needed so far: a fresh set owns no words at all, `set_range` grows the array to the end of the batch (rounded up to whole
+// bins, at least doubling), reads treat everything past the allocated part as the zeros it logically is.  Operations
+// that cannot bound what they touch (the stream-ordered `_dev` forms, groups, invert, the raw word view) ask for the whole array.
+constexpr int64_t BITS_ALL = -1;
+static int64_t cap_bits(const bxmi_bits *h) { return h->cap_words * 64; }
+
+static int bits_need(bxmi_bits *h, int64_t upto_bits /* exclusive; BITS_ALL = the whole set */)
+{
+    int64_t want = h->nwords;
+    if (upto_bits != BITS_ALL) {
+        if (upto_bits <= cap_bits(h)) return BXMI_OK;
+        const int64_t bins = div_up(upto_bits, h->bin_size);
+        want = (div_up(bins * (int64_t)h->bin_size, 64) + 1) & ~1ll;
+        if (want < 2 * h->cap_words) want = 2 * h->cap_words;
+        if (want > h->nwords) want = h->nwords;
+    }
+    if (want <= h->cap_words) return BXMI_OK;
+    void *np = nullptr;
+    const size_t bytes = (size_t)want * 8 + 64;
+    hipError_t e = hipMalloc(&np, bytes);
+    if (e != hipSuccess)
+        return fail(BXMI_ENOMEM, "BinnedBitSet of %d bits: no room for %zu MiB of words on the device (%s); every set holds dense words up "
+                    "to its highest set bit -- size the sets with `lens` instead of the 512 Mi default", h->size, bytes >> 20, hipGetErrorString(e));
+    if (h->cap_words) e = hipMemcpy(np, h->words.p, (size_t)h->cap_words * 8, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemset(static_cast<char *>(np) + (size_t)h->cap_words * 8, 0, bytes - (size_t)h->cap_words * 8);
+    if (e != hipSuccess) {
+        (void)hipFree(np);
+        return fail(BXMI_EHIP, "bits_need: %s", hipGetErrorString(e));
+    }
+    h->words.release();
+    h->words.p = np;
+    h->words.cap = bytes;
+    h->cap_words = want;
     return BXMI_OK;
 }
 
@@ -652,9 +693,7 @@ extern "C" int bxmi_bits_create(int64_t size, int64_t granularity, bxmi_bits_t *
         h->total_bits = tag_count * h->bin_size;
     }
     h->nwords = (div_up(h->total_bits, 64) + 1) & ~1ll;
-    int rc = h->words.reserve((size_t)h->nwords * 8 + 64);
-    if (rc == BXMI_OK) rc = h->tags.reserve((size_t)tag_count + 64);
-    if (rc == BXMI_OK && hipMemset(h->words.p, 0, h->words.cap) != hipSuccess) rc = fail(BXMI_EHIP, "hipMemset failed");
+    int rc = h->tags.reserve((size_t)tag_count + 64);  // the words come with the first bit (bits_need)
     if (rc == BXMI_OK && hipMemset(h->tags.p, 0, h->tags.cap) != hipSuccess) rc = fail(BXMI_EHIP, "hipMemset failed");
     if (rc != BXMI_OK) {
         delete h;
@@ -685,6 +724,7 @@ extern "C" int bxmi_bits_info(const bxmi_bits_t *h, int32_t *size, int32_t *bin_
 extern "C" int bxmi_bits_words_dev(bxmi_bits_t *h, uint64_t **words_dev, int64_t *nwords)
 {
     if (!h) return fail(BXMI_EINVAL, "bxmi_bits_words_dev: NULL handle");
+    BXMI_TRY(bits_need(h, BITS_ALL));
     if (words_dev) *words_dev = h->words.as<uint64_t>();
     if (nwords) *nwords = h->nwords;
     return BXMI_OK;
@@ -709,7 +749,7 @@ extern "C" int bxmi_bits_get(bxmi_bits_t *h, int32_t pos, int *bit)
     BXMI_TRY(check_pos(h, pos, "bxmi_bits_get"));
     if (!bit) return fail(BXMI_EINVAL, "bxmi_bits_get: bit is NULL");
     unsigned long long w = 0;
-    BXMI_HIP(hipMemcpy(&w, h->words.as<unsigned long long>() + (pos >> 6), 8, hipMemcpyDeviceToHost));
+    if (pos < cap_bits(h)) BXMI_HIP(hipMemcpy(&w, h->words.as<unsigned long long>() + (pos >> 6), 8, hipMemcpyDeviceToHost));
     *bit = (int)((w >> (pos & 63)) & 1ull);
     return BXMI_OK;
 }
@@ -717,6 +757,7 @@ extern "C" int bxmi_bits_get(bxmi_bits_t *h, int32_t pos, int *bit)
 static int bits_point(bxmi_bits *h, int32_t pos, int set)
 {
     BXMI_TRY(bits_stream(h));
+    BXMI_TRY(bits_need(h, h->maybe_one ? BITS_ALL : (int64_t)pos + 1));
     hipLaunchKernelGGL(bits_point_kernel, dim3(1), dim3(64), 0, h->stream, h->words.as<unsigned long long>(), h->tags.as<uint8_t>(),
                        (int64_t)pos, (int64_t)(pos / h->bin_size), set);
     BXMI_LAUNCH_CHECK();
@@ -740,6 +781,7 @@ extern "C" int bxmi_bits_set_ranges_dev(bxmi_bits_t *h, const int32_t *start, co
 {
     if (!h || n < 0 || (n > 0 && (!start || !len))) return fail(BXMI_EINVAL, "bxmi_bits_set_ranges_dev: bad arguments");
     if (n == 0) return BXMI_OK;
+    if (!h->bounded_call) BXMI_TRY(bits_need(h, BITS_ALL));  // device-resident ranges: their extent is not known here
     hipLaunchKernelGGL(bits_set_ranges_kernel, dim3(bits_grid(n, BITS_THREADS)), dim3(BITS_THREADS), 0, as_stream(stream),
                        h->words.as<unsigned long long>(), h->tags.as<uint8_t>(), h->bin_size, start, len, n);
     BXMI_LAUNCH_CHECK();
@@ -775,8 +817,16 @@ extern "C" int bxmi_bits_set_ranges(bxmi_bits_t *h, const int32_t *start, const 
     if (!h || n < 0 || (n > 0 && (!start || !len))) return fail(BXMI_EINVAL, "bxmi_bits_set_ranges: bad arguments");
     if (n == 0) return BXMI_OK;
     BXMI_TRY(validate_ranges(h, start, len, n, "bxmi_bits_set_ranges"));
+    int64_t top = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (len[i] > 0 && (int64_t)start[i] + len[i] > top) top = (int64_t)start[i] + len[i];
+    if (top == 0) return BXMI_OK;  // nothing but empty ranges: no bin is touched (binBits.c:101)
+    BXMI_TRY(bits_need(h, h->maybe_one ? BITS_ALL : top));
     BXMI_TRY(upload_ranges(h, start, len, n));
-    BXMI_TRY(bxmi_bits_set_ranges_dev(h, h->q_a.as<int32_t>(), h->q_b.as<int32_t>(), n, h->stream));
+    h->bounded_call = true;
+    const int rc = bxmi_bits_set_ranges_dev(h, h->q_a.as<int32_t>(), h->q_b.as<int32_t>(), n, h->stream);
+    h->bounded_call = false;
+    BXMI_TRY(rc);
     BXMI_HIP(hipStreamSynchronize(h->stream));
     return BXMI_OK;
 }
@@ -786,6 +836,7 @@ extern "C" int bxmi_bits_count_ranges_dev(bxmi_bits_t *h, const int32_t *start, 
 {
     if (!h || n < 0 || (n > 0 && (!start || !len || !out))) return fail(BXMI_EINVAL, "bxmi_bits_count_ranges_dev: bad arguments");
     if (n == 0) return BXMI_OK;
+    if (!h->bounded_call) BXMI_TRY(bits_need(h, BITS_ALL));
     hipLaunchKernelGGL(bits_count_ranges_kernel, dim3(bits_grid(n, BITS_THREADS)), dim3(BITS_THREADS), 0, as_stream(stream),
                        h->words.as<unsigned long long>(), h->maybe_one ? h->tags.as<uint8_t>() : nullptr, h->bin_size, start, len, n, out);
     BXMI_LAUNCH_CHECK();
@@ -797,9 +848,31 @@ extern "C" int bxmi_bits_count_ranges(bxmi_bits_t *h, const int32_t *start, cons
     if (!h || n < 0 || (n > 0 && (!start || !len || !out))) return fail(BXMI_EINVAL, "bxmi_bits_count_ranges: bad arguments");
     if (n == 0) return BXMI_OK;
     BXMI_TRY(validate_ranges(h, start, len, n, "bxmi_bits_count_ranges"));
-    BXMI_TRY(upload_ranges(h, start, len, n));
+    if (h->cap_words < h->nwords) {
+        // bits past the allocated words are zero (and no bin there is ALL_ONE: invert allocates everything): count what lies
+        // inside, on clamped copies of the ranges
+        const int64_t cap = cap_bits(h);
+        if (cap == 0) {
+            memset(out, 0, (size_t)n * 4);
+            return BXMI_OK;
+        }
+        std::vector<int32_t> cs((size_t)n), cl((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t s0 = start[i], e0 = s0 + len[i];
+            const bool in = s0 < cap;
+            cs[(size_t)i] = in ? (int32_t)s0 : 0;
+            cl[(size_t)i] = in ? (int32_t)((e0 < cap ? e0 : cap) - s0) : 0;
+        }
+        BXMI_TRY(upload_ranges(h, cs.data(), cl.data(), n));
+        BXMI_HIP(hipStreamSynchronize(h->stream));  // the staging vectors die with this scope
+    } else {
+        BXMI_TRY(upload_ranges(h, start, len, n));
+    }
     BXMI_TRY(h->q_out.reserve((size_t)(n + 4) * 4));
-    BXMI_TRY(bxmi_bits_count_ranges_dev(h, h->q_a.as<int32_t>(), h->q_b.as<int32_t>(), n, h->q_out.as<int32_t>(), h->stream));
+    h->bounded_call = true;
+    const int rc = bxmi_bits_count_ranges_dev(h, h->q_a.as<int32_t>(), h->q_b.as<int32_t>(), n, h->q_out.as<int32_t>(), h->stream);
+    h->bounded_call = false;
+    BXMI_TRY(rc);
     BXMI_HIP(hipMemcpyAsync(out, h->q_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
     BXMI_HIP(hipStreamSynchronize(h->stream));
     return BXMI_OK;
@@ -811,6 +884,11 @@ extern "C" int bxmi_bits_count_range(bxmi_bits_t *h, int32_t start, int32_t len,
     BXMI_TRY(validate_ranges(h, &start, &len, 1, "bxmi_bits_count_range"));
     *out = 0;
     if (len == 0) return BXMI_OK;
+    if (h->cap_words < h->nwords) {  // past the allocated words everything is zero
+        const int64_t cap = cap_bits(h);
+        if (start >= cap) return BXMI_OK;
+        if ((int64_t)start + len > cap) len = (int32_t)(cap - start);
+    }
     if (len < (1 << 20)) {  // up to 16 Ki words: one workgroup, result straight into host-visible memory
         BXMI_TRY(bits_stream(h));
         if (!h->one_buf) BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->one_buf), 64, hipHostMallocDefault));
@@ -849,7 +927,17 @@ extern "C" int bxmi_bits_next(bxmi_bits_t *h, int32_t start, int val, int32_t *o
     BXMI_TRY(h->acc.reserve(64));
     // The reference scans whole bins, i.e. up to nbins*bin_size, and a hit in the padding of the
     // last bin is reported as-is; the first such index is `size`, so clamping is exact.
-    const int64_t limit = h->total_bits;
+    int64_t limit = h->total_bits;
+    if (h->cap_words < h->nwords) {
+        // zeros from the end of the allocated words on: a set bit can only be found before it, a clear one is there at the latest
+        const int64_t cap = cap_bits(h);
+        if (start >= cap) {
+            *out = val ? h->size : start;
+            return BXMI_OK;
+        }
+        limit = cap;
+    }
+    const int64_t scanned_to = limit;
     const unsigned long long none = ~0ull;
     int64_t w_begin = start >> 6, w_all = div_up(limit, 64);
     // stage 1: the next 64 Ki bits with one workgroup; stage 2: the rest of the chromosome, whole grid
@@ -865,6 +953,7 @@ extern "C" int bxmi_bits_next(bxmi_bits_t *h, int32_t start, int val, int32_t *o
         BXMI_HIP(hipMemcpyAsync(&res, h->acc.p, 8, hipMemcpyDeviceToHost, h->stream));
         BXMI_HIP(hipStreamSynchronize(h->stream));
     }
+    if (res == none && !val && scanned_to < h->size) res = (unsigned long long)scanned_to;  // the first bit past the allocated words is clear
     *out = (res == none || res >= (unsigned long long)h->size) ? h->size : (int32_t)res;
     return BXMI_OK;
 }
@@ -882,11 +971,21 @@ static int same_shape(const bxmi_bits *a, const bxmi_bits *b, const char *who)
 template <int OP, bool COUNT>
 static int bits_binary(bxmi_bits *h, const bxmi_bits *other, unsigned long long *acc_dev, hipStream_t st)
 {
-    int64_t npairs = h->nwords >> 1;
+    // Lazily allocated operands (bits_need): past its allocated words a set is all zeros.  AND leaves nothing of `h` beyond
+    // `other`'s words; OR / XOR need `h` to reach as far as `other` does.
+    if (OP == 0) {
+        if (other->cap_words < h->cap_words)
+            BXMI_HIP(hipMemsetAsync(h->words.as<unsigned long long>() + other->cap_words, 0, (size_t)(h->cap_words - other->cap_words) * 8, st));
+    } else if (h->cap_words < other->cap_words) {
+        BXMI_TRY(bits_need(h, other->cap_words == other->nwords ? BITS_ALL : other->cap_words * 64));
+    }
+    const int64_t nw = h->cap_words < other->cap_words ? h->cap_words : other->cap_words;  // words both operands own
+    const int64_t npairs = nw >> 1;
+    const int64_t nb = h->flat || OP == 2 ? 0 : div_up(h->total_bits, h->bin_size);
+    if (npairs == 0 && nb == 0) return BXMI_OK;
     // a workgroup moves BITS_UNROLL x 4 KiB per operand and sweep; counting variants stay at one workgroup per CU
     int grid = bits_grid(npairs, BITS_THREADS * BITS_UNROLL);
     if (COUNT && grid > device_props().cus) grid = device_props().cus;
-    const int64_t nb = h->flat || OP == 2 ? 0 : div_up(h->total_bits, h->bin_size);
     hipLaunchKernelGGL((bits_binary_kernel<OP, COUNT>), dim3(grid), dim3(BITS_THREADS), 0, st,
                        h->words.as<unsigned long long>(), other->words.as<unsigned long long>(), npairs, (int64_t)h->size, acc_dev,
                        h->tags.as<uint8_t>(), other->tags.as<uint8_t>(), nb);
@@ -921,7 +1020,8 @@ extern "C" int bxmi_bits_and_count_dev(bxmi_bits_t *h, const bxmi_bits_t *other,
 extern "C" int bxmi_bits_popcount_dev(bxmi_bits_t *h, int64_t *count_dev, void *stream)
 {
     if (!h || !count_dev) return fail(BXMI_EINVAL, "bxmi_bits_popcount_dev: bad arguments");
-    int64_t npairs = h->nwords >> 1;
+    int64_t npairs = h->cap_words >> 1;  // (nothing is set past the allocated words)
+    if (npairs == 0) return BXMI_OK;
     int grid = bits_grid(npairs, BITS_THREADS * BITS_UNROLL);
     if (grid > device_props().cus) grid = device_props().cus;
     hipLaunchKernelGGL(bits_popcount_kernel, dim3(grid), dim3(BITS_THREADS), 0, as_stream(stream),
@@ -976,6 +1076,7 @@ extern "C" int bxmi_bits_not(bxmi_bits_t *h)
 {
     if (!h) return fail(BXMI_EINVAL, "bxmi_bits_not: NULL handle");
     BXMI_TRY(bits_stream(h));
+    BXMI_TRY(bits_need(h, BITS_ALL));  // every untouched bit becomes a one
     hipLaunchKernelGGL(bits_not_kernel, dim3(bits_grid(h->nwords, BITS_THREADS * 2)), dim3(BITS_THREADS), 0, h->stream,
                        h->words.as<unsigned long long>(), h->nwords, h->total_bits);
     int64_t nb = div_up(h->total_bits, h->bin_size);
@@ -994,7 +1095,10 @@ extern "C" int bxmi_bits_runs(bxmi_bits_t *h, int32_t from, int32_t *run_start, 
     if (from == h->size) return BXMI_OK;
     BXMI_TRY(bits_stream(h));
     hipStream_t st = h->stream;
-    const int64_t size = h->size;
+    // past the allocated words there is no set bit, hence no run: scan [from, min(size, allocated bits)) -- a run that
+    // reaches the end of the allocated words ends there, as the next bit is a zero
+    const int64_t size = h->cap_words < h->nwords && cap_bits(h) < h->size ? cap_bits(h) : h->size;
+    if (from >= size) return BXMI_OK;
     int64_t w_first = from >> 6, w_last = (size - 1) >> 6;
     int64_t ntiles = div_up(w_last - w_first + 1, RUN_TILE);
     BXMI_TRY(h->tiles_s.reserve((size_t)(ntiles + 2) * 4));
@@ -1046,6 +1150,10 @@ extern "C" int bxmi_bits_group_create(bxmi_bits_t *const *members, int n, bxmi_b
             return fail(BXMI_EINVAL, "bxmi_bits_group_create: member %d is NULL", i);
         }
         g->members.push_back(m);
+        if (bits_need(m, BITS_ALL) != BXMI_OK) {  // a group addresses whole members
+            delete g;
+            return BXMI_ENOMEM;
+        }
         GroupSeg &s = segs[(size_t)i];
         s.words = m->words.as<unsigned long long>();
         s.tags = m->tags.as<uint8_t>();

@@ -227,6 +227,89 @@ def test_group_ops_match_per_member_ops(O):
         assert d.count_range(0, d.size) == o.count_range(0, o.size)
 
 
+def test_thousands_of_default_sized_sets_stay_small(O, B):
+    """bitset_builders.py:31-45 creates one BinnedBitSet(MAX) per sequence name; a scaffold-level assembly has thousands.
+    The reference allocates 64 KiB bins on first touch; here the dense words grow lazily to the highest bit needed, so
+    4000 default-sized sets (256 GB if they were allocated whole) with a few low ranges each must fit -- and every
+    operation the scripts use must see the untouched rest as zeros: count_range over the whole set, next_set / next_clear
+    runs, iand / ior between sets of different extents, reads far beyond anything set."""
+    import ctypes
+
+    hip = ctypes.CDLL("libamdhip64.so")  # (the runtime libbxmi already runs on; torch's own copy is not brought in here)
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    rng = np.random.default_rng(12)
+    B.BinnedBitSet(100).count_range(0, 10)  # the runtime's own start-up allocations happen before the first reading
+    free0 = free_bytes()
+    n_sets = 4000
+    sets, oracles = [], []
+    for k in range(n_sets):
+        b = B.BinnedBitSet()  # MAX bits
+        sets.append(b)
+        if k < 40:
+            oracles.append(O.OracleBinnedBitSet())
+    hi = [int(rng.integers(1_000, 3_000_000)) for _ in range(n_sets)]
+    for k, b in enumerate(sets):
+        st = rng.integers(0, hi[k], size=5)
+        ln = rng.integers(1, 900, size=5)
+        for s, c in zip(st.tolist(), ln.tolist()):
+            b.set_range(s, c)
+            if k < 40:
+                oracles[k].set_range(s, c)
+    tot = sum(b.count_range(0, b.size) for b in sets)  # bed_coverage.py:27-29 (flushes every set's queued ranges)
+    assert tot > 0
+    used = free0 - free_bytes()
+    assert used < 8 << 30, "lazy words: %d MiB in use for %d sets" % (used >> 20, n_sets)
+    for k in range(40):
+        b, o = sets[k], oracles[k]
+        assert b.count_range(0, b.size) == o.count_range(0, o.size)
+        assert b.count_range(hi[k] + 5000, 10_000_000) == 0 and b.count_range(B.MAX - 10, 10) == 0
+        assert b.next_set(B.MAX - 5) == o.next_set(B.MAX - 5) == B.MAX
+        assert b.next_clear(400_000_000) == o.next_clear(400_000_000) == 400_000_000
+        pos, runs, oruns = 0, [], []
+        while True:  # bed_intersect_basewise.py:32-38
+            s = b.next_set(pos)
+            if s == b.size:
+                break
+            e = b.next_clear(s)
+            runs.append((s, e))
+            pos = e
+        pos = 0
+        while True:
+            s = o.next_set(pos)
+            if s == o.size:
+                break
+            e = o.next_clear(s)
+            oruns.append((s, e))
+            pos = e
+        assert runs == oruns, k
+        assert b[hi[k] + 100_000] == 0 and b[B.MAX - 1] == 0
+    # sets of different extents against each other
+    for k in range(0, 40, 2):
+        a, b, oa, ob = sets[k], sets[k + 1], oracles[k], oracles[k + 1]
+        if k % 4 == 0:
+            a.iand(b), oa.iand(ob)
+        else:
+            a.ior(b), oa.ior(ob)
+        assert a.count_range(0, a.size) == oa.count_range(0, oa.size), k
+        w = rng.integers(0, 3_500_000, size=50).astype(np.int32)
+        n = rng.integers(0, 5000, size=50).astype(np.int32)
+        assert [a.count_range(int(x), int(y)) for x, y in zip(w[:8], n[:8])] == [oa.count_range(int(x), int(y)) for x, y in zip(w[:8], n[:8])]
+    # a bit far up makes that one set grow, and only that one
+    sets[100].set_range(B.MAX - 1000, 500)
+    assert sets[100].count_range(B.MAX - 2000, 2000) == 500 and sets[100].next_set(3_000_000 + 1000) == B.MAX - 1000
+    inv = sets[101]
+    before = inv.count_range(0, inv.size)
+    inv.invert()
+    assert inv.count_range(0, 100) in (100 - k for k in range(101)) and sets[102].count_range(0, sets[102].size) >= 0
+    inv.invert()
+    assert inv.count_range(0, inv.size) == before
+
+
 def test_batch_errors_match_reference_messages():
     from bxmi.bitset import DeviceBitSet
 
