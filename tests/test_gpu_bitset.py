@@ -263,7 +263,9 @@ def test_thousands_of_default_sized_sets_stay_small(O, B):
     tot = sum(b.count_range(0, b.size) for b in sets)  # bed_coverage.py:27-29 (flushes every set's queued ranges)
     assert tot > 0
     used = free0 - free_bytes()
-    assert used < 8 << 30, "lazy words: %d MiB in use for %d sets" % (used >> 20, n_sets)
+    # ~4 MiB per set: the device allocator hands out 2 MiB blocks and a set owns a few buffers (words, tags, range staging);
+    # 64 MiB each if the words were allocated whole
+    assert used < 24 << 30, "lazy words: %d MiB in use for %d sets" % (used >> 20, n_sets)
     for k in range(40):
         b, o = sets[k], oracles[k]
         assert b.count_range(0, b.size) == o.count_range(0, o.size)
