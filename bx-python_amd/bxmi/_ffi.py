@@ -85,6 +85,10 @@ _SIGNATURES = {
     "bxmi_bed_info": [vp, _p(i64), _p(i32), _p(i64), _p(i64), _p(i64)],
     "bxmi_bed_columns": [vp, _p(vp), _p(vp), _p(vp), _p(vp), _p(vp)],
     "bxmi_bed_emit_lines": [vp, vp, vp, C.c_char_p, C.c_int],
+    "bxmi_tab_parse": [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, _p(vp)],
+    "bxmi_tab_destroy": [vp],
+    "bxmi_tab_info": [vp, _p(i64), _p(i32), _p(i64)],
+    "bxmi_tab_columns": [vp, _p(vp), _p(vp), _p(vp), _p(vp), _p(vp), _p(vp), _p(vp)],
     "bxmi_bits_group_create": [_p(vp), C.c_int, _p(vp)],
     "bxmi_bits_group_destroy": [vp],
     "bxmi_bits_group_and_dev": [vp, vp, vp, vp],
@@ -92,7 +96,7 @@ _SIGNATURES = {
     "bxmi_bits_group_popcount_dev": [vp, vp, vp],
 }
 _OTHER_RESTYPE = {"bxmi_version": (C.c_int, []), "bxmi_last_error": (C.c_char_p, []),
-                  "bxmi_bed_chrom_name": (C.c_char_p, [vp, i32])}
+                  "bxmi_bed_chrom_name": (C.c_char_p, [vp, i32]), "bxmi_tab_chrom_name": (C.c_char_p, [vp, i32])}
 
 EXPORTED = sorted(list(_SIGNATURES) + list(_OTHER_RESTYPE))
 

@@ -154,6 +154,27 @@ class GenomicInterval(TableRow):
             fields[strand_col] = str(strand)
         d["strand"] = strand
 
+    @classmethod
+    def _from_parsed(cls, reader, line, chrom, start, end, strand):
+        """A row the native parser (csrc/bedparse.cpp, table mode) has already accepted: its fields are in the normal
+        form the constructor would write back, so nothing is parsed or rewritten here and the TAB split itself waits
+        until somebody looks at `fields` (a row that is only compared and dropped never pays for it)."""
+        new = object.__new__(cls)
+        d = new.__dict__
+        d["reader"], d["_line"] = reader, line
+        d["chrom_col"], d["start_col"], d["end_col"], d["strand_col"] = reader.chrom_col, reader.start_col, reader.end_col, reader.strand_col
+        d["chrom"], d["start"], d["end"], d["strand"] = chrom, start, end, strand
+        return new
+
+    def __getattr__(self, name):  # only reached for attributes that are not there yet
+        if name == "fields":
+            fields = self.__dict__["fields"] = self.__dict__["_line"].split("\t")
+            return fields
+        if name == "nfields":
+            n = self.__dict__["nfields"] = len(self.fields)
+            return n
+        raise AttributeError(name)
+
     def __setattr__(self, name, value):
         col_attr = _SYNCED.get(name)
         if col_attr is not None:
@@ -193,7 +214,48 @@ class TableReader:
     def __iter__(self):
         return self
 
+    # -- native bulk parse (GenomicIntervalReader only; see _bulk_open) --
+    _bulk = None       # parsed prefix of the input, or None
+    _bulk_i = 0        # lines of it already delivered
+    _bulk_tried = False
+
+    def _bulk_open(self):
+        """Hook: subclasses that know how to pre-parse their input natively return a bxmi.tabio.ParsedTable."""
+        return None
+
+    def _bulk_rest(self):
+        """Switch from the parsed prefix to the per-line code for whatever follows it."""
+        self.input_iter = iter(self._bulk.rest_lines(self.input))
+        self._bulk = None
+
+    def _bulk_item(self, i):
+        """Line i of the parsed prefix as the object the per-line code would have produced (None = not delivered)."""
+        b = self._bulk
+        kind = b.kind[i]
+        if kind == 0:
+            return self._bulk_row(b, i)
+        if kind == 1:
+            return Comment("") if self.return_comments else None
+        line = b.line(i)
+        if kind == 3 and self.header is None:
+            self.header = self.parse_header(line)
+            return self.header if self.return_header else None
+        return self.parse_comment(line) if self.return_comments else None
+
     def __next__(self):
+        if not self._bulk_tried:
+            self._bulk_tried = True
+            self._bulk = self._bulk_open() if self.linenum == 0 else None
+        while self._bulk is not None:
+            i = self._bulk_i
+            if i >= self._bulk.n:
+                self._bulk_rest()
+                break
+            self._bulk_i = i + 1
+            self.linenum += 1
+            item = self._bulk_item(i)
+            if item is not None:
+                return item
         while True:
             line = next(self.input_iter)
             self.linenum += 1
@@ -248,6 +310,22 @@ class GenomicIntervalReader(TableReader):
         self.fix_strand = fix_strand
         self.allow_spaces = allow_spaces
 
+    def _bulk_open(self):
+        # only for the classes of this module as they are (a subclass with its own row or header handling keeps the per-line
+        # path), with the default header rule, on input whose text can be taken as a whole
+        from . import tabio
+
+        cls = type(self)
+        if (cls.parse_row is not GenomicIntervalReader.parse_row or cls.parse_header is not TableReader.parse_header
+                or cls.parse_comment is not TableReader.parse_comment or self.header is not None or not tabio.enabled()):
+            return None
+        return tabio.parse_input(self.input, self.chrom_col, self.start_col, self.end_col, self.strand_col, self.comment_lines_startswith)
+
+    def _bulk_row(self, b, i):
+        strand = b.strand[i]
+        return GenomicInterval._from_parsed(self, b.line(i), b.names[b.chrom[i]], b.start[i], b.end[i],
+                                            self.default_strand if strand == 0 else ("+" if strand == 43 else "-"))
+
     def parse_row(self, line):
         # tab first; any whitespace as a second try when allowed -- the FIRST error is the one reported
         first_error = None
@@ -268,6 +346,7 @@ class GenomicIntervalReader(TableReader):
         lens = {} if lens is None else lens
         bitsets = {}
         last_chrom, last = None, None
+        self._bulk_bitsets(bitsets, lens, BinnedBitSet)  # the natively parsed prefix in one go; the loop below takes the rest
         for row in self:
             if not isinstance(row, GenomicInterval):
                 continue
@@ -286,6 +365,105 @@ class GenomicIntervalReader(TableReader):
         return bitsets
 
 
+def _bulk_bitsets(self, bitsets, lens, BinnedBitSet):
+    """binned_bitsets() over the natively parsed prefix of the input without making a row object per line: what the loop
+    in binned_bitsets does row by row -- new set at a chromosome's first row, start clamped at 0, end at the set's size,
+    set_range -- done per chromosome with one batch call, stopping where that loop would have raised (and raising the
+    same thing), and leaving the reader as if it had iterated those lines (line number, header, and for the wrappers
+    the delivered / skipped bookkeeping, in file order)."""
+    import numpy as np
+
+    if self._bulk_tried or self.linenum != 0:
+        return
+    self._bulk_tried = True
+    b = self._bulk = self._bulk_open()
+    if b is None:
+        return
+    kind = b.kind_a
+    rows = np.nonzero(kind == 0)[0]
+    chrom, st, en = b.chrom_a[rows], b.start_a[rows], b.end_a[rows]
+    keep = self._bulk_keep(b, rows, chrom, en)  # None = every row is delivered
+    kr = rows if keep is None else rows[keep]
+    kc, ks, ke = (chrom, st, en) if keep is None else (chrom[keep], st[keep], en[keep])
+    stop_line = b.n  # first line the row loop would NOT have got past
+    problem = None
+    if len(kr):
+        nn = len(b.names)
+        first = np.full(nn, len(kr), dtype=np.int64)
+        np.minimum.at(first, kc, np.arange(len(kr)))
+        order = [c for c in np.argsort(first, kind="stable").tolist() if first[c] < len(kr)]
+        sizes = np.zeros(nn, dtype=np.int64)
+        cut = len(kr)  # position (among the kept rows) of the first row that raises
+        made = {}
+        for c in order:
+            name = b.names[c]
+            try:
+                size = lens.get(name, MAX)
+                made[c] = BinnedBitSet(size)
+                sizes[c] = made[c].size
+            except ValueError as e:
+                cut = int(first[c])
+                problem = Exception("Invalid chrom length %s in 'lens' dictionary. %s" % (str(size), str(e)))
+                break
+        known = np.zeros(nn, dtype=bool)
+        known[list(made)] = True
+        sz = sizes[kc]
+        cs = np.maximum(ks, 0)
+        ce = np.minimum(ke, sz)
+        cnt = ce - cs
+        bad = known[kc] & ((cs >= sz) | (cnt < 0))
+        pos = np.arange(len(kr))
+        if bad[:cut].any():
+            cut = int(np.argmax(bad[:cut]))
+            problem = ("range", cut)
+        for c in order:
+            if c not in made or first[c] > cut or (first[c] == cut and not isinstance(problem, tuple)):
+                continue
+            bitsets[b.names[c]] = made[c]
+            sel = (kc == c) & (pos < cut) & (cnt > 0)
+            if sel.any():
+                made[c].set_ranges(cs[sel].astype(np.int32), cnt[sel].astype(np.int32))
+        if problem is not None:
+            stop_line = int(kr[cut]) + 1
+    self._bulk_account(b, keep, rows, stop_line)
+    if problem is not None:
+        if isinstance(problem, tuple):
+            c = int(kc[cut])
+            bitsets[b.names[c]].set_range(int(cs[cut]), int(cnt[cut]))  # raises what the row loop would have raised
+            raise AssertionError("unreachable: the range was found invalid")
+        raise problem
+
+
+def _bulk_account(self, b, keep, rows, stop_line):
+    """Reader state after lines [0, stop_line) of the parsed prefix have gone by (plain reader: line number and header)."""
+    if b.n and b.kind[0] == 3 and self.header is None:
+        self.header = self.parse_header(b.line(0))
+    self.linenum = stop_line
+    self._bulk_i = stop_line
+
+
+def _bulk_take(self):
+    """Hand the natively parsed prefix of a fresh reader to a caller that works on its arrays (bxmi.operations): the reader
+    is left as if it had iterated those lines and delivered every one of them.  None if there is nothing to hand over (not
+    fresh, input not parseable that way, or a reader that holds some kinds of lines back)."""
+    if self._bulk_tried or self.linenum != 0 or not (self.return_header and self.return_comments):
+        return None
+    if type(self)._bulk_keep is not GenomicIntervalReader._bulk_keep:
+        return None  # (a wrapper that drops rows: its items are not one per line)
+    self._bulk_tried = True
+    b = self._bulk = self._bulk_open()
+    if b is None:
+        return None
+    self._bulk_account(b, None, None, b.n)
+    return b
+
+
+GenomicIntervalReader._bulk_take = _bulk_take
+GenomicIntervalReader._bulk_bitsets = _bulk_bitsets
+GenomicIntervalReader._bulk_account = _bulk_account
+GenomicIntervalReader._bulk_keep = lambda self, b, rows, chrom, end: None
+
+
 class NiceReaderWrapper(GenomicIntervalReader):
     """Skips unparsable lines and keeps count (intervals/io.py:219-265).  `current_line` is the raw line last read.
     `skip_log` (ours) keeps EVERY skip with the number of items delivered before it, so that a batched operation can
@@ -295,16 +473,54 @@ class NiceReaderWrapper(GenomicIntervalReader):
         self.outstream = kwargs.pop("outstream", None)
         self.print_delegate = kwargs.pop("print_delegate", None)
         GenomicIntervalReader.__init__(self, reader, **kwargs)
-        self.input_wrapper = iter(self.input)
+        self._current_line = None
+        self.input_wrapper = None  # iter(self.input), made when the per-line code first needs it (a parsed prefix may come first)
         self.input_iter = self._tracking_lines()
         self.skipped = 0
         self.skipped_lines = []
         self.skip_log = []
         self.delivered = 0
 
+    @property
+    def current_line(self):
+        """The raw line last read (with its line end), whichever path read it."""
+        b = self._bulk
+        if b is not None and self._bulk_i > 0:
+            return b.raw_line(self._bulk_i - 1)
+        return self._current_line
+
+    @current_line.setter
+    def current_line(self, value):
+        self._current_line = value
+
+    def _bulk_rest(self):
+        self._current_line = self.current_line
+        self.input_wrapper = iter(self._bulk.rest_lines(self.input))
+        self._bulk = None
+
+    def _bulk_account(self, b, keep, rows, stop_line):
+        import numpy as np
+
+        GenomicIntervalReader._bulk_account(self, b, keep, rows, stop_line)
+        kind = b.kind_a[:stop_line]
+        delivered = np.where(kind == 0, True, np.where(kind == 3, self.return_header, self.return_comments))
+        if keep is not None:
+            dropped = rows[~keep]
+            dropped = dropped[dropped < stop_line]
+            delivered[dropped] = False
+            before = np.concatenate([[0], np.cumsum(delivered)])
+            base = self.delivered
+            for i in dropped.tolist():  # in file order, each with the count of items delivered before it
+                self.delivered = base + int(before[i])
+                self.note_skip(i + 1, b.raw_line(i), "Error in BitsetSafeReaderWrapper")
+            self.delivered = base
+        self.delivered += int(delivered.sum())
+
     def _tracking_lines(self):
-        for self.current_line in self.input_wrapper:
-            yield self.current_line
+        if self.input_wrapper is None:
+            self.input_wrapper = iter(self.input)
+        for self._current_line in self.input_wrapper:
+            yield self._current_line
 
     def note_skip(self, linenum, line, message):
         self.skipped += 1
@@ -335,6 +551,12 @@ class BitsetSafeReaderWrapper(NiceReaderWrapper):
         NiceReaderWrapper.__init__(self, reader.input, chrom_col=reader.chrom_col, start_col=reader.start_col,
                                    end_col=reader.end_col, strand_col=reader.strand_col)
         self.lens = {} if lens is None else lens
+
+    def _bulk_keep(self, b, rows, chrom, end):
+        import numpy as np
+
+        limit = np.array([self.lens.get(name, MAX) for name in b.names] or [MAX], dtype=np.int64)
+        return end <= limit[chrom] if len(rows) else np.ones(0, dtype=bool)
 
     def __next__(self):
         while True:

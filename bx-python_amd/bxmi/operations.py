@@ -137,6 +137,40 @@ class _RunTable:
         return poff, gs[keep], ge[keep], off_end
 
 
+class _Items:
+    """The primary's items in order.  The natively parsed prefix (bxmi.tabio) is kept as arrays and a row object is only
+    made when somebody asks for it -- an interval that overlaps nothing is never built; what follows the prefix, or
+    everything when there is no prefix, are the objects the reader delivered."""
+
+    def __init__(self, reader, bulk):
+        self.reader, self.bulk = reader, bulk
+        self.nb = bulk.n if bulk is not None else 0
+        self.objs = [None] * self.nb
+        self.tail_where = []
+        if bulk is not None:  # headers and comments are few: made now (the header through the reader, which keeps it)
+            for i in np.nonzero(bulk.kind_a != 0)[0].tolist():
+                kind = bulk.kind[i]
+                self.objs[i] = reader.header if kind == 3 else (Comment("") if kind == 1 else reader.parse_comment(bulk.line(i)))
+
+    def __len__(self):
+        return len(self.objs)
+
+    def __getitem__(self, i):
+        item = self.objs[i]
+        if item is None:
+            item = self.objs[i] = self.reader._bulk_row(self.bulk, i)
+        return item
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self.objs)))
+
+    def where(self, i):
+        """(line number, raw line) the reader was at when it delivered item i."""
+        if i < self.nb:
+            return i + 1, self.bulk.raw_line(i)
+        return self.tail_where[i - self.nb]
+
+
 class _Primary:
     """The primary reader, drained: items in order with the line bookkeeping the reference would have seen."""
 
@@ -147,10 +181,12 @@ class _Primary:
         self.skipped0 = getattr(reader, "skipped", None)
         self.lines0 = list(getattr(reader, "skipped_lines", []) or [])
         self.base = reader.delivered if self.tracks else 0
-        self.items, self.where = [], []
+        take = getattr(reader, "_bulk_take", None)
+        self.bulk = take() if take is not None else None
+        self.items = _Items(reader, self.bulk)
         for item in reader:
-            self.items.append(item)
-            self.where.append((getattr(reader, "linenum", None), getattr(reader, "current_line", None)))
+            self.items.objs.append(item)
+            self.items.tail_where.append((getattr(reader, "linenum", None), getattr(reader, "current_line", None)))
         self.own = []  # (item index, message)
 
     def skip(self, i, message):
@@ -163,7 +199,7 @@ class _Primary:
         if not self.own or self.skipped0 is None or not hasattr(r, "skipped_lines"):
             return
         self.own.sort(key=lambda t: t[0])
-        events = [(self.base + i + 0.25, (self.where[i][0], self.where[i][1], msg)) for i, msg in self.own]
+        events = [(self.base + i + 0.25, self.items.where(i) + (msg,)) for i, msg in self.own]
         if self.tracks:
             events += [(d - 0.5, entry) for d, entry in r.skip_log[self.log_from:]]
         events.sort(key=lambda t: t[0])
@@ -195,7 +231,31 @@ def _range_error(bits, start, end):
 def _rows_by_chrom(primary, bitsets, start_after_end):
     """Valid interval rows grouped by chromosome: {chrom: (item indices, starts, ends)}; invalid ones are logged."""
     groups = {}
-    for i, item in enumerate(primary.items):
+    nb = 0
+    b = primary.bulk
+    if b is not None:
+        # the natively parsed prefix: rows are valid by construction (start <= end), so only the range check is left
+        nb = b.n
+        rows = np.nonzero(b.kind_a == 0)[0]
+        cid, st, en = b.chrom_a[rows], b.start_a[rows], b.end_a[rows]
+        for c, name in enumerate(b.names):
+            if name not in bitsets:
+                continue
+            sel = cid == c
+            if not sel.any():
+                continue
+            ri, rs, re_ = rows[sel], st[sel], en[sel]
+            size = bitsets[name].size
+            bad = (rs < 0) | (rs >= size) | (re_ > size)
+            for k in np.nonzero(bad)[0].tolist():
+                primary.skip(int(ri[k]), _range_error(bitsets[name], int(rs[k]), int(re_[k])))
+            ok = ~bad
+            groups[name] = ([ri[ok]], [rs[ok]], [re_[ok]])
+        # (dict order = first appearance among the rows that made it, as the loop below would have given)
+        firsts = sorted((int(g[0][0][0]) if len(g[0][0]) else -1, name) for name, g in groups.items())
+        groups = {name: groups[name] for f, name in firsts if f >= 0}
+    for i in range(nb, len(primary.items)):
+        item = primary.items[i]
         if not isinstance(item, GenomicInterval):
             continue
         chrom = item.chrom
@@ -213,8 +273,14 @@ def _rows_by_chrom(primary, bitsets, start_after_end):
             continue
         g = groups.setdefault(chrom, ([], [], []))
         g[0].append(i), g[1].append(start), g[2].append(end)
-    return {c: (np.array(g[0], dtype=np.int64), np.array(g[1], dtype=np.int64), np.array(g[2], dtype=np.int64))
-            for c, g in groups.items()}
+
+    def column(parts):  # arrays of the parsed prefix first (if any), then the plain numbers of the rest
+        arrays = [np.asarray(x, dtype=np.int64) if isinstance(x, np.ndarray) else None for x in parts]
+        lead = [a for a in arrays if a is not None]
+        rest = np.array([x for x, a in zip(parts, arrays) if a is None], dtype=np.int64)
+        return np.concatenate(lead + [rest]) if lead else rest
+
+    return {c: (column(g[0]), column(g[1]), column(g[2])) for c, g in groups.items()}
 
 
 def _covered(bits, starts, ends):
@@ -223,7 +289,24 @@ def _covered(bits, starts, ends):
 
 def _emit(primary, comments, per_item, passthrough=None):
     """Yield in primary order: headers, comments, and for interval rows whatever `per_item` holds."""
-    for i, item in enumerate(primary.items):
+    b = primary.bulk
+    nb = b.n if b is not None else 0
+    if nb:
+        # in the parsed prefix only headers, comments, rows with output and (passthrough) rows of unknown chromosomes matter
+        want = b.kind_a != 0
+        if per_item:
+            idx = np.fromiter((i for i in per_item if i < nb), dtype=np.int64)
+            want[idx] = True
+        if passthrough is not None:
+            for c, name in enumerate(b.names):
+                probe = GenomicInterval._from_parsed(primary.reader, "", name, 0, 0, "+")
+                if passthrough(probe):
+                    want |= (b.kind_a == 0) & (b.chrom_a == c)
+        todo = np.nonzero(want)[0].tolist()
+    else:
+        todo = []
+    for i in todo + list(range(nb, len(primary.items))):
+        item = primary.items[i]
         if isinstance(item, Header):
             yield item
         if isinstance(item, Comment) and comments:

@@ -2042,6 +2042,7 @@ constexpr int PT_MAX_SUB = 1;  // scratch regions are addressed per sub-batch; o
 constexpr int PT_SLOT_STRIDE = PT_SLOTS + 8;  // per sub-batch: the partial totals, then the "unsorted" flag
 static int64_t g_opt_count_cells = 1;  // 1 = direct-addressed cells in the bucket search, 0 = LDS search trees
 static int64_t g_opt_sorted_path = 1;  // 1 = batches whose starts are already sorted skip the bucketing (detected on the device)
+static int64_t g_opt_find_fill = 0;    // bucketed find: 0 = hits written from bucket order, 1 / 2 = from query order (8 lanes / 1 lane per window)
 static int64_t g_opt_bitmap = -1;      // second-generation count pass (count_bitmap.hpp): -1 = when the index qualifies, 0 = never, 1 = same as -1
 static int64_t g_opt_bitmap_min = 2 << 20;  // auto: batches of at least this many queries take it (when the index qualifies)
 static int64_t g_opt_bm_variant = -1;  // tile kernel shape: -1 = by batch size, 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
@@ -2080,6 +2081,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.partition_min")) {
         g_opt_partition_min = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.find_fill")) {
+        g_opt_find_fill = value;
         return 1;
     }
     if (!strcmp(key, "ivl.bitmap_min")) {
@@ -2344,6 +2349,27 @@ static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *q
     if (total_host) *total_host = total;
     if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     if (total == 0) return BXMI_OK;
+    if (g_opt_find_fill) {
+        // Hits written in QUERY order: the windows go back to query order like the counts did (two more gathers), and the fill
+        // then reads the index at random places but stores to consecutive ones -- instead of the other way round below.
+        BXMI_TRY(h->q_lo.reserve((size_t)(nq + 4) * 4));
+        BXMI_TRY(h->q_hi.reserve((size_t)(nq + 4) * 4));
+        hipLaunchKernelGGL(part_gather_kernel<int32_t>, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_lo.as<int32_t>(), lpos, table, ntiles, nq,
+                           h->q_lo.as<int32_t>(), (const unsigned *)nullptr, index_dev(h), (const int32_t *)nullptr, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr);
+        hipLaunchKernelGGL(part_gather_kernel<int32_t>, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_hi.as<int32_t>(), lpos, table, ntiles, nq,
+                           h->q_hi.as<int32_t>(), (const unsigned *)nullptr, index_dev(h), (const int32_t *)nullptr, (const int32_t *)nullptr,
+                           (const int32_t *)nullptr);
+        const int fgrid = device_props().cus * 8;
+        if (g_opt_find_fill == 2)
+            hipLaunchKernelGGL(part_fill_lane_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->q_lo.as<int32_t>(),
+                               h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
+        else
+            hipLaunchKernelGGL(part_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->q_lo.as<int32_t>(),
+                               h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
+        BXMI_LAUNCH_CHECK();
+        return BXMI_OK;
+    }
     const size_t perm_lds = (size_t)PT_TILE * 8 + (PT_NB + 2) * 2 + PT_NB * 4 + 64;
     BXMI_TRY(allow_big_lds(part_permute_i64_kernel, perm_lds));
     hipLaunchKernelGGL(part_permute_i64_kernel, dim3(tgrid), dim3(PT_THREADS), perm_lds, st, reinterpret_cast<const long long *>(offsets), lpos,

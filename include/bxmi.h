@@ -216,6 +216,24 @@ const char *bxmi_bed_chrom_name(const bxmi_bed_t *b, int32_t id);
 /* Write the lines with mask[row] != 0, each followed by `suffix`, to file descriptor fd. */
 int bxmi_bed_emit_lines(const bxmi_bed_t *b, const char *data, const uint8_t *mask, const char *suffix, int fd);
 
+/* ---- delimited interval text -> SoA columns (the reader side of the operations layer) --------
+ * What lib/bx/intervals/io.py:106-216 (GenomicIntervalReader over tabular/io.py:86-156) does per line, for the lines
+ * whose outcome is certain: blank lines, comment / header lines (first line starting with one of `comment_prefixes`),
+ * and rows whose TAB-separated chromosome / start / end / strand fields are already in the normal form the reader writes
+ * back (stripped name, canonical integers, "+" or "-", start <= end).  It STOPS at the first other line (stop_off); the
+ * caller continues from there with the reference's own per-line semantics.  strand_col < 0 or beyond the row: no strand. */
+typedef struct bxmi_tab bxmi_tab_t;
+int bxmi_tab_parse(const char *data, int64_t len, int chrom_col, int start_col, int end_col, int strand_col,
+                   const char *const *comment_prefixes, int n_prefixes, bxmi_tab_t **out);
+int bxmi_tab_destroy(bxmi_tab_t *b);
+int bxmi_tab_info(const bxmi_tab_t *b, int64_t *n_lines, int32_t *n_chroms, int64_t *stop_off);
+/* Borrowed per-LINE views, valid until bxmi_tab_destroy: kind (0 row, 1 blank, 2 comment, 3 header), the line's offset and
+ * length (without its newline) in the parsed buffer, and for rows the chromosome id (first-appearance order), start, end
+ * and strand byte ('+', '-', 0 = no strand field). */
+int bxmi_tab_columns(const bxmi_tab_t *b, const uint8_t **kind, const int64_t **line_off, const int32_t **line_len, const int32_t **chrom_id,
+                     const int64_t **start, const int64_t **end, const uint8_t **strand);
+const char *bxmi_tab_chrom_name(const bxmi_tab_t *b, int32_t id);
+
 #ifdef __cplusplus
 }
 #endif

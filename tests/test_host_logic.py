@@ -278,3 +278,51 @@ def test_interval_readers_follow_the_reference_docstring_examples():
     # construction normalises the fields it parsed (whitespace, sign, strand '.')
     row = GenomicInterval(None, [" chr7 ", "+5", "9", "x", "0", "."], 0, 1, 2, 5, "-")
     assert row.fields == ["chr7", "5", "9", "x", "0", "-"] and row.copy().fields == row.fields
+
+
+def test_native_table_parse_equals_per_line_readers(monkeypatch):
+    """bxmi.tabio (csrc/bedparse.cpp table mode) under the three readers: items, line numbers, raw lines, skip bookkeeping
+    and escaping errors are those of the per-line code, on files where the parser gets far (clean rows), nowhere (a header
+    it must leave alone, CRLF) and part of the way (odd rows in the middle: signs, spaces, leading zeros, '.', bad strands,
+    too few fields, start > end, non-ASCII)."""
+    from bxmi import genomic, tabio
+
+    rng = np.random.default_rng(5)
+    clean = ["chr%d\t%d\t%d\tn%d\t0\t%s\n" % (rng.integers(1, 4), a, a + rng.integers(0, 500), i, "+-"[i % 2])
+             for i, a in enumerate(rng.integers(0, 10**6, size=300).tolist())]
+    odd = ["chr1\t+5\t9\tx\t0\t+\n", "chr1\t 5\t9\n", "chr1\t007\t9\n", "chr1\t5\t9\tx\t0\t.\n", "chr1\t5\t9\tx\t0\t*\n", "chr1\t5\n",
+           "chr1\t9\t5\n", " chr1 \t5\t9\n", "chr\u00e9\t5\t9\n", "chr1\t-0\t9\n", "chr1\t5\t9\tx\t0\t+\r\n", "\n", "# note\n", "track name=x\n",
+           "chr1\t1_0\t20\n", "chr2\t-7\t-3\n", "chr1\t5\t9\tx\t0\t-\n"]
+    files = {
+        "clean": clean,
+        "header then clean": ["#chrom\tstart\tend\n"] + clean[:50],
+        "comment later": clean[:20] + ["# c\n", "\n", "track t\n"] + clean[20:40],
+        "odd rows": [x for pair in zip(clean[:len(odd)], odd) for x in pair] + clean[100:120],
+        "crlf everywhere": [x[:-1] + "\r\n" for x in clean[:30]],
+        "no line ends": [x.rstrip("\n") for x in clean[:10]],
+        "empty": [],
+    }
+
+    def run(cls, lines, **kw):
+        r = cls(list(lines), **kw) if cls is not genomic.BitsetSafeReaderWrapper else cls(genomic.GenomicIntervalReader(list(lines)), lens={"chr1": 600000})
+        out, err = [], None
+        try:
+            for x in r:
+                out.append((type(x).__name__, str(x), r.linenum, getattr(r, "current_line", None), getattr(x, "strand", None),
+                            getattr(x, "start", None), getattr(x, "end", None), getattr(x, "chrom", None)))
+        except Exception as e:  # noqa: BLE001 -- whatever escapes must be the same thing
+            err = (type(e).__name__, str(e))
+        return out, err, getattr(r, "skipped", None), list(getattr(r, "skipped_lines", [])), list(getattr(r, "skip_log", [])), getattr(r, "delivered", None)
+
+    used = 0
+    for name, lines in files.items():
+        for cls, kw in ((genomic.GenomicIntervalReader, {}), (genomic.GenomicIntervalReader, {"fix_strand": True, "strand_col": 5}),
+                        (genomic.NiceReaderWrapper, {}), (genomic.NiceReaderWrapper, {"return_comments": False}), (genomic.BitsetSafeReaderWrapper, {})):
+            monkeypatch.setenv("BXMI_NO_FASTPARSE", "1")
+            want = run(cls, lines, **kw)
+            monkeypatch.delenv("BXMI_NO_FASTPARSE")
+            got = run(cls, lines, **kw)
+            assert got == want, (name, cls.__name__, kw)
+        t = tabio.parse_input(list(lines), 0, 1, 2, 5, ["#", "track "])
+        used += 0 if t is None else t.n
+    assert used > 300  # the parser did take most of the clean lines: the comparison above was not per-line against per-line
