@@ -6,8 +6,13 @@ reference keeps a self-balancing tree of clusters and merges on every insert; he
 collected and the clusters of the whole set are computed in one go on the device the first time
 they are asked for (sort by start, running maximum of the ends, a boundary wherever
 `start - mincols > largest end so far`) -- for mincols >= 0 the reference's outcome does not
-depend on the insertion order, so the results are identical.  A negative `mincols` makes the
-reference's result depend on insertion order; that is not reproduced (ValueError on query).
+depend on the insertion order, so the results are identical.
+
+A negative `mincols` is refused (ValueError on query), because the reference has no answer to reproduce
+there: with max_dist < 0 an interval can be both "to the right of" and "to the left of" a cluster
+(src/cluster.c:224-230, the first test wins), the tree stops being ordered by position, and which cluster a
+later interval meets depends on the tree's shape -- i.e. on the node priorities, which come from the process-wide
+unseeded rand() (src/cluster.c:66-69) and so on how many nodes any earlier tree in the process has created.
 """
 from bxmi.intervals import IntervalIndex
 

@@ -199,6 +199,78 @@ def write_runs(out, chrom, bits, clip=None):
         raise IndexError("%d is larger than the size of this BitSet (%d)." % (bits.size, bits.size))
 
 
-def binned_bitsets_from_list(rows):
-    """bitset_builders.py:142-156: rows of (chrom, start, end)."""
-    return binned_bitsets_from_file(("%s\t%s\t%s\n" % (r[0], int(r[1]), int(r[2])) for r in rows))
+def _c_int(v):
+    if not -2147483648 <= v <= 2147483647:
+        raise OverflowError("value too large to convert to int")
+    return v
+
+
+def _set_all(rows):
+    """rows: iterable of (chrom, start, count) in call order, each what the reference hands to set_range on a
+    MAX-sized bitset.  The first range the reference would reject raises (nothing is returned then, so the sets made
+    before it are not observable); otherwise one set_ranges launch per chromosome."""
+    per = {}
+    for chrom, start, count in rows:
+        g = per.get(chrom)
+        if g is None:
+            g = per[chrom] = ([], [])
+        if start is None:  # chromosome seen, nothing to set
+            continue
+        err = _check_range(MAX, _c_int(start), count)  # `int start`, then the range check, then count -> C int
+        if err is not None:
+            raise err
+        if _c_int(count):
+            g[0].append(start), g[1].append(count)
+    out = {}
+    for chrom, (s, c) in per.items():
+        b = out[chrom] = BinnedBitSet(MAX)
+        if s:
+            b.set_ranges(np.array(s, dtype=np.int32), np.array(c, dtype=np.int32))
+    return out
+
+
+def binned_bitsets_from_list(list=[]):
+    """bitset_builders.py:142-156: rows of (chrom, start, end); every row is set_range(start, end - start)."""
+    def rows():
+        for r in list:
+            chrom = r[0]
+            start, end = int(r[1]), int(r[2])
+            yield chrom, start, end - start
+    return _set_all(rows())
+
+
+def binned_bitsets_proximity(f, chrom_col=0, start_col=1, end_col=2, strand_col=5, upstream=0, downstream=0):
+    """bitset_builders.py:107-139: each interval grown by `upstream` / `downstream` bases on the strand-aware side,
+    clamped to [0, MAX]; empty and reversed intervals are dropped without a word."""
+    def rows():
+        for line in f:
+            if line.startswith("#"):
+                continue
+            fields = line.split()
+            minus = len(fields) >= strand_col + 1 and fields[strand_col] == "-"
+            chrom = fields[chrom_col]
+            start, end = int(fields[start_col]), int(fields[end_col])
+            grow_start, grow_end = (downstream, upstream) if minus else (upstream, downstream)
+            if grow_start:
+                start = max(0, start - grow_start)
+            if grow_end:
+                end = min(MAX, end + grow_end)
+            if end - start > 0:
+                yield chrom, start, end - start
+            else:
+                yield chrom, None, None
+    return _set_all(rows())
+
+
+def binned_bitsets_by_chrom(f, chrom, chrom_col=0, start_col=1, end_col=2):
+    """bitset_builders.py:159-169: ONE bitset holding the rows of `chrom`."""
+    def rows():
+        yield chrom, None, None
+        for line in f:
+            if line.startswith("#"):
+                continue
+            fields = line.split()
+            if fields[chrom_col] == chrom:
+                start, end = int(fields[start_col]), int(fields[end_col])
+                yield chrom, start, end - start
+    return _set_all(rows())[chrom]

@@ -16,7 +16,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liboracle.so")
+# ORACLE_SANITIZED=1: the same sources built with -fsanitize=address,undefined (make san); the process must have
+# been started with LD_PRELOAD=$(gcc -print-file-name=libasan.so) -- tests/test_oracle_golden.py does that in a child
+_SAN = os.environ.get("ORACLE_SANITIZED") == "1"
+_LIB = os.path.join(_HERE, "liboracle_san.so" if _SAN else "liboracle.so")
 _REF = os.path.join(_HERE, "_ref", "libbinbits_ref.so")
 _REF_CLUSTER = os.path.join(_HERE, "_ref", "libcluster_ref.so")
 
@@ -33,7 +36,7 @@ def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("ivtree.c", "binbits.c", "cluster.c")]
     stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_LIB)], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/src") and (force or not os.path.exists(_REF) or not os.path.exists(_REF_CLUSTER)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 

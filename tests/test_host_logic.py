@@ -326,3 +326,26 @@ def test_native_table_parse_equals_per_line_readers(monkeypatch):
         t = tabio.parse_input(list(lines), 0, 1, 2, 5, ["#", "track "])
         used += 0 if t is None else t.n
     assert used > 300  # the parser did take most of the clean lines: the comparison above was not per-line against per-line
+
+
+def test_small_builders_raise_what_the_reference_raises_before_touching_the_device():
+    """bitset_builders.py:107-169: the failing cases of tests/golden/builders_quicksect.json are decided on the
+    host (the reference's own exceptions, made by oracle/gen_golden_extra.py), so they are checked here too."""
+    import json
+
+    import bx.bitset_builders as bb
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "builders_quicksect.json")) as f:
+        doc = json.load(f)
+    failing = [c for c in doc["builders"] if "error" in c["want"]]
+    assert len(failing) >= 10
+    for case in failing:
+        a = case["args"]
+        with pytest.raises(Exception) as ei:
+            if case["fn"] == "from_list":
+                bb.binned_bitsets_from_list(a["rows"])
+            elif case["fn"] == "proximity":
+                bb.binned_bitsets_proximity(iter(a["lines"]), **a["kw"])
+            else:
+                bb.binned_bitsets_by_chrom(iter(a["lines"]), a["chrom"], **a["kw"])
+        assert [type(ei.value).__name__, str(ei.value)] == case["want"]["error"], case["name"]

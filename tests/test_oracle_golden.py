@@ -307,3 +307,25 @@ def test_cluster_restatement_equals_compiled_reference_c():
         want = O.ref_cluster_regions([(int(s[i]), int(e[i]), int(ids[i])) for i in order], md, mn)
         got = O.cluster_regions(s, e, ids, md, mn)
         assert got == want, (trial, md, mn, n)
+
+
+def test_restatement_is_clean_under_asan_and_ubsan():
+    """The checker itself is checked: the golden-vector tests of this file run once more in a child python whose
+    liboracle is built with -fsanitize=address,undefined (oracle/Makefile `san`).  Any out-of-bounds access, use
+    after free, signed overflow or misaligned load in oracle/*.c aborts the child."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("ORACLE_SANITIZED") == "1":
+        pytest.skip("already inside the sanitized child")
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan in this toolchain")
+    env = dict(os.environ, ORACLE_SANITIZED="1", LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    picks = "vectors or known_answers or ctor_limits or big_sizes or order_key or batch_apis"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k", picks],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "passed" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
