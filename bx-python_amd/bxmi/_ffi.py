@@ -51,6 +51,7 @@ _SIGNATURES = {
     "bxmi_ivl_count_dev": [vp, vp, vp, i64, vp, vp, vp],
     "bxmi_ivl_count_multi_dev": [vp, C.c_int, vp, vp, vp, vp, vp, vp],
     "bxmi_ivl_bitmap_state": [vp, _p(C.c_int), _p(i64)],
+    "bxmi_ivl_slice_state": [vp, _p(C.c_int), vp],
     "bxmi_ivl_find": [vp, vp, vp, i64, vp, vp, i64, _p(i64)],
     "bxmi_ivl_find_dev": [vp, vp, vp, i64, vp, vp, i64, _p(i64), vp],
     "bxmi_ivl_find_one": [vp, i32, i32, vp, i64, _p(i64)],
@@ -119,6 +120,10 @@ def load():
             f.restype = res
             f.argtypes = args
         _lib = L
+        # BXMI_OPTS="ivl.bm_u=4,bits.grid=512": tuning knobs for A/B runs of unmodified scripts (results never depend on them)
+        for kv in filter(None, os.environ.get("BXMI_OPTS", "").split(",")):
+            key, _, value = kv.partition("=")
+            check(L.bxmi_set_option(key.strip().encode(), int(value)))
     return _lib
 
 

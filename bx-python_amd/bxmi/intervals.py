@@ -82,6 +82,13 @@ class IntervalIndex:
         call("bxmi_ivl_bitmap_state", self._h, C.byref(st), C.byref(hc))
         return st.value, hc.value
 
+    def slice_state(self):
+        """(state, unit_keys[7]) of the slice search stage: 1 = usable, -1 = a bucket's keys do not fit the LDS, 0 = undecided."""
+        self._ready()
+        st, need = C.c_int(0), (C.c_int64 * 7)()
+        call("bxmi_ivl_slice_state", self._h, C.byref(st), need)
+        return st.value, list(need)
+
     def order(self):
         """Insertion indices in the treap's in-order (== IntervalTree.traverse order)."""
         self._ready()

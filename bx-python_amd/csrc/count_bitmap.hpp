@@ -34,7 +34,7 @@ namespace bxmi {
 
 constexpr int BM_NB = PT_NB;             // coordinate buckets (the grid of the first-generation path: same geometry)
 constexpr int BM_MARGIN = 32768;         // the starts' cells reach this far past the bucket: every record's qe is covered
-constexpr unsigned BM_LEN_ESC = 0x7FFFu;  // length field of an escape record
+constexpr unsigned BM_LEN_ESC = 0x7FFFu;  // length field of an escape record (17-bit offsets: the image format)
 constexpr unsigned BM_REC_ESC = 0xFFFFFFFFu;
 constexpr int BM_MAX_SHIFT = 17;         // bucket width <= 131072 coordinates: (4098 + 5121) cells = 72 KiB of LDS
 constexpr int BM_MIN_SHIFT = 5;          // at least one whole cell per bucket
@@ -51,7 +51,15 @@ struct BmGeom {
     int32_t nce;     // cells of the ends' image, sentinel included:   (W >> 5) + 2
     int32_t ncs;     // cells of the starts' image, sentinel included: ((W + BM_MARGIN) >> 5) + 1
     int32_t stride;  // cells per bucket image in global memory (nce + ncs rounded up to 16 bytes)
+    // record format: offset in the low `rshift` bits, length above; the offset is relative to the first coordinate of
+    // the record's UNIT = 2^f neighbouring buckets.  The image pass has f = 0 and rshift = 17; the slice pass
+    // (count_slices.hpp) picks f per batch, rshift = max(17, shift + f), and uses nce / ncs / dshift for its directories.
+    int32_t f;
+    int32_t rshift;
+    int32_t dshift;
 };
+
+__device__ __forceinline__ unsigned bm_len_esc(const BmGeom &g) { return (1u << (32 - g.rshift)) - 1u; }
 
 struct BmBucket {
     int32_t eLo;  // #{ends   < bucket's first coordinate}
@@ -71,6 +79,7 @@ struct BmSeg {
     int64_t tile_end;         // first tile of the next segment (tile0 + ntiles rounded up to a plan group)
     const uint2 *images;
     const BmBucket *bmeta;
+    const int4 *smeta;        // slice pass: ranks at every bucket boundary (SlMeta, count_slices.hpp)
     IndexDev ix;              // the sealed index (escapes, hard cells)
     const int32_t *e_sorted;
 };
@@ -247,8 +256,8 @@ __device__ __forceinline__ unsigned bm_record_of(int qs, int qe, const BmGeom &g
 {
     const unsigned rel = (unsigned)qs - (unsigned)g.cmin;
     const unsigned len = (unsigned)qe - (unsigned)qs;
-    const bool ok = qs >= g.cmin && (rel >> g.shift) < (unsigned)BM_NB && qe > qs && len < BM_LEN_ESC;
-    return ok ? ((rel & ((1u << g.shift) - 1u)) | (len << 17)) : BM_REC_ESC;
+    const bool ok = qs >= g.cmin && (rel >> g.shift) < (unsigned)BM_NB && qe > qs && len < bm_len_esc(g);
+    return ok ? ((rel & ((1u << (g.shift + g.f)) - 1u)) | (len << g.rshift)) : BM_REC_ESC;
 }
 
 template <int THREADS, int ITEMS>
@@ -905,12 +914,15 @@ __device__ __forceinline__ int bm_escape_count(const IndexDev &ix, const int32_t
     return count_one_global(ix, e_sorted, qs, qe);
 }
 
-template <int THREADS, int ITEMS>
+// FIND: also leave loff[tile-sorted position] = exclusive prefix of the counts inside the tile, in tile-sorted order
+// (bit 31 = escape record, which contributes nothing): where the record's hits go in the tile's scratch region
+// (count_slices.hpp, sl_fill_pipe_kernel).
+template <int THREADS, int ITEMS, bool FIND = false>
 __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *__restrict__ cnt /* tile-sorted: the records array after the search */,
                                                                const unsigned short *__restrict__ slots, const BmSeg *__restrict__ segs,
                                                                const unsigned short *__restrict__ tile_seg,
                                                                unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS], may be NULL */,
-                                                               const unsigned *__restrict__ gate)
+                                                               const unsigned *__restrict__ gate, unsigned *__restrict__ loff = nullptr)
 {
     constexpr int TILE = THREADS * ITEMS;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
@@ -945,6 +957,33 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
         }
     }
     __syncthreads();
+    if (FIND) {
+        // every wave scans its contiguous share of the tile, 64 positions at a time
+        constexpr int NW = THREADS / 64, PER_WAVE = TILE / NW, CH = PER_WAVE / 64;
+        __shared__ unsigned s_wtot[NW];
+        const int w = threadIdx.x >> 6, lane = lane_id();
+        unsigned e[CH], carry = 0;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int idx = w * PER_WAVE + c * 64 + lane;
+            const unsigned v = idx < n ? vals[idx] : 0u;
+            const bool esc = v == BM_REC_ESC;
+            const unsigned x = esc ? 0u : v;
+            const unsigned inc = wave_inclusive_scan(x, OpSum());
+            e[c] = (carry + inc - x) | (esc ? 0x80000000u : 0u);
+            carry += (unsigned)__shfl((int)inc, 63, 64);
+        }
+        if (lane == 0) s_wtot[w] = carry;
+        __syncthreads();
+        unsigned wbase = 0;
+        for (int i = 0; i < w; i++) wbase += s_wtot[i];
+        unsigned *lo_out = loff + tile * TILE;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int idx = w * PER_WAVE + c * 64 + lane;
+            lo_out[idx] = ((e[c] & 0x7FFFFFFFu) + wbase) | (e[c] & 0x80000000u);
+        }
+    }
     long long acc = 0;
     if (n == TILE) {
         const uint2 *l4 = reinterpret_cast<const uint2 *>(slots + base);

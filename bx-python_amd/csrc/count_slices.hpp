@@ -1,0 +1,658 @@
+// count_slices.hpp -- the search stage of the large-batch pass for indexes whose bucket images do not pay or do not
+// fit ("sl_*" kernels).  Included by intervals.hip after count_bitmap.hpp: tile sort, run table, plan and un-permute
+// are the bm_* kernels unchanged; only what a search workgroup keeps in LDS differs.
+//
+// The image pass spends 0.5 B of image per COORDINATE of the index's span.  That is nothing for 10M targets on 250M
+// coordinates, but a genome's chromosomes carry one target per ~300 coordinates (1.5 GB of images for 100M queries,
+// a 147 KB image load in front of every ~4000 queries), and a span of 2e9 (configs[4]) needs buckets whose image is
+// larger than the LDS.  Here a workgroup stages the SORTED KEYS themselves: the starts and the ends that fall into
+// its unit of 2^f neighbouring buckets, as 16-bit values under a directory --
+//     dir[c]  = #{keys of the slice below cell c},   cell = 2^dshift coordinates, at most 2047 cells per slice
+//     low[i]  = key i's offset inside its cell (dshift <= 16 bits)
+// so a rank is two directory reads and a binary search over ONE cell's keys (a handful): 2 B of LDS per target,
+// whatever the span.  Cost per query is about twice the image lookup's; there are no hard cells, no duplicates to
+// describe, no images to build or to read, and the unit grows until its keys fill the LDS, which makes the (tile,
+// unit) runs longer than the image pass's (tile, bucket pair) runs on sparse indexes.
+//
+// count(q) = (sLo + #{slice starts < qe}) - (eLo + #{slice ends <= qs})       (intersection.pyx:180-189)
+// with sLo / eLo the ranks of the unit's first coordinate, from the per-index boundary table (sl_meta_kernel).
+#pragma once
+
+namespace bxmi {
+
+constexpr int SL_MARGIN = 32768;     // the starts' slice reaches this far past the unit: every record's qe is covered
+constexpr int SL_CAP = 61440;        // 16-bit keys of both slices together (120 KB of the CU's 160 KB)
+constexpr int SL_DIR_CELLS = 2047;   // directory cells per slice, sentinel excluded
+constexpr int SL_MAX_F = 6;
+constexpr int SL_THREADS = 1024;
+
+// ranks at bucket boundary b (first coordinate lo_b = cmin + b * W), b = 0 .. BM_NB:
+//   x = #{start < lo_b}, y = #{end < lo_b}, z = #{start < lo_b + SL_MARGIN}, w = #{end <= lo_b}
+__global__ __launch_bounds__(256) void sl_meta_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted, int n, int32_t cmin,
+                                                      int shift, int4 *__restrict__ meta)
+{
+    const int b = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b > BM_NB) return;
+    const long long lo = (long long)cmin + ((long long)b << shift);
+    meta[b] = make_int4(bm_rank_lt64(s_ord, n, lo), bm_rank_lt64(e_sorted, n, lo), bm_rank_lt64(s_ord, n, lo + SL_MARGIN),
+                        bm_rank_lt64(e_sorted, n, lo + 1));
+}
+
+// need[f] = the most keys a unit of 2^f buckets stages (both slices), f = 0 .. SL_MAX_F
+__global__ __launch_bounds__(1024) void sl_fit_kernel(const int4 *__restrict__ meta, unsigned *__restrict__ need)
+{
+    for (int f = 0; f <= SL_MAX_F; f++) {
+        unsigned m = 0;
+        for (int u = threadIdx.x; (u << f) < BM_NB; u += 1024) {
+            const int b0 = u << f, b1 = (b0 + (1 << f)) < BM_NB ? b0 + (1 << f) : BM_NB;
+            const int4 a = meta[b0], c = meta[b1];
+            const unsigned k = (unsigned)(c.z - a.x) + (unsigned)(c.w - a.y);
+            m = k > m ? k : m;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = __shfl_down(m, off, 64);
+            m = o > m ? o : m;
+        }
+        if (lane_id() == 0) atomicMax(&need[f], m);
+    }
+}
+
+// grpcnt[group][bucket] -> per unit of 2^f buckets (f is the segment's), in the same [group][BM_NB] layout so that
+// bm_plan_kernel<2> plans units exactly as it plans single buckets.
+__global__ __launch_bounds__(1024) void sl_unit_sums_kernel(const unsigned *__restrict__ grpcnt, const BmSeg *__restrict__ segs,
+                                                            const unsigned short *__restrict__ tile_seg, unsigned *__restrict__ unitcnt,
+                                                            const unsigned *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;
+    const int grp = blockIdx.x;
+    const int f = segs[tile_seg[(int64_t)grp * BM_GROUP_TILES]].g.f;
+    const unsigned *row = grpcnt + (int64_t)grp * BM_NB;
+    for (int u = threadIdx.x; u < BM_NB; u += 1024) {
+        unsigned s = 0;
+        if ((u << f) < BM_NB)
+            for (int k = 0; k < (1 << f); k++) s += row[(u << f) + k];
+        unitcnt[(int64_t)grp * BM_NB + u] = s;
+    }
+}
+
+typedef __attribute__((address_space(3))) const unsigned short *lds_u16_p;
+
+// #{keys of the slice below x}: the directory narrows to one cell, `steps` halvings finish (steps covers the fullest
+// cell of the unit, so every lane runs the same straight-line code).
+__device__ __forceinline__ int sl_rank(lds_u16_p low, lds_u16_p dir, unsigned x, int dshift, int steps)
+{
+    const unsigned c = x >> dshift, xl = x & ((1u << dshift) - 1u);
+    unsigned lo = dir[c], hi = dir[c + 1];
+    for (int i = 0; i < steps; i++) {
+        const unsigned mid = (lo + hi) >> 1;
+        const bool go = lo < hi && (unsigned)low[mid] < xl;
+        lo = go ? mid + 1 : lo;
+        hi = go ? hi : mid;
+    }
+    return (int)lo;
+}
+
+// What a search workgroup holds for its unit.
+struct SlUnit {
+    lds_u16_p lowS, lowE, dirS, dirE;
+    int sLo, eLo;   // global ranks of the unit's first coordinate
+    int nS, nE;
+    int steps;
+};
+
+// Stage the unit's keys and build the directories.  dyn = [lowS nS_pad][lowE nE_pad][dirS ncs + 2][dirE nce + 2] (u16).
+__device__ __forceinline__ SlUnit sl_stage_unit(const BmSeg &sg, int unit, int32_t *dyn, int *s_tmp /* [20] shared */)
+{
+    const BmGeom g = sg.g;
+    const int b0 = unit << g.f, b1 = (b0 + (1 << g.f)) < BM_NB ? b0 + (1 << g.f) : BM_NB;
+    const int4 m0 = sg.smeta[b0], m1 = sg.smeta[b1];
+    SlUnit U;
+    U.sLo = m0.x, U.eLo = m0.y;
+    U.nS = m1.z - m0.x, U.nE = m1.w - m0.y;
+    unsigned short *lowS = reinterpret_cast<unsigned short *>(dyn);
+    unsigned short *lowE = lowS + ((U.nS + 8) & ~7);
+    unsigned short *dirS = lowE + ((U.nE + 8) & ~7);
+    unsigned short *dirE = dirS + ((g.ncs + 2 + 7) & ~7);
+    const long long lo_u = (long long)g.cmin + ((long long)b0 << g.shift);
+    const int dshift = g.dshift;
+    const unsigned dmask = (1u << dshift) - 1u;
+    for (int c = threadIdx.x; c <= g.ncs; c += SL_THREADS) dirS[c] = 0xFFFFu;
+    for (int c = threadIdx.x; c <= g.nce; c += SL_THREADS) dirE[c] = 0xFFFFu;
+    if (threadIdx.x == 0) s_tmp[16] = 0;
+    __syncthreads();
+    for (int arr = 0; arr < 2; arr++) {
+        const int32_t *__restrict__ A = arr == 0 ? sg.ix.s_ord + U.sLo : sg.e_sorted + U.eLo;
+        const int n = arr == 0 ? U.nS : U.nE;
+        unsigned short *low = arr == 0 ? lowS : lowE, *dir = arr == 0 ? dirS : dirE;
+        for (int i = threadIdx.x; i < n; i += SL_THREADS) {
+            const unsigned rel = (unsigned)((long long)A[i] - lo_u);
+            const unsigned prev = i > 0 ? (unsigned)((long long)A[i - 1] - lo_u) >> dshift : 0xFFFFFFFFu;
+            low[i] = (unsigned short)(rel & dmask);
+            if ((rel >> dshift) != prev) dir[rel >> dshift] = (unsigned short)i;  // first key of its cell
+        }
+    }
+    __syncthreads();
+    // empty cells take the next occupied cell's first key (suffix minimum, the sentinel = n); two cells per thread,
+    // thread 0 owns the LAST two, so that an exclusive min-scan over the threads brings "everything to my right".
+    unsigned maxocc = 0;
+    for (int arr = 0; arr < 2; arr++) {
+        unsigned short *dir = arr == 0 ? dirS : dirE;
+        const int nc = arr == 0 ? g.ncs : g.nce;
+        const unsigned n = (unsigned)(arr == 0 ? U.nS : U.nE);
+        const int c0 = 2 * (SL_THREADS - 1 - (int)threadIdx.x), c1 = c0 + 1;
+        unsigned a = c1 < nc ? (unsigned)dir[c1] : n, b = c0 < nc ? (unsigned)dir[c0] : n;
+        a = a == 0xFFFFu ? n : a, b = b == 0xFFFFu ? n : b;  // (n <= SL_CAP < 0xFFFF)
+        unsigned tot;
+        const unsigned right = block_exclusive_scan(a < b ? a : b, OpMin(), n, reinterpret_cast<unsigned *>(s_tmp), &tot);
+        a = a < right ? a : right;
+        b = b < a ? b : a;
+        if (c1 <= nc) dir[c1] = (unsigned short)a;
+        if (c0 <= nc) dir[c0] = (unsigned short)b;
+        if (c0 < nc) {
+            const unsigned occ0 = a - b, occ1 = (c1 < nc ? right : a) - a;  // keys of cells c0 and c1
+            maxocc = occ0 > maxocc ? occ0 : maxocc;
+            maxocc = occ1 > maxocc ? occ1 : maxocc;
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = __shfl_down(maxocc, off, 64);
+        maxocc = o > maxocc ? o : maxocc;
+    }
+    if (lane_id() == 0) atomicMax(&s_tmp[16], (int)maxocc);
+    __syncthreads();
+    U.steps = 32 - __clz(s_tmp[16]);
+    U.lowS = (lds_u16_p)lowS, U.lowE = (lds_u16_p)lowE, U.dirS = (lds_u16_p)dirS, U.dirE = (lds_u16_p)dirE;
+    return U;
+}
+
+__device__ __forceinline__ unsigned sl_count_record(const SlUnit &U, const BmGeom &g, unsigned rec)
+{
+    const unsigned len = rec >> g.rshift, off = rec & ((1u << g.rshift) - 1u);
+    if (len == bm_len_esc(g)) return BM_REC_ESC;
+    const int rE = sl_rank(U.lowE, U.dirE, off + 1u, g.dshift, U.steps);
+    const int rS = sl_rank(U.lowS, U.dirS, off + len, g.dshift, U.steps);
+    return (unsigned)((U.sLo - U.eLo) + (rS - rE));
+}
+
+// The walk of bm_search_pipe_kernel (rounds of U runs per L-lane group, the next round's records requested before
+// this round is computed, long runs finished by the whole workgroup) over the runs of one UNIT: the run of unit u in
+// tile t is what lies between the first slots of buckets u << f and (u + 1) << f in the tile-sorted order.
+template <int L, int U>
+__global__ __launch_bounds__(SL_THREADS) void sl_search_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
+                                                                    const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
+                                                                    const unsigned *recs, unsigned *out /* counts: == recs (in place) or apart */,
+                                                                    int tile_log2, const unsigned *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;
+    constexpr int NG = SL_THREADS / L;
+    constexpr unsigned LONG_RUN = 4 * L;
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ uint2 s_long[BM_LONG_CAP];
+    __shared__ int s_nlong;
+    __shared__ int s_tmp[20];
+    const int nit = *n_items;
+    const int per_xcd = (nit + 7) >> 3;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int it = (int)(blockIdx.x & 7) * per_xcd + slot;
+    if (slot >= per_xcd || it >= nit) return;
+    const int4 item = items[it];
+    const int unit = item.x & 0xffff, t0 = item.y, t1 = item.z;
+    const BmSeg &sg = segs[item.x >> 16];
+    const BmGeom g = sg.g;
+    const int b0 = unit << g.f, b1 = b0 + (1 << g.f);
+    const bool open_end = b1 >= BM_NB;  // the unit reaches the end of the grid: its runs end where the tiles end
+    const unsigned *__restrict__ runs0 = runT + (int64_t)b0 * ntp;
+    const unsigned *__restrict__ runs1 = runT + (int64_t)(open_end ? b0 : b1) * ntp;
+    const int64_t seg_t0 = sg.tile0, seg_nq = sg.nq;
+    const int gid = threadIdx.x / L, sub = threadIdx.x % L;
+    unsigned run[U];  // first slot | length << 16
+    auto load_runs = [&](int tb) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tb + u * NG + gid;
+            const int tc = t < t1 ? t : t0;  // a valid address: no branch around the loads
+            const unsigned a = runs0[tc] & 0xffffu;
+            unsigned e = runs1[tc] & 0xffffu;
+            if (open_end) {
+                const int64_t left = seg_nq - (((int64_t)tc - seg_t0) << tile_log2);
+                e = left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2;
+            }
+            run[u] = t < t1 ? (a | ((e - a) << 16)) : 0u;
+        }
+    };
+    load_runs(t0);
+    const SlUnit UN = sl_stage_unit(sg, unit, dyn, s_tmp);
+    if (threadIdx.x == 0) s_nlong = 0;
+    __syncthreads();
+    auto answer = [&](unsigned at, unsigned rec) { out[(size_t)at] = sl_count_record(UN, g, rec); };
+    auto prep = [&](BmRound<U> &R, int tb) {
+        unsigned cum = 0, lf_at = ~0u, listed_mask = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tb + u * NG + gid;
+            const unsigned first = ((unsigned)t << tile_log2) + (run[u] & 0xffffu);
+            const unsigned len = run[u] >> 16;
+            R.first[u] = first;
+            R.lens[u] = len;
+            R.rec[u] = recs[(size_t)((unsigned)sub < len ? first + (unsigned)sub : 0u)];
+            unsigned rem = len > (unsigned)L ? len - (unsigned)L : 0u;
+            if (len > LONG_RUN) {  // left to the whole workgroup
+                bool listed = false;
+                if (sub == 0) {
+                    const int k = atomicAdd(&s_nlong, 1);
+                    if (k < BM_LONG_CAP) {
+                        s_long[k] = make_uint2(first, len);
+                        listed = true;
+                    }
+                }
+                listed = __shfl(listed, (int)(threadIdx.x & 63) - sub, 64);
+                if (listed) {
+                    rem = 0;
+                    listed_mask |= 1u << u;
+                }
+            }
+            const unsigned i = (unsigned)sub - cum;
+            if ((unsigned)sub >= cum && i < rem) lf_at = first + (unsigned)L + i;
+            cum += rem;
+        }
+        R.lf_total = cum;
+        R.listed = listed_mask;
+        R.lf_at = lf_at;
+        R.lf_second = false;
+        R.lf_rec = recs[(size_t)(lf_at != ~0u ? lf_at : 0u)];
+    };
+    auto finish = [&](BmRound<U> &R) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if ((unsigned)sub < R.lens[u]) answer(R.first[u] + (unsigned)sub, R.rec[u]);
+        if (R.lf_at != ~0u) answer(R.lf_at, R.lf_rec);
+        for (unsigned base = L; __any(base < R.lf_total); base += L) {  // further leftover passes
+            const unsigned i = base + (unsigned)sub;
+            unsigned cum = 0, at = ~0u;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned len = R.lens[u];
+                const unsigned rem = len > (unsigned)L && !((R.listed >> u) & 1u) ? len - (unsigned)L : 0u;
+                const unsigned j = i - cum;
+                if (i >= cum && j < rem) at = R.first[u] + (unsigned)L + j;
+                cum += rem;
+            }
+            if (at != ~0u) answer(at, recs[(size_t)at]);
+        }
+    };
+    BmRound<U> A, B;
+    prep(A, t0);
+    load_runs(t0 + NG * U);
+    for (int tb = t0; tb < t1; tb += 2 * NG * U) {
+        prep(B, tb + NG * U);
+        load_runs(tb + 2 * NG * U);
+        finish(A);
+        prep(A, tb + 2 * NG * U);
+        load_runs(tb + 3 * NG * U);
+        finish(B);
+    }
+    __syncthreads();
+    {
+        const int nl = s_nlong < BM_LONG_CAP ? s_nlong : BM_LONG_CAP;
+        for (int k = 0; k < nl; k++) {
+            const uint2 e = s_long[k];
+            for (unsigned p = (unsigned)L + threadIdx.x; p < e.y; p += SL_THREADS) answer(e.x + p, recs[(size_t)e.x + p]);
+        }
+    }
+}
+
+// The same search for LONG runs (a unit of many buckets on a sparse index: hundreds of records per tile).  L lanes per
+// run waste their passes there; instead the item's runs are laid end to end -- a prefix sum over the run lengths of up
+// to SL_FLAT_TILES tiles in LDS -- and the workgroup strides over that flat sequence, every thread keeping DEPTH
+// records in flight and advancing its own run pointer as its positions grow.
+constexpr int SL_FLAT_TILES = 2048;
+
+template <int DEPTH>
+__global__ __launch_bounds__(SL_THREADS) void sl_search_flat_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
+                                                                    const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
+                                                                    const unsigned *recs, unsigned *out /* counts: == recs (in place) or apart */,
+                                                                    int tile_log2, const unsigned *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ unsigned s_first[SL_FLAT_TILES], s_cum[SL_FLAT_TILES + 1];
+    __shared__ int s_tmp[20];
+    const int nit = *n_items;
+    const int per_xcd = (nit + 7) >> 3;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int it = (int)(blockIdx.x & 7) * per_xcd + slot;
+    if (slot >= per_xcd || it >= nit) return;
+    const int4 item = items[it];
+    const int unit = item.x & 0xffff, t0 = item.y, t1 = item.z;
+    const BmSeg &sg = segs[item.x >> 16];
+    const BmGeom g = sg.g;
+    const int b0 = unit << g.f, b1 = b0 + (1 << g.f);
+    const bool open_end = b1 >= BM_NB;
+    const unsigned *__restrict__ runs0 = runT + (int64_t)b0 * ntp;
+    const unsigned *__restrict__ runs1 = runT + (int64_t)(open_end ? b0 : b1) * ntp;
+    const int64_t seg_t0 = sg.tile0, seg_nq = sg.nq;
+    const SlUnit UN = sl_stage_unit(sg, unit, dyn, s_tmp);
+    for (int tbase = t0; tbase < t1; tbase += SL_FLAT_TILES) {
+        const int nt = t1 - tbase < SL_FLAT_TILES ? t1 - tbase : SL_FLAT_TILES;
+        unsigned len[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int j = 2 * (int)threadIdx.x + k;
+            const int t = tbase + (j < nt ? j : 0);
+            const unsigned a = runs0[t] & 0xffffu;
+            unsigned e = runs1[t] & 0xffffu;
+            if (open_end) {
+                const int64_t left = seg_nq - (((int64_t)t - seg_t0) << tile_log2);
+                e = left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2;
+            }
+            len[k] = j < nt ? e - a : 0u;
+            s_first[j] = a;
+        }
+        unsigned total;
+        const unsigned exc = block_exclusive_scan(len[0] + len[1], OpSum(), 0u, reinterpret_cast<unsigned *>(s_tmp), &total);
+        s_cum[2 * threadIdx.x] = exc;
+        s_cum[2 * threadIdx.x + 1] = exc + len[0];
+        if (threadIdx.x == SL_THREADS - 1) s_cum[SL_FLAT_TILES] = total;
+        __syncthreads();
+        int r = 0;
+        for (unsigned i0 = threadIdx.x; i0 < total; i0 += DEPTH * SL_THREADS) {
+            unsigned at[DEPTH], rec[DEPTH];
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++) {
+                const unsigned i = i0 + (unsigned)k * SL_THREADS;
+                const bool live = i < total;
+                if (live)
+                    while (i >= s_cum[r + 1]) r++;  // (runs of length 0 are stepped over)
+                at[k] = live ? ((unsigned)(tbase + r) << tile_log2) + s_first[r] + (i - s_cum[r]) : ~0u;
+                rec[k] = recs[(size_t)(live ? at[k] : 0u)];
+            }
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++)
+                if (at[k] != ~0u) out[(size_t)at[k]] = sl_count_record(UN, g, rec[k]);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// find(): the hit lists through the same exchange
+// ---------------------------------------------------------------------------
+// IntervalTree.find for a batch (intersection.pyx:400-406 -> :180-189), hits as CSR in query order.  The count pass
+// above runs first with its counts written APART from the records (the records are needed again) and its un-permute
+// kernel also leaves, per tile, the exclusive prefix of the counts in TILE-SORTED order (`loff`, bit 31 = escape
+// record).  After the CSR offsets are known (scan over the query-order counts) the search walk runs a second time:
+//   sl_fill_pipe_kernel   per record: hi = #{start < qe} and the count again from the staged slices, then the
+//                         candidates hi-1, hi-2, ... of the start-ordered index are tested (end > qs) until `count`
+//                         hits are found, and written -- ascending -- into the TILE's region of a scratch hit list at
+//                         the record's tile-sorted offset.  The index reads stay inside the unit's lines (all records
+//                         of the workgroup lie in one unit), the writes inside the run's few hundred bytes.
+//   sl_hits_unpermute_kernel   per tile: every query copies its hits from the tile's scratch region (offset through
+//                         its 16-bit slot) to its CSR position.  The reads are random but confined to the tile's
+//                         region (~0.6 MB, L2), the writes stream.  Escape records (improper, off-grid, over-long
+//                         queries) are answered here from the sealed index.
+// Compared with the bucketed find of the first generation (window kernel + random 20-byte hit writes or reads over
+// the whole 1 GB hit list): configs[4] 9.0 -> see DESIGN.md.
+constexpr int SL_WALK = 8;
+
+template <int U>
+struct SlFillRound {
+    unsigned first[U], lens[U], rec[U], lo[U];
+    long long tbase[U];  // first hit of the run's tile in the scratch list
+    unsigned lf_at, lf_rec, lf_lo, lf_total, listed;
+    long long lf_tbase;
+};
+
+// (end, insertion index) of every target in start order, interleaved: one candidate = one 8-byte read, a step of the walk
+// = 64 contiguous bytes.  SL_WALK dummy pairs (end = INT_MIN: never a hit) lie in front, so a walk may step past index 0.
+typedef int sl_v4a8 __attribute__((ext_vector_type(4), aligned(8)));
+
+__global__ void sl_pack_eid_kernel(const int32_t *__restrict__ e_ord, const int32_t *__restrict__ idx, int n, int2 *__restrict__ eid)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - SL_WALK;
+    if (i >= n) return;
+    eid[i + SL_WALK] = i < 0 ? make_int2(INT_MIN, 0) : make_int2(e_ord[i], idx[i]);
+}
+
+// One record: its hits, ascending in index order, to dst[0 .. count).
+__device__ __forceinline__ void sl_emit_record(const SlUnit &U, const BmGeom &g, long long lo_u, const int2 *__restrict__ eid /* at index 0 */,
+                                               unsigned rec, unsigned lo, int32_t *__restrict__ dst)
+{
+    if (lo >> 31) return;  // escape record: answered by the hit un-permute kernel
+    const unsigned len = rec >> g.rshift, off = rec & ((1u << g.rshift) - 1u);
+    const int rE = sl_rank(U.lowE, U.dirE, off + 1u, g.dshift, U.steps);
+    const int rS = sl_rank(U.lowS, U.dirS, off + len, g.dshift, U.steps);
+    int c = (U.sLo - U.eLo) + (rS - rE);
+    const int qs = (int)(lo_u + (long long)off);
+    dst += (lo & 0x7FFFFFFFu);
+    // SL_WALK candidates per step, from the top of the window down; most windows end within the first step.  Candidates
+    // below the last hit are read for nothing, never stored.
+    for (int top = U.sLo + rS; c > 0 && top > 0; top -= SL_WALK) {
+        const sl_v4a8 *p = reinterpret_cast<const sl_v4a8 *>(eid + (top - SL_WALK));
+        const sl_v4a8 a = p[0], b = p[1], d = p[2], f = p[3];
+        const int e[SL_WALK] = {a.x, a.z, b.x, b.z, d.x, d.z, f.x, f.z}, id[SL_WALK] = {a.y, a.w, b.y, b.w, d.y, d.w, f.y, f.w};
+#pragma unroll
+        for (int j = SL_WALK - 1; j >= 0; j--)
+            if (c > 0 && e[j] > qs) dst[--c] = id[j];
+    }
+}
+
+template <int L, int U>
+__global__ __launch_bounds__(SL_THREADS) void sl_fill_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
+                                                                  const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
+                                                                  const unsigned *__restrict__ recs, const unsigned *__restrict__ loff,
+                                                                  const long long *__restrict__ offsets /* CSR offsets of the segment's queries */,
+                                                                  const int2 *__restrict__ eid, int32_t *__restrict__ tmp_hits, int tile_log2)
+{
+    constexpr int NG = SL_THREADS / L;
+    constexpr unsigned LONG_RUN = 4 * L;
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ uint2 s_long[BM_LONG_CAP];
+    __shared__ int s_nlong;
+    __shared__ int s_tmp[20];
+    const int nit = *n_items;
+    const int per_xcd = (nit + 7) >> 3;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int it = (int)(blockIdx.x & 7) * per_xcd + slot;
+    if (slot >= per_xcd || it >= nit) return;
+    const int4 item = items[it];
+    const int unit = item.x & 0xffff, t0 = item.y, t1 = item.z;
+    const BmSeg &sg = segs[item.x >> 16];
+    const BmGeom g = sg.g;
+    const int b0 = unit << g.f, b1 = b0 + (1 << g.f);
+    const bool open_end = b1 >= BM_NB;
+    const unsigned *__restrict__ runs0 = runT + (int64_t)b0 * ntp;
+    const unsigned *__restrict__ runs1 = runT + (int64_t)(open_end ? b0 : b1) * ntp;
+    const int64_t seg_t0 = sg.tile0, seg_nq = sg.nq;
+    const long long lo_u = (long long)g.cmin + ((long long)b0 << g.shift);
+    const int gid = threadIdx.x / L, sub = threadIdx.x % L;
+    unsigned run[U];
+    long long tb[U];
+    auto load_runs = [&](int tbs) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tbs + u * NG + gid;
+            const int tc = t < t1 ? t : t0;
+            const unsigned a = runs0[tc] & 0xffffu;
+            unsigned e = runs1[tc] & 0xffffu;
+            if (open_end) {
+                const int64_t left = seg_nq - (((int64_t)tc - seg_t0) << tile_log2);
+                e = left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2;
+            }
+            run[u] = t < t1 ? (a | ((e - a) << 16)) : 0u;
+            tb[u] = offsets[((int64_t)tc - seg_t0) << tile_log2];
+        }
+    };
+    load_runs(t0);
+    const SlUnit UN = sl_stage_unit(sg, unit, dyn, s_tmp);
+    if (threadIdx.x == 0) s_nlong = 0;
+    __syncthreads();
+    auto emit = [&](long long tbase, unsigned rec, unsigned lo) { sl_emit_record(UN, g, lo_u, eid, rec, lo, tmp_hits + tbase); };
+    auto prep = [&](SlFillRound<U> &R, int tbs) {
+        unsigned cum = 0, lf_at = ~0u, listed_mask = 0;
+        long long lf_tbase = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int t = tbs + u * NG + gid;
+            const unsigned first = ((unsigned)t << tile_log2) + (run[u] & 0xffffu);
+            const unsigned len = run[u] >> 16;
+            R.first[u] = first;
+            R.lens[u] = len;
+            R.tbase[u] = tb[u];
+            const size_t a0 = (size_t)((unsigned)sub < len ? first + (unsigned)sub : 0u);
+            R.rec[u] = recs[a0];
+            R.lo[u] = loff[a0];
+            unsigned rem = len > (unsigned)L ? len - (unsigned)L : 0u;
+            if (len > LONG_RUN) {
+                bool listed = false;
+                if (sub == 0) {
+                    const int k = atomicAdd(&s_nlong, 1);
+                    if (k < BM_LONG_CAP) {
+                        s_long[k] = make_uint2(first, len);
+                        listed = true;
+                    }
+                }
+                listed = __shfl(listed, (int)(threadIdx.x & 63) - sub, 64);
+                if (listed) {
+                    rem = 0;
+                    listed_mask |= 1u << u;
+                }
+            }
+            const unsigned i = (unsigned)sub - cum;
+            if ((unsigned)sub >= cum && i < rem) {
+                lf_at = first + (unsigned)L + i;
+                lf_tbase = tb[u];
+            }
+            cum += rem;
+        }
+        R.lf_total = cum;
+        R.listed = listed_mask;
+        R.lf_at = lf_at;
+        R.lf_tbase = lf_tbase;
+        const size_t a1 = (size_t)(lf_at != ~0u ? lf_at : 0u);
+        R.lf_rec = recs[a1];
+        R.lf_lo = loff[a1];
+    };
+    auto finish = [&](SlFillRound<U> &R) {
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if ((unsigned)sub < R.lens[u]) emit(R.tbase[u], R.rec[u], R.lo[u]);
+        if (R.lf_at != ~0u) emit(R.lf_tbase, R.lf_rec, R.lf_lo);
+        for (unsigned base = L; __any(base < R.lf_total); base += L) {
+            const unsigned i = base + (unsigned)sub;
+            unsigned cum = 0, at = ~0u;
+            long long tbase = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const unsigned len = R.lens[u];
+                const unsigned rem = len > (unsigned)L && !((R.listed >> u) & 1u) ? len - (unsigned)L : 0u;
+                const unsigned j = i - cum;
+                if (i >= cum && j < rem) {
+                    at = R.first[u] + (unsigned)L + j;
+                    tbase = R.tbase[u];
+                }
+                cum += rem;
+            }
+            if (at != ~0u) emit(tbase, recs[(size_t)at], loff[(size_t)at]);
+        }
+    };
+    SlFillRound<U> A, B;
+    prep(A, t0);
+    load_runs(t0 + NG * U);
+    for (int tbs = t0; tbs < t1; tbs += 2 * NG * U) {
+        prep(B, tbs + NG * U);
+        load_runs(tbs + 2 * NG * U);
+        finish(A);
+        prep(A, tbs + 2 * NG * U);
+        load_runs(tbs + 3 * NG * U);
+        finish(B);
+    }
+    __syncthreads();
+    {
+        const int nl = s_nlong < BM_LONG_CAP ? s_nlong : BM_LONG_CAP;
+        for (int k = 0; k < nl; k++) {
+            const uint2 e = s_long[k];
+            const long long tbase = offsets[((int64_t)(e.x >> tile_log2) - seg_t0) << tile_log2];
+            for (unsigned p = (unsigned)L + threadIdx.x; p < e.y; p += SL_THREADS) emit(tbase, recs[(size_t)e.x + p], loff[(size_t)e.x + p]);
+        }
+    }
+}
+
+// Per tile: hits from the tile's scratch region (tile-sorted order) to CSR order; escapes answered from the index.
+// The tile's scratch offsets (by tile-sorted slot) sit in LDS; the tile is then taken SL_HU_CHUNK queries at a time:
+// their CSR offsets and scratch offsets go to LDS with coalesced reads, and 8 lanes copy each query's run, SL_HU_Q
+// queries per group in flight (with one workgroup per CU -- the LDS is full -- a single load in flight per thread
+// leaves the copy waiting on latency).  The reads are 20-byte runs at random places of the tile's region: that, not
+// occupancy, bounds the kernel (an LDS-free variant with full CUs and random reads of the offsets was slower).
+constexpr int SL_HU_CHUNK = 2048;
+constexpr int SL_HU_Q = 8;
+
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void sl_hits_unpermute_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
+                                                                    const unsigned *__restrict__ loff, const unsigned short *__restrict__ slots,
+                                                                    const long long *__restrict__ offsets, const int32_t *__restrict__ tmp_hits,
+                                                                    int32_t *__restrict__ hits)
+{
+    constexpr int TILE = THREADS * ITEMS;
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    unsigned *lo_s = reinterpret_cast<unsigned *>(dyn);  // [TILE] scratch offsets by tile-sorted slot
+    __shared__ unsigned c_off[SL_HU_CHUNK + 1];          // CSR offsets of the chunk's queries, relative to the chunk's first
+    __shared__ unsigned c_src[SL_HU_CHUNK];              // where each query's hits lie in the tile's scratch region (bit 31: escape)
+    const int64_t tile = blockIdx.x;
+    const BmSeg &sg = segs[tile_seg[tile]];
+    const int64_t ltile = tile - sg.tile0;
+    if (ltile >= sg.ntiles) return;
+    const IndexDev ix = sg.ix;
+    const int64_t q0 = ltile * TILE;
+    const int64_t left = sg.nq - q0;
+    const int n = (int)(left < TILE ? left : TILE);
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(loff + tile * TILE);
+        const int n4 = (n + 3) >> 2;
+        for (int i = threadIdx.x; i < n4; i += THREADS) reinterpret_cast<int4 *>(lo_s)[i] = src[i];
+    }
+    const int32_t *__restrict__ region = tmp_hits + offsets[q0];
+    for (int k0 = 0; k0 < n; k0 += SL_HU_CHUNK) {
+        const int m = n - k0 < SL_HU_CHUNK ? n - k0 : SL_HU_CHUNK;
+        const long long obase = offsets[q0 + k0];
+        __syncthreads();  // (first pass: lo_s complete; later passes: the previous chunk is done with c_off / c_src)
+        for (int k = threadIdx.x; k <= m; k += THREADS) {
+            c_off[k] = (unsigned)(offsets[q0 + k0 + k] - obase);
+            if (k < m) c_src[k] = lo_s[slots[tile * TILE + k0 + k]];
+        }
+        __syncthreads();
+        int32_t *__restrict__ out = hits + obase;
+        constexpr int G = THREADS / 8;
+        const unsigned sub = threadIdx.x & 7u;
+        for (int kb = threadIdx.x >> 3; kb < m; kb += SL_HU_Q * G) {
+            unsigned o[SL_HU_Q], c[SL_HU_Q], sv[SL_HU_Q];
+            int v[SL_HU_Q];
+#pragma unroll
+            for (int u = 0; u < SL_HU_Q; u++) {
+                const int k = kb + u * G;
+                const bool live = k < m;
+                o[u] = c_off[live ? k : 0];
+                sv[u] = live ? c_src[k] : 0x80000000u;
+                c[u] = (sv[u] >> 31) ? 0u : c_off[live ? k + 1 : 0] - o[u];
+            }
+#pragma unroll
+            for (int u = 0; u < SL_HU_Q; u++) v[u] = region[sub < c[u] ? sv[u] + sub : 0u];
+#pragma unroll
+            for (int u = 0; u < SL_HU_Q; u++)
+                if (sub < c[u]) out[o[u] + sub] = v[u];
+#pragma unroll
+            for (int u = 0; u < SL_HU_Q; u++)
+                for (unsigned j = 8 + sub; j < c[u]; j += 8) out[o[u] + j] = region[sv[u] + j];
+        }
+        for (int k = threadIdx.x; k < m; k += THREADS) {  // escapes: rare
+            if (!(c_src[k] >> 31)) continue;
+            int c = (int)(c_off[k + 1] - c_off[k]);
+            const int qs = sg.qs[q0 + k0 + k], qe = sg.qe[q0 + k0 + k];
+            int32_t *__restrict__ dst = out + c_off[k];
+            for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; c > 0; j--)
+                if (ix.e_ord[j] > qs) dst[--c] = ix.idx[j];
+        }
+    }
+}
+
+}  // namespace bxmi

@@ -1336,6 +1336,7 @@ __device__ __forceinline__ int count_one_global(const IndexDev &ix, const int32_
 
 }  // namespace bxmi
 #include "count_bitmap.hpp"
+#include "count_slices.hpp"
 namespace bxmi {
 
 // ---- partitioned find: window + count per query in bucket order, offsets carried to bucket order ----
@@ -2051,6 +2052,11 @@ static int64_t g_opt_bm_pair = 1;      // 1 = a search workgroup holds two neigh
 static int64_t g_opt_bm_nt = 0;        // 1 = non-temporal image loads in the pipelined search kernel
 static int64_t g_opt_bm_pipe = 1;      // 1 = the software-pipelined search kernel
 static int64_t g_opt_bm_exp = 0;       // diagnostics only (wrong results): price the pieces of the search kernel, see count_bitmap.hpp
+static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
+static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
+static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by run length and LDS, else forced (tests)
+static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
+static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
 
 int ivl_set_option(const char *key, int64_t value)
@@ -2119,6 +2125,26 @@ int ivl_set_option(const char *key, int64_t value)
         g_opt_bm_exp = value;
         return 1;
     }
+    if (!strcmp(key, "ivl.find_sliced")) {
+        g_opt_find_sliced = value != 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.slice")) {
+        g_opt_slice = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.sl_f")) {
+        g_opt_sl_f = value > SL_MAX_F ? SL_MAX_F : value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.sl_rbits")) {
+        g_opt_sl_rbits = value < 17 ? 17 : (value > 24 ? 24 : value);
+        return 1;
+    }
+    if (!strcmp(key, "ivl.sl_lanes")) {
+        g_opt_sl_lanes = value == 16 || value == 64 ? value : (value == 1 ? -1 : 0);  // 1 = the flat walk
+        return 1;
+    }
     if (!strcmp(key, "ivl.bm_hard_ppm")) {
         g_opt_bm_hard_ppm = value;
         return 1;
@@ -2155,8 +2181,13 @@ struct bxmi_ivl {
     int32_t cmax = 0;            // largest end of the sealed index
     int bm_state = 0;            // 0 = not decided yet, 1 = images built and the index qualifies, -1 = it does not
     int64_t bm_hard_cells = 0;   // what bm_image_kernel reported
-    BmGeom bm_geom{0, 0, 0, 0, 0, 0};
+    BmGeom bm_geom{0, 0, 0, 0, 0, 0, 0, 17, 0};
     DevBuf bm_images, bm_meta, bm_stats, bm_recs, bm_slots, bm_tbl, bm_runT, bm_grpcnt, bm_items, bm_params;
+    // slice search (count_slices.hpp)
+    int sl_state = 0;            // 0 = not decided yet, 1 = boundary table built and a single bucket's keys fit the LDS, -1 = they do not
+    unsigned sl_need[SL_MAX_F + 1] = {0, 0, 0, 0, 0, 0, 0};  // most keys a unit of 2^f buckets stages
+    DevBuf sl_meta, sl_stats, sl_unitcnt, sl_cnt, sl_loff, sl_hits, sl_eid;
+    bool sl_eid_ready = false;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][hits...]
     hipStream_t stream = nullptr;
     int device = 0;
@@ -2397,6 +2428,7 @@ static int bm_prepare_index(bxmi_ivl *h, hipStream_t st)
     g.nce = (int32_t)(W >> 5) + 2;
     g.ncs = (int32_t)((W + BM_MARGIN) >> 5) + 1;
     g.stride = (g.nce + g.ncs + 1) & ~1;
+    g.f = 0, g.rshift = 17, g.dshift = 0;
     BXMI_TRY(h->bm_images.reserve((size_t)BM_NB * g.stride * sizeof(uint2)));
     BXMI_TRY(h->bm_meta.reserve(BM_NB * sizeof(BmBucket)));
     BXMI_TRY(h->bm_stats.reserve(64));
@@ -2415,6 +2447,55 @@ static int bm_prepare_index(bxmi_ivl *h, hipStream_t st)
     const int64_t cells = 2 * ((((int64_t)h->cmax - (int64_t)h->geom.cmin) >> 5) + 1);
     if (stats[1] == 0 && (int64_t)stats[0] * 1000000 <= cells * g_opt_bm_hard_ppm) h->bm_state = 1;
     return BXMI_OK;
+}
+
+// Slice search: the ranks at every bucket boundary, and how many keys a unit of 2^f buckets would have to stage.
+static int sl_prepare_index(bxmi_ivl *h, hipStream_t st)
+{
+    h->sl_state = -1;
+    if (h->has_reversed || h->n < 1) return BXMI_OK;
+    BXMI_TRY(h->sl_meta.reserve((size_t)(BM_NB + 1) * sizeof(int4)));
+    BXMI_TRY(h->sl_stats.reserve(64));
+    BXMI_HIP(hipMemsetAsync(h->sl_stats.p, 0, 64, st));
+    hipLaunchKernelGGL(sl_meta_kernel, dim3((BM_NB + 1 + 255) / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n,
+                       h->geom.cmin, h->geom.shift, h->sl_meta.as<int4>());
+    hipLaunchKernelGGL(sl_fit_kernel, dim3(1), dim3(1024), 0, st, h->sl_meta.as<int4>(), h->sl_stats.as<unsigned>());
+    BXMI_LAUNCH_CHECK();
+    BXMI_HIP(hipMemcpyAsync(h->sl_need, h->sl_stats.p, sizeof(h->sl_need), hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    if (h->sl_need[0] <= (unsigned)SL_CAP) h->sl_state = 1;
+    return BXMI_OK;
+}
+
+// The slice geometry of one index for a batch with `tile` queries per tile: the unit grows while its keys fit and its
+// offsets leave 12 bits for the record's length (longer units = longer runs and fewer work items).
+static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_t *run_len)
+{
+    BmGeom g;
+    g.cmin = h->geom.cmin, g.cmax = h->cmax, g.shift = h->geom.shift;
+    const int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin;
+    const int64_t nb_used = ((span > 0 ? span : 0) >> g.shift) + 1;
+    int f = 0;
+    if (g_opt_sl_f >= 0) {
+        for (f = (int)g_opt_sl_f; f > 0 && h->sl_need[f] > (unsigned)SL_CAP; f--) {}
+    } else {
+        for (int k = 1; k <= SL_MAX_F; k++) {
+            if (h->sl_need[k] > (unsigned)SL_CAP || g.shift + k > g_opt_sl_rbits) break;
+            f = k;
+        }
+    }
+    g.f = f;
+    g.rshift = g.shift + f > 17 ? g.shift + f : 17;
+    const int64_t Wu = (int64_t)1 << (g.shift + f);
+    int d = 0;
+    while (((Wu + SL_MARGIN) >> d) + 1 > SL_DIR_CELLS) d++;
+    g.dshift = d;
+    g.ncs = (int32_t)((Wu + SL_MARGIN) >> d) + 1;
+    g.nce = (int32_t)(Wu >> d) + 1;
+    g.stride = 0;
+    *lds_bytes = 2 * ((size_t)h->sl_need[f] + 16) + 2 * (size_t)((g.ncs + 2 + 7) & ~7) + 2 * (size_t)(g.nce + 2 + 8);
+    *run_len = (tile << f) / nb_used;
+    return g;
 }
 
 // Everything the kernels of one batch need, as they are handed to every launch.
@@ -2487,13 +2568,20 @@ static int bm_launch_search_u(const BmLaunch &L, unsigned grid, hipStream_t st)
 }
 
 template <int THREADS, int ITEMS>
-static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st)
+static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st, const unsigned *cnt = nullptr, unsigned *loff = nullptr)
 {
     bxmi_ivl *h = L.owner;
     const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);
-    BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS>), lds));
-    hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bm_recs.as<unsigned>(),
-                       h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate);
+    if (!cnt) cnt = h->bm_recs.as<unsigned>();
+    if (loff) {
+        BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS, true>), lds));
+        hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, loff);
+    } else {
+        BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS>), lds));
+        hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, (unsigned *)nullptr);
+    }
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -2501,8 +2589,64 @@ static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hip
 // The bitmap-cell pass over a batch of n segments (n sealed, qualifying indexes with their queries): [order check ->]
 // tile sort -> run table + plan -> search -> un-permute -> totals, all on `st`, six launches whatever n is.
 // counts[i] must not be NULL; totals_dev[i] may be.  The scratch of hs[0] serves the whole batch.
+template <int LANES>
+static int sl_launch_search(const BmLaunch &L, unsigned grid, hipStream_t st, unsigned *out)
+{
+    bxmi_ivl *h = L.owner;
+    BXMI_TRY(allow_big_lds((sl_search_pipe_kernel<LANES, 2>), L.search_lds));
+    hipLaunchKernelGGL((sl_search_pipe_kernel<LANES, 2>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+                       h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), out, L.tile_log2, L.gate);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+template <int LANES>
+static int sl_launch_fill(const BmLaunch &L, unsigned grid, hipStream_t st, const unsigned *loff, const long long *offsets, const int2 *eid,
+                          int32_t *tmp_hits)
+{
+    bxmi_ivl *h = L.owner;
+    BXMI_TRY(allow_big_lds((sl_fill_pipe_kernel<LANES, 2>), L.search_lds));
+    hipLaunchKernelGGL((sl_fill_pipe_kernel<LANES, 2>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+                       h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), loff, offsets, eid, tmp_hits, L.tile_log2);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+template <int THREADS, int ITEMS>
+static int sl_launch_hits_unpermute(const BmLaunch &L, hipStream_t st, const unsigned *loff, const long long *offsets, const int32_t *tmp_hits,
+                                    int32_t *hits)
+{
+    bxmi_ivl *h = L.owner;
+    const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);  // + 16 KB static
+    BXMI_TRY(allow_big_lds((sl_hits_unpermute_kernel<THREADS, ITEMS>), lds));
+    hipLaunchKernelGGL((sl_hits_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg, loff,
+                       h->bm_slots.as<unsigned short>(), offsets, tmp_hits, hits);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+// find() through the exchange (count_slices.hpp): what the count half leaves behind for the fill half.
+struct BmFindCtx {
+    BmLaunch L;      // the batch as launched (items, run table and records stay in the owner's scratch)
+    unsigned sgrid;
+    int lanes;       // 16 or 64
+    int variant;     // tile shape
+};
+
+static int sl_launch_search_flat(const BmLaunch &L, unsigned grid, hipStream_t st, unsigned *out)
+{
+    bxmi_ivl *h = L.owner;
+    BXMI_TRY(allow_big_lds((sl_search_flat_kernel<4>), L.search_lds));
+    hipLaunchKernelGGL((sl_search_flat_kernel<4>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+                       h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), out, L.tile_log2, L.gate);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+// `slices`: the search stage stages key slices (count_slices.hpp) instead of bucket images; every index of the batch
+// must have qualified for the chosen kind.
 static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
-                             int32_t *const *counts, int64_t *const *totals_dev, hipStream_t st)
+                             int32_t *const *counts, int64_t *const *totals_dev, hipStream_t st, bool slices = false, BmFindCtx *fx = nullptr)
 {
     bxmi_ivl *h = hs[0];
     int64_t nq_all = 0;
@@ -2517,17 +2661,27 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     // the batch's tile numbering: every segment starts on a plan-group boundary
     std::vector<BmSeg> segs((size_t)n);
     int64_t ntp = 0;
-    size_t max_stride = 0;
+    size_t max_stride = 0, sl_lds = 0;
+    int64_t sl_run = INT64_MAX;  // shortest expected (tile, unit) run of the batch
     bool any_total = false;
     for (int i = 0; i < n; i++) {
         BmSeg &sg = segs[(size_t)i];
-        sg.g = hs[i]->bm_geom;
+        if (slices) {
+            size_t lds = 0;
+            int64_t run_len = 0;
+            sg.g = sl_geom(hs[i], tile, &lds, &run_len);
+            if (lds > sl_lds) sl_lds = lds;
+            if (run_len < sl_run) sl_run = run_len;
+        } else {
+            sg.g = hs[i]->bm_geom;
+        }
         sg.qs = qs[i], sg.qe = qe[i], sg.counts = counts[i];
         sg.nq = nq[i];
         sg.tile0 = ntp;
         sg.ntiles = div_up(nq[i], tile);
         sg.images = hs[i]->bm_images.as<uint2>();
         sg.bmeta = hs[i]->bm_meta.as<BmBucket>();
+        sg.smeta = slices ? hs[i]->sl_meta.as<int4>() : nullptr;
         sg.ix = index_dev(hs[i]);
         sg.e_sorted = hs[i]->e_sorted.as<int32_t>();
         ntp += div_up(sg.ntiles, BM_GROUP_TILES) * BM_GROUP_TILES;
@@ -2538,7 +2692,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (ntp == 0) return BXMI_OK;
     const int ngroups = (int)(ntp / BM_GROUP_TILES);
     // PAIR: a search workgroup holds the images of two neighbouring buckets (needs both in one CU's LDS)
-    const bool pair = g_opt_bm_pair != 0 && 2 * max_stride * sizeof(uint2) + 8192 <= 160 * 1024;
+    const bool pair = !slices && g_opt_bm_pair != 0 && 2 * max_stride * sizeof(uint2) + 8192 <= 160 * 1024;
     const int chunk = pair ? 2 * BM_CHUNK : BM_CHUNK;
     const int64_t max_items = (int64_t)n * ((pair ? BM_NB / 2 : BM_NB) + 2) + 2 * (nq_all / chunk) + 2;
     BXMI_TRY(h->bm_recs.reserve((size_t)ntp * tile * 4));
@@ -2546,7 +2700,13 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     BXMI_TRY(h->bm_tbl.reserve((size_t)ntp * BM_NB * 2));
     BXMI_TRY(h->bm_runT.reserve((size_t)ntp * BM_NB * 4));
     BXMI_TRY(h->bm_grpcnt.reserve((size_t)ngroups * BM_NB * 4));
+    if (slices) BXMI_TRY(h->sl_unitcnt.reserve((size_t)ngroups * BM_NB * 4));
     BXMI_TRY(h->bm_items.reserve((size_t)(max_items + 2) * sizeof(int4)));  // [0] = the item count, items from [1]
+    if (fx) {  // find(): counts apart from the records, and the tile-sorted offsets
+        BXMI_TRY(h->sl_cnt.reserve((size_t)ntp * tile * 4));
+        BXMI_TRY(h->sl_loff.reserve((size_t)ntp * tile * 4));
+    }
+    unsigned *search_out = fx ? h->sl_cnt.as<unsigned>() : h->bm_recs.as<unsigned>();
     // parameter block in HBM: [segments][totals pointers][tile -> segment], written by bm_params_kernel from its arguments
     const size_t seg_bytes = (size_t)n * sizeof(BmSeg), tot_bytes = (size_t)n * sizeof(void *);
     const size_t tile_off = (seg_bytes + tot_bytes + 15) & ~(size_t)15, par_bytes = tile_off + (size_t)ntp * sizeof(unsigned short);
@@ -2567,7 +2727,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     // [segments][PT_SLOTS partial totals], then the flag: 1 = the starts are NOT sorted
     BXMI_TRY(h->p_slots.reserve(((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long)));
     unsigned long long *slots = h->p_slots.as<unsigned long long>();
-    unsigned *unsorted = g_opt_sorted_path && n == 1 ? reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS) : nullptr;
+    unsigned *unsorted = g_opt_sorted_path && n == 1 && !fx ? reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS) : nullptr;
     BXMI_HIP(hipMemsetAsync(slots, 0, ((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long), st));
     unsigned long long *tslots = any_total ? slots : nullptr;
     BmLaunch L;
@@ -2575,7 +2735,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.tile_seg = reinterpret_cast<const unsigned short *>(h->bm_params.as<unsigned char>() + tile_off);
     L.owner = h;
     L.ntp = ntp, L.ngroups = ngroups, L.tile_log2 = tile_log2;
-    L.search_lds = (size_t)(pair ? 2 : 1) * max_stride * sizeof(uint2);
+    L.search_lds = slices ? sl_lds : (size_t)(pair ? 2 : 1) * max_stride * sizeof(uint2);
     L.gate = unsorted;
     if (unsorted) {
         // one index, its batch possibly sorted by start already: one pass over the queries as they lie then, and every
@@ -2595,7 +2755,12 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY((bm_launch_tiles<512, 32>(L, st)));
     hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                        tile_log2, h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
-    if (pair)
+    if (slices) {
+        hipLaunchKernelGGL(sl_unit_sums_kernel, dim3((unsigned)ngroups), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), L.segs, L.tile_seg,
+                           h->sl_unitcnt.as<unsigned>(), unsorted);
+        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(1), dim3(1024), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
+                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
+    } else if (pair)
         hipLaunchKernelGGL(bm_plan_kernel<1>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
                            h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     else
@@ -2603,14 +2768,26 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
                            h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     BXMI_LAUNCH_CHECK();
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
-    if (pair)
+    if (slices) {
+        // long runs (sparse index, big units): the flat walk; else L lanes per run
+        int lanes = g_opt_sl_lanes < 0 ? 0 : (g_opt_sl_lanes ? (int)g_opt_sl_lanes : (sl_run >= 96 ? 0 : (sl_run >= 40 ? 64 : 16)));
+        if (fx && lanes == 0) lanes = 64;  // (the fill half has no flat walk)
+        if (lanes == 0)
+            BXMI_TRY(sl_launch_search_flat(L, sgrid, st, search_out));
+        else if (lanes == 64)
+            BXMI_TRY(sl_launch_search<64>(L, sgrid, st, search_out));
+        else
+            BXMI_TRY(sl_launch_search<16>(L, sgrid, st, search_out));
+        if (fx) fx->L = L, fx->sgrid = sgrid, fx->lanes = lanes, fx->variant = variant;
+    } else if (pair)
         BXMI_TRY(bm_launch_search_u<true>(L, sgrid, st));
     else
         BXMI_TRY(bm_launch_search_u<false>(L, sgrid, st));
+    unsigned *loff = fx ? h->sl_loff.as<unsigned>() : nullptr;
     if (variant == 2)
-        BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st)));
+        BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff)));
     else
-        BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st)));
+        BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff)));
     if (any_total) {
         hipLaunchKernelGGL(bm_fold_totals_kernel, dim3((unsigned)n), dim3(64), 0, st, slots,
                            reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes));
@@ -2619,9 +2796,73 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     return BXMI_OK;
 }
 
-static int ivl_count_bitmap(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total_dev, hipStream_t st)
+// find() for a large unsorted batch on an index the slice stage serves: count half (counts in query order, tile-sorted
+// offsets), CSR offsets, capacity check on the host, fill half, hits back to query order.  See count_slices.hpp.
+static int ivl_find_sliced(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits, int64_t cap,
+                           int64_t *total_host, hipStream_t st)
 {
-    return bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &total_dev, st);
+    BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
+    BmFindCtx fx;
+    int32_t *counts = h->q_cnt.as<int32_t>();
+    int64_t *no_total = nullptr;
+    BXMI_TRY(bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &no_total, st, true, &fx));
+    BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
+                                                           reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
+    int64_t total = 0;
+    BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    if (total_host) *total_host = total;
+    if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
+    if (total == 0) return BXMI_OK;
+    BXMI_TRY(h->sl_hits.reserve((size_t)(total + 16) * 4));
+    if (!h->sl_eid_ready) {  // (end, index) pairs in start order, once per sealed index
+        BXMI_TRY(h->sl_eid.reserve(((size_t)h->n + SL_WALK) * sizeof(int2)));
+        hipLaunchKernelGGL(sl_pack_eid_kernel, dim3((unsigned)div_up(h->n + SL_WALK, 256)), dim3(256), 0, st, h->e_ord.as<int32_t>(),
+                           h->idx.as<int32_t>(), (int)h->n, h->sl_eid.as<int2>());
+        BXMI_LAUNCH_CHECK();
+        h->sl_eid_ready = true;
+    }
+    const unsigned *loff = h->sl_loff.as<unsigned>();
+    const long long *offs = reinterpret_cast<const long long *>(offsets);
+    const int2 *eid = h->sl_eid.as<int2>() + SL_WALK;
+    if (fx.lanes == 64)
+        BXMI_TRY(sl_launch_fill<64>(fx.L, fx.sgrid, st, loff, offs, eid, h->sl_hits.as<int32_t>()));
+    else
+        BXMI_TRY(sl_launch_fill<16>(fx.L, fx.sgrid, st, loff, offs, eid, h->sl_hits.as<int32_t>()));
+    if (fx.variant == 2)
+        BXMI_TRY((sl_launch_hits_unpermute<1024, 32>(fx.L, st, loff, offs, h->sl_hits.as<int32_t>(), hits)));
+    else
+        BXMI_TRY((sl_launch_hits_unpermute<1024, 16>(fx.L, st, loff, offs, h->sl_hits.as<int32_t>(), hits)));
+    return BXMI_OK;
+}
+
+// Which search stage serves a sealed index in the large-batch pass: 0 = neither (older paths), 1 = bucket images,
+// 2 = key slices.  Images cost 0.5 B per coordinate of the span and win on dense indexes; sparse ones (fewer than one
+// target per 64 coordinates) and spans whose bucket image outgrows the LDS take slices.  Prepared on first use.
+static int bm_choose_stage(bxmi_ivl *h, hipStream_t st, int *kind)
+{
+    *kind = 0;
+    if (h->has_reversed || h->n < 4096) return BXMI_OK;
+    int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin;
+    if (span < 0) span = 0;
+    const bool slices_first = g_opt_slice == 1 || (g_opt_slice < 0 && (span / h->n >= 64 || h->geom.shift > BM_MAX_SHIFT));
+    if (slices_first) {
+        if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
+        if (h->sl_state == 1) {
+            *kind = 2;
+            return BXMI_OK;
+        }
+    }
+    if (h->bm_state == 0) BXMI_TRY(bm_prepare_index(h, st));
+    if (h->bm_state == 1) {
+        *kind = 1;
+        return BXMI_OK;
+    }
+    if (!slices_first && g_opt_slice != 0) {
+        if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
+        if (h->sl_state == 1) *kind = 2;
+    }
+    return BXMI_OK;
 }
 
 static int ivl_stream(bxmi_ivl *h)
@@ -2766,6 +3007,8 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         h->geom.shift = shift;
         h->cmax = cmax;
         h->bm_state = 0;
+        h->sl_state = 0;
+        h->sl_eid_ready = false;
         BXMI_TRY(h->slice_bounds.reserve(PT_NB * sizeof(SliceBound)));
         hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
                            h->pm.as<int32_t>(), (int)n, h->geom, h->slice_bounds.as<SliceBound>());
@@ -2804,6 +3047,15 @@ extern "C" int bxmi_ivl_bitmap_state(const bxmi_ivl_t *h, int *state, int64_t *h
     BXMI_TRY(need_sealed(h, "bxmi_ivl_bitmap_state"));
     if (state) *state = h->bm_state;
     if (hard_cells) *hard_cells = h->bm_hard_cells;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_slice_state(const bxmi_ivl_t *h, int *state, int64_t *unit_keys)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_slice_state"));
+    if (state) *state = h->sl_state;
+    if (unit_keys)
+        for (int f = 0; f <= SL_MAX_F; f++) unit_keys[f] = h->sl_need[f];
     return BXMI_OK;
 }
 
@@ -2859,8 +3111,9 @@ extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_
     const bool bitmap = counts && g_opt_bitmap != 0 && !h->has_reversed && h->n >= 4096 &&
                         (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_bitmap_min));
     if (bitmap) {
-        if (h->bm_state == 0) BXMI_TRY(bm_prepare_index(h, st));
-        if (h->bm_state == 1) return ivl_count_bitmap(h, qs, qe, nq, counts, total_dev, st);
+        int kind = 0;
+        BXMI_TRY(bm_choose_stage(h, st, &kind));
+        if (kind) return bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &total_dev, st, kind == 2);
     }
     if (partition) return ivl_count_partitioned(h, qs, qe, nq, counts, total_dev, st);
     TreeDev S = h->treeS.dev, E = h->treeE.dev;
@@ -2892,11 +3145,11 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
     if (n < 0 || (n > 0 && (!hs || !qs || !qe || !nq))) return fail(BXMI_EINVAL, "bxmi_ivl_count_multi_dev: bad arguments");
     hipStream_t st = as_stream(stream);
     // indexes whose batch can ride the bitmap-cell pass are answered together (one pass, six launches); the others one by one
-    std::vector<bxmi_ivl *> fh;
-    std::vector<const int32_t *> fqs, fqe;
-    std::vector<int64_t> fnq;
-    std::vector<int32_t *> fc;
-    std::vector<int64_t *> ft;
+    std::vector<bxmi_ivl *> fh[2];  // [0] images, [1] slices
+    std::vector<const int32_t *> fqs[2], fqe[2];
+    std::vector<int64_t> fnq[2];
+    std::vector<int32_t *> fc[2];
+    std::vector<int64_t *> ft[2];
     std::vector<int> rest;
     int64_t nq_all = 0;
     for (int i = 0; i < n; i++) {
@@ -2910,16 +3163,20 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
     for (int i = 0; i < n; i++) {
         bxmi_ivl *h = hs[i];
         if (nq[i] == 0) continue;
-        bool ok = fused && counts[i] && !h->has_reversed && h->n >= 4096;
-        if (ok && h->bm_state == 0) BXMI_TRY(bm_prepare_index(h, st));
-        if (ok && h->bm_state == 1) {
-            fh.push_back(h), fqs.push_back(qs[i]), fqe.push_back(qe[i]), fnq.push_back(nq[i]), fc.push_back(counts[i]);
-            ft.push_back(totals_dev ? totals_dev[i] : nullptr);
+        int kind = 0;
+        if (fused && counts[i]) BXMI_TRY(bm_choose_stage(h, st, &kind));
+        if (kind) {
+            const int k = kind - 1;
+            fh[k].push_back(h), fqs[k].push_back(qs[i]), fqe[k].push_back(qe[i]), fnq[k].push_back(nq[i]), fc[k].push_back(counts[i]);
+            ft[k].push_back(totals_dev ? totals_dev[i] : nullptr);
         } else {
             rest.push_back(i);
         }
     }
-    if (!fh.empty()) BXMI_TRY(bm_count_segments(fh.data(), (int)fh.size(), fqs.data(), fqe.data(), fnq.data(), fc.data(), ft.data(), st));
+    for (int k = 0; k < 2; k++)
+        if (!fh[k].empty())
+            BXMI_TRY(bm_count_segments(fh[k].data(), (int)fh[k].size(), fqs[k].data(), fqe[k].data(), fnq[k].data(), fc[k].data(), ft[k].data(), st,
+                                       k == 1));
     for (int i : rest)
         BXMI_TRY(bxmi_ivl_count_dev(hs[i], qs[i], qe[i], nq[i], counts ? counts[i] : nullptr, totals_dev ? totals_dev[i] : nullptr, stream));
     return BXMI_OK;
@@ -2980,6 +3237,11 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
             BXMI_HIP(hipMemcpyAsync(&unsorted, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
             BXMI_HIP(hipStreamSynchronize(st));
             if (!unsorted) return ivl_find_local(h, qs, qe, nq, offsets, hits, cap, total_host, st);
+        }
+        if (g_opt_find_sliced && g_opt_bitmap != 0 && g_opt_slice != 0 && h->n >= 4096 && nq >= g_opt_bitmap_min &&
+            !(((uintptr_t)qs | (uintptr_t)qe) & 15)) {
+            if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
+            if (h->sl_state == 1) return ivl_find_sliced(h, qs, qe, nq, offsets, hits, cap, total_host, st);
         }
         return ivl_find_partitioned(h, qs, qe, nq, offsets, hits, cap, total_host, st);
     }

@@ -65,6 +65,9 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *   ivl.count_cells    1 (default): bucket search by direct-addressed cells; 0: LDS search trees
  *   ivl.bitmap         -1 (default): large batches with per-query counts take the bitmap-cell pass when the index qualifies; 0 never
  *   ivl.bm_variant, ivl.bm_u, ivl.bm_hard_ppm   tile shape / runs in flight / qualification threshold of that pass
+ *   ivl.slice          -1 (default): that pass searches staged key slices instead of bucket images where the index is
+ *                      sparse or its span too wide for images; 0 never; 1 wherever the slices fit
+ *   ivl.sl_f, ivl.sl_lanes   buckets per slice unit (2^f) / lanes per run of the slice search (tests)
  *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search
  *   ivl.lds_ints, ivl.count_grid   staging budget / grid of the direct count kernel
  *   bits.grid          grid of the per-bitset kernels
@@ -111,6 +114,10 @@ int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int32_t *const 
  * bitmap-cell pass (count_bitmap.hpp: its per-bucket images are built), -1 = the bucketed search pass (span wider than
  * 2^28, reversed targets, or too many coordinates carrying duplicates: *hard_cells of them).  Introspection only. */
 int bxmi_ivl_bitmap_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
+/* The same for the slice search stage (count_slices.hpp: sorted keys staged per unit of 2^f buckets; serves sparse
+ * indexes and spans whose bucket image outgrows the LDS): *state = 0 not decided yet, 1 = usable, -1 = one bucket's
+ * keys alone do not fit; unit_keys[0..6] = the most keys a unit of 2^f buckets stages.  Introspection only. */
+int bxmi_ivl_slice_state(const bxmi_ivl_t *h, int *state, int64_t *unit_keys);
 
 /* IntervalTree.find for a batch, as CSR: offsets[nq+1] (int64) and, for query
  * i, hits[offsets[i]..offsets[i+1]) = insertion indices in the reference's

@@ -36,7 +36,8 @@ def set_opt(key, value):
 
 
 DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
-                "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 0, "ivl.bm_exp": 0}
+                "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 0, "ivl.bm_exp": 0, "ivl.slice": -1, "ivl.sl_f": -1,
+                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20}
 
 
 def reset_opts():
@@ -347,11 +348,13 @@ def test_incremental_append_reseals(O, IntervalIndex):
         assert np.array_equal(ix.find(qs, qe)[1], t.find_batch(qs, qe)[1])
 
 
+@pytest.mark.parametrize("stage", ["images", "slices"])
 @pytest.mark.parametrize("shape", ["uniform", "sorted", "one_bucket", "messy", "ragged_tail", "dups"])
-def test_bitmap_pass_differential(O, IntervalIndex, shape):
-    """The bitmap-cell count pass (count_bitmap.hpp) against the oracle treap: shuffled, sorted and clumped batches,
-    zero-length / reversed / off-grid / very long queries (escapes), tiles that are not full, targets whose coordinates
-    carry duplicates (duplicate descriptors and hard cells), all tile shapes and unroll depths."""
+def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
+    """The large-batch count pass (count_bitmap.hpp, and its slice search stage count_slices.hpp) against the oracle
+    treap: shuffled, sorted and clumped batches, zero-length / reversed / off-grid / very long queries (escapes), tiles
+    that are not full, targets whose coordinates carry duplicates (duplicate descriptors and hard cells; cells with
+    thousands of keys for the slices), all tile shapes, unroll depths, unit sizes and run widths."""
     rng = np.random.default_rng(7 + ["uniform", "sorted", "one_bucket", "messy", "ragged_tail", "dups"].index(shape))
     n, span = 120_000, 40_000_000  # bucket width 2^15
     s = rng.integers(1000, span, size=n)
@@ -388,6 +391,24 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape):
     ix = make_index(IntervalIndex, s, e)
     set_opt("ivl.partition", 1)
     try:
+        if stage == "slices":
+            set_opt("ivl.slice", 1)
+            # lanes: 16 / 64 per (tile, unit) run, 1 = the flat walk over the item's runs, 0 = by expected run length
+            for k, (variant, f, lanes) in enumerate(((0, -1, 0), (1, 0, 16), (2, 2, 64), (0, 6, 16), (2, 6, 64), (1, 3, 0), (0, 1, 64), (-1, -1, 0),
+                                                     (0, 6, 1), (2, 0, 1), (1, 4, 1))):
+                set_opt("ivl.sorted_path", k % 2)
+                set_opt("ivl.bm_variant", variant)
+                set_opt("ivl.sl_f", f)
+                set_opt("ivl.sl_lanes", lanes)
+                got, got_total = ix.count(qs, qe)
+                state = ix.slice_state()
+                assert state[0] == 1 and ix.bitmap_state()[0] == 0, (state, ix.bitmap_state())
+                bad = np.nonzero(got != want)[0]
+                assert len(bad) == 0, (shape, variant, f, lanes, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+                assert got_total == want_total
+            assert state[1][0] > 0 and all(a <= b for a, b in zip(state[1], state[1][1:]))  # keys per unit grow with the unit
+            return
+        set_opt("ivl.slice", 0)
         for k, (variant, u, pair, pipe) in enumerate(((0, 4, 0, 0), (1, 2, 1, 0), (2, 8, 0, 0), (0, 4, 1, 0), (0, 2, 0, 1), (0, 4, 0, 1), (2, 2, 1, 1),
                                                       (1, 4, 1, 1), (-1, 2, 1, 1))):
             set_opt("ivl.sorted_path", k % 2)  # off: a sorted batch goes through the exchange too (long runs, one bucket per tile)
@@ -407,8 +428,73 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape):
         reset_opts()
 
 
+@pytest.mark.parametrize("shape", ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target"])
+def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
+    """find() on large unsorted batches (count_slices.hpp: count half, CSR offsets, fill half, hits back to query order)
+    against the oracle treap's find: same offsets, same hits in the same order.  Escapes (zero-length / reversed /
+    off-grid / over-long queries), duplicated coordinates, a tile that is not full, one target spanning everything,
+    all tile shapes, unit sizes and run widths; and the bucketed find of the first generation on the same input."""
+    shapes = ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target"]
+    rng = np.random.default_rng(70 + shapes.index(shape))
+    n, span = 100_000, 30_000_000
+    s = rng.integers(1000, span, size=n)
+    if shape == "dups":
+        s[: n // 2] = rng.choice(s[n // 2:], size=n // 2)
+        s[:1500] = rng.integers(5_000_000, 5_000_040, size=1500)
+    e = s + rng.integers(0, 1200, size=n)
+    if shape == "long_target":
+        s[0], e[0] = 2000, span - 5  # every query meets it, and the walk down from hi passes thousands of candidates
+        s[1], e[1] = 15_000_000, 15_400_000
+    nq = {"ragged_tail": 16384 * 2 + 311}.get(shape, 50_000)
+    qs = rng.integers(0, span + 2000, size=nq)
+    qe = qs + rng.integers(1, 2500, size=nq)
+    if shape == "sorted":
+        o = np.argsort(qs, kind="stable")
+        qs, qe = qs[o], qe[o]
+    elif shape == "messy":
+        k = nq // 10
+        qe[:k] = qs[:k]
+        qe[k:2 * k] = qs[k:2 * k] - rng.integers(1, 50, size=k)
+        qe[2 * k:3 * k] = qs[2 * k:3 * k] + rng.integers(32766, 300_000, size=k)
+        qs[3 * k:4 * k] = rng.integers(-(2**31), 1000, size=k)
+        qe[3 * k:4 * k] = qs[3 * k:4 * k] + rng.integers(1, 2000, size=k)
+        qs[4 * k:5 * k] = rng.integers(span + 2000, 2**31 - 5000, size=k)
+        qe[4 * k:5 * k] = qs[4 * k:5 * k] + rng.integers(1, 2000, size=k)
+        p = rng.permutation(nq)
+        qs, qe = qs[p], qe[p]
+    s, e, qs, qe = (np.clip(a, -(2**31), 2**31 - 1).astype(np.int32) for a in (s, e, qs, qe))
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    want_off, want_hits = t.find_batch(qs, qe)
+    ix = make_index(IntervalIndex, s, e)
+    set_opt("ivl.partition", 1)
+    set_opt("ivl.bitmap_min", 1)
+    try:
+        for k, (variant, f, lanes, sorted_path) in enumerate(((0, -1, 0, 0), (1, 0, 16, 0), (2, 2, 64, 0), (0, 6, 16, 0), (2, 6, 64, 0), (-1, -1, 0, 1))):
+            set_opt("ivl.sorted_path", sorted_path)
+            set_opt("ivl.bm_variant", variant)
+            set_opt("ivl.sl_f", f)
+            set_opt("ivl.sl_lanes", lanes)
+            off, hits = ix.find(qs, qe)
+            assert ix.slice_state()[0] == 1
+            assert np.array_equal(off, want_off), (shape, variant, f, lanes, np.nonzero(np.diff(off) != np.diff(want_off))[0][:8])
+            bad = np.nonzero(hits != want_hits)[0]
+            assert len(bad) == 0, (shape, variant, f, lanes, bad[:8], hits[bad[:8]], want_hits[bad[:8]])
+        set_opt("ivl.find_sliced", 0)
+        off, hits = ix.find(qs, qe)
+        assert np.array_equal(off, want_off) and np.array_equal(hits, want_hits), "bucketed find"
+        # a buffer that is too small is reported with the total (the wrapper then retries with the exact size)
+        set_opt("ivl.find_sliced", 1)
+        off, hits = ix.find(qs, qe, cap_hint=max(1, int(want_off[-1]) // 2 - 1))
+        assert np.array_equal(off, want_off) and np.array_equal(hits, want_hits), "after BXMI_ERANGE"
+    finally:
+        reset_opts()
+
+
 def test_bitmap_pass_is_refused_where_it_does_not_fit(O, IntervalIndex):
-    """Spans beyond 2^28, reversed targets and heavily duplicated coordinates keep the bucketed search pass."""
+    """Spans beyond 2^28, reversed targets and heavily duplicated coordinates keep the bucketed search pass when the slice
+    stage is off; with it on (the default) the wide span and the duplicates are served by slices, and a bucket that
+    holds more keys than the LDS refuses the slices too."""
     rng = np.random.default_rng(9)
     cases = {}
     s = rng.integers(0, 2**30, size=50_000)
@@ -421,6 +507,9 @@ def test_bitmap_pass_is_refused_where_it_does_not_fit(O, IntervalIndex):
     cases["duplicates"] = (s, s + 8 * rng.integers(0, 10, size=50_000))
     qs = rng.integers(0, 10_000_000, size=20_000).astype(np.int32)
     qe = (qs + rng.integers(1, 800, size=20_000)).astype(np.int32)
+    s = rng.integers(0, 2**29, size=150_000)
+    s[:90_000] = rng.integers(1_000_000, 1_001_000, size=90_000)  # one bucket with 90k keys: more than a workgroup stages
+    cases["pile"] = (s, s + rng.integers(0, 500, size=150_000))
     set_opt("ivl.partition", 1)
     try:
         for name, (s, e) in cases.items():
@@ -428,11 +517,24 @@ def test_bitmap_pass_is_refused_where_it_does_not_fit(O, IntervalIndex):
             t = O.OracleIntervalTree()
             t.insert_many_arrays(s, e)
             want, want_total = t.count_batch(qs, qe)
-            ix = make_index(IntervalIndex, s, e)
-            assert ix.bitmap_state()[0] == 0
-            got, got_total = ix.count(qs, qe)
-            assert np.array_equal(got, want) and got_total == want_total, name
-            assert ix.bitmap_state()[0] == (0 if name == "reversed" else -1), (name, ix.bitmap_state())
+            for slices in (0, -1):
+                set_opt("ivl.slice", slices)
+                ix = make_index(IntervalIndex, s, e)
+                assert ix.bitmap_state()[0] == 0 and ix.slice_state()[0] == 0
+                got, got_total = ix.count(qs, qe)
+                assert np.array_equal(got, want) and got_total == want_total, (name, slices)
+                bm, sl = ix.bitmap_state()[0], ix.slice_state()[0]
+                if name == "reversed":
+                    assert (bm, sl) == (0, 0)
+                elif slices == 0:
+                    assert (bm, sl) == (-1, 0), (name, bm, sl)
+                elif name == "pile":
+                    assert (bm, sl) == (-1, -1), (name, bm, sl)
+                elif name == "wide":
+                    assert (bm, sl) == (0, 1), (name, bm, sl)     # slices first: the images are never built
+                else:
+                    assert (bm, sl) == (-1, 1), (name, bm, sl)    # dense index: images tried first, then slices
+                ix.close()
     finally:
         reset_opts()
 
@@ -452,6 +554,14 @@ def test_scale_1M_hash(golden_scale, IntervalIndex):
     set_opt("ivl.lds_ints", 18688)
     set_opt("ivl.partition", 1)
     try:
+        for variant in (0, 1, 2, 3):  # the slice stage (1M targets on 250M coordinates are sparse): tile shapes, unit sizes, run widths
+            set_opt("ivl.bm_variant", variant % 3)
+            set_opt("ivl.sl_f", (-1, 0, 3, 6)[variant])
+            set_opt("ivl.sl_lanes", (0, 64, 16, 1)[variant])
+            counts, total = ix.count(qs, qe)
+            assert (ix.bitmap_state()[0], ix.slice_state()[0]) == (0, 1)
+            assert total == pt["total"] and hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], ("slice stage", variant)
+        set_opt("ivl.slice", 0)
         for variant in (0, 1, 2, 3):  # the bitmap-cell pass: all three tile shapes, then bucket pairs
             set_opt("ivl.bm_variant", variant % 3)
             set_opt("ivl.bm_pair", variant == 3)
@@ -560,9 +670,13 @@ def test_count_multi_equals_one_index_at_a_time(O, IntervalIndex):
     totals = _ffi.DeviceArray(8 * len(specs))
     set_opt("ivl.partition", 1)
     try:
-        for pair, variant in ((1, -1), (0, 0), (1, 2)):
+        for pair, variant, slices in ((1, -1, 0), (0, 0, 0), (1, 2, 0), (1, -1, -1), (0, 1, 1)):
             set_opt("ivl.bm_pair", pair)
             set_opt("ivl.bm_variant", variant)
+            set_opt("ivl.slice", slices)  # -1: the dense index on images, the sparse and the wide ones on slices, in the same call
+            if slices == -1:
+                assert [ix.bitmap_state()[0] for ix in ixs] == [1, 1, 1, 0, -1, 0]  # empty batch: never looked at; too wide; reversed targets
+                assert [ix.slice_state()[0] for ix in ixs] == [0] * 6
             totals.zero()
             IntervalIndex.count_multi_dev(ixs, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [d[3] for d in dev], [d[2].ptr for d in dev],
                                           [totals.ptr + 8 * i for i in range(len(specs))], None)
@@ -572,7 +686,7 @@ def test_count_multi_equals_one_index_at_a_time(O, IntervalIndex):
                 got = dev[k][2].to_numpy(np.int32, dev[k][3])
                 bad = np.nonzero(got != wc)[0]
                 assert len(bad) == 0 and int(tot[k]) == wt, (pair, variant, k, ixs[k].bitmap_state(), bad[:5], got[bad[:5]], wc[bad[:5]], int(tot[k]), wt)
-        assert [ix.bitmap_state()[0] for ix in ixs] == [1, 1, 1, 0, -1, 0]  # empty batch: never looked at; too wide; reversed targets
+        assert [ix.slice_state()[0] for ix in ixs] == [1, 1, 1, 0, 1, 0]
     finally:
         reset_opts()
 
@@ -594,10 +708,12 @@ def test_genome_cfg4_full_size_golden(golden_scale_doc, IntervalIndex):
         sub = np.ascontiguousarray(counts[:: g["stride"]])
         assert int(sub.sum(dtype=np.int64)) == pt["total"], chrom
         assert hashlib.sha256(sub.tobytes()).hexdigest() == pt["counts_sha256"], chrom
-        paths.add(ix.bitmap_state()[0])
+        paths.add((ix.bitmap_state()[0], ix.slice_state()[0]))
         grand += total
         ix.close()
-    assert paths == {0, 1}  # big chromosomes through the bitmap-cell pass, small ones (< 2 Mi queries) through the direct kernel
+    # big chromosomes through the large-batch pass -- on key slices, a chromosome has one target per ~300 coordinates --
+    # small ones (< 2 Mi queries) through the direct kernel
+    assert paths == {(0, 1), (0, 0)}, paths
     assert grand > 0
 
 
