@@ -2,7 +2,11 @@
 bx.intervals.operations -- same names as lib/bx/intervals/operations/__init__.py:6-33;
 the operations themselves live in bxmi.operations (one batched engine call per chromosome).
 """
-from bxmi.operations import (  # noqa: F401
+from pkgutil import extend_path
+
+__path__ = extend_path(__path__, __name__)  # operations this package does not carry (concat) come from an installed bx-python
+
+from bxmi.operations import (  # noqa: E402,F401
     BED_DEFAULT_COLS,
     MAX_END,
     bits_clear_in_range,

@@ -159,18 +159,26 @@ def test_sharded_count_world_size_2_gloo(tmp_path):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/lib/bx"), reason="reference tree not mounted (build container only)")
 def test_overlay_resolves_next_to_an_installed_bx_python():
-    """PYTHONPATH=bx-python_amd:<bx-python>/lib: our two modules win, everything else comes from bx-python."""
+    """PYTHONPATH=bx-python_amd:<bx-python>/lib: the hot-path modules and their batch-aware callers are ours, everything
+    else (cookbook, the concat operation, sequence modules, ...) comes from bx-python."""
     code = (
         "import bx, bx.bitset, bx.intervals, bx.intervals.intersection, bx.bitset_builders, bx.intervals.io, bx.cookbook.doc_optparse\n"
+        "import bx.intervals.operations.concat, bx.intervals.operations.intersect, bx.tabular.io, bx.cookbook.attribute\n"
         "print(bx.bitset.__file__); print(bx.intervals.intersection.__file__)\n"
         "print(bx.bitset_builders.__file__); print(bx.intervals.io.__file__)\n"
         "print(bx.bitset_builders.BinnedBitSet is bx.bitset.BinnedBitSet, bx.intervals.Intersecter is bx.intervals.intersection.IntervalTree)\n"
+        "print(bx.cookbook.doc_optparse.__file__); print(bx.intervals.operations.concat.__file__); print(bx.cookbook.attribute.__file__)\n"
+        "print(bx.intervals.operations.intersect.__file__); print(bx.tabular.io.__file__)\n"
+        "print(bx.intervals.io.GenomicInterval.__mro__[1] is bx.tabular.io.TableRow)\n"
     )
     env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "bx-python_amd") + os.pathsep + "/root/reference/lib")
     out = subprocess.check_output([sys.executable, "-c", code], text=True, env=env).splitlines()
     assert out[0].endswith("bx-python_amd/bx/bitset.py") and out[1].endswith("bx-python_amd/bx/intervals/intersection.py")
-    assert out[2].startswith("/root/reference/lib/bx/") and out[3].startswith("/root/reference/lib/bx/")
+    assert out[2].endswith("bx-python_amd/bx/bitset_builders.py") and out[3].endswith("bx-python_amd/bx/intervals/io.py")
     assert out[4] == "True True"
+    assert all(o.startswith("/root/reference/lib/bx/") for o in out[5:8]), out[5:8]
+    assert out[8].endswith("bx-python_amd/bx/intervals/operations/intersect.py") and out[9].endswith("bx-python_amd/bx/tabular/io.py")
+    assert out[10] == "True"
 
 
 def _python_parse(text, chrom_col=0, start_col=1, end_col=2):
