@@ -76,6 +76,7 @@ __global__ __launch_bounds__(1024) void sl_unit_sums_kernel(const unsigned *__re
 }
 
 typedef __attribute__((address_space(3))) const unsigned short *lds_u16_p;
+typedef int sl_v4a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // #{keys of the slice below x}: the directory narrows to one cell, `steps` halvings finish (steps covers the fullest
 // cell of the unit, so every lane runs the same straight-line code).
@@ -120,15 +121,43 @@ __device__ __forceinline__ SlUnit sl_stage_unit(const BmSeg &sg, int unit, int32
     for (int c = threadIdx.x; c <= g.nce; c += SL_THREADS) dirE[c] = 0xFFFFu;
     if (threadIdx.x == 0) s_tmp[16] = 0;
     __syncthreads();
-    for (int arr = 0; arr < 2; arr++) {
-        const int32_t *__restrict__ A = arr == 0 ? sg.ix.s_ord + U.sLo : sg.e_sorted + U.eLo;
-        const int n = arr == 0 ? U.nS : U.nE;
-        unsigned short *low = arr == 0 ? lowS : lowE, *dir = arr == 0 ? dirS : dirE;
-        for (int i = threadIdx.x; i < n; i += SL_THREADS) {
-            const unsigned rel = (unsigned)((long long)A[i] - lo_u);
-            const unsigned prev = i > 0 ? (unsigned)((long long)A[i - 1] - lo_u) >> dshift : 0xFFFFFFFFu;
-            low[i] = (unsigned short)(rel & dmask);
-            if ((rel >> dshift) != prev) dir[rel >> dshift] = (unsigned short)i;  // first key of its cell
+    // four keys per 16-byte load (the slices start at arbitrary ranks: dword-aligned vector loads), every thread's loads
+    // of both slices issued before the first is used -- staging is the fixed cost of a work item
+    constexpr int SL_STAGE_V = 4;  // vector loads in flight per thread and slice
+    for (int base = 0; base < (U.nS > U.nE ? U.nS : U.nE); base += SL_STAGE_V * 4 * SL_THREADS) {
+        sl_v4a4 v[2][SL_STAGE_V];
+        int pv[2][SL_STAGE_V];
+#pragma unroll
+        for (int arr = 0; arr < 2; arr++) {
+            const int32_t *__restrict__ A = arr == 0 ? sg.ix.s_ord + U.sLo : sg.e_sorted + U.eLo;
+            const int n = arr == 0 ? U.nS : U.nE;
+#pragma unroll
+            for (int k = 0; k < SL_STAGE_V; k++) {
+                const int i = base + (k * SL_THREADS + (int)threadIdx.x) * 4;
+                // (the index arrays are padded past n: a vector that starts below n may read up to 3 keys beyond it)
+                v[arr][k] = *reinterpret_cast<const sl_v4a4 *>(A + (i < n ? i : 0));
+                pv[arr][k] = A[i > 0 && i < n ? i - 1 : 0];
+            }
+        }
+#pragma unroll
+        for (int arr = 0; arr < 2; arr++) {
+            const int n = arr == 0 ? U.nS : U.nE;
+            unsigned short *low = arr == 0 ? lowS : lowE, *dir = arr == 0 ? dirS : dirE;
+#pragma unroll
+            for (int k = 0; k < SL_STAGE_V; k++) {
+                const int i = base + (k * SL_THREADS + (int)threadIdx.x) * 4;
+                if (i >= n) continue;
+                const int key[4] = {v[arr][k].x, v[arr][k].y, v[arr][k].z, v[arr][k].w};
+                unsigned prev = i > 0 ? (unsigned)((long long)pv[arr][k] - lo_u) >> dshift : 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (i + j >= n) break;
+                    const unsigned rel = (unsigned)((long long)key[j] - lo_u);
+                    low[i + j] = (unsigned short)(rel & dmask);
+                    if ((rel >> dshift) != prev) dir[rel >> dshift] = (unsigned short)(i + j);  // first key of its cell
+                    prev = rel >> dshift;
+                }
+            }
         }
     }
     __syncthreads();
@@ -583,7 +612,8 @@ __global__ __launch_bounds__(SL_THREADS) void sl_fill_pipe_kernel(const BmSeg *_
 // their CSR offsets and scratch offsets go to LDS with coalesced reads, and 8 lanes copy each query's run, SL_HU_Q
 // queries per group in flight (with one workgroup per CU -- the LDS is full -- a single load in flight per thread
 // leaves the copy waiting on latency).  The reads are 20-byte runs at random places of the tile's region: that, not
-// occupancy, bounds the kernel (an LDS-free variant with full CUs and random reads of the offsets was slower).
+// occupancy, bounds the kernel: LDS-free variants with full CUs were slower (1.96 ms against 1.56 ms on configs[4];
+// 1.63 ms when the workgroups of one tile were kept on one XCD so that its region stays in that L2).
 constexpr int SL_HU_CHUNK = 2048;
 constexpr int SL_HU_Q = 8;
 

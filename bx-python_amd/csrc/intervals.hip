@@ -2055,6 +2055,7 @@ static int64_t g_opt_bm_exp = 0;       // diagnostics only (wrong results): pric
 static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
 static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by run length and LDS, else forced (tests)
+static int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_CHUNK, twice that for bucket pairs)
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
@@ -2135,6 +2136,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.sl_f")) {
         g_opt_sl_f = value > SL_MAX_F ? SL_MAX_F : value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bm_chunk")) {
+        g_opt_bm_chunk = value < 0 ? 0 : value;
         return 1;
     }
     if (!strcmp(key, "ivl.sl_rbits")) {
@@ -2693,7 +2698,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     const int ngroups = (int)(ntp / BM_GROUP_TILES);
     // PAIR: a search workgroup holds the images of two neighbouring buckets (needs both in one CU's LDS)
     const bool pair = !slices && g_opt_bm_pair != 0 && 2 * max_stride * sizeof(uint2) + 8192 <= 160 * 1024;
-    const int chunk = pair ? 2 * BM_CHUNK : BM_CHUNK;
+    const int chunk = g_opt_bm_chunk ? (int)g_opt_bm_chunk : (pair ? 2 * BM_CHUNK : BM_CHUNK);
     const int64_t max_items = (int64_t)n * ((pair ? BM_NB / 2 : BM_NB) + 2) + 2 * (nq_all / chunk) + 2;
     BXMI_TRY(h->bm_recs.reserve((size_t)ntp * tile * 4));
     BXMI_TRY(h->bm_slots.reserve((size_t)ntp * tile * 2));
