@@ -112,18 +112,49 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_kernel(const In *in, 
     int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     Acc v[SCAN_ITEMS];
     Acc run = identity;
+    // a thread's SCAN_ITEMS consecutive inputs as 16-byte loads, its outputs as 16-byte stores, when the types and the
+    // alignment allow (the CSR offsets of find(): int32 counts in, int64 offsets out)
+    const bool wide = sizeof(In) == 4 && (sizeof(Acc) == 8 || sizeof(Acc) == 4) && SCAN_ITEMS % 4 == 0 && base + SCAN_ITEMS <= n &&
+                      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (wide) {
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-        v[j] = (base + j < n) ? (Acc)in[base + j] : identity;
-        run = op(run, v[j]);
+        for (int j = 0; j < SCAN_ITEMS; j += 4) {
+            const int4 w = *reinterpret_cast<const int4 *>(reinterpret_cast<const int32_t *>(in) + base + j);
+            const int32_t q[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                In x;
+                __builtin_memcpy(&x, &q[u], sizeof(In) == 4 ? 4 : 0);
+                v[j + u] = (Acc)x;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) v[j] = (base + j < n) ? (Acc)in[base + j] : identity;
     }
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) run = op(run, v[j]);
     Acc total;
     Acc off = op(block_sums[blockIdx.x], block_exclusive_scan(run, op, identity, lds, &total));
+    Acc r[SCAN_ITEMS];
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
         Acc inc = op(off, v[j]);
-        if (base + j < n) out[base + j] = INCLUSIVE ? inc : off;
+        r[j] = INCLUSIVE ? inc : off;
         off = inc;
+    }
+    if (wide) {
+        constexpr int PER = 16 / (int)sizeof(Acc);  // outputs per 16-byte store
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j += PER) {
+            int4 w;
+            __builtin_memcpy(&w, &r[j], 16);
+            *reinterpret_cast<int4 *>(out + base + j) = w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++)
+            if (base + j < n) out[base + j] = r[j];
     }
 }
 

@@ -242,7 +242,10 @@ def test_thousands_of_default_sized_sets_stay_small(O, B):
         assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
         return free.value
 
+    import gc
+
     rng = np.random.default_rng(12)
+    gc.collect()  # handles of earlier tests release their device memory now, not in the middle of the measurement
     B.BinnedBitSet(100).count_range(0, 10)  # the runtime's own start-up allocations happen before the first reading
     free0 = free_bytes()
     n_sets = 4000
