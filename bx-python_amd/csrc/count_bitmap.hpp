@@ -453,10 +453,11 @@ __device__ __forceinline__ void bm_plan_walk(const unsigned *__restrict__ grpcnt
     int g_first[2] = {0, 0};
     int out[2] = {out0, out1};
     int seg = tile_seg[0];
+    int64_t t_last = EMIT ? segs[seg].tile0 + segs[seg].ntiles : 0;  // of the current segment (kept in registers: a load per item otherwise)
     cnt[0] = cnt[1] = 0;
     auto close = [&](int u, int g_end) {  // the item of unit u that ends before group g_end (same segment as `seg`)
         if (EMIT) {
-            const int64_t t_last = segs[seg].tile0 + segs[seg].ntiles, t_end = (int64_t)g_end * BM_GROUP_TILES;
+            const int64_t t_end = (int64_t)g_end * BM_GROUP_TILES;
             items[out[u]++] = make_int4((b0 + u) | (seg << 16), g_first[u] * BM_GROUP_TILES, (int)(t_end < t_last ? t_end : t_last), (int)acc[u]);
         }
         cnt[u]++;
@@ -481,6 +482,7 @@ __device__ __forceinline__ void bm_plan_walk(const unsigned *__restrict__ grpcnt
                 for (int u = 0; u < UNITS; u++)
                     if (acc[u] > 0) close(u, gi);
                 seg = sg[i];
+                if (EMIT) t_last = segs[seg].tile0 + segs[seg].ntiles;
             }
 #pragma unroll
             for (int u = 0; u < UNITS; u++) {

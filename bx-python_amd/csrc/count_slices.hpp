@@ -124,7 +124,21 @@ __device__ __forceinline__ SlUnit sl_stage_unit(const BmSeg &sg, int unit, int32
     // four keys per 16-byte load (the slices start at arbitrary ranks: dword-aligned vector loads), every thread's loads
     // of both slices issued before the first is used -- staging is the fixed cost of a work item
     constexpr int SL_STAGE_V = 4;  // vector loads in flight per thread and slice
-    for (int base = 0; base < (U.nS > U.nE ? U.nS : U.nE); base += SL_STAGE_V * 4 * SL_THREADS) {
+    const int n_max = U.nS > U.nE ? U.nS : U.nE;
+    if (n_max <= 2 * 4 * SL_THREADS) {  // small slices (sparse index): a key per thread and step, nothing issued in vain
+        for (int arr = 0; arr < 2; arr++) {
+            const int32_t *__restrict__ A = arr == 0 ? sg.ix.s_ord + U.sLo : sg.e_sorted + U.eLo;
+            const int n = arr == 0 ? U.nS : U.nE;
+            unsigned short *low = arr == 0 ? lowS : lowE, *dir = arr == 0 ? dirS : dirE;
+            for (int i = threadIdx.x; i < n; i += SL_THREADS) {
+                const unsigned rel = (unsigned)((long long)A[i] - lo_u);
+                const unsigned prev = i > 0 ? (unsigned)((long long)A[i - 1] - lo_u) >> dshift : 0xFFFFFFFFu;
+                low[i] = (unsigned short)(rel & dmask);
+                if ((rel >> dshift) != prev) dir[rel >> dshift] = (unsigned short)i;
+            }
+        }
+    } else
+    for (int base = 0; base < n_max; base += SL_STAGE_V * 4 * SL_THREADS) {
         sl_v4a4 v[2][SL_STAGE_V];
         int pv[2][SL_STAGE_V];
 #pragma unroll
