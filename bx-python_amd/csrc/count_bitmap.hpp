@@ -8,7 +8,7 @@
 //
 // Why a second path: the first one (part_* kernels) moves every query into GLOBAL bucket order and its count back,
 // 47 B of HBM traffic per query against 12 algorithmic.  Here
-//   1. bm_tile_sort_kernel   one workgroup orders a tile of 16384 queries by coordinate bucket INSIDE LDS and writes it
+//   1. bm_tile_sort_kernel   one workgroup orders a tile of 16384 / 32768 queries by coordinate bucket INSIDE LDS and writes it
 //                            back in place of the tile: a 4-byte record per query (17-bit offset in the bucket, 15-bit
 //                            length), the 16-bit slot of every query in the tile's sorted order, and the tile's 2048
 //                            bucket offsets.  No global histogram, no prefix over tiles, every byte coalesced;
@@ -18,10 +18,13 @@
 //                            8-byte cell per 32 coordinates = {bitmap of occupied coordinates, rank of the cell's first
 //                            key : 20, one duplicate descriptor : 12}.  A rank is ONE ds_read_b64, a mask, a popcount
 //                            and an add -- no search at all.  The workgroup walks the tiles, 8 lanes per (tile, bucket)
-//                            run, and leaves 16-bit counts where it found the records;
+//                            run (16 per run of a bucket PAIR: bm_search_pipe_kernel, the default), and leaves the
+//                            32-bit counts where it found the records;
 //   4. bm_unpermute_kernel   per tile: counts pulled through the 16-bit slots back into query order, escapes recomputed.
 // HBM bytes per query: 8 (queries) + 4 + 4 (records out and in) + 2 + 2 (slots) + 4 + 4 (counts, in place) + 4 (result) = 32, plus
 // the images (151 MB per pass) and the tables (75 MB).
+// count_slices.hpp holds a second search stage on the same exchange (sorted key slices instead of images: sparse
+// indexes, wide spans) and the two kernels that turn the pass into find().
 //
 // A cell holds exact multiplicities only when at most one of its 32 coordinates carries duplicates (<= 126 extra copies);
 // other cells are "hard": their rank is finished by a short binary search in the sorted array between the cell's and the
