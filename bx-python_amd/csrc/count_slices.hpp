@@ -622,79 +622,79 @@ __global__ __launch_bounds__(SL_THREADS) void sl_fill_pipe_kernel(const BmSeg *_
 }
 
 // Per tile: hits from the tile's scratch region (tile-sorted order) to CSR order; escapes answered from the index.
-// The tile's scratch offsets (by tile-sorted slot) sit in LDS; the tile is then taken SL_HU_CHUNK queries at a time:
-// their CSR offsets and scratch offsets go to LDS with coalesced reads, and 8 lanes copy each query's run, SL_HU_Q
-// queries per group in flight (with one workgroup per CU -- the LDS is full -- a single load in flight per thread
-// leaves the copy waiting on latency).  The reads are 20-byte runs at random places of the tile's region: that, not
-// occupancy, bounds the kernel: LDS-free variants with full CUs were slower (1.96 ms against 1.56 ms on configs[4];
-// 1.63 ms when the workgroups of one tile were kept on one XCD so that its region stays in that L2).
-constexpr int SL_HU_CHUNK = 2048;
-constexpr int SL_HU_Q = 8;
-
+// The tile's scratch offsets (by tile-sorted slot) sit in LDS.  An 8-lane group takes 8 CONSECUTIVE queries: lane u
+// fetches query u's CSR range and scratch offset (coalesced reads of `offsets` and `slots`), the group shares them by
+// shuffles, then copies the eight runs, lane j the j-th hit of each -- eight loads in flight per thread, and the
+// group's stores cover one contiguous stretch of the CSR list.  No staging through LDS and no barrier inside the
+// tile: a version that staged 2048 queries' offsets per barrier interval spent its time waiting at the barriers
+// (1.55 ms on configs[4]; proportional to 1 / workgroups when the grid was cut, i.e. not bound by memory).
 template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void sl_hits_unpermute_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
                                                                     const unsigned *__restrict__ loff, const unsigned short *__restrict__ slots,
                                                                     const long long *__restrict__ offsets, const int32_t *__restrict__ tmp_hits,
-                                                                    int32_t *__restrict__ hits)
+                                                                    int32_t *__restrict__ hits, int64_t ntp, int parts)
 {
     constexpr int TILE = THREADS * ITEMS;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     unsigned *lo_s = reinterpret_cast<unsigned *>(dyn);  // [TILE] scratch offsets by tile-sorted slot
-    __shared__ unsigned c_off[SL_HU_CHUNK + 1];          // CSR offsets of the chunk's queries, relative to the chunk's first
-    __shared__ unsigned c_src[SL_HU_CHUNK];              // where each query's hits lie in the tile's scratch region (bit 31: escape)
-    const int64_t tile = blockIdx.x;
-    const BmSeg &sg = segs[tile_seg[tile]];
-    const int64_t ltile = tile - sg.tile0;
-    if (ltile >= sg.ntiles) return;
-    const IndexDev ix = sg.ix;
-    const int64_t q0 = ltile * TILE;
-    const int64_t left = sg.nq - q0;
-    const int n = (int)(left < TILE ? left : TILE);
+    // `parts` workgroups share a tile, one after the other on the SAME XCD (blockIdx -> XCD is round robin): only a few
+    // tiles' regions are live in an XCD's 4 MB of L2 at a time, so a line of a region is fetched from HBM once, not
+    // once per run that lies in it.  Each of them stages the whole tile's offsets (L2 hits after the first).
+    const int xcd = (int)(blockIdx.x & 7u), seq = (int)(blockIdx.x >> 3);
+    const int part = seq % parts;
     {
-        const int4 *src = reinterpret_cast<const int4 *>(loff + tile * TILE);
-        const int n4 = (n + 3) >> 2;
-        for (int i = threadIdx.x; i < n4; i += THREADS) reinterpret_cast<int4 *>(lo_s)[i] = src[i];
-    }
-    const int32_t *__restrict__ region = tmp_hits + offsets[q0];
-    for (int k0 = 0; k0 < n; k0 += SL_HU_CHUNK) {
-        const int m = n - k0 < SL_HU_CHUNK ? n - k0 : SL_HU_CHUNK;
-        const long long obase = offsets[q0 + k0];
-        __syncthreads();  // (first pass: lo_s complete; later passes: the previous chunk is done with c_off / c_src)
-        for (int k = threadIdx.x; k <= m; k += THREADS) {
-            c_off[k] = (unsigned)(offsets[q0 + k0 + k] - obase);
-            if (k < m) c_src[k] = lo_s[slots[tile * TILE + k0 + k]];
+        const int64_t tile = (int64_t)(seq / parts) * 8 + xcd;
+        if (tile >= ntp) return;
+        const BmSeg &sg = segs[tile_seg[tile]];
+        const int64_t ltile = tile - sg.tile0;
+        if (ltile >= sg.ntiles) return;
+        const IndexDev ix = sg.ix;
+        const int64_t q0 = ltile * TILE;
+        const int64_t left = sg.nq - q0;
+        const int n = (int)(left < TILE ? left : TILE);
+        const int k_lo = part * (TILE / parts), k_hi = k_lo + TILE / parts < n ? k_lo + TILE / parts : n;
+        if (k_lo >= n) return;
+        {
+            const int4 *src = reinterpret_cast<const int4 *>(loff + tile * TILE);
+            const int n4 = (n + 3) >> 2;
+            for (int i = threadIdx.x; i < n4; i += THREADS) reinterpret_cast<int4 *>(lo_s)[i] = src[i];
         }
         __syncthreads();
-        int32_t *__restrict__ out = hits + obase;
-        constexpr int G = THREADS / 8;
-        const unsigned sub = threadIdx.x & 7u;
-        for (int kb = threadIdx.x >> 3; kb < m; kb += SL_HU_Q * G) {
-            unsigned o[SL_HU_Q], c[SL_HU_Q], sv[SL_HU_Q];
-            int v[SL_HU_Q];
+        const long long *__restrict__ off_t = offsets + q0;
+        const unsigned short *__restrict__ sl_t = slots + tile * TILE;
+        const int32_t *__restrict__ region = tmp_hits + off_t[0];
+        const int sub = (int)(threadIdx.x & 7u), lane0 = (int)(threadIdx.x & 63u) - sub;
+        for (int kb = k_lo + (int)(threadIdx.x >> 3) * 8; kb < k_hi; kb += THREADS) {
+            const int k = kb + sub;
+            const bool live = k < k_hi;
+            const long long my_o = off_t[live ? k : 0];
+            const unsigned my_c = live ? (unsigned)(off_t[k + 1] - my_o) : 0u;
+            const unsigned my_sv = lo_s[sl_t[live ? k : 0]];
+            long long o[8];
+            unsigned c[8], sv[8];
+            int v[8];
 #pragma unroll
-            for (int u = 0; u < SL_HU_Q; u++) {
-                const int k = kb + u * G;
-                const bool live = k < m;
-                o[u] = c_off[live ? k : 0];
-                sv[u] = live ? c_src[k] : 0x80000000u;
-                c[u] = (sv[u] >> 31) ? 0u : c_off[live ? k + 1 : 0] - o[u];
+            for (int u = 0; u < 8; u++) {
+                o[u] = __shfl(my_o, lane0 + u, 64);
+                c[u] = (unsigned)__shfl((int)my_c, lane0 + u, 64);
+                sv[u] = (unsigned)__shfl((int)my_sv, lane0 + u, 64);
             }
 #pragma unroll
-            for (int u = 0; u < SL_HU_Q; u++) v[u] = region[sub < c[u] ? sv[u] + sub : 0u];
+            for (int u = 0; u < 8; u++) v[u] = region[(unsigned)sub < c[u] && !(sv[u] >> 31) ? sv[u] + (unsigned)sub : 0u];
 #pragma unroll
-            for (int u = 0; u < SL_HU_Q; u++)
-                if (sub < c[u]) out[o[u] + sub] = v[u];
+            for (int u = 0; u < 8; u++)
+                if ((unsigned)sub < c[u] && !(sv[u] >> 31)) hits[o[u] + sub] = v[u];
 #pragma unroll
-            for (int u = 0; u < SL_HU_Q; u++)
-                for (unsigned j = 8 + sub; j < c[u]; j += 8) out[o[u] + j] = region[sv[u] + j];
-        }
-        for (int k = threadIdx.x; k < m; k += THREADS) {  // escapes: rare
-            if (!(c_src[k] >> 31)) continue;
-            int c = (int)(c_off[k + 1] - c_off[k]);
-            const int qs = sg.qs[q0 + k0 + k], qe = sg.qe[q0 + k0 + k];
-            int32_t *__restrict__ dst = out + c_off[k];
-            for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; c > 0; j--)
-                if (ix.e_ord[j] > qs) dst[--c] = ix.idx[j];
+            for (int u = 0; u < 8; u++)
+                if (!(sv[u] >> 31))
+                    for (unsigned j = 8 + (unsigned)sub; j < c[u]; j += 8) hits[o[u] + j] = region[sv[u] + j];
+            if ((my_sv >> 31) && my_c) {  // escape record: rare, answered from the sealed index by its own lane
+                const int qs = sg.qs[q0 + k], qe = sg.qe[q0 + k];
+                int cc = (int)my_c;
+                int32_t *__restrict__ dst = hits + my_o;
+                for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; cc > 0; j--)
+                    if (ix.e_ord[j] > qs) dst[--cc] = ix.idx[j];
+            }
         }
     }
 }

@@ -2056,6 +2056,7 @@ static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through 
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
 static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by run length and LDS, else forced (tests)
 static int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_CHUNK, twice that for bucket pairs)
+static int64_t g_opt_sl_hu_parts = 1;  // hit un-permute: workgroups per tile (1, 2, 4, 8, 16), run back to back on one XCD
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
@@ -2140,6 +2141,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.bm_chunk")) {
         g_opt_bm_chunk = value < 0 ? 0 : value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.sl_hu_parts")) {
+        g_opt_sl_hu_parts = value == 2 || value == 4 || value == 8 || value == 16 ? value : 1;
         return 1;
     }
     if (!strcmp(key, "ivl.sl_rbits")) {
@@ -2622,10 +2627,12 @@ static int sl_launch_hits_unpermute(const BmLaunch &L, hipStream_t st, const uns
                                     int32_t *hits)
 {
     bxmi_ivl *h = L.owner;
-    const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);  // + 16 KB static
+    const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);
     BXMI_TRY(allow_big_lds((sl_hits_unpermute_kernel<THREADS, ITEMS>), lds));
-    hipLaunchKernelGGL((sl_hits_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg, loff,
-                       h->bm_slots.as<unsigned short>(), offsets, tmp_hits, hits);
+    const int parts = g_opt_sl_hu_parts > 0 ? (int)g_opt_sl_hu_parts : 1;
+    const unsigned grid = (unsigned)(div_up(L.ntp, 8) * 8 * parts);
+    hipLaunchKernelGGL((sl_hits_unpermute_kernel<THREADS, ITEMS>), dim3(grid), dim3(THREADS), lds, st, L.segs, L.tile_seg, loff,
+                       h->bm_slots.as<unsigned short>(), offsets, tmp_hits, hits, L.ntp, parts);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }

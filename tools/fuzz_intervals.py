@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One-off randomized differential run of the interval engine against the CPU oracle (not part of the test suite):
-many target / query distributions, both large-batch variants forced on, sorted and unsorted batches, count and find.
+many target / query distributions, every count and find path forced on in turn (direct kernels, round 1's bucketed pass,
+the large-batch pass on bucket images and on key slices with random tile shapes / unit sizes / run widths, find through
+the exchange), sorted and unsorted batches.
 ROUNDS env (default 20).  Prints the first disagreement and exits 1, or a summary line.
 The CPU oracle dominates the run time and its cost grows with the number of HITS: every round is sized so that the
 expected overlaps stay below ~20 M (an unbounded version of this script once spent a whole GPU allowance waiting for
@@ -55,24 +57,47 @@ for r in range(rounds):
     want_c, want_t = t.count_batch(qs, qe)
     ix = IntervalIndex()
     ix.append(s, e)
-    for part, cells in ((0, 1), (1, 1), (1, 0)):
+    opt("ivl.bitmap_min", 1)
+    # (partition, count_cells, bitmap, slice): direct kernel, round 1's pass in both search variants, the large-batch pass
+    # on images first / slices first / slices only, each with random tile shapes, unit sizes and run widths
+    for part, cells, bitmap, slices in ((0, 1, 0, 0), (1, 1, 0, 0), (1, 0, 0, 0), (1, 1, -1, 0), (1, 1, -1, -1), (1, 1, -1, 1), (1, 1, -1, 1)):
+        knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64, 1])), pair=int(rng.integers(0, 2)),
+                     sorted_path=int(rng.integers(0, 2)))
         opt("ivl.partition", part)
         opt("ivl.count_cells", cells)
+        opt("ivl.bitmap", bitmap)
+        opt("ivl.slice", slices)
+        opt("ivl.bm_variant", knobs["variant"])
+        opt("ivl.sl_f", knobs["f"])
+        opt("ivl.sl_lanes", knobs["lanes"])
+        opt("ivl.bm_pair", knobs["pair"])
+        opt("ivl.sorted_path", knobs["sorted_path"])
         got_c, got_t = ix.count(qs, qe)
         if not np.array_equal(got_c, want_c) or got_t != want_t:
             bad = np.nonzero(got_c != want_c)[0][:5]
-            print("MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells), bad, qs[bad], qe[bad], got_c[bad], want_c[bad])
+            print("MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells, bitmap=bitmap, slices=slices, **knobs),
+                  ix.bitmap_state(), ix.slice_state(), bad, qs[bad], qe[bad], got_c[bad], want_c[bad])
             sys.exit(1)
     opt("ivl.count_cells", 1)
+    opt("ivl.bitmap", -1)
     m = min(nq, 20000)
     w_off, w_hits = t.find_batch(qs[:m], qe[:m])
-    for part in (0, 1):
+    for part, sliced in ((0, 0), (1, 0), (1, 1), (1, 1)):  # direct kernels, the bucketed find, find through the exchange (twice, other knobs)
+        knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64])), sorted_path=int(rng.integers(0, 2)))
         opt("ivl.partition", part)
+        opt("ivl.find_sliced", sliced)
+        opt("ivl.slice", -1)
+        opt("ivl.bm_variant", knobs["variant"])
+        opt("ivl.sl_f", knobs["f"])
+        opt("ivl.sl_lanes", knobs["lanes"])
+        opt("ivl.sorted_path", knobs["sorted_path"])
         off, hits = ix.find(qs[:m], qe[:m])
         if not (np.array_equal(off, w_off) and np.array_equal(hits, w_hits)):
-            print("FIND MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part))
+            print("FIND MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, sliced=sliced, **knobs), ix.slice_state())
             sys.exit(1)
-    opt("ivl.partition", -1)
+    for k, v in (("ivl.partition", -1), ("ivl.find_sliced", 1), ("ivl.bm_variant", -1), ("ivl.sl_f", -1), ("ivl.sl_lanes", 0), ("ivl.bm_pair", 1),
+                 ("ivl.sorted_path", 1)):
+        opt(k, v)
     checked += 1
     ix.close()
 print("fuzz: %d rounds, all counts and hit lists equal the oracle" % checked)
