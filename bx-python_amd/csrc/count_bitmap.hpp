@@ -500,20 +500,29 @@ __device__ __forceinline__ void bm_plan_walk(const unsigned *__restrict__ grpcnt
         if (acc[u] > 0) close(u, ngroups);
 }
 
+// BM_PLAN_BLOCKS workgroups of BM_PLAN_THREADS threads share the 1024 bucket pairs (one workgroup read the whole group
+// table through one CU: 45 us for 100 M queries); each reserves room for its items with one atomic on the item count,
+// which the host zeroes before the launch.  The order of the workgroups' ranges in the item list is not fixed; inside
+// a range neighbouring buckets stay neighbours, which is what the search's XCD-aware item mapping wants.
+constexpr int BM_PLAN_BLOCKS = 8, BM_PLAN_THREADS = BM_NB / 2 / BM_PLAN_BLOCKS;
+
 template <int UNITS>
-__global__ __launch_bounds__(1024) void bm_plan_kernel(const unsigned *__restrict__ grpcnt, int ngroups, const BmSeg *__restrict__ segs,
-                                                       const unsigned short *__restrict__ tile_seg, int chunk, int4 *__restrict__ items,
-                                                       int *__restrict__ n_items, const unsigned *__restrict__ gate)
+__global__ __launch_bounds__(BM_PLAN_THREADS) void bm_plan_kernel(const unsigned *__restrict__ grpcnt, int ngroups, const BmSeg *__restrict__ segs,
+                                                                  const unsigned short *__restrict__ tile_seg, int chunk, int4 *__restrict__ items,
+                                                                  int *__restrict__ n_items, const unsigned *__restrict__ gate)
 {
     __shared__ int scan_tmp[16];
+    __shared__ int s_base;
     if (gate && *gate == 0) return;
-    const int b0 = 2 * threadIdx.x;
+    const int b0 = 2 * (int)(blockIdx.x * BM_PLAN_THREADS + threadIdx.x);
     int cnt[2], again[2];
     bm_plan_walk<false, UNITS>(grpcnt, ngroups, segs, tile_seg, b0, chunk, cnt, nullptr, 0, 0);
     int tot;
     const int at = block_exclusive_scan(cnt[0] + cnt[1], OpSum(), 0, scan_tmp, &tot);
-    if (threadIdx.x == 0) n_items[0] = tot;
-    bm_plan_walk<true, UNITS>(grpcnt, ngroups, segs, tile_seg, b0, chunk, again, items, at, at + cnt[0]);  // bucket b0's items, then bucket b0 + 1's
+    if (threadIdx.x == 0) s_base = atomicAdd(n_items, tot);
+    __syncthreads();
+    const int base = s_base;
+    bm_plan_walk<true, UNITS>(grpcnt, ngroups, segs, tile_seg, b0, chunk, again, items, base + at, base + at + cnt[0]);  // bucket b0's items, then bucket b0 + 1's
 }
 
 // ---------------------------------------------------------------------------

@@ -123,7 +123,7 @@ __device__ __forceinline__ SlUnit sl_stage_unit(const BmSeg &sg, int unit, int32
     __syncthreads();
     // four keys per 16-byte load (the slices start at arbitrary ranks: dword-aligned vector loads), every thread's loads
     // of both slices issued before the first is used -- staging is the fixed cost of a work item
-    constexpr int SL_STAGE_V = 4;  // vector loads in flight per thread and slice
+    constexpr int SL_STAGE_V = 2;  // vector loads in flight per thread and slice (4 cost the search kernel its 64-register budget)
     const int n_max = U.nS > U.nE ? U.nS : U.nE;
     if (n_max <= 2 * 4 * SL_THREADS) {  // small slices (sparse index): a key per thread and step, nothing issued in vain
         for (int arr = 0; arr < 2; arr++) {
@@ -221,12 +221,18 @@ __device__ __forceinline__ unsigned sl_count_record(const SlUnit &U, const BmGeo
 // The walk of bm_search_pipe_kernel (rounds of U runs per L-lane group, the next round's records requested before
 // this round is computed, long runs finished by the whole workgroup) over the runs of one UNIT: the run of unit u in
 // tile t is what lies between the first slots of buckets u << f and (u + 1) << f in the tile-sorted order.
-template <int L, int U>
-__global__ __launch_bounds__(SL_THREADS) void sl_search_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
+// APART: the counts go to `out_apart` and the records stay (find() needs them again); otherwise every count is written
+// over its record.  Two instantiations rather than two possibly-equal pointers: with may-alias loads and stores the
+// compiler drains the memory pipe between a round's stores and the next round's loads (genome search 0.68 -> 0.80 ms).
+// (8 waves per SIMD = at most 64 VGPRs: two workgroups per CU when the unit's keys leave room, so that one stages its
+// unit while the other searches -- sparse indexes have small units and many work items)
+template <int L, int U, bool APART>
+__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void sl_search_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                     const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
-                                                                    const unsigned *recs, unsigned *out /* counts: == recs (in place) or apart */,
-                                                                    int tile_log2, const unsigned *__restrict__ gate)
+                                                                    unsigned *__restrict__ recs, unsigned *__restrict__ out_apart, int tile_log2,
+                                                                    const unsigned *__restrict__ gate)
 {
+    unsigned *const out = APART ? out_apart : recs;  // (based on one of the two restrict parameters)
     if (gate && *gate == 0) return;
     constexpr int NG = SL_THREADS / L;
     constexpr unsigned LONG_RUN = 4 * L;
@@ -354,9 +360,10 @@ constexpr int SL_FLAT_TILES = 2048;
 template <int DEPTH>
 __global__ __launch_bounds__(SL_THREADS) void sl_search_flat_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                     const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
-                                                                    const unsigned *recs, unsigned *out /* counts: == recs (in place) or apart */,
-                                                                    int tile_log2, const unsigned *__restrict__ gate)
+                                                                    unsigned *__restrict__ recs /* records in, counts out */, int tile_log2,
+                                                                    const unsigned *__restrict__ gate)
 {
+    unsigned *const out = recs;
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     __shared__ unsigned s_first[SL_FLAT_TILES], s_cum[SL_FLAT_TILES + 1];

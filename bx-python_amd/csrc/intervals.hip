@@ -2603,9 +2603,15 @@ template <int LANES>
 static int sl_launch_search(const BmLaunch &L, unsigned grid, hipStream_t st, unsigned *out)
 {
     bxmi_ivl *h = L.owner;
-    BXMI_TRY(allow_big_lds((sl_search_pipe_kernel<LANES, 2>), L.search_lds));
-    hipLaunchKernelGGL((sl_search_pipe_kernel<LANES, 2>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
-                       h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), out, L.tile_log2, L.gate);
+    if (out != h->bm_recs.as<unsigned>()) {
+        BXMI_TRY(allow_big_lds((sl_search_pipe_kernel<LANES, 2, true>), L.search_lds));
+        hipLaunchKernelGGL((sl_search_pipe_kernel<LANES, 2, true>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+                           h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), out, L.tile_log2, L.gate);
+    } else {
+        BXMI_TRY(allow_big_lds((sl_search_pipe_kernel<LANES, 2, false>), L.search_lds));
+        hipLaunchKernelGGL((sl_search_pipe_kernel<LANES, 2, false>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+                           h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), (unsigned *)nullptr, L.tile_log2, L.gate);
+    }
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -2645,12 +2651,12 @@ struct BmFindCtx {
     int variant;     // tile shape
 };
 
-static int sl_launch_search_flat(const BmLaunch &L, unsigned grid, hipStream_t st, unsigned *out)
+static int sl_launch_search_flat(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
     BXMI_TRY(allow_big_lds((sl_search_flat_kernel<4>), L.search_lds));
     hipLaunchKernelGGL((sl_search_flat_kernel<4>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
-                       h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), out, L.tile_log2, L.gate);
+                       h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), L.tile_log2, L.gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -2767,16 +2773,17 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY((bm_launch_tiles<512, 32>(L, st)));
     hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                        tile_log2, h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
+    BXMI_HIP(hipMemsetAsync(h->bm_items.p, 0, sizeof(int), st));  // the item count: the plan's workgroups add to it
     if (slices) {
         hipLaunchKernelGGL(sl_unit_sums_kernel, dim3((unsigned)ngroups), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), L.segs, L.tile_seg,
                            h->sl_unitcnt.as<unsigned>(), unsorted);
-        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(1), dim3(1024), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
+        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
                            h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     } else if (pair)
-        hipLaunchKernelGGL(bm_plan_kernel<1>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
+        hipLaunchKernelGGL(bm_plan_kernel<1>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
                            h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     else
-        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(1), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
+        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
                            h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     BXMI_LAUNCH_CHECK();
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
@@ -2785,7 +2792,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         int lanes = g_opt_sl_lanes < 0 ? 0 : (g_opt_sl_lanes ? (int)g_opt_sl_lanes : (sl_run >= 96 ? 0 : (sl_run >= 40 ? 64 : 16)));
         if (fx && lanes == 0) lanes = 64;  // (the fill half has no flat walk)
         if (lanes == 0)
-            BXMI_TRY(sl_launch_search_flat(L, sgrid, st, search_out));
+            BXMI_TRY(sl_launch_search_flat(L, sgrid, st));
         else if (lanes == 64)
             BXMI_TRY(sl_launch_search<64>(L, sgrid, st, search_out));
         else
