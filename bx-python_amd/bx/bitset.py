@@ -130,7 +130,7 @@ class BinnedBitSet(_Queued):
     def count_range(self, start, count):
         self._d.check_range_count(start, count)
         self._flush()
-        return self._d.count_range(_cint(start), _cint(count))
+        return self._d.count_range_checked(_cint(start), _cint(count))
 
     def next_set(self, start):
         self._d.check_index(start)

@@ -113,7 +113,7 @@ class _Core:
     def find(self, start, end):
         self._flush()
         vals = self.values
-        return [vals[i] for i in self.index.find_one(start, end).tolist()]
+        return [vals[i] for i in self.index.find_one_list(start, end)]
 
     def order(self):
         if self._order is None:

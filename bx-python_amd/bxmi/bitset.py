@@ -111,8 +111,19 @@ class DeviceBitSet:
 
     def count_range(self, start, count):
         self.check_range_count(start, count)
-        out = C.c_int32(0)
-        call("bxmi_bits_count_range", self._h, int(start), int(count), C.byref(out))
+        return self.count_range_checked(int(start), int(count))
+
+    def count_range_checked(self, start, count):
+        """count_range for arguments the caller has validated already (the drop-in class has): the per-call path an
+        unmodified script pays once per line, so nothing is looked up or allocated here that can be kept."""
+        fast = self.__dict__.get("_cr")
+        if fast is None:
+            out = C.c_int32(0)
+            fast = self._cr = (_ffi.load().bxmi_bits_count_range, out, C.byref(out))
+        fn, out, ref = fast
+        rc = fn(self._h, start, count, ref)
+        if rc:
+            _ffi.check(rc)
         return out.value
 
     def get(self, index):

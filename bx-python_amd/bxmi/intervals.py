@@ -139,6 +139,24 @@ class IntervalIndex:
             call("bxmi_ivl_find_one", self._h, int(qs), int(qe), ptr(buf), len(buf), C.byref(n))
         return buf[: n.value].copy()  # the buffer is reused by the next call
 
+    def find_one_list(self, qs, qe):
+        """find() for one query -> Python list of insertion indices: the per-call path of the drop-in tree (one launch,
+        the answer polled from host-visible memory); nothing is looked up or allocated that can be kept between calls."""
+        if not self._sealed:
+            self.seal()
+        fast = self.__dict__.get("_fo")
+        if fast is None or fast[1] is not self._one_buf:
+            n = C.c_int64(0)
+            fast = self._fo = (_ffi.load().bxmi_ivl_find_one, self._one_buf, self._one_buf.ctypes.data, n, C.byref(n))
+        fn, buf, addr, n, ref = fast
+        rc = fn(self._h, qs, qe, addr, len(buf), ref)
+        if rc:
+            if rc != _ffi.ERANGE:
+                _ffi.check(rc)
+            self._one_buf = np.empty(int(n.value) * 2, dtype=np.int32)
+            return self.find_one_list(qs, qe)
+        return buf[: n.value].tolist()
+
     def count_dev(self, qs_ptr, qe_ptr, nq, counts_ptr, total_ptr, stream=None):
         """Device-pointer form used by bench.py / the sharded driver (no host sync)."""
         self._ready()

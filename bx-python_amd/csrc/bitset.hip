@@ -140,7 +140,7 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_count_ranges_kernel(const u
 // Arguments travel as kernel arguments and the answer lands in host-visible memory: launch + one stream sync.
 __global__ __launch_bounds__(BITS_THREADS) void bits_count_one_kernel(const unsigned long long *__restrict__ words,
                                                                      const uint8_t *__restrict__ tags, int bin_size, int64_t s,
-                                                                     int64_t e, long long *__restrict__ out_host)
+                                                                     int64_t e, long long *__restrict__ out_host, unsigned long long seq)
 {
     __shared__ long long red[BITS_THREADS / 64];
     __shared__ unsigned long long total;
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_count_one_kernel(const unsi
         long long r = (long long)total;
         if (tags && tags[s / bin_size] == TAG_ONE) r -= s % bin_size;  // binBits.c:155,161
         *out_host = r;
+        publish_to_host(reinterpret_cast<unsigned long long *>(out_host) + 1, seq);
     }
 }
 
@@ -617,7 +618,8 @@ struct bxmi_bits {
     bool maybe_one = false;  // some bin may be ALL_ONE (only after invert / ior with such a set)
     bool flat = false;       // plain BitSet (bitset.pyx:107-173): no bins, no tri-state quirks
     DevBuf q_a, q_b, q_out, acc, tiles_s, tiles_l, run_s, run_e, scan_tmp;
-    long long *one_buf = nullptr;  // host-visible result of the one-range latency path
+    long long *one_buf = nullptr;  // host-visible result of the one-range latency path: [0] the count, [1] completion word
+    unsigned long long one_seq = 0;
     hipStream_t stream = nullptr;
 };
 
@@ -891,11 +893,15 @@ extern "C" int bxmi_bits_count_range(bxmi_bits_t *h, int32_t start, int32_t len,
     }
     if (len < (1 << 20)) {  // up to 16 Ki words: one workgroup, result straight into host-visible memory
         BXMI_TRY(bits_stream(h));
-        if (!h->one_buf) BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->one_buf), 64, hipHostMallocDefault));
+        if (!h->one_buf) {
+            BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->one_buf), 64, hipHostMallocDefault));
+            memset(h->one_buf, 0, 64);
+        }
+        const unsigned long long seq = ++h->one_seq;
         hipLaunchKernelGGL(bits_count_one_kernel, dim3(1), dim3(BITS_THREADS), 0, h->stream, h->words.as<unsigned long long>(),
-                           h->maybe_one ? h->tags.as<uint8_t>() : nullptr, h->bin_size, (int64_t)start, (int64_t)start + len, h->one_buf);
+                           h->maybe_one ? h->tags.as<uint8_t>() : nullptr, h->bin_size, (int64_t)start, (int64_t)start + len, h->one_buf, seq);
         BXMI_LAUNCH_CHECK();
-        BXMI_HIP(hipStreamSynchronize(h->stream));
+        BXMI_TRY(wait_for_host_flag(reinterpret_cast<const unsigned long long *>(h->one_buf) + 1, seq, h->stream));
         *out = (int32_t)*reinterpret_cast<volatile long long *>(h->one_buf);
         return BXMI_OK;
     }

@@ -155,4 +155,19 @@ __device__ __forceinline__ void block_accumulate_i64(long long v, long long *red
     }
 }
 
+// ---- completion through host memory (the per-call latency paths) ------------
+// A one-workgroup kernel that answers ONE call leaves its result in host-visible memory; its last act is to publish a
+// sequence number next to it (system-scope release after a workgroup barrier: everything the workgroup wrote before
+// is visible to whoever reads the number with acquire).  The host then polls that word instead of going through the
+// stream's completion signal -- and falls back to a stream synchronisation if the number does not show up soon
+// (queue busy with earlier work, `core.poll` = 0).
+extern int64_t g_opt_poll;
+
+__device__ __forceinline__ void publish_to_host(unsigned long long *flag, unsigned long long seq)
+{
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int wait_for_host_flag(const unsigned long long *flag, unsigned long long seq, hipStream_t st);
+
 }  // namespace bxmi

@@ -2,6 +2,8 @@
 // selection, raw HBM staging and the tuning knobs.
 #include <mutex>
 
+#include <chrono>
+#include <cstring>
 #include "common.hpp"
 
 namespace bxmi {
@@ -126,9 +128,31 @@ extern "C" int bxmi_memset(void *dst_dev, int value, size_t bytes)
     return BXMI_OK;
 }
 
+namespace bxmi {
+int64_t g_opt_poll = 1;
+
+int wait_for_host_flag(const unsigned long long *flag, unsigned long long seq, hipStream_t st)
+{
+    if (g_opt_poll) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spins = 0;; spins++) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return BXMI_OK;
+            if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200)) break;
+        }
+    }
+    BXMI_HIP(hipStreamSynchronize(st));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(BXMI_EHIP, "completion word of a one-call kernel never arrived");
+    return BXMI_OK;
+}
+}  // namespace bxmi
+
 extern "C" int bxmi_set_option(const char *key, int64_t value)
 {
     if (!key) return fail(BXMI_EINVAL, "bxmi_set_option: key is NULL");
+    if (!strcmp(key, "core.poll")) {
+        bxmi::g_opt_poll = value != 0;
+        return BXMI_OK;
+    }
     if (ivl_set_option(key, value) || bits_set_option(key, value)) return BXMI_OK;
     return fail(BXMI_EINVAL, "bxmi_set_option: unknown key '%s'", key);
 }

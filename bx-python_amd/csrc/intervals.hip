@@ -1859,7 +1859,7 @@ __global__ __launch_bounds__(FIND_THREADS) void ivl_find_fill_kernel(IndexDev ix
 constexpr int ONE_THREADS = 256;
 __global__ __launch_bounds__(ONE_THREADS) void ivl_find_one_kernel(TreeDev S, TreeDev P, IndexDev ix, int qs, int qe,
                                                                   int32_t *__restrict__ out /* [0] = n (64-bit), hits from [2] */,
-                                                                  int cap)
+                                                                  int cap, unsigned long long seq)
 {
     __shared__ int s_lo, s_hi;
     __shared__ int wave_tot[ONE_THREADS / 64];
@@ -1892,7 +1892,11 @@ __global__ __launch_bounds__(ONE_THREADS) void ivl_find_one_kernel(TreeDev S, Tr
         run += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *reinterpret_cast<long long *>(out) = run;
+    __syncthreads();  // every hit is written before the completion word goes out
+    if (threadIdx.x == 0) {
+        *reinterpret_cast<long long *>(out) = run;
+        publish_to_host(reinterpret_cast<unsigned long long *>(out + 2 + cap), seq);
+    }
 }
 
 // before()/after() candidate filter over a window of the in-order arrays
@@ -2198,7 +2202,8 @@ struct bxmi_ivl {
     unsigned sl_need[SL_MAX_F + 1] = {0, 0, 0, 0, 0, 0, 0};  // most keys a unit of 2^f buckets stages
     DevBuf sl_meta, sl_stats, sl_unitcnt, sl_cnt, sl_loff, sl_hits, sl_eid;
     bool sl_eid_ready = false;
-    int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][hits...]
+    int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][ONE_CAP hits][completion word:int64]
+    unsigned long long one_seq = 0;
     hipStream_t stream = nullptr;
     int device = 0;
 };
@@ -3337,13 +3342,17 @@ extern "C" int bxmi_ivl_find_one(bxmi_ivl_t *h, int32_t qs, int32_t qe, int32_t 
     *n_hits = 0;
     if (h->n == 0) return BXMI_OK;
     BXMI_TRY(ivl_stream(h));
-    if (!h->one_buf) BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->one_buf), 4096 * sizeof(int32_t), hipHostMallocDefault));
+    if (!h->one_buf) {
+        BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->one_buf), (4096 + 2) * sizeof(int32_t), hipHostMallocDefault));
+        memset(h->one_buf, 0, (4096 + 2) * sizeof(int32_t));
+    }
+    const unsigned long long seq = ++h->one_seq;
     Tree tS = Tree(), tP = Tree();
     tS.dev = h->treeS.dev, tP.dev = h->treeP.dev;
     tS.set_lds_budget(0), tP.set_lds_budget(0);  // every level from global memory (L2): nothing to stage for one query
-    hipLaunchKernelGGL(ivl_find_one_kernel, dim3(1), dim3(ONE_THREADS), 0, h->stream, tS.dev, tP.dev, index_dev(h), qs, qe, h->one_buf, ONE_CAP);
+    hipLaunchKernelGGL(ivl_find_one_kernel, dim3(1), dim3(ONE_THREADS), 0, h->stream, tS.dev, tP.dev, index_dev(h), qs, qe, h->one_buf, ONE_CAP, seq);
     BXMI_LAUNCH_CHECK();
-    BXMI_HIP(hipStreamSynchronize(h->stream));
+    BXMI_TRY(wait_for_host_flag(reinterpret_cast<const unsigned long long *>(h->one_buf + 2 + ONE_CAP), seq, h->stream));
     const int64_t n = *reinterpret_cast<volatile long long *>(h->one_buf);
     *n_hits = n;
     if (n > ONE_CAP) {  // a very popular region: take the batched path once

@@ -71,6 +71,8 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search
  *   ivl.lds_ints, ivl.count_grid   staging budget / grid of the direct count kernel
  *   bits.grid          grid of the per-bitset kernels
+ *   core.poll          1 (default): the one-call paths (bxmi_ivl_find_one, short bxmi_bits_count_range) poll a completion
+ *                      word their kernel writes to host memory; 0: they wait for the stream
  * Unknown keys return BXMI_EINVAL. */
 int bxmi_set_option(const char *key, int64_t value);
 
