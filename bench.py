@@ -269,6 +269,37 @@ def bench_find(torch, reps=3):
     return out
 
 
+def bench_per_call():
+    """What an UNMODIFIED script pays per line on the drop-in classes (bx.intervals.IntervalTree.find,
+    bx.bitset.BinnedBitSet.count_range): one launch and one answer across PCIe per call.  Microseconds per call."""
+    import bx.bitset
+    import bx.intervals
+
+    rng = np.random.default_rng(1)
+    s = rng.integers(0, 10_000_000, size=200_000)
+    e = s + rng.integers(1, 1000, size=len(s))
+    t = bx.intervals.IntervalTree()
+    t.insert_batch(s, e, list(range(len(s))))
+    t.find(1, 2)
+    q = rng.integers(0, 10_000_000, size=3000).tolist()
+    t0 = time.perf_counter()
+    hits = 0
+    for x in q:
+        hits += len(t.find(x, x + 500))
+    find_us = (time.perf_counter() - t0) / len(q) * 1e6
+    b = bx.bitset.BinnedBitSet()
+    for i in range(20000):
+        b.set_range(int(s[i]), int(e[i] - s[i]))
+    b.count_range(0, 10)
+    t0 = time.perf_counter()
+    bases = 0
+    for x in q:
+        bases += b.count_range(x, 500)
+    count_us = (time.perf_counter() - t0) / len(q) * 1e6
+    return dict(IntervalTree_find_us=round(find_us, 2), BinnedBitSet_count_range_us=round(count_us, 2), calls=len(q), hits=hits, bases=bases,
+                note="drop-in classes, one call per query, 200k-interval tree / 20k-range bitset; host wall time incl. the Python wrapper")
+
+
 def genome_golden_check(chrom, counts_np, golden):
     """Owner-side parity of one chromosome: the strided subsample against the reference treap's hash (tests/golden/scale.json)."""
     pt = golden["chroms"].get(chrom) if golden else None
@@ -715,6 +746,11 @@ def main():
             line["genome"] = bench_genome(torch, dist, 0, 1, max(5, args.steps), args.warmup, args.targets, args.queries)
         except Exception as ex:
             line["genome"] = {"error": repr(ex)}
+    if world == 1 and not args.no_find:
+        try:
+            line["per_call_latency"] = bench_per_call()
+        except Exception as ex:
+            line["per_call_latency"] = {"error": repr(ex)}
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
