@@ -438,11 +438,11 @@ __global__ __launch_bounds__(SL_THREADS) void sl_search_flat_kernel(const BmSeg 
 //                         the record's tile-sorted offset.  The index reads stay inside the unit's lines (all records
 //                         of the workgroup lie in one unit), the writes inside the run's few hundred bytes.
 //   sl_hits_unpermute_kernel   per tile: every query copies its hits from the tile's scratch region (offset through
-//                         its 16-bit slot) to its CSR position.  The reads are random but confined to the tile's
-//                         region (~0.6 MB, L2), the writes stream.  Escape records (improper, off-grid, over-long
-//                         queries) are answered here from the sealed index.
+//                         its 16-bit slot) to its CSR position.  The reads are random 20-byte runs, but confined to
+//                         the tile's region (~0.6 MB), the writes stream.  Escape records (improper, off-grid,
+//                         over-long queries) are answered here from the sealed index.
 // Compared with the bucketed find of the first generation (window kernel + random 20-byte hit writes or reads over
-// the whole 1 GB hit list): configs[4] 9.0 -> see DESIGN.md.
+// the whole 1 GB hit list): configs[4] 9.1 -> 4.7 ms (with what was tried on the two hit-moving kernels).
 constexpr int SL_WALK = 8;
 
 template <int U>
