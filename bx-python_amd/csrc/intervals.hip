@@ -2734,6 +2734,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     const size_t seg_bytes = (size_t)n * sizeof(BmSeg), tot_bytes = (size_t)n * sizeof(void *);
     const size_t tile_off = (seg_bytes + tot_bytes + 15) & ~(size_t)15, par_bytes = tile_off + (size_t)ntp * sizeof(unsigned short);
     BXMI_TRY(h->bm_params.reserve(par_bytes));
+    // [segments][PT_SLOTS partial totals], then the flag: 1 = the starts are NOT sorted
+    BXMI_TRY(h->p_slots.reserve(((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long)));
+    unsigned long long *slots = h->p_slots.as<unsigned long long>();
     for (int first = 0; first < n; first += BM_PAR_CHUNK) {
         BmSegChunk c;
         memset(&c, 0, sizeof(c));
@@ -2744,14 +2747,11 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         }
         hipLaunchKernelGGL(bm_params_kernel, dim3((unsigned)cnt), dim3(256), 0, st, c, first, h->bm_params.as<BmSeg>(),
                            reinterpret_cast<unsigned long long **>(h->bm_params.as<unsigned char>() + seg_bytes),
-                           reinterpret_cast<unsigned short *>(h->bm_params.as<unsigned char>() + tile_off));
+                           reinterpret_cast<unsigned short *>(h->bm_params.as<unsigned char>() + tile_off), slots, n * PT_SLOTS + 8,
+                           h->bm_items.as<int>());
     }
     BXMI_LAUNCH_CHECK();
-    // [segments][PT_SLOTS partial totals], then the flag: 1 = the starts are NOT sorted
-    BXMI_TRY(h->p_slots.reserve(((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long)));
-    unsigned long long *slots = h->p_slots.as<unsigned long long>();
     unsigned *unsorted = g_opt_sorted_path && n == 1 && !fx ? reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS) : nullptr;
-    BXMI_HIP(hipMemsetAsync(slots, 0, ((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long), st));
     unsigned long long *tslots = any_total ? slots : nullptr;
     BmLaunch L;
     L.segs = h->bm_params.as<BmSeg>();
@@ -2778,7 +2778,6 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY((bm_launch_tiles<512, 32>(L, st)));
     hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                        tile_log2, h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
-    BXMI_HIP(hipMemsetAsync(h->bm_items.p, 0, sizeof(int), st));  // the item count: the plan's workgroups add to it
     if (slices) {
         hipLaunchKernelGGL(sl_unit_sums_kernel, dim3((unsigned)ngroups), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), L.segs, L.tile_seg,
                            h->sl_unitcnt.as<unsigned>(), unsorted);
