@@ -2061,6 +2061,7 @@ static int64_t g_opt_slice = -1;       // search stage on staged key slices (cou
 static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by run length and LDS, else forced (tests)
 static int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_CHUNK, twice that for bucket pairs)
 static int64_t g_opt_sl_hu_parts = 1;  // hit un-permute: workgroups per tile (1, 2, 4, 8, 16), run back to back on one XCD
+static int64_t g_opt_sl_run_cap = 160;  // a slice unit grows only while its expected (tile, unit) run stays within this many records
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
@@ -2149,6 +2150,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.sl_hu_parts")) {
         g_opt_sl_hu_parts = value == 2 || value == 4 || value == 8 || value == 16 ? value : 1;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.sl_run_cap")) {
+        g_opt_sl_run_cap = value < 8 ? 8 : value;
         return 1;
     }
     if (!strcmp(key, "ivl.sl_rbits")) {
@@ -2482,8 +2487,8 @@ static int sl_prepare_index(bxmi_ivl *h, hipStream_t st)
     return BXMI_OK;
 }
 
-// The slice geometry of one index for a batch with `tile` queries per tile: the unit grows while its keys fit and its
-// offsets leave 12 bits for the record's length (longer units = longer runs and fewer work items).
+// The slice geometry of one index for a batch with `tile` queries per tile: the unit grows while its keys fit, its
+// offsets leave 12 bits for the record's length, and its runs stay short enough for one pass of a wave.
 static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_t *run_len)
 {
     BmGeom g;
@@ -2495,7 +2500,10 @@ static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_
         for (f = (int)g_opt_sl_f; f > 0 && h->sl_need[f] > (unsigned)SL_CAP; f--) {}
     } else {
         for (int k = 1; k <= SL_MAX_F; k++) {
-            if (h->sl_need[k] > (unsigned)SL_CAP || g.shift + k > g_opt_sl_rbits) break;
+            // ... and while a (tile, unit) run of a uniform batch stays within ~2.5 waves: longer runs go through the
+            // leftover passes / the workgroup's long-run list, which cost small chromosomes (narrow buckets, f = 5)
+            // 15 % of the genome pass
+            if (h->sl_need[k] > (unsigned)SL_CAP || g.shift + k > g_opt_sl_rbits || (tile << k) / nb_used > g_opt_sl_run_cap) break;
             f = k;
         }
     }
