@@ -364,12 +364,18 @@ def bench_genome(torch, dist, rank, world, steps, warmup, n_targets, n_queries, 
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        pending = []
         for k in range(k_steps):
             ev[k][0].record()
             sh.step(rows[k_warm + k])
             ev[k][1].record()
             if collective:
-                dist.all_reduce(rows[k_warm + k])  # RCCL over xGMI: 24 x int64, the path's only collective
+                # RCCL over xGMI: 24 x int64, the path's only collective.  Asynchronous: step k + 1 does not need step k's
+                # reduced totals, so its kernels may run while the 192 bytes travel; every reduction is waited for inside
+                # the timed region.
+                pending.append(dist.all_reduce(rows[k_warm + k], async_op=True))
+        for w in pending:
+            w.wait()
         torch.cuda.synchronize()
         if collective:
             dist.barrier()
@@ -492,11 +498,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # BENCH_DRY_MULTI=1: rehearsal of the N > 1 code path on a box with ONE GPU (all ranks on cuda:0, gloo instead of
+    # RCCL, which refuses two ranks on one device).  The line it prints says so; it is not a scaling measurement.
+    dry = os.environ.get("BENCH_DRY_MULTI") == "1"
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     _ffi.call("bxmi_set_device", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     workload = args.workload if args.workload != "auto" else ("count" if world == 1 else "genome")
     if workload == "count" and world > 1 and not args.weak:
@@ -527,6 +541,8 @@ def main():
             for k in ("single_gpu_same_run", "speedup_vs_1gpu"):
                 if k in g:
                     line[k] = g[k]
+            if dry:
+                line["dry_run"] = "BENCH_DRY_MULTI=1: every rank on cuda:0, gloo instead of RCCL -- a rehearsal of the code path, not a measurement"
             print(json.dumps(line), flush=True)
         if world > 1:
             dist.barrier()
