@@ -1667,7 +1667,8 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_lane_kernel(IndexDev i
                                                                      const int32_t *__restrict__ win_hi,
                                                                      const int32_t *__restrict__ cnt,
                                                                      const long long *__restrict__ boffs,
-                                                                     int32_t *__restrict__ hits)
+                                                                     int32_t *__restrict__ hits,
+                                                                     const int2 *__restrict__ eid /* (end, index) pairs in start order, or NULL */)
 {
     const int lane = lane_id();
     // contiguous block of queries per workgroup, XCD-aware: neighbours in bucket order share lines
@@ -1683,9 +1684,16 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_lane_kernel(IndexDev i
         int64_t off = live ? boffs[q] : 0;
         const bool wide = hi - lo > LANE_WINDOW;
         if (!wide) {
-            for (int k = lo; k < hi; k++) {
-                const int e = ix.e_ord[k], id = ix.idx[k];
-                if (e > qs) hits[off++] = id;
+            if (eid) {  // one 8-byte read per candidate instead of two 4-byte reads from two arrays
+                for (int k = lo; k < hi; k++) {
+                    const int2 p = eid[k];
+                    if (p.x > qs) hits[off++] = p.y;
+                }
+            } else {
+                for (int k = lo; k < hi; k++) {
+                    const int e = ix.e_ord[k], id = ix.idx[k];
+                    if (e > qs) hits[off++] = id;
+                }
             }
         }
         unsigned long long m = __ballot(wide);
@@ -2062,6 +2070,7 @@ static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by 
 static int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_CHUNK, twice that for bucket pairs)
 static int64_t g_opt_sl_hu_parts = 1;  // hit un-permute: workgroups per tile (1, 2, 4, 8, 16), run back to back on one XCD
 static int64_t g_opt_sl_run_cap = 160;  // a slice unit grows only while its expected (tile, unit) run stays within this many records
+static int64_t g_opt_find_pairs = 1;   // sorted find(): the fill reads (end, index) pairs (one array) instead of the two index arrays
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
@@ -2154,6 +2163,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.sl_run_cap")) {
         g_opt_sl_run_cap = value < 8 ? 8 : value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.find_pairs")) {
+        g_opt_find_pairs = value != 0;
         return 1;
     }
     if (!strcmp(key, "ivl.sl_rbits")) {
@@ -2337,6 +2350,18 @@ static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *
 }
 
 
+// (end, insertion index) pairs in start order (count_slices.hpp: sl_pack_eid_kernel), once per sealed index.
+static int sl_ensure_eid(bxmi_ivl *h, hipStream_t st)
+{
+    if (h->sl_eid_ready) return BXMI_OK;
+    BXMI_TRY(h->sl_eid.reserve(((size_t)h->n + SL_WALK) * sizeof(int2)));
+    hipLaunchKernelGGL(sl_pack_eid_kernel, dim3((unsigned)div_up(h->n + SL_WALK, 256)), dim3(256), 0, st, h->e_ord.as<int32_t>(), h->idx.as<int32_t>(),
+                       (int)h->n, h->sl_eid.as<int2>());
+    BXMI_LAUNCH_CHECK();
+    h->sl_eid_ready = true;
+    return BXMI_OK;
+}
+
 // find() on a batch with sorted starts: windows in query order -> scan -> fill, no bucketing.
 static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits, int64_t cap,
                           int64_t *total_host, hipStream_t st)
@@ -2358,8 +2383,10 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     if (total == 0) return BXMI_OK;
     int fgrid = device_props().cus * 8;
+    BXMI_TRY(sl_ensure_eid(h, st));
     hipLaunchKernelGGL(part_fill_lane_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->p_lo.as<int32_t>(),
-                       h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
+                       h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits,
+                       g_opt_find_pairs ? h->sl_eid.as<int2>() + SL_WALK : (const int2 *)nullptr);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -2414,7 +2441,7 @@ static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *q
         const int fgrid = device_props().cus * 8;
         if (g_opt_find_fill == 2)
             hipLaunchKernelGGL(part_fill_lane_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->q_lo.as<int32_t>(),
-                               h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
+                               h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (const int2 *)nullptr);
         else
             hipLaunchKernelGGL(part_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->q_lo.as<int32_t>(),
                                h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
@@ -2846,13 +2873,7 @@ static int ivl_find_sliced(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, in
     if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     if (total == 0) return BXMI_OK;
     BXMI_TRY(h->sl_hits.reserve((size_t)(total + 16) * 4));
-    if (!h->sl_eid_ready) {  // (end, index) pairs in start order, once per sealed index
-        BXMI_TRY(h->sl_eid.reserve(((size_t)h->n + SL_WALK) * sizeof(int2)));
-        hipLaunchKernelGGL(sl_pack_eid_kernel, dim3((unsigned)div_up(h->n + SL_WALK, 256)), dim3(256), 0, st, h->e_ord.as<int32_t>(),
-                           h->idx.as<int32_t>(), (int)h->n, h->sl_eid.as<int2>());
-        BXMI_LAUNCH_CHECK();
-        h->sl_eid_ready = true;
-    }
+    BXMI_TRY(sl_ensure_eid(h, st));
     const unsigned *loff = h->sl_loff.as<unsigned>();
     const long long *offs = reinterpret_cast<const long long *>(offsets);
     const int2 *eid = h->sl_eid.as<int2>() + SL_WALK;
