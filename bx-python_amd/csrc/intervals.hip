@@ -1088,7 +1088,8 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
                                                                      const int32_t *__restrict__ qe_arr, int64_t nq,
                                                                      int32_t *__restrict__ counts /* may be NULL */,
                                                                      unsigned long long *__restrict__ total_slots,
-                                                                     const unsigned *__restrict__ gate)
+                                                                     const unsigned *__restrict__ gate,
+                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
     __shared__ int s_mm[3][LC_THREADS / 64];
@@ -1209,6 +1210,7 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
                 for (int t = lo; t < s_rank; t++) c += ix.e_ord[t] > s;
             }
             if (counts) counts[base + k] = c;
+            if (his) his[base + k] = s_rank;
             acc += c;
         }
     }
@@ -1708,6 +1710,52 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_lane_kernel(IndexDev i
                 const unsigned long long fm = __ballot(f);
                 if (f) hits[o + __popcll(fm & ((1ull << lane) - 1ull))] = ix.idx[k];
                 o += __popcll(fm);
+            }
+        }
+    }
+}
+
+// Fill pass for sorted batches from (hi, count) instead of a window [lo, hi): every hit has index < hi = #{start < qe},
+// and the count is known exactly, so a lane walks DOWN from hi - 1 through the (end, index) pairs until it has found its
+// `count` hits, writing them from the end of its CSR range (ascending order is kept).  No prefix-max array, no window
+// kernel: the count pass for sorted batches (ivl_local_count_kernel) supplies both numbers.  A lane that has not finished
+// after LANE_WINDOW candidates hands its walk to the whole wave (64 candidates per step, ballot-compacted from the end).
+__global__ __launch_bounds__(FIND_THREADS) void part_fill_walk_kernel(const int2 *__restrict__ eid /* at index 0 */, const int32_t *__restrict__ qs_arr,
+                                                                     int64_t nq, const int32_t *__restrict__ his, const int32_t *__restrict__ cnt,
+                                                                     const long long *__restrict__ offs, int32_t *__restrict__ hits)
+{
+    const int lane = lane_id();
+    const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
+    const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
+    for (int64_t qb = q0; qb < q1; qb += FIND_THREADS) {
+        const int64_t q = qb + threadIdx.x;
+        const bool live = q < q1;
+        int c = live ? cnt[q] : 0;
+        int k = (live && c ? his[q] : 0) - 1;
+        const int qs = live ? qs_arr[q] : 0;
+        int32_t *__restrict__ dst = hits + (live ? offs[q] : 0);
+        for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
+            const int2 p = eid[k];
+            if (p.x > qs) dst[--c] = p.y;
+        }
+        unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int C = __shfl(c, src, 64), K = __shfl(k, src, 64);
+            const int S = __shfl(qs, src, 64);
+            int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
+            while (C > 0 && K >= 0) {
+                const int kk = K - lane;
+                const bool f = kk >= 0 && eid[kk > 0 ? kk : 0].x > S;
+                const unsigned long long fm = __ballot(f);
+                // hits at higher indices come later in the list: lane 0 (the highest index of the step) takes the last free slot
+                const int before = __popcll(fm & ((1ull << lane) - 1ull));
+                if (f && before < C) D[C - 1 - before] = eid[kk].y;
+                C -= __popcll(fm);
+                K -= 64;
             }
         }
     }
@@ -2369,10 +2417,19 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     BXMI_TRY(h->p_lo.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_hi.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
-    TreeDev S = h->treeS.dev, P = h->treeP.dev;
-    S.lds_from = S.nlev, S.lds_ints = 0, P.lds_from = P.nlev, P.lds_ints = 0;  // walk the global levels only
-    hipLaunchKernelGGL(ivl_local_window_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, P, index_dev(h), qs, qe, nq,
-                       h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
+    const bool walk = g_opt_find_pairs != 0;  // (hi, count) from the sorted-batch count kernel, then a walk down the pairs
+    if (walk) {
+        TreeDev S = h->treeS.dev, E = h->treeE.dev;
+        S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
+        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
+                           h->e_sorted.as<int32_t>(), qs, qe, nq, h->q_cnt.as<int32_t>(), (unsigned long long *)nullptr, (const unsigned *)nullptr,
+                           h->p_hi.as<int32_t>());
+    } else {
+        TreeDev S = h->treeS.dev, P = h->treeP.dev;
+        S.lds_from = S.nlev, S.lds_ints = 0, P.lds_from = P.nlev, P.lds_ints = 0;  // walk the global levels only
+        hipLaunchKernelGGL(ivl_local_window_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, P, index_dev(h), qs, qe, nq,
+                           h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
+    }
     BXMI_LAUNCH_CHECK();
     BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
                                                            reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
@@ -2383,10 +2440,14 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     if (total == 0) return BXMI_OK;
     int fgrid = device_props().cus * 8;
-    BXMI_TRY(sl_ensure_eid(h, st));
-    hipLaunchKernelGGL(part_fill_lane_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->p_lo.as<int32_t>(),
-                       h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits,
-                       g_opt_find_pairs ? h->sl_eid.as<int2>() + SL_WALK : (const int2 *)nullptr);
+    if (walk) {
+        BXMI_TRY(sl_ensure_eid(h, st));
+        hipLaunchKernelGGL(part_fill_walk_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq, h->p_hi.as<int32_t>(),
+                           h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
+    } else {
+        hipLaunchKernelGGL(part_fill_lane_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->p_lo.as<int32_t>(),
+                           h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (const int2 *)nullptr);
+    }
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
