@@ -357,3 +357,14 @@ def test_small_builders_raise_what_the_reference_raises_before_touching_the_devi
             else:
                 bb.binned_bitsets_by_chrom(iter(a["lines"]), a["chrom"], **a["kw"])
         assert [type(ei.value).__name__, str(ei.value)] == case["want"]["error"], case["name"]
+
+
+def test_bxmi_opts_environment_applies_the_tuning_knobs():
+    """BXMI_OPTS="key=value,..." is read when the library is loaded (bxmi/_ffi.py): known keys are applied through
+    bxmi_set_option (no GPU call involved), an unknown key is an error at load time, not a silently ignored typo."""
+    code = "from bxmi import _ffi; _ffi.load(); print('loaded')"
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "bx-python_amd"), BXMI_OPTS="ivl.bm_u=4, core.poll=0,ivl.sl_run_cap=128")
+    assert subprocess.check_output([sys.executable, "-c", code], text=True, env=env).strip() == "loaded"
+    env["BXMI_OPTS"] = "ivl.no_such_knob=1"
+    r = subprocess.run([sys.executable, "-c", code], text=True, env=env, capture_output=True)
+    assert r.returncode != 0 and "unknown key" in r.stderr
