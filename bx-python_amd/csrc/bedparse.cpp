@@ -4,7 +4,7 @@
 // (lib/bx/bitset_builders.py:33-46, scripts/bed_intersect.py:46-50); once the GPU answers a
 // chromosome's queries in microseconds that loop is all that is left of the run time.
 // This is a strict, single-pass C++ parser for the common case.  It never guesses: the moment a
-// line is not plain ASCII BED -- a field that is not [+-]?[0-9]+, a '\r', a byte >= 0x80, too few
+// line is not plain ASCII BED -- a field that is not [+-]?[0-9]+, a '\r', a NUL, a byte >= 0x80, too few
 // columns -- it STOPS and reports the line number, and the Python code takes over from that line
 // with the reference's exact semantics (and exceptions).  Lines starting with '#' and
 // whitespace-only lines are skipped, fields are split on runs of ASCII whitespace like
@@ -88,7 +88,7 @@ extern "C" int bxmi_bed_parse(const char *data, int64_t len, int chrom_col, int 
             bool plain = true, blank = true;
             for (const char *q = line; q < eol; ++q) {
                 unsigned char c = (unsigned char)*q;
-                if (c >= 0x80 || c == '\r') {
+                if (c >= 0x80 || c == '\r' || c == 0) {  // (a NUL is an ordinary character to Python, but ends a C string: names would be cut)
                     plain = false;
                     break;
                 }
@@ -213,7 +213,7 @@ extern "C" int bxmi_tab_parse(const char *data, int64_t len, int chrom_col, int 
             const char *eol = nl ? nl : fin, *next = nl ? nl + 1 : fin;
             bool plain = true;
             for (const char *q = line; q < eol; ++q)
-                if ((unsigned char)*q >= 0x80 || *q == '\r') {
+                if ((unsigned char)*q >= 0x80 || *q == '\r' || *q == 0) {
                     plain = false;
                     break;
                 }

@@ -192,7 +192,7 @@ def _python_parse(text, chrom_col=0, start_col=1, end_col=2):
     # to the per-line path, which sees it through universal newlines)
     for ln, line in enumerate(re.findall(r"[^\n]*\n|[^\n]+\Z", text)):
         body = line[:-1] if line.endswith("\n") else line
-        if any(ord(ch) >= 0x80 for ch in body) or "\r" in body:
+        if any(ord(ch) >= 0x80 for ch in body) or "\r" in body or "\x00" in body:
             stop = ln
             break
         if line.startswith("#") or line.isspace():
@@ -300,7 +300,7 @@ def test_native_table_parse_equals_per_line_readers(monkeypatch):
              for i, a in enumerate(rng.integers(0, 10**6, size=300).tolist())]
     odd = ["chr1\t+5\t9\tx\t0\t+\n", "chr1\t 5\t9\n", "chr1\t007\t9\n", "chr1\t5\t9\tx\t0\t.\n", "chr1\t5\t9\tx\t0\t*\n", "chr1\t5\n",
            "chr1\t9\t5\n", " chr1 \t5\t9\n", "chr\u00e9\t5\t9\n", "chr1\t-0\t9\n", "chr1\t5\t9\tx\t0\t+\r\n", "\n", "# note\n", "track name=x\n",
-           "chr1\t1_0\t20\n", "chr2\t-7\t-3\n", "chr1\t5\t9\tx\t0\t-\n"]
+           "chr1\t1_0\t20\n", "chr2\t-7\t-3\n", "chr1\t5\t9\tx\t0\t-\n", "chr\x001\t5\t9\n", "chr1\t5\t9\tna\x00me\t0\t+\n"]
     files = {
         "clean": clean,
         "header then clean": ["#chrom\tstart\tend\n"] + clean[:50],
