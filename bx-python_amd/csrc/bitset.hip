@@ -214,7 +214,7 @@ __device__ __forceinline__ long long pair_popcount(ulonglong2 x, int64_t w, int6
 
 __device__ __forceinline__ void tags_binary(int op, uint8_t *__restrict__ ta, const uint8_t *__restrict__ tb, int64_t nbins)
 {
-    for (int64_t i = threadIdx.x; i < nbins; i += BITS_THREADS) {
+    for (int64_t i = threadIdx.x; i < nbins; i += blockDim.x) {
         const uint8_t x = ta[i], y = tb[i];
         if (op == 0) {                                 // binBitsAnd, binBits.c:237-256
             if (x == TAG_ZERO) continue;
@@ -230,14 +230,22 @@ __device__ __forceinline__ void tags_binary(int op, uint8_t *__restrict__ ta, co
     }
 }
 
+// (these two run with 256 threads per workgroup when they only stream, with BITS_COUNT_THREADS when they also count:
+// a counting launch ends in one atomic per workgroup on the caller's int64 -- ~85 ns each on the same address, and no
+// cheaper spread over 64 partial sums with per-slot tickets: the fences cost more than they save (measured: popcount
+// 0.17 -> 0.23 ms at the same grid, 0.52 ms at 8 workgroups per CU) -- which keeps the grid at one workgroup per CU, and 256
+// threads per CU cannot keep enough loads in flight: 2 TB/s on a chromosome-sized set, 2.2-2.4 with 1024)
+constexpr int BITS_COUNT_THREADS = 1024;
+constexpr int64_t BITS_WIDE_BELOW = (int64_t)1 << 21;  // 16-byte pairs (32 MiB of words): larger sets stream well enough at 256 threads (5.4 TB/s at 64 MiB)
+
 template <int OP, bool COUNT>
-__global__ __launch_bounds__(BITS_THREADS) void bits_binary_kernel(unsigned long long *__restrict__ a,
+__global__ __launch_bounds__(BITS_COUNT_THREADS) void bits_binary_kernel(unsigned long long *__restrict__ a,
                                                                   const unsigned long long *__restrict__ b,
                                                                   int64_t npairs /* 16-byte pairs */, int64_t size_bits,
                                                                   unsigned long long *__restrict__ acc, uint8_t *__restrict__ ta,
                                                                   const uint8_t *__restrict__ tb, int64_t nbins /* 0: no tags (flat set) */)
 {
-    __shared__ long long red[BITS_THREADS / 64];
+    __shared__ long long red[BITS_COUNT_THREADS / 64];
     ulonglong2 *va = reinterpret_cast<ulonglong2 *>(a);
     const ulonglong2 *vb = reinterpret_cast<const ulonglong2 *>(b);
     const int64_t full_words = size_bits >> 6;  // words entirely inside [0,size)
@@ -246,8 +254,8 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_binary_kernel(unsigned long
     // the per-bin tags (an array of their own): by the FIRST workgroup, before its share of the words, so that the three
     // dependent round trips hide behind everybody else's streaming instead of trailing the launch
     if (nbins > 0 && blockIdx.x == 0) tags_binary(OP, ta, tb, nbins);
-    const int64_t nth = (int64_t)gridDim.x * BITS_THREADS;
-    int64_t p = (int64_t)blockIdx.x * BITS_THREADS + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; p + (BITS_UNROLL - 1) * nth < npairs; p += BITS_UNROLL * nth) {
         ulonglong2 x[BITS_UNROLL], y[BITS_UNROLL];
 #pragma unroll
@@ -272,16 +280,16 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_binary_kernel(unsigned long
     if (COUNT) block_accumulate_i64(c, red, acc);
 }
 
-__global__ __launch_bounds__(BITS_THREADS) void bits_popcount_kernel(const unsigned long long *__restrict__ a, int64_t npairs,
-                                                                    int64_t size_bits, unsigned long long *__restrict__ acc)
+__global__ __launch_bounds__(BITS_COUNT_THREADS) void bits_popcount_kernel(const unsigned long long *__restrict__ a, int64_t npairs,
+                                                                          int64_t size_bits, unsigned long long *__restrict__ acc)
 {
-    __shared__ long long red[BITS_THREADS / 64];
+    __shared__ long long red[BITS_COUNT_THREADS / 64];
     const ulonglong2 *va = reinterpret_cast<const ulonglong2 *>(a);
     const int64_t full_words = size_bits >> 6;
     const unsigned long long tail_mask = (size_bits & 63) ? ~(~0ull << (size_bits & 63)) : 0ull;
     long long c = 0;
-    const int64_t nth = (int64_t)gridDim.x * BITS_THREADS;
-    int64_t p = (int64_t)blockIdx.x * BITS_THREADS + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x;
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; p + (BITS_UNROLL - 1) * nth < npairs; p += BITS_UNROLL * nth) {
         ulonglong2 x[BITS_UNROLL];
 #pragma unroll
@@ -990,9 +998,10 @@ static int bits_binary(bxmi_bits *h, const bxmi_bits *other, unsigned long long 
     const int64_t nb = h->flat || OP == 2 ? 0 : div_up(h->total_bits, h->bin_size);
     if (npairs == 0 && nb == 0) return BXMI_OK;
     // a workgroup moves BITS_UNROLL x 4 KiB per operand and sweep; counting variants stay at one workgroup per CU
-    int grid = bits_grid(npairs, BITS_THREADS * BITS_UNROLL);
+    const int threads = COUNT && npairs <= BITS_WIDE_BELOW ? BITS_COUNT_THREADS : BITS_THREADS;
+    int grid = bits_grid(npairs, threads * BITS_UNROLL);
     if (COUNT && grid > device_props().cus) grid = device_props().cus;
-    hipLaunchKernelGGL((bits_binary_kernel<OP, COUNT>), dim3(grid), dim3(BITS_THREADS), 0, st,
+    hipLaunchKernelGGL((bits_binary_kernel<OP, COUNT>), dim3(grid), dim3(threads), 0, st,
                        h->words.as<unsigned long long>(), other->words.as<unsigned long long>(), npairs, (int64_t)h->size, acc_dev,
                        h->tags.as<uint8_t>(), other->tags.as<uint8_t>(), nb);
     BXMI_LAUNCH_CHECK();
@@ -1028,9 +1037,10 @@ extern "C" int bxmi_bits_popcount_dev(bxmi_bits_t *h, int64_t *count_dev, void *
     if (!h || !count_dev) return fail(BXMI_EINVAL, "bxmi_bits_popcount_dev: bad arguments");
     int64_t npairs = h->cap_words >> 1;  // (nothing is set past the allocated words)
     if (npairs == 0) return BXMI_OK;
-    int grid = bits_grid(npairs, BITS_THREADS * BITS_UNROLL);
+    const int threads = npairs <= BITS_WIDE_BELOW ? BITS_COUNT_THREADS : BITS_THREADS;
+    int grid = bits_grid(npairs, threads * BITS_UNROLL);
     if (grid > device_props().cus) grid = device_props().cus;
-    hipLaunchKernelGGL(bits_popcount_kernel, dim3(grid), dim3(BITS_THREADS), 0, as_stream(stream),
+    hipLaunchKernelGGL(bits_popcount_kernel, dim3(grid), dim3(threads), 0, as_stream(stream),
                        h->words.as<unsigned long long>(), npairs, (int64_t)h->size, reinterpret_cast<unsigned long long *>(count_dev));
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;

@@ -1948,7 +1948,11 @@ __global__ __launch_bounds__(ONE_THREADS) void ivl_find_one_kernel(TreeDev S, Tr
         run += tot;
         __syncthreads();
     }
-    __syncthreads();  // every hit is written before the completion word goes out
+    // Every wave's hits must have LEFT the GPU before the completion word goes out: the barrier orders the waves, but a
+    // workgroup-scope barrier does not wait for the other waves' stores to host memory, and thread 0's release only
+    // covers its own wave's (seen as a rare wrong hit list in a per-line script).  So each wave drains its stores first.
+    __threadfence_system();
+    __syncthreads();
     if (threadIdx.x == 0) {
         *reinterpret_cast<long long *>(out) = run;
         publish_to_host(reinterpret_cast<unsigned long long *>(out + 2 + cap), seq);
