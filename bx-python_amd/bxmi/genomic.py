@@ -166,6 +166,25 @@ class GenomicInterval(TableRow):
         d["chrom"], d["start"], d["end"], d["strand"] = chrom, start, end, strand
         return new
 
+    def __str__(self):
+        d = self.__dict__
+        if "fields" not in d and "_line" in d:
+            return d["_line"]  # never split, hence never changed: the line is its own normal form (_from_parsed)
+        return "\t".join(self.fields)
+
+    def _append_fields(self, *more):
+        """`self.fields.append(x)` for every x (what operations/coverage.py:71-72 does to a row) -- on a row that has not
+        been split yet the text grows instead, which is the same thing seen through `fields`; `nfields` keeps the value
+        the constructor gave it in the reference (the number of fields the row came with)."""
+        d = self.__dict__
+        if "fields" in d:
+            d["fields"].extend(more)
+            return
+        line = d["_line"]
+        if "nfields" not in d:
+            d["nfields"] = line.count("\t") + 1
+        d["_line"] = line + "\t" + "\t".join(more)
+
     def __getattr__(self, name):  # only reached for attributes that are not there yet
         if name == "fields":
             fields = self.__dict__["fields"] = self.__dict__["_line"].split("\t")

@@ -265,6 +265,8 @@ def _rows_by_chrom(primary, bitsets, start_after_end):
         if start > end and start_after_end == "skip":
             primary.skip(i, "Interval start after end!")
             continue
+        if start > end and start_after_end == "drop":  # (the caller has dealt with the row already)
+            continue
         if start > end and start_after_end == "warn":
             warn("Interval start after end!")
         err = _range_error(bitsets[chrom], start, end)
@@ -315,8 +317,19 @@ def _emit(primary, comments, per_item, passthrough=None):
             if passthrough is not None and passthrough(item):
                 yield item
                 continue
-            for start, end in per_item.get(i, ()):
-                yield item._piece(start, end) if type(item) is GenomicInterval else _copy_with(item, start, end)
+            todo_i = per_item.get(i, ())
+            if type(item) is GenomicInterval:
+                if len(todo_i) == 1 and todo_i[0] == (item.start, item.end):
+                    # the row survives whole: the reference yields `interval.copy()` with the same start and end -- an equal
+                    # row nobody else holds -- so the row itself will do (its fields are in normal form already), and a
+                    # row that came from the native parser is then printed without ever being split
+                    yield item
+                else:
+                    for start, end in todo_i:
+                        yield item._piece(start, end)
+            else:
+                for start, end in todo_i:
+                    yield _copy_with(item, start, end)
 
 
 def _copy_with(item, start, end):
@@ -399,39 +412,50 @@ def coverage(readers, comments=True):
             if chrom in more:
                 bitsets[chrom].ior(more[chrom])
     p = _Primary(primary)
-    covered_of = {}
-    pending = {}
-    for i, item in enumerate(p.items):
+    n_items = len(p.items)
+    have = np.zeros(n_items, dtype=bool)        # rows that are written out
+    bases = np.zeros(n_items, dtype=np.int64)
+    length = np.full(n_items, -1, dtype=np.int64)  # -1: chromosome without a bitset -> "0", "0.0"
+    b = p.bulk
+    nb = b.n if b is not None else 0
+    if nb:  # the natively parsed prefix: every row is valid (start <= end); those of unknown chromosomes are written with zeros
+        known = np.array([name in bitsets for name in b.names] or [False])
+        rows = b.kind_a == 0
+        have[:nb] = rows & ~known[np.where(rows, b.chrom_a, 0)]
+    for i in range(nb, n_items):  # what the reader delivered object by object: coverage.py:36-62, row by row
+        item = p.items[i]
         if not isinstance(item, GenomicInterval):
             continue
-        start, end = int(item.start), int(item.end)
-        if start > end:
+        if int(item.start) > int(item.end):
             p.skip(i, "Interval start after end!")
-            continue
-        if item.chrom not in bitsets:
-            covered_of[i] = (0, 0.0)
-            continue
-        err = _range_error(bitsets[item.chrom], start, end)
-        if err is not None:
-            p.skip(i, err)
-            continue
-        g = pending.setdefault(item.chrom, ([], [], []))
-        g[0].append(i), g[1].append(start), g[2].append(end)
-    for chrom, (idx, starts, ends) in pending.items():
-        starts, ends = np.array(starts, dtype=np.int64), np.array(ends, dtype=np.int64)
-        covered = _covered(bitsets[chrom], starts, ends)
-        for i, c, length in zip(idx, covered.tolist(), (ends - starts).tolist()):
-            covered_of[i] = (c, 0 if length == 0 else float(c) / float(length))
+        elif item.chrom not in bitsets:
+            have[i] = True
+    for chrom, (idx, starts, ends) in _rows_by_chrom(p, bitsets, "drop").items():
+        have[idx] = True
+        bases[idx] = _covered(bitsets[chrom], starts, ends)
+        length[idx] = ends - starts
+    for i, _ in p.own:  # (a row the range check refused is logged, not written)
+        have[i] = False
     p.settle()
-    for i, item in enumerate(p.items):
+    bases_l, length_l = bases.tolist(), length.tolist()
+    want = have.copy()
+    if nb:
+        want[:nb] |= b.kind_a != 0
+    want[nb:] = True
+    for i in np.nonzero(want)[0].tolist():
+        item = p.items[i]
         if isinstance(item, Header):
             yield item
         if isinstance(item, Comment) and comments:
             yield item
-        elif isinstance(item, GenomicInterval) and i in covered_of:
-            bases, fraction = covered_of[i]
-            item.fields.append(str(bases))
-            item.fields.append(str(fraction))
+        elif isinstance(item, GenomicInterval) and have[i]:
+            c, ln = bases_l[i], length_l[i]
+            fraction = 0.0 if ln < 0 else (0 if ln == 0 else float(c) / float(ln))
+            if type(item) is GenomicInterval:
+                item._append_fields(str(c), str(fraction))
+            else:
+                item.fields.append(str(c))
+                item.fields.append(str(fraction))
             yield item
 
 
