@@ -178,3 +178,39 @@ def test_readers_iterate_like_the_reference(golden):
         if c["skips"] is not None:
             assert r.skipped == c["skips"]["skipped"], tag
             assert [list(t) for t in r.skipped_lines] == c["skips"]["skipped_lines"], tag
+
+
+def test_quicksect_tree_host_logic(monkeypatch):
+    """bx.intervals.operations.quicksect.IntervalTree on the oracle index: the hit sets, the in-order traverse and the
+    per-chromosome objects of the three trees captured from the reference (tests/golden/builders_quicksect.json)."""
+    import bx.intervals.intersection as inter
+    from bx.intervals.operations.quicksect import IntervalTree
+
+    class _Index(_OracleIndex):
+        def find_one_list(self, qs, qe):
+            off, hits = self.find([qs], [qe])
+            return hits.tolist()
+
+        def order(self):
+            return np.array(sorted(range(len(self._s)), key=lambda j: (self._s[j], -j)), dtype=np.int32)
+
+    monkeypatch.setattr(inter, "IntervalIndex", _Index)
+    with open(os.path.join(os.path.dirname(GOLDEN), "builders_quicksect.json")) as f:
+        doc = json.load(f)
+
+    class Row:
+        def __init__(self, chrom, start, end):
+            self.chrom, self.start, self.end = chrom, start, end
+
+    for case in doc["quicksect"]:
+        tree = IntervalTree()
+        for i, (c, s, e) in enumerate(case["rows"]):
+            tree.insert(Row(c, s, e), linenum=i, other="row%d" % i)
+        assert list(tree.chroms) == case["chrom_order"]
+        for (c, s, e), want in zip(case["queries"], case["found"]):
+            got = []
+            tree.intersect(Row(c, s, e), lambda node: got.append([node.linenum, node.start, node.end, node.other]))
+            assert sorted(got) == want, (case["name"], c, s, e)
+        order = []
+        tree.traverse(lambda node: order.append(node.linenum))
+        assert order == case["traverse"], case["name"]
