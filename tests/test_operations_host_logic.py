@@ -214,3 +214,37 @@ def test_quicksect_tree_host_logic(monkeypatch):
         order = []
         tree.traverse(lambda node: order.append(node.linenum))
         assert order == case["traverse"], case["name"]
+
+
+def test_small_builders_host_logic(monkeypatch):
+    """bxmi.builders' list / proximity / by-chromosome builders on the oracle bitset: all 27 reference cases of
+    tests/golden/builders_quicksect.json (resulting runs per chromosome, dict order, or the exception)."""
+    import bxmi.builders as builders
+
+    monkeypatch.setattr(builders, "BinnedBitSet", _OracleBits)
+    with open(os.path.join(os.path.dirname(GOLDEN), "builders_quicksect.json")) as f:
+        doc = json.load(f)
+
+    def runs(bits):
+        s, e = bits.runs()
+        return [[int(a), int(b)] for a, b in zip(s, e)]
+
+    def observe(fn):
+        try:
+            got = fn()
+        except Exception as e:  # noqa: BLE001 -- the reference's own failure is the expectation
+            return dict(error=[type(e).__name__, str(e)])
+        if isinstance(got, dict):
+            return dict(order=list(got), runs={c: runs(b) for c, b in got.items()})
+        return dict(runs=runs(got))
+
+    assert len(doc["builders"]) >= 25
+    for case in doc["builders"]:
+        a = case["args"]
+        if case["fn"] == "from_list":
+            got = observe(lambda: builders.binned_bitsets_from_list(a["rows"]))
+        elif case["fn"] == "proximity":
+            got = observe(lambda: builders.binned_bitsets_proximity(iter(a["lines"]), **a["kw"]))
+        else:
+            got = observe(lambda: builders.binned_bitsets_by_chrom(iter(a["lines"]), a["chrom"], **a["kw"]))
+        assert got == case["want"], case["name"]
