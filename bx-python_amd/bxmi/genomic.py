@@ -172,6 +172,25 @@ class GenomicInterval(TableRow):
             return d["_line"]  # never split, hence never changed: the line is its own normal form (_from_parsed)
         return "\t".join(self.fields)
 
+    @classmethod
+    def _from_values(cls, reader, fields, chrom, start, end, strand):
+        """A NEW row made by an operation from values that are in normal form already (a chromosome name taken from a
+        reader's rows, integers with start <= end, strand "+" or "-"): what the constructor would leave behind for
+        `fields` holding those values, without parsing them back (complement.py:44-49 builds its rows this way)."""
+        new = object.__new__(cls)
+        d = new.__dict__
+        d["reader"], d["fields"] = reader, fields
+        cc, sc, ec, tc = reader.chrom_col, reader.start_col, reader.end_col, reader.strand_col
+        d["chrom_col"], d["start_col"], d["end_col"], d["strand_col"] = cc, sc, ec, tc
+        d["nfields"] = len(fields)
+        d["chrom"] = fields[cc] = chrom
+        d["start"], fields[sc] = start, str(start)
+        d["end"], fields[ec] = end, str(end)
+        if 0 <= tc < len(fields):
+            fields[tc] = strand
+        d["strand"] = strand
+        return new
+
     def _append_fields(self, *more):
         """`self.fields.append(x)` for every x (what operations/coverage.py:71-72 does to a row) -- on a row that has not
         been split yet the text grows instead, which is the same thing seen through `fields`; `nfields` keeps the value

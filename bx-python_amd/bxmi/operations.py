@@ -506,7 +506,10 @@ def complement(reader, lens):
             if start >= limit:
                 break
             fields = ["."] * width
-            if 0 <= safe.strand_col < len(fields):
+            if chrom == chrom.strip() and start <= min(end, limit):
+                yield GenomicInterval._from_values(safe, fields, chrom, start, min(end, limit), "+")
+                continue
+            if 0 <= safe.strand_col < len(fields):  # anything unusual: through the constructor, which says what is wrong
                 fields[safe.strand_col] = "+"
             fields[safe.chrom_col] = chrom
             fields[safe.start_col] = start
