@@ -89,6 +89,21 @@ class IntervalIndex:
         call("bxmi_ivl_slice_state", self._h, C.byref(st), need)
         return st.value, list(need)
 
+    def flat_state(self):
+        """(state, hard_cells) of the flat walk on cell images: 1 = usable, -1 = the index does not qualify, 0 = undecided."""
+        self._ready()
+        st, hc = C.c_int(0), C.c_int64(0)
+        call("bxmi_ivl_flat_state", self._h, C.byref(st), C.byref(hc))
+        return st.value, hc.value
+
+    def dense_state(self):
+        """(state, [most keys of a block, most overflow entries of a unit]) of the dense-image search stage: 1 = usable,
+        -1 = the index does not fit the format, 0 = undecided."""
+        self._ready()
+        st, worst = C.c_int(0), (C.c_int64 * 2)()
+        call("bxmi_ivl_dense_state", self._h, C.byref(st), worst)
+        return st.value, list(worst)
+
     def order(self):
         """Insertion indices in the treap's in-order (== IntervalTree.traverse order)."""
         self._ready()

@@ -81,6 +81,8 @@ struct BmSeg {
     int64_t tile0, ntiles;    // first tile of the segment in the batch's numbering, tiles that hold queries
     int64_t tile_end;         // first tile of the next segment (tile0 + ntiles rounded up to a plan group)
     const uint2 *images;
+    const unsigned char *dimages;  // dense stage: the index's unit images (count_dense.hpp)
+    const unsigned char *pimages;  // flat walk on cell images: the index's unit images (count_dense.hpp, bp_*)
     const BmBucket *bmeta;
     const int4 *smeta;        // slice pass: ranks at every bucket boundary (SlMeta, count_slices.hpp)
     IndexDev ix;              // the sealed index (escapes, hard cells)

@@ -1,0 +1,830 @@
+// count_dense.hpp -- third search stage of the large-batch count pass: DENSE UNIT IMAGES ("bd_*" kernels).
+// Included by intervals.hip after count_slices.hpp: tile sort, run table, unit sums, plan and un-permute are the bm_* /
+// sl_* kernels unchanged; what differs is what a search workgroup keeps in LDS and how it walks its records.
+//
+// Why: the bucket-pair search of count_bitmap.hpp moves 1.0 GB at 2.5 TB/s while its neighbours stream at 5 TB/s.  A
+// (tile, bucket pair) run is ~32 records = 128 unaligned bytes, fetched and stored as 4-byte pieces per lane: 17.6 M +
+// 22 M quarter-line requests per 100 M queries, and that request rate -- not bytes, not compute -- is its bound.
+// Two changes halve the runs' number and quarter the requests:
+//   1. a bitmap of 1 bit per coordinate instead of 2: one 16-byte cell per 128 coordinates holds which of them carry a
+//      key, a 16-bit word per cell holds the rank of the cell's first key relative to its 2^17-coordinate block, and a
+//      small overflow list describes the coordinates that carry more than one key (exact for any multiset, see below).
+//      1.14 bits per coordinate: a UNIT of 2^19 coordinates (four buckets of configs[1]) fits one CU's LDS with both of
+//      its arrays, so a (tile, unit) run is ~64 records = 256 bytes;
+//   2. the walk is FLAT and 16 bytes wide: a wave lays the runs of 64 tiles end to end (a DPP prefix sum over their
+//      lengths in 16-byte slots), every lane takes one aligned int4 of four records per pass -- found through one ballot,
+//      a few readlanes and two ds_bpermutes, no LDS table, no workgroup barrier -- answers the four records and writes
+//      the four counts back as one int4 (records of neighbouring units at a run's two ends are masked: their lanes
+//      store single dwords).  Every lane is busy in every pass whatever the run lengths are; waves pull batches of 64
+//      tiles from a workgroup counter, runs longer than 256 records (sorted / clumped input) go to the workgroup's
+//      cooperative finish as in the other stages.
+//
+// rank(rel) = #{keys of the unit's slice below coordinate lo_u + rel}
+//           = qbase[block(cell)] + base15(cell) + popcount(cell's bits below rel) + extras(cell, rel)
+// A cell whose coordinates carry no duplicate keys has meta = base15 (< 2^15).  Any other cell has meta = 0x8000 | i and
+// ov[i] = base15, ov[i+1..] = one 16-bit entry per duplicated coordinate: position : 7 | extra copies : 8 | more : 1
+// (more than 255 extra copies take several entries; a lone entry is followed by a zero), extras(cell, rel) sums the
+// copies of the entries below rel.  ov[0..2] are zeros: a lookup reads {ov[i], ov[i+1], ov[i+2]} with i = 0 for a plain
+// cell -- no branch on the common path; only a third entry (three duplicated coordinates in one cell) takes a loop.
+// An index qualifies while every block holds < 2^15 keys and every unit's overflow list fits BD_OV_CAP entries;
+// bd_image_kernel reports both maxima when it builds the images (once per sealed index).
+//
+// count(q) = (sLo + rankS(off + len)) - (eLo + rankE(off + 1))        (intersection.pyx:180-189)
+#pragma once
+
+namespace bxmi {
+
+constexpr int BD_UNIT_LOG2 = 19;     // coordinates per unit, at most: the offset field of a record
+constexpr int BD_RSHIFT = 19;        // record = offset : 19 | length : 13 (8191 = escape)
+constexpr int BD_MARGIN = 8192;      // the starts' cells reach this far past the unit: every record's qe is covered
+constexpr int BD_MAX_F = 6;          // buckets per unit = 2^f
+constexpr int BD_MAX_SHIFT = 19;     // bucket width <= 2^19: spans up to 2^30
+constexpr int BD_OV_CAP = 5632;      // 16-bit overflow entries per unit (11 KiB of LDS)
+constexpr int BD_THREADS = 1024;
+constexpr int BD_LONG_SLOTS = 64;    // runs of more 16-byte slots than this go to the cooperative finish
+constexpr int BD_LONG_CAP = 320;
+constexpr int BD_HDR_QS = 6;         // header words: [0..5] qbaseE, [6..11] qbaseS, [12] overflow entries, [13] eLo, [14] sLo
+
+// Layout of one unit's image, in bytes (the same in HBM and in LDS; every part starts 16-byte aligned).
+struct BdLayout {
+    int nce, ncs;                      // cells, sentinel included
+    int bitsE, bitsS, metaE, metaS, hdr, ov, bytes;
+};
+
+__host__ __device__ inline BdLayout bd_layout(int unit_log2)
+{
+    BdLayout L;
+    const int UW = 1 << unit_log2;
+    L.nce = (UW >> 7) + 1;
+    L.ncs = ((UW + BD_MARGIN) >> 7) + 1;
+    L.bitsE = 0;
+    L.bitsS = L.nce * 16;
+    L.metaE = L.bitsS + L.ncs * 16;
+    L.metaS = L.metaE + ((L.nce * 2 + 15) & ~15);
+    L.hdr = L.metaS + ((L.ncs * 2 + 15) & ~15);
+    L.ov = L.hdr + 64;
+    L.bytes = L.ov + BD_OV_CAP * 2;
+    return L;
+}
+
+// ---------------------------------------------------------------------------
+// images: built once per sealed index, one workgroup per unit
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int bd_lower_bound(const int32_t *__restrict__ a, int lo, int hi, int key)
+{
+    while (lo < hi) {
+        const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (a[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// stats: [0] most keys in one block of 2^bshift cells, [1] most overflow entries of one unit
+__global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted, int n,
+                                                              BmGeom g, int bshift, unsigned char *__restrict__ images, unsigned *__restrict__ stats)
+{
+    const int bmask = (1 << bshift) - 1;
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ int s_r[2];
+    __shared__ unsigned scan_tmp[16];
+    const int unit = blockIdx.x;
+    const int ulog = g.shift + g.f;
+    const BdLayout L = bd_layout(ulog);
+    const long long UW = 1ll << ulog;
+    const long long lo = (long long)g.cmin + (long long)unit * UW;
+    unsigned char *__restrict__ img = images + (size_t)unit * L.bytes;
+    unsigned *hdr = reinterpret_cast<unsigned *>(img + L.hdr);
+    unsigned short *ov = reinterpret_cast<unsigned short *>(img + L.ov);
+    // LDS: bits [ncs * 4], cnt [ncs], ecnt [ncs], ovoff [ncs], ecur [ncs]
+    unsigned *bits = reinterpret_cast<unsigned *>(dyn);
+    unsigned *cnt = bits + 4 * L.ncs, *ecnt = cnt + L.ncs, *ovoff = ecnt + L.ncs, *ecur = ovoff + L.ncs;
+    unsigned ov_base = 3;  // overflow entries used so far (three zeros for the plain cells, then the ends' lists, then the starts')
+    unsigned worst_block = 0;
+    if (threadIdx.x < 2 * BD_HDR_QS) hdr[threadIdx.x] = 0u;  // (one block per unit: a kernel that reads the table finds zeros)
+    if (threadIdx.x < 3) ov[threadIdx.x] = 0;
+    for (int arr = 0; arr < 2; arr++) {
+        const int32_t *__restrict__ A = arr == 0 ? e_sorted : s_ord;
+        const int nc = arr == 0 ? L.nce : L.ncs;
+        const long long cover = arr == 0 ? UW : UW + BD_MARGIN;  // keys with rel in [0, cover) belong to this image
+        if (threadIdx.x < 2) s_r[threadIdx.x] = bm_rank_lt64(A, n, threadIdx.x == 0 ? lo : lo + cover);
+        for (int c = threadIdx.x; c < nc; c += BD_THREADS) {
+            bits[4 * c] = bits[4 * c + 1] = bits[4 * c + 2] = bits[4 * c + 3] = 0u;
+            cnt[c] = ecnt[c] = ecur[c] = 0u;
+        }
+        __syncthreads();
+        const int r0 = s_r[0], r1 = s_r[1];
+        if (threadIdx.x == 0) hdr[arr == 0 ? 13 : 14] = (unsigned)r0;
+        // pass 1: bits, keys per cell, overflow entries per cell
+        for (int r = r0 + (int)threadIdx.x; r < r1; r += BD_THREADS) {
+            const int k = A[r];
+            const unsigned rel = (unsigned)((long long)k - lo);
+            const unsigned c = rel >> 7, p = rel & 127u;
+            atomicAdd(&cnt[c], 1u);
+            const bool first = r == r0 || A[r - 1] != k, last = r + 1 == r1 || A[r + 1] != k;
+            if (first) atomicOr(&bits[4 * c + (p >> 5)], 1u << (p & 31u));
+            if (last && !first) {
+                const unsigned extras = (unsigned)(r - bd_lower_bound(A, r0, r, k));
+                atomicAdd(&ecnt[c], (extras + 254u) / 255u);
+            }
+        }
+        __syncthreads();
+        // exclusive prefixes over the cells: keys below the cell, overflow words before the cell's
+        const int K = (nc + BD_THREADS - 1) / BD_THREADS;
+        const int c_lo = (int)threadIdx.x * K, c_hi = c_lo + K < nc ? c_lo + K : nc;
+        unsigned ksum = 0, osum = 0;
+        for (int c = c_lo; c < c_hi; c++) {
+            ksum += cnt[c];
+            osum += ecnt[c] ? 1u + (ecnt[c] > 2u ? ecnt[c] : 2u) : 0u;
+        }
+        unsigned ktot, otot;
+        unsigned kexc = block_exclusive_scan(ksum, OpSum(), 0u, scan_tmp, &ktot);
+        unsigned oexc = block_exclusive_scan(osum, OpSum(), 0u, scan_tmp, &otot);
+        for (int c = c_lo; c < c_hi; c++) {
+            const unsigned k = cnt[c], o = ecnt[c] ? 1u + (ecnt[c] > 2u ? ecnt[c] : 2u) : 0u;
+            cnt[c] = kexc;  // keys of the slice below cell c
+            ovoff[c] = oexc;
+            kexc += k;
+            oexc += o;
+        }
+        __syncthreads();
+        unsigned short *meta = reinterpret_cast<unsigned short *>(img + (arr == 0 ? L.metaE : L.metaS));
+        for (int c = threadIdx.x; c < nc; c += BD_THREADS) {
+            const int blk = c >> bshift;
+            const unsigned qb = cnt[blk << bshift];
+            const unsigned base = cnt[c] - qb;
+            if ((c & bmask) == 0) hdr[(arr == 0 ? 0 : BD_HDR_QS) + blk] = qb;
+            // keys of this block: up to the next block's first cell (or the end of the image)
+            if ((c & bmask) == bmask || c == nc - 1) {
+                const unsigned in_block = base + ((c == nc - 1) ? ktot - cnt[c] : cnt[c + 1] - cnt[c]);
+                worst_block = in_block > worst_block ? in_block : worst_block;
+            }
+            unsigned m = base & 0x7FFFu;
+            if (ecnt[c]) {
+                const unsigned at = ov_base + ovoff[c];
+                m = 0x8000u | (at & 0x7FFFu);
+                if (at < (unsigned)BD_OV_CAP) ov[at] = (unsigned short)(base & 0x7FFFu);
+                if (ecnt[c] == 1u && at + 2u < (unsigned)BD_OV_CAP) ov[at + 2u] = 0;  // the zero after a lone entry
+            }
+            meta[c] = (unsigned short)m;
+        }
+        // pass 2: the overflow entries themselves
+        for (int r = r0 + (int)threadIdx.x; r < r1; r += BD_THREADS) {
+            const int k = A[r];
+            const bool first = r == r0 || A[r - 1] != k, last = r + 1 == r1 || A[r + 1] != k;
+            if (last && !first) {
+                const unsigned rel = (unsigned)((long long)k - lo);
+                const unsigned c = rel >> 7, p = rel & 127u;
+                unsigned extras = (unsigned)(r - bd_lower_bound(A, r0, r, k));
+                const unsigned ne = (extras + 254u) / 255u;
+                unsigned j = atomicAdd(&ecur[c], ne);
+                const unsigned at0 = ov_base + ovoff[c] + 1u;
+                for (unsigned i = 0; i < ne; i++, j++) {
+                    const unsigned chunk = extras < 255u ? extras : 255u;
+                    extras -= chunk;
+                    const unsigned more = j + 1u < ecnt[c] ? 0x8000u : 0u;
+                    if (at0 + j < (unsigned)BD_OV_CAP) ov[at0 + j] = (unsigned short)(p | (chunk << 7) | more);
+                }
+            }
+        }
+        // the bitmap, as it lies
+        {
+            int4 *dst = reinterpret_cast<int4 *>(img + (arr == 0 ? L.bitsE : L.bitsS));
+            for (int c = threadIdx.x; c < nc; c += BD_THREADS) dst[c] = reinterpret_cast<const int4 *>(bits)[c];
+        }
+        ov_base += otot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        hdr[12] = ov_base;
+        hdr[15] = 0u;
+        atomicMax(&stats[1], ov_base);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = __shfl_down(worst_block, off, 64);
+        worst_block = o > worst_block ? o : worst_block;
+    }
+    if (lane_id() == 0) atomicMax(&stats[0], worst_block);
+}
+
+// ---------------------------------------------------------------------------
+// the same walk on CELL images ("bp_*"): count_bitmap.hpp's 8-byte cells, one unit = 2^18 coordinates
+// ---------------------------------------------------------------------------
+// Measured on configs[1]: the dense lookups cost ~400 vector instructions per 16-byte slot and the search is bound by
+// them (65 % VALU activity, 390-425 us whatever the record pipeline's depth), while the walk alone takes 225 us.  A cell
+// of count_bitmap.hpp -- {bitmap of 32 coordinates, rank of the cell's first key : 20, one duplicated coordinate's
+// (position, extra copies) : 12} -- answers a rank with ONE ds_read_b64 and ~13 instructions, duplicates included, at
+// 2 bits per coordinate: a unit of 2^18 coordinates (two buckets of configs[1]), (tile, unit) runs of ~32 records.
+// Their walk is slower (270 us: 128-byte runs) but nothing else is in its way.  A cell with two duplicated coordinates
+// (or more than 126 extra copies) is HARD: its rank is finished by a binary search in the sorted array; indexes where
+// those are not rare take the dense images, whose overflow lists hold any multiset.
+constexpr int BP_UNIT_LOG2 = 18;
+constexpr int BP_RSHIFT = 18;     // record = offset : 18 | length : 14 (16383 = escape)
+constexpr int BP_MARGIN = 16384;
+
+struct BpLayout {
+    int nce, ncs;              // cells, sentinel included
+    int cellsE, cellsS, hdr, bytes;
+};
+
+__host__ __device__ inline BpLayout bp_layout(int unit_log2)
+{
+    BpLayout L;
+    const int UW = 1 << unit_log2;
+    L.nce = (UW >> 5) + 2;
+    L.ncs = ((UW + BP_MARGIN) >> 5) + 1;
+    L.cellsE = 0;
+    L.cellsS = L.nce * 8;
+    L.hdr = (L.cellsS + L.ncs * 8 + 15) & ~15;  // header: [0] eLo, [1] sLo, [2..3] first coordinate of the unit (int64)
+    L.bytes = L.hdr + 16;
+    return L;
+}
+
+// One workgroup per unit, one array at a time (bm_image_kernel for units; the duplicate bookkeeping of a cell is a
+// bitmap of its duplicated coordinates and the number of extra copies: four words of LDS per cell instead of five).
+// stats: [0] hard cells, [1] units whose slice holds 2^20 keys or more
+__global__ __launch_bounds__(BD_THREADS) void bp_image_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted, int n,
+                                                              BmGeom g, unsigned char *__restrict__ images, unsigned *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ int s_r[2];
+    __shared__ int scan_tmp[16];
+    const int unit = blockIdx.x;
+    const int ulog = g.shift + g.f;
+    const BpLayout L = bp_layout(ulog);
+    const long long UW = 1ll << ulog;
+    const long long lo = (long long)g.cmin + (long long)unit * UW;
+    unsigned char *__restrict__ img = images + (size_t)unit * L.bytes;
+    unsigned hard = 0;
+    int r0s[2];
+    for (int arr = 0; arr < 2; arr++) {
+        const int32_t *__restrict__ A = arr == 0 ? e_sorted : s_ord;
+        const int nc = arr == 0 ? L.nce : L.ncs;
+        const long long span = arr == 0 ? UW + 1 : UW + BP_MARGIN;  // keys with rel in [0, span) belong to this image
+        unsigned *bm = reinterpret_cast<unsigned *>(dyn);
+        int *first = dyn + nc;
+        unsigned *dmask = reinterpret_cast<unsigned *>(dyn + 2 * nc), *dcnt = reinterpret_cast<unsigned *>(dyn + 3 * nc);
+        if (threadIdx.x < 2) s_r[threadIdx.x] = bm_rank_lt64(A, n, threadIdx.x == 0 ? lo : lo + span);
+        __syncthreads();
+        const int r0 = s_r[0], r1 = s_r[1], ns = r1 - r0;
+        r0s[arr] = r0;
+        for (int c = threadIdx.x; c < nc; c += BD_THREADS) {
+            bm[c] = 0u;
+            first[c] = ns;
+            dmask[c] = 0u;
+            dcnt[c] = 0u;
+        }
+        __syncthreads();
+        for (int r = r0 + (int)threadIdx.x; r < r1; r += BD_THREADS) {
+            const int k = A[r];
+            const unsigned rel = (unsigned)((long long)k - lo);
+            const int c = (int)(rel >> 5), p = (int)(rel & 31);
+            if (r == r0 || A[r - 1] != k) {
+                atomicOr(&bm[c], 1u << p);
+                atomicMin(&first[c], r - r0);
+            } else {
+                atomicAdd(&dcnt[c], 1u);
+                atomicOr(&dmask[c], 1u << p);
+            }
+        }
+        __syncthreads();
+        // suffix minimum of `first`: thread t owns chunk 1023 - t, so an exclusive scan in thread order covers the higher chunks
+        const int K = (nc + BD_THREADS - 1) / BD_THREADS;
+        const int chunk = BD_THREADS - 1 - (int)threadIdx.x;
+        const int c_lo = chunk * K < nc ? chunk * K : nc, c_hi = c_lo + K < nc ? c_lo + K : nc;
+        int run = INT_MAX;
+        for (int c = c_hi - 1; c >= c_lo; c--) {
+            run = first[c] < run ? first[c] : run;
+            first[c] = run;
+        }
+        int tot;
+        const int above = block_exclusive_scan(run, OpMin(), INT_MAX, scan_tmp, &tot);
+        uint2 *out = reinterpret_cast<uint2 *>(img + (arr == 0 ? L.cellsE : L.cellsS));
+        for (int c = c_lo; c < c_hi; c++) {
+            const int base = first[c] < above ? first[c] : above;
+            unsigned meta = (unsigned)base & 0xFFFFFu;
+            if (dcnt[c] > 0u) {
+                if (__popc(dmask[c]) == 1 && dcnt[c] < (unsigned)BM_HARD)
+                    meta |= ((unsigned)(__ffs((int)dmask[c]) - 1) << 20) | (dcnt[c] << 25);
+                else {
+                    meta |= (unsigned)BM_HARD << 25;
+                    hard++;
+                }
+            }
+            out[c] = make_uint2(bm[c], meta);
+        }
+        if (threadIdx.x == 0 && ns >= (1 << 20)) atomicAdd(&stats[1], 1u);
+        __syncthreads();
+    }
+    if (hard) atomicAdd(&stats[0], hard);
+    if (threadIdx.x == 0) {
+        unsigned *hdr = reinterpret_cast<unsigned *>(img + L.hdr);
+        hdr[0] = (unsigned)r0s[0], hdr[1] = (unsigned)r0s[1];
+        hdr[2] = (unsigned)(unsigned long long)lo, hdr[3] = (unsigned)((unsigned long long)lo >> 32);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// the run table of the flat walk
+// ---------------------------------------------------------------------------
+// The walk needs one number per (unit, tile): the first slot of the unit's first bucket in the tile's sorted order (a
+// run ends where the next unit's begins).  tbl[tile][bucket] -> unitT[unit][tile] (16 bits) and
+// unitcnt[group][unit] = queries of the unit in the 64 tiles of the group, which is what the plan cuts into work items:
+// 12.5 MB read and 6 MB written per 100 M queries where bm_transpose_kernel + sl_unit_sums_kernel moved 75 MB.
+// One workgroup per (group of 64 tiles, 64 buckets), as there.
+__global__ __launch_bounds__(256) void bd_transpose_kernel(const unsigned short *__restrict__ tbl, const BmSeg *__restrict__ segs,
+                                                           const unsigned short *__restrict__ tile_seg, int tile_log2,
+                                                           unsigned short *__restrict__ unitT /* [BM_NB >> f][ntp] */, int64_t ntp,
+                                                           unsigned *__restrict__ unitcnt /* [ngroups][BM_NB] */, const unsigned *__restrict__ gate)
+{
+    __shared__ unsigned short t[BM_GROUP_TILES][66];
+    if (gate && *gate == 0) return;
+    const int grp = blockIdx.x, b0 = blockIdx.y * 64;
+    const int f = segs[tile_seg[(int64_t)grp * BM_GROUP_TILES]].g.f;  // (a plan group never straddles two segments)
+    if (blockIdx.y == 0)  // the plan walks BM_NB columns: the ones past the last unit are empty
+        for (int u = (BM_NB >> f) + (int)threadIdx.x; u < BM_NB; u += 256) unitcnt[(int64_t)grp * BM_NB + u] = 0u;
+    {
+        const int r = threadIdx.x >> 2, q = threadIdx.x & 3;  // 4 threads per tile row, 16 buckets each
+        const int64_t tile = (int64_t)grp * BM_GROUP_TILES + r;
+        const BmSeg &sg = segs[tile_seg[tile]];
+        const bool live = tile - sg.tile0 < sg.ntiles;
+        const int64_t left = sg.nq - ((tile - sg.tile0) << tile_log2);
+        const unsigned ntile = !live ? 0u : (left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2);
+        const unsigned short *row = tbl + tile * BM_NB + b0 + 16 * q;
+        uint4 a = make_uint4(0, 0, 0, 0), c = a;
+        if (live) {
+            a = *reinterpret_cast<const uint4 *>(row);
+            c = *reinterpret_cast<const uint4 *>(row + 8);
+        }
+        const unsigned w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            t[r][16 * q + 2 * i] = (unsigned short)(w[i] & 0xffffu);
+            t[r][16 * q + 2 * i + 1] = (unsigned short)(w[i] >> 16);
+        }
+        // (a full tile's total is 1 << 16 when the tile has 65536 queries: lengths are taken modulo 2^16 below)
+        if (q == 3) t[r][64] = (unsigned short)(b0 + 64 < BM_NB ? (live ? row[16] : 0) : ntile);
+    }
+    __syncthreads();
+    {
+        // 64 >> f units in this patch, 64 tiles each: thread = (unit, 4 tiles ... ) laid out so that a unit's 64 tiles
+        // are written as whole 16-byte pieces
+        const int nu = 64 >> f;                      // units of the patch (>= 1: f <= 6)
+        const int per_unit = 256 / nu;               // threads per unit: 4 (f = 0) .. 256 (f = 6)
+        const int u = threadIdx.x / per_unit, k = threadIdx.x % per_unit;
+        const int tiles_per_thread = 64 / per_unit;  // 16 .. (for per_unit > 64 some threads idle)
+        const int c0 = u << f, c1 = c0 + (1 << f);   // bucket columns of the unit inside the patch
+        unsigned sum = 0;
+        if (tiles_per_thread >= 1) {
+            unsigned short *dst = unitT + (int64_t)((b0 >> f) + u) * ntp + (int64_t)grp * BM_GROUP_TILES + k * tiles_per_thread;
+            for (int i = 0; i < tiles_per_thread; i++) {
+                const int r = k * tiles_per_thread + i;
+                dst[i] = t[r][c0];
+                sum += (unsigned)(unsigned short)(t[r][c1] - t[r][c0]);
+            }
+        } else if (k < 64) {  // more threads than tiles: one tile per thread
+            unitT[(int64_t)((b0 >> f) + u) * ntp + (int64_t)grp * BM_GROUP_TILES + k] = t[k][c0];
+            sum = (unsigned)(unsigned short)(t[k][c1] - t[k][c0]);
+        }
+        // per-unit sum over its threads (per_unit is a power of two, 4 .. 256)
+        __shared__ unsigned s_sum[256];
+        s_sum[threadIdx.x] = sum;
+        __syncthreads();
+        if (k == 0) {
+            unsigned tot = 0;
+            for (int i = 0; i < per_unit; i++) tot += s_sum[threadIdx.x + i];
+            unitcnt[(int64_t)grp * BM_NB + (b0 >> f) + u] = tot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// search
+// ---------------------------------------------------------------------------
+typedef unsigned bd_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned bd_v2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const bd_v4u *lds_v4u_p;
+typedef __attribute__((address_space(3))) const unsigned *lds_u32_p;
+
+struct BdImage {
+    lds_v4u_p bitsE, bitsS;
+    lds_u16_p metaE, metaS, ov;
+    lds_u32_p qbE, qbS;
+    int bias;          // sLo - eLo
+    unsigned off_mask;  // offsets of a record: the unit's width - 1
+    // cell images (FMT 1)
+    lds_cell_p cE, cS;
+    int eLo, sLo;
+    long long lo;
+    const int32_t *s_ord, *e_sorted;
+};
+
+// FMT 1: the count of one record from a unit's cell image (bm_count_record for units; 16 bits, 0xFFFF = ask the index again)
+__device__ __forceinline__ unsigned bp_count_record(const BdImage &I, unsigned rec)
+{
+    const unsigned off = rec & I.off_mask, len = rec >> BP_RSHIFT;
+    const unsigned relE = off + 1u, relS = off + len;
+    bool odd = false;
+    const int rE = bm_cell_rank(I.cE, relE, odd);
+    const int rS = bm_cell_rank(I.cS, relS, odd);
+    unsigned c = (unsigned)(I.bias + (rS - rE));
+    if (odd) {  // a hard cell (rare: the index qualifies only while they are)
+        bool e_hard = false, s_hard = false;
+        int hE = bm_cell_rank(I.cE, relE, e_hard), hS = bm_cell_rank(I.cS, relS, s_hard);
+        if (e_hard) hE = bm_hard_rank(I.cE, relE, I.e_sorted, I.eLo, I.lo);
+        if (s_hard) hS = bm_hard_rank(I.cS, relS, I.s_ord, I.sLo, I.lo);
+        c = (unsigned)(I.bias + (hS - hE));
+    }
+    c = c < 0xFFFFu ? c : 0xFFFFu;
+    return rec == BM_REC_ESC ? 0xFFFFu : c;
+}
+
+// One lookup in three steps, so that a slot's eight lookups can keep their LDS reads in flight together (a lookup
+// that reads, waits, computes and branches before the next one starts leaves the CU's four waves per SIMD waiting on
+// LDS latency eight times per slot: measured 67 % VALU activity at 430 wave-instructions per slot).
+//   1. bd_look_cell:     the cell's bits and its 16-bit meta word requested
+//   2. bd_look_overflow: {ov[i], ov[i+1], ov[i+2]} requested, i = 0 (three zeros) for a plain cell
+//   3. bd_look_rank:     popcount below the position + base + the copies of up to two duplicated coordinates below it;
+//                        a third entry -- three duplicated coordinates in one 128-coordinate cell -- takes a loop
+// QB: the image's ranks are relative to blocks of 1024 cells (a table read per lookup); otherwise one block spans the
+// unit (fewer than 2^15 keys per slice: configs[1] has 22 000) and a plain cell's 16 bits are its rank in the unit.
+struct BdLook {
+    bd_v4u w;
+    unsigned m, q;
+    unsigned ob, e1, e2;
+    unsigned at;  // index of ov[i]
+};
+
+template <bool QB>
+__device__ __forceinline__ void bd_look_cell(BdLook &K, lds_v4u_p bits, lds_u16_p meta, lds_u32_p qb, unsigned rel)
+{
+    const unsigned c = rel >> 7;
+    K.w = bits[c];
+    K.m = meta[c];
+    K.q = QB ? qb[c >> 10] : 0u;
+}
+
+__device__ __forceinline__ void bd_look_overflow(BdLook &K, lds_u16_p ov)
+{
+    const unsigned hard = (unsigned)((int)(K.m << 16) >> 31);  // all ones when bit 15 of the meta word is set
+    K.at = K.m & 0x7FFFu & hard;
+    K.ob = ov[K.at], K.e1 = ov[K.at + 1u], K.e2 = ov[K.at + 2u];
+}
+
+__device__ __forceinline__ int bd_look_rank(const BdLook &K, lds_u16_p ov, unsigned rel)
+{
+    const unsigned p = rel & 127u;
+    const unsigned long long lo = (unsigned long long)K.w.x | ((unsigned long long)K.w.y << 32);
+    const unsigned long long hi = (unsigned long long)K.w.z | ((unsigned long long)K.w.w << 32);
+    const bool up = p >= 64u;
+    const unsigned long long below = (1ull << (p & 63u)) - 1ull;
+    int r = __popcll((up ? hi : lo) & below) + (up ? __popcll(lo) : 0);
+    const unsigned base = K.at ? K.ob : K.m;  // (a plain cell has at = 0; a list never starts at 0)
+    r += (K.e1 & 127u) < p ? (int)((K.e1 >> 7) & 255u) : 0;
+    r += (K.e2 & 127u) < p ? (int)((K.e2 >> 7) & 255u) : 0;
+    if (K.e2 & 0x8000u) {  // rare: more than two entries
+        unsigned i = K.at + 2u, e;
+        do {
+            e = ov[++i];
+            r += (e & 127u) < p ? (int)((e >> 7) & 255u) : 0;
+        } while (e & 0x8000u);
+    }
+    return (int)(K.q + base) + r;
+}
+
+// The same lookup in one piece: read, wait, compute, and a branch for the cell with duplicated coordinates (taken by
+// some lane of the wave in nearly every lookup).  Fewer registers than the three-step form: deeper record pipelines fit.
+template <bool QB>
+__device__ __forceinline__ int bd_rank(lds_v4u_p bits, lds_u16_p meta, lds_u32_p qb, lds_u16_p ov, unsigned rel)
+{
+    const unsigned c = rel >> 7, p = rel & 127u;
+    const bd_v4u w = bits[c];
+    unsigned m = meta[c];
+    unsigned q = 0u;
+    if (QB) q = qb[c >> 10];
+    const unsigned long long lo = (unsigned long long)w.x | ((unsigned long long)w.y << 32);
+    const unsigned long long hi = (unsigned long long)w.z | ((unsigned long long)w.w << 32);
+    const bool up = p >= 64u;
+    const unsigned long long below = (1ull << (p & 63u)) - 1ull;
+    int r = __popcll((up ? hi : lo) & below) + (up ? __popcll(lo) : 0);
+    if (m & 0x8000u) {
+        unsigned i = m & 0x7FFFu;
+        m = ov[i];
+        unsigned e;
+        do {
+            e = ov[++i];
+            r += (e & 127u) < p ? (int)((e >> 7) & 255u) : 0;
+        } while (e & 0x8000u);
+    }
+    return (int)(q + m) + r;
+}
+
+// 16 bits of count: 0xFFFF = "ask the index again" (an escape record, or a count that does not fit)
+__device__ __forceinline__ unsigned bd_count16(int bias, int rS, int rE, unsigned rec)
+{
+    unsigned c = (unsigned)(bias + (rS - rE));
+    c = c < 0xFFFFu ? c : 0xFFFFu;
+    return rec == BM_REC_ESC ? 0xFFFFu : c;
+}
+
+// four records of one aligned 16-byte slot -> four 16-bit counts at the same positions of the count array;
+// `valid` bit j = record j belongs to this workgroup's run (the others are a neighbouring unit's: looked up all the
+// same -- any 32-bit word is a safe argument, the offset is masked to the unit and the length cannot leave the margin --
+// and not stored)
+// EXP (diagnostics, ivl.bd_exp; wrong results): 1 = no lookups at all -- the price of the walk and of its memory traffic alone
+// EXP 2 = the lookups one after the other (bd_rank) instead of batched
+// FMT: 0 = dense unit image, 1 = cell image
+template <int FMT, bool QB, int EXP>
+__device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short *__restrict__ out, unsigned idx4, unsigned valid, bd_v4u v)
+{
+    if (valid == 0u) return;
+    const unsigned rec[4] = {v.x, v.y, v.z, v.w};
+    unsigned c[4];
+    if (EXP == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = rec[j] & 0xffu;
+    } else if (FMT == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = bp_count_record(I, rec[j]);
+    } else if (EXP == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned off = rec[j] & I.off_mask;
+            const int rE = bd_rank<QB>(I.bitsE, I.metaE, I.qbE, I.ov, off + 1u);
+            const int rS = bd_rank<QB>(I.bitsS, I.metaS, I.qbS, I.ov, off + (rec[j] >> BD_RSHIFT));
+            c[j] = bd_count16(I.bias, rS, rE, rec[j]);
+        }
+    } else {
+        unsigned relE[4], relS[4];
+        BdLook E[4], S[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned off = rec[j] & I.off_mask;
+            relE[j] = off + 1u, relS[j] = off + (rec[j] >> BD_RSHIFT);
+            bd_look_cell<QB>(E[j], I.bitsE, I.metaE, I.qbE, relE[j]);
+            bd_look_cell<QB>(S[j], I.bitsS, I.metaS, I.qbS, relS[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bd_look_overflow(E[j], I.ov);
+            bd_look_overflow(S[j], I.ov);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = bd_count16(I.bias, bd_look_rank(S[j], I.ov, relS[j]), bd_look_rank(E[j], I.ov, relE[j]), rec[j]);
+    }
+    unsigned short *p = out + 4 * (size_t)idx4;
+    if (valid == 15u) {
+        bd_v2u o;
+        o.x = c[0] | (c[1] << 16), o.y = c[2] | (c[3] << 16);
+        *reinterpret_cast<bd_v2u *>(p) = o;
+    } else {
+        if (valid & 1u) p[0] = (unsigned short)c[0];
+        if (valid & 2u) p[1] = (unsigned short)c[1];
+        if (valid & 4u) p[2] = (unsigned short)c[2];
+        if (valid & 8u) p[3] = (unsigned short)c[3];
+    }
+}
+
+// records [ra, re) of a tile against the four records of the 16-byte slot that starts at record f0 (the slot meets the run)
+__device__ __forceinline__ unsigned bd_valid_mask(unsigned f0, unsigned ra, unsigned re)
+{
+    const int lo = max((int)(ra - f0), 0), hi = min((int)(re - f0), 4);
+    return ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+}
+
+// DEPTH: passes whose records are in flight per wave.  The walk alone (no lookups) moves 0.72 GB in 225 us with two:
+// neither bandwidth (3.2 TB/s, no read amplification: FETCH_SIZE = the records once) nor instructions, but 2 KB per
+// wave in flight against ~2 us of loaded HBM latency.
+template <int FMT, bool QB, int EXP = 0, int DEPTH = 2>
+__global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
+                                                               const int *__restrict__ n_items, const unsigned short *__restrict__ unitT, int64_t ntp,
+                                                               const unsigned *__restrict__ recs /* tile-sorted records */,
+                                                               unsigned short *__restrict__ out /* their counts, same order */, int tile_log2,
+                                                               const unsigned *__restrict__ gate)
+{
+    if (gate && *gate == 0) return;
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ uint2 s_long[BD_LONG_CAP];  // {first record, length} of the long runs met during the walk
+    __shared__ int s_nlong, s_next;
+    const int nit = *n_items;
+    const int per_xcd = (nit + 7) >> 3;
+    const int slot = (int)(blockIdx.x >> 3);
+    const int it = (int)(blockIdx.x & 7) * per_xcd + slot;  // neighbouring units on one XCD (see bm_search_kernel)
+    if (slot >= per_xcd || it >= nit) return;
+    const int4 item = items[it];
+    const int unit = item.x & 0xffff, t0 = item.y, t1 = item.z;
+    const BmSeg &sg = segs[item.x >> 16];
+    const BmGeom g = sg.g;
+    const BdLayout L = bd_layout(g.shift + g.f);
+    const BpLayout LP = bp_layout(g.shift + g.f);
+    const int image_bytes = FMT == 1 ? LP.bytes : L.bytes;
+    const bool open_end = ((unit + 1) << g.f) >= BM_NB;  // the unit reaches the end of the grid: its runs end where the tiles end
+    const unsigned short *__restrict__ runs0 = unitT + (int64_t)unit * ntp;
+    const unsigned short *__restrict__ runs1 = unitT + (int64_t)(open_end ? unit : unit + 1) * ntp;
+    const int64_t seg_t0 = sg.tile0, seg_nq = sg.nq;
+    const int lane = lane_id();
+    if (threadIdx.x == 0) s_nlong = 0, s_next = 64 * (BD_THREADS / 64);  // (every wave starts with the batch of its number)
+    // this wave's first 64 tiles: their runs travel with the image
+    int tb = t0 + 64 * (int)(threadIdx.x >> 6);
+    unsigned a_nx, e_nx;
+    auto load_runs = [&](int tbase) {
+        const int t = tbase + lane;
+        const int tc = t < t1 ? t : t0;  // a valid address: no branch around the loads
+        const unsigned a = runs0[tc];
+        unsigned e = runs1[tc];
+        if (open_end) {
+            const int64_t left = seg_nq - (((int64_t)tc - seg_t0) << tile_log2);
+            e = left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2;
+        }
+        a_nx = t < t1 ? a : 0u;
+        e_nx = t < t1 ? e : 0u;
+    };
+    load_runs(tb);
+    {
+        // the image (streams through L2 once: non-temporal loads); every load of a lane issued before its first LDS store
+        const bm_v4i *src = reinterpret_cast<const bm_v4i *>((FMT == 1 ? sg.pimages : sg.dimages) + (size_t)unit * image_bytes);
+        const int n4 = image_bytes >> 4;
+        constexpr int SWEEPS = 5;
+        for (int i0 = 0; i0 < n4; i0 += SWEEPS * BD_THREADS) {
+            bm_v4i v[SWEEPS];
+#pragma unroll
+            for (int k = 0; k < SWEEPS; k++) {
+                const int i = i0 + k * BD_THREADS + (int)threadIdx.x;
+                v[k] = __builtin_nontemporal_load(src + (i < n4 ? i : n4 - 1));
+            }
+#pragma unroll
+            for (int k = 0; k < SWEEPS; k++) {
+                const int i = i0 + k * BD_THREADS + (int)threadIdx.x;
+                if (i < n4) reinterpret_cast<bm_v4i *>(dyn)[i] = v[k];
+            }
+        }
+    }
+    __syncthreads();
+    BdImage I;
+    if (FMT == 1) {
+        unsigned char *base = reinterpret_cast<unsigned char *>(dyn);
+        I.cE = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsE);
+        I.cS = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsS);
+        const unsigned *hdr = reinterpret_cast<const unsigned *>(base + LP.hdr);
+        I.eLo = (int)hdr[0], I.sLo = (int)hdr[1];
+        I.bias = I.sLo - I.eLo;
+        I.lo = (long long)((unsigned long long)hdr[2] | ((unsigned long long)hdr[3] << 32));
+        I.s_ord = sg.ix.s_ord, I.e_sorted = sg.e_sorted;
+        I.off_mask = (1u << (g.shift + g.f)) - 1u;
+    } else {
+        unsigned char *base = reinterpret_cast<unsigned char *>(dyn);
+        I.bitsE = (lds_v4u_p) reinterpret_cast<bd_v4u *>(base + L.bitsE);
+        I.bitsS = (lds_v4u_p) reinterpret_cast<bd_v4u *>(base + L.bitsS);
+        I.metaE = (lds_u16_p) reinterpret_cast<unsigned short *>(base + L.metaE);
+        I.metaS = (lds_u16_p) reinterpret_cast<unsigned short *>(base + L.metaS);
+        I.ov = (lds_u16_p) reinterpret_cast<unsigned short *>(base + L.ov);
+        I.qbE = (lds_u32_p) reinterpret_cast<unsigned *>(base + L.hdr);
+        I.qbS = I.qbE + BD_HDR_QS;
+        const unsigned *hdr = reinterpret_cast<const unsigned *>(base + L.hdr);
+        I.bias = (int)hdr[14] - (int)hdr[13];
+        I.off_mask = (1u << (g.shift + g.f)) - 1u;
+    }
+    const unsigned slot_mask = (1u << (tile_log2 - 2)) - 1u;  // 16-byte slots of a tile
+    while (tb < t1) {
+        const int t = tb + lane;
+        const unsigned a = a_nx, e = e_nx;
+        // the batch after this one: its number from the workgroup's counter, its runs requested now
+        int tn = 0;
+        if (lane == 0) tn = atomicAdd(&s_next, 64);
+        tn = t0 + __builtin_amdgcn_readfirstlane(tn);
+        load_runs(tn);
+        unsigned n4 = e > a ? ((e + 3u) >> 2) - (a >> 2) : 0u;  // 16-byte slots that hold the run
+        if (n4 > (unsigned)BD_LONG_SLOTS) {  // sorted / clumped input: left to the whole workgroup
+            const int k = atomicAdd(&s_nlong, 1);
+            if (k < BD_LONG_CAP) {
+                s_long[k] = make_uint2(((unsigned)t << tile_log2) + a, e - a);
+                n4 = 0u;
+            }  // (a full list: the wave walks the run itself, exactness never depends on it)
+        }
+        const unsigned incl = wave_inclusive_scan(n4, OpSum());
+        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        // slot s of the flat sequence lies in run r = #{runs that end at or before s}; its int4 is at delta[r] + s
+        const unsigned delta = (((unsigned)t << (tile_log2 - 2)) + (a >> 2)) - (incl - n4);
+        const unsigned ae = a | (e << 15);  // a < 2^15, e <= 2^15
+        bd_v4u ring_v[DEPTH];
+        unsigned ring_idx[DEPTH], ring_valid[DEPTH];
+        auto prep = [&](unsigned s0, unsigned &idx4, unsigned &valid, bd_v4u &v) {
+            const unsigned s = s0 + (unsigned)lane;
+            int k = (int)__popcll(__ballot(incl <= s0));  // runs that end at or before the pass's first slot
+            unsigned r = (unsigned)k;
+            for (; k < 63; k++) {
+                const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)incl, k);
+                if (c > s0 + 63u) break;
+                r += s >= c ? 1u : 0u;
+            }
+            r = r < 63u ? r : 63u;
+            const unsigned d = (unsigned)__shfl((int)delta, (int)r, 64), x = (unsigned)__shfl((int)ae, (int)r, 64);
+            const bool active = s < total;
+            idx4 = active ? d + s : 0u;
+            valid = active ? bd_valid_mask((idx4 & slot_mask) << 2, x & 0x7fffu, x >> 15) : 0u;
+            v = reinterpret_cast<const bd_v4u *>(recs)[idx4];
+        };
+        // DEPTH passes at a time: their records requested together, then answered one after the other (the compiler's
+        // wait counts only work out inside one iteration: with a ring carried around the loop it drains the memory
+        // pipe -- loads AND the stores of the pass before -- in front of every pass)
+        for (unsigned s0 = 0; s0 < total; s0 += 64u * DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * d, ring_idx[d], ring_valid[d], ring_v[d]);
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
+        }
+        tb = tn;
+    }
+    __syncthreads();
+    {
+        const int nl = s_nlong < BD_LONG_CAP ? s_nlong : BD_LONG_CAP;
+        for (int k = 0; k < nl; k++) {
+            const uint2 lr = s_long[k];
+            const unsigned first = lr.x, end = lr.x + lr.y;
+            const unsigned q0 = first >> 2, nq4 = ((end + 3u) >> 2) - q0;
+            for (unsigned q = threadIdx.x; q < nq4; q += BD_THREADS) {
+                const unsigned idx4 = q0 + q;
+                bd_answer_slot<FMT, QB, EXP>(I, out, idx4, bd_valid_mask(4u * idx4, first, end), reinterpret_cast<const bd_v4u *>(recs)[idx4]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// counts back into query order
+// ---------------------------------------------------------------------------
+// bm_unpermute_kernel for 16-bit counts: half the bytes to read, half the LDS (two workgroups share a CU).
+// 0xFFFF = recompute from the sealed index (escape records, counts of 65535 and more).
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned short *__restrict__ cnt /* tile-sorted */,
+                                                               const unsigned short *__restrict__ slots, const BmSeg *__restrict__ segs,
+                                                               const unsigned short *__restrict__ tile_seg,
+                                                               unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS], may be NULL */,
+                                                               const unsigned *__restrict__ gate)
+{
+    constexpr int TILE = THREADS * ITEMS;
+    static_assert(ITEMS % 8 == 0, "whole 16-byte vectors of 16-bit counts per thread");
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    if (gate && *gate == 0) return;
+    unsigned short *vals = reinterpret_cast<unsigned short *>(dyn);  // [TILE]
+    __shared__ long long red[THREADS / 64];
+    const int64_t tile = blockIdx.x;
+    const int seg_id = tile_seg[tile];
+    const BmSeg &sg = segs[seg_id];
+    const int64_t ltile = tile - sg.tile0;
+    if (ltile >= sg.ntiles) return;  // padding up to the next plan group
+    const IndexDev ix = sg.ix;
+    const BmGeom g = sg.g;
+    const int32_t *__restrict__ e_sorted = sg.e_sorted;
+    const int32_t *__restrict__ qs_arr = sg.qs + ltile * TILE, *__restrict__ qe_arr = sg.qe + ltile * TILE;  // escapes only
+    int32_t *__restrict__ out = sg.counts + ltile * TILE;
+    cnt += tile * TILE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
+    const int64_t nq = sg.nq - ltile * TILE;
+    const int n = (int)(nq < TILE ? nq : TILE);
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(cnt);
+        if (n == TILE) {
+            int4 v[ITEMS / 8];
+#pragma unroll
+            for (int j = 0; j < ITEMS / 8; j++) v[j] = src[j * THREADS + threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < ITEMS / 8; j++) reinterpret_cast<int4 *>(vals)[j * THREADS + threadIdx.x] = v[j];
+        } else {
+            const int n8 = (n + 7) >> 3;  // (the scratch is padded to whole tiles)
+            for (int i = threadIdx.x; i < n8; i += THREADS) reinterpret_cast<int4 *>(vals)[i] = src[i];
+        }
+    }
+    __syncthreads();
+    long long acc = 0;
+    if (n == TILE) {
+        const uint2 *l4 = reinterpret_cast<const uint2 *>(slots);
+        int4 *o4 = reinterpret_cast<int4 *>(out);
+        uint2 sl[ITEMS / 4];
+#pragma unroll
+        for (int j = 0; j < ITEMS / 4; j++) sl[j] = l4[j * THREADS + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < ITEMS / 4; j++) {
+            unsigned c[4] = {vals[sl[j].x & 0xffffu], vals[sl[j].x >> 16], vals[sl[j].y & 0xffffu], vals[sl[j].y >> 16]};
+            if (c[0] == 0xFFFFu || c[1] == 0xFFFFu || c[2] == 0xFFFFu || c[3] == 0xFFFFu) {
+                const int64_t k0 = 4 * (int64_t)(j * THREADS + threadIdx.x);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (c[u] == 0xFFFFu) c[u] = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k0 + u], qe_arr[k0 + u]);
+            }
+            o4[j * THREADS + threadIdx.x] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);
+            acc += (long long)c[0] + c[1] + c[2] + c[3];
+        }
+    } else {
+        for (int k = threadIdx.x; k < n; k += THREADS) {
+            unsigned c = vals[slots[k]];
+            if (c == 0xFFFFu) c = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k], qe_arr[k]);
+            out[k] = (int)c;
+            acc += c;
+        }
+    }
+    if (total_slots) block_accumulate_i64(acc, red, total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)));
+}
+
+}  // namespace bxmi

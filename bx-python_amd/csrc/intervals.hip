@@ -1339,6 +1339,7 @@ __device__ __forceinline__ int count_one_global(const IndexDev &ix, const int32_
 }  // namespace bxmi
 #include "count_bitmap.hpp"
 #include "count_slices.hpp"
+#include "count_dense.hpp"
 namespace bxmi {
 
 // ---- partitioned find: window + count per query in bucket order, offsets carried to bucket order ----
@@ -2126,6 +2127,14 @@ static int64_t g_opt_find_pairs = 1;   // sorted find(): the fill reads (end, in
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
+static int64_t g_opt_flat = -1;       // the flat 16-byte walk on cell images of 2^18-coordinate units (count_dense.hpp, bp_*): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
+static int64_t g_opt_dense = -1;      // search stage on dense unit images (count_dense.hpp): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
+static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
+static int64_t g_opt_bd_nt = 1;       // 1 = non-temporal image loads in the dense search kernel
+static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
+static int64_t g_opt_bd_depth = 4;    // passes of records in flight per wave of the dense search kernel (2, 3, 4 or 6)
+static int64_t g_opt_bd_exp = 0;      // diagnostics only (wrong results): 1 = the dense search kernel without its lookups
+static int64_t g_opt_bd_unit_log2 = BD_UNIT_LOG2;  // coordinates per unit of the dense images (read when an index is prepared): 19, or less for shorter runs (A/B)
 
 int ivl_set_option(const char *key, int64_t value)
 {
@@ -2233,6 +2242,38 @@ int ivl_set_option(const char *key, int64_t value)
         g_opt_bm_hard_ppm = value;
         return 1;
     }
+    if (!strcmp(key, "ivl.flat")) {
+        g_opt_flat = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.dense")) {
+        g_opt_dense = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bd_chunk")) {
+        g_opt_bd_chunk = value < 0 ? 0 : value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bd_nt")) {
+        g_opt_bd_nt = value != 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bd_blocks")) {
+        g_opt_bd_blocks = value != 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bd_depth")) {
+        g_opt_bd_depth = value == 2 || value == 3 || value == 6 || value == 8 ? value : 4;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bd_exp")) {
+        g_opt_bd_exp = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bd_unit_log2")) {
+        g_opt_bd_unit_log2 = value < 12 || value > BD_UNIT_LOG2 ? BD_UNIT_LOG2 : value;
+        return 1;
+    }
     return 0;
 }
 
@@ -2271,6 +2312,16 @@ struct bxmi_ivl {
     int sl_state = 0;            // 0 = not decided yet, 1 = boundary table built and a single bucket's keys fit the LDS, -1 = they do not
     unsigned sl_need[SL_MAX_F + 1] = {0, 0, 0, 0, 0, 0, 0};  // most keys a unit of 2^f buckets stages
     DevBuf sl_meta, sl_stats, sl_unitcnt, sl_cnt, sl_loff, sl_hits, sl_eid;
+    // dense unit images (count_dense.hpp)
+    int bd_state = 0;            // 0 = not decided yet, 1 = images built and the index qualifies, -1 = it does not
+    unsigned bd_worst[2] = {0, 0};  // what bd_image_kernel reported: most keys of one block, most overflow entries of one unit
+    BmGeom bd_geom{0, 0, 0, 0, 0, 0, 0, BD_RSHIFT, 0};
+    int bp_state = 0;            // cell images of units for the flat walk: 0 = not decided yet, 1 = built and the index qualifies, -1 = it does not
+    int64_t bp_hard_cells = 0;
+    BmGeom bp_geom{0, 0, 0, 0, 0, 0, 0, BP_RSHIFT, 0};
+    DevBuf bp_images, bp_stats;
+    bool bd_blocks = false;      // the images' ranks are relative to blocks of 1024 cells (more than 32767 keys in some unit's slice)
+    DevBuf bd_images, bd_stats, bd_cnt16, bd_unitT;
     bool sl_eid_ready = false;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][ONE_CAP hits][completion word:int64]
     unsigned long long one_seq = 0;
@@ -2561,6 +2612,86 @@ static int bm_prepare_index(bxmi_ivl *h, hipStream_t st)
     return BXMI_OK;
 }
 
+// Cell images of 2^18-coordinate units for the flat walk (count_dense.hpp, bp_*): built once per sealed index.
+static int bp_prepare_index(bxmi_ivl *h, hipStream_t st)
+{
+    h->bp_state = -1;
+    const int shift = h->geom.shift;
+    if (h->has_reversed || h->n < 4096 || shift > BP_UNIT_LOG2 || shift < BM_MIN_SHIFT) return BXMI_OK;
+    BmGeom g;
+    g.cmin = h->geom.cmin;
+    g.cmax = h->cmax;
+    g.shift = shift;
+    const int f = BP_UNIT_LOG2 - shift;
+    g.f = f > BD_MAX_F ? BD_MAX_F : f;
+    g.rshift = BP_RSHIFT;
+    g.dshift = 0;
+    const BpLayout L = bp_layout(g.shift + g.f);
+    g.nce = L.nce, g.ncs = L.ncs;
+    g.stride = L.bytes >> 4;
+    const int units = BM_NB >> g.f;
+    BXMI_TRY(h->bp_images.reserve((size_t)units * L.bytes));
+    BXMI_TRY(h->bp_stats.reserve(64));
+    BXMI_HIP(hipMemsetAsync(h->bp_stats.p, 0, 64, st));
+    const size_t lds = (size_t)4 * L.ncs * sizeof(int32_t);
+    BXMI_TRY(allow_big_lds(bp_image_kernel, lds));
+    hipLaunchKernelGGL(bp_image_kernel, dim3((unsigned)units), dim3(BD_THREADS), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n, g,
+                       h->bp_images.as<unsigned char>(), h->bp_stats.as<unsigned>());
+    BXMI_LAUNCH_CHECK();
+    unsigned stats[2] = {0, 0};
+    BXMI_HIP(hipMemcpyAsync(stats, h->bp_stats.p, sizeof(stats), hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    h->bp_geom = g;
+    h->bp_hard_cells = stats[0];
+    // cells that queries can land in: the span of the index, twice (ends and starts)
+    const int64_t cells = 2 * ((((int64_t)h->cmax - (int64_t)h->geom.cmin) >> 5) + 1);
+    if (stats[1] == 0 && (int64_t)stats[0] * 1000000 <= cells * g_opt_bm_hard_ppm) h->bp_state = 1;
+    return BXMI_OK;
+}
+
+// Dense unit images (count_dense.hpp): built once per sealed index; the kernel reports whether the index fits the format.
+static int bd_prepare_index(bxmi_ivl *h, hipStream_t st)
+{
+    h->bd_state = -1;
+    const int shift = h->geom.shift;
+    if (h->has_reversed || h->n < 4096 || shift > BD_MAX_SHIFT || shift < BM_MIN_SHIFT) return BXMI_OK;
+    BmGeom g;
+    g.cmin = h->geom.cmin;
+    g.cmax = h->cmax;
+    g.shift = shift;
+    int f = (int)g_opt_bd_unit_log2 - shift;
+    g.f = f < 0 ? 0 : (f > BD_MAX_F ? BD_MAX_F : f);
+    g.rshift = BD_RSHIFT;
+    g.dshift = 0;
+    const BdLayout L = bd_layout(g.shift + g.f);
+    g.nce = L.nce, g.ncs = L.ncs;
+    g.stride = L.bytes >> 4;
+    const int units = BM_NB >> g.f;
+    BXMI_TRY(h->bd_images.reserve((size_t)units * L.bytes));
+    BXMI_TRY(h->bd_stats.reserve(64));
+    BXMI_HIP(hipMemsetAsync(h->bd_stats.p, 0, 64, st));
+    const size_t lds = (size_t)8 * L.ncs * sizeof(int32_t);
+    BXMI_TRY(allow_big_lds(bd_image_kernel, lds));
+    h->bd_geom = g;
+    // ranks relative to the whole unit when every slice holds fewer than 2^15 keys (no table read per lookup), else
+    // relative to blocks of 1024 cells
+    for (int bshift = g_opt_bd_blocks ? 10 : 13; bshift >= 10; bshift -= 3) {
+        BXMI_HIP(hipMemsetAsync(h->bd_stats.p, 0, 64, st));
+        hipLaunchKernelGGL(bd_image_kernel, dim3((unsigned)units), dim3(BD_THREADS), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n,
+                           g, bshift, h->bd_images.as<unsigned char>(), h->bd_stats.as<unsigned>());
+        BXMI_LAUNCH_CHECK();
+        BXMI_HIP(hipMemcpyAsync(h->bd_worst, h->bd_stats.p, sizeof(h->bd_worst), hipMemcpyDeviceToHost, st));
+        BXMI_HIP(hipStreamSynchronize(st));
+        h->bd_blocks = bshift == 10;
+        if (h->bd_worst[1] > (unsigned)BD_OV_CAP) break;  // too many duplicated coordinates: blocks do not help
+        if (h->bd_worst[0] <= 32767u) {
+            h->bd_state = 1;
+            break;
+        }
+    }
+    return BXMI_OK;
+}
+
 // Slice search: the ranks at every bucket boundary, and how many keys a unit of 2^f buckets would have to stage.
 static int sl_prepare_index(bxmi_ivl *h, hipStream_t st)
 {
@@ -2766,11 +2897,57 @@ static int sl_launch_search_flat(const BmLaunch &L, unsigned grid, hipStream_t s
     return BXMI_OK;
 }
 
-// `slices`: the search stage stages key slices (count_slices.hpp) instead of bucket images; every index of the batch
-// must have qualified for the chosen kind.
-static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
-                             int32_t *const *counts, int64_t *const *totals_dev, hipStream_t st, bool slices = false, BmFindCtx *fx = nullptr)
+template <int FMT, bool QB, int EXP, int DEPTH>
+static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
+    bxmi_ivl *h = L.owner;
+    BXMI_TRY(allow_big_lds((bd_search_kernel<FMT, QB, EXP, DEPTH>), L.search_lds));
+    hipLaunchKernelGGL((bd_search_kernel<FMT, QB, EXP, DEPTH>), dim3(grid), dim3(BD_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+                       h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(), h->bd_cnt16.as<unsigned short>(),
+                       L.tile_log2, L.gate);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+template <int FMT, bool QB, int EXP>
+static int bd_launch_search_d(const BmLaunch &L, unsigned grid, hipStream_t st)
+{
+    switch (g_opt_bd_depth) {
+    case 2: return bd_launch_search_t<FMT, QB, EXP, 2>(L, grid, st);
+    case 3: return bd_launch_search_t<FMT, QB, EXP, 3>(L, grid, st);
+    case 6: return bd_launch_search_t<FMT, QB, EXP, 6>(L, grid, st);
+    case 8: return bd_launch_search_t<FMT, QB, EXP, 8>(L, grid, st);
+    default: return bd_launch_search_t<FMT, QB, EXP, 4>(L, grid, st);
+    }
+}
+
+static int bd_launch_search(const BmLaunch &L, unsigned grid, bool cells, bool blocks, hipStream_t st)
+{
+    if (cells) return g_opt_bd_exp == 1 ? bd_launch_search_d<1, false, 1>(L, grid, st) : bd_launch_search_d<1, false, 0>(L, grid, st);
+    if (g_opt_bd_exp == 1) return blocks ? bd_launch_search_d<0, true, 1>(L, grid, st) : bd_launch_search_d<0, false, 1>(L, grid, st);
+    if (g_opt_bd_exp == 2) return blocks ? bd_launch_search_d<0, true, 2>(L, grid, st) : bd_launch_search_d<0, false, 2>(L, grid, st);
+    return blocks ? bd_launch_search_d<0, true, 0>(L, grid, st) : bd_launch_search_d<0, false, 0>(L, grid, st);
+}
+
+template <int THREADS, int ITEMS>
+static int bd_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st)
+{
+    bxmi_ivl *h = L.owner;
+    const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned short);
+    BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS>), lds));
+    hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
+                       h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+// `kind`: what a search workgroup keeps in LDS -- 1 = bucket images (count_bitmap.hpp), 2 = key slices
+// (count_slices.hpp), 3 = dense unit images, 4 = cell images of units (both count_dense.hpp: the flat walk, 16-bit
+// counts out of place); every index of the batch must have qualified for it.
+static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
+                             int32_t *const *counts, int64_t *const *totals_dev, hipStream_t st, int kind = 1, BmFindCtx *fx = nullptr)
+{
+    const bool slices = kind == 2, cells = kind == 4, dense = kind == 3 || cells /* the flat walk */, units = slices || dense;
     bxmi_ivl *h = hs[0];
     int64_t nq_all = 0;
     for (int i = 0; i < n; i++) nq_all += nq[i];
@@ -2786,15 +2963,20 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     int64_t ntp = 0;
     size_t max_stride = 0, sl_lds = 0;
     int64_t sl_run = INT64_MAX;  // shortest expected (tile, unit) run of the batch
-    bool any_total = false;
+    bool any_total = false, any_blocks = false;
     for (int i = 0; i < n; i++) {
         BmSeg &sg = segs[(size_t)i];
+        any_blocks |= kind == 3 && hs[i]->bd_blocks;
         if (slices) {
             size_t lds = 0;
             int64_t run_len = 0;
             sg.g = sl_geom(hs[i], tile, &lds, &run_len);
             if (lds > sl_lds) sl_lds = lds;
             if (run_len < sl_run) sl_run = run_len;
+        } else if (cells) {
+            sg.g = hs[i]->bp_geom;
+        } else if (dense) {
+            sg.g = hs[i]->bd_geom;
         } else {
             sg.g = hs[i]->bm_geom;
         }
@@ -2803,6 +2985,8 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         sg.tile0 = ntp;
         sg.ntiles = div_up(nq[i], tile);
         sg.images = hs[i]->bm_images.as<uint2>();
+        sg.dimages = hs[i]->bd_images.as<unsigned char>();
+        sg.pimages = hs[i]->bp_images.as<unsigned char>();
         sg.bmeta = hs[i]->bm_meta.as<BmBucket>();
         sg.smeta = slices ? hs[i]->sl_meta.as<int4>() : nullptr;
         sg.ix = index_dev(hs[i]);
@@ -2815,15 +2999,21 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (ntp == 0) return BXMI_OK;
     const int ngroups = (int)(ntp / BM_GROUP_TILES);
     // PAIR: a search workgroup holds the images of two neighbouring buckets (needs both in one CU's LDS)
-    const bool pair = !slices && g_opt_bm_pair != 0 && 2 * max_stride * sizeof(uint2) + 8192 <= 160 * 1024;
-    const int chunk = g_opt_bm_chunk ? (int)g_opt_bm_chunk : (pair ? 2 * BM_CHUNK : BM_CHUNK);
-    const int64_t max_items = (int64_t)n * ((pair ? BM_NB / 2 : BM_NB) + 2) + 2 * (nq_all / chunk) + 2;
+    const bool pair = !units && g_opt_bm_pair != 0 && 2 * max_stride * sizeof(uint2) + 8192 <= 160 * 1024;
+    const int chunk = dense ? (g_opt_bd_chunk ? (int)g_opt_bd_chunk : (cells ? 2 : 4) * BM_CHUNK) : g_opt_bm_chunk ? (int)g_opt_bm_chunk : (pair ? 2 * BM_CHUNK : BM_CHUNK);
+    int64_t max_items = (int64_t)n * ((pair ? BM_NB / 2 : BM_NB) + 2) + 2 * (nq_all / chunk) + 2;
+    if (dense) {  // every segment has at most BM_NB >> f units; empty workgroups of 157 KB of LDS are not free
+        max_items = 2 * (nq_all / chunk) + 2;
+        for (int i = 0; i < n; i++) max_items += (BM_NB >> segs[(size_t)i].g.f) + 2;
+    }
     BXMI_TRY(h->bm_recs.reserve((size_t)ntp * tile * 4));
     BXMI_TRY(h->bm_slots.reserve((size_t)ntp * tile * 2));
     BXMI_TRY(h->bm_tbl.reserve((size_t)ntp * BM_NB * 2));
-    BXMI_TRY(h->bm_runT.reserve((size_t)ntp * BM_NB * 4));
+    if (!dense) BXMI_TRY(h->bm_runT.reserve((size_t)ntp * BM_NB * 4));
+    if (dense) BXMI_TRY(h->bd_unitT.reserve((size_t)ntp * BM_NB * 2));
     BXMI_TRY(h->bm_grpcnt.reserve((size_t)ngroups * BM_NB * 4));
-    if (slices) BXMI_TRY(h->sl_unitcnt.reserve((size_t)ngroups * BM_NB * 4));
+    if (units) BXMI_TRY(h->sl_unitcnt.reserve((size_t)ngroups * BM_NB * 4));
+    if (dense) BXMI_TRY(h->bd_cnt16.reserve((size_t)ntp * tile * 2));
     BXMI_TRY(h->bm_items.reserve((size_t)(max_items + 2) * sizeof(int4)));  // [0] = the item count, items from [1]
     if (fx) {  // find(): counts apart from the records, and the tile-sorted offsets
         BXMI_TRY(h->sl_cnt.reserve((size_t)ntp * tile * 4));
@@ -2858,7 +3048,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.tile_seg = reinterpret_cast<const unsigned short *>(h->bm_params.as<unsigned char>() + tile_off);
     L.owner = h;
     L.ntp = ntp, L.ngroups = ngroups, L.tile_log2 = tile_log2;
-    L.search_lds = slices ? sl_lds : (size_t)(pair ? 2 : 1) * max_stride * sizeof(uint2);
+    L.search_lds = slices ? sl_lds : dense ? max_stride * 16 : (size_t)(pair ? 2 : 1) * max_stride * sizeof(uint2);
     L.gate = unsorted;
     if (unsorted) {
         // one index, its batch possibly sorted by start already: one pass over the queries as they lie then, and every
@@ -2876,9 +3066,15 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY((bm_launch_tiles<1024, 16>(L, st)));
     else
         BXMI_TRY((bm_launch_tiles<512, 32>(L, st)));
+    if (dense) {
+        hipLaunchKernelGGL(bd_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
+                           tile_log2, h->bd_unitT.as<unsigned short>(), ntp, h->sl_unitcnt.as<unsigned>(), unsorted);
+        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
+                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
+    } else {
     hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                        tile_log2, h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
-    if (slices) {
+    if (units) {
         hipLaunchKernelGGL(sl_unit_sums_kernel, dim3((unsigned)ngroups), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), L.segs, L.tile_seg,
                            h->sl_unitcnt.as<unsigned>(), unsorted);
         hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
@@ -2889,6 +3085,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     else
         hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
                            h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
+    }
     BXMI_LAUNCH_CHECK();
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
     if (slices) {
@@ -2902,12 +3099,19 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         else
             BXMI_TRY(sl_launch_search<16>(L, sgrid, st, search_out));
         if (fx) fx->L = L, fx->sgrid = sgrid, fx->lanes = lanes, fx->variant = variant;
-    } else if (pair)
+    } else if (dense)
+        BXMI_TRY(bd_launch_search(L, sgrid, cells, any_blocks, st));
+    else if (pair)
         BXMI_TRY(bm_launch_search_u<true>(L, sgrid, st));
     else
         BXMI_TRY(bm_launch_search_u<false>(L, sgrid, st));
     unsigned *loff = fx ? h->sl_loff.as<unsigned>() : nullptr;
-    if (variant == 2)
+    if (dense) {
+        if (variant == 2)
+            BXMI_TRY((bd_launch_unpermute<1024, 32>(L, tslots, st)));
+        else
+            BXMI_TRY((bd_launch_unpermute<1024, 16>(L, tslots, st)));
+    } else if (variant == 2)
         BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff)));
     else
         BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff)));
@@ -2928,7 +3132,7 @@ static int ivl_find_sliced(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, in
     BmFindCtx fx;
     int32_t *counts = h->q_cnt.as<int32_t>();
     int64_t *no_total = nullptr;
-    BXMI_TRY(bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &no_total, st, true, &fx));
+    BXMI_TRY(bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &no_total, st, 2, &fx));
     BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
                                                            reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
     int64_t total = 0;
@@ -2954,7 +3158,7 @@ static int ivl_find_sliced(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, in
 }
 
 // Which search stage serves a sealed index in the large-batch pass: 0 = neither (older paths), 1 = bucket images,
-// 2 = key slices.  Images cost 0.5 B per coordinate of the span and win on dense indexes; sparse ones (fewer than one
+// 2 = key slices, 3 = dense unit images (dense indexes try them before the bucket images).  Images cost 0.5 B per coordinate of the span and win on dense indexes; sparse ones (fewer than one
 // target per 64 coordinates) and spans whose bucket image outgrows the LDS take slices.  Prepared on first use.
 static int bm_choose_stage(bxmi_ivl *h, hipStream_t st, int *kind)
 {
@@ -2962,11 +3166,25 @@ static int bm_choose_stage(bxmi_ivl *h, hipStream_t st, int *kind)
     if (h->has_reversed || h->n < 4096) return BXMI_OK;
     int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin;
     if (span < 0) span = 0;
-    const bool slices_first = g_opt_slice == 1 || (g_opt_slice < 0 && (span / h->n >= 64 || h->geom.shift > BM_MAX_SHIFT));
+    const bool slices_first = g_opt_dense != 1 && g_opt_flat != 1 && (g_opt_slice == 1 || (g_opt_slice < 0 && (span / h->n >= 64 || h->geom.shift > BD_MAX_SHIFT)));
     if (slices_first) {
         if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
         if (h->sl_state == 1) {
             *kind = 2;
+            return BXMI_OK;
+        }
+    }
+    if (g_opt_flat != 0) {
+        if (h->bp_state == 0) BXMI_TRY(bp_prepare_index(h, st));
+        if (h->bp_state == 1) {
+            *kind = 4;
+            return BXMI_OK;
+        }
+    }
+    if (g_opt_dense != 0) {
+        if (h->bd_state == 0) BXMI_TRY(bd_prepare_index(h, st));
+        if (h->bd_state == 1) {
+            *kind = 3;
             return BXMI_OK;
         }
     }
@@ -3125,6 +3343,8 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         h->cmax = cmax;
         h->bm_state = 0;
         h->sl_state = 0;
+        h->bd_state = 0;
+        h->bp_state = 0;
         h->sl_eid_ready = false;
         BXMI_TRY(h->slice_bounds.reserve(PT_NB * sizeof(SliceBound)));
         hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
@@ -3164,6 +3384,22 @@ extern "C" int bxmi_ivl_bitmap_state(const bxmi_ivl_t *h, int *state, int64_t *h
     BXMI_TRY(need_sealed(h, "bxmi_ivl_bitmap_state"));
     if (state) *state = h->bm_state;
     if (hard_cells) *hard_cells = h->bm_hard_cells;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_flat_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_flat_state"));
+    if (state) *state = h->bp_state;
+    if (hard_cells) *hard_cells = h->bp_hard_cells;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_dense_state(const bxmi_ivl_t *h, int *state, int64_t *worst)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_dense_state"));
+    if (state) *state = h->bd_state;
+    if (worst) worst[0] = h->bd_worst[0], worst[1] = h->bd_worst[1];
     return BXMI_OK;
 }
 
@@ -3230,7 +3466,7 @@ extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_
     if (bitmap) {
         int kind = 0;
         BXMI_TRY(bm_choose_stage(h, st, &kind));
-        if (kind) return bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &total_dev, st, kind == 2);
+        if (kind) return bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &total_dev, st, kind);
     }
     if (partition) return ivl_count_partitioned(h, qs, qe, nq, counts, total_dev, st);
     TreeDev S = h->treeS.dev, E = h->treeE.dev;
@@ -3262,11 +3498,11 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
     if (n < 0 || (n > 0 && (!hs || !qs || !qe || !nq))) return fail(BXMI_EINVAL, "bxmi_ivl_count_multi_dev: bad arguments");
     hipStream_t st = as_stream(stream);
     // indexes whose batch can ride the bitmap-cell pass are answered together (one pass, six launches); the others one by one
-    std::vector<bxmi_ivl *> fh[2];  // [0] images, [1] slices
-    std::vector<const int32_t *> fqs[2], fqe[2];
-    std::vector<int64_t> fnq[2];
-    std::vector<int32_t *> fc[2];
-    std::vector<int64_t *> ft[2];
+    std::vector<bxmi_ivl *> fh[4];  // [0] bucket images, [1] slices, [2] dense unit images, [3] cell images of units
+    std::vector<const int32_t *> fqs[4], fqe[4];
+    std::vector<int64_t> fnq[4];
+    std::vector<int32_t *> fc[4];
+    std::vector<int64_t *> ft[4];
     std::vector<int> rest;
     int64_t nq_all = 0;
     for (int i = 0; i < n; i++) {
@@ -3290,10 +3526,10 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
             rest.push_back(i);
         }
     }
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < 4; k++)
         if (!fh[k].empty())
             BXMI_TRY(bm_count_segments(fh[k].data(), (int)fh[k].size(), fqs[k].data(), fqe[k].data(), fnq[k].data(), fc[k].data(), ft[k].data(), st,
-                                       k == 1));
+                                       k + 1));
     for (int i : rest)
         BXMI_TRY(bxmi_ivl_count_dev(hs[i], qs[i], qe[i], nq[i], counts ? counts[i] : nullptr, totals_dev ? totals_dev[i] : nullptr, stream));
     return BXMI_OK;

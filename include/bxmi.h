@@ -120,6 +120,16 @@ int bxmi_ivl_bitmap_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
  * indexes and spans whose bucket image outgrows the LDS): *state = 0 not decided yet, 1 = usable, -1 = one bucket's
  * keys alone do not fit; unit_keys[0..6] = the most keys a unit of 2^f buckets stages.  Introspection only. */
 int bxmi_ivl_slice_state(const bxmi_ivl_t *h, int *state, int64_t *unit_keys);
+/* The same for the dense-image search stage (count_dense.hpp: one bit per coordinate, units of 2^19 coordinates; serves
+ * dense indexes, duplicated coordinates included): *state = 0 not decided yet, 1 = usable, -1 = the index does not fit
+ * the format; worst[0] = most keys of one 2^17-coordinate block (limit 32767), worst[1] = most overflow entries of one
+ * unit (limit 5632).  Introspection only. */
+int bxmi_ivl_dense_state(const bxmi_ivl_t *h, int *state, int64_t *worst);
+/* The same for the flat walk on cell images (count_dense.hpp, bp_*: the cells of the bitmap pass laid out per unit of
+ * 2^18 coordinates, records walked 16 bytes at a time, 16-bit counts): *state = 0 not decided yet, 1 = usable, -1 = the
+ * index does not qualify (span wider than 2^29, reversed targets, too many cells with several duplicated coordinates:
+ * *hard_cells of them).  This is the stage a dense index takes first.  Introspection only. */
+int bxmi_ivl_flat_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
 
 /* IntervalTree.find for a batch, as CSR: offsets[nq+1] (int64) and, for query
  * i, hits[offsets[i]..offsets[i+1]) = insertion indices in the reference's

@@ -37,7 +37,8 @@ def set_opt(key, value):
 
 DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
                 "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 1, "ivl.bm_exp": 0, "ivl.slice": -1, "ivl.sl_f": -1,
-                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20}
+                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.bd_depth": 4, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 19, "ivl.bd_blocks": 0,
+                "ivl.bm_chunk": 0}
 
 
 def reset_opts():
@@ -161,6 +162,10 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     assert got_t == want_t
     set_opt("ivl.partition", 1)  # same batch through the large-batch paths
     try:
+        fl_c, fl_t = ix.count(qs, qe)  # the flat walk on cell images where the index qualifies, else as the next line
+        set_opt("ivl.flat", 0)
+        dn_c, dn_t = ix.count(qs, qe)  # dense unit images where the index qualifies, else as the next line
+        set_opt("ivl.dense", 0)
         bm_c, bm_t = ix.count(qs, qe)  # bitmap-cell pass where the index qualifies (else identical to the next line)
         set_opt("ivl.bitmap", 0)       # the bucketed search pass
         got_c, got_t = ix.count(qs, qe)
@@ -172,6 +177,10 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
             p_off, p_hits = ix.find(qs, qe)
     finally:
         reset_opts()
+    bad = np.nonzero(fl_c != want_c)[0]
+    assert len(bad) == 0 and fl_t == want_t, ("flat walk on cells", ix.flat_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], fl_c[bad[:5]], want_c[bad[:5]])
+    bad = np.nonzero(dn_c != want_c)[0]
+    assert len(bad) == 0 and dn_t == want_t, ("dense pass", ix.dense_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], dn_c[bad[:5]], want_c[bad[:5]])
     bad = np.nonzero(bm_c != want_c)[0]
     assert len(bad) == 0 and bm_t == want_t, ("bitmap pass", ix.bitmap_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
     assert np.array_equal(tree_c, want_c) and tree_t == want_t, "partitioned, tree variant"
@@ -211,6 +220,10 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
     try:
         loc_c, loc_t = ix.count(qs, qe)  # the order check of the bitmap-cell pass hands a sorted batch to the local kernel
         set_opt("ivl.sorted_path", 0)
+        fl_c, fl_t = ix.count(qs, qe)  # the flat walk on cell images (where the index qualifies): long runs, the cooperative finish
+        set_opt("ivl.flat", 0)
+        dn_c, dn_t = ix.count(qs, qe)  # the same on dense unit images
+        set_opt("ivl.dense", 0)
         bm_c, bm_t = ix.count(qs, qe)  # bitmap-cell pass (where the index qualifies): long runs, one bucket per tile
         set_opt("ivl.sorted_path", 1)
         set_opt("ivl.bitmap", 0)
@@ -227,6 +240,8 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
         u_c, u_t = ix.count(qs2, qe2)
     finally:
         reset_opts()
+    assert np.array_equal(fl_c, want_c) and fl_t == want_t, ("flat walk on a sorted batch", ix.flat_state())
+    assert np.array_equal(dn_c, want_c) and dn_t == want_t, ("dense pass on a sorted batch", ix.dense_state())
     bad = np.nonzero(bm_c != want_c)[0]
     assert len(bad) == 0 and bm_t == want_t, ("bitmap pass", ix.bitmap_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
     assert np.array_equal(loc_c, want_c) and loc_t == want_t, "sorted batch behind the bitmap pass's order check"
@@ -262,6 +277,12 @@ def test_partitioned_counts_beyond_16_bits(O, IntervalIndex):
     ix = make_index(IntervalIndex, s, e)
     set_opt("ivl.partition", 1)
     try:
+        fl, fl_total = ix.count(qs, qe)  # the flat walk on cell images: the pile is one hard cell per array, counts of 65535 and more escape
+        fstate = ix.flat_state()
+        set_opt("ivl.flat", 0)
+        dn, dn_total = ix.count(qs, qe)  # dense unit images refuse the index (70 000 keys in one block: more than 15 bits of rank)
+        dstate = ix.dense_state()
+        set_opt("ivl.dense", 0)
         bm, bm_total = ix.count(qs, qe)  # bitmap-cell pass: the pile is one hard cell per array, its counts escape
         state = ix.bitmap_state()
         set_opt("ivl.bitmap", 0)
@@ -272,6 +293,12 @@ def test_partitioned_counts_beyond_16_bits(O, IntervalIndex):
         reset_opts()
     assert int(want.max()) >= pile
     assert state[0] == 1 and state[1] >= 2, state
+    assert dstate[0] == -1 and dstate[1][0] >= pile, dstate
+    assert fstate[0] == 1 and fstate[1] >= 2, fstate
+    bad = np.nonzero(fl != want)[0]
+    assert len(bad) == 0 and fl_total == want_total, ("flat walk", bad[:5], qs[bad[:5]], qe[bad[:5]], fl[bad[:5]], want[bad[:5]])
+    bad = np.nonzero(dn != want)[0]
+    assert len(bad) == 0 and dn_total == want_total, ("dense pass", bad[:5], qs[bad[:5]], qe[bad[:5]], dn[bad[:5]], want[bad[:5]])
     bad = np.nonzero(bm != want)[0]
     assert len(bad) == 0 and bm_total == want_total, ("bitmap pass", bad[:5], qs[bad[:5]], qe[bad[:5]], bm[bad[:5]], want[bad[:5]])
     bad = np.nonzero(got != want)[0]
@@ -298,6 +325,8 @@ def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
     set_opt("ivl.partition", 1)
     try:
         set_opt("ivl.bm_hard_ppm", 10**6)  # keep the bitmap-cell pass although the dense stretch is all hard cells
+        set_opt("ivl.dense", 0)            # (250k keys on 4000 coordinates: far more duplicates than a unit's overflow list holds)
+        set_opt("ivl.flat", 0)
         bm, bm_total = ix.count(qs, qe)
         state = ix.bitmap_state()
         set_opt("ivl.bitmap", 0)
@@ -348,10 +377,10 @@ def test_incremental_append_reseals(O, IntervalIndex):
         assert np.array_equal(ix.find(qs, qe)[1], t.find_batch(qs, qe)[1])
 
 
-@pytest.mark.parametrize("stage", ["images", "slices"])
+@pytest.mark.parametrize("stage", ["images", "slices", "dense", "flat"])
 @pytest.mark.parametrize("shape", ["uniform", "sorted", "one_bucket", "messy", "ragged_tail", "dups"])
 def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
-    """The large-batch count pass (count_bitmap.hpp, and its slice search stage count_slices.hpp) against the oracle
+    """The large-batch count pass (count_bitmap.hpp, and its search stages count_slices.hpp and count_dense.hpp) against the oracle
     treap: shuffled, sorted and clumped batches, zero-length / reversed / off-grid / very long queries (escapes), tiles
     that are not full, targets whose coordinates carry duplicates (duplicate descriptors and hard cells; cells with
     thousands of keys for the slices), all tile shapes, unroll depths, unit sizes and run widths."""
@@ -389,8 +418,40 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
     t.insert_many_arrays(s, e)
     want, want_total = t.count_batch(qs, qe)
     ix = make_index(IntervalIndex, s, e)
+    ix_blocks = [0]
     set_opt("ivl.partition", 1)
     try:
+        if stage in ("dense", "flat"):
+            # units of 16 (8) buckets; tile shapes, work items of every size (several waves' batches / several items per
+            # unit / one item per unit), record pipelines of every depth, both lookup styles and both rank bases of the
+            # dense images, sorted batches through the exchange (long runs)
+            set_opt("ivl.flat", 1 if stage == "flat" else 0)
+            set_opt("ivl.dense", 1)
+            if shape == "dups" and stage == "flat":
+                set_opt("ivl.bm_hard_ppm", 10**6)  # (two cells' worth of piled-up coordinates and 60 000 repeated starts: keep the cells anyway)
+            for k, (variant, chunk, depth, exp, blocks) in enumerate(((0, 0, 4, 0, 0), (1, 4096, 2, 2, 1), (2, 1 << 20, 3, 0, 1), (-1, 20000, 4, 2, 0),
+                                                                      (0, 1024, 2, 0, 0))):
+                set_opt("ivl.sorted_path", k % 2)
+                set_opt("ivl.bm_variant", variant)
+                set_opt("ivl.bd_chunk", chunk)
+                set_opt("ivl.bd_depth", depth)
+                set_opt("ivl.bd_exp", exp if stage == "dense" else 0)
+                if stage == "dense" and blocks != ix_blocks[0]:
+                    set_opt("ivl.bd_blocks", blocks)
+                    ix.seal()  # (the rank base of the images is decided when the index is prepared)
+                    ix_blocks[0] = blocks
+                got, got_total = ix.count(qs, qe)
+                state = ix.dense_state() if stage == "dense" else ix.flat_state()
+                assert state[0] == 1 and ix.bitmap_state()[0] == 0 and ix.slice_state()[0] == 0, (state, ix.bitmap_state(), ix.slice_state())
+                assert (ix.flat_state()[0] == 0) == (stage == "dense")
+                bad = np.nonzero(got != want)[0]
+                assert len(bad) == 0, (shape, stage, variant, chunk, depth, exp, blocks, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+                assert got_total == want_total
+            if shape == "dups":
+                assert (state[1][1] > 100) if stage == "dense" else (state[1] > 0)  # overflow entries / hard cells
+            return
+        set_opt("ivl.dense", 0)
+        set_opt("ivl.flat", 0)
         if stage == "slices":
             set_opt("ivl.slice", 1)
             # lanes: 16 / 64 per (tile, unit) run, 1 = the flat walk over the item's runs, 0 = by expected run length
@@ -511,6 +572,8 @@ def test_bitmap_pass_is_refused_where_it_does_not_fit(O, IntervalIndex):
     s[:90_000] = rng.integers(1_000_000, 1_001_000, size=90_000)  # one bucket with 90k keys: more than a workgroup stages
     cases["pile"] = (s, s + rng.integers(0, 500, size=150_000))
     set_opt("ivl.partition", 1)
+    set_opt("ivl.dense", 0)  # (the dense images and the flat walk have their own limits: test_dense_pass_limits)
+    set_opt("ivl.flat", 0)
     try:
         for name, (s, e) in cases.items():
             s, e = s.astype(np.int32), e.astype(np.int32)
@@ -539,6 +602,66 @@ def test_bitmap_pass_is_refused_where_it_does_not_fit(O, IntervalIndex):
         reset_opts()
 
 
+def test_dense_pass_limits(O, IntervalIndex):
+    """What the dense unit images (count_dense.hpp) hold and what they refuse: a span of 2^30 (buckets of 2^19, one per
+    unit) is served when asked for; more than 32767 keys in one 2^17-coordinate block, more duplicated coordinates than a
+    unit's overflow list holds, and reversed targets are refused -- the batch then takes the other stages, same counts."""
+    rng = np.random.default_rng(19)
+    cases = {}
+    s = rng.integers(0, 2**30, size=50_000)
+    cases["wide"] = (s, s + rng.integers(0, 500, size=50_000), 1)
+    s = rng.integers(0, 2**29, size=150_000)
+    s[:90_000] = rng.integers(1_000_000, 1_001_000, size=90_000)  # 90k keys on 1000 coordinates: one block overflows its 15-bit ranks
+    cases["pile"] = (s, s + rng.integers(0, 500, size=150_000), -1)
+    s = rng.integers(0, 125_000, size=500_000) * 8  # 125 000 coordinates, each several times over: 4096 of them per unit of 2^15
+    cases["duplicates"] = (s, s + 8 * rng.integers(0, 10, size=500_000), -1)
+    s = rng.integers(0, 400_000, size=60_000)
+    s[:3000] = rng.choice(s[3000:], size=3000)  # a few thousand duplicated coordinates in a few units: fits
+    cases["some_duplicates"] = (s, s + rng.integers(0, 300, size=60_000), 1)
+    s = rng.integers(0, 10_000_000, size=50_000)
+    e = s + rng.integers(0, 500, size=50_000)
+    e[7] = s[7] - 3
+    cases["reversed"] = (s, e, 0)
+    set_opt("ivl.partition", 1)
+    set_opt("ivl.dense", 1)
+    set_opt("ivl.flat", 0)
+    try:
+        for name, (s, e, expect) in cases.items():
+            s, e = s.astype(np.int32), e.astype(np.int32)
+            hi = int(s.max()) + 1000
+            qs = rng.integers(-500, hi, size=40_000).astype(np.int32)
+            qe = (qs + rng.integers(1, 900, size=40_000)).astype(np.int32)
+            t = O.OracleIntervalTree()
+            t.insert_many_arrays(s, e)
+            want, want_total = t.count_batch(qs, qe)
+            ix = make_index(IntervalIndex, s, e)
+            got, got_total = ix.count(qs, qe)
+            state = ix.dense_state()
+            bad = np.nonzero(got != want)[0]
+            assert len(bad) == 0 and got_total == want_total, (name, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+            assert state[0] == expect, (name, state)
+            if name == "pile":
+                assert state[1][0] > 32767
+            if name == "duplicates":
+                assert state[1][1] > 5632
+            # the flat walk on cell images: spans up to 2^29; a pile is a few hard cells (finished in the sorted array),
+            # coordinates duplicated all over are too many of them (a key on every 7th coordinate and a duplicate on every
+            # 60th: a tenth of the cells hold two duplicated coordinates -- the dense images' overflow lists take those)
+            set_opt("ivl.flat", 1)
+            ix.seal()
+            got, got_total = ix.count(qs, qe)
+            fstate = ix.flat_state()
+            set_opt("ivl.flat", 0)
+            bad = np.nonzero(got != want)[0]
+            assert len(bad) == 0 and got_total == want_total, ("flat", name, fstate, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+            assert fstate[0] == {"wide": -1, "pile": 1, "duplicates": -1, "some_duplicates": -1, "reversed": 0}[name], (name, fstate)
+            if name == "pile":
+                assert fstate[1] > 20
+            ix.close()
+    finally:
+        reset_opts()
+
+
 # --------------------------------------------------------- scale / golden hash --
 def test_scale_1M_hash(golden_scale, IntervalIndex):
     pt = golden_scale["1M x 200k"]
@@ -554,6 +677,20 @@ def test_scale_1M_hash(golden_scale, IntervalIndex):
     set_opt("ivl.lds_ints", 18688)
     set_opt("ivl.partition", 1)
     try:
+        set_opt("ivl.flat", 1)  # the flat walk on cell images although the index is sparse
+        for variant in (0, 1, 2):
+            set_opt("ivl.bm_variant", variant)
+            counts, total = ix.count(qs, qe)
+            assert ix.flat_state()[0] == 1
+            assert total == pt["total"] and hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], ("flat walk", variant)
+        set_opt("ivl.flat", 0)
+        set_opt("ivl.dense", 1)  # dense unit images
+        for variant in (0, 1, 2):
+            set_opt("ivl.bm_variant", variant)
+            counts, total = ix.count(qs, qe)
+            assert ix.dense_state()[0] == 1
+            assert total == pt["total"] and hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], ("dense stage", variant)
+        set_opt("ivl.dense", 0)
         for variant in (0, 1, 2, 3):  # the slice stage (1M targets on 250M coordinates are sparse): tile shapes, unit sizes, run widths
             set_opt("ivl.bm_variant", variant % 3)
             set_opt("ivl.sl_f", (-1, 0, 3, 6)[variant])
@@ -593,12 +730,21 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
         sub = counts[:: pt["stride"]]
         assert int(sub.sum(dtype=np.int64)) == pt["total"]
         assert hashlib.sha256(np.ascontiguousarray(sub).tobytes()).hexdigest() == pt["counts_sha256"]
-    assert ix.bitmap_state()[0] == 1  # the full batch above went through the bitmap-cell pass
+    assert ix.flat_state()[0] == 1 and ix.dense_state()[0] == 0 and ix.bitmap_state()[0] == 0  # the full batch above went through the flat walk on cell images
     # the direct tree kernel and the large-batch passes agree (first 8M queries through the direct kernel)
     set_opt("ivl.partition", 0)
     try:
         direct, _ = ix.count(qs[:8_000_000], qe[:8_000_000])
         set_opt("ivl.partition", -1)
+        set_opt("ivl.flat", 0)    # the same pass on dense unit images
+        img, img_total = ix.count(qs, qe)
+        assert ix.dense_state()[0] == 1
+        assert np.array_equal(img, counts) and img_total == total
+        set_opt("ivl.dense", 0)   # on bucket-pair images
+        img, img_total = ix.count(qs, qe)
+        assert ix.bitmap_state()[0] == 1
+        assert np.array_equal(img, counts) and img_total == total
+        del img
         set_opt("ivl.bitmap", 0)  # the bucketed search pass on the whole batch
         old, old_total = ix.count(qs, qe)
     finally:
@@ -648,7 +794,7 @@ def test_count_multi_equals_one_index_at_a_time(O, IntervalIndex):
     from bxmi import _ffi
 
     rng = np.random.default_rng(31)
-    specs = [(60_000, 2_000_000, 300_001), (9_000, 250_000_000, 70_000), (200_000, 40_000_000, 16384 * 5), (5_000, 900_000, 0),
+    specs = [(60_000, 2_000_000, 300_001), (9_000, 250_000_000, 70_000), (200_000, 6_000_000, 16384 * 5), (5_000, 900_000, 0),
              (30_000, 2**30, 50_000), (20_000, 5_000_000, 40_000)]
     ixs, dev, want = [], [], []
     for k, (n, span, nq) in enumerate(specs):
@@ -670,6 +816,32 @@ def test_count_multi_equals_one_index_at_a_time(O, IntervalIndex):
     totals = _ffi.DeviceArray(8 * len(specs))
     set_opt("ivl.partition", 1)
     try:
+        # all defaults: indexes 0 and 2 (dense) ride one pass on dense unit images, 1 and 4 (sparse / wide) one on slices
+        totals.zero()
+        IntervalIndex.count_multi_dev(ixs, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [d[3] for d in dev], [d[2].ptr for d in dev],
+                                      [totals.ptr + 8 * i for i in range(len(specs))], None)
+        _ffi.call("bxmi_synchronize", None)
+        tot = totals.to_numpy(np.int64, len(specs))
+        for k, (wc, wt) in enumerate(want):
+            got = dev[k][2].to_numpy(np.int32, dev[k][3])
+            bad = np.nonzero(got != wc)[0]
+            assert len(bad) == 0 and int(tot[k]) == wt, ("defaults", k, ixs[k].dense_state(), bad[:5], got[bad[:5]], wc[bad[:5]], int(tot[k]), wt)
+        assert [ix.flat_state()[0] for ix in ixs] == [1, 0, 1, 0, 0, 0], [ix.flat_state() for ix in ixs]
+        assert [ix.slice_state()[0] for ix in ixs] == [0, 1, 0, 0, 1, 0]
+        set_opt("ivl.flat", 0)  # the same on dense unit images
+        totals.zero()
+        IntervalIndex.count_multi_dev(ixs, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [d[3] for d in dev], [d[2].ptr for d in dev],
+                                      [totals.ptr + 8 * i for i in range(len(specs))], None)
+        _ffi.call("bxmi_synchronize", None)
+        tot = totals.to_numpy(np.int64, len(specs))
+        for k, (wc, wt) in enumerate(want):
+            got = dev[k][2].to_numpy(np.int32, dev[k][3])
+            bad = np.nonzero(got != wc)[0]
+            assert len(bad) == 0 and int(tot[k]) == wt, ("dense", k, ixs[k].dense_state(), bad[:5], got[bad[:5]], wc[bad[:5]], int(tot[k]), wt)
+        assert [ix.dense_state()[0] for ix in ixs] == [1, 0, 1, 0, 0, 0], [ix.dense_state() for ix in ixs]
+        for ix in ixs:
+            ix.seal()  # (forget the stages chosen so far: the loop below asserts on what each setting prepares)
+        set_opt("ivl.dense", 0)
         for pair, variant, slices in ((1, -1, 0), (0, 0, 0), (1, 2, 0), (1, -1, -1), (0, 1, 1)):
             set_opt("ivl.bm_pair", pair)
             set_opt("ivl.bm_variant", variant)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# round 3, GPU call F: the flat walk on cell images -- tests, timing against the dense images and the bucket-pair search
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+REPO=$PWD
+OUT=$REPO/gpurun_out/r3h
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests/test_gpu_intervals.py -m gpu -q -x --timeout 900 -p no:cacheprovider \
+  -k "bitmap_pass_differential or dense or random_differential or sorted or beyond_16 or count_multi or scale_1M or refused" > $OUT/tests.log 2>&1
+echo "tests rc=$?" | tee -a $OUT/tests.log
+tail -5 $OUT/tests.log
+export VARIANTS="flat:,flat_nolook:ivl.bd_exp=1,dense:ivl.flat=0+ivl.bd_exp=2,pair:ivl.flat=0+ivl.dense=0"
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python $REPO/tools/count_variants.py > $OUT/variants_traced.json 2> $OUT/trace.err; echo "trace rc=$?"
+cut -c1-150 $OUT/variants_traced.json | grep "variant\|mism"
+cd $REPO
+python tools/trace_segments.py $OUT/trace 20 4 > $OUT/segments.txt 2>&1
+grep -A12 "per pass" $OUT/segments.txt | grep -v "rs_\|ivl_un\|ivl_make\|scan_\|part_b\|rocprim\|at::"
+find $OUT/trace -name "*.csv" -size +20M -delete
