@@ -400,6 +400,80 @@ __global__ __launch_bounds__(256) void bd_transpose_kernel(const unsigned short 
     }
 }
 
+// The plan of a batch of ONE index (bm_plan_kernel<2> walks every column twice, three dependent batches of loads each
+// time, from eight workgroups that reserve their room with an atomic: 20 us for 100 M queries).  One workgroup, a thread
+// per unit, the column's group counts pulled 16 at a time with independent loads, the items of a unit kept in registers
+// (up to six; a unit cut into more is walked a second time), one block scan for their places: units stay in order, which
+// is what the search's XCD-aware item mapping wants.
+// items[i] = {unit, first tile, last tile + 1, queries}; *n_items = number of items.
+__global__ __launch_bounds__(1024) void bd_plan_kernel(const unsigned *__restrict__ unitcnt /* [ngroups][BM_NB] */, int ngroups, int nunits,
+                                                       const BmSeg *__restrict__ segs, int chunk, int4 *__restrict__ items, int *__restrict__ n_items,
+                                                       const unsigned *__restrict__ gate)
+{
+    __shared__ int scan_tmp[16];
+    if (gate && *gate == 0) return;
+    const int t_last = (int)(segs[0].tile0 + segs[0].ntiles);
+    int carry = 0;
+    for (int u0 = 0; u0 < nunits; u0 += 1024) {
+        const int u = u0 + (int)threadIdx.x;
+        const bool live = u < nunits;
+        const unsigned *__restrict__ col = unitcnt + (live ? u : 0);
+        int fb[6], fe[6];
+        unsigned fq[6];
+        int cnt = 0;
+        auto walk = [&](bool emit, int at) {
+            unsigned acc = 0;
+            int g_first = 0, k = 0;
+            auto close = [&](int g_end) {
+                if (emit) {
+                    const int t_end = g_end * BM_GROUP_TILES;
+                    items[at + k] = make_int4(u, g_first * BM_GROUP_TILES, t_end < t_last ? t_end : t_last, (int)acc);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 6; j++)
+                        if (k == j) fb[j] = g_first, fe[j] = g_end, fq[j] = acc;
+                }
+                k++;
+                acc = 0;
+            };
+            for (int g0 = 0; g0 < ngroups; g0 += 16) {
+                unsigned v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int gi = g0 + i < ngroups ? g0 + i : ngroups - 1;  // a valid address: no branch around the loads
+                    v[i] = col[(int64_t)gi * BM_NB];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int gi = g0 + i;
+                    if (gi >= ngroups) break;
+                    const unsigned c = live ? v[i] : 0u;
+                    if (acc > 0 && acc + c > (unsigned)chunk) close(gi);
+                    if (acc == 0) g_first = gi;
+                    acc += c;
+                }
+            }
+            if (acc > 0) close(ngroups);
+            return k;
+        };
+        cnt = walk(false, 0);
+        int tot;
+        const int at = carry + block_exclusive_scan(cnt, OpSum(), 0, scan_tmp, &tot);
+        if (cnt <= 6) {
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                if (j < cnt) {
+                    const int t_end = fe[j] * BM_GROUP_TILES;
+                    items[at + j] = make_int4(u, fb[j] * BM_GROUP_TILES, t_end < t_last ? t_end : t_last, (int)fq[j]);
+                }
+        } else {
+            (void)walk(true, at);
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *n_items = carry;
+}
+
 // ---------------------------------------------------------------------------
 // search
 // ---------------------------------------------------------------------------
@@ -441,61 +515,12 @@ __device__ __forceinline__ unsigned bp_count_record(const BdImage &I, unsigned r
     return rec == BM_REC_ESC ? 0xFFFFu : c;
 }
 
-// One lookup in three steps, so that a slot's eight lookups can keep their LDS reads in flight together (a lookup
-// that reads, waits, computes and branches before the next one starts leaves the CU's four waves per SIMD waiting on
-// LDS latency eight times per slot: measured 67 % VALU activity at 430 wave-instructions per slot).
-//   1. bd_look_cell:     the cell's bits and its 16-bit meta word requested
-//   2. bd_look_overflow: {ov[i], ov[i+1], ov[i+2]} requested, i = 0 (three zeros) for a plain cell
-//   3. bd_look_rank:     popcount below the position + base + the copies of up to two duplicated coordinates below it;
-//                        a third entry -- three duplicated coordinates in one 128-coordinate cell -- takes a loop
+// One lookup: read, wait, compute, and a branch for the cell with duplicated coordinates (taken by some lane of the wave
+// in nearly every lookup).  (A three-step form that keeps a slot's eight lookups' LDS reads in flight together -- all
+// cells, then {ov[i], ov[i+1], ov[i+2]} with i = 0 for plain cells, then the ranks -- measured no faster and needs twice
+// the registers.)
 // QB: the image's ranks are relative to blocks of 1024 cells (a table read per lookup); otherwise one block spans the
 // unit (fewer than 2^15 keys per slice: configs[1] has 22 000) and a plain cell's 16 bits are its rank in the unit.
-struct BdLook {
-    bd_v4u w;
-    unsigned m, q;
-    unsigned ob, e1, e2;
-    unsigned at;  // index of ov[i]
-};
-
-template <bool QB>
-__device__ __forceinline__ void bd_look_cell(BdLook &K, lds_v4u_p bits, lds_u16_p meta, lds_u32_p qb, unsigned rel)
-{
-    const unsigned c = rel >> 7;
-    K.w = bits[c];
-    K.m = meta[c];
-    K.q = QB ? qb[c >> 10] : 0u;
-}
-
-__device__ __forceinline__ void bd_look_overflow(BdLook &K, lds_u16_p ov)
-{
-    const unsigned hard = (unsigned)((int)(K.m << 16) >> 31);  // all ones when bit 15 of the meta word is set
-    K.at = K.m & 0x7FFFu & hard;
-    K.ob = ov[K.at], K.e1 = ov[K.at + 1u], K.e2 = ov[K.at + 2u];
-}
-
-__device__ __forceinline__ int bd_look_rank(const BdLook &K, lds_u16_p ov, unsigned rel)
-{
-    const unsigned p = rel & 127u;
-    const unsigned long long lo = (unsigned long long)K.w.x | ((unsigned long long)K.w.y << 32);
-    const unsigned long long hi = (unsigned long long)K.w.z | ((unsigned long long)K.w.w << 32);
-    const bool up = p >= 64u;
-    const unsigned long long below = (1ull << (p & 63u)) - 1ull;
-    int r = __popcll((up ? hi : lo) & below) + (up ? __popcll(lo) : 0);
-    const unsigned base = K.at ? K.ob : K.m;  // (a plain cell has at = 0; a list never starts at 0)
-    r += (K.e1 & 127u) < p ? (int)((K.e1 >> 7) & 255u) : 0;
-    r += (K.e2 & 127u) < p ? (int)((K.e2 >> 7) & 255u) : 0;
-    if (K.e2 & 0x8000u) {  // rare: more than two entries
-        unsigned i = K.at + 2u, e;
-        do {
-            e = ov[++i];
-            r += (e & 127u) < p ? (int)((e >> 7) & 255u) : 0;
-        } while (e & 0x8000u);
-    }
-    return (int)(K.q + base) + r;
-}
-
-// The same lookup in one piece: read, wait, compute, and a branch for the cell with duplicated coordinates (taken by
-// some lane of the wave in nearly every lookup).  Fewer registers than the three-step form: deeper record pipelines fit.
 template <bool QB>
 __device__ __forceinline__ int bd_rank(lds_v4u_p bits, lds_u16_p meta, lds_u32_p qb, lds_u16_p ov, unsigned rel)
 {
@@ -534,7 +559,6 @@ __device__ __forceinline__ unsigned bd_count16(int bias, int rS, int rE, unsigne
 // same -- any 32-bit word is a safe argument, the offset is masked to the unit and the length cannot leave the margin --
 // and not stored)
 // EXP (diagnostics, ivl.bd_exp; wrong results): 1 = no lookups at all -- the price of the walk and of its memory traffic alone
-// EXP 2 = the lookups one after the other (bd_rank) instead of batched
 // FMT: 0 = dense unit image, 1 = cell image
 template <int FMT, bool QB, int EXP>
 __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short *__restrict__ out, unsigned idx4, unsigned valid, bd_v4u v)
@@ -548,7 +572,7 @@ __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short 
     } else if (FMT == 1) {
 #pragma unroll
         for (int j = 0; j < 4; j++) c[j] = bp_count_record(I, rec[j]);
-    } else if (EXP == 2) {
+    } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const unsigned off = rec[j] & I.off_mask;
@@ -556,25 +580,12 @@ __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short 
             const int rS = bd_rank<QB>(I.bitsS, I.metaS, I.qbS, I.ov, off + (rec[j] >> BD_RSHIFT));
             c[j] = bd_count16(I.bias, rS, rE, rec[j]);
         }
-    } else {
-        unsigned relE[4], relS[4];
-        BdLook E[4], S[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned off = rec[j] & I.off_mask;
-            relE[j] = off + 1u, relS[j] = off + (rec[j] >> BD_RSHIFT);
-            bd_look_cell<QB>(E[j], I.bitsE, I.metaE, I.qbE, relE[j]);
-            bd_look_cell<QB>(S[j], I.bitsS, I.metaS, I.qbS, relS[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            bd_look_overflow(E[j], I.ov);
-            bd_look_overflow(S[j], I.ov);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) c[j] = bd_count16(I.bias, bd_look_rank(S[j], I.ov, relS[j]), bd_look_rank(E[j], I.ov, relE[j]), rec[j]);
     }
     unsigned short *p = out + 4 * (size_t)idx4;
+    if (EXP == 3) {  // diagnostics: the lookups alone -- nothing stored unless a count is impossible
+        if ((c[0] & c[1] & c[2] & c[3]) == 0x12345u) p[0] = 1;
+        return;
+    }
     if (valid == 15u) {
         bd_v2u o;
         o.x = c[0] | (c[1] << 16), o.y = c[2] | (c[3] << 16);
@@ -597,7 +608,24 @@ __device__ __forceinline__ unsigned bd_valid_mask(unsigned f0, unsigned ra, unsi
 // DEPTH: passes whose records are in flight per wave.  The walk alone (no lookups) moves 0.72 GB in 225 us with two:
 // neither bandwidth (3.2 TB/s, no read amplification: FETCH_SIZE = the records once) nor instructions, but 2 KB per
 // wave in flight against ~2 us of loaded HBM latency.
-template <int FMT, bool QB, int EXP = 0, int DEPTH = 2>
+// The record loads of the pipelined walk are issued by hand: the compiler does not know them, so it neither waits for
+// them nor drains the memory pipe in front of every pass (which is what its own bookkeeping does to loads that stay in
+// flight around a loop: measured, every pass waited for its own stores).  bd_wait<K> is the wait: K = the number of
+// memory operations known to have been issued after the wanted load -- the counter retires in order.
+__device__ __forceinline__ void bd_issue_load(bd_v4u &v, const unsigned *recs, unsigned idx4)
+{
+    const bd_v4u *p = reinterpret_cast<const bd_v4u *>(recs) + idx4;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+}
+
+template <int K>
+__device__ __forceinline__ void bd_wait(bd_v4u &v)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(K) : "memory");
+}
+
+// PIPE: two sets of DEPTH passes; while one set is answered the other's records are on their way.
+template <int FMT, bool QB, int EXP = 0, int DEPTH = 2, bool PIPE = false>
 __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                const int *__restrict__ n_items, const unsigned short *__restrict__ unitT, int64_t ntp,
                                                                const unsigned *__restrict__ recs /* tile-sorted records */,
@@ -710,7 +738,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         const unsigned ae = a | (e << 15);  // a < 2^15, e <= 2^15
         bd_v4u ring_v[DEPTH];
         unsigned ring_idx[DEPTH], ring_valid[DEPTH];
-        auto prep = [&](unsigned s0, unsigned &idx4, unsigned &valid, bd_v4u &v) {
+        auto prep = [&](unsigned s0, unsigned &idx4, unsigned &valid, bd_v4u &v, bool by_hand = false) {
             const unsigned s = s0 + (unsigned)lane;
             int k = (int)__popcll(__ballot(incl <= s0));  // runs that end at or before the pass's first slot
             unsigned r = (unsigned)k;
@@ -724,11 +752,45 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
             const bool active = s < total;
             idx4 = active ? d + s : 0u;
             valid = active ? bd_valid_mask((idx4 & slot_mask) << 2, x & 0x7fffu, x >> 15) : 0u;
-            v = reinterpret_cast<const bd_v4u *>(recs)[idx4];
+            if (EXP == 3) {  // diagnostics: no record loads -- synthetic records (offsets all over the unit, lengths < 1000)
+                const unsigned h = idx4 * 2654435761u;
+                v = bd_v4u{(h & 0x3ffffu) | (500u << 18), ((h >> 3) & 0x3ffffu) | (100u << 18), ((h >> 7) & 0x3ffffu) | (900u << 18),
+                           ((h >> 11) & 0x3ffffu) | (300u << 18)};
+            } else if (by_hand)
+                bd_issue_load(v, recs, idx4);
+            else
+                v = reinterpret_cast<const bd_v4u *>(recs)[idx4];
         };
         // DEPTH passes at a time: their records requested together, then answered one after the other (the compiler's
         // wait counts only work out inside one iteration: with a ring carried around the loop it drains the memory
         // pipe -- loads AND the stores of the pass before -- in front of every pass)
+        if (PIPE) {
+            bd_v4u y_v[DEPTH];
+            unsigned y_idx[DEPTH], y_valid[DEPTH];
+            // When set X's pass d is wanted, at least these were issued after its load: X's passes d + 1 .. DEPTH - 1 and
+            // all DEPTH of set Y (stores of the answers in between only add to that) -> wait until at most
+            // 2 * DEPTH - 1 - d operations are outstanding.  Passes past the end of the batch are loaded (from record 0)
+            // and not answered, so the count holds in the last round too.
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) prep(64u * d, ring_idx[d], ring_valid[d], ring_v[d], true);
+            for (unsigned s0 = 0; s0 < total; s0 += 128u * DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * (DEPTH + d), y_idx[d], y_valid[d], y_v[d], true);
+                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(ring_v[0]); bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[0], ring_valid[0], ring_v[0]); }
+                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(ring_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[1 % DEPTH], ring_valid[1 % DEPTH], ring_v[1 % DEPTH]); }
+                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(ring_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[2 % DEPTH], ring_valid[2 % DEPTH], ring_v[2 % DEPTH]); }
+                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(ring_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[3 % DEPTH], ring_valid[3 % DEPTH], ring_v[3 % DEPTH]); }
+#pragma unroll
+                for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * (2 * DEPTH + d), ring_idx[d], ring_valid[d], ring_v[d], true);
+                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(y_v[0]); bd_answer_slot<FMT, QB, EXP>(I, out, y_idx[0], y_valid[0], y_v[0]); }
+                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(y_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, y_idx[1 % DEPTH], y_valid[1 % DEPTH], y_v[1 % DEPTH]); }
+                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(y_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, y_idx[2 % DEPTH], y_valid[2 % DEPTH], y_v[2 % DEPTH]); }
+                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(y_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, y_idx[3 % DEPTH], y_valid[3 % DEPTH], y_v[3 % DEPTH]); }
+            }
+            // the loads of the round after the last are still on their way: nothing may reuse their registers before they land
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) bd_wait<0>(ring_v[d]);
+        } else
         for (unsigned s0 = 0; s0 < total; s0 += 64u * DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * d, ring_idx[d], ring_valid[d], ring_v[d]);

@@ -1083,21 +1083,29 @@ constexpr int LC_ITEMS = 8;
 constexpr int LC_CHUNK = LC_THREADS * LC_ITEMS;  // 4096 consecutive queries per workgroup
 constexpr int LC_TREE_KEYS = (1 << 12) - 1;      // two trees of 4096 slots = 32 KiB of LDS: four workgroups per CU
 
+// LOOP: a small grid whose workgroups stride over the chunks (35 % slower on a sorted batch than one workgroup per chunk,
+// but it stands down in 2 us instead of 12 when the batch is NOT sorted: the host launches it when the handle's previous
+// batch was unsorted -- `hint`, a host-visible word, carries that from one pass to the next without a synchronisation).
+template <bool LOOP>
 __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
                                                                      const int32_t *__restrict__ qs_arr,
                                                                      const int32_t *__restrict__ qe_arr, int64_t nq,
                                                                      int32_t *__restrict__ counts /* may be NULL */,
                                                                      unsigned long long *__restrict__ total_slots,
                                                                      const unsigned *__restrict__ gate,
-                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */)
+                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */,
+                                                                     unsigned *__restrict__ hint = nullptr)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
     __shared__ int s_mm[3][LC_THREADS / 64];
     __shared__ int s_slice[6];  // eLo, eHi, sLo, sHi, qeLo, qeHi
     __shared__ long long red[LC_THREADS / 64];
+    if (hint && gate && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint, *gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (gate && *gate != 0) return;  // unsorted batch: the bucketed path answers it
     long long acc = 0;
-    const int64_t base = (int64_t)blockIdx.x * LC_CHUNK;  // (a persistent grid looping over chunks measured 35 % slower)
+    for (int64_t chunk = blockIdx.x; chunk * LC_CHUNK < nq; chunk += LOOP ? (int64_t)gridDim.x : ((int64_t)1 << 40)) {
+    if (LOOP && chunk != (int64_t)blockIdx.x) __syncthreads();  // the shared arrays of the chunk before are done with
+    const int64_t base = chunk * LC_CHUNK;
     const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
     int qs[LC_ITEMS], qe[LC_ITEMS];
     int mn = INT_MAX, mx = INT_MIN, emx = INT_MIN;
@@ -1213,6 +1221,7 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
             if (his) his[base + k] = s_rank;
             acc += c;
         }
+    }
     }
     if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
 }
@@ -2133,6 +2142,7 @@ static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the den
 static int64_t g_opt_bd_nt = 1;       // 1 = non-temporal image loads in the dense search kernel
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
 static int64_t g_opt_bd_depth = 4;    // passes of records in flight per wave of the dense search kernel (2, 3, 4 or 6)
+static int64_t g_opt_bd_pipe = 1;     // 1 = the walk keeps two sets of passes in flight (record loads issued by hand), 0 = one set per round
 static int64_t g_opt_bd_exp = 0;      // diagnostics only (wrong results): 1 = the dense search kernel without its lookups
 static int64_t g_opt_bd_unit_log2 = BD_UNIT_LOG2;  // coordinates per unit of the dense images (read when an index is prepared): 19, or less for shorter runs (A/B)
 
@@ -2263,7 +2273,11 @@ int ivl_set_option(const char *key, int64_t value)
         return 1;
     }
     if (!strcmp(key, "ivl.bd_depth")) {
-        g_opt_bd_depth = value == 2 || value == 3 || value == 6 || value == 8 ? value : 4;
+        g_opt_bd_depth = value == 2 || value == 3 ? value : 4;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bd_pipe")) {
+        g_opt_bd_pipe = value != 0;
         return 1;
     }
     if (!strcmp(key, "ivl.bd_exp")) {
@@ -2323,6 +2337,7 @@ struct bxmi_ivl {
     bool bd_blocks = false;      // the images' ranks are relative to blocks of 1024 cells (more than 32767 keys in some unit's slice)
     DevBuf bd_images, bd_stats, bd_cnt16, bd_unitT;
     bool sl_eid_ready = false;
+    unsigned *sort_hint = nullptr;  // host-visible: 1 = the last large batch was not sorted by start (ivl_local_count_kernel)
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][ONE_CAP hits][completion word:int64]
     unsigned long long one_seq = 0;
     hipStream_t stream = nullptr;
@@ -2401,7 +2416,7 @@ static int ivl_count_part_sub(bxmi_ivl *h, int sub, int64_t q0, const int32_t *q
         // sorted batch: one pass over the queries as they lie (exits at once otherwise)
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
-        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
+        hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
                            h->e_sorted.as<int32_t>(), qs, qe, nq, counts, total_dev ? slots : nullptr, unsorted);
     }
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
@@ -2476,7 +2491,7 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     if (walk) {
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
-        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
+        hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
                            h->e_sorted.as<int32_t>(), qs, qe, nq, h->q_cnt.as<int32_t>(), (unsigned long long *)nullptr, (const unsigned *)nullptr,
                            h->p_hi.as<int32_t>());
     } else {
@@ -2897,12 +2912,12 @@ static int sl_launch_search_flat(const BmLaunch &L, unsigned grid, hipStream_t s
     return BXMI_OK;
 }
 
-template <int FMT, bool QB, int EXP, int DEPTH>
+template <int FMT, bool QB, int EXP, int DEPTH, bool PIPE>
 static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
-    BXMI_TRY(allow_big_lds((bd_search_kernel<FMT, QB, EXP, DEPTH>), L.search_lds));
-    hipLaunchKernelGGL((bd_search_kernel<FMT, QB, EXP, DEPTH>), dim3(grid), dim3(BD_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+    BXMI_TRY(allow_big_lds((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE>), L.search_lds));
+    hipLaunchKernelGGL((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE>), dim3(grid), dim3(BD_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
                        h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(), h->bd_cnt16.as<unsigned short>(),
                        L.tile_log2, L.gate);
     BXMI_LAUNCH_CHECK();
@@ -2912,20 +2927,26 @@ static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
 template <int FMT, bool QB, int EXP>
 static int bd_launch_search_d(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
+    if (g_opt_bd_pipe) {
+        switch (g_opt_bd_depth) {
+        case 2: return bd_launch_search_t<FMT, QB, EXP, 2, true>(L, grid, st);
+        case 3: return bd_launch_search_t<FMT, QB, EXP, 3, true>(L, grid, st);
+        default: return bd_launch_search_t<FMT, QB, EXP, 4, true>(L, grid, st);
+        }
+    }
     switch (g_opt_bd_depth) {
-    case 2: return bd_launch_search_t<FMT, QB, EXP, 2>(L, grid, st);
-    case 3: return bd_launch_search_t<FMT, QB, EXP, 3>(L, grid, st);
-    case 6: return bd_launch_search_t<FMT, QB, EXP, 6>(L, grid, st);
-    case 8: return bd_launch_search_t<FMT, QB, EXP, 8>(L, grid, st);
-    default: return bd_launch_search_t<FMT, QB, EXP, 4>(L, grid, st);
+    case 2: return bd_launch_search_t<FMT, QB, EXP, 2, false>(L, grid, st);
+    case 3: return bd_launch_search_t<FMT, QB, EXP, 3, false>(L, grid, st);
+    default: return bd_launch_search_t<FMT, QB, EXP, 4, false>(L, grid, st);
     }
 }
 
 static int bd_launch_search(const BmLaunch &L, unsigned grid, bool cells, bool blocks, hipStream_t st)
 {
+    if (cells && g_opt_bd_exp == 3) return bd_launch_search_d<1, false, 3>(L, grid, st);
     if (cells) return g_opt_bd_exp == 1 ? bd_launch_search_d<1, false, 1>(L, grid, st) : bd_launch_search_d<1, false, 0>(L, grid, st);
+    if (g_opt_bd_exp == 3) return bd_launch_search_d<0, false, 3>(L, grid, st);
     if (g_opt_bd_exp == 1) return blocks ? bd_launch_search_d<0, true, 1>(L, grid, st) : bd_launch_search_d<0, false, 1>(L, grid, st);
-    if (g_opt_bd_exp == 2) return blocks ? bd_launch_search_d<0, true, 2>(L, grid, st) : bd_launch_search_d<0, false, 2>(L, grid, st);
     return blocks ? bd_launch_search_d<0, true, 0>(L, grid, st) : bd_launch_search_d<0, false, 0>(L, grid, st);
 }
 
@@ -3056,8 +3077,17 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         hipLaunchKernelGGL(bm_sorted_check_kernel, dim3(2048), dim3(256), 0, st, qs[0], nq[0], unsorted);
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
-        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)div_up(nq[0], LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
-                           h->e_sorted.as<int32_t>(), qs[0], qe[0], nq[0], counts[0], tslots, unsorted);
+        if (!h->sort_hint) {
+            BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->sort_hint), 64, hipHostMallocMapped));
+            *h->sort_hint = 0u;
+        }
+        const int64_t nchunks = div_up(nq[0], LC_CHUNK);
+        if (*reinterpret_cast<volatile unsigned *>(h->sort_hint) != 0u && nchunks > 1024)  // the batch before was not sorted: expect the same
+            hipLaunchKernelGGL(ivl_local_count_kernel<true>, dim3(1024), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(), qs[0], qe[0],
+                               nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->sort_hint);
+        else
+            hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(),
+                               qs[0], qe[0], nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->sort_hint);
         BXMI_LAUNCH_CHECK();
     }
     if (variant == 2)
@@ -3069,8 +3099,12 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (dense) {
         hipLaunchKernelGGL(bd_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                            tile_log2, h->bd_unitT.as<unsigned short>(), ntp, h->sl_unitcnt.as<unsigned>(), unsorted);
-        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
-                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
+        if (n == 1)
+            hipLaunchKernelGGL(bd_plan_kernel, dim3(1), dim3(1024), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, BM_NB >> segs[0].g.f, L.segs, chunk,
+                               h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
+        else
+            hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg,
+                               chunk, h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     } else {
     hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                        tile_log2, h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
@@ -3223,6 +3257,7 @@ extern "C" int bxmi_ivl_destroy(bxmi_ivl_t *h)
     if (!h) return BXMI_OK;
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->one_buf) (void)hipHostFree(h->one_buf);
+    if (h->sort_hint) (void)hipHostFree(h->sort_hint);
     delete h;
     return BXMI_OK;
 }

@@ -37,7 +37,7 @@ def set_opt(key, value):
 
 DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
                 "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 1, "ivl.bm_exp": 0, "ivl.slice": -1, "ivl.sl_f": -1,
-                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.bd_depth": 4, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 19, "ivl.bd_blocks": 0,
+                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.bd_depth": 4, "ivl.bd_pipe": 1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 19, "ivl.bd_blocks": 0,
                 "ivl.bm_chunk": 0}
 
 
@@ -429,13 +429,13 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
             set_opt("ivl.dense", 1)
             if shape == "dups" and stage == "flat":
                 set_opt("ivl.bm_hard_ppm", 10**6)  # (two cells' worth of piled-up coordinates and 60 000 repeated starts: keep the cells anyway)
-            for k, (variant, chunk, depth, exp, blocks) in enumerate(((0, 0, 4, 0, 0), (1, 4096, 2, 2, 1), (2, 1 << 20, 3, 0, 1), (-1, 20000, 4, 2, 0),
-                                                                      (0, 1024, 2, 0, 0))):
+            for k, (variant, chunk, depth, pipe, blocks) in enumerate(((0, 0, 4, 1, 0), (1, 4096, 2, 0, 1), (2, 1 << 20, 3, 1, 1), (-1, 20000, 4, 0, 0),
+                                                                      (0, 1024, 2, 1, 0))):
                 set_opt("ivl.sorted_path", k % 2)
                 set_opt("ivl.bm_variant", variant)
                 set_opt("ivl.bd_chunk", chunk)
                 set_opt("ivl.bd_depth", depth)
-                set_opt("ivl.bd_exp", exp if stage == "dense" else 0)
+                set_opt("ivl.bd_pipe", pipe)
                 if stage == "dense" and blocks != ix_blocks[0]:
                     set_opt("ivl.bd_blocks", blocks)
                     ix.seal()  # (the rank base of the images is decided when the index is prepared)
@@ -445,7 +445,7 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                 assert state[0] == 1 and ix.bitmap_state()[0] == 0 and ix.slice_state()[0] == 0, (state, ix.bitmap_state(), ix.slice_state())
                 assert (ix.flat_state()[0] == 0) == (stage == "dense")
                 bad = np.nonzero(got != want)[0]
-                assert len(bad) == 0, (shape, stage, variant, chunk, depth, exp, blocks, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+                assert len(bad) == 0, (shape, stage, variant, chunk, depth, pipe, blocks, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
                 assert got_total == want_total
             if shape == "dups":
                 assert (state[1][1] > 100) if stage == "dense" else (state[1] > 0)  # overflow entries / hard cells
