@@ -22,7 +22,9 @@ Coordinates are C ints, as everywhere in the engine.
 """
 import numpy as np
 
+from bx.bitset import _cint
 from bx.intervals.intersection import _Core
+from bxmi._ffi import as_i32
 
 __all__ = ["IntervalTree", "IntervalNode"]
 
@@ -52,11 +54,14 @@ class _Chrom:
         return len(self._core)
 
     def insert(self, start, end, linenum=0, other=None):
+        # (the device index holds C ints: a coordinate beyond them raises here, as everywhere else in the overlay,
+        # instead of wrapping around on its way through ctypes)
+        start, end = _cint(start), _cint(end)
         self._core.insert(start, end, IntervalNode(start, end, linenum, other))
         return self
 
     def intersect(self, start, end, report_func):
-        for node in self._core.find(start, end):
+        for node in self._core.find(_cint(start), _cint(end)):
             report_func(node)
 
     def traverse(self, func):
@@ -69,7 +74,7 @@ class _Chrom:
         """-> (offsets int64[nq+1], list of node views): query k's hits are nodes[offsets[k]:offsets[k+1]]."""
         core = self._core
         core._flush()
-        off, hits = core.index.find(np.asarray(starts, dtype=np.int32), np.asarray(ends, dtype=np.int32))
+        off, hits = core.index.find(as_i32(starts), as_i32(ends))
         vals = core.values
         return off, [vals[i] for i in hits.tolist()]
 

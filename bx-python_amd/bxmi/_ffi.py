@@ -121,11 +121,19 @@ def load():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
+        # BXMI_OPTS="ivl.bm_u=4,bits.grid=512": tuning knobs for A/B runs of unmodified scripts (results never depend on them).
+        # All of them are parsed and applied before the library is published: a malformed entry fails every load().
+        for kv in filter(None, (x.strip() for x in os.environ.get("BXMI_OPTS", "").split(","))):
+            key, eq, value = kv.partition("=")
+            try:
+                number = int(value)
+            except ValueError:
+                number = None
+            if not eq or not key.strip() or number is None:
+                raise BxmiError(EINVAL, "BXMI_OPTS: %r is not key=integer" % kv)
+            if L.bxmi_set_option(key.strip().encode(), number) != OK:
+                raise BxmiError(EINVAL, "BXMI_OPTS: %s" % L.bxmi_last_error().decode(errors="replace"))
         _lib = L
-        # BXMI_OPTS="ivl.bm_u=4,bits.grid=512": tuning knobs for A/B runs of unmodified scripts (results never depend on them)
-        for kv in filter(None, os.environ.get("BXMI_OPTS", "").split(",")):
-            key, _, value = kv.partition("=")
-            check(L.bxmi_set_option(key.strip().encode(), int(value)))
     return _lib
 
 

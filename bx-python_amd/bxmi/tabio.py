@@ -73,9 +73,13 @@ class ParsedTable:
 def parse_input(source, chrom_col, start_col, end_col, strand_col, prefixes):
     """ParsedTable for a list / tuple of '\\n'-terminated lines or a text file at its beginning; None for anything else
     (generators, pipes, lines without line ends, non-ASCII prefixes ...) or when nothing could be consumed."""
+    is_file = False
     try:
         prefixes = [str(p) for p in prefixes]
-        if any(not p or not p.isascii() for p in prefixes):
+        if any(not p or not p.isascii() or "\0" in p for p in prefixes):
+            return None
+        # the native parser takes column NUMBERS; the per-line code also accepts Python's negative indices
+        if min(int(chrom_col), int(start_col), int(end_col)) < 0 or (strand_col is not None and int(strand_col) < -1):
             return None
         if isinstance(source, (list, tuple)):
             if not source or not all(type(x) is str for x in source):
@@ -93,10 +97,16 @@ def parse_input(source, chrom_col, start_col, end_col, strand_col, prefixes):
             data = bedio.file_bytes(source)
             if data is None:
                 return None
+            is_file = True  # (drained: whatever happens from here on, the per-line code must find the file at its beginning)
             table = ParsedTable(data, chrom_col, start_col, end_col, strand_col, prefixes, source_file=source)
             if table.n == 0:
                 source.seek(0)  # nothing taken: the per-line code reads the file itself
                 return None
         return table if table.n else None
     except (_ffi.BxmiError, OSError, ValueError):
+        if is_file:
+            try:
+                source.seek(0)
+            except (OSError, ValueError):
+                pass
         return None

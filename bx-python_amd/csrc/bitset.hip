@@ -663,7 +663,10 @@ static int bits_need(bxmi_bits *h, int64_t upto_bits /* exclusive; BITS_ALL = th
     if (e != hipSuccess)
         return fail(BXMI_ENOMEM, "BinnedBitSet of %d bits: no room for %zu MiB of words on the device (%s); every set holds dense words up "
                     "to its highest set bit -- size the sets with `lens` instead of the 512 Mi default", h->size, bytes >> 20, hipGetErrorString(e));
-    if (h->cap_words) e = hipMemcpy(np, h->words.p, (size_t)h->cap_words * 8, hipMemcpyDeviceToDevice);
+    // The old words may still be written by stream-ordered work on a caller's non-blocking stream (a `_dev` call queued
+    // before this one): growing is rare, so the whole device drains before the words move.
+    if (h->cap_words) e = hipDeviceSynchronize();
+    if (e == hipSuccess && h->cap_words) e = hipMemcpy(np, h->words.p, (size_t)h->cap_words * 8, hipMemcpyDeviceToDevice);
     if (e == hipSuccess) e = hipMemset(static_cast<char *>(np) + (size_t)h->cap_words * 8, 0, bytes - (size_t)h->cap_words * 8);
     if (e != hipSuccess) {
         (void)hipFree(np);

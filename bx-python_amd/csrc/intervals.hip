@@ -3552,7 +3552,10 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
         bxmi_ivl *h = hs[i];
         if (nq[i] == 0) continue;
         int kind = 0;
-        if (fused && counts[i]) BXMI_TRY(bm_choose_stage(h, st, &kind));
+        // a segment occupies whole groups of 64 tiles of scratch whatever its size: in a batch over hundreds of indexes
+        // (a scaffold-level assembly) the ones with a handful of queries are answered one by one instead
+        const bool tiny = n > 256 && nq[i] < 65536;
+        if (fused && counts[i] && !tiny) BXMI_TRY(bm_choose_stage(h, st, &kind));
         if (kind) {
             const int k = kind - 1;
             fh[k].push_back(h), fqs[k].push_back(qs[i]), fqe[k].push_back(qe[i]), fnq[k].push_back(nq[i]), fc[k].push_back(counts[i]);
