@@ -453,7 +453,8 @@ def source_stamps():
         return h.hexdigest()[:16]
 
     csrc = os.path.join(ROOT, "bx-python_amd", "csrc")
-    kernels = [os.path.join(csrc, f) for f in ("common.hpp", "primitives.hpp", "count_bitmap.hpp", "count_slices.hpp", "intervals.hip")]  # what the count pass is made of
+    kernels = [os.path.join(csrc, f) for f in ("common.hpp", "primitives.hpp", "count_bitmap.hpp", "count_slices.hpp", "count_dense.hpp",
+                                               "intervals.hip")]  # what the count pass is made of
     return dict(bench_sha16=sha([os.path.join(ROOT, "bench.py")]), kernel_sha16=sha(kernels))
 
 
@@ -477,11 +478,11 @@ def main():
                     "dismiss the bucketed kernels at once and would halve their average durations)")
     ap.add_argument("--allreduce-total", type=int, default=1, help="all-reduce the int64 overlap total each step when --gpus > 1")
     ap.add_argument("--workload", choices=["auto", "count", "genome"], default="auto",
-                    help="count = configs[1] (100M x 10M, one chromosome); genome = configs[3] (24 chromosomes sharded by LPT, strong scaling); "
-                         "auto = count on one GPU (with the genome as a side measurement), genome on several")
-    ap.add_argument("--weak", action="store_true", help="with --workload count on several GPUs: every rank its own 100M queries against a replica "
-                    "of the index (weak scaling, round 1's multi-GPU mode)")
-    ap.add_argument("--no-genome", action="store_true", help="skip the configs[3] side measurement of the one-GPU line")
+                    help="count (= auto) = configs[1] at EVERY N: each rank its own 100M queries against a replica of the 10M-target index, weak "
+                         "scaling, the same metric and per-GPU work whatever --gpus is; the genome (configs[3], 24 chromosomes dealt to the ranks "
+                         "by LPT, strong scaling) rides the same line as the `genome` object.  genome = that leg alone as the top-level line.")
+    ap.add_argument("--weak", action="store_true", help="(accepted for compatibility: --workload count is weak scaling at every N)")
+    ap.add_argument("--no-genome", action="store_true", help="skip the configs[3] leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -512,9 +513,8 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    workload = args.workload if args.workload != "auto" else ("count" if world == 1 else "genome")
-    if workload == "count" and world > 1 and not args.weak:
-        log("note: --workload count on %d GPUs is the weak-scaling mode (every rank its own 100M queries); say --weak to silence this" % world)
+    # The top-level line is configs[1] at every N (a 1 -> 8 curve must compare one workload with itself).
+    workload = "count" if args.workload == "auto" else args.workload
     if workload == "genome":
         g = bench_genome(torch, dist, rank, world, args.steps, args.warmup, args.targets, args.queries)
         if rank == 0:
@@ -655,6 +655,18 @@ def main():
                         same_total_as_unsorted=bool(same), kernel="bm_sorted_check (detects the order) + ivl_local_count_kernel")
         del sqs, sqe, scounts
 
+    stages = dict(zip(("flat_walk_on_cell_images", "dense_unit_images", "bucket_pair_images", "key_slices"),
+                      (ix.flat_state()[0], ix.dense_state()[0], ix.bitmap_state()[0], ix.slice_state()[0])))
+    # configs[3] on all the ranks of this job (strong scaling, chromosomes dealt by LPT, totals all-reduced): a collective
+    # leg, so every rank walks through it; rank 0 keeps the result for the line
+    genome_leg = None
+    if world > 1 and not args.no_genome:
+        del qs, qe, counts
+        torch.cuda.empty_cache()
+        try:
+            genome_leg = bench_genome(torch, dist, rank, world, max(5, args.steps), args.warmup, args.targets, args.queries)
+        except Exception as ex:  # (a rank that fails here would hang the others in the collective: let it surface)
+            raise
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -691,8 +703,10 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
-            "kernel": ("count pass = bm_sorted_check + bm_tile_sort + bm_transpose + bm_plan + bm_search_pipe + bm_unpermute "
-                       "(dominant: bm_search_pipe_kernel)" if partitioned else "ivl_count_kernel"),
+            "kernel": ("count pass = bm_params + bm_sorted_check + ivl_local_count (stands down) + bm_tile_sort + bd_transpose + bd_plan + "
+                       "bd_search (the flat 16-byte walk on cell images of 2^18-coordinate units) + bd_unpermute (16-bit counts) + bm_fold_totals; "
+                       "dominant: bd_search_kernel" if partitioned else "ivl_count_kernel"),
+            "search_stage_of_this_index": stages,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
             "timed_with": "HIP events on the launch stream around every bxmi_ivl_count_dev call of the timed region",
         },
@@ -762,6 +776,8 @@ def main():
             line["genome"] = bench_genome(torch, dist, 0, 1, max(5, args.steps), args.warmup, args.targets, args.queries)
         except Exception as ex:
             line["genome"] = {"error": repr(ex)}
+    if genome_leg is not None:
+        line["genome"] = genome_leg
     if world == 1 and not args.no_find:
         try:
             line["per_call_latency"] = bench_per_call()

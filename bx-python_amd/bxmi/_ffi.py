@@ -92,6 +92,10 @@ _SIGNATURES = {
     "bxmi_tab_destroy": [vp],
     "bxmi_tab_info": [vp, _p(i64), _p(i32), _p(i64)],
     "bxmi_tab_columns": [vp, _p(vp), _p(vp), _p(vp), _p(vp), _p(vp), _p(vp), _p(vp)],
+    "bxmi_comm_unique_id": [vp],
+    "bxmi_comm_create": [_p(vp), vp, C.c_int, C.c_int],
+    "bxmi_comm_destroy": [vp],
+    "bxmi_allreduce_i64": [vp, vp, i64, vp],
     "bxmi_bits_group_create": [_p(vp), C.c_int, _p(vp)],
     "bxmi_bits_group_destroy": [vp],
     "bxmi_bits_group_and_dev": [vp, vp, vp, vp],

@@ -54,6 +54,53 @@ def allreduce_counts(per_key, keys, device=None):
     return dict(zip(keys, vec.tolist()))
 
 
+class Comm:
+    """The C ABI's collective (include/bxmi.h: bxmi_comm_* / bxmi_allreduce_i64, RCCL underneath): what a host without
+    torch would use.  `exchange(bytes_or_None) -> bytes` carries rank 0's 128-byte id to the other ranks -- any channel
+    the launcher offers; with torch.distributed initialised, `Comm.from_torch()` broadcasts it there."""
+
+    def __init__(self, rank, world, exchange):
+        import ctypes as C
+
+        from . import _ffi
+
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            _ffi.call("bxmi_comm_unique_id", ident)
+        raw = exchange(ident.raw if rank == 0 else None)
+        ident = C.create_string_buffer(bytes(raw), 128)
+        h = C.c_void_p()
+        _ffi.call("bxmi_comm_create", C.byref(h), ident, rank, world)
+        self._h, self.rank, self.world = h, rank, world
+
+    @classmethod
+    def from_torch(cls):
+        import torch
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def exchange(raw):
+            box = [raw]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        return cls(rank, world, exchange)
+
+    def allreduce_i64(self, dev_ptr, n, stream=None):
+        """In place on `n` int64 at device address `dev_ptr`, ordered on `stream`."""
+        from . import _ffi
+
+        _ffi.call("bxmi_allreduce_i64", self._h, dev_ptr, n, stream)
+
+    def close(self):
+        from . import _ffi
+
+        if self._h:
+            _ffi.call("bxmi_comm_destroy", self._h)
+            self._h = None
+
+
 def gather_concat(arr, rank_order_key=None):
     """Host-side concatenation of per-rank int arrays in rank order (hit lists / per-query counts)."""
     import torch.distributed as dist

@@ -45,6 +45,33 @@ def cfg5(n_targets=50_000_000, n_queries=50_000_000):
     )
 
 
+def clustered(n_targets=10_000_000, n_queries=100_000_000, hot_spots=20_000, genome=250_000_000, seed=601, sort_queries=False):
+    """Non-uniform counterpart of cfg2: everything sits around `hot_spots` places (exons, peaks).  A
+    target's start is its hot spot + a small offset drawn from a geometric distribution (many targets share a start),
+    its length one of a few dozen values, so coordinates are duplicated heavily; queries are drawn the same way with
+    wider scatter.  -> ((target_start, target_end), (query_start, query_end)) int32, queries in generated order (or
+    sorted by start, as a sorted BED file arrives)."""
+    rng = np.random.default_rng(seed)
+    centres = np.sort(rng.integers(10_000, genome - 10_000, size=hot_spots, dtype=np.int64))
+    # some hot spots are several times busier than others
+    weight = rng.lognormal(0.0, 0.6, size=hot_spots)
+    weight /= weight.sum()
+    lengths = rng.integers(30, 2000, size=48, dtype=np.int64)
+
+    def draw(n, scatter):
+        k = rng.choice(hot_spots, size=n, p=weight)
+        start = centres[k] + rng.geometric(1.0 / scatter, size=n) - 1
+        length = lengths[rng.integers(0, len(lengths), size=n)]
+        return start.astype(np.int32), (start + length).astype(np.int32)
+
+    ts, te = draw(n_targets, 60.0)
+    qs, qe = draw(n_queries, 400.0)
+    if sort_queries:
+        o = np.argsort(qs, kind="stable")
+        qs, qe = qs[o], qe[o]
+    return (ts, te), (qs, qe)
+
+
 def cfg4_sizes(n_total, sizes=None):
     """Intervals per chromosome for a set of n_total placed proportionally to chromosome length (rounded per chromosome)."""
     sizes = sizes or HG19_SIZES

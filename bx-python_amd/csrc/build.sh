@@ -11,7 +11,7 @@ mkdir -p "$OBJ"
 # a change of flags (BXMI_DEFS experiments) must rebuild everything
 if [ "$(cat "$OBJ/.flags" 2>/dev/null)" != "$FLAGS" ]; then rm -f "$OBJ"/*.o; echo "$FLAGS" > "$OBJ/.flags"; fi
 pids=()
-for f in core intervals bitset bedparse; do
+for f in core intervals bitset bedparse comm; do
   src="$HERE/$f.hip"; [ -f "$src" ] || src="$HERE/$f.cpp"
   if [ ! -f "$OBJ/$f.o" ] || [ "$src" -nt "$OBJ/$f.o" ] || [ "$HERE/common.hpp" -nt "$OBJ/$f.o" ] \
      || [ "$HERE/primitives.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_bitmap.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_slices.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_dense.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/bxmi.h" -nt "$OBJ/$f.o" ]; then
@@ -20,5 +20,5 @@ for f in core intervals bitset bedparse; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/core.o" "$OBJ/intervals.o" "$OBJ/bitset.o" "$OBJ/bedparse.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ/core.o" "$OBJ/intervals.o" "$OBJ/bitset.o" "$OBJ/bedparse.o" "$OBJ/comm.o" -ldl
 echo "built $OUT"

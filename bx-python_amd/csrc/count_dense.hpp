@@ -493,6 +493,9 @@ struct BdImage {
     int eLo, sLo;
     long long lo;
     const int32_t *s_ord, *e_sorted;
+    // key slices (FMT 2: count_slices.hpp's staged unit; sparse indexes, duplicated coordinates of any kind)
+    SlUnit sl;
+    BmGeom g;
 };
 
 // FMT 1: the count of one record from a unit's cell image (bm_count_record for units; 16 bits, 0xFFFF = ask the index again)
@@ -559,7 +562,7 @@ __device__ __forceinline__ unsigned bd_count16(int bias, int rS, int rE, unsigne
 // same -- any 32-bit word is a safe argument, the offset is masked to the unit and the length cannot leave the margin --
 // and not stored)
 // EXP (diagnostics, ivl.bd_exp; wrong results): 1 = no lookups at all -- the price of the walk and of its memory traffic alone
-// FMT: 0 = dense unit image, 1 = cell image
+// FMT: 0 = dense unit image, 1 = cell image, 2 = staged key slices
 template <int FMT, bool QB, int EXP>
 __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short *__restrict__ out, unsigned idx4, unsigned valid, bd_v4u v)
 {
@@ -572,6 +575,14 @@ __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short 
     } else if (FMT == 1) {
 #pragma unroll
         for (int j = 0; j < 4; j++) c[j] = bp_count_record(I, rec[j]);
+    } else if (FMT == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // (a neighbouring unit's record is a valid argument: its offset lies inside the unit's width, the directory
+            // lookups stay inside the staged arrays)
+            const unsigned x = sl_count_record(I.sl, I.g, rec[j]);
+            c[j] = x < 0xFFFFu ? x : 0xFFFFu;  // (BM_REC_ESC included)
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -636,6 +647,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     __shared__ uint2 s_long[BD_LONG_CAP];  // {first record, length} of the long runs met during the walk
     __shared__ int s_nlong, s_next;
+    __shared__ int s_tmp[20];  // FMT 2: sl_stage_unit's scratch
     const int nit = *n_items;
     const int per_xcd = (nit + 7) >> 3;
     const int slot = (int)(blockIdx.x >> 3);
@@ -670,7 +682,11 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         e_nx = t < t1 ? e : 0u;
     };
     load_runs(tb);
-    {
+    BdImage I;
+    if (FMT == 2) {
+        I.sl = sl_stage_unit(sg, unit, dyn, s_tmp);
+        I.g = g;
+    } else {
         // the image (streams through L2 once: non-temporal loads); every load of a lane issued before its first LDS store
         const bm_v4i *src = reinterpret_cast<const bm_v4i *>((FMT == 1 ? sg.pimages : sg.dimages) + (size_t)unit * image_bytes);
         const int n4 = image_bytes >> 4;
@@ -690,8 +706,8 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         }
     }
     __syncthreads();
-    BdImage I;
-    if (FMT == 1) {
+    if (FMT == 2) {
+    } else if (FMT == 1) {
         unsigned char *base = reinterpret_cast<unsigned char *>(dyn);
         I.cE = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsE);
         I.cS = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsS);

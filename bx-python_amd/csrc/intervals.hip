@@ -2133,6 +2133,7 @@ static int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_C
 static int64_t g_opt_sl_hu_parts = 1;  // hit un-permute: workgroups per tile (1, 2, 4, 8, 16), run back to back on one XCD
 static int64_t g_opt_sl_run_cap = 160;  // a slice unit grows only while its expected (tile, unit) run stays within this many records
 static int64_t g_opt_find_pairs = 1;   // sorted find(): the fill reads (end, index) pairs (one array) instead of the two index arrays
+static int64_t g_opt_sl_flat = 1;      // 1 = count-only passes on key slices take the flat 16-byte walk of count_dense.hpp (16-bit counts, unit run table), 0 = the 16 / 64 lanes-per-run kernels of count_slices.hpp
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
@@ -2238,6 +2239,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.find_pairs")) {
         g_opt_find_pairs = value != 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.sl_flat")) {
+        g_opt_sl_flat = value != 0;
         return 1;
     }
     if (!strcmp(key, "ivl.sl_rbits")) {
@@ -2727,7 +2732,7 @@ static int sl_prepare_index(bxmi_ivl *h, hipStream_t st)
 
 // The slice geometry of one index for a batch with `tile` queries per tile: the unit grows while its keys fit, its
 // offsets leave 12 bits for the record's length, and its runs stay short enough for one pass of a wave.
-static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_t *run_len)
+static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_t *run_len, bool flat_walk = false)
 {
     BmGeom g;
     g.cmin = h->geom.cmin, g.cmax = h->cmax, g.shift = h->geom.shift;
@@ -2741,7 +2746,8 @@ static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_
             // ... and while a (tile, unit) run of a uniform batch stays within ~2.5 waves: longer runs go through the
             // leftover passes / the workgroup's long-run list, which cost small chromosomes (narrow buckets, f = 5)
             // 15 % of the genome pass
-            if (h->sl_need[k] > (unsigned)SL_CAP || g.shift + k > g_opt_sl_rbits || (tile << k) / nb_used > g_opt_sl_run_cap) break;
+            // (the flat walk keeps every lane busy whatever the run length: the longer the better)
+            if (h->sl_need[k] > (unsigned)SL_CAP || g.shift + k > g_opt_sl_rbits || (!flat_walk && (tile << k) / nb_used > g_opt_sl_run_cap)) break;
             f = k;
         }
     }
@@ -2941,8 +2947,10 @@ static int bd_launch_search_d(const BmLaunch &L, unsigned grid, hipStream_t st)
     }
 }
 
-static int bd_launch_search(const BmLaunch &L, unsigned grid, bool cells, bool blocks, hipStream_t st)
+static int bd_launch_search(const BmLaunch &L, unsigned grid, int fmt /* 0 dense, 1 cells, 2 slices */, bool blocks, hipStream_t st)
 {
+    if (fmt == 2) return bd_launch_search_d<2, false, 0>(L, grid, st);
+    const bool cells = fmt == 1;
     if (cells && g_opt_bd_exp == 3) return bd_launch_search_d<1, false, 3>(L, grid, st);
     if (cells) return g_opt_bd_exp == 1 ? bd_launch_search_d<1, false, 1>(L, grid, st) : bd_launch_search_d<1, false, 0>(L, grid, st);
     if (g_opt_bd_exp == 3) return bd_launch_search_d<0, false, 3>(L, grid, st);
@@ -2968,7 +2976,9 @@ static int bd_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hip
 static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
                              int32_t *const *counts, int64_t *const *totals_dev, hipStream_t st, int kind = 1, BmFindCtx *fx = nullptr)
 {
-    const bool slices = kind == 2, cells = kind == 4, dense = kind == 3 || cells /* the flat walk */, units = slices || dense;
+    const bool slices = kind == 2, cells = kind == 4;
+    const bool slices_flat = slices && !fx && g_opt_sl_flat != 0;  // (find() needs 32-bit counts apart from the records and the tile-sorted offsets)
+    const bool dense = kind == 3 || cells || slices_flat /* the flat walk */, units = slices || dense;
     bxmi_ivl *h = hs[0];
     int64_t nq_all = 0;
     for (int i = 0; i < n; i++) nq_all += nq[i];
@@ -2991,7 +3001,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         if (slices) {
             size_t lds = 0;
             int64_t run_len = 0;
-            sg.g = sl_geom(hs[i], tile, &lds, &run_len);
+            sg.g = sl_geom(hs[i], tile, &lds, &run_len, slices_flat);
             if (lds > sl_lds) sl_lds = lds;
             if (run_len < sl_run) sl_run = run_len;
         } else if (cells) {
@@ -3021,7 +3031,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     const int ngroups = (int)(ntp / BM_GROUP_TILES);
     // PAIR: a search workgroup holds the images of two neighbouring buckets (needs both in one CU's LDS)
     const bool pair = !units && g_opt_bm_pair != 0 && 2 * max_stride * sizeof(uint2) + 8192 <= 160 * 1024;
-    const int chunk = dense ? (g_opt_bd_chunk ? (int)g_opt_bd_chunk : (cells ? 2 : 4) * BM_CHUNK) : g_opt_bm_chunk ? (int)g_opt_bm_chunk : (pair ? 2 * BM_CHUNK : BM_CHUNK);
+    const int chunk = dense ? (g_opt_bd_chunk ? (int)g_opt_bd_chunk : (cells || slices_flat ? 2 : 4) * BM_CHUNK) : g_opt_bm_chunk ? (int)g_opt_bm_chunk : (pair ? 2 * BM_CHUNK : BM_CHUNK);
     int64_t max_items = (int64_t)n * ((pair ? BM_NB / 2 : BM_NB) + 2) + 2 * (nq_all / chunk) + 2;
     if (dense) {  // every segment has at most BM_NB >> f units; empty workgroups of 157 KB of LDS are not free
         max_items = 2 * (nq_all / chunk) + 2;
@@ -3070,6 +3080,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.owner = h;
     L.ntp = ntp, L.ngroups = ngroups, L.tile_log2 = tile_log2;
     L.search_lds = slices ? sl_lds : dense ? max_stride * 16 : (size_t)(pair ? 2 : 1) * max_stride * sizeof(uint2);
+    if (slices_flat && L.search_lds < 4096) L.search_lds = 4096;
     L.gate = unsorted;
     if (unsorted) {
         // one index, its batch possibly sorted by start already: one pass over the queries as they lie then, and every
@@ -3122,7 +3133,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     }
     BXMI_LAUNCH_CHECK();
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
-    if (slices) {
+    if (slices_flat)
+        BXMI_TRY(bd_launch_search(L, sgrid, 2, false, st));
+    else if (slices) {
         // long runs (sparse index, big units): the flat walk; else L lanes per run
         int lanes = g_opt_sl_lanes < 0 ? 0 : (g_opt_sl_lanes ? (int)g_opt_sl_lanes : (sl_run >= 96 ? 0 : (sl_run >= 40 ? 64 : 16)));
         if (fx && lanes == 0) lanes = 64;  // (the fill half has no flat walk)
@@ -3134,7 +3147,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
             BXMI_TRY(sl_launch_search<16>(L, sgrid, st, search_out));
         if (fx) fx->L = L, fx->sgrid = sgrid, fx->lanes = lanes, fx->variant = variant;
     } else if (dense)
-        BXMI_TRY(bd_launch_search(L, sgrid, cells, any_blocks, st));
+        BXMI_TRY(bd_launch_search(L, sgrid, cells ? 1 : 0, any_blocks, st));
     else if (pair)
         BXMI_TRY(bm_launch_search_u<true>(L, sgrid, st));
     else

@@ -253,6 +253,19 @@ int bxmi_tab_columns(const bxmi_tab_t *b, const uint8_t **kind, const int64_t **
                      const int64_t **start, const int64_t **end, const uint8_t **strand);
 const char *bxmi_tab_chrom_name(const bxmi_tab_t *b, int32_t id);
 
+/* ---- the path's only collective (multi-GPU, one process per GPU) ---------------------------
+ * Intervals on different chromosomes never meet (scripts/interval_join.py:21-28 keeps one tree per chromosome,
+ * lib/bx/bitset_builders.py:31-45 one bitset), so a genome is sharded by chromosome with NO data-path exchange; what
+ * the ranks do exchange is the vector of per-chromosome overlap totals: an int64 sum all-reduce, RCCL over xGMI.
+ * rank 0 makes the 128-byte id and hands it to the others through whatever launched them; every rank then creates
+ * its communicator on its CURRENT device.  bxmi_allreduce_i64 works in place on device memory, ordered on `stream`.
+ * librccl.so is opened on first use; without it these four calls fail with BXMI_EHIP and nothing else is affected. */
+typedef struct bxmi_comm bxmi_comm_t;
+int bxmi_comm_unique_id(void *id128);
+int bxmi_comm_create(bxmi_comm_t **out, const void *id128, int rank, int world);
+int bxmi_comm_destroy(bxmi_comm_t *c);
+int bxmi_allreduce_i64(bxmi_comm_t *c, int64_t *buf_dev, int64_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

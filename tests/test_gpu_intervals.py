@@ -37,7 +37,7 @@ def set_opt(key, value):
 
 DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
                 "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 1, "ivl.bm_exp": 0, "ivl.slice": -1, "ivl.sl_f": -1,
-                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.bd_depth": 4, "ivl.bd_pipe": 1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 19, "ivl.bd_blocks": 0,
+                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 4, "ivl.bd_pipe": 1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 19, "ivl.bd_blocks": 0,
                 "ivl.bm_chunk": 0}
 
 
@@ -461,6 +461,7 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                 set_opt("ivl.bm_variant", variant)
                 set_opt("ivl.sl_f", f)
                 set_opt("ivl.sl_lanes", lanes)
+                set_opt("ivl.sl_flat", (k >> 1) & 1)  # the flat 16-byte walk of count_dense.hpp, or the lanes-per-run kernels
                 got, got_total = ix.count(qs, qe)
                 state = ix.slice_state()
                 assert state[0] == 1 and ix.bitmap_state()[0] == 0, (state, ix.bitmap_state())
@@ -762,6 +763,24 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
     # monotonicity: widening a query never loses hits
     wide, _ = ix.count(qs[:1_000_000] - 100, qe[:1_000_000] + 100)
     assert (wide >= counts[:1_000_000]).all()
+
+
+def test_c_abi_allreduce_world_of_one():
+    """bxmi_comm_* / bxmi_allreduce_i64 (RCCL opened at first use): a communicator of one rank on this GPU; the sum
+    all-reduce of int64 totals in place is then the identity, stream-ordered behind the kernel that produced them.  (Two
+    ranks need two GPUs: RCCL refuses a second rank on the same device.  The 2-rank bookkeeping is the gloo test.)"""
+    from bxmi import _ffi, shard
+
+    comm = shard.Comm(0, 1, lambda raw: raw)
+    vals = np.array([5, -7, 2**40, 0, 123456789012], dtype=np.int64)
+    buf = _ffi.DeviceArray.from_numpy(vals)
+    comm.allreduce_i64(buf.ptr, len(vals))
+    _ffi.call("bxmi_synchronize", None)
+    assert buf.to_numpy(np.int64, len(vals)).tolist() == vals.tolist()
+    comm.allreduce_i64(buf.ptr, 0)
+    comm.close()
+    with pytest.raises(_ffi.BxmiError):
+        _ffi.call("bxmi_comm_create", _ffi.C.byref(_ffi.vp()), None, 0, 1)
 
 
 def test_genome_sharded_count_single_rank():
