@@ -55,10 +55,14 @@ class _Queued:
         self._ps, self._pc = [], []
         self._runs = None  # (from_pos, run_starts list, run_ends list)
         self._scans = 0  # next_* calls since the last mutation
+        self._mirror = None  # (run_starts, run_ends, bits before each run, per-bin states or None): see _count
+        self._reads = 0  # count_range calls since the last mutation
 
     def _touch(self):
         self._runs = None
         self._scans = 0
+        self._mirror = None
+        self._reads = 0
 
     def _flush(self):
         if self._ps:
@@ -71,6 +75,8 @@ class _Queued:
         self._pc.append(count)
         self._runs = None
         self._scans = 0
+        self._mirror = None
+        self._reads = 0
         if len(self._ps) >= _FLUSH_AT:
             self._flush()
 
@@ -93,6 +99,46 @@ class _Queued:
         if i < len(rs) and rs[i] <= start:
             return re[i]  # inside a run: first clear bit is its end (== size when it runs to the end)
         return start
+
+    def _count(self, start, count, binned):
+        """count_range behind a read-only phase (scripts/bed_intersect.py:46-60 asks once per line and never writes
+        again): the first calls after a mutation go to the device one by one; from the third on the set's RUN LIST --
+        extracted on the device once, what next_set / next_clear already walk -- answers them: two bisections and a
+        subtraction, nothing crosses PCIe.  A run list describes the logical bits; what the reference makes observable
+        on top of them is the first bin's offset when that bin is ALL_ONE (binBits.c:155,161), taken from the per-bin
+        states.  Any mutation drops the list (_touch / _queue)."""
+        m = self._mirror
+        if m is None:
+            self._reads += 1
+            if self._reads < 3:
+                return self._d.count_range_checked(start, count)
+            rs, re = self._d.runs(0)
+            rs, re = rs.tolist(), re.tolist()
+            before, acc = [0] * (len(rs) + 1), 0
+            for i in range(len(rs)):
+                acc += re[i] - rs[i]
+                before[i + 1] = acc
+            m = self._mirror = (rs, re, before, bytes(self._d.bin_states()) if binned else None)
+            self._runs = (0, rs, re)
+        if count <= 0:
+            return 0
+        rs, re, before, states = m
+        end = start + count
+        i0 = bisect.bisect_right(re, start)  # first run that ends after `start`
+        i1 = bisect.bisect_left(rs, end)     # first run that starts at or after `end`
+        n = 0
+        if i1 > i0:
+            n = before[i1] - before[i0]
+            if rs[i0] < start:
+                n -= start - rs[i0]
+            if re[i1 - 1] > end:
+                n -= re[i1 - 1] - end
+        if states is not None:
+            bs = self._d.bin_size
+            b = start // bs
+            if states[b] == 1:  # ALL_ONE: the reference counts `piece - offset` for the first bin
+                n -= start - b * bs
+        return n
 
     @property
     def size(self):
@@ -129,8 +175,9 @@ class BinnedBitSet(_Queued):
 
     def count_range(self, start, count):
         self._d.check_range_count(start, count)
-        self._flush()
-        return self._d.count_range_checked(_cint(start), _cint(count))
+        if self._ps:
+            self._flush()
+        return self._count(_cint(start), _cint(count), True)
 
     def next_set(self, start):
         self._d.check_index(start)
@@ -236,8 +283,9 @@ class BitSet(_Queued):
         if count is None:
             count = self._d.size - start
         self._d.check_range_count(start, count)
-        self._flush()
-        return self._d.count_range(_cint(start), _cint(count))
+        if self._ps:
+            self._flush()
+        return self._count(_cint(start), _cint(count), False)
 
     def next_set(self, start, end=None):
         if end is None:

@@ -665,21 +665,26 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
     const unsigned short *__restrict__ runs1 = unitT + (int64_t)(open_end ? unit : unit + 1) * ntp;
     const int64_t seg_t0 = sg.tile0, seg_nq = sg.nq;
     const int lane = lane_id();
-    if (threadIdx.x == 0) s_nlong = 0, s_next = 64 * (BD_THREADS / 64);  // (every wave starts with the batch of its number)
-    // this wave's first 64 tiles: their runs travel with the image
-    int tb = t0 + 64 * (int)(threadIdx.x >> 6);
+    // tiles per batch of a wave: 64 when the item has plenty (configs[1]: 3052 tiles, 48 batches for 16 waves), fewer when it
+    // does not -- a chromosome's item of 120 tiles in batches of 64 kept two of the sixteen waves busy (genome pass 2.3 ms
+    // instead of 1.0); at least 8, so that a batch is still a few passes long
+    int B = 64;
+    while (B > 8 && (t1 - t0) < 2 * (BD_THREADS / 64) * B) B >>= 1;
+    if (threadIdx.x == 0) s_nlong = 0, s_next = B * (BD_THREADS / 64);  // (every wave starts with the batch of its number)
+    // this wave's first B tiles: their runs travel with the image
+    int tb = t0 + B * (int)(threadIdx.x >> 6);
     unsigned a_nx, e_nx;
     auto load_runs = [&](int tbase) {
         const int t = tbase + lane;
-        const int tc = t < t1 ? t : t0;  // a valid address: no branch around the loads
+        const int tc = t < t1 && lane < B ? t : t0;  // a valid address: no branch around the loads
         const unsigned a = runs0[tc];
         unsigned e = runs1[tc];
         if (open_end) {
             const int64_t left = seg_nq - (((int64_t)tc - seg_t0) << tile_log2);
             e = left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2;
         }
-        a_nx = t < t1 ? a : 0u;
-        e_nx = t < t1 ? e : 0u;
+        a_nx = t < t1 && lane < B ? a : 0u;
+        e_nx = t < t1 && lane < B ? e : 0u;
     };
     load_runs(tb);
     BdImage I;
@@ -736,7 +741,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         const unsigned a = a_nx, e = e_nx;
         // the batch after this one: its number from the workgroup's counter, its runs requested now
         int tn = 0;
-        if (lane == 0) tn = atomicAdd(&s_next, 64);
+        if (lane == 0) tn = atomicAdd(&s_next, B);
         tn = t0 + __builtin_amdgcn_readfirstlane(tn);
         load_runs(tn);
         unsigned n4 = e > a ? ((e + 3u) >> 2) - (a >> 2) : 0u;  // 16-byte slots that hold the run

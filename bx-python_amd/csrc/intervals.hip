@@ -1083,9 +1083,9 @@ constexpr int LC_ITEMS = 8;
 constexpr int LC_CHUNK = LC_THREADS * LC_ITEMS;  // 4096 consecutive queries per workgroup
 constexpr int LC_TREE_KEYS = (1 << 12) - 1;      // two trees of 4096 slots = 32 KiB of LDS: four workgroups per CU
 
-// LOOP: a small grid whose workgroups stride over the chunks (35 % slower on a sorted batch than one workgroup per chunk,
-// but it stands down in 2 us instead of 12 when the batch is NOT sorted: the host launches it when the handle's previous
-// batch was unsorted -- `hint`, a host-visible word, carries that from one pass to the next without a synchronisation).
+// LOOP: a workgroup takes LC_LOOP consecutive chunks instead of one: a quarter of the workgroups to dismiss when the batch
+// is NOT sorted (the stand-down of 24 000 workgroups cost 12 us per 100 M queries, 1.5 % of the unsorted pass).
+constexpr int LC_LOOP = 4;
 template <bool LOOP>
 __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
                                                                      const int32_t *__restrict__ qs_arr,
@@ -1093,18 +1093,17 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
                                                                      int32_t *__restrict__ counts /* may be NULL */,
                                                                      unsigned long long *__restrict__ total_slots,
                                                                      const unsigned *__restrict__ gate,
-                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */,
-                                                                     unsigned *__restrict__ hint = nullptr)
+                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
     __shared__ int s_mm[3][LC_THREADS / 64];
     __shared__ int s_slice[6];  // eLo, eHi, sLo, sHi, qeLo, qeHi
     __shared__ long long red[LC_THREADS / 64];
-    if (hint && gate && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(hint, *gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (gate && *gate != 0) return;  // unsorted batch: the bucketed path answers it
     long long acc = 0;
-    for (int64_t chunk = blockIdx.x; chunk * LC_CHUNK < nq; chunk += LOOP ? (int64_t)gridDim.x : ((int64_t)1 << 40)) {
-    if (LOOP && chunk != (int64_t)blockIdx.x) __syncthreads();  // the shared arrays of the chunk before are done with
+    const int64_t chunk0 = (int64_t)blockIdx.x * (LOOP ? LC_LOOP : 1);
+    for (int64_t chunk = chunk0; chunk < chunk0 + (LOOP ? LC_LOOP : 1) && chunk * LC_CHUNK < nq; chunk++) {
+    if (LOOP && chunk != chunk0) __syncthreads();  // the shared arrays of the chunk before are done with
     const int64_t base = chunk * LC_CHUNK;
     const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
     int qs[LC_ITEMS], qe[LC_ITEMS];
@@ -2133,6 +2132,7 @@ static int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_C
 static int64_t g_opt_sl_hu_parts = 1;  // hit un-permute: workgroups per tile (1, 2, 4, 8, 16), run back to back on one XCD
 static int64_t g_opt_sl_run_cap = 160;  // a slice unit grows only while its expected (tile, unit) run stays within this many records
 static int64_t g_opt_find_pairs = 1;   // sorted find(): the fill reads (end, index) pairs (one array) instead of the two index arrays
+static int64_t g_opt_lc_loop = 0;      // 1 = the sorted-batch kernel behind the order check takes four chunks per workgroup: its stand-down on an unsorted batch costs 5 us instead of 12, but a sorted batch 0.89 instead of 0.65 ms -- off
 static int64_t g_opt_sl_flat = 1;      // 1 = count-only passes on key slices take the flat 16-byte walk of count_dense.hpp (16-bit counts, unit run table), 0 = the 16 / 64 lanes-per-run kernels of count_slices.hpp
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
@@ -2142,7 +2142,7 @@ static int64_t g_opt_dense = -1;      // search stage on dense unit images (coun
 static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
 static int64_t g_opt_bd_nt = 1;       // 1 = non-temporal image loads in the dense search kernel
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
-static int64_t g_opt_bd_depth = 4;    // passes of records in flight per wave of the dense search kernel (2, 3, 4 or 6)
+static int64_t g_opt_bd_depth = 0;    // passes of records per round and wave of the flat walk: 0 = by format (4 for the images, 2 for key slices), else 2, 3 or 4
 static int64_t g_opt_bd_pipe = 1;     // 1 = the walk keeps two sets of passes in flight (record loads issued by hand), 0 = one set per round
 static int64_t g_opt_bd_exp = 0;      // diagnostics only (wrong results): 1 = the dense search kernel without its lookups
 static int64_t g_opt_bd_unit_log2 = BD_UNIT_LOG2;  // coordinates per unit of the dense images (read when an index is prepared): 19, or less for shorter runs (A/B)
@@ -2241,6 +2241,10 @@ int ivl_set_option(const char *key, int64_t value)
         g_opt_find_pairs = value != 0;
         return 1;
     }
+    if (!strcmp(key, "ivl.lc_loop")) {
+        g_opt_lc_loop = value != 0;
+        return 1;
+    }
     if (!strcmp(key, "ivl.sl_flat")) {
         g_opt_sl_flat = value != 0;
         return 1;
@@ -2278,7 +2282,7 @@ int ivl_set_option(const char *key, int64_t value)
         return 1;
     }
     if (!strcmp(key, "ivl.bd_depth")) {
-        g_opt_bd_depth = value == 2 || value == 3 ? value : 4;
+        g_opt_bd_depth = value == 2 || value == 3 || value == 4 ? value : 0;
         return 1;
     }
     if (!strcmp(key, "ivl.bd_pipe")) {
@@ -2342,7 +2346,6 @@ struct bxmi_ivl {
     bool bd_blocks = false;      // the images' ranks are relative to blocks of 1024 cells (more than 32767 keys in some unit's slice)
     DevBuf bd_images, bd_stats, bd_cnt16, bd_unitT;
     bool sl_eid_ready = false;
-    unsigned *sort_hint = nullptr;  // host-visible: 1 = the last large batch was not sorted by start (ivl_local_count_kernel)
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][ONE_CAP hits][completion word:int64]
     unsigned long long one_seq = 0;
     hipStream_t stream = nullptr;
@@ -2746,8 +2749,11 @@ static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_
             // ... and while a (tile, unit) run of a uniform batch stays within ~2.5 waves: longer runs go through the
             // leftover passes / the workgroup's long-run list, which cost small chromosomes (narrow buckets, f = 5)
             // 15 % of the genome pass
-            // (the flat walk keeps every lane busy whatever the run length: the longer the better)
-            if (h->sl_need[k] > (unsigned)SL_CAP || g.shift + k > g_opt_sl_rbits || (!flat_walk && (tile << k) / nb_used > g_opt_sl_run_cap)) break;
+            // (the flat walk keeps every lane busy whatever the run length, but a unit's directory has 2047 cells however
+            // wide the unit is: a larger unit means more keys per cell and more halvings per lookup -- measured: the genome
+            // pass 1.0 -> 2.4 ms with units as large as the LDS allows -- so the same cap serves both walks)
+            (void)flat_walk;
+            if (h->sl_need[k] > (unsigned)SL_CAP || g.shift + k > g_opt_sl_rbits || (tile << k) / nb_used > g_opt_sl_run_cap) break;
             f = k;
         }
     }
@@ -2949,7 +2955,9 @@ static int bd_launch_search_d(const BmLaunch &L, unsigned grid, hipStream_t st)
 
 static int bd_launch_search(const BmLaunch &L, unsigned grid, int fmt /* 0 dense, 1 cells, 2 slices */, bool blocks, hipStream_t st)
 {
-    if (fmt == 2) return bd_launch_search_d<2, false, 0>(L, grid, st);
+    // key slices: the lean shape (two passes per round, compiler-issued loads: 50 registers) -- two workgroups share a CU
+    // when the units are small, one stages its unit while the other searches (a third of a sparse index's search time)
+    if (fmt == 2) return g_opt_bd_depth == 4 && g_opt_bd_pipe ? bd_launch_search_t<2, false, 0, 4, true>(L, grid, st) : bd_launch_search_t<2, false, 0, 2, false>(L, grid, st);
     const bool cells = fmt == 1;
     if (cells && g_opt_bd_exp == 3) return bd_launch_search_d<1, false, 3>(L, grid, st);
     if (cells) return g_opt_bd_exp == 1 ? bd_launch_search_d<1, false, 1>(L, grid, st) : bd_launch_search_d<1, false, 0>(L, grid, st);
@@ -3088,17 +3096,13 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         hipLaunchKernelGGL(bm_sorted_check_kernel, dim3(2048), dim3(256), 0, st, qs[0], nq[0], unsorted);
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
-        if (!h->sort_hint) {
-            BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->sort_hint), 64, hipHostMallocMapped));
-            *h->sort_hint = 0u;
-        }
         const int64_t nchunks = div_up(nq[0], LC_CHUNK);
-        if (*reinterpret_cast<volatile unsigned *>(h->sort_hint) != 0u && nchunks > 1024)  // the batch before was not sorted: expect the same
-            hipLaunchKernelGGL(ivl_local_count_kernel<true>, dim3(1024), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(), qs[0], qe[0],
-                               nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->sort_hint);
+        if (g_opt_lc_loop && nchunks >= 4096)
+            hipLaunchKernelGGL(ivl_local_count_kernel<true>, dim3((unsigned)div_up(nchunks, LC_LOOP)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
+                               h->e_sorted.as<int32_t>(), qs[0], qe[0], nq[0], counts[0], tslots, unsorted);
         else
             hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(),
-                               qs[0], qe[0], nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->sort_hint);
+                               qs[0], qe[0], nq[0], counts[0], tslots, unsorted);
         BXMI_LAUNCH_CHECK();
     }
     if (variant == 2)
@@ -3270,7 +3274,6 @@ extern "C" int bxmi_ivl_destroy(bxmi_ivl_t *h)
     if (!h) return BXMI_OK;
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->one_buf) (void)hipHostFree(h->one_buf);
-    if (h->sort_hint) (void)hipHostFree(h->sort_hint);
     delete h;
     return BXMI_OK;
 }

@@ -368,3 +368,99 @@ def test_bxmi_opts_environment_applies_the_tuning_knobs():
     env["BXMI_OPTS"] = "ivl.no_such_knob=1"
     r = subprocess.run([sys.executable, "-c", code], text=True, env=env, capture_output=True)
     assert r.returncode != 0 and "unknown key" in r.stderr
+
+
+def test_count_range_from_the_run_list_host_logic(monkeypatch):
+    """bx.bitset's read-only phase (count_range answered from the set's run list after two device calls) against the
+    oracle BinnedBitSet on a device look-alike: random op sequences with mutations in between (each drops the list),
+    inverted sets (ALL_ONE bins: the first bin's offset is subtracted, binBits.c:155,161), empty and full ranges."""
+    import bx.bitset as B
+    from oracle import oracle as O
+
+    calls = {"device": 0}
+
+    class FakeDev:
+        def __init__(self, size, granularity=1024, flat=False):
+            self.o = O.OracleBinnedBitSet(size, granularity)
+            self.size, self.bin_size, self.flat = size, self.o.bin_size, flat
+
+        def check_index(self, i):
+            self.o._check_index(i)
+
+        def check_range_count(self, s, c):
+            self.o._check_range_count(s, c)
+
+        def check_same_size(self, other):
+            self.o._check_same(other.o)
+
+        def set_ranges(self, s, c):
+            self.o.set_ranges(np.asarray(s, np.int32), np.asarray(c, np.int32))
+
+        def count_range_checked(self, s, c):
+            calls["device"] += 1
+            return self.o.count_range(s, c)
+
+        def runs(self, start=0):
+            rs, re = self.o.runs()
+            keep = re > start
+            return np.maximum(rs[keep], start), re[keep]
+
+        def bin_states(self):
+            return np.asarray(self.o.states(), dtype=np.uint8)
+
+        def next(self, start, val):
+            return self.o.next_set(start) if val else self.o.next_clear(start)
+
+        def invert(self):
+            self.o.invert()
+
+        def iand(self, other):
+            self.o.iand(other.o)
+
+        def ior(self, other):
+            self.o.ior(other.o)
+
+        def clear(self, i):
+            self.o.clear(i)
+
+        def get(self, i):
+            return self.o[i]
+
+    monkeypatch.setattr(B, "DeviceBitSet", FakeDev)
+    rng = np.random.default_rng(5)
+    size = 300_000
+    a, ref = B.BinnedBitSet(size, 1000), O.OracleBinnedBitSet(size, 1000)
+    other, oref = B.BinnedBitSet(size, 1000), O.OracleBinnedBitSet(size, 1000)
+    for s, c in zip(rng.integers(0, size - 3000, 300).tolist(), rng.integers(1, 3000, 300).tolist()):
+        other.set_range(s, c)
+        oref.set_range(s, c)
+    answered_on_host = 0
+    for rnd in range(60):
+        op = rng.integers(0, 6)
+        if op == 0:
+            for s, c in zip(rng.integers(0, size - 5000, 20).tolist(), rng.integers(0, 5000, 20).tolist()):
+                a.set_range(s, c)
+                ref.set_range(s, c)
+        elif op == 1:
+            a.invert()
+            ref.invert()
+        elif op == 2:
+            a.iand(other)
+            ref.iand(oref)
+        elif op == 3:
+            a.ior(other)
+            ref.ior(oref)
+        elif op == 4:
+            i = int(rng.integers(0, size))
+            a.clear(i)
+            ref.clear(i)
+        before = calls["device"]
+        qs = rng.integers(0, size, 40).tolist() + [0, 0, size - 1, 999, 1000, 1001]
+        for s in qs:
+            c = int(rng.integers(0, size - s + 1)) if rng.random() < 0.5 else int(rng.integers(0, min(size - s, 3000) + 1))
+            assert a.count_range(s, c) == ref.count_range(s, c), (rnd, op, s, c)
+            assert a.next_set(s) == ref.next_set(s) and a.next_clear(s) == ref.next_clear(s)
+        assert a.count_range(0, size) == ref.count_range(0, size)
+        assert calls["device"] - before <= 2  # after a mutation: two device calls, then the run list
+        answered_on_host += len(qs) + 1 - (calls["device"] - before)
+    assert answered_on_host > 2000
