@@ -269,6 +269,69 @@ def bench_find(torch, reps=3):
     return out
 
 
+def bench_clustered(torch, reps=5, nt=10_000_000, nq=100_000_000, hot_spots=20_000, genome=250_000_000):
+    """The non-uniform counterpart of configs[1] -- a side measurement, never `value`: targets and
+    queries around 20 000 hot spots with heavily duplicated coordinates (bxmi.synth.clustered's recipe, drawn with the
+    device's generator here: 110 M draws take numpy half a minute), in generated order and sorted by start.  Says which
+    search stage served the index; the counts are checked against the direct tree kernel on a 4 M-query slice."""
+    from bxmi import _ffi
+    from bxmi.intervals import IntervalIndex
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(601)
+    centres = torch.sort(torch.randint(10_000, genome - 10_000, (hot_spots,), generator=g, device="cuda"))[0]
+    weight = torch.exp(0.6 * torch.randn(hot_spots, generator=g, device="cuda", dtype=torch.float64))
+    cum = torch.cumsum(weight / weight.sum(), 0)
+    lengths = torch.randint(30, 2000, (48,), generator=g, device="cuda")
+
+    def draw(n, scatter):
+        k = torch.searchsorted(cum, torch.rand(n, generator=g, device="cuda", dtype=torch.float64)).clamp_(max=hot_spots - 1)
+        off = torch.empty(n, device="cuda", dtype=torch.float32).geometric_(1.0 / scatter, generator=g).long() - 1
+        start = centres[k] + off
+        length = lengths[torch.randint(0, 48, (n,), generator=g, device="cuda")]
+        return start.int().contiguous(), (start + length).int().contiguous()
+
+    ts, te = draw(nt, 60.0)
+    qs, qe = draw(nq, 400.0)
+    ix = IntervalIndex()
+    ix.append_dev(ts.data_ptr(), te.data_ptr(), nt)
+    ix.seal()
+    stream = torch.cuda.current_stream().cuda_stream
+    counts = torch.empty(nq, dtype=torch.int32, device="cuda")
+    tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+    out = {"workload": "%d queries x %d targets around %d hot spots on %d coordinates (geometric scatter 400 / 60, 48 lengths): %d distinct target "
+                       "starts" % (nq, nt, hot_spots, genome, int(torch.unique(ts).numel()))}
+    for label in ("generated_order", "sorted_by_start"):
+        if label == "sorted_by_start":
+            o = torch.argsort(qs, stable=True)
+            qs, qe = qs[o].contiguous(), qe[o].contiguous()
+            del o
+        ix.count_dev(qs.data_ptr(), qe.data_ptr(), nq, counts.data_ptr(), tot.data_ptr(), stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ix.count_dev(qs.data_ptr(), qe.data_ptr(), nq, counts.data_ptr(), tot.data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        # the same first 4 M queries through the direct tree kernel (no exchange, no images)
+        m = 4 << 20
+        ref = torch.empty(m, dtype=torch.int32, device="cuda")
+        _ffi.call("bxmi_set_option", b"ivl.partition", 0)
+        try:
+            ix.count_dev(qs.data_ptr(), qe.data_ptr(), m, ref.data_ptr(), None, stream)
+            torch.cuda.synchronize()
+        finally:
+            _ffi.call("bxmi_set_option", b"ivl.partition", -1)
+        out[label] = dict(ms=round(ms, 4), m_queries_per_s=round(nq / ms / 1e3, 1), frac_of_hbm_peak=round(alg_bytes_of(nq, nt) / ms / 1e6 / HBM_PEAK_GBS, 4),
+                          same_as_direct_kernel=bool(torch.equal(counts[:m], ref)))
+    out["search_stage_of_this_index"] = dict(zip(("flat_walk_on_cell_images", "dense_unit_images", "bucket_pair_images", "key_slices"),
+                                                 (ix.flat_state()[0], ix.dense_state()[0], ix.bitmap_state()[0], ix.slice_state()[0])))
+    ix.close()
+    return out
+
+
 def bench_per_call():
     """What an UNMODIFIED script pays per line on the drop-in classes (bx.intervals.IntervalTree.find,
     bx.bitset.BinnedBitSet.count_range): one launch and one answer across PCIe per call.  Microseconds per call."""
@@ -794,6 +857,14 @@ def main():
             line["genome"] = {"error": repr(ex)}
     if genome_leg is not None:
         line["genome"] = genome_leg
+    if world == 1 and not args.no_find:
+        try:
+            torch.cuda.empty_cache()
+            line["clustered"] = bench_clustered(torch)
+            u = line["ms_per_step"]
+            line["clustered"]["generated_order"]["x_uniform_time"] = round(line["clustered"]["generated_order"]["ms"] / u, 2)
+        except Exception as ex:
+            line["clustered"] = {"error": repr(ex)}
     if world == 1 and not args.no_find:
         try:
             line["per_call_latency"] = bench_per_call()

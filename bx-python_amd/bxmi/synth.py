@@ -58,8 +58,10 @@ def clustered(n_targets=10_000_000, n_queries=100_000_000, hot_spots=20_000, gen
     weight /= weight.sum()
     lengths = rng.integers(30, 2000, size=48, dtype=np.int64)
 
+    cum = np.cumsum(weight)
+
     def draw(n, scatter):
-        k = rng.choice(hot_spots, size=n, p=weight)
+        k = np.minimum(np.searchsorted(cum, rng.random(n)), hot_spots - 1)  # (rng.choice(p=...) is ten times slower)
         start = centres[k] + rng.geometric(1.0 / scatter, size=n) - 1
         length = lengths[rng.integers(0, len(lengths), size=n)]
         return start.astype(np.int32), (start + length).astype(np.int32)

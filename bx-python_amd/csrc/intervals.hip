@@ -3039,7 +3039,15 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     const int ngroups = (int)(ntp / BM_GROUP_TILES);
     // PAIR: a search workgroup holds the images of two neighbouring buckets (needs both in one CU's LDS)
     const bool pair = !units && g_opt_bm_pair != 0 && 2 * max_stride * sizeof(uint2) + 8192 <= 160 * 1024;
-    const int chunk = dense ? (g_opt_bd_chunk ? (int)g_opt_bd_chunk : (cells || slices_flat ? 2 : 4) * BM_CHUNK) : g_opt_bm_chunk ? (int)g_opt_bm_chunk : (pair ? 2 * BM_CHUNK : BM_CHUNK);
+    int chunk = dense ? (g_opt_bd_chunk ? (int)g_opt_bd_chunk : (cells || slices_flat ? 2 : 4) * BM_CHUNK) : g_opt_bm_chunk ? (int)g_opt_bm_chunk : (pair ? 2 * BM_CHUNK : BM_CHUNK);
+    // a small batch (one rank's share of a genome on eight GPUs: 13 M queries) cut into items of 128 Ki queries is a hundred
+    // workgroups on 256 CUs (measured: search 154 us of a 255 us pass); items of nq / 512, at least a tile
+    // (every item stages its unit's keys again: at 25 M queries, 192 items, the smaller items already cost more than
+    // the idle CUs did -- 0.33 -> 0.38 ms -- so only batches that leave a third of the chip idle are cut finer)
+    if (!(dense ? g_opt_bd_chunk : g_opt_bm_chunk) && !(kind == 3 || cells) && nq_all / chunk < 160) {
+        const int64_t c = nq_all / 512;
+        chunk = (int)(c < 16384 ? 16384 : c);
+    }
     int64_t max_items = (int64_t)n * ((pair ? BM_NB / 2 : BM_NB) + 2) + 2 * (nq_all / chunk) + 2;
     if (dense) {  // every segment has at most BM_NB >> f units; empty workgroups of 157 KB of LDS are not free
         max_items = 2 * (nq_all / chunk) + 2;
