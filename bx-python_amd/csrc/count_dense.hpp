@@ -24,9 +24,12 @@
 // A cell whose coordinates carry no duplicate keys has meta = base15 (< 2^15).  Any other cell has meta = 0x8000 | i and
 // ov[i] = base15, ov[i+1..] = one 16-bit entry per duplicated coordinate: position : 7 | extra copies : 8 | more : 1
 // (more than 255 extra copies take several entries; a lone entry is followed by a zero), extras(cell, rel) sums the
-// copies of the entries below rel.  ov[0..2] are zeros: a lookup reads {ov[i], ov[i+1], ov[i+2]} with i = 0 for a plain
-// cell -- no branch on the common path; only a third entry (three duplicated coordinates in one cell) takes a loop.
-// An index qualifies while every block holds < 2^15 keys and every unit's overflow list fits BD_OV_CAP entries;
+// copies of the entries below rel.  A cell with more than two such entries -- a clump: hundreds of keys on a few dozen
+// coordinates, exon starts, peak summits -- gets a TABLE instead: ov[i] = 0x8000 | base15, then T[p] = #{keys of the
+// cell below position p} for p = 0 .. 127 as bytes (ov[i + 1] = 0, 64 words) when the cell holds fewer than 256 keys,
+// else as 16-bit words (ov[i + 1] = 1, 128 words): its rank is two more reads and no popcount.  Units of 2^18
+// coordinates leave 64 KiB of LDS for lists and tables.  ov[0..2] are zeros.
+// An index qualifies while every block holds < 2^15 keys and every unit's overflow area fits what the image leaves of the LDS;
 // bd_image_kernel reports both maxima when it builds the images (once per sealed index).
 //
 // count(q) = (sLo + rankS(off + len)) - (eLo + rankE(off + 1))        (intersection.pyx:180-189)
@@ -39,7 +42,8 @@ constexpr int BD_RSHIFT = 19;        // record = offset : 19 | length : 13 (8191
 constexpr int BD_MARGIN = 8192;      // the starts' cells reach this far past the unit: every record's qe is covered
 constexpr int BD_MAX_F = 6;          // buckets per unit = 2^f
 constexpr int BD_MAX_SHIFT = 19;     // bucket width <= 2^19: spans up to 2^30
-constexpr int BD_OV_CAP = 5632;      // 16-bit overflow entries per unit (11 KiB of LDS)
+constexpr int BD_OV_MAX = 32704;     // 16-bit overflow entries per unit, at most (a cell's 15-bit index must reach them)
+constexpr int BD_TABLE_FROM = 6;     // list entries from which a cell gets a rank table
 constexpr int BD_THREADS = 1024;
 constexpr int BD_LONG_SLOTS = 64;    // runs of more 16-byte slots than this go to the cooperative finish
 constexpr int BD_LONG_CAP = 320;
@@ -49,6 +53,7 @@ constexpr int BD_HDR_QS = 6;         // header words: [0..5] qbaseE, [6..11] qba
 struct BdLayout {
     int nce, ncs;                      // cells, sentinel included
     int bitsE, bitsS, metaE, metaS, hdr, ov, bytes;
+    int ov_cap;                        // 16-bit entries of the overflow area: what is left of the CU's LDS, at most BD_OV_MAX
 };
 
 __host__ __device__ inline BdLayout bd_layout(int unit_log2)
@@ -63,7 +68,9 @@ __host__ __device__ inline BdLayout bd_layout(int unit_log2)
     L.metaS = L.metaE + ((L.nce * 2 + 15) & ~15);
     L.hdr = L.metaS + ((L.ncs * 2 + 15) & ~15);
     L.ov = L.hdr + 64;
-    L.bytes = L.ov + BD_OV_CAP * 2;
+    const int room = (160 * 1024 - 3072 /* the search kernel's static LDS */ - L.ov) / 2;
+    L.ov_cap = (room < BD_OV_MAX ? room : BD_OV_MAX) & ~7;
+    L.bytes = L.ov + L.ov_cap * 2;
     return L;
 }
 
@@ -134,16 +141,22 @@ __global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__r
         // exclusive prefixes over the cells: keys below the cell, overflow words before the cell's
         const int K = (nc + BD_THREADS - 1) / BD_THREADS;
         const int c_lo = (int)threadIdx.x * K, c_hi = c_lo + K < nc ? c_lo + K : nc;
+        // overflow words of a cell: none, {base, entry, entry or zero}, or {base, 128 ranks}
+        auto ov_words = [](unsigned entries, unsigned keys) {
+            if (entries == 0u) return 0u;
+            if (entries >= (unsigned)BD_TABLE_FROM) return keys < 256u ? 66u : 130u;
+            return 1u + (entries > 2u ? entries : 2u);
+        };
         unsigned ksum = 0, osum = 0;
         for (int c = c_lo; c < c_hi; c++) {
             ksum += cnt[c];
-            osum += ecnt[c] ? 1u + (ecnt[c] > 2u ? ecnt[c] : 2u) : 0u;
+            osum += ov_words(ecnt[c], cnt[c]);
         }
         unsigned ktot, otot;
         unsigned kexc = block_exclusive_scan(ksum, OpSum(), 0u, scan_tmp, &ktot);
         unsigned oexc = block_exclusive_scan(osum, OpSum(), 0u, scan_tmp, &otot);
         for (int c = c_lo; c < c_hi; c++) {
-            const unsigned k = cnt[c], o = ecnt[c] ? 1u + (ecnt[c] > 2u ? ecnt[c] : 2u) : 0u;
+            const unsigned k = cnt[c], o = ov_words(ecnt[c], cnt[c]);
             cnt[c] = kexc;  // keys of the slice below cell c
             ovoff[c] = oexc;
             kexc += k;
@@ -165,10 +178,29 @@ __global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__r
             if (ecnt[c]) {
                 const unsigned at = ov_base + ovoff[c];
                 m = 0x8000u | (at & 0x7FFFu);
-                if (at < (unsigned)BD_OV_CAP) ov[at] = (unsigned short)(base & 0x7FFFu);
-                if (ecnt[c] == 1u && at + 2u < (unsigned)BD_OV_CAP) ov[at + 2u] = 0;  // the zero after a lone entry
+                const unsigned table = ecnt[c] >= (unsigned)BD_TABLE_FROM ? 0x8000u : 0u;
+                if (at < (unsigned)L.ov_cap) ov[at] = (unsigned short)((base & 0x7FFFu) | table);
+                if (ecnt[c] == 1u && at + 2u < (unsigned)L.ov_cap) ov[at + 2u] = 0;  // the zero after a lone entry
             }
             meta[c] = (unsigned short)m;
+        }
+        // rank tables: 128 threads per clumped cell, T[p] = #{keys of the cell below position p} (the cell's keys are
+        // a contiguous range of the sorted array)
+        for (int c = (int)(threadIdx.x >> 7); c < nc; c += BD_THREADS >> 7) {
+            if (ecnt[c] < (unsigned)BD_TABLE_FROM) continue;
+            const unsigned p = threadIdx.x & 127u;
+            const int k0 = r0 + (int)cnt[c], k1 = r0 + (int)(c + 1 < nc ? cnt[c + 1] : ktot);
+            const long long key = lo + (long long)c * 128 + (long long)p;
+            const unsigned below = (unsigned)(key > INT_MAX ? k1 - k0 : bd_lower_bound(A, k0, k1, (int)key) - k0);
+            const bool wide = k1 - k0 >= 256;
+            const unsigned at = ov_base + ovoff[c] + 1u;
+            if (p == 0 && at < (unsigned)L.ov_cap) ov[at] = wide ? 1 : 0;
+            if (wide) {
+                if (at + 1u + p < (unsigned)L.ov_cap) ov[at + 1u + p] = (unsigned short)below;
+            } else {
+                const unsigned nb = (unsigned)__shfl_down((int)below, 1, 64);  // (p and p + 1 sit in one wave: 128 threads = two waves, p even pairs with p + 1)
+                if ((p & 1u) == 0u && at + 1u + (p >> 1) < (unsigned)L.ov_cap) ov[at + 1u + (p >> 1)] = (unsigned short)(below | (nb << 8));
+            }
         }
         // pass 2: the overflow entries themselves
         for (int r = r0 + (int)threadIdx.x; r < r1; r += BD_THREADS) {
@@ -177,6 +209,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__r
             if (last && !first) {
                 const unsigned rel = (unsigned)((long long)k - lo);
                 const unsigned c = rel >> 7, p = rel & 127u;
+                if (ecnt[c] >= (unsigned)BD_TABLE_FROM) continue;  // (a table cell has no list)
                 unsigned extras = (unsigned)(r - bd_lower_bound(A, r0, r, k));
                 const unsigned ne = (extras + 254u) / 255u;
                 unsigned j = atomicAdd(&ecur[c], ne);
@@ -185,7 +218,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__r
                     const unsigned chunk = extras < 255u ? extras : 255u;
                     extras -= chunk;
                     const unsigned more = j + 1u < ecnt[c] ? 0x8000u : 0u;
-                    if (at0 + j < (unsigned)BD_OV_CAP) ov[at0 + j] = (unsigned short)(p | (chunk << 7) | more);
+                    if (at0 + j < (unsigned)L.ov_cap) ov[at0 + j] = (unsigned short)(p | (chunk << 7) | more);
                 }
             }
         }
@@ -540,11 +573,18 @@ __device__ __forceinline__ int bd_rank(lds_v4u_p bits, lds_u16_p meta, lds_u32_p
     if (m & 0x8000u) {
         unsigned i = m & 0x7FFFu;
         m = ov[i];
-        unsigned e;
-        do {
-            e = ov[++i];
-            r += (e & 127u) < p ? (int)((e >> 7) & 255u) : 0;
-        } while (e & 0x8000u);
+        if (m & 0x8000u) {  // a clumped cell: its ranks are tabulated, as bytes or as 16-bit words
+            m &= 0x7FFFu;
+            const unsigned wide = ov[i + 1u];
+            const unsigned w = ov[i + 2u + (wide ? p : p >> 1)];
+            r = (int)(wide ? w : (w >> ((p & 1u) << 3)) & 255u);
+        } else {
+            unsigned e;
+            do {
+                e = ov[++i];
+                r += (e & 127u) < p ? (int)((e >> 7) & 255u) : 0;
+            } while (e & 0x8000u);
+        }
     }
     return (int)(q + m) + r;
 }
@@ -694,7 +734,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
     } else {
         // the image (streams through L2 once: non-temporal loads); every load of a lane issued before its first LDS store
         const bm_v4i *src = reinterpret_cast<const bm_v4i *>((FMT == 1 ? sg.pimages : sg.dimages) + (size_t)unit * image_bytes);
-        const int n4 = image_bytes >> 4;
+        const int n4 = (FMT == 1 ? image_bytes : L.ov) >> 4;  // (dense images: the overflow area follows, as much of it as is used)
         constexpr int SWEEPS = 5;
         for (int i0 = 0; i0 < n4; i0 += SWEEPS * BD_THREADS) {
             bm_v4i v[SWEEPS];
@@ -711,6 +751,13 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         }
     }
     __syncthreads();
+    if (FMT == 0) {
+        const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.dimages + (size_t)unit * image_bytes + L.ov);
+        const int used = (int)reinterpret_cast<const unsigned *>(reinterpret_cast<unsigned char *>(dyn) + L.hdr)[12];  // overflow entries of this unit
+        const int n4 = (used * 2 + 15) >> 4;
+        for (int i = threadIdx.x; i < n4; i += BD_THREADS) reinterpret_cast<bm_v4i *>(reinterpret_cast<unsigned char *>(dyn) + L.ov)[i] = __builtin_nontemporal_load(src + i);
+        __syncthreads();
+    }
     if (FMT == 2) {
     } else if (FMT == 1) {
         unsigned char *base = reinterpret_cast<unsigned char *>(dyn);

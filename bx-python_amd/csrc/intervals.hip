@@ -2145,7 +2145,7 @@ static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ra
 static int64_t g_opt_bd_depth = 0;    // passes of records per round and wave of the flat walk: 0 = by format (4 for the images, 2 for key slices), else 2, 3 or 4
 static int64_t g_opt_bd_pipe = 1;     // 1 = the walk keeps two sets of passes in flight (record loads issued by hand), 0 = one set per round
 static int64_t g_opt_bd_exp = 0;      // diagnostics only (wrong results): 1 = the dense search kernel without its lookups
-static int64_t g_opt_bd_unit_log2 = BD_UNIT_LOG2;  // coordinates per unit of the dense images (read when an index is prepared): 19, or less for shorter runs (A/B)
+static int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
 
 int ivl_set_option(const char *key, int64_t value)
 {
@@ -2294,7 +2294,7 @@ int ivl_set_option(const char *key, int64_t value)
         return 1;
     }
     if (!strcmp(key, "ivl.bd_unit_log2")) {
-        g_opt_bd_unit_log2 = value < 12 || value > BD_UNIT_LOG2 ? BD_UNIT_LOG2 : value;
+        g_opt_bd_unit_log2 = value < 12 || value > BD_UNIT_LOG2 ? 0 : value;
         return 1;
     }
     return 0;
@@ -2678,39 +2678,43 @@ static int bd_prepare_index(bxmi_ivl *h, hipStream_t st)
     h->bd_state = -1;
     const int shift = h->geom.shift;
     if (h->has_reversed || h->n < 4096 || shift > BD_MAX_SHIFT || shift < BM_MIN_SHIFT) return BXMI_OK;
-    BmGeom g;
-    g.cmin = h->geom.cmin;
-    g.cmax = h->cmax;
-    g.shift = shift;
-    int f = (int)g_opt_bd_unit_log2 - shift;
-    g.f = f < 0 ? 0 : (f > BD_MAX_F ? BD_MAX_F : f);
-    g.rshift = BD_RSHIFT;
-    g.dshift = 0;
-    const BdLayout L = bd_layout(g.shift + g.f);
-    g.nce = L.nce, g.ncs = L.ncs;
-    g.stride = L.bytes >> 4;
-    const int units = BM_NB >> g.f;
-    BXMI_TRY(h->bd_images.reserve((size_t)units * L.bytes));
-    BXMI_TRY(h->bd_stats.reserve(64));
-    BXMI_HIP(hipMemsetAsync(h->bd_stats.p, 0, 64, st));
-    const size_t lds = (size_t)8 * L.ncs * sizeof(int32_t);
-    BXMI_TRY(allow_big_lds(bd_image_kernel, lds));
-    h->bd_geom = g;
-    // ranks relative to the whole unit when every slice holds fewer than 2^15 keys (no table read per lookup), else
-    // relative to blocks of 1024 cells
-    for (int bshift = g_opt_bd_blocks ? 10 : 13; bshift >= 10; bshift -= 3) {
-        BXMI_HIP(hipMemsetAsync(h->bd_stats.p, 0, 64, st));
-        hipLaunchKernelGGL(bd_image_kernel, dim3((unsigned)units), dim3(BD_THREADS), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n,
-                           g, bshift, h->bd_images.as<unsigned char>(), h->bd_stats.as<unsigned>());
-        BXMI_LAUNCH_CHECK();
-        BXMI_HIP(hipMemcpyAsync(h->bd_worst, h->bd_stats.p, sizeof(h->bd_worst), hipMemcpyDeviceToHost, st));
-        BXMI_HIP(hipStreamSynchronize(st));
-        h->bd_blocks = bshift == 10;
-        if (h->bd_worst[1] > (unsigned)BD_OV_CAP) break;  // too many duplicated coordinates: blocks do not help
-        if (h->bd_worst[0] <= 32767u) {
-            h->bd_state = 1;
-            break;
+    // Units of 2^19 coordinates first (runs twice as long, 12 KiB of LDS for duplicated coordinates: enough for an index
+    // whose duplicates are accidents), then units of 2^18 (64 KiB: rank tables for clumped cells).
+    for (int ulog = g_opt_bd_unit_log2 ? (int)g_opt_bd_unit_log2 : BD_UNIT_LOG2; ulog >= 18 || ulog == (int)g_opt_bd_unit_log2; ulog--) {
+        BmGeom g;
+        g.cmin = h->geom.cmin;
+        g.cmax = h->cmax;
+        g.shift = shift;
+        const int f = ulog - shift;
+        g.f = f < 0 ? 0 : (f > BD_MAX_F ? BD_MAX_F : f);
+        g.rshift = BD_RSHIFT;
+        g.dshift = 0;
+        const BdLayout L = bd_layout(g.shift + g.f);
+        g.nce = L.nce, g.ncs = L.ncs;
+        g.stride = L.bytes >> 4;
+        const int units = BM_NB >> g.f;
+        BXMI_TRY(h->bd_images.reserve((size_t)units * L.bytes));
+        BXMI_TRY(h->bd_stats.reserve(64));
+        const size_t lds = (size_t)8 * L.ncs * sizeof(int32_t);
+        BXMI_TRY(allow_big_lds(bd_image_kernel, lds));
+        h->bd_geom = g;
+        // ranks relative to the whole unit when every slice holds fewer than 2^15 keys (no table read per lookup), else
+        // relative to blocks of 1024 cells
+        for (int bshift = g_opt_bd_blocks ? 10 : 13; bshift >= 10; bshift -= 3) {
+            BXMI_HIP(hipMemsetAsync(h->bd_stats.p, 0, 64, st));
+            hipLaunchKernelGGL(bd_image_kernel, dim3((unsigned)units), dim3(BD_THREADS), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
+                               (int)h->n, g, bshift, h->bd_images.as<unsigned char>(), h->bd_stats.as<unsigned>());
+            BXMI_LAUNCH_CHECK();
+            BXMI_HIP(hipMemcpyAsync(h->bd_worst, h->bd_stats.p, sizeof(h->bd_worst), hipMemcpyDeviceToHost, st));
+            BXMI_HIP(hipStreamSynchronize(st));
+            h->bd_blocks = bshift == 10;
+            if (h->bd_worst[1] > (unsigned)L.ov_cap) break;  // too many duplicated coordinates: blocks do not help
+            if (h->bd_worst[0] <= 32767u) {
+                h->bd_state = 1;
+                return BXMI_OK;
+            }
         }
+        if (g_opt_bd_unit_log2 || g.shift + g.f < ulog) break;  // forced, or the span is so small that the unit cannot shrink with ulog
     }
     return BXMI_OK;
 }

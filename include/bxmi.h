@@ -122,8 +122,9 @@ int bxmi_ivl_bitmap_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
 int bxmi_ivl_slice_state(const bxmi_ivl_t *h, int *state, int64_t *unit_keys);
 /* The same for the dense-image search stage (count_dense.hpp: one bit per coordinate, units of 2^19 coordinates; serves
  * dense indexes, duplicated coordinates included): *state = 0 not decided yet, 1 = usable, -1 = the index does not fit
- * the format; worst[0] = most keys of one 2^17-coordinate block (limit 32767), worst[1] = most overflow entries of one
- * unit (limit 5632).  Introspection only. */
+ * the format; worst[0] = most keys of one block (the unit, or 2^17 coordinates: limit 32767), worst[1] = most 16-bit
+ * overflow entries of one unit (lists of duplicated coordinates and the 129-entry rank tables of clumped cells; limit
+ * 32704 with units of 2^18 coordinates).  Introspection only. */
 int bxmi_ivl_dense_state(const bxmi_ivl_t *h, int *state, int64_t *worst);
 /* The same for the flat walk on cell images (count_dense.hpp, bp_*: the cells of the bitmap pass laid out per unit of
  * 2^18 coordinates, records walked 16 bytes at a time, 16-bit counts): *state = 0 not decided yet, 1 = usable, -1 = the
