@@ -11,23 +11,24 @@ A reader yields, in file order, `Header` (first line if it is a comment line), `
 `ParseError`s and logs them in `skipped` / `skipped_lines`; `BitsetSafeReaderWrapper`
 additionally drops rows that end beyond the chromosome length.
 """
-from itertools import count
-
 from bx.bitset import MAX
 
 FIRST_LINE_IS_HEADER = object()
 
 
 class ParseError(Exception):
-    """tabular/io.py:9-18 -- the line number is appended to the text once known."""
+    """A line the reader cannot turn into a row.  The reader adds the line number afterwards (`linenum`, also accepted
+    as a keyword); the text then ends in " on line N" (what tabular/io.py:9-18 prints)."""
 
-    def __init__(self, *args, **kwargs):
-        Exception.__init__(self, *args)
-        self.linenum = kwargs.get("linenum", None)
+    def __init__(self, *args, linenum=None, **_other_keywords):
+        super().__init__(*args)
+        self.linenum = linenum
 
     def _base(self):
-        text = Exception.__str__(self)
-        return text + " on line " + str(self.linenum) if self.linenum else text
+        parts = [super().__str__()]
+        if self.linenum:
+            parts.append("on line %s" % (self.linenum,))
+        return " ".join(parts)
 
     def __str__(self):
         return self._base()
@@ -38,66 +39,74 @@ class MissingFieldError(ParseError):
 
 
 class FieldFormatError(ParseError):
-    """intervals/io.py:20-29 -- '<text>[ on line N], integer expected'."""
+    """'<text>[ on line N], integer expected' (intervals/io.py:20-29): `expected` names what the field should have held."""
 
-    def __init__(self, *args, **kwargs):
-        ParseError.__init__(self, *args, **kwargs)
-        self.expected = kwargs.get("expected", None)
+    def __init__(self, *args, expected=None, **keywords):
+        super().__init__(*args, **keywords)
+        self.expected = expected
 
     def __str__(self):
-        return self._base() + ", " + self.expected + " expected" if self.expected else self._base()
+        text = self._base()
+        return "%s, %s expected" % (text, self.expected) if self.expected else text
 
 
 class StrandFormatError(ParseError):
     pass
 
 
+def _field(fields, key, by_name):
+    """What `obj[key]` means for the row-like objects of a table: a column number indexes `fields`, a column name goes
+    through `by_name`, anything else is a TypeError with the reference's text (tabular/io.py:30-40, :64-70)."""
+    if isinstance(key, int):
+        return fields[key]
+    if isinstance(key, str):
+        return by_name(key)
+    raise TypeError("field indices must be integers or strings")
+
+
 class Header:
-    """tabular/io.py:50-73"""
+    """The first line of a table when it is a comment line: column names, and `field_to_column` from a name to its
+    (last) column (tabular/io.py:50-73).  `header["name"]` answers the name itself when the table has that column, else None."""
 
     def __init__(self, fields):
         self.set_fields(fields)
 
     def set_fields(self, fields):
         self.fields = fields
-        self.field_to_column = dict(zip(fields, count()))
+        self.field_to_column = {name: column for column, name in enumerate(fields)}
 
     def __getitem__(self, key):
-        if isinstance(key, int):
-            return self.fields[key]
-        if isinstance(key, str):
-            return key if key in self.field_to_column else None
-        raise TypeError("field indices must be integers or strings")
+        return _field(self.fields, key, lambda name: name if name in self.field_to_column else None)
 
     def __str__(self):
         return "#" + "\t".join(self.fields)
 
 
 class Comment:
-    """tabular/io.py:76-83"""
+    """A comment or blank line, kept as it stood; printed with a leading '#' whether it had one or not (tabular/io.py:76-83)."""
 
     def __init__(self, line):
         self.line = line
 
     def __str__(self):
-        return self.line if self.line.startswith("#") else "#" + self.line
+        return self.line if self.line[:1] == "#" else "#" + self.line
 
 
 class TableRow:
-    """tabular/io.py:21-47"""
+    """One data line split into `fields`; columns by number, or by name when the reader saw a header (tabular/io.py:21-47)."""
 
     def __init__(self, reader, fields):
         self.reader = reader
         self.fields = fields
 
-    def __getitem__(self, key):
-        if isinstance(key, int):
-            return self.fields[key]
-        if isinstance(key, str):
-            if self.reader.header:
-                return self.fields[self.reader.header.field_to_column[key]]
+    def _named(self, name):
+        header = self.reader.header
+        if not header:
             raise TypeError("column names only supported for files with headers")
-        raise TypeError("field indices must be integers or strings")
+        return self.fields[header.field_to_column[name]]
+
+    def __getitem__(self, key):
+        return _field(self.fields, key, self._named)
 
     @property
     def fieldnames(self):

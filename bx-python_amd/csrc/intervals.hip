@@ -3868,15 +3868,17 @@ extern "C" int bxmi_ivl_neighbors(bxmi_ivl_t *h, int32_t position, int32_t max_d
         // i.e. p - max_dist < end <= p.  Candidates lie in [first k with pm[k] > p-max_dist, #{start <= p}):
         // the upper bound is the reference's own `minstart > position` prune (:196-197).
         // (With stored intervals whose start exceeds their end -- IntervalTree.insert accepts them -- the reference prunes by
-        // subtree, so whether such an interval with start > position is still reported there depends on the treap's random
-        // shape; the cut at #{start <= p} used here always leaves it out.  Appendix A.3 of SURVEY.md pins before/after for
-        // proper intervals only, for that reason.)
+        // SUBTREE (`minstart > position`, :196-197), so whether such an interval with start > position is still reported
+        // there depends on the treap's random shape: it is when it shares a subtree with a start <= position.  An index
+        // that holds reversed intervals therefore scans the whole window above `lo` and reports every interval whose END
+        // qualifies -- everything the reference can report whatever its priorities were; Appendix A.3 of SURVEY.md pins
+        // before/after for proper intervals only, for that reason.)
         long long p = (long long)position - 1;
         vlo = p - max_dist + 1, vhi = p + 1;
         hipLaunchKernelGGL(ivl_two_ranks_kernel, dim3(1), dim3(64), 0, st, h->pm.as<int32_t>(), vlo, h->s_ord.as<int32_t>(), vhi, n, d_r);
         BXMI_HIP(hipMemcpyAsync(r, d_r, 8, hipMemcpyDeviceToHost, st));
         BXMI_HIP(hipStreamSynchronize(st));
-        lo = r[0], hi = r[1];
+        lo = r[0], hi = h->has_reversed ? n : r[1];
         if (hi < lo) hi = lo;
         hipLaunchKernelGGL(ivl_filter_window_kernel, dim3(1), dim3(256), 0, st, h->e_ord.as<int32_t>(), h->idx.as<int32_t>(), lo, hi, vlo, vhi,
                            1, h->q_hits.as<int32_t>(), cap, h->q_total.as<unsigned long long>());

@@ -105,6 +105,30 @@ def test_neighbours_match_reference_vectors(golden_trees, IntervalIndex):
     assert n > 300
 
 
+def test_before_with_reversed_targets_reports_every_interval_whose_end_qualifies(IntervalIndex):
+    """An index holding intervals with start > end: the reference's left() prunes by subtree (`minstart > position`,
+    intersection.pyx:196-197), so whether a reversed interval whose start lies right of the position is reported depends
+    on the treap's random shape.  The engine reports every interval whose END qualifies (0 <= position - 1 - end <
+    max_dist) -- the union of what the reference can report -- and after() is untouched."""
+    rng = np.random.default_rng(44)
+    n = 3000
+    s = rng.integers(0, 100_000, size=n).astype(np.int32)
+    e = (s + rng.integers(1, 400, size=n)).astype(np.int32)
+    flip = rng.random(n) < 0.1
+    s2, e2 = np.where(flip, e, s).astype(np.int32), np.where(flip, s, e).astype(np.int32)
+    ix = make_index(IntervalIndex, s2, e2)
+    assert ix.has_reversed
+    for pos, md in ((50_000, 2500), (10, 100), (99_000, 50_000), (70_123, 1)):
+        got = sorted(ix.neighbors(pos, md, -1).tolist())
+        p = pos - 1
+        want = sorted(np.nonzero((p - e2.astype(np.int64) >= 0) & (p - e2.astype(np.int64) < md))[0].tolist())
+        assert got == want, (pos, md, len(got), len(want))
+        got = sorted(ix.neighbors(pos, md, +1).tolist())
+        q = pos + 1
+        want = sorted(np.nonzero((s2.astype(np.int64) - q >= 0) & (s2.astype(np.int64) - q < md))[0].tolist())
+        assert got == want, ("after", pos, md)
+
+
 def test_find_one_beyond_its_buffer(IntervalIndex):
     """More hits than the 16 KiB host-visible result buffer holds: falls over to the batched path."""
     n = 10000

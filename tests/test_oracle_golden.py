@@ -9,6 +9,7 @@ Pins the CPU oracle (oracle/*.c) to the reference:
 CPU only.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -329,3 +330,21 @@ def test_restatement_is_clean_under_asan_and_ubsan():
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "passed" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+def test_negative_cluster_distance_has_no_answer_to_reproduce():
+    """ClusterTree(max_dist < 0) is refused by the engine (BXMI_EINVAL).  The committed experiment on the reference's own
+    src/cluster.c (oracle/cluster_negative_distance.py, its table in tests/golden/cluster_negative_distance.txt) shows why:
+    for distances of -5 and below the regions depend on the insertion order AND on the rand() priorities of the treap,
+    while every non-negative distance gives one answer."""
+    import subprocess
+    import sys
+
+    from oracle import oracle as O
+
+    if not O.have_ref_cluster():
+        pytest.skip("oracle/_ref/libcluster_ref.so not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "cluster_negative_distance.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "negative distances depend on order / priorities: True" in r.stdout
