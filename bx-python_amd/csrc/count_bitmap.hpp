@@ -272,20 +272,30 @@ __device__ __forceinline__ unsigned bm_record_of(int qs, int qe, const BmGeom &g
     return ok ? ((rel & ((1u << (g.shift + g.f)) - 1u)) | (len << g.rshift)) : BM_REC_ESC;
 }
 
-template <int THREADS, int ITEMS>
+// PAD (the flat walk of count_dense.hpp): the records of a UNIT (2^f buckets, f from the segment's geometry; the host asks
+// for PAD only when a unit is at least a thread's BPT buckets) start on a multiple of four slots -- up to three escape
+// records fill the gap behind every unit -- so that every 16-byte slot of the tile-sorted array belongs to ONE unit: the
+// search stores whole slots and knows how many memory operations it has in flight.  A tile then takes up to
+// BM_PAD_ROOM more slots: its stride in the record / count arrays is TILE + BM_PAD_ROOM, its used length goes to `tend`.
+constexpr int BM_PAD_ROOM = 4096;
+
+template <int THREADS, int ITEMS, bool PAD = false>
 __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
-                                                               unsigned *__restrict__ recs /* [ntiles][TILE], tile-sorted */,
+                                                               unsigned *__restrict__ recs /* [ntiles][TILE (+ BM_PAD_ROOM)], tile-sorted */,
                                                                unsigned short *__restrict__ slots /* [nq] slot of every query in its tile */,
                                                                unsigned short *__restrict__ tbl /* [ntiles][BM_NB] first slot of every bucket */,
-                                                               const unsigned *__restrict__ gate /* NULL, or 0 = sorted batch: stand down */)
+                                                               const unsigned *__restrict__ gate /* NULL, or 0 = sorted batch: stand down */,
+                                                               unsigned *__restrict__ tend = nullptr /* PAD: [ntiles] slots used */)
 {
     constexpr int TILE = THREADS * ITEMS;
     if (gate && *gate == 0) return;
     constexpr int BPT = BM_NB / THREADS;  // buckets per thread in the scan
     static_assert(BM_NB % THREADS == 0 && (BPT == 2 || BPT == 4), "2 or 4 buckets per thread");
+    constexpr int STAGED = PAD ? TILE + 3 * THREADS : TILE;  // (at most one unit per thread: three pad slots each)
+    constexpr int STRIDE = PAD ? TILE + BM_PAD_ROOM : TILE;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    unsigned *staged = reinterpret_cast<unsigned *>(dyn);                          // [TILE] records in sorted order
-    unsigned *cnt = staged + TILE;                                                 // [BM_NB]
+    unsigned *staged = reinterpret_cast<unsigned *>(dyn);                          // [STAGED] records in sorted order
+    unsigned *cnt = staged + STAGED;                                               // [BM_NB]
     unsigned short *toff = reinterpret_cast<unsigned short *>(cnt + BM_NB);        // [BM_NB]
     unsigned *scan_tmp = reinterpret_cast<unsigned *>(toff + BM_NB);               // [16]
     const int64_t tile = blockIdx.x;
@@ -295,9 +305,10 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
     const BmGeom g = sg.g;
     const int32_t *__restrict__ qs = sg.qs + ltile * TILE, *__restrict__ qe = sg.qe + ltile * TILE;  // this tile's queries
     const int64_t nq = sg.nq - ltile * TILE;
-    recs += tile * TILE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
+    recs += tile * STRIDE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
     const int64_t base = 0;
     const int n = (int)(nq < TILE ? nq : TILE);
+    int n_out = n;  // slots of the sorted tile (PAD: the units' gaps included)
     for (int i = threadIdx.x; i < BM_NB; i += THREADS) cnt[i] = 0;
     __syncthreads();
     unsigned br[ITEMS];  // bucket << 16 | rank inside the (tile, bucket) run
@@ -348,7 +359,29 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
             sum += c[u];
         }
         unsigned tot;
-        unsigned exc = block_exclusive_scan(sum, OpSum(), 0u, scan_tmp, &tot);
+        unsigned exc;
+        if (PAD) {
+            const int lane = lane_id();
+            const int lanes = (1 << g.f) / BPT;  // lanes per unit: a power of two, 1 .. 32
+            unsigned usum = sum;                 // the unit's queries, in every lane of the unit
+            for (int d = 1; d < lanes; d <<= 1) usum += (unsigned)__shfl_xor((int)usum, d, 64);
+            const unsigned padded = (usum + 3u) & ~3u;
+            const bool leader = (lane & (lanes - 1)) == 0;
+            const unsigned before = block_exclusive_scan(leader ? padded : 0u, OpSum(), 0u, scan_tmp, &tot);
+            const unsigned ubase = (unsigned)__shfl((int)before, lane & ~(lanes - 1), 64);  // the unit's first slot: its leader's prefix
+            unsigned inc = sum;  // inclusive prefix of the lanes' sums inside the unit
+            for (int d = 1; d < lanes; d <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)inc, d, 64);
+                if ((lane & (lanes - 1)) >= d) inc += up;
+            }
+            exc = ubase + inc - sum;
+            if (leader)
+                for (unsigned k = usum; k < padded; k++) staged[ubase + k] = BM_REC_ESC;  // (nobody's slot: answered, never read)
+            n_out = (int)tot;
+            if (threadIdx.x == 0) tend[tile] = tot;
+        } else {
+            exc = block_exclusive_scan(sum, OpSum(), 0u, scan_tmp, &tot);
+        }
         unsigned short o[BPT];
 #pragma unroll
         for (int u = 0; u < BPT; u++) {
@@ -388,7 +421,7 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
     }
     __syncthreads();
     int4 *out = reinterpret_cast<int4 *>(recs + base);
-    const int n4 = (n + 3) >> 2;  // (the scratch is padded to whole tiles)
+    const int n4 = (n_out + 3) >> 2;  // (the scratch is padded to whole tiles)
     for (int i = threadIdx.x; i < n4; i += THREADS) out[i] = reinterpret_cast<const int4 *>(staged)[i];
 }
 

@@ -367,10 +367,13 @@ __global__ __launch_bounds__(BD_THREADS) void bp_image_kernel(const int32_t *__r
 // unitcnt[group][unit] = queries of the unit in the 64 tiles of the group, which is what the plan cuts into work items:
 // 12.5 MB read and 6 MB written per 100 M queries where bm_transpose_kernel + sl_unit_sums_kernel moved 75 MB.
 // One workgroup per (group of 64 tiles, 64 buckets), as there.
+// unitT has one row more than there are units: where the last unit's run ends = the slots the tile uses (its queries,
+// or `tend` when the tile sort left gaps between the units: PAD).
 __global__ __launch_bounds__(256) void bd_transpose_kernel(const unsigned short *__restrict__ tbl, const BmSeg *__restrict__ segs,
                                                            const unsigned short *__restrict__ tile_seg, int tile_log2,
-                                                           unsigned short *__restrict__ unitT /* [BM_NB >> f][ntp] */, int64_t ntp,
-                                                           unsigned *__restrict__ unitcnt /* [ngroups][BM_NB] */, const unsigned *__restrict__ gate)
+                                                           unsigned short *__restrict__ unitT /* [(BM_NB >> f) + 1][ntp] */, int64_t ntp,
+                                                           unsigned *__restrict__ unitcnt /* [ngroups][BM_NB] */, const unsigned *__restrict__ gate,
+                                                           const unsigned *__restrict__ tend /* PAD: slots used per tile, else NULL */)
 {
     __shared__ unsigned short t[BM_GROUP_TILES][66];
     if (gate && *gate == 0) return;
@@ -384,7 +387,8 @@ __global__ __launch_bounds__(256) void bd_transpose_kernel(const unsigned short 
         const BmSeg &sg = segs[tile_seg[tile]];
         const bool live = tile - sg.tile0 < sg.ntiles;
         const int64_t left = sg.nq - ((tile - sg.tile0) << tile_log2);
-        const unsigned ntile = !live ? 0u : (left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2);
+        unsigned ntile = !live ? 0u : (left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2);
+        if (tend && live) ntile = tend[tile];
         const unsigned short *row = tbl + tile * BM_NB + b0 + 16 * q;
         uint4 a = make_uint4(0, 0, 0, 0), c = a;
         if (live) {
@@ -398,7 +402,10 @@ __global__ __launch_bounds__(256) void bd_transpose_kernel(const unsigned short 
             t[r][16 * q + 2 * i + 1] = (unsigned short)(w[i] >> 16);
         }
         // (a full tile's total is 1 << 16 when the tile has 65536 queries: lengths are taken modulo 2^16 below)
-        if (q == 3) t[r][64] = (unsigned short)(b0 + 64 < BM_NB ? (live ? row[16] : 0) : ntile);
+        if (q == 3) {
+            t[r][64] = (unsigned short)(b0 + 64 < BM_NB ? (live ? row[16] : 0) : ntile);
+            if (b0 + 64 >= BM_NB) unitT[(int64_t)(BM_NB >> f) * ntp + tile] = (unsigned short)ntile;  // the row behind the last unit
+        }
     }
     __syncthreads();
     {
@@ -531,20 +538,33 @@ struct BdImage {
     BmGeom g;
 };
 
-// FMT 1: the count of one record from a unit's cell image (bm_count_record for units; 16 bits, 0xFFFF = ask the index again)
+// FMT 1: a rank from a unit's cell image (bm_cell_rank written for the instruction count: the walk is bound by vector
+// instructions -- 274 per 16-byte slot, 58 % VALU activity at 330 us -- so the duplicate term is one bit-field extract
+// and one multiply-add, and the hard-cell test is left to the caller, once per record).
+__device__ __forceinline__ unsigned bp_cell_rank(lds_cell_p cells, unsigned rel, unsigned &meta_out)
+{
+    const unsigned long long c = cells[rel >> 5];
+    const unsigned bits = (unsigned)c, meta = (unsigned)(c >> 32);
+    meta_out = meta;
+    const unsigned below = ~(0xFFFFFFFFu << (rel & 31u));  // the coordinates of the cell below rel
+    // the duplicated coordinate counts `extra` more times when it lies below rel: bit dpos of the mask says so
+    const unsigned dup = __builtin_amdgcn_ubfe(below, (meta >> 20) & 31u, 1u);
+    return (meta & 0xFFFFFu) + (unsigned)__popc(bits & below) + (meta >> 25) * dup;
+}
+
+// the count of one record (16 bits, 0xFFFF = ask the index again)
 __device__ __forceinline__ unsigned bp_count_record(const BdImage &I, unsigned rec)
 {
     const unsigned off = rec & I.off_mask, len = rec >> BP_RSHIFT;
     const unsigned relE = off + 1u, relS = off + len;
-    bool odd = false;
-    const int rE = bm_cell_rank(I.cE, relE, odd);
-    const int rS = bm_cell_rank(I.cS, relS, odd);
-    unsigned c = (unsigned)(I.bias + (rS - rE));
-    if (odd) {  // a hard cell (rare: the index qualifies only while they are)
-        bool e_hard = false, s_hard = false;
-        int hE = bm_cell_rank(I.cE, relE, e_hard), hS = bm_cell_rank(I.cS, relS, s_hard);
-        if (e_hard) hE = bm_hard_rank(I.cE, relE, I.e_sorted, I.eLo, I.lo);
-        if (s_hard) hS = bm_hard_rank(I.cS, relS, I.s_ord, I.sLo, I.lo);
+    unsigned mE, mS;
+    const unsigned rE = bp_cell_rank(I.cE, relE, mE);
+    const unsigned rS = bp_cell_rank(I.cS, relS, mS);
+    unsigned c = (unsigned)I.bias + (rS - rE);
+    if ((mE > mS ? mE : mS) >= ((unsigned)BM_HARD << 25)) {  // a hard cell (rare: the index qualifies only while they are)
+        int hE = (int)rE, hS = (int)rS;
+        if ((mE >> 25) == (unsigned)BM_HARD) hE = bm_hard_rank(I.cE, relE, I.e_sorted, I.eLo, I.lo);
+        if ((mS >> 25) == (unsigned)BM_HARD) hS = bm_hard_rank(I.cS, relS, I.s_ord, I.sLo, I.lo);
         c = (unsigned)(I.bias + (hS - hE));
     }
     c = c < 0xFFFFu ? c : 0xFFFFu;
@@ -669,14 +689,26 @@ __device__ __forceinline__ void bd_issue_load(bd_v4u &v, const unsigned *recs, u
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
 }
 
+// (the register is named in a comment of the instruction: tools/check_ring_isa.py reads the compiled code and refuses a
+// build in which the compiler moved or touched a register while a hand-issued load was on its way to it)
 template <int K>
 __device__ __forceinline__ void bd_wait(bd_v4u &v)
 {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(K) : "memory");
+    asm volatile("s_waitcnt vmcnt(%1) ; ring %0" : "+v"(v) : "n"(K) : "memory");
+}
+
+// One memory operation that nobody waits for: a 4-byte store to a slot no query owns.  It stands in for "the answer of
+// the pass before" where the ring starts, so that one wait count fits every pass.
+__device__ __forceinline__ void bd_dummy_store(unsigned short *slot)
+{
+    asm volatile("global_store_dword %0, %1, off" : : "v"(slot), "v"(0u) : "memory");
 }
 
 // PIPE: two sets of DEPTH passes; while one set is answered the other's records are on their way.
-template <int FMT, bool QB, int EXP = 0, int DEPTH = 2, bool PIPE = false>
+// PAD: the tile sort left every unit's run on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): no slot is shared with a
+// neighbouring unit, every answered pass is exactly one store, and the walk keeps a RING of DEPTH passes in flight all
+// the time -- the wait in front of a pass counts the DEPTH - 1 younger loads and the DEPTH - 1 stores issued since.
+template <int FMT, bool QB, int EXP = 0, int DEPTH = 2, bool PIPE = false, bool PAD = false>
 __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                const int *__restrict__ n_items, const unsigned short *__restrict__ unitT, int64_t ntp,
                                                                const unsigned *__restrict__ recs /* tile-sorted records */,
@@ -700,11 +732,10 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
     const BdLayout L = bd_layout(g.shift + g.f);
     const BpLayout LP = bp_layout(g.shift + g.f);
     const int image_bytes = FMT == 1 ? LP.bytes : L.bytes;
-    const bool open_end = ((unit + 1) << g.f) >= BM_NB;  // the unit reaches the end of the grid: its runs end where the tiles end
     const unsigned short *__restrict__ runs0 = unitT + (int64_t)unit * ntp;
-    const unsigned short *__restrict__ runs1 = unitT + (int64_t)(open_end ? unit : unit + 1) * ntp;
-    const int64_t seg_t0 = sg.tile0, seg_nq = sg.nq;
+    const unsigned short *__restrict__ runs1 = runs0 + ntp;  // (the next unit's first slots, or the row behind the last unit)
     const int lane = lane_id();
+    const unsigned tile_slots = ((1u << tile_log2) + (PAD ? (unsigned)BM_PAD_ROOM : 0u)) >> 2;  // 16-byte slots between two tiles
     // tiles per batch of a wave: 64 when the item has plenty (configs[1]: 3052 tiles, 48 batches for 16 waves), fewer when it
     // does not -- a chromosome's item of 120 tiles in batches of 64 kept two of the sixteen waves busy (genome pass 2.3 ms
     // instead of 1.0); at least 8, so that a batch is still a few passes long
@@ -718,11 +749,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         const int t = tbase + lane;
         const int tc = t < t1 && lane < B ? t : t0;  // a valid address: no branch around the loads
         const unsigned a = runs0[tc];
-        unsigned e = runs1[tc];
-        if (open_end) {
-            const int64_t left = seg_nq - (((int64_t)tc - seg_t0) << tile_log2);
-            e = left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2;
-        }
+        const unsigned e = runs1[tc];
         a_nx = t < t1 && lane < B ? a : 0u;
         e_nx = t < t1 && lane < B ? e : 0u;
     };
@@ -782,7 +809,6 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         I.bias = (int)hdr[14] - (int)hdr[13];
         I.off_mask = (1u << (g.shift + g.f)) - 1u;
     }
-    const unsigned slot_mask = (1u << (tile_log2 - 2)) - 1u;  // 16-byte slots of a tile
     while (tb < t1) {
         const int t = tb + lane;
         const unsigned a = a_nx, e = e_nx;
@@ -795,31 +821,38 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         if (n4 > (unsigned)BD_LONG_SLOTS) {  // sorted / clumped input: left to the whole workgroup
             const int k = atomicAdd(&s_nlong, 1);
             if (k < BD_LONG_CAP) {
-                s_long[k] = make_uint2(((unsigned)t << tile_log2) + a, e - a);
+                s_long[k] = make_uint2(((unsigned)t * tile_slots << 2) + a, e - a);
                 n4 = 0u;
             }  // (a full list: the wave walks the run itself, exactness never depends on it)
         }
         const unsigned incl = wave_inclusive_scan(n4, OpSum());
         const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
         // slot s of the flat sequence lies in run r = #{runs that end at or before s}; its int4 is at delta[r] + s
-        const unsigned delta = (((unsigned)t << (tile_log2 - 2)) + (a >> 2)) - (incl - n4);
+        const unsigned delta = ((unsigned)t * tile_slots + (a >> 2)) - (incl - n4);
         const unsigned ae = a | (e << 15);  // a < 2^15, e <= 2^15
         bd_v4u ring_v[DEPTH];
         unsigned ring_idx[DEPTH], ring_valid[DEPTH];
         auto prep = [&](unsigned s0, unsigned &idx4, unsigned &valid, bd_v4u &v, bool by_hand = false) {
-            const unsigned s = s0 + (unsigned)lane;
-            int k = (int)__popcll(__ballot(incl <= s0));  // runs that end at or before the pass's first slot
-            unsigned r = (unsigned)k;
-            for (; k < 63; k++) {
-                const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)incl, k);
-                if (c > s0 + 63u) break;
-                r += s >= c ? 1u : 0u;
+            unsigned at = 0u, ok = 0u;
+            if (!PAD || s0 < total) {  // (the ring asks for passes behind the batch's last: record 0, nothing to answer)
+                const unsigned s = s0 + (unsigned)lane;
+                int k = (int)__popcll(__ballot(incl <= s0));  // runs that end at or before the pass's first slot
+                unsigned r = (unsigned)k;
+                for (; k < 63; k++) {
+                    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)incl, k);
+                    if (c > s0 + 63u) break;
+                    r += s >= c ? 1u : 0u;
+                }
+                r = r < 63u ? r : 63u;
+                const unsigned d = (unsigned)__shfl((int)delta, (int)r, 64), x = (unsigned)__shfl((int)ae, (int)r, 64);
+                const bool active = s < total;
+                at = active ? d + s : 0u;
+                if (PAD)
+                    ok = active ? 15u : 0u;
+                else
+                    ok = active ? bd_valid_mask((at & ((1u << (tile_log2 - 2)) - 1u)) << 2, x & 0x7fffu, x >> 15) : 0u;
             }
-            r = r < 63u ? r : 63u;
-            const unsigned d = (unsigned)__shfl((int)delta, (int)r, 64), x = (unsigned)__shfl((int)ae, (int)r, 64);
-            const bool active = s < total;
-            idx4 = active ? d + s : 0u;
-            valid = active ? bd_valid_mask((idx4 & slot_mask) << 2, x & 0x7fffu, x >> 15) : 0u;
+            idx4 = at, valid = ok;
             if (EXP == 3) {  // diagnostics: no record loads -- synthetic records (offsets all over the unit, lengths < 1000)
                 const unsigned h = idx4 * 2654435761u;
                 v = bd_v4u{(h & 0x3ffffu) | (500u << 18), ((h >> 3) & 0x3ffffu) | (100u << 18), ((h >> 7) & 0x3ffffu) | (900u << 18),
@@ -832,7 +865,35 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         // DEPTH passes at a time: their records requested together, then answered one after the other (the compiler's
         // wait counts only work out inside one iteration: with a ring carried around the loop it drains the memory
         // pipe -- loads AND the stores of the pass before -- in front of every pass)
-        if (PIPE) {
+        if (PIPE && PAD) {
+            // a ring of DEPTH passes: in front of a pass, the DEPTH - 1 other slots were (re)loaded after its own load
+            // and DEPTH - 1 passes stored once each.
+            // The memory pipe sees  [store, load] x DEPTH  at the start (the stores are dummies) and  [answer's store, load]
+            // per pass afterwards: 2 * DEPTH - 2 operations follow every load before its pass comes round again.  Passes
+            // past the end of the batch load record 0 and store a dummy: the count has to hold for them too -- the
+            // registers of a pass are scratch for the next load's address as soon as its wait is over (measured the hard
+            // way: a late record landing in the middle of an address computation is a memory fault).
+            unsigned short *nobody = out + (((size_t)tb + 1) * tile_slots << 2) - 2;  // the end of a tile's room: past every unit's padding
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) {
+                if (d > 0) bd_dummy_store(nobody);
+                prep(64u * d, ring_idx[d], ring_valid[d], ring_v[d], true);
+            }
+            for (unsigned s0 = 0; s0 < total; s0 += 64u * DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; d++) {
+                    bd_wait<2 * DEPTH - 2>(ring_v[d]);
+                    if (s0 + 64u * d < total)
+                        bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
+                    else
+                        bd_dummy_store(nobody);
+                    prep(s0 + 64u * (d + DEPTH), ring_idx[d], ring_valid[d], ring_v[d], true);
+                }
+            }
+            // the loads of the round after the last are still on their way: nothing may reuse their registers before they land
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) bd_wait<0>(ring_v[d]);
+        } else if (PIPE) {
             bd_v4u y_v[DEPTH];
             unsigned y_idx[DEPTH], y_valid[DEPTH];
             // When set X's pass d is wanted, at least these were issued after its load: X's passes d + 1 .. DEPTH - 1 and
@@ -887,14 +948,15 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
 // ---------------------------------------------------------------------------
 // bm_unpermute_kernel for 16-bit counts: half the bytes to read, half the LDS (two workgroups share a CU).
 // 0xFFFF = recompute from the sealed index (escape records, counts of 65535 and more).
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, bool PAD = false>
 __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned short *__restrict__ cnt /* tile-sorted */,
                                                                const unsigned short *__restrict__ slots, const BmSeg *__restrict__ segs,
                                                                const unsigned short *__restrict__ tile_seg,
                                                                unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS], may be NULL */,
-                                                               const unsigned *__restrict__ gate)
+                                                               const unsigned *__restrict__ gate, const unsigned *__restrict__ tend = nullptr)
 {
     constexpr int TILE = THREADS * ITEMS;
+    constexpr int STRIDE = PAD ? TILE + BM_PAD_ROOM : TILE;  // slots between two tiles of the count array (PAD: gaps between the units)
     static_assert(ITEMS % 8 == 0, "whole 16-byte vectors of 16-bit counts per thread");
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     if (gate && *gate == 0) return;
@@ -910,10 +972,14 @@ __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned sh
     const int32_t *__restrict__ e_sorted = sg.e_sorted;
     const int32_t *__restrict__ qs_arr = sg.qs + ltile * TILE, *__restrict__ qe_arr = sg.qe + ltile * TILE;  // escapes only
     int32_t *__restrict__ out = sg.counts + ltile * TILE;
-    cnt += tile * TILE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
+    cnt += tile * STRIDE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
     const int64_t nq = sg.nq - ltile * TILE;
     const int n = (int)(nq < TILE ? nq : TILE);
-    {
+    if (PAD) {
+        const int n8 = ((int)tend[tile] + 7) >> 3;  // the slots the tile's sorted order uses
+        const int4 *src = reinterpret_cast<const int4 *>(cnt);
+        for (int i = threadIdx.x; i < n8; i += THREADS) reinterpret_cast<int4 *>(vals)[i] = src[i];
+    } else {
         const int4 *src = reinterpret_cast<const int4 *>(cnt);
         if (n == TILE) {
             int4 v[ITEMS / 8];

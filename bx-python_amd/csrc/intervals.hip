@@ -2142,7 +2142,9 @@ static int64_t g_opt_dense = -1;      // search stage on dense unit images (coun
 static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
 static int64_t g_opt_bd_nt = 1;       // 1 = non-temporal image loads in the dense search kernel
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
-static int64_t g_opt_bd_depth = 0;    // passes of records per round and wave of the flat walk: 0 = by format (4 for the images, 2 for key slices), else 2, 3 or 4
+static int64_t g_opt_bd_depth = 0;    // passes of records in flight per wave of the flat walk: 0 = by layout (ring of 3 on padded runs, two sets of 4 on packed runs, 2 for key slices), else 2, 3, 4 (8: ring only)
+static int64_t g_opt_bd_pad = 1;      // 1 = the units' runs of a tile on whole 16-byte slots and the walk's ring of loads (count_dense.hpp), 0 = packed runs
+static int64_t g_opt_stage_sync = 0;  // diagnostics: wait for every stage of the count pass and say on stderr which one finished
 static int64_t g_opt_bd_pipe = 1;     // 1 = the walk keeps two sets of passes in flight (record loads issued by hand), 0 = one set per round
 static int64_t g_opt_bd_exp = 0;      // diagnostics only (wrong results): 1 = the dense search kernel without its lookups
 static int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
@@ -2282,7 +2284,15 @@ int ivl_set_option(const char *key, int64_t value)
         return 1;
     }
     if (!strcmp(key, "ivl.bd_depth")) {
-        g_opt_bd_depth = value == 2 || value == 3 || value == 4 ? value : 0;
+        g_opt_bd_depth = value == 2 || value == 3 || value == 4 || value == 8 ? value : 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bd_pad")) {
+        g_opt_bd_pad = value != 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.stage_sync")) {
+        g_opt_stage_sync = value;
         return 1;
     }
     if (!strcmp(key, "ivl.bd_pipe")) {
@@ -2344,7 +2354,7 @@ struct bxmi_ivl {
     BmGeom bp_geom{0, 0, 0, 0, 0, 0, 0, BP_RSHIFT, 0};
     DevBuf bp_images, bp_stats;
     bool bd_blocks = false;      // the images' ranks are relative to blocks of 1024 cells (more than 32767 keys in some unit's slice)
-    DevBuf bd_images, bd_stats, bd_cnt16, bd_unitT;
+    DevBuf bd_images, bd_stats, bd_cnt16, bd_unitT, bd_tend;
     bool sl_eid_ready = false;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][ONE_CAP hits][completion word:int64]
     unsigned long long one_seq = 0;
@@ -2784,16 +2794,25 @@ struct BmLaunch {
     int ngroups, tile_log2;
     size_t search_lds;
     const unsigned *gate;
+    bool pad = false;  // the units' runs on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): tile stride TILE + BM_PAD_ROOM
 };
 
 template <int THREADS, int ITEMS>
 static int bm_launch_tiles(const BmLaunch &L, hipStream_t st)
 {
     constexpr int TILE = THREADS * ITEMS;
-    const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64;
-    BXMI_TRY(allow_big_lds(bm_tile_sort_kernel<THREADS, ITEMS>, lds));
-    hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
-                       L.owner->bm_recs.as<unsigned>(), L.owner->bm_slots.as<unsigned short>(), L.owner->bm_tbl.as<unsigned short>(), L.gate);
+    bxmi_ivl *h = L.owner;
+    if (L.pad) {
+        const size_t lds = (size_t)(TILE + 3 * THREADS) * 4 + BM_NB * 4 + BM_NB * 2 + 64;
+        BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, true>), lds));
+        hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
+                           h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, h->bd_tend.as<unsigned>());
+    } else {
+        const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64;
+        BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, false>), lds));
+        hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, false>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
+                           h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, (unsigned *)nullptr);
+    }
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -2928,14 +2947,14 @@ static int sl_launch_search_flat(const BmLaunch &L, unsigned grid, hipStream_t s
     return BXMI_OK;
 }
 
-template <int FMT, bool QB, int EXP, int DEPTH, bool PIPE>
+template <int FMT, bool QB, int EXP, int DEPTH, bool PIPE, bool PAD = false>
 static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
-    BXMI_TRY(allow_big_lds((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE>), L.search_lds));
-    hipLaunchKernelGGL((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE>), dim3(grid), dim3(BD_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
-                       h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(), h->bd_cnt16.as<unsigned short>(),
-                       L.tile_log2, L.gate);
+    BXMI_TRY(allow_big_lds((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE, PAD>), L.search_lds));
+    hipLaunchKernelGGL((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE, PAD>), dim3(grid), dim3(BD_THREADS), L.search_lds, st, L.segs,
+                       h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(),
+                       h->bd_cnt16.as<unsigned short>(), L.tile_log2, L.gate);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -2943,6 +2962,16 @@ static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
 template <int FMT, bool QB, int EXP>
 static int bd_launch_search_d(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
+    if (L.pad) {  // the ring of the padded layout (hand-issued loads, exact wait counts)
+        switch (g_opt_bd_depth) {
+        case 2: return bd_launch_search_t<FMT, QB, EXP, 2, true, true>(L, grid, st);
+        case 4: return bd_launch_search_t<FMT, QB, EXP, 4, true, true>(L, grid, st);
+        case 8: return bd_launch_search_t<FMT, QB, EXP, 8, true, true>(L, grid, st);
+        // configs[1], search kernel: packed runs 315 us; ring of 2: 270, 3: 264, 4: 269, 6: 274 (every pass of a round that
+        // lies behind the batch's end still costs a load and a store)
+        default: return bd_launch_search_t<FMT, QB, EXP, 3, true, true>(L, grid, st);
+        }
+    }
     if (g_opt_bd_pipe) {
         switch (g_opt_bd_depth) {
         case 2: return bd_launch_search_t<FMT, QB, EXP, 2, true>(L, grid, st);
@@ -2961,7 +2990,7 @@ static int bd_launch_search(const BmLaunch &L, unsigned grid, int fmt /* 0 dense
 {
     // key slices: the lean shape (two passes per round, compiler-issued loads: 50 registers) -- two workgroups share a CU
     // when the units are small, one stages its unit while the other searches (a third of a sparse index's search time)
-    if (fmt == 2) return g_opt_bd_depth == 4 && g_opt_bd_pipe ? bd_launch_search_t<2, false, 0, 4, true>(L, grid, st) : bd_launch_search_t<2, false, 0, 2, false>(L, grid, st);
+    if (fmt == 2) return g_opt_bd_depth == 4 && g_opt_bd_pipe ? bd_launch_search_t<2, false, 0, 4, true>(L, grid, st) : bd_launch_search_t<2, false, 0, 2, false>(L, grid, st);  // (never padded: see bm_count_segments)
     const bool cells = fmt == 1;
     if (cells && g_opt_bd_exp == 3) return bd_launch_search_d<1, false, 3>(L, grid, st);
     if (cells) return g_opt_bd_exp == 1 ? bd_launch_search_d<1, false, 1>(L, grid, st) : bd_launch_search_d<1, false, 0>(L, grid, st);
@@ -2974,10 +3003,17 @@ template <int THREADS, int ITEMS>
 static int bd_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
-    const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned short);
-    BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS>), lds));
-    hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
-                       h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate);
+    if (L.pad) {
+        const size_t lds = (size_t)(THREADS * ITEMS + BM_PAD_ROOM) * sizeof(unsigned short);
+        BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, true>), lds));
+        hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, h->bd_tend.as<unsigned>());
+    } else {
+        const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned short);
+        BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, false>), lds));
+        hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, false>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, (const unsigned *)nullptr);
+    }
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -3054,17 +3090,26 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     }
     int64_t max_items = (int64_t)n * ((pair ? BM_NB / 2 : BM_NB) + 2) + 2 * (nq_all / chunk) + 2;
     if (dense) {  // every segment has at most BM_NB >> f units; empty workgroups of 157 KB of LDS are not free
-        max_items = 2 * (nq_all / chunk) + 2;
+        // (the padded layout counts up to three more slots per tile and unit as "queries" of the unit)
+        int64_t pad_slots = 0;
+        for (int i = 0; i < n; i++) pad_slots += 3 * (int64_t)(BM_NB >> segs[(size_t)i].g.f) * (segs[(size_t)i].tile_end - segs[(size_t)i].tile0);
+        max_items = 2 * ((nq_all + pad_slots) / chunk) + 2;
         for (int i = 0; i < n; i++) max_items += (BM_NB >> segs[(size_t)i].g.f) + 2;
     }
-    BXMI_TRY(h->bm_recs.reserve((size_t)ntp * tile * 4));
+    // PAD: every unit's run of a tile on whole 16-byte slots (the search's load ring needs one store per pass); the tile
+    // sort's scan keeps a unit inside one thread or a few neighbouring lanes
+    bool pad = (kind == 3 || cells) && g_opt_bd_pad != 0;
+    for (int i = 0; i < n && pad; i++) pad = (1 << segs[(size_t)i].g.f) >= (variant == 0 ? 4 : 2);
+    const int64_t tile_stride = tile + (pad ? BM_PAD_ROOM : 0);
+    BXMI_TRY(h->bm_recs.reserve((size_t)ntp * tile_stride * 4));
+    if (pad) BXMI_TRY(h->bd_tend.reserve((size_t)ntp * 4));
     BXMI_TRY(h->bm_slots.reserve((size_t)ntp * tile * 2));
     BXMI_TRY(h->bm_tbl.reserve((size_t)ntp * BM_NB * 2));
     if (!dense) BXMI_TRY(h->bm_runT.reserve((size_t)ntp * BM_NB * 4));
-    if (dense) BXMI_TRY(h->bd_unitT.reserve((size_t)ntp * BM_NB * 2));
+    if (dense) BXMI_TRY(h->bd_unitT.reserve((size_t)ntp * (BM_NB + 1) * 2));  // (+ the row behind the last unit)
     BXMI_TRY(h->bm_grpcnt.reserve((size_t)ngroups * BM_NB * 4));
     if (units) BXMI_TRY(h->sl_unitcnt.reserve((size_t)ngroups * BM_NB * 4));
-    if (dense) BXMI_TRY(h->bd_cnt16.reserve((size_t)ntp * tile * 2));
+    if (dense) BXMI_TRY(h->bd_cnt16.reserve((size_t)ntp * tile_stride * 2));
     BXMI_TRY(h->bm_items.reserve((size_t)(max_items + 2) * sizeof(int4)));  // [0] = the item count, items from [1]
     if (fx) {  // find(): counts apart from the records, and the tile-sorted offsets
         BXMI_TRY(h->sl_cnt.reserve((size_t)ntp * tile * 4));
@@ -3102,6 +3147,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.search_lds = slices ? sl_lds : dense ? max_stride * 16 : (size_t)(pair ? 2 : 1) * max_stride * sizeof(uint2);
     if (slices_flat && L.search_lds < 4096) L.search_lds = 4096;
     L.gate = unsorted;
+    L.pad = pad;
     if (unsorted) {
         // one index, its batch possibly sorted by start already: one pass over the queries as they lie then, and every
         // kernel below stands down (the local kernel exits at once otherwise)
@@ -3123,9 +3169,17 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY((bm_launch_tiles<1024, 16>(L, st)));
     else
         BXMI_TRY((bm_launch_tiles<512, 32>(L, st)));
+    auto stage_done = [&](const char *what) {
+        if (!g_opt_stage_sync) return;
+        const hipError_t e = hipStreamSynchronize(st);
+        fprintf(stderr, "[bxmi] count pass: %s %s (ntp %lld, pad %d, variant %d, chunk %d)\n", what, e == hipSuccess ? "done" : hipGetErrorString(e),
+                (long long)ntp, (int)pad, variant, chunk);
+    };
+    stage_done("tile sort");
     if (dense) {
         hipLaunchKernelGGL(bd_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
-                           tile_log2, h->bd_unitT.as<unsigned short>(), ntp, h->sl_unitcnt.as<unsigned>(), unsorted);
+                           tile_log2, h->bd_unitT.as<unsigned short>(), ntp, h->sl_unitcnt.as<unsigned>(), unsorted,
+                           pad ? h->bd_tend.as<unsigned>() : (const unsigned *)nullptr);
         if (n == 1)
             hipLaunchKernelGGL(bd_plan_kernel, dim3(1), dim3(1024), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, BM_NB >> segs[0].g.f, L.segs, chunk,
                                h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
@@ -3148,6 +3202,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
                            h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     }
     BXMI_LAUNCH_CHECK();
+    stage_done("transpose + plan");
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
     if (slices_flat)
         BXMI_TRY(bd_launch_search(L, sgrid, 2, false, st));
@@ -3169,6 +3224,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     else
         BXMI_TRY(bm_launch_search_u<false>(L, sgrid, st));
     unsigned *loff = fx ? h->sl_loff.as<unsigned>() : nullptr;
+    stage_done("search");
     if (dense) {
         if (variant == 2)
             BXMI_TRY((bd_launch_unpermute<1024, 32>(L, tslots, st)));
@@ -3178,6 +3234,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff)));
     else
         BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff)));
+    stage_done("unpermute");
     if (any_total) {
         hipLaunchKernelGGL(bm_fold_totals_kernel, dim3((unsigned)n), dim3(64), 0, st, slots,
                            reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes));

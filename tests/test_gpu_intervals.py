@@ -37,7 +37,7 @@ def set_opt(key, value):
 
 DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
                 "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 1, "ivl.bm_exp": 0, "ivl.slice": -1, "ivl.sl_f": -1,
-                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 0, "ivl.lc_loop": 0, "ivl.bd_pipe": 1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 0, "ivl.bd_blocks": 0,
+                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 0, "ivl.lc_loop": 0, "ivl.bd_pipe": 1, "ivl.bd_pad": 1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 0, "ivl.bd_blocks": 0,
                 "ivl.bm_chunk": 0}
 
 
@@ -453,13 +453,15 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
             set_opt("ivl.dense", 1)
             if shape == "dups" and stage == "flat":
                 set_opt("ivl.bm_hard_ppm", 10**6)  # (two cells' worth of piled-up coordinates and 60 000 repeated starts: keep the cells anyway)
-            for k, (variant, chunk, depth, pipe, blocks) in enumerate(((0, 0, 4, 1, 0), (1, 4096, 2, 0, 1), (2, 1 << 20, 3, 1, 1), (-1, 20000, 4, 0, 0),
-                                                                      (0, 1024, 2, 1, 0))):
+            # pad: the units' runs of a tile on whole 16-byte slots + the ring of record loads, or packed runs
+            for k, (variant, chunk, depth, pipe, blocks, pad) in enumerate(((0, 0, 4, 1, 0, 1), (1, 4096, 2, 0, 1, 0), (2, 1 << 20, 3, 1, 1, 0), (-1, 20000, 4, 0, 0, 0),
+                                                                           (0, 1024, 2, 1, 0, 1), (2, 0, 8, 1, 1, 1), (1, 65536, 3, 1, 0, 1), (2, 4096, 4, 1, 0, 0))):
                 set_opt("ivl.sorted_path", k % 2)
                 set_opt("ivl.bm_variant", variant)
                 set_opt("ivl.bd_chunk", chunk)
                 set_opt("ivl.bd_depth", depth)
                 set_opt("ivl.bd_pipe", pipe)
+                set_opt("ivl.bd_pad", pad)
                 if stage == "dense" and blocks != ix_blocks[0]:
                     set_opt("ivl.bd_blocks", blocks)
                     ix.seal()  # (the rank base of the images is decided when the index is prepared)
@@ -469,7 +471,7 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                 assert state[0] == 1 and ix.bitmap_state()[0] == 0 and ix.slice_state()[0] == 0, (state, ix.bitmap_state(), ix.slice_state())
                 assert (ix.flat_state()[0] == 0) == (stage == "dense")
                 bad = np.nonzero(got != want)[0]
-                assert len(bad) == 0, (shape, stage, variant, chunk, depth, pipe, blocks, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+                assert len(bad) == 0, (shape, stage, variant, chunk, depth, pipe, blocks, pad, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
                 assert got_total == want_total
             if shape == "dups":
                 assert (state[1][1] > 100) if stage == "dense" else (state[1] > 0)  # overflow entries / hard cells
@@ -787,6 +789,40 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
     # monotonicity: widening a query never loses hits
     wide, _ = ix.count(qs[:1_000_000] - 100, qe[:1_000_000] + 100)
     assert (wide >= counts[:1_000_000]).all()
+
+
+@pytest.mark.parametrize("stage", ["dense", "flat"])
+def test_padded_runs_on_many_full_tiles(O, IntervalIndex, stage):
+    """The padded layout of the flat walk (every unit's run of a tile on whole 16-byte slots, ring of record loads) at the
+    shape the headline uses: 32768-query tiles, all of them full but the last, batches of 64 tiles per wave, several rounds
+    of the ring per batch -- against the oracle treap, for every ring depth and against the packed layout."""
+    rng = np.random.default_rng(77)
+    n, span = 300_000, 60_000_000
+    s = rng.integers(1000, span, size=n)
+    e = s + rng.integers(1, 1500, size=n)
+    nq = 32768 * 150 + 4321
+    qs = rng.integers(0, span + 2000, size=nq)
+    qe = qs + rng.integers(1, 3000, size=nq)
+    s, e, qs, qe = (a.astype(np.int32) for a in (s, e, qs, qe))
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    want, want_total = t.count_batch(qs, qe)
+    ix = make_index(IntervalIndex, s, e)
+    set_opt("ivl.partition", 1)
+    set_opt("ivl.bm_variant", 2)
+    set_opt("ivl.flat", 1 if stage == "flat" else 0)
+    set_opt("ivl.dense", 1)
+    try:
+        for pad, depth in ((0, 4), (1, 4), (1, 8), (1, 2), (1, 3), (1, 0)):
+            set_opt("ivl.bd_pad", pad)
+            set_opt("ivl.bd_depth", depth)
+            got, got_total = ix.count(qs, qe)
+            state = ix.dense_state() if stage == "dense" else ix.flat_state()
+            assert state[0] == 1, state
+            bad = np.nonzero(got != want)[0]
+            assert len(bad) == 0 and got_total == want_total, (stage, pad, depth, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+    finally:
+        reset_opts()
 
 
 def test_clustered_distribution_differential(O, IntervalIndex):
