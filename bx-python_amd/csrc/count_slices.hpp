@@ -706,4 +706,124 @@ __global__ __launch_bounds__(THREADS) void sl_hits_unpermute_kernel(const BmSeg 
     }
 }
 
+// The same copy laid out for the L2: a run of ~20 bytes drags a 128-byte line of the tile's region from HBM, and with one
+// workgroup per tile (32 tiles = 21 MB of regions per XCD against 4 MB of L2) the line is gone before the next run in it
+// is asked for -- measured 6.8 GB fetched for 1 GB of hits (TCC_MISS = one per query).  Here the unit of work is HC_Q
+// CONSECUTIVE queries of a tile, and the units of an XCD's tiles (tile = 8 i + xcd; blockIdx -> XCD is round robin) are
+// taken in order by the XCD's 64 resident workgroups: two or three tiles' regions, offsets and CSR windows are live in an
+// XCD's L2 at a time (measured: 1.7 GB fetched, the regions once + the offsets, slots and scratch offsets).  No LDS: the
+// scratch offset of a query comes from the tile's `loff` array by its slot (an L2 hit after the first touch); the
+// streaming inputs are read with non-temporal loads so that they do not push the regions out.
+// One workgroup per unit, in unit order (two of 1024 threads per CU = 64 units in flight per XCD; units of 256 queries
+// and eight workgroups per CU: the same 0.92 ms).  Persistent workgroups that spread the three dependent reads of a unit
+// (offsets + slot -> scratch offset -> hits) over three rounds of a loop were slower both times they were tried
+// (1.31 ms with 64 x 1024 threads per XCD, 1.17 ms with 256 x 256 and nothing consumed in the round that loads it).
+constexpr int HC_Q = 1024;  // queries per unit = threads per workgroup
+
+struct HcUnit {  // one unit as a thread sees it
+    const int32_t *region;  // the tile's region of the scratch list
+    const unsigned *lo_t;   // the tile's scratch offsets by slot
+    const BmSeg *sg;
+    int64_t q;              // the thread's query (in its segment)
+    long long o, o_next;    // its CSR range
+    bool live;              // (not past the end of the tile)
+    unsigned slot;
+};
+
+template <int TILE>
+__global__ __launch_bounds__(HC_Q) void sl_hits_copy_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
+                                                            const unsigned *__restrict__ loff, const unsigned short *__restrict__ slots,
+                                                            const long long *__restrict__ offsets, const int32_t *__restrict__ tmp_hits,
+                                                            int32_t *__restrict__ hits, int64_t ntp)
+{
+    constexpr int PARTS = TILE / HC_Q;
+    __shared__ unsigned s_ends[HC_Q / 64][64];  // per wave: where each query's hits end in the wave's stretch
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int64_t unit = (int64_t)(blockIdx.x >> 3), units = ((ntp + 7 - xcd) >> 3) * PARTS;  // of this XCD's tiles
+    const int lane = lane_id();
+    // stage 1: where the unit lies, the thread's CSR range and slot (all loads independent of each other)
+    auto stage1 = [&](int64_t u, HcUnit &m) {
+        m.live = false, m.slot = 0u, m.o = 0, m.o_next = 0, m.q = 0, m.sg = segs, m.region = tmp_hits, m.lo_t = loff;
+        if (u >= units) return;
+        const int64_t tile = (u / PARTS) * 8 + xcd;
+        const int part = (int)(u % PARTS);
+        const BmSeg *sg = segs + tile_seg[tile];
+        const int64_t ltile = tile - sg->tile0;
+        if (ltile >= sg->ntiles) return;  // padding up to the next plan group
+        const int64_t q0 = ltile * TILE;
+        const int64_t left = sg->nq - q0;
+        const int n = (int)(left < TILE ? left : TILE);
+        const int k = part * HC_Q + (int)threadIdx.x;
+        const long long *__restrict__ off_t = offsets + q0;
+        m.sg = sg;
+        m.region = tmp_hits + off_t[0];
+        m.lo_t = loff + tile * TILE;
+        if (k >= n) return;
+        m.q = q0 + k;
+        m.live = true;
+        m.o = __builtin_nontemporal_load(off_t + k);
+        m.o_next = __builtin_nontemporal_load(off_t + k + 1);
+        m.slot = __builtin_nontemporal_load(slots + tile * TILE + k);
+    };
+    // stage 3: the wave's 64 consecutive queries own one stretch of the CSR list (escape records leave holes in it,
+    // filled by their own lanes).  The stretch is copied as ONE flat sequence: position s of it belongs to query
+    // r = #{queries whose hits end at or before s}; lane i takes positions i, i + 64, ... -- a store instruction writes
+    // 256 contiguous bytes instead of one 20-byte piece per query (measured on configs[4] for eight lanes per query:
+    // 66 M write and 101 M read requests at the L2 for 50 M queries).
+    auto copy = [&](const HcUnit &m, unsigned my_sv) {
+        const unsigned my_c = m.live ? (unsigned)(m.o_next - m.o) : 0u;
+        const unsigned n_me = (my_sv >> 31) ? 0u : my_c;
+        const unsigned incl = wave_inclusive_scan(n_me, OpSum());
+        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        const long long o_first = __shfl(m.o, 0, 64);
+        int32_t *__restrict__ out = hits + o_first;
+        const int32_t *__restrict__ region = m.region;
+        const unsigned d_src = my_sv - (incl - n_me);                       // + s = the hit's place in the tile's region
+        const unsigned d_dst = (unsigned)(m.o - o_first) - (incl - n_me);   // + s = its place behind the wave's first CSR offset
+        // r by six halvings over the wave's 64 prefix sums in LDS (walking them with readlane, as the count pass's flat walk
+        // does for its 16-byte slots, cost 540 scalar + 380 vector instructions per wave here: a pass of 64 hits spans ~13 queries)
+        unsigned *ends = s_ends[threadIdx.x >> 6];
+        ends[lane] = incl;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        auto locate = [&](unsigned s0, unsigned &src, unsigned &dst, bool &active) {
+            const unsigned s = s0 + (unsigned)lane;
+            unsigned r = 0u;
+#pragma unroll
+            for (unsigned step = 32u; step >= 1u; step >>= 1)
+                if (ends[r + step - 1u] <= s) r += step;
+            r = r < 63u ? r : 63u;
+            active = s < total;
+            src = (unsigned)__shfl((int)d_src, (int)r, 64) + s;
+            dst = (unsigned)__shfl((int)d_dst, (int)r, 64) + s;
+        };
+        for (unsigned s0 = 0; s0 < total; s0 += 256u) {  // four passes at a time: their loads in flight together
+            unsigned src[4], dst[4];
+            bool act[4];
+            int v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (s0 + 64u * j < total) {  // (wave-uniform)
+                    locate(s0 + 64u * j, src[j], dst[j], act[j]);
+                    v[j] = region[act[j] ? src[j] : 0u];
+                }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (s0 + 64u * j < total && act[j]) out[dst[j]] = v[j];
+        }
+        if ((my_sv >> 31) && my_c) {  // escape record: rare, answered from the sealed index by its own lane
+            const IndexDev ix = m.sg->ix;
+            const int qs = m.sg->qs[m.q], qe = m.sg->qe[m.q];
+            int cc = (int)my_c;
+            int32_t *__restrict__ dst = hits + m.o;
+            for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; cc > 0; j--)
+                if (ix.e_ord[j] > qs) dst[--cc] = ix.idx[j];
+        }
+    };
+    if (unit >= units) return;
+    HcUnit a;
+    stage1(unit, a);
+    copy(a, a.lo_t[a.slot]);
+}
+
 }  // namespace bxmi

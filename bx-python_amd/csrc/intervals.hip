@@ -2129,6 +2129,7 @@ static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through 
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
 static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by run length and LDS, else forced (tests)
 static int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_CHUNK, twice that for bucket pairs)
+static int64_t g_opt_sl_hcopy = 1;     // hit un-permute: 1 = sl_hits_copy_kernel (1024 consecutive queries per workgroup, a tile's workgroups on one XCD), 0 = one workgroup per tile
 static int64_t g_opt_sl_hu_parts = 1;  // hit un-permute: workgroups per tile (1, 2, 4, 8, 16), run back to back on one XCD
 static int64_t g_opt_sl_run_cap = 160;  // a slice unit grows only while its expected (tile, unit) run stays within this many records
 static int64_t g_opt_find_pairs = 1;   // sorted find(): the fill reads (end, index) pairs (one array) instead of the two index arrays
@@ -2229,6 +2230,10 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.bm_chunk")) {
         g_opt_bm_chunk = value < 0 ? 0 : value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.sl_hcopy")) {
+        g_opt_sl_hcopy = value != 0;
         return 1;
     }
     if (!strcmp(key, "ivl.sl_hu_parts")) {
@@ -2919,6 +2924,14 @@ static int sl_launch_hits_unpermute(const BmLaunch &L, hipStream_t st, const uns
                                     int32_t *hits)
 {
     bxmi_ivl *h = L.owner;
+    if (g_opt_sl_hcopy) {
+        constexpr int TILE = THREADS * ITEMS;
+        const unsigned grid = (unsigned)(div_up(L.ntp, 8) * 8 * (TILE / HC_Q));
+        hipLaunchKernelGGL((sl_hits_copy_kernel<TILE>), dim3(grid), dim3(HC_Q), 0, st, L.segs, L.tile_seg, loff, h->bm_slots.as<unsigned short>(), offsets,
+                           tmp_hits, hits, L.ntp);
+        BXMI_LAUNCH_CHECK();
+        return BXMI_OK;
+    }
     const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);
     BXMI_TRY(allow_big_lds((sl_hits_unpermute_kernel<THREADS, ITEMS>), lds));
     const int parts = g_opt_sl_hu_parts > 0 ? (int)g_opt_sl_hu_parts : 1;

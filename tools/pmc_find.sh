@@ -8,12 +8,8 @@ rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 i=0
-while read -r grp; do
-  [ -z "$grp" ] && continue
-  i=$((i+1))
-  MODE=${MODE:-random} timeout 300 rocprofv3 --pmc $grp -d $OUT/run$i -o p --output-format csv -- python $REPO/tools/bench_find.py > $OUT/run$i.log 2>&1
-  echo "run$i [$grp] rc=$?" >> $OUT/index.txt
-done <<'GROUPS'
+# PMC_GROUPS="FETCH_SIZE;WRITE_SIZE" limits the passes (one rocprofv3 run of ~25 s each)
+if [ -n "${PMC_GROUPS:-}" ]; then exec 3< <(echo "$PMC_GROUPS" | tr ';' '\n'); else exec 3< <(cat <<'GROUPS'
 FETCH_SIZE
 WRITE_SIZE
 TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum
@@ -21,6 +17,13 @@ TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 GROUPS
+); fi
+while read -r grp <&3; do
+  [ -z "$grp" ] && continue
+  i=$((i+1))
+  MODE=${MODE:-random} timeout 300 rocprofv3 --pmc $grp -d $OUT/run$i -o p --output-format csv -- python $REPO/tools/bench_find.py > $OUT/run$i.log 2>&1
+  echo "run$i [$grp] rc=$?" >> $OUT/index.txt
+done
 cd $REPO
 python - <<'PY'
 import csv, glob, collections
