@@ -96,6 +96,14 @@ class IntervalIndex:
         call("bxmi_ivl_flat_state", self._h, C.byref(st), C.byref(hc))
         return st.value, hc.value
 
+    def count_width(self):
+        """(bits, wide_counts): 8 or 16 bits per count between the search and the un-permute kernel of a flat-walk pass, and how
+        many counts did not fit 8 bits so far (as last mirrored to the host)."""
+        self._ready()
+        bits, wide = C.c_int(0), C.c_int64(0)
+        call("bxmi_ivl_count_width", self._h, C.byref(bits), C.byref(wide))
+        return bits.value, wide.value
+
     def dense_state(self):
         """(state, [most keys of a block, most overflow entries of a unit]) of the dense-image search stage: 1 = usable,
         -1 = the index does not fit the format, 0 = undecided."""

@@ -623,7 +623,9 @@ __device__ __forceinline__ unsigned bd_count16(int bias, int rS, int rE, unsigne
 // and not stored)
 // EXP (diagnostics, ivl.bd_exp; wrong results): 1 = no lookups at all -- the price of the walk and of its memory traffic alone
 // FMT: 0 = dense unit image, 1 = cell image, 2 = staged key slices
-template <int FMT, bool QB, int EXP>
+// W8: the counts are 8 bits wide (0xFF = "ask the index again": escape records and counts of 255 and more) -- half the bytes
+// for indexes whose counts are small; the host decides per batch (bm_count_segments).
+template <int FMT, bool QB, int EXP, bool W8 = false>
 __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short *__restrict__ out, unsigned idx4, unsigned valid, bd_v4u v)
 {
     if (valid == 0u) return;
@@ -655,6 +657,19 @@ __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short 
     unsigned short *p = out + 4 * (size_t)idx4;
     if (EXP == 3) {  // diagnostics: the lookups alone -- nothing stored unless a count is impossible
         if ((c[0] & c[1] & c[2] & c[3]) == 0x12345u) p[0] = 1;
+        return;
+    }
+    if (W8) {
+        unsigned char *p8 = reinterpret_cast<unsigned char *>(out) + 4 * (size_t)idx4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = c[j] < 0xFFu ? c[j] : 0xFFu;
+        if (valid == 15u) {
+            *reinterpret_cast<unsigned *>(p8) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (valid & (1u << j)) p8[j] = (unsigned char)c[j];
+        }
         return;
     }
     if (valid == 15u) {
@@ -708,7 +723,7 @@ __device__ __forceinline__ void bd_dummy_store(unsigned short *slot)
 // PAD: the tile sort left every unit's run on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): no slot is shared with a
 // neighbouring unit, every answered pass is exactly one store, and the walk keeps a RING of DEPTH passes in flight all
 // the time -- the wait in front of a pass counts the DEPTH - 1 younger loads and the DEPTH - 1 stores issued since.
-template <int FMT, bool QB, int EXP = 0, int DEPTH = 2, bool PIPE = false, bool PAD = false>
+template <int FMT, bool QB, int EXP = 0, int DEPTH = 2, bool PIPE = false, bool PAD = false, bool W8 = false>
 __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                const int *__restrict__ n_items, const unsigned short *__restrict__ unitT, int64_t ntp,
                                                                const unsigned *__restrict__ recs /* tile-sorted records */,
@@ -873,7 +888,9 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
             // past the end of the batch load record 0 and store a dummy: the count has to hold for them too -- the
             // registers of a pass are scratch for the next load's address as soon as its wait is over (measured the hard
             // way: a late record landing in the middle of an address computation is a memory fault).
-            unsigned short *nobody = out + (((size_t)tb + 1) * tile_slots << 2) - 2;  // the end of a tile's room: past every unit's padding
+            // the end of a tile's room: past every unit's padding
+            unsigned short *nobody = W8 ? reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned char *>(out) + (((size_t)tb + 1) * tile_slots << 2) - 4)
+                                        : out + (((size_t)tb + 1) * tile_slots << 2) - 2;
 #pragma unroll
             for (int d = 0; d < DEPTH; d++) {
                 if (d > 0) bd_dummy_store(nobody);
@@ -884,7 +901,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
                 for (int d = 0; d < DEPTH; d++) {
                     bd_wait<2 * DEPTH - 2>(ring_v[d]);
                     if (s0 + 64u * d < total)
-                        bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
+                        bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
                     else
                         bd_dummy_store(nobody);
                     prep(s0 + 64u * (d + DEPTH), ring_idx[d], ring_valid[d], ring_v[d], true);
@@ -905,16 +922,16 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
             for (unsigned s0 = 0; s0 < total; s0 += 128u * DEPTH) {
 #pragma unroll
                 for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * (DEPTH + d), y_idx[d], y_valid[d], y_v[d], true);
-                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(ring_v[0]); bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[0], ring_valid[0], ring_v[0]); }
-                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(ring_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[1 % DEPTH], ring_valid[1 % DEPTH], ring_v[1 % DEPTH]); }
-                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(ring_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[2 % DEPTH], ring_valid[2 % DEPTH], ring_v[2 % DEPTH]); }
-                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(ring_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[3 % DEPTH], ring_valid[3 % DEPTH], ring_v[3 % DEPTH]); }
+                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(ring_v[0]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[0], ring_valid[0], ring_v[0]); }
+                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(ring_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[1 % DEPTH], ring_valid[1 % DEPTH], ring_v[1 % DEPTH]); }
+                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(ring_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[2 % DEPTH], ring_valid[2 % DEPTH], ring_v[2 % DEPTH]); }
+                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(ring_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[3 % DEPTH], ring_valid[3 % DEPTH], ring_v[3 % DEPTH]); }
 #pragma unroll
                 for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * (2 * DEPTH + d), ring_idx[d], ring_valid[d], ring_v[d], true);
-                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(y_v[0]); bd_answer_slot<FMT, QB, EXP>(I, out, y_idx[0], y_valid[0], y_v[0]); }
-                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(y_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, y_idx[1 % DEPTH], y_valid[1 % DEPTH], y_v[1 % DEPTH]); }
-                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(y_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, y_idx[2 % DEPTH], y_valid[2 % DEPTH], y_v[2 % DEPTH]); }
-                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(y_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP>(I, out, y_idx[3 % DEPTH], y_valid[3 % DEPTH], y_v[3 % DEPTH]); }
+                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(y_v[0]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, y_idx[0], y_valid[0], y_v[0]); }
+                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(y_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, y_idx[1 % DEPTH], y_valid[1 % DEPTH], y_v[1 % DEPTH]); }
+                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(y_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, y_idx[2 % DEPTH], y_valid[2 % DEPTH], y_v[2 % DEPTH]); }
+                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(y_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, y_idx[3 % DEPTH], y_valid[3 % DEPTH], y_v[3 % DEPTH]); }
             }
             // the loads of the round after the last are still on their way: nothing may reuse their registers before they land
 #pragma unroll
@@ -924,7 +941,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
 #pragma unroll
             for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * d, ring_idx[d], ring_valid[d], ring_v[d]);
 #pragma unroll
-            for (int d = 0; d < DEPTH; d++) bd_answer_slot<FMT, QB, EXP>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
+            for (int d = 0; d < DEPTH; d++) bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
         }
         tb = tn;
     }
@@ -937,7 +954,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
             const unsigned q0 = first >> 2, nq4 = ((end + 3u) >> 2) - q0;
             for (unsigned q = threadIdx.x; q < nq4; q += BD_THREADS) {
                 const unsigned idx4 = q0 + q;
-                bd_answer_slot<FMT, QB, EXP>(I, out, idx4, bd_valid_mask(4u * idx4, first, end), reinterpret_cast<const bd_v4u *>(recs)[idx4]);
+                bd_answer_slot<FMT, QB, EXP, W8>(I, out, idx4, bd_valid_mask(4u * idx4, first, end), reinterpret_cast<const bd_v4u *>(recs)[idx4]);
             }
         }
     }
@@ -948,12 +965,14 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
 // ---------------------------------------------------------------------------
 // bm_unpermute_kernel for 16-bit counts: half the bytes to read, half the LDS (two workgroups share a CU).
 // 0xFFFF = recompute from the sealed index (escape records, counts of 65535 and more).
-template <int THREADS, int ITEMS, bool PAD = false>
-__global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned short *__restrict__ cnt /* tile-sorted */,
+template <int THREADS, int ITEMS, bool PAD = false, bool W8 = false>
+__global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned short *__restrict__ cnt /* tile-sorted; W8: bytes */,
                                                                const unsigned short *__restrict__ slots, const BmSeg *__restrict__ segs,
                                                                const unsigned short *__restrict__ tile_seg,
                                                                unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS], may be NULL */,
-                                                               const unsigned *__restrict__ gate, const unsigned *__restrict__ tend = nullptr)
+                                                               const unsigned *__restrict__ gate, const unsigned *__restrict__ tend = nullptr,
+                                                               unsigned long long *__restrict__ fb_dev = nullptr /* W8: counts that did not fit, ever */,
+                                                               unsigned long long *__restrict__ fb_host = nullptr /* its copy in host memory */)
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int STRIDE = PAD ? TILE + BM_PAD_ROOM : TILE;  // slots between two tiles of the count array (PAD: gaps between the units)
@@ -972,11 +991,15 @@ __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned sh
     const int32_t *__restrict__ e_sorted = sg.e_sorted;
     const int32_t *__restrict__ qs_arr = sg.qs + ltile * TILE, *__restrict__ qe_arr = sg.qe + ltile * TILE;  // escapes only
     int32_t *__restrict__ out = sg.counts + ltile * TILE;
-    cnt += tile * STRIDE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
+    static_assert(!W8 || PAD, "8-bit counts come with the padded layout");
+    const unsigned char *vals8 = reinterpret_cast<const unsigned char *>(dyn);
+    cnt = W8 ? reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(cnt) + tile * STRIDE) : cnt + tile * STRIDE;
+    slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
     const int64_t nq = sg.nq - ltile * TILE;
     const int n = (int)(nq < TILE ? nq : TILE);
+    constexpr unsigned ESC = W8 ? 0xFFu : 0xFFFFu;
     if (PAD) {
-        const int n8 = ((int)tend[tile] + 7) >> 3;  // the slots the tile's sorted order uses
+        const int n8 = W8 ? ((int)tend[tile] + 15) >> 4 : ((int)tend[tile] + 7) >> 3;  // the slots the tile's sorted order uses
         const int4 *src = reinterpret_cast<const int4 *>(cnt);
         for (int i = threadIdx.x; i < n8; i += THREADS) reinterpret_cast<int4 *>(vals)[i] = src[i];
     } else {
@@ -994,6 +1017,7 @@ __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned sh
     }
     __syncthreads();
     long long acc = 0;
+    unsigned wide = 0;  // W8: counts of this thread that came back as "ask again"
     if (n == TILE) {
         const uint2 *l4 = reinterpret_cast<const uint2 *>(slots);
         int4 *o4 = reinterpret_cast<int4 *>(out);
@@ -1002,25 +1026,48 @@ __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned sh
         for (int j = 0; j < ITEMS / 4; j++) sl[j] = l4[j * THREADS + threadIdx.x];
 #pragma unroll
         for (int j = 0; j < ITEMS / 4; j++) {
-            unsigned c[4] = {vals[sl[j].x & 0xffffu], vals[sl[j].x >> 16], vals[sl[j].y & 0xffffu], vals[sl[j].y >> 16]};
-            if (c[0] == 0xFFFFu || c[1] == 0xFFFFu || c[2] == 0xFFFFu || c[3] == 0xFFFFu) {
+            unsigned c[4];
+            if (W8) {
+                c[0] = vals8[sl[j].x & 0xffffu], c[1] = vals8[sl[j].x >> 16], c[2] = vals8[sl[j].y & 0xffffu], c[3] = vals8[sl[j].y >> 16];
+            } else {
+                c[0] = vals[sl[j].x & 0xffffu], c[1] = vals[sl[j].x >> 16], c[2] = vals[sl[j].y & 0xffffu], c[3] = vals[sl[j].y >> 16];
+            }
+            if (c[0] == ESC || c[1] == ESC || c[2] == ESC || c[3] == ESC) {
                 const int64_t k0 = 4 * (int64_t)(j * THREADS + threadIdx.x);
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (c[u] == 0xFFFFu) c[u] = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k0 + u], qe_arr[k0 + u]);
+                    if (c[u] == ESC) {
+                        c[u] = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k0 + u], qe_arr[k0 + u]);
+                        wide++;
+                    }
             }
             o4[j * THREADS + threadIdx.x] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);
             acc += (long long)c[0] + c[1] + c[2] + c[3];
         }
     } else {
         for (int k = threadIdx.x; k < n; k += THREADS) {
-            unsigned c = vals[slots[k]];
-            if (c == 0xFFFFu) c = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k], qe_arr[k]);
+            unsigned c = W8 ? (unsigned)vals8[slots[k]] : (unsigned)vals[slots[k]];
+            if (c == ESC) {
+                c = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k], qe_arr[k]);
+                wide++;
+            }
             out[k] = (int)c;
             acc += c;
         }
     }
     if (total_slots) block_accumulate_i64(acc, red, total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)));
+    if (W8 && fb_dev) {
+        // feedback for the host's choice of the count width (bm_count_segments): a running total of the counts that did
+        // not fit 8 bits, and -- from whichever workgroup comes first -- its value so far into host memory, where the
+        // next call finds it without a synchronisation (a pass or two late: the choice only has to converge)
+        if (__any(wide != 0u)) {
+            unsigned w = wide;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) w += (unsigned)__shfl_down((int)w, off, 64);
+            if (lane_id() == 0 && w) atomicAdd(fb_dev, (unsigned long long)w);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && fb_host) *fb_host = __hip_atomic_load(fb_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace bxmi

@@ -2144,6 +2144,7 @@ static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the den
 static int64_t g_opt_bd_nt = 1;       // 1 = non-temporal image loads in the dense search kernel
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
 static int64_t g_opt_bd_depth = 0;    // passes of records in flight per wave of the flat walk: 0 = by layout (ring of 3 on padded runs, two sets of 4 on packed runs, 2 for key slices), else 2, 3, 4 (8: ring only)
+static int64_t g_opt_bd_w8 = -1;      // 8-bit counts out of place: -1 = by index and feedback, 0 = never, 1 = whenever the layout allows
 static int64_t g_opt_bd_pad = 1;      // 1 = the units' runs of a tile on whole 16-byte slots and the walk's ring of loads (count_dense.hpp), 0 = packed runs
 static int64_t g_opt_stage_sync = 0;  // diagnostics: wait for every stage of the count pass and say on stderr which one finished
 static int64_t g_opt_bd_pipe = 1;     // 1 = the walk keeps two sets of passes in flight (record loads issued by hand), 0 = one set per round
@@ -2292,6 +2293,10 @@ int ivl_set_option(const char *key, int64_t value)
         g_opt_bd_depth = value == 2 || value == 3 || value == 4 || value == 8 ? value : 0;
         return 1;
     }
+    if (!strcmp(key, "ivl.bd_w8")) {
+        g_opt_bd_w8 = value;
+        return 1;
+    }
     if (!strcmp(key, "ivl.bd_pad")) {
         g_opt_bd_pad = value != 0;
         return 1;
@@ -2360,6 +2365,12 @@ struct bxmi_ivl {
     DevBuf bp_images, bp_stats;
     bool bd_blocks = false;      // the images' ranks are relative to blocks of 1024 cells (more than 32767 keys in some unit's slice)
     DevBuf bd_images, bd_stats, bd_cnt16, bd_unitT, bd_tend;
+    // 8-bit counts between the search and the un-permute kernel (bm_count_segments): the un-permute kernel keeps a running
+    // total of the counts that did not fit and mirrors it into host memory
+    DevBuf bd_fb;                              // the running total (device)
+    unsigned long long *bd_fb_host = nullptr;  // its mirror (host memory the device can write)
+    int64_t w8_queries = 0;                    // queries of the passes launched with 8-bit counts
+    bool w8_off = false;                       // too many of them did not fit: this index keeps 16-bit counts
     bool sl_eid_ready = false;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][ONE_CAP hits][completion word:int64]
     unsigned long long one_seq = 0;
@@ -2800,6 +2811,7 @@ struct BmLaunch {
     size_t search_lds;
     const unsigned *gate;
     bool pad = false;  // the units' runs on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): tile stride TILE + BM_PAD_ROOM
+    bool w8 = false;   // 8-bit counts between the search and the un-permute kernel (padded layout, cell images)
 };
 
 template <int THREADS, int ITEMS>
@@ -2960,12 +2972,12 @@ static int sl_launch_search_flat(const BmLaunch &L, unsigned grid, hipStream_t s
     return BXMI_OK;
 }
 
-template <int FMT, bool QB, int EXP, int DEPTH, bool PIPE, bool PAD = false>
+template <int FMT, bool QB, int EXP, int DEPTH, bool PIPE, bool PAD = false, bool W8 = false>
 static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
-    BXMI_TRY(allow_big_lds((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE, PAD>), L.search_lds));
-    hipLaunchKernelGGL((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE, PAD>), dim3(grid), dim3(BD_THREADS), L.search_lds, st, L.segs,
+    BXMI_TRY(allow_big_lds((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE, PAD, W8>), L.search_lds));
+    hipLaunchKernelGGL((bd_search_kernel<FMT, QB, EXP, DEPTH, PIPE, PAD, W8>), dim3(grid), dim3(BD_THREADS), L.search_lds, st, L.segs,
                        h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(),
                        h->bd_cnt16.as<unsigned short>(), L.tile_log2, L.gate);
     BXMI_LAUNCH_CHECK();
@@ -2976,6 +2988,7 @@ template <int FMT, bool QB, int EXP>
 static int bd_launch_search_d(const BmLaunch &L, unsigned grid, hipStream_t st)
 {
     if (L.pad) {  // the ring of the padded layout (hand-issued loads, exact wait counts)
+        if (L.w8 && FMT == 1 && EXP == 0 && !QB) return bd_launch_search_t<1, false, 0, 3, true, true, true>(L, grid, st);
         switch (g_opt_bd_depth) {
         case 2: return bd_launch_search_t<FMT, QB, EXP, 2, true, true>(L, grid, st);
         case 4: return bd_launch_search_t<FMT, QB, EXP, 4, true, true>(L, grid, st);
@@ -3016,7 +3029,13 @@ template <int THREADS, int ITEMS>
 static int bd_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
-    if (L.pad) {
+    if (L.pad && L.w8) {
+        const size_t lds = (size_t)(THREADS * ITEMS + BM_PAD_ROOM);
+        BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, true, true>), lds));
+        hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, true, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, h->bd_tend.as<unsigned>(),
+                           h->bd_fb.as<unsigned long long>(), h->bd_fb_host);
+    } else if (L.pad) {
         const size_t lds = (size_t)(THREADS * ITEMS + BM_PAD_ROOM) * sizeof(unsigned short);
         BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, true>), lds));
         hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
@@ -3161,6 +3180,26 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (slices_flat && L.search_lds < 4096) L.search_lds = 4096;
     L.gate = unsorted;
     L.pad = pad;
+    // 8-bit counts (0xFF = recomputed by the un-permute kernel, exact either way): half the bytes of the second exchange
+    // when the counts are small.  Cell images only serve indexes without piled-up coordinates, so the density says what to
+    // expect: fewer than 128 targets per 2048 coordinates (configs[1]: 82; a count of 255 needs a query of ~6000).  What the
+    // prediction misses -- long queries, targets crowded into part of the span -- the feedback catches: once more than one
+    // count in 64 did not fit, the index keeps 16-bit counts (worst case before that: every count recomputed, ~2 x the pass).
+    L.w8 = false;
+    if (pad && cells && n == 1 && g_opt_bd_w8 != 0 && g_opt_bd_exp == 0 && g_opt_bd_depth == 0) {
+        if (!h->bd_fb_host) {
+            BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->bd_fb_host), 64, hipHostMallocDefault));
+            *h->bd_fb_host = 0;
+            BXMI_TRY(h->bd_fb.reserve(64));
+            BXMI_HIP(hipMemsetAsync(h->bd_fb.p, 0, 64, st));
+        }
+        const unsigned long long wide = *reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host);
+        if ((int64_t)wide * 64 > h->w8_queries && wide > 4096) h->w8_off = true;
+        const int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin + 1;
+        const bool sparse_enough = (int64_t)h->n * 2048 < span * 128;
+        L.w8 = g_opt_bd_w8 > 0 || (!h->w8_off && sparse_enough);
+        if (L.w8) h->w8_queries += nq_all;
+    }
     if (unsorted) {
         // one index, its batch possibly sorted by start already: one pass over the queries as they lie then, and every
         // kernel below stands down (the local kernel exits at once otherwise)
@@ -3356,6 +3395,7 @@ extern "C" int bxmi_ivl_destroy(bxmi_ivl_t *h)
     if (!h) return BXMI_OK;
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->one_buf) (void)hipHostFree(h->one_buf);
+    if (h->bd_fb_host) (void)hipHostFree(h->bd_fb_host);
     delete h;
     return BXMI_OK;
 }
@@ -3478,6 +3518,11 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         h->sl_state = 0;
         h->bd_state = 0;
         h->bp_state = 0;
+        h->w8_off = false, h->w8_queries = 0;  // (the feedback of the 8-bit counts belongs to the index that was)
+        if (h->bd_fb_host) {
+            BXMI_HIP(hipMemsetAsync(h->bd_fb.p, 0, 64, st));
+            *h->bd_fb_host = 0;
+        }
         h->sl_eid_ready = false;
         BXMI_TRY(h->slice_bounds.reserve(PT_NB * sizeof(SliceBound)));
         hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
@@ -3525,6 +3570,16 @@ extern "C" int bxmi_ivl_flat_state(const bxmi_ivl_t *h, int *state, int64_t *har
     BXMI_TRY(need_sealed(h, "bxmi_ivl_flat_state"));
     if (state) *state = h->bp_state;
     if (hard_cells) *hard_cells = h->bp_hard_cells;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_count_width(const bxmi_ivl_t *h, int *bits, int64_t *wide_counts)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_count_width"));
+    const unsigned long long wide = h->bd_fb_host ? *reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host) : 0ull;
+    const int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin + 1;
+    if (bits) *bits = !h->w8_off && (int64_t)h->n * 2048 < span * 128 ? 8 : 16;
+    if (wide_counts) *wide_counts = (int64_t)wide;
     return BXMI_OK;
 }
 

@@ -131,6 +131,11 @@ int bxmi_ivl_dense_state(const bxmi_ivl_t *h, int *state, int64_t *worst);
  * index does not qualify (span wider than 2^29, reversed targets, too many cells with several duplicated coordinates:
  * *hard_cells of them).  This is the stage a dense index takes first.  Introspection only. */
 int bxmi_ivl_flat_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
+/* The width of the counts a flat-walk pass over cell images hands from its search to its un-permute kernel: *bits = 8
+ * while the index is sparse enough for small counts (fewer than 128 targets per 2048 coordinates) and fewer than one count
+ * in 64 of the passes so far came back as "does not fit" (*wide_counts of them, as last mirrored to the host; such counts
+ * are recomputed, the results are exact either way), else 16.  Introspection only. */
+int bxmi_ivl_count_width(const bxmi_ivl_t *h, int *bits, int64_t *wide_counts);
 
 /* IntervalTree.find for a batch, as CSR: offsets[nq+1] (int64) and, for query
  * i, hits[offsets[i]..offsets[i+1]) = insertion indices in the reference's

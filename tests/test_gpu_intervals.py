@@ -37,7 +37,7 @@ def set_opt(key, value):
 
 DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
                 "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 1, "ivl.bm_exp": 0, "ivl.slice": -1, "ivl.sl_f": -1,
-                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 0, "ivl.lc_loop": 0, "ivl.bd_pipe": 1, "ivl.bd_pad": 1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 0, "ivl.bd_blocks": 0,
+                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 0, "ivl.lc_loop": 0, "ivl.bd_pipe": 1, "ivl.bd_pad": 1, "ivl.bd_w8": -1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 0, "ivl.bd_blocks": 0,
                 "ivl.bm_chunk": 0}
 
 
@@ -454,14 +454,19 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
             if shape == "dups" and stage == "flat":
                 set_opt("ivl.bm_hard_ppm", 10**6)  # (two cells' worth of piled-up coordinates and 60 000 repeated starts: keep the cells anyway)
             # pad: the units' runs of a tile on whole 16-byte slots + the ring of record loads, or packed runs
-            for k, (variant, chunk, depth, pipe, blocks, pad) in enumerate(((0, 0, 4, 1, 0, 1), (1, 4096, 2, 0, 1, 0), (2, 1 << 20, 3, 1, 1, 0), (-1, 20000, 4, 0, 0, 0),
-                                                                           (0, 1024, 2, 1, 0, 1), (2, 0, 8, 1, 1, 1), (1, 65536, 3, 1, 0, 1), (2, 4096, 4, 1, 0, 0))):
+            # w8: 8-bit counts between the search and the un-permute kernel (cell images, padded layout, default depth): forced
+            # on (counts of 255 and more come back as "ask again" and are recomputed), off, or left to the density + feedback
+            for k, (variant, chunk, depth, pipe, blocks, pad, w8) in enumerate(((0, 0, 4, 1, 0, 1, 0), (1, 4096, 2, 0, 1, 0, 0), (2, 1 << 20, 3, 1, 1, 0, 0),
+                                                                               (-1, 20000, 4, 0, 0, 0, 0), (0, 1024, 2, 1, 0, 1, 0), (2, 0, 8, 1, 1, 1, 0),
+                                                                               (1, 65536, 3, 1, 0, 1, 0), (2, 4096, 4, 1, 0, 0, 0), (2, 0, 0, 1, 0, 1, 1),
+                                                                               (1, 8192, 0, 1, 0, 1, 1), (-1, 0, 0, 1, 0, 1, -1), (2, 0, 0, 1, 0, 1, 0))):
                 set_opt("ivl.sorted_path", k % 2)
                 set_opt("ivl.bm_variant", variant)
                 set_opt("ivl.bd_chunk", chunk)
                 set_opt("ivl.bd_depth", depth)
                 set_opt("ivl.bd_pipe", pipe)
                 set_opt("ivl.bd_pad", pad)
+                set_opt("ivl.bd_w8", w8)
                 if stage == "dense" and blocks != ix_blocks[0]:
                     set_opt("ivl.bd_blocks", blocks)
                     ix.seal()  # (the rank base of the images is decided when the index is prepared)
@@ -471,7 +476,7 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                 assert state[0] == 1 and ix.bitmap_state()[0] == 0 and ix.slice_state()[0] == 0, (state, ix.bitmap_state(), ix.slice_state())
                 assert (ix.flat_state()[0] == 0) == (stage == "dense")
                 bad = np.nonzero(got != want)[0]
-                assert len(bad) == 0, (shape, stage, variant, chunk, depth, pipe, blocks, pad, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+                assert len(bad) == 0, (shape, stage, variant, chunk, depth, pipe, blocks, pad, w8, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
                 assert got_total == want_total
             if shape == "dups":
                 assert (state[1][1] > 100) if stage == "dense" else (state[1] > 0)  # overflow entries / hard cells
@@ -813,14 +818,55 @@ def test_padded_runs_on_many_full_tiles(O, IntervalIndex, stage):
     set_opt("ivl.flat", 1 if stage == "flat" else 0)
     set_opt("ivl.dense", 1)
     try:
-        for pad, depth in ((0, 4), (1, 4), (1, 8), (1, 2), (1, 3), (1, 0)):
+        for pad, depth, w8 in ((0, 4, 0), (1, 4, 0), (1, 8, 0), (1, 2, 0), (1, 3, 0), (1, 0, 0), (1, 0, 1), (1, 0, -1)):
             set_opt("ivl.bd_pad", pad)
             set_opt("ivl.bd_depth", depth)
+            set_opt("ivl.bd_w8", w8)
             got, got_total = ix.count(qs, qe)
             state = ix.dense_state() if stage == "dense" else ix.flat_state()
             assert state[0] == 1, state
             bad = np.nonzero(got != want)[0]
-            assert len(bad) == 0 and got_total == want_total, (stage, pad, depth, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+            assert len(bad) == 0 and got_total == want_total, (stage, pad, depth, w8, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+    finally:
+        reset_opts()
+
+
+def test_count_width_feedback(O, IntervalIndex):
+    """8-bit counts between the search and the un-permute kernel of the flat walk.  The index is sparse as a whole (the host
+    starts with 8 bits) but 150 000 of its targets crowd into 400 000 coordinates; queries elsewhere have small counts,
+    queries inside the crowd collect 255 targets and more: each of those comes back as "ask again" and is recomputed
+    (exact), and the running total mirrored to the host makes the index fall back to 16-bit counts within a few passes."""
+    rng = np.random.default_rng(91)
+    span = 30_000_000
+    s = np.concatenate([rng.integers(1000, span, size=400_000), rng.integers(5_000_000, 5_400_000, size=150_000)])
+    e = s + rng.integers(1, 300, size=len(s))
+    nq = 32768 * 70 + 99  # (the large-batch pass takes batches of 2 Mi queries and more)
+    s, e = s.astype(np.int32), e.astype(np.int32)
+    ix = make_index(IntervalIndex, s, e)
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    set_opt("ivl.partition", 1)
+    set_opt("ivl.flat", 1)
+    set_opt("ivl.bm_hard_ppm", 10**6)  # (the crowd has cells with several duplicated coordinates: keep the cell images anyway)
+    try:
+        qs = rng.integers(6_000_000, span, size=nq).astype(np.int32)   # away from the crowd
+        qe = (qs + rng.integers(1, 800, size=nq)).astype(np.int32)
+        want, want_total = t.count_batch(qs, qe)
+        got, got_total = ix.count(qs, qe)
+        assert ix.flat_state()[0] == 1
+        assert np.array_equal(got, want) and got_total == want_total
+        assert ix.count_width() == (8, 0)
+        qs = rng.integers(5_000_000, 5_400_000, size=nq).astype(np.int32)  # inside it: ~ 0.4 targets per coordinate
+        qe = (qs + rng.integers(900, 1200, size=nq)).astype(np.int32)
+        want, want_total = t.count_batch(qs, qe)
+        assert (want >= 255).mean() > 0.9
+        for _ in range(4):
+            got, got_total = ix.count(qs, qe)
+            assert np.array_equal(got, want) and got_total == want_total
+        bits, wide = ix.count_width()
+        assert bits == 16 and wide >= nq // 2, (bits, wide)  # (the mirror is a pass or two behind)
+        got, got_total = ix.count(qs, qe)
+        assert np.array_equal(got, want) and got_total == want_total
     finally:
         reset_opts()
 
