@@ -1093,12 +1093,16 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
                                                                      int32_t *__restrict__ counts /* may be NULL */,
                                                                      unsigned long long *__restrict__ total_slots,
                                                                      const unsigned *__restrict__ gate,
-                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */)
+                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */,
+                                                                     unsigned long long *__restrict__ order_host = nullptr, unsigned long long seq = 0)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
     __shared__ int s_mm[3][LC_THREADS / 64];
     __shared__ int s_slice[6];  // eLo, eHi, sLo, sHi, qeLo, qeHi
     __shared__ long long red[LC_THREADS / 64];
+    // what the order check found, into host memory: the host picks the shape of THIS kernel for later batches by it
+    // (bm_count_segments; pass number << 1 | 1 = not sorted)
+    if (order_host && blockIdx.x == 0 && threadIdx.x == 0) *order_host = (seq << 1) | (gate && *gate != 0 ? 1ull : 0ull);
     if (gate && *gate != 0) return;  // unsorted batch: the bucketed path answers it
     long long acc = 0;
     const int64_t chunk0 = (int64_t)blockIdx.x * (LOOP ? LC_LOOP : 1);
@@ -2133,7 +2137,7 @@ static int64_t g_opt_sl_hcopy = 1;     // hit un-permute: 1 = sl_hits_copy_kerne
 static int64_t g_opt_sl_hu_parts = 1;  // hit un-permute: workgroups per tile (1, 2, 4, 8, 16), run back to back on one XCD
 static int64_t g_opt_sl_run_cap = 160;  // a slice unit grows only while its expected (tile, unit) run stays within this many records
 static int64_t g_opt_find_pairs = 1;   // sorted find(): the fill reads (end, index) pairs (one array) instead of the two index arrays
-static int64_t g_opt_lc_loop = 0;      // 1 = the sorted-batch kernel behind the order check takes four chunks per workgroup: its stand-down on an unsorted batch costs 5 us instead of 12, but a sorted batch 0.89 instead of 0.65 ms -- off
+static int64_t g_opt_lc_loop = -1;     // the sorted-batch kernel behind the order check: 0 = a workgroup per chunk, 1 = four chunks per workgroup, -1 = by what the handle's earlier order checks found (bm_count_segments)
 static int64_t g_opt_sl_flat = 1;      // 1 = count-only passes on key slices take the flat 16-byte walk of count_dense.hpp (16-bit counts, unit run table), 0 = the 16 / 64 lanes-per-run kernels of count_slices.hpp
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
@@ -2250,7 +2254,7 @@ int ivl_set_option(const char *key, int64_t value)
         return 1;
     }
     if (!strcmp(key, "ivl.lc_loop")) {
-        g_opt_lc_loop = value != 0;
+        g_opt_lc_loop = value < 0 ? -1 : (value != 0);
         return 1;
     }
     if (!strcmp(key, "ivl.sl_flat")) {
@@ -2371,6 +2375,9 @@ struct bxmi_ivl {
     unsigned long long *bd_fb_host = nullptr;  // its mirror (host memory the device can write)
     int64_t w8_queries = 0;                    // queries of the passes launched with 8-bit counts
     bool w8_off = false;                       // too many of them did not fit: this index keeps 16-bit counts
+    // [1] of the same host words: what the order check of an earlier pass found (ivl_local_count_kernel writes it)
+    unsigned long long order_seq = 0, order_seen = 0;  // passes launched with an order check / the last one the host has seen the answer of
+    int unsorted_streak = 0;                           // consecutive answers "not sorted"
     bool sl_eid_ready = false;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][ONE_CAP hits][completion word:int64]
     unsigned long long one_seq = 0;
@@ -3050,6 +3057,18 @@ static int bd_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hip
     return BXMI_OK;
 }
 
+// Two 64-bit words of host memory the kernels of a pass write for the NEXT calls on this handle (never waited for):
+// [0] counts that did not fit 8 bits so far, [1] what the latest order check found.
+static int ensure_feedback(bxmi_ivl *h, hipStream_t st)
+{
+    if (h->bd_fb_host) return BXMI_OK;
+    BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->bd_fb_host), 64, hipHostMallocDefault));
+    memset(h->bd_fb_host, 0, 64);
+    BXMI_TRY(h->bd_fb.reserve(64));
+    BXMI_HIP(hipMemsetAsync(h->bd_fb.p, 0, 64, st));
+    return BXMI_OK;
+}
+
 // `kind`: what a search workgroup keeps in LDS -- 1 = bucket images (count_bitmap.hpp), 2 = key slices
 // (count_slices.hpp), 3 = dense unit images, 4 = cell images of units (both count_dense.hpp: the flat walk, 16-bit
 // counts out of place); every index of the batch must have qualified for it.
@@ -3187,12 +3206,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     // count in 64 did not fit, the index keeps 16-bit counts (worst case before that: every count recomputed, ~2 x the pass).
     L.w8 = false;
     if (pad && cells && n == 1 && g_opt_bd_w8 != 0 && g_opt_bd_exp == 0 && g_opt_bd_depth == 0) {
-        if (!h->bd_fb_host) {
-            BXMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->bd_fb_host), 64, hipHostMallocDefault));
-            *h->bd_fb_host = 0;
-            BXMI_TRY(h->bd_fb.reserve(64));
-            BXMI_HIP(hipMemsetAsync(h->bd_fb.p, 0, 64, st));
-        }
+        BXMI_TRY(ensure_feedback(h, st));
         const unsigned long long wide = *reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host);
         if ((int64_t)wide * 64 > h->w8_queries && wide > 4096) h->w8_off = true;
         const int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin + 1;
@@ -3207,12 +3221,25 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
         const int64_t nchunks = div_up(nq[0], LC_CHUNK);
-        if (g_opt_lc_loop && nchunks >= 4096)
+        // The kernel for sorted batches has two shapes: a workgroup per chunk (0.64 ms for 100 M sorted queries, but 24 000
+        // workgroups to dismiss when the batch is NOT sorted: 12 us) or LC_LOOP chunks per workgroup (5 us to dismiss, 0.89 ms
+        // when it does run).  Which one is launched follows what the order checks of the handle's earlier passes found
+        // (read from host memory, no synchronisation, possibly a few passes late): after two answers "not sorted" in a
+        // row the second shape, after one "sorted" the first again.  The results never depend on it.
+        BXMI_TRY(ensure_feedback(h, st));
+        const unsigned long long seen = reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host)[1];
+        if ((seen >> 1) > h->order_seen) {
+            h->unsorted_streak = (seen & 1ull) ? h->unsorted_streak + 1 : 0;
+            h->order_seen = seen >> 1;
+        }
+        const unsigned long long seq = ++h->order_seq;
+        const bool loop = g_opt_lc_loop > 0 || (g_opt_lc_loop < 0 && h->unsorted_streak >= 2);
+        if (loop && nchunks >= 4096)
             hipLaunchKernelGGL(ivl_local_count_kernel<true>, dim3((unsigned)div_up(nchunks, LC_LOOP)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
-                               h->e_sorted.as<int32_t>(), qs[0], qe[0], nq[0], counts[0], tslots, unsorted);
+                               h->e_sorted.as<int32_t>(), qs[0], qe[0], nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->bd_fb_host + 1, seq);
         else
             hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(),
-                               qs[0], qe[0], nq[0], counts[0], tslots, unsorted);
+                               qs[0], qe[0], nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->bd_fb_host + 1, seq);
         BXMI_LAUNCH_CHECK();
     }
     if (variant == 2)
@@ -3523,6 +3550,7 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
             BXMI_HIP(hipMemsetAsync(h->bd_fb.p, 0, 64, st));
             *h->bd_fb_host = 0;
         }
+        h->unsorted_streak = 0;
         h->sl_eid_ready = false;
         BXMI_TRY(h->slice_bounds.reserve(PT_NB * sizeof(SliceBound)));
         hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),

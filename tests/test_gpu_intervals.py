@@ -37,7 +37,7 @@ def set_opt(key, value):
 
 DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
                 "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 1, "ivl.bm_exp": 0, "ivl.slice": -1, "ivl.sl_f": -1,
-                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 0, "ivl.lc_loop": 0, "ivl.bd_pipe": 1, "ivl.bd_pad": 1, "ivl.bd_w8": -1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 0, "ivl.bd_blocks": 0,
+                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 0, "ivl.lc_loop": -1, "ivl.bd_pipe": 1, "ivl.bd_pad": 1, "ivl.bd_w8": -1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 0, "ivl.bd_blocks": 0,
                 "ivl.bm_chunk": 0}
 
 
@@ -829,6 +829,35 @@ def test_padded_runs_on_many_full_tiles(O, IntervalIndex, stage):
             assert len(bad) == 0 and got_total == want_total, (stage, pad, depth, w8, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
     finally:
         reset_opts()
+
+
+def test_sorted_kernel_shape_follows_the_order_checks(O, IntervalIndex):
+    """The kernel for sorted batches is launched in one of two shapes, by what the order checks of the handle's earlier
+    passes found (mirrored to host memory): after shuffled batches the four-chunks-per-workgroup shape is the one that
+    meets the first sorted batch, after that the chunk-per-workgroup shape again.  Same counts every time."""
+    rng = np.random.default_rng(93)
+    n, span, nq = 200_000, 50_000_000, 4096 * 4200 + 77
+    s = rng.integers(1000, span, size=n)
+    e = s + rng.integers(1, 1500, size=n)
+    qs = rng.integers(0, span, size=nq)
+    qe = qs + rng.integers(1, 2500, size=nq)
+    s, e, qs, qe = (a.astype(np.int32) for a in (s, e, qs, qe))
+    ix = make_index(IntervalIndex, s, e)
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    pick = rng.integers(0, nq, size=300_000)
+    want, _ = t.count_batch(qs[pick], qe[pick])
+    first, first_total = ix.count(qs, qe)
+    assert np.array_equal(first[pick], want)
+    for _ in range(2):
+        got, got_total = ix.count(qs, qe)
+        assert np.array_equal(got, first) and got_total == first_total
+    o = np.argsort(qs, kind="stable")
+    for _ in range(3):  # the first of these meets the looping shape, the others the plain one
+        got, got_total = ix.count(qs[o], qe[o])
+        assert np.array_equal(got, first[o]) and got_total == first_total
+    got, got_total = ix.count(qs, qe)
+    assert np.array_equal(got, first) and got_total == first_total
 
 
 def test_count_width_feedback(O, IntervalIndex):

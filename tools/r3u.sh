@@ -1,6 +1,15 @@
 #!/bin/bash
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
+REPO=$PWD
+OUT=$REPO/gpurun_out/r3u
+mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_intervals.py -m gpu -q --timeout 600 -p no:cacheprovider -x -k "count_width or padded_runs or dense_pass or bitmap_pass_differential or scale_ or random_differential or beyond_16" 2>&1 | tail -8
-REPS=10 VARIANTS="auto:,w16:ivl.bd_w8=0,auto2:" timeout 200 python tools/count_variants.py 2>&1 | grep variant | cut -c1-100
+timeout 900 python -m pytest tests/test_gpu_intervals.py -m gpu -q --timeout 600 -p no:cacheprovider -x -k "count_width or order_checks or sorted" 2>&1 | tail -4
+ORDER=sorted REPS=10 VARIANTS="auto:,auto2:" timeout 200 python tools/count_variants.py 2>&1 | grep variant | cut -c1-100
+cd /tmp
+REPS=10 VARIANTS="auto:,auto2:,plain:ivl.lc_loop=0" timeout 200 rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python $REPO/tools/count_variants.py > $OUT/v.json 2> $OUT/trace.err
+cd $REPO
+cut -c1-100 $OUT/v.json
+python tools/trace_segments.py $OUT/trace 20 4 | grep -A12 "per pass" | grep "per pass\|ivl_local\|sorted_check"
+rm -rf $OUT/trace
