@@ -2137,7 +2137,7 @@ static int64_t g_opt_sl_hcopy = 1;     // hit un-permute: 1 = sl_hits_copy_kerne
 static int64_t g_opt_sl_hu_parts = 1;  // hit un-permute: workgroups per tile (1, 2, 4, 8, 16), run back to back on one XCD
 static int64_t g_opt_sl_run_cap = 160;  // a slice unit grows only while its expected (tile, unit) run stays within this many records
 static int64_t g_opt_find_pairs = 1;   // sorted find(): the fill reads (end, index) pairs (one array) instead of the two index arrays
-static int64_t g_opt_lc_loop = -1;     // the sorted-batch kernel behind the order check: 0 = a workgroup per chunk, 1 = four chunks per workgroup, -1 = by what the handle's earlier order checks found (bm_count_segments)
+static int64_t g_opt_lc_loop = 0;      // the sorted-batch kernel behind the order check: 0 = a workgroup per chunk, 1 = four chunks per workgroup, -1 = by what the handle's earlier order checks found (bm_count_segments; see there why it is not the default)
 static int64_t g_opt_sl_flat = 1;      // 1 = count-only passes on key slices take the flat 16-byte walk of count_dense.hpp (16-bit counts, unit run table), 0 = the 16 / 64 lanes-per-run kernels of count_slices.hpp
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
@@ -3226,6 +3226,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         // when it does run).  Which one is launched follows what the order checks of the handle's earlier passes found
         // (read from host memory, no synchronisation, possibly a few passes late): after two answers "not sorted" in a
         // row the second shape, after one "sorted" the first again.  The results never depend on it.
+        // NOT the default (ivl.lc_loop = -1 asks for it): a caller that enqueues passes back to back is many passes ahead of
+        // the answers, so the first sorted batches after shuffled ones ALL meet the slow shape (bench.py's sorted leg: 0.88
+        // instead of 0.64 ms) -- 7 us per shuffled pass do not pay for that.
         BXMI_TRY(ensure_feedback(h, st));
         const unsigned long long seen = reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host)[1];
         if ((seen >> 1) > h->order_seen) {
