@@ -1,15 +1,7 @@
 #!/bin/bash
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-REPO=$PWD
-OUT=$REPO/gpurun_out/r3u
-mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_intervals.py -m gpu -q --timeout 600 -p no:cacheprovider -x -k "count_width or order_checks or sorted" 2>&1 | tail -4
-ORDER=sorted REPS=10 VARIANTS="auto:,auto2:" timeout 200 python tools/count_variants.py 2>&1 | grep variant | cut -c1-100
-cd /tmp
-REPS=10 VARIANTS="auto:,auto2:,plain:ivl.lc_loop=0" timeout 200 rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python $REPO/tools/count_variants.py > $OUT/v.json 2> $OUT/trace.err
-cd $REPO
-cut -c1-100 $OUT/v.json
-python tools/trace_segments.py $OUT/trace 20 4 | grep -A12 "per pass" | grep "per pass\|ivl_local\|sorted_check"
-rm -rf $OUT/trace
+for o in "ivl.bm_chunk=0" "ivl.bm_chunk=40000" "ivl.bm_chunk=65536" "ivl.bm_chunk=131072" "ivl.sl_flat=0"; do
+echo "== $o: $(BXMI_OPTS=$o WORLDS=8 timeout 100 python tools/rank_share.py 2>&1 | tail -1 | cut -c1-120)"
+done
