@@ -464,3 +464,19 @@ def test_count_range_from_the_run_list_host_logic(monkeypatch):
         assert calls["device"] - before <= 2  # after a mutation: two device calls, then the run list
         answered_on_host += len(qs) + 1 - (calls["device"] - before)
     assert answered_on_host > 2000
+
+
+def test_ring_kernels_keep_registers_of_loads_in_flight_untouched():
+    """The flat walk's record loads are issued by inline asm (count_dense.hpp: bd_issue_load / bd_wait), so the compiler
+    does not know which registers are still being written.  tools/check_ring_isa.py compiles intervals.hip to gfx950
+    assembly (no GPU needed) and follows every such kernel's basic blocks: no instruction may name a register while a
+    hand-issued load is on its way to it, and every wait must name the destination of a load in flight."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_ring_isa.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    m = re.match(r"(\d+) kernels checked, 0 with problems", last)
+    assert m and int(m.group(1)) >= 20, last
+    assert " ring " in r.stdout and "two sets" in r.stdout
