@@ -719,6 +719,9 @@ def main():
         scounts = torch.empty_like(counts)
         for _ in range(2):
             ix.count_dev(sqs.data_ptr(), sqe.data_ptr(), nq, scounts.data_ptr(), total.data_ptr(), stream)
+        # (the warm-up has to END before the timed passes are enqueued: after the shuffled batches above the library goes
+        # without its order check, and what brings it back is the report of a finished pass -- bxmi_ivl_order_state)
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = max(5, args.steps)
         e0.record()
@@ -781,9 +784,10 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
-            "kernel": ("count pass = bm_params + bm_sorted_check + ivl_local_count (stands down) + bm_tile_sort + bd_transpose + bd_plan + "
-                       "bd_search (the flat 16-byte walk on cell images of 2^18-coordinate units) + bd_unpermute (16-bit counts) + bm_fold_totals; "
-                       "dominant: bd_search_kernel" if partitioned else "ivl_count_kernel"),
+            "kernel": ("count pass = bm_params (with a probe of 8192 starts for the order; the exact bm_sorted_check + the stand-down of "
+                       "ivl_local_count run only until two batches in a row were shuffled) + bm_tile_sort + bd_transpose + bd_plan + "
+                       "bd_search (the flat 16-byte walk on cell images of 2^18-coordinate units, ring of hand-issued loads) + bd_unpermute "
+                       "(8-bit counts) + bm_fold_totals; dominant: bd_search_kernel" if partitioned else "ivl_count_kernel"),
             "search_stage_of_this_index": stages,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
             "timed_with": "HIP events on the launch stream around every bxmi_ivl_count_dev call of the timed region",

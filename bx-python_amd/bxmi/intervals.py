@@ -104,6 +104,14 @@ class IntervalIndex:
         call("bxmi_ivl_count_width", self._h, C.byref(bits), C.byref(wide))
         return bits.value, wide.value
 
+    def order_state(self):
+        """(skipping, answers_seen): whether large count batches currently go without the order check, and how many order
+        reports the host has read."""
+        self._ready()
+        sk, seen = C.c_int(0), C.c_int64(0)
+        call("bxmi_ivl_order_state", self._h, C.byref(sk), C.byref(seen))
+        return sk.value, seen.value
+
     def dense_state(self):
         """(state, [most keys of a block, most overflow entries of a unit]) of the dense-image search stage: 1 = usable,
         -1 = the index does not fit the format, 0 = undecided."""

@@ -101,11 +101,30 @@ struct BmSegChunk {
 // order flag behind them, the plan's item count): two memsets less on the stream.
 __global__ __launch_bounds__(256) void bm_params_kernel(BmSegChunk c, int first, BmSeg *__restrict__ segs, unsigned long long **__restrict__ totals,
                                                         unsigned short *__restrict__ tile_seg, unsigned long long *__restrict__ zero_u64, int n_zero,
-                                                        int *__restrict__ n_items)
+                                                        int *__restrict__ n_items, unsigned *__restrict__ probe = nullptr)
 {
     if (first == 0 && blockIdx.x == 0) {
         for (int i = threadIdx.x; i < n_zero; i += 256) zero_u64[i] = 0ull;
         if (threadIdx.x == 0) *n_items = 0;
+        if (probe) {
+            // No order check in this pass (bm_count_segments stopped launching it after shuffled batches): a PROBE instead --
+            // two stretches of 4096 consecutive starts of segment 0.  A descent in them says "shuffled" for certain; none
+            // says "could be sorted", and the host brings the exact check back.  *probe (zeroed above) = 1: descent seen.
+            const BmSeg &s0 = c.seg[0];
+            bool descent = false;
+#pragma unroll
+            for (int part = 1; part <= 2; part++) {
+                const int64_t at = ((s0.nq / 3 * part) & ~(int64_t)15) + 16 * (int64_t)threadIdx.x;
+                if (at + 17 <= s0.nq) {
+                    const int4 *p = reinterpret_cast<const int4 *>(s0.qs + at);
+                    const int4 a = p[0], b = p[1], d = p[2], e = p[3];
+                    const int nxt = s0.qs[at + 16];
+                    descent |= a.x > a.y || a.y > a.z || a.z > a.w || a.w > b.x || b.x > b.y || b.y > b.z || b.z > b.w || b.w > d.x || d.x > d.y ||
+                               d.y > d.z || d.z > d.w || d.w > e.x || e.x > e.y || e.y > e.z || e.z > e.w || e.w > nxt;
+                }
+            }
+            if (__syncthreads_or(descent) && threadIdx.x == 0) *probe = 1u;  // (behind the barrier: after the zeroing above)
+        }
     }
     const BmSeg &sg = c.seg[blockIdx.x];
     const int id = first + (int)blockIdx.x;
@@ -1072,8 +1091,13 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
 
 // the segments' partial totals, folded into the caller's int64 per segment (accumulated, like bxmi_ivl_count_dev's total)
 __global__ void bm_fold_totals_kernel(const unsigned long long *__restrict__ slots /* [segments][PT_SLOTS] */,
-                                      unsigned long long *const *__restrict__ totals /* [segments] */)
+                                      unsigned long long *const *__restrict__ totals /* [segments] */,
+                                      const unsigned *__restrict__ probe = nullptr, unsigned long long *__restrict__ order_host = nullptr,
+                                      unsigned long long seq = 0)
 {
+    // (what the probe of bm_params_kernel saw, into host memory for the next calls: see bm_count_segments)
+    if (order_host && blockIdx.x == 0 && threadIdx.x == 0) *order_host = (seq << 1) | (*probe != 0 ? 1ull : 0ull);
+    if (!totals) return;
     unsigned long long v = threadIdx.x < PT_SLOTS ? slots[(int64_t)blockIdx.x * PT_SLOTS + threadIdx.x] : 0ull;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -2150,6 +2150,7 @@ static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ra
 static int64_t g_opt_bd_depth = 0;    // passes of records in flight per wave of the flat walk: 0 = by layout (ring of 3 on padded runs, two sets of 4 on packed runs, 2 for key slices), else 2, 3, 4 (8: ring only)
 static int64_t g_opt_bd_w8 = -1;      // 8-bit counts out of place: -1 = by index and feedback, 0 = never, 1 = whenever the layout allows
 static int64_t g_opt_bd_pad = 1;      // 1 = the units' runs of a tile on whole 16-byte slots and the walk's ring of loads (count_dense.hpp), 0 = packed runs
+static int64_t g_opt_order_skip = -1;  // -1 = stop launching the order check after two batches in a row were not sorted (a probe of 8192 starts rides on the parameter kernel then), 0 = always check
 static int64_t g_opt_stage_sync = 0;  // diagnostics: wait for every stage of the count pass and say on stderr which one finished
 static int64_t g_opt_bd_pipe = 1;     // 1 = the walk keeps two sets of passes in flight (record loads issued by hand), 0 = one set per round
 static int64_t g_opt_bd_exp = 0;      // diagnostics only (wrong results): 1 = the dense search kernel without its lookups
@@ -2305,6 +2306,10 @@ int ivl_set_option(const char *key, int64_t value)
         g_opt_bd_pad = value != 0;
         return 1;
     }
+    if (!strcmp(key, "ivl.order_skip")) {
+        g_opt_order_skip = value;
+        return 1;
+    }
     if (!strcmp(key, "ivl.stage_sync")) {
         g_opt_stage_sync = value;
         return 1;
@@ -2378,6 +2383,7 @@ struct bxmi_ivl {
     // [1] of the same host words: what the order check of an earlier pass found (ivl_local_count_kernel writes it)
     unsigned long long order_seq = 0, order_seen = 0;  // passes launched with an order check / the last one the host has seen the answer of
     int unsorted_streak = 0;                           // consecutive answers "not sorted"
+    bool order_skip = false;                           // the order check is not launched at present (the tile sort reports the order)
     bool sl_eid_ready = false;
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][ONE_CAP hits][completion word:int64]
     unsigned long long one_seq = 0;
@@ -2819,6 +2825,7 @@ struct BmLaunch {
     const unsigned *gate;
     bool pad = false;  // the units' runs on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): tile stride TILE + BM_PAD_ROOM
     bool w8 = false;   // 8-bit counts between the search and the un-permute kernel (padded layout, cell images)
+    unsigned *descent = nullptr;  // no order check in this pass: bm_params_kernel's probe raises this word when it sees a descent
 };
 
 template <int THREADS, int ITEMS>
@@ -2827,12 +2834,12 @@ static int bm_launch_tiles(const BmLaunch &L, hipStream_t st)
     constexpr int TILE = THREADS * ITEMS;
     bxmi_ivl *h = L.owner;
     if (L.pad) {
-        const size_t lds = (size_t)(TILE + 3 * THREADS) * 4 + BM_NB * 4 + BM_NB * 2 + 64;
+        const size_t lds = (size_t)(TILE + 3 * THREADS) * 4 + BM_NB * 4 + BM_NB * 2 + 64 + 528;  // (+ the waves' first starts: order watch)
         BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, true>), lds));
         hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
                            h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, h->bd_tend.as<unsigned>());
     } else {
-        const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64;
+        const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64 + 528;
         BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, false>), lds));
         hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, false>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
                            h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, (unsigned *)nullptr);
@@ -3174,6 +3181,27 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     // [segments][PT_SLOTS partial totals], then the flag: 1 = the starts are NOT sorted
     BXMI_TRY(h->p_slots.reserve(((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long)));
     unsigned long long *slots = h->p_slots.as<unsigned long long>();
+    unsigned *unsorted = g_opt_sorted_path && n == 1 && !fx ? reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS) : nullptr;
+    // The order check and the stand-down of the sorted-batch kernel cost a shuffled batch 24 us (of 750).  What the order
+    // checks find is mirrored into host memory (ivl_local_count_kernel / bm_fold_totals_kernel write it, nobody waits for
+    // it): after two batches in a row that were NOT sorted the check is no longer launched -- every kernel of the exchange
+    // runs unconditionally -- and a PROBE rides on the parameter kernel instead: 8192 consecutive starts; a descent among
+    // them says "shuffled" for certain, none brings the exact check back with the next call.  A sorted batch that arrives
+    // in between goes through the exchange (0.78 instead of 0.62 ms per 100 M), exact as ever.  (Watching the order
+    // exactly inside the tile sort, which has every start in registers, cost that kernel 13-19 us -- what the check costs.)
+    unsigned *descent = nullptr;
+    unsigned long long order_seq = 0;
+    if (unsorted) {
+        BXMI_TRY(ensure_feedback(h, st));
+        const unsigned long long seen = reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host)[1];
+        if ((seen >> 1) > h->order_seen) {
+            h->unsorted_streak = (seen & 1ull) ? h->unsorted_streak + 1 : 0;
+            h->order_seen = seen >> 1;
+            h->order_skip = h->unsorted_streak >= 2;
+        }
+        order_seq = ++h->order_seq;
+        if (h->order_skip && g_opt_order_skip != 0) descent = unsorted, unsorted = nullptr;  // (the word is zeroed with the partial totals)
+    }
     for (int first = 0; first < n; first += BM_PAR_CHUNK) {
         BmSegChunk c;
         memset(&c, 0, sizeof(c));
@@ -3185,10 +3213,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         hipLaunchKernelGGL(bm_params_kernel, dim3((unsigned)cnt), dim3(256), 0, st, c, first, h->bm_params.as<BmSeg>(),
                            reinterpret_cast<unsigned long long **>(h->bm_params.as<unsigned char>() + seg_bytes),
                            reinterpret_cast<unsigned short *>(h->bm_params.as<unsigned char>() + tile_off), slots, n * PT_SLOTS + 8,
-                           h->bm_items.as<int>());
+                           h->bm_items.as<int>(), first == 0 ? descent : (unsigned *)nullptr);
     }
     BXMI_LAUNCH_CHECK();
-    unsigned *unsorted = g_opt_sorted_path && n == 1 && !fx ? reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS) : nullptr;
     unsigned long long *tslots = any_total ? slots : nullptr;
     BmLaunch L;
     L.segs = h->bm_params.as<BmSeg>();
@@ -3198,6 +3225,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.search_lds = slices ? sl_lds : dense ? max_stride * 16 : (size_t)(pair ? 2 : 1) * max_stride * sizeof(uint2);
     if (slices_flat && L.search_lds < 4096) L.search_lds = 4096;
     L.gate = unsorted;
+    L.descent = descent;
     L.pad = pad;
     // 8-bit counts (0xFF = recomputed by the un-permute kernel, exact either way): half the bytes of the second exchange
     // when the counts are small.  Cell images only serve indexes without piled-up coordinates, so the density says what to
@@ -3229,13 +3257,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         // NOT the default (ivl.lc_loop = -1 asks for it): a caller that enqueues passes back to back is many passes ahead of
         // the answers, so the first sorted batches after shuffled ones ALL meet the slow shape (bench.py's sorted leg: 0.88
         // instead of 0.64 ms) -- 7 us per shuffled pass do not pay for that.
-        BXMI_TRY(ensure_feedback(h, st));
-        const unsigned long long seen = reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host)[1];
-        if ((seen >> 1) > h->order_seen) {
-            h->unsorted_streak = (seen & 1ull) ? h->unsorted_streak + 1 : 0;
-            h->order_seen = seen >> 1;
-        }
-        const unsigned long long seq = ++h->order_seq;
+        const unsigned long long seq = order_seq;
         const bool loop = g_opt_lc_loop > 0 || (g_opt_lc_loop < 0 && h->unsorted_streak >= 2);
         if (loop && nchunks >= 4096)
             hipLaunchKernelGGL(ivl_local_count_kernel<true>, dim3((unsigned)div_up(nchunks, LC_LOOP)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
@@ -3317,9 +3339,10 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     else
         BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff)));
     stage_done("unpermute");
-    if (any_total) {
+    if (any_total || descent) {
         hipLaunchKernelGGL(bm_fold_totals_kernel, dim3((unsigned)n), dim3(64), 0, st, slots,
-                           reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes));
+                           any_total ? reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes) : nullptr,
+                           (const unsigned *)descent, descent ? h->bd_fb_host + 1 : nullptr, order_seq);
         BXMI_LAUNCH_CHECK();
     }
     return BXMI_OK;
@@ -3553,7 +3576,7 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
             BXMI_HIP(hipMemsetAsync(h->bd_fb.p, 0, 64, st));
             *h->bd_fb_host = 0;
         }
-        h->unsorted_streak = 0;
+        h->unsorted_streak = 0, h->order_skip = false;
         h->sl_eid_ready = false;
         BXMI_TRY(h->slice_bounds.reserve(PT_NB * sizeof(SliceBound)));
         hipLaunchKernelGGL(part_bounds_kernel, dim3(PT_NB / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
@@ -3611,6 +3634,14 @@ extern "C" int bxmi_ivl_count_width(const bxmi_ivl_t *h, int *bits, int64_t *wid
     const int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin + 1;
     if (bits) *bits = !h->w8_off && (int64_t)h->n * 2048 < span * 128 ? 8 : 16;
     if (wide_counts) *wide_counts = (int64_t)wide;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_order_state(const bxmi_ivl_t *h, int *skipping, int64_t *answers_seen)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_order_state"));
+    if (skipping) *skipping = h->order_skip && g_opt_order_skip != 0 ? 1 : 0;
+    if (answers_seen) *answers_seen = (int64_t)h->order_seen;
     return BXMI_OK;
 }
 

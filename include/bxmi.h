@@ -136,6 +136,12 @@ int bxmi_ivl_flat_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
  * in 64 of the passes so far came back as "does not fit" (*wide_counts of them, as last mirrored to the host; such counts
  * are recomputed, the results are exact either way), else 16.  Introspection only. */
 int bxmi_ivl_count_width(const bxmi_ivl_t *h, int *bits, int64_t *wide_counts);
+/* Whether large count batches on this index currently go without the order check (bm_sorted_check_kernel + the
+ * stand-down of the sorted-batch kernel): *skipping = 1 after the checks of two batches in a row found the starts NOT sorted
+ * -- a probe of 8192 consecutive starts then rides on every batch, and the first one without a descent brings the check back --
+ * *answers_seen = order reports the host has read so far (they arrive through host memory, a pass or more late).
+ * Introspection only: a sorted batch met without the check goes through the exchange, with the same counts. */
+int bxmi_ivl_order_state(const bxmi_ivl_t *h, int *skipping, int64_t *answers_seen);
 
 /* IntervalTree.find for a batch, as CSR: offsets[nq+1] (int64) and, for query
  * i, hits[offsets[i]..offsets[i+1]) = insertion indices in the reference's

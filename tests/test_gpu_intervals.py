@@ -37,7 +37,7 @@ def set_opt(key, value):
 
 DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
                 "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 1, "ivl.bm_exp": 0, "ivl.slice": -1, "ivl.sl_f": -1,
-                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 0, "ivl.lc_loop": 0, "ivl.bd_pipe": 1, "ivl.bd_pad": 1, "ivl.bd_w8": -1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 0, "ivl.bd_blocks": 0,
+                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 0, "ivl.lc_loop": 0, "ivl.order_skip": -1, "ivl.bd_pipe": 1, "ivl.bd_pad": 1, "ivl.bd_w8": -1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 0, "ivl.bd_blocks": 0,
                 "ivl.bm_chunk": 0}
 
 
@@ -848,6 +848,7 @@ def test_sorted_kernel_shape_follows_the_order_checks(O, IntervalIndex):
     pick = rng.integers(0, nq, size=300_000)
     want, _ = t.count_batch(qs[pick], qe[pick])
     set_opt("ivl.lc_loop", -1)  # (opt-in: see bm_count_segments)
+    set_opt("ivl.order_skip", 0)  # (or the check itself would be dropped after the shuffled batches)
     first, first_total = ix.count(qs, qe)
     assert np.array_equal(first[pick], want)
     for _ in range(2):
@@ -860,6 +861,59 @@ def test_sorted_kernel_shape_follows_the_order_checks(O, IntervalIndex):
     got, got_total = ix.count(qs, qe)
     reset_opts()
     assert np.array_equal(got, first) and got_total == first_total
+
+
+@pytest.mark.parametrize("stage", ["flat", "dense", "slices", "images"])
+def test_order_check_is_dropped_and_comes_back(O, IntervalIndex, stage):
+    """After two shuffled batches in a row the order check is no longer launched: a probe of 8192 starts rides on the
+    parameter kernel and reports through host memory.  A batch without a descent in the probe -- sorted, or sorted but for
+    its last two queries -- brings the exact check (and the kernel for sorted batches) back; met without the check it
+    goes through the exchange.  Same counts at every step, for every search stage."""
+    rng = np.random.default_rng(95)
+    n, span, nq = 150_000, 40_000_000, 32768 * 66 + 1234
+    s = rng.integers(1000, span, size=n)
+    e = s + rng.integers(1, 1500, size=n)
+    qs = rng.integers(0, span, size=nq)
+    qe = qs + rng.integers(1, 2500, size=nq)
+    s, e, qs, qe = (a.astype(np.int32) for a in (s, e, qs, qe))
+    ix = make_index(IntervalIndex, s, e)
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    want, want_total = t.count_batch(qs, qe)
+    o = np.argsort(qs, kind="stable")
+    almost = o.copy()
+    almost[-1], almost[-3] = almost[-3], almost[-1]  # a descent at the very end of the batch: not in the probe
+    set_opt("ivl.partition", 1)
+    set_opt("ivl.flat", 1 if stage == "flat" else 0)
+    set_opt("ivl.dense", 1 if stage in ("flat", "dense") else 0)
+    set_opt("ivl.slice", 1 if stage == "slices" else 0)
+
+    def shuffled(times):
+        for k in range(times):
+            got, got_total = ix.count(qs, qe)
+            assert np.array_equal(got, want) and got_total == want_total, ("shuffled", k)
+
+    def ordered(order, what):
+        got, got_total = ix.count(qs[order], qe[order])
+        assert np.array_equal(got, want[order]) and got_total == want_total, what
+
+    try:
+        assert ix.order_state()[0] == 0
+        shuffled(3)
+        skipping, seen = ix.order_state()
+        assert skipping == 1 and seen >= 2, (skipping, seen)
+        ordered(almost, "almost sorted, no check")       # through the exchange; the probe sees no descent
+        shuffled(1)                                      # ... so this one is checked again
+        assert ix.order_state()[0] == 0
+        shuffled(2)
+        assert ix.order_state()[0] == 1
+        ordered(o, "sorted, no check")                   # through the exchange
+        ordered(o, "sorted, checked")                    # its report has arrived: the check is back
+        assert ix.order_state()[0] == 0
+        ordered(almost, "almost sorted, checked")        # the exact check finds the descent
+        shuffled(1)
+    finally:
+        reset_opts()
 
 
 def test_count_width_feedback(O, IntervalIndex):

@@ -5,12 +5,11 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/r3u
 mkdir -p $OUT
 export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_intervals.py -m gpu -q --timeout 600 -p no:cacheprovider -x -k "order_check or order_checks or count_width or sorted" 2>&1 | tail -4
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/bits -o b --output-format csv -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sorted --no-find --no-genome > $OUT/b.json 2> $OUT/b.err
-python - <<PY
-import csv,glob
-f=glob.glob('$OUT/bits/**/*kernel_stats.csv',recursive=True)
-for r in list(csv.DictReader(open(f[0]))):
-    if 'bits_' in r['Name'] or 'tags_' in r['Name']: print("%-64s calls=%-5s avg=%9.1f us min=%7.1f max=%7.1f" % (r['Name'].split('(')[0][-64:], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3))
-PY
-rm -rf $OUT/bits
+REPS=10 VARIANTS="auto:,nocheck:ivl.sorted_path=0,check:ivl.order_skip=0,auto2:" timeout 200 rocprofv3 --kernel-trace -d $OUT/trace -o t --output-format csv -- python $REPO/tools/count_variants.py > $OUT/v.json 2> $OUT/trace.err
+cd $REPO
+cut -c1-100 $OUT/v.json
+python tools/trace_segments.py $OUT/trace 20 4 | grep -A12 "per pass" | grep "per pass\|tile_sort\|params\|fold"
+rm -rf $OUT/trace
+ORDER=sorted REPS=10 VARIANTS="auto:,auto2:" timeout 200 python tools/count_variants.py 2>&1 | grep variant | cut -c1-100
