@@ -698,10 +698,23 @@ __device__ __forceinline__ unsigned bd_valid_mask(unsigned f0, unsigned ra, unsi
 // them nor drains the memory pipe in front of every pass (which is what its own bookkeeping does to loads that stay in
 // flight around a loop: measured, every pass waited for its own stores).  bd_wait<K> is the wait: K = the number of
 // memory operations known to have been issued after the wanted load -- the counter retires in order.
+// BD_LOAD_NT (diagnostics / tuning): 1 = the record loads are non-temporal -- the records stream through L2 once, the
+// count lines a workgroup and its neighbours are filling should outlive them there
+#ifndef BD_LOAD_NT
+#define BD_LOAD_NT 0
+#endif
 __device__ __forceinline__ void bd_issue_load(bd_v4u &v, const unsigned *recs, unsigned idx4)
 {
     const bd_v4u *p = reinterpret_cast<const bd_v4u *>(recs) + idx4;
+#if BD_LOAD_NT == 1
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+#elif BD_LOAD_NT == 2
+    asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+#elif BD_LOAD_NT == 3
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+#else
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+#endif
 }
 
 // (the register is named in a comment of the instruction: tools/check_ring_isa.py reads the compiled code and refuses a
@@ -957,6 +970,314 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
                 bd_answer_slot<FMT, QB, EXP, W8>(I, out, idx4, bd_valid_mask(4u * idx4, first, end), reinterpret_cast<const bd_v4u *>(recs)[idx4]);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// search, second generation ("bw_*"): persistent workgroups, a ring that never drains, run look-up by bitmap
+// ---------------------------------------------------------------------------
+// What round 4's experiments said about bd_search_kernel on configs[1] (profiles/r04_search_*.txt): its memory operations
+// alone take 200 us, its look-ups alone 118 us, together 258-270 us.  The memory side is bound by how many cache LINES a CU
+// keeps in flight (a 137-byte run touches 2.07 lines, a CU gets ~0.27 lines per ns whatever the ring's depth), the
+// compute side paid ~100 scalar instructions and a dozen branches per pass to find which run a slot belongs to (the
+// readlane walk) and looked its four records up one after the other.  This kernel keeps the data layout (padded runs,
+// cell images, 8-bit counts) and changes what the compute side costs, so that it hides under the memory side:
+//   1. a slot's run comes from a BITMAP: every non-empty run of the batch sets the bit of its last slot (one LDS atomic
+//      per lane and batch), lane p keeps the 64-bit window of pass p and the number of runs that end before it, and a
+//      pass is three readlanes, two mbcnt and one ds_bpermute -- no loop, no branch (look-ups alone: 118 -> 70 us);
+//   2. the ring is fed across batches (a wave sets the next batch up while its loads are in flight: nothing drains
+//      before the item's last pass);
+//   3. workgroups are persistent: one per CU, items handed out per XCD in unit order by a counter (no 157 KB workgroups
+//      to launch and retire per item);
+//   4. the four records of a slot are looked up together (eight LDS reads in flight, one hard-cell test per slot).
+// Measured: 265 -> 226 us.  Tried on top and dropped: the next item's image requested into registers when a wave runs
+// out of batches (the compiler keeps 36 more registers only by spilling them: 261 us), the same as a touch of the
+// image's lines (L2 prefetch: 0.5 % and one memory fault under the profiler), non-temporal record loads (+4 %), batches
+// of 16 / 32 tiles (+10 / +4 %).
+constexpr int BW_MASK_WORDS = 128;  // run-end bitmap of a batch: 64 runs of at most 64 slots each
+constexpr int BW_PF = 9;            // 16-byte pieces per thread of an image (9 x 1024 x 16 = 147 KB)
+constexpr unsigned BW_IDLE = 0xFFFFFFFFu;
+// diagnostics (compile time, wrong results): bit 0 = no look-ups, bit 1 = no count stores, bit 2 = no record loads
+#ifndef BW_EXP
+#define BW_EXP 0
+#endif
+#ifndef BW_B
+#define BW_B 64  // tiles per batch of a wave, at most
+#endif
+
+__device__ __forceinline__ unsigned bw_wave_inclusive_sum(unsigned v)
+{
+    // Hillis-Steele inside the rows of 16 lanes, then lane 15 -> next row, lane 31 -> upper half (gfx9 DPP)
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// the four counts of a slot from a cell image (16 bits each, 0xFFFF = ask the index again); all eight cells are read
+// before the first is used, hard cells are noticed once per slot
+__device__ __forceinline__ void bp_count_slot(const BdImage &I, bd_v4u v, unsigned (&c)[4])
+{
+    const unsigned rec[4] = {v.x, v.y, v.z, v.w};
+    unsigned relE[4], relS[4];
+    unsigned long long cellE[4], cellS[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const unsigned off = rec[j] & I.off_mask;
+        relE[j] = off + 1u, relS[j] = off + (rec[j] >> BP_RSHIFT);
+        cellE[j] = I.cE[relE[j] >> 5];
+        cellS[j] = I.cS[relS[j] >> 5];
+    }
+    unsigned worst = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bd_v2u ce = __builtin_bit_cast(bd_v2u, cellE[j]), cs = __builtin_bit_cast(bd_v2u, cellS[j]);
+        const unsigned bE = ce.x, mE = ce.y, bS = cs.x, mS = cs.y;
+        const unsigned geE = 0xFFFFFFFFu << (relE[j] & 31u), geS = 0xFFFFFFFFu << (relS[j] & 31u);  // the coordinates of the cell from rel on
+        // the duplicated coordinate counts `extra` more times when it lies below rel
+        const unsigned rE = (mE & 0xFFFFFu) + (unsigned)__popc(bE & ~geE) + (mE >> 25) * __builtin_amdgcn_ubfe(~geE, (mE >> 20) & 31u, 1u);
+        const unsigned rS = (mS & 0xFFFFFu) + (unsigned)__popc(bS & ~geS) + (mS >> 25) * __builtin_amdgcn_ubfe(~geS, (mS >> 20) & 31u, 1u);
+        c[j] = (unsigned)I.bias + (rS - rE);
+        const unsigned m = mE > mS ? mE : mS;
+        worst = worst > m ? worst : m;
+    }
+    if (worst >= ((unsigned)BM_HARD << 25)) {  // some hard cell among the eight (rare): those records again, one by one
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned mE = __builtin_bit_cast(bd_v2u, cellE[j]).y, mS = __builtin_bit_cast(bd_v2u, cellS[j]).y;
+            if ((mE > mS ? mE : mS) >= ((unsigned)BM_HARD << 25)) c[j] = bp_count_record(I, rec[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c[j] = c[j] < 0xFFFFu ? c[j] : 0xFFFFu;
+        c[j] = rec[j] == BM_REC_ESC ? 0xFFFFu : c[j];
+    }
+}
+
+template <bool W8>
+__device__ __forceinline__ void bw_store_slot(unsigned short *__restrict__ out, unsigned idx4, const unsigned (&c)[4])
+{
+    if (W8) {
+        unsigned b[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) b[j] = c[j] < 0xFFu ? c[j] : 0xFFu;
+        reinterpret_cast<unsigned *>(out)[idx4] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    } else {
+        bd_v2u o;
+        o.x = c[0] | (c[1] << 16), o.y = c[2] | (c[3] << 16);
+        reinterpret_cast<bd_v2u *>(out)[idx4] = o;
+    }
+}
+
+template <bool W8, int DEPTH>
+__global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
+                                                               const int *__restrict__ n_items, const unsigned short *__restrict__ unitT, int64_t ntp,
+                                                               const unsigned *__restrict__ recs /* tile-sorted records, padded runs */,
+                                                               unsigned short *__restrict__ out /* their counts, same order */, int tile_log2,
+                                                               const unsigned *__restrict__ gate, unsigned *__restrict__ xcd_next /* [8], zero */)
+{
+    if (gate && *gate == 0) return;
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ uint2 s_long[BD_LONG_CAP];  // {first record, length} of the long runs met during the walk
+    __shared__ int s_nlong, s_next, s_item_next;
+    __shared__ __attribute__((aligned(8))) unsigned s_mask[BD_THREADS / 64][BW_MASK_WORDS];
+    const int nit = *n_items;
+    const int per_xcd = (nit + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7);
+    const int it_lo = xcd * per_xcd, it_hi = it_lo + per_xcd < nit ? it_lo + per_xcd : nit;  // neighbouring units on one XCD, in order
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (said out loud: a wave's number is uniform)
+    unsigned *const wmask = s_mask[wave];
+    wmask[lane] = 0u, wmask[64 + lane] = 0u;
+    if (threadIdx.x == 0) s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
+    __syncthreads();
+    int it = __builtin_amdgcn_readfirstlane(s_item_next);
+    __syncthreads();  // (thread 0 writes the word again at the top of the loop)
+    const unsigned tile_slots = ((1u << tile_log2) + (unsigned)BM_PAD_ROOM) >> 2;  // 16-byte slots between two tiles
+    while (it < it_hi) {
+        const int4 item = items[it];
+        const int unit = item.x & 0xffff, t0 = item.y, t1 = item.z;
+        const BmSeg &sg = segs[item.x >> 16];
+        const BmGeom g = sg.g;
+        const BpLayout LP = bp_layout(g.shift + g.f);
+        const unsigned short *__restrict__ runs0 = unitT + (int64_t)unit * ntp;
+        const unsigned short *__restrict__ runs1 = runs0 + ntp;  // (the next unit's first slots, or the row behind the last unit)
+        int B = BW_B;
+        while (B > 8 && (t1 - t0) < 2 * (BD_THREADS / 64) * B) B >>= 1;
+        if (threadIdx.x == 0) {
+            s_nlong = 0, s_next = B * (BD_THREADS / 64);  // (every wave starts with the batch of its number)
+            s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
+        }
+        unsigned a_nx, e_nx;
+        auto load_runs = [&](int tbase) {
+            const int t = tbase + lane;
+            const int tc = t < t1 && lane < B ? t : t0;  // a valid address: no branch around the loads
+            const unsigned a = runs0[tc];
+            const unsigned e = runs1[tc];
+            a_nx = t < t1 && lane < B ? a : 0u;
+            e_nx = t < t1 && lane < B ? e : 0u;
+        };
+        int tb_next = t0 + B * wave;
+        load_runs(tb_next);
+        {   // the image (streams through L2 once: non-temporal loads); every load of a lane issued before its first LDS store
+            const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.pimages + (size_t)unit * LP.bytes);
+            const int n4 = LP.bytes >> 4;
+            bm_v4i v[BW_PF];
+#pragma unroll
+            for (int k = 0; k < BW_PF; k++) {
+                const int i = k * BD_THREADS + (int)threadIdx.x;
+                v[k] = __builtin_nontemporal_load(src + (i < n4 ? i : n4 - 1));
+            }
+#pragma unroll
+            for (int k = 0; k < BW_PF; k++) {
+                const int i = k * BD_THREADS + (int)threadIdx.x;
+                if (i < n4) reinterpret_cast<bm_v4i *>(dyn)[i] = v[k];
+            }
+        }
+        __syncthreads();
+        const int it_nx = __builtin_amdgcn_readfirstlane(s_item_next);
+        BdImage I;
+        {
+            unsigned char *base = reinterpret_cast<unsigned char *>(dyn);
+            I.cE = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsE);
+            I.cS = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsS);
+            const unsigned *hdr = reinterpret_cast<const unsigned *>(base + LP.hdr);
+            I.eLo = (int)hdr[0], I.sLo = (int)hdr[1];
+            I.bias = I.sLo - I.eLo;
+            I.lo = (long long)((unsigned long long)hdr[2] | ((unsigned long long)hdr[3] << 32));
+            I.s_ord = sg.ix.s_ord, I.e_sorted = sg.e_sorted;
+            I.off_mask = (1u << (g.shift + g.f)) - 1u;
+        }
+        // a slot no query owns (the end of a tile's room, past every unit's padding): where the ring's idle passes store
+        unsigned *const nobody = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(out) +
+                                                              (((size_t)(t0 + (unit * 7 + wave * 64) % (t1 - t0)) + 1) * tile_slots - 1) * (W8 ? 4 : 8));
+        // --- the batch a wave is issuing passes of ---
+        unsigned total = 0u, s0 = 0u;      // slots of the batch, first slot of the next pass
+        unsigned delta_c = 0u;             // lane k: where run k's slots lie (non-empty runs, in order): slot s of the batch is at delta_c[k] + s
+        unsigned win_lo = 0u, win_hi = 0u, win_before = 0u;  // lane p: run-end bits of pass p, runs that end before pass p
+        bool live = true;
+        auto advance = [&]() -> bool {
+            while (tb_next < t1) {
+                const int t = tb_next + lane;
+                const unsigned a = a_nx, e = e_nx;
+                int tn = 0;
+                if (lane == 0) tn = atomicAdd(&s_next, B);
+                tb_next = t0 + __builtin_amdgcn_readfirstlane(tn);
+                load_runs(tb_next);
+                unsigned n4 = e > a ? ((e + 3u) >> 2) - (a >> 2) : 0u;  // 16-byte slots that hold the run
+                if (n4 > (unsigned)BD_LONG_SLOTS) {  // sorted / clumped input: left to the whole workgroup
+                    const int k = atomicAdd(&s_nlong, 1);
+                    const unsigned first = ((unsigned)t * tile_slots << 2) + a;
+                    if (k < BD_LONG_CAP) {
+                        s_long[k] = make_uint2(first, e - a);
+                    } else {  // (a full list: the run's counts say "ask the index again" -- exactness never depends on the list)
+                        const unsigned esc[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
+                        for (unsigned q = first >> 2; q < ((first + (e - a) + 3u) >> 2); q++) bw_store_slot<W8>(out, q, esc);
+                    }
+                    n4 = 0u;
+                }
+                const unsigned incl = bw_wave_inclusive_sum(n4);
+                total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                if (total == 0u) continue;
+                const unsigned delta = ((unsigned)t * tile_slots + (a >> 2)) - (incl - n4);
+                // the non-empty runs move to the low lanes (the empty ones fill the lanes from the top)
+                const bool ne = n4 != 0u;
+                const unsigned long long bal = __ballot(ne);
+                const unsigned below = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                const unsigned dest = ne ? below : 63u - ((unsigned)lane - below);
+                delta_c = (unsigned)__builtin_amdgcn_ds_permute((int)(dest << 2), (int)delta);
+                if (ne) atomicOr(&wmask[(incl - 1u) >> 5], 1u << ((incl - 1u) & 31u));
+                const uint2 w = reinterpret_cast<uint2 *>(wmask)[lane];  // (this wave's own LDS operations stay in order)
+                reinterpret_cast<uint2 *>(wmask)[lane] = make_uint2(0u, 0u);
+                win_lo = w.x, win_hi = w.y;
+                const unsigned ends = (unsigned)__popc(w.x) + (unsigned)__popc(w.y);
+                win_before = bw_wave_inclusive_sum(ends) - ends;
+                s0 = 0u;
+                return true;
+            }
+            return false;
+        };
+        // The ring: DEPTH passes of records in flight per wave, each slot of it a fixed set of registers (the loop is
+        // unrolled over the slots).  The memory pipe sees [store, load] per pass from the first to the last: 2 * DEPTH - 2
+        // operations follow every load before its slot comes round again (run-table and image loads in between only make
+        // a wait stronger: the counter retires in order).  Idle passes -- before the first batch, behind the last -- load
+        // record 0 and store to the slot nobody owns.
+        bd_v4u ring_v[DEPTH];
+        unsigned ring_idx[DEPTH];
+        int inflight = 0;  // passes of the ring that hold records of a batch
+        auto issue = [&](unsigned &idx4, bd_v4u &v) {
+            if (live && s0 >= total) live = advance();
+            unsigned at = BW_IDLE;
+            if (live) {
+                const int p = (int)(s0 >> 6);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)win_lo, p), hi = (unsigned)__builtin_amdgcn_readlane((int)win_hi, p);
+                const unsigned before = (unsigned)__builtin_amdgcn_readlane((int)win_before, p);
+                // slot s lies in run r = #{runs whose last slot is below s}
+                const unsigned r = before + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+                const unsigned dl = (unsigned)__builtin_amdgcn_ds_bpermute((int)(r << 2), (int)delta_c);
+                const unsigned s = s0 + (unsigned)lane;
+                at = s < total ? dl + s : BW_IDLE;
+                s0 += 64u;
+            }
+            idx4 = at;
+            if (live) inflight++;
+            bd_issue_load(v, recs, at == BW_IDLE || (BW_EXP & 4) ? 0u : at);
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) {
+            if (d > 0) bd_dummy_store(reinterpret_cast<unsigned short *>(nobody));
+            ring_idx[d] = BW_IDLE;
+            bd_issue_load(ring_v[d], recs, 0u);
+        }
+        for (;;) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; d++) {
+                bd_wait<2 * DEPTH - 2>(ring_v[d]);
+                if (__any(ring_idx[d] != BW_IDLE)) {
+                    inflight--;
+                    if (ring_idx[d] != BW_IDLE) {
+                        unsigned c[4];
+                        bd_v4u rv = ring_v[d];
+                        if (BW_EXP & 4) {  // synthetic records: offsets all over the unit, lengths < 1000
+                            const unsigned h = ring_idx[d] * 2654435761u;
+                            rv = bd_v4u{(h & 0x3ffffu) | (500u << 18), ((h >> 3) & 0x3ffffu) | (100u << 18), ((h >> 7) & 0x3ffffu) | (900u << 18),
+                                        ((h >> 11) & 0x3ffffu) | (300u << 18)};
+                        }
+                        if (BW_EXP & 1)
+                            c[0] = rv.x & 0xffu, c[1] = rv.y & 0xffu, c[2] = rv.z & 0xffu, c[3] = rv.w & 0xffu;
+                        else
+                            bp_count_slot(I, rv, c);
+                        if (!(BW_EXP & 2) || (c[0] & c[1] & c[2] & c[3]) == 0x12345u) bw_store_slot<W8>(out, ring_idx[d], c);
+                        else bd_dummy_store(reinterpret_cast<unsigned short *>(nobody));
+                    }
+                } else {
+                    bd_dummy_store(reinterpret_cast<unsigned short *>(nobody));
+                }
+                issue(ring_idx[d], ring_v[d]);
+            }
+            if (!live && inflight == 0) break;
+        }
+        // the loads of the round after the last are still on their way: nothing may reuse their registers before they land
+#pragma unroll
+        for (int d = 0; d < DEPTH; d++) bd_wait<0>(ring_v[d]);
+        __syncthreads();
+        {
+            const int nl = s_nlong < BD_LONG_CAP ? s_nlong : BD_LONG_CAP;
+            for (int k = 0; k < nl; k++) {
+                const uint2 lr = s_long[k];
+                const unsigned q0 = lr.x >> 2, nq4 = ((lr.x + lr.y + 3u) >> 2) - q0;  // (padded runs: whole slots)
+                for (unsigned q = threadIdx.x; q < nq4; q += BD_THREADS) {
+                    unsigned c[4];
+                    bp_count_slot(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
+                    bw_store_slot<W8>(out, q0 + q, c);
+                }
+            }
+        }
+        __syncthreads();
+        it = it_nx;
     }
 }
 

@@ -2154,6 +2154,9 @@ static int64_t g_opt_order_skip = -1;  // -1 = stop launching the order check af
 static int64_t g_opt_stage_sync = 0;  // diagnostics: wait for every stage of the count pass and say on stderr which one finished
 static int64_t g_opt_bd_pipe = 1;     // 1 = the walk keeps two sets of passes in flight (record loads issued by hand), 0 = one set per round
 static int64_t g_opt_bd_exp = 0;      // diagnostics only (wrong results): 1 = the dense search kernel without its lookups
+static int64_t g_opt_bw = 1;          // 1 = cell images on padded runs are searched by the persistent walk (bw_search_kernel), 0 = bd_search_kernel's ring
+static int64_t g_opt_bw_grid = 256;   // workgroups of the persistent walk (a multiple of 8: one per CU)
+static int64_t g_opt_bw_depth = 6;    // passes of records in flight per wave of the persistent walk: 3, 4 or 6
 static int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
 
 int ivl_set_option(const char *key, int64_t value)
@@ -2168,6 +2171,18 @@ int ivl_set_option(const char *key, int64_t value)
     }
     if (!strcmp(key, "ivl.count_grid")) {
         g_opt_count_grid = value;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bw")) {
+        g_opt_bw = value != 0;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bw_grid")) {
+        g_opt_bw_grid = value >= 8 && value <= 2048 ? (value + 7) / 8 * 8 : 256;
+        return 1;
+    }
+    if (!strcmp(key, "ivl.bw_depth")) {
+        g_opt_bw_depth = value == 3 || value == 4 ? value : 6;
         return 1;
     }
     if (!strcmp(key, "ivl.partition")) {
@@ -2826,6 +2841,7 @@ struct BmLaunch {
     bool pad = false;  // the units' runs on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): tile stride TILE + BM_PAD_ROOM
     bool w8 = false;   // 8-bit counts between the search and the un-permute kernel (padded layout, cell images)
     unsigned *descent = nullptr;  // no order check in this pass: bm_params_kernel's probe raises this word when it sees a descent
+    unsigned *xcd_next = nullptr;  // eight item counters of the persistent search, zeroed with the partial totals
 };
 
 template <int THREADS, int ITEMS>
@@ -3026,8 +3042,32 @@ static int bd_launch_search_d(const BmLaunch &L, unsigned grid, hipStream_t st)
     }
 }
 
+// the persistent walk on cell images (count_dense.hpp, bw_*): one workgroup per CU, items handed out per XCD
+template <bool W8, int DEPTH>
+static int bw_launch_search_t(const BmLaunch &L, hipStream_t st)
+{
+    bxmi_ivl *h = L.owner;
+    BXMI_TRY(allow_big_lds((bw_search_kernel<W8, DEPTH>), L.search_lds));
+    hipLaunchKernelGGL((bw_search_kernel<W8, DEPTH>), dim3((unsigned)g_opt_bw_grid), dim3(BD_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+                       h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(), h->bd_cnt16.as<unsigned short>(),
+                       L.tile_log2, L.gate, L.xcd_next);
+    BXMI_LAUNCH_CHECK();
+    return BXMI_OK;
+}
+
+template <bool W8>
+static int bw_launch_search(const BmLaunch &L, hipStream_t st)
+{
+    switch (g_opt_bw_depth) {
+    case 3: return bw_launch_search_t<W8, 3>(L, st);
+    case 4: return bw_launch_search_t<W8, 4>(L, st);
+    default: return bw_launch_search_t<W8, 6>(L, st);  // (8: spills inside the loop)
+    }
+}
+
 static int bd_launch_search(const BmLaunch &L, unsigned grid, int fmt /* 0 dense, 1 cells, 2 slices */, bool blocks, hipStream_t st)
 {
+    if (fmt == 1 && L.pad && g_opt_bw != 0 && g_opt_bd_exp == 0) return L.w8 ? bw_launch_search<true>(L, st) : bw_launch_search<false>(L, st);
     // key slices: the lean shape (two passes per round, compiler-issued loads: 50 registers) -- two workgroups share a CU
     // when the units are small, one stages its unit while the other searches (a third of a sparse index's search time)
     if (fmt == 2) return g_opt_bd_depth == 4 && g_opt_bd_pipe ? bd_launch_search_t<2, false, 0, 4, true>(L, grid, st) : bd_launch_search_t<2, false, 0, 2, false>(L, grid, st);  // (never padded: see bm_count_segments)
@@ -3227,6 +3267,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.gate = unsorted;
     L.descent = descent;
     L.pad = pad;
+    L.xcd_next = reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS + 4);
     // 8-bit counts (0xFF = recomputed by the un-permute kernel, exact either way): half the bytes of the second exchange
     // when the counts are small.  Cell images only serve indexes without piled-up coordinates, so the density says what to
     // expect: fewer than 128 targets per 2048 coordinates (configs[1]: 82; a count of 255 needs a query of ~6000).  What the

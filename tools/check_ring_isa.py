@@ -146,7 +146,7 @@ def main():
                                "-I" + os.path.join(ROOT, "include"), os.path.join(CSRC, "intervals.hip"), "-o", path], stderr=subprocess.DEVNULL)
     kernels, cur = {}, None
     for no, line in enumerate(open(path), 1):
-        m = re.match(r"^(_ZN4bxmi16bd_search_kernel\w+):", line)
+        m = re.match(r"^(_ZN4bxmi16b[dw]_search_kernel\w+):", line)
         if m:
             cur = m.group(1)
             kernels[cur] = []
@@ -156,21 +156,25 @@ def main():
             kernels[cur].append((no, line.rstrip("\n")))
     failed = 0
     for name, lines in kernels.items():
-        t = re.search(r"ILi(\d)ELb(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)E", name)
-        fmt, qb, exp, depth, pipe, pad = (int(x) for x in t.groups())
-        if not pipe:
-            continue
-        if exp == 3:
-            continue  # (diagnostics: synthetic records, no loads to wait for)
+        if "bw_search_kernel" in name:  # the persistent walk: bw_search_kernel<W8, DEPTH>
+            t = re.search(r"ILb(\d)ELi(\d)E", name)
+            tag = "persistent walk W8 %s DEPTH %s" % t.groups()
+        else:
+            t = re.search(r"ILi(\d)ELb(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)E", name)
+            fmt, qb, exp, depth, pipe, pad = (int(x) for x in t.groups())
+            if not pipe:
+                continue
+            if exp == 3:
+                continue  # (diagnostics: synthetic records, no loads to wait for)
+            tag = "FMT %d QB %d EXP %d DEPTH %d %s" % (fmt, qb, exp, depth, "ring" if pad else "two sets")
         loads, waits, errors = check_kernel(name, lines)
-        tag = "FMT %d QB %d EXP %d DEPTH %d %s" % (fmt, qb, exp, depth, "ring" if pad else "two sets")
         if loads == 0 or waits == 0:
             errors.append((0, "no hand-issued loads / waits found (%d / %d)" % (loads, waits)))
         print("%-40s loads %2d waits %2d  %s" % (tag, loads, waits, "ok" if not errors else "%d PROBLEMS" % len(errors)))
         for no, msg in errors[:6]:
             print("    line %d: %s" % (no, msg))
         failed += bool(errors)
-    print("%d kernels checked, %d with problems" % (sum(1 for k in kernels if "ELb1ELb" in k), failed))
+    print("%d kernels checked, %d with problems" % (sum(1 for k in kernels if "ELb1ELb" in k or "bw_search" in k), failed))
     return 1 if failed else 0
 
 
