@@ -1065,6 +1065,7 @@ __device__ __forceinline__ void bw_store_slot(unsigned short *__restrict__ out, 
         unsigned b[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) b[j] = c[j] < 0xFFu ? c[j] : 0xFFu;
+        // (an ordinary store: the 34 bytes of a run meet their neighbours' in L2 -- as non-temporal stores the pass takes 0.80 instead of 0.71 ms)
         reinterpret_cast<unsigned *>(out)[idx4] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
     } else {
         bd_v2u o;

@@ -2156,7 +2156,7 @@ static int64_t g_opt_bd_pipe = 1;     // 1 = the walk keeps two sets of passes i
 static int64_t g_opt_bd_exp = 0;      // diagnostics only (wrong results): 1 = the dense search kernel without its lookups
 static int64_t g_opt_bw = 1;          // 1 = cell images on padded runs are searched by the persistent walk (bw_search_kernel), 0 = bd_search_kernel's ring
 static int64_t g_opt_bw_grid = 256;   // workgroups of the persistent walk (a multiple of 8: one per CU)
-static int64_t g_opt_bw_depth = 6;    // passes of records in flight per wave of the persistent walk: 3, 4 or 6
+static int64_t g_opt_bw_depth = 3;    // passes of records in flight per wave of the persistent walk: 3, 4 or 6 (configs[1]: 0.703 / 0.711 / 0.715 ms per pass -- the memory side is bound by lines in flight per CU, not by the ring)
 static int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
 
 int ivl_set_option(const char *key, int64_t value)
@@ -2182,7 +2182,7 @@ int ivl_set_option(const char *key, int64_t value)
         return 1;
     }
     if (!strcmp(key, "ivl.bw_depth")) {
-        g_opt_bw_depth = value == 3 || value == 4 ? value : 6;
+        g_opt_bw_depth = value == 4 || value == 6 ? value : 3;
         return 1;
     }
     if (!strcmp(key, "ivl.partition")) {
@@ -3059,9 +3059,9 @@ template <bool W8>
 static int bw_launch_search(const BmLaunch &L, hipStream_t st)
 {
     switch (g_opt_bw_depth) {
-    case 3: return bw_launch_search_t<W8, 3>(L, st);
     case 4: return bw_launch_search_t<W8, 4>(L, st);
-    default: return bw_launch_search_t<W8, 6>(L, st);  // (8: spills inside the loop)
+    case 6: return bw_launch_search_t<W8, 6>(L, st);  // (8: spills inside the loop)
+    default: return bw_launch_search_t<W8, 3>(L, st);
     }
 }
 

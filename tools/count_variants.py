@@ -78,6 +78,6 @@ for name, opts in VARIANTS:
     time.sleep(0.05)
     for k, _ in opts:  # back to the defaults this script knows
         _ffi.call("bxmi_set_option", k.encode(), {"ivl.dense": -1, "ivl.bm_variant": -1, "ivl.bd_nt": 1, "ivl.bm_pair": 1, "ivl.bm_u": 2,
-                                                   "ivl.slice": -1, "ivl.sorted_path": 1, "ivl.bd_unit_log2": 0, "ivl.flat": -1, "ivl.bd_pipe": 1, "ivl.bd_depth": 0, "ivl.bd_pad": 1, "ivl.bd_w8": -1, "ivl.order_skip": -1, "ivl.bw": 1, "ivl.bw_depth": 6, "ivl.bw_grid": 256}.get(k, 0))
+                                                   "ivl.slice": -1, "ivl.sorted_path": 1, "ivl.bd_unit_log2": 0, "ivl.flat": -1, "ivl.bd_pipe": 1, "ivl.bd_depth": 0, "ivl.bd_pad": 1, "ivl.bd_w8": -1, "ivl.order_skip": -1, "ivl.bw": 1, "ivl.bw_depth": 3, "ivl.bw_grid": 256}.get(k, 0))
     if any(k == "ivl.bd_unit_log2" for k, _ in opts):
         ix.seal()
