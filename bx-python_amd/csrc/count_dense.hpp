@@ -638,13 +638,11 @@ __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short 
 #pragma unroll
         for (int j = 0; j < 4; j++) c[j] = bp_count_record(I, rec[j]);
     } else if (FMT == 2) {
+        // (a neighbouring unit's record is a valid argument: its offset lies inside the unit's width, the directory
+        // lookups stay inside the staged arrays)
+        sl_count_slot(I.sl, I.g, rec, c);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            // (a neighbouring unit's record is a valid argument: its offset lies inside the unit's width, the directory
-            // lookups stay inside the staged arrays)
-            const unsigned x = sl_count_record(I.sl, I.g, rec[j]);
-            c[j] = x < 0xFFFFu ? x : 0xFFFFu;  // (BM_REC_ESC included)
-        }
+        for (int j = 0; j < 4; j++) c[j] = c[j] < 0xFFFFu ? c[j] : 0xFFFFu;  // (BM_REC_ESC included)
     } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {

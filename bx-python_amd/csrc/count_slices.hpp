@@ -218,6 +218,56 @@ __device__ __forceinline__ unsigned sl_count_record(const SlUnit &U, const BmGeo
     return (unsigned)((U.sLo - U.eLo) + (rS - rE));
 }
 
+// The four records of a 16-byte slot at once (the flat walk of count_dense.hpp): the eight ranks advance in step -- their
+// directory reads, then every halving's eight key reads, are in flight together -- instead of one rank after the other,
+// each a chain of 2 + steps dependent LDS reads (round 4: the slice search of a genome share spent its time waiting for
+// them: 126 -> see DESIGN.md).  c[j] = the count (BM_REC_ESC for an escape record).
+// (Tried in round 4: a rank in TWO LDS reads where the cells are small -- the directory pair as one 4-byte read, the cell's first
+// eight keys as one 16-byte read at a 2-byte boundary (gfx950's LDS returns the right bytes: tools/micro/lds_unaligned.hip),
+// key < x for all eight by four v_pk_sub_i16 and a popcount.  Exact, and slower: genome pass 1.35 against 0.97 ms, the
+// 16-byte reads move eight times the bytes of the halving search through the LDS.  Not kept.)
+#ifndef SL_SLOT_RECS
+#define SL_SLOT_RECS 2  // records of a slot whose ranks advance together (4: 73 registers in the flat walk -- one workgroup per CU: genome pass 1.18 ms; 2: 0.96; 1: 0.96; one rank after the other: 1.04)
+#endif
+__device__ __forceinline__ void sl_count_slot(const SlUnit &U, const BmGeom &g, const unsigned (&rec)[4], unsigned (&c)[4])
+{
+    const unsigned omask = (1u << g.rshift) - 1u, dmask = (1u << g.dshift) - 1u, esc_len = bm_len_esc(g);
+    constexpr int R = SL_SLOT_RECS, K = 2 * R;
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0 += R) {
+        unsigned lo[K], hi[K], xl[K];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const unsigned len = rec[j0 + j] >> g.rshift, off = rec[j0 + j] & omask;
+            const bool esc = len == esc_len;
+            const unsigned xe = esc ? 0u : off + 1u, xs = esc ? 0u : off + len;  // (an escape record's look-ups stay inside the unit)
+            const unsigned ce = xe >> g.dshift, cs = xs >> g.dshift;
+            xl[2 * j] = xe & dmask, xl[2 * j + 1] = xs & dmask;
+            lo[2 * j] = U.dirE[ce], hi[2 * j] = U.dirE[ce + 1];
+            lo[2 * j + 1] = U.dirS[cs], hi[2 * j + 1] = U.dirS[cs + 1];
+        }
+        for (int i = 0; i < U.steps; i++) {
+            unsigned mid[K], key[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                mid[k] = (lo[k] + hi[k]) >> 1;
+                key[k] = (k & 1) ? (unsigned)U.lowS[mid[k]] : (unsigned)U.lowE[mid[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const bool go = lo[k] < hi[k] && key[k] < xl[k];
+                lo[k] = go ? mid[k] + 1 : lo[k];
+                hi[k] = go ? hi[k] : mid[k];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const unsigned x = (unsigned)((U.sLo - U.eLo) + ((int)lo[2 * j + 1] - (int)lo[2 * j]));
+            c[j0 + j] = (rec[j0 + j] >> g.rshift) == esc_len ? BM_REC_ESC : x;
+        }
+    }
+}
+
 // The walk of bm_search_pipe_kernel (rounds of U runs per L-lane group, the next round's records requested before
 // this round is computed, long runs finished by the whole workgroup) over the runs of one UNIT: the run of unit u in
 // tile t is what lies between the first slots of buckets u << f and (u + 1) << f in the tile-sorted order.
