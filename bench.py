@@ -698,6 +698,28 @@ def main():
             ok = hashlib.sha256(sub.tobytes()).hexdigest() == pt["counts_sha256"] and int(sub.sum(dtype=np.int64)) == pt["total"]
             parity += "; sha256 of the 1M-query subsample == reference treap's: %s" % ok
 
+    # what a caller's FIRST passes cost (the headline is a steady-state number).  A fresh handle over the same
+    # targets: pass 1 builds the index's unit images, allocates the pass's scratch and asks the order probe synchronously
+    # (all once per handle); pass 2 is what every later pass costs unless the batch looks sorted.
+    cold = None
+    if rank == 0 and world == 1:
+        ixc = IntervalIndex()
+        ixc.append(ts, te)
+        ixc.seal()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        ixc.count_dev(qs.data_ptr(), qe.data_ptr(), nq, counts.data_ptr(), total.data_ptr(), stream)
+        ev[1].record()
+        ixc.count_dev(qs.data_ptr(), qe.data_ptr(), nq, counts.data_ptr(), total.data_ptr(), stream)
+        ev[2].record()
+        torch.cuda.synchronize()
+        cold = dict(first_pass_ms=round(ev[0].elapsed_time(ev[1]), 4), second_pass_ms=round(ev[1].elapsed_time(ev[2]), 4),
+                    order_check_skipped_after_first_pass=bool(ixc.order_state()[0]),
+                    note="fresh handle, same 10M targets and 100M shuffled queries: pass 1 = image build (once per sealed index) + scratch "
+                         "allocation + the order probe answered synchronously; pass 2 = the steady state")
+        ixc.close()
+
     # the same batch through the HOST-pointer entry point (pageable numpy buffers over PCIe): reported, never `value`
     pcie = None
     if rank == 0 and world == 1:
@@ -717,6 +739,14 @@ def main():
         sqs, sqe = qs[order].contiguous(), qe[order].contiguous()
         del order
         scounts = torch.empty_like(counts)
+        # the first sorted batch after shuffled ones meets no order check: it goes through the exchange, exact as ever
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        ix.count_dev(sqs.data_ptr(), sqe.data_ptr(), nq, scounts.data_ptr(), total.data_ptr(), stream)
+        f1.record()
+        torch.cuda.synchronize()
+        first_sorted_ms = f0.elapsed_time(f1)
         for _ in range(2):
             ix.count_dev(sqs.data_ptr(), sqe.data_ptr(), nq, scounts.data_ptr(), total.data_ptr(), stream)
         # (the warm-up has to END before the timed passes are enqueued: after the shuffled batches above the library goes
@@ -733,7 +763,8 @@ def main():
         same = int(scounts.sum(dtype=torch.int64).item()) == local_total
         sorted_q = dict(value=round(nq / s_ms / 1e3, 1), unit="M queries/s", ms_per_pass=round(s_ms, 4),
                         frac_of_hbm_peak=round(alg_bytes_of(nq, args.targets) / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        same_total_as_unsorted=bool(same), kernel="bm_sorted_check (detects the order) + ivl_local_count_kernel")
+                        same_total_as_unsorted=bool(same), kernel="bm_sorted_check (detects the order) + ivl_local_count_kernel",
+                        first_sorted_pass_after_shuffled_ms=round(first_sorted_ms, 4))
         del sqs, sqe, scounts
 
     stages = dict(zip(("flat_walk_on_cell_images", "dense_unit_images", "bucket_pair_images", "key_slices"),
@@ -770,6 +801,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
+        "first_pass_ms": cold["first_pass_ms"] if cold else None,
+        "second_pass_ms": cold["second_pass_ms"] if cold else None,
+        "first_sorted_pass_after_shuffled_ms": sorted_q["first_sorted_pass_after_shuffled_ms"] if sorted_q else None,
+        "cold_passes": cold,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -785,9 +820,9 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "kernel": ("count pass = bm_params (with a probe of 8192 starts for the order; the exact bm_sorted_check + the stand-down of "
-                       "ivl_local_count run only until two batches in a row were shuffled) + bm_tile_sort + bd_transpose + bd_plan + "
-                       "bd_search (the flat 16-byte walk on cell images of 2^18-coordinate units, ring of hand-issued loads) + bd_unpermute "
-                       "(8-bit counts) + bm_fold_totals; dominant: bd_search_kernel" if partitioned else "ivl_count_kernel"),
+                       "ivl_local_count run only while the probes see no descent) + bm_tile_sort + bd_transpose + bd_plan + "
+                       "bw_search (persistent walk on cell images of 2^18-coordinate units, ring of hand-issued loads) + bd_unpermute "
+                       "(8-bit counts) + bm_fold_totals; dominant by time: bm_tile_sort_kernel (HBM-bound), then bw_search_kernel" if partitioned else "ivl_count_kernel"),
             "search_stage_of_this_index": stages,
             "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
             "timed_with": "HIP events on the launch stream around every bxmi_ivl_count_dev call of the timed region",

@@ -47,6 +47,9 @@ def _cint(x):
     return x
 
 
+_MIRROR_MAX_RUNS = 2_000_000  # count_range answers from a host copy of the device's run list only while it is this short
+
+
 class _Queued:
     """Shared machinery: queued set_range + run-list cache on top of a DeviceBitSet."""
 
@@ -57,8 +60,10 @@ class _Queued:
         self._scans = 0  # next_* calls since the last mutation
         self._mirror = None  # (run_starts, run_ends, bits before each run, per-bin states or None): see _count
         self._reads = 0  # count_range calls since the last mutation
+        self._mirror_ok = True  # False: the run list was found too long to mirror (until the next mutation)
 
     def _touch(self):
+        self._mirror_ok = True
         self._runs = None
         self._scans = 0
         self._mirror = None
@@ -77,6 +82,7 @@ class _Queued:
         self._scans = 0
         self._mirror = None
         self._reads = 0
+        self._mirror_ok = True
         if len(self._ps) >= _FLUSH_AT:
             self._flush()
 
@@ -112,12 +118,14 @@ class _Queued:
             self._reads += 1
             if self._reads < 3:
                 return self._d.count_range_checked(start, count)
+            if self._reads > 3 and not self._mirror_ok:
+                return self._d.count_range_checked(start, count)  # (a set with millions of runs: asked on the device every time)
             rs, re = self._d.runs(0)
+            if len(rs) > _MIRROR_MAX_RUNS:  # tens of millions of runs would cost gigabytes of host lists to save microseconds
+                self._mirror_ok = False
+                return self._d.count_range_checked(start, count)
+            before = np.concatenate(([0], np.cumsum(re.astype(np.int64) - rs.astype(np.int64)))).tolist()
             rs, re = rs.tolist(), re.tolist()
-            before, acc = [0] * (len(rs) + 1), 0
-            for i in range(len(rs)):
-                acc += re[i] - rs[i]
-                before[i + 1] = acc
             m = self._mirror = (rs, re, before, bytes(self._d.bin_states()) if binned else None)
             self._runs = (0, rs, re)
         if count <= 0:

@@ -199,6 +199,46 @@ def write_runs(out, chrom, bits, clip=None):
         raise IndexError("%d is larger than the size of this BitSet (%d)." % (bits.size, bits.size))
 
 
+def as_group(bitsets, mutated=False):
+    """One BitSetGroup over the device sets behind a sequence of drop-in bitsets: their queued ranges are flushed, and with
+    `mutated` their host-side caches of device results are dropped (the group is about to change them).  The group entry
+    points run ONE kernel launch for all members where the reference's scripts loop over the chromosomes."""
+    from .bitset import BitSetGroup
+
+    members = list(bitsets)
+    for b in members:
+        b._flush()
+        if mutated:
+            b._touch()
+    return BitSetGroup([b._d for b in members])
+
+
+# A group launch works on whole word arrays: it makes every member allocate its full size (64 MiB for a default-sized set),
+# where the per-set calls leave untouched bins unallocated.  Fine for a genome's chromosomes; a scaffold-level assembly
+# with thousands of sequence names keeps the per-set loop (tests/test_gpu_bitset.py::test_thousands_of_default_sized_sets_stay_small).
+GROUP_MAX_MEMBERS = 128
+
+
+def group_coverage(bitsets):
+    """sum of count_range(0, size) over the sets -- bed_coverage.py:27-29 -- as one grid-wide popcount launch."""
+    members = list(bitsets)
+    if not members:
+        return 0
+    if len(members) > GROUP_MAX_MEMBERS:
+        return sum(b.count_range(0, b.size) for b in members)
+    return int(as_group(members).popcounts().sum())
+
+
+def group_iand(targets, others):
+    """targets[i].iand(others[i]) for all i -- bed_intersect_basewise.py:25-28 -- as one launch."""
+    targets, others = list(targets), list(others)
+    if len(targets) > GROUP_MAX_MEMBERS:
+        for a, b in zip(targets, others):
+            a.iand(b)
+    elif targets:
+        as_group(targets, mutated=True).iand(as_group(others))
+
+
 def _c_int(v):
     if not -2147483648 <= v <= 2147483647:
         raise OverflowError("value too large to convert to int")

@@ -5,12 +5,12 @@ intervals counts once.
 
 usage: %prog bed files ...
 """
-# Counterpart of the reference's scripts/bed_coverage.py:19-31: one set_ranges launch and one
-# grid-wide popcount per chromosome.
+# Counterpart of the reference's scripts/bed_coverage.py:19-31: one set_ranges launch per chromosome and ONE
+# grid-wide popcount for the genome (bxmi_bits_group_popcount_dev) where the reference loops count_range over the chromosomes.
 import fileinput
 import sys
 
-from bxmi.builders import binned_bitsets_from_file, binned_bitsets_from_paths
+from bxmi.builders import binned_bitsets_from_file, binned_bitsets_from_paths, group_coverage
 
 
 def main(argv=None, out=None, stdin=None):
@@ -20,9 +20,7 @@ def main(argv=None, out=None, stdin=None):
         bitsets = binned_bitsets_from_paths(bed_filenames)  # what fileinput would chain, each file ingested in bulk
     else:
         bitsets = binned_bitsets_from_file(fileinput.input(bed_filenames) if bed_filenames else (stdin or sys.stdin))
-    total = 0
-    for chrom in bitsets:
-        total += bitsets[chrom].count_range(0, bitsets[chrom].size)
+    total = group_coverage(bitsets.values())  # (fresh sets, never inverted: count_range(0, size) is the popcount)
     out.write("%d\n" % total)
     out.flush()
 

@@ -8,7 +8,7 @@ usage: %prog bed_file_1 bed_file_2
 # then one run extraction per chromosome instead of the next_set/next_clear walk.
 import sys
 
-from bxmi.builders import binned_bitsets_from_file, write_runs
+from bxmi.builders import binned_bitsets_from_file, group_iand, write_runs
 
 
 def main(argv=None, out=None):
@@ -20,11 +20,11 @@ def main(argv=None, out=None):
         raise SystemExit(__doc__.replace("%prog", sys.argv[0]))
     bitsets1 = binned_bitsets_from_file(open(in_fname))
     bitsets2 = binned_bitsets_from_file(open(in2_fname))
+    shared = [chrom for chrom in bitsets1 if chrom in bitsets2]
+    for chrom in shared:
+        bitsets2[chrom].invert()
+    group_iand([bitsets1[c] for c in shared], [bitsets2[c] for c in shared])  # one launch for the genome's and-not
     for chrom, bits1 in bitsets1.items():
-        if chrom in bitsets2:
-            bits2 = bitsets2[chrom]
-            bits2.invert()
-            bits1.iand(bits2)
         write_runs(out, chrom, bits1)
     out.flush()
 

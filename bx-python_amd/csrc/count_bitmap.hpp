@@ -97,6 +97,32 @@ struct BmSegChunk {
     unsigned long long *total[BM_PAR_CHUNK];  // where each segment's overlap total is accumulated (may be NULL)
 };
 
+// The order PROBE (a workgroup of 256 threads): two stretches of 4096 consecutive starts.  A descent in them says "shuffled"
+// for certain; none says "could be sorted", and the host keeps / brings back the exact check.
+__device__ __forceinline__ bool bm_probe_descent(const int32_t *__restrict__ qs, int64_t nq)
+{
+    bool descent = false;
+#pragma unroll
+    for (int part = 1; part <= 2; part++) {
+        const int64_t at = ((nq / 3 * part) & ~(int64_t)15) + 16 * (int64_t)threadIdx.x;
+        if (at + 17 <= nq) {
+            const int4 *p = reinterpret_cast<const int4 *>(qs + at);
+            const int4 a = p[0], b = p[1], d = p[2], e = p[3];
+            const int nxt = qs[at + 16];
+            descent |= a.x > a.y || a.y > a.z || a.z > a.w || a.w > b.x || b.x > b.y || b.y > b.z || b.z > b.w || b.w > d.x || d.x > d.y ||
+                       d.y > d.z || d.z > d.w || d.w > e.x || e.x > e.y || e.y > e.z || e.z > e.w || e.w > nxt;
+        }
+    }
+    return __syncthreads_or(descent);
+}
+
+// a handle's first large batch asks the probe alone and waits for the answer (bm_count_segments)
+__global__ __launch_bounds__(256) void bm_probe_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ answer)
+{
+    const bool d = bm_probe_descent(qs, nq);
+    if (threadIdx.x == 0) *answer = d ? 1u : 0u;
+}
+
 // The first launch of a batch also zeroes what the later kernels accumulate into (the segments' partial totals with the
 // order flag behind them, the plan's item count): two memsets less on the stream.
 __global__ __launch_bounds__(256) void bm_params_kernel(BmSegChunk c, int first, BmSeg *__restrict__ segs, unsigned long long **__restrict__ totals,
@@ -107,23 +133,9 @@ __global__ __launch_bounds__(256) void bm_params_kernel(BmSegChunk c, int first,
         for (int i = threadIdx.x; i < n_zero; i += 256) zero_u64[i] = 0ull;
         if (threadIdx.x == 0) *n_items = 0;
         if (probe) {
-            // No order check in this pass (bm_count_segments stopped launching it after shuffled batches): a PROBE instead --
-            // two stretches of 4096 consecutive starts of segment 0.  A descent in them says "shuffled" for certain; none
-            // says "could be sorted", and the host brings the exact check back.  *probe (zeroed above) = 1: descent seen.
-            const BmSeg &s0 = c.seg[0];
-            bool descent = false;
-#pragma unroll
-            for (int part = 1; part <= 2; part++) {
-                const int64_t at = ((s0.nq / 3 * part) & ~(int64_t)15) + 16 * (int64_t)threadIdx.x;
-                if (at + 17 <= s0.nq) {
-                    const int4 *p = reinterpret_cast<const int4 *>(s0.qs + at);
-                    const int4 a = p[0], b = p[1], d = p[2], e = p[3];
-                    const int nxt = s0.qs[at + 16];
-                    descent |= a.x > a.y || a.y > a.z || a.z > a.w || a.w > b.x || b.x > b.y || b.y > b.z || b.z > b.w || b.w > d.x || d.x > d.y ||
-                               d.y > d.z || d.z > d.w || d.w > e.x || e.x > e.y || e.y > e.z || e.z > e.w || e.w > nxt;
-                }
-            }
-            if (__syncthreads_or(descent) && threadIdx.x == 0) *probe = 1u;  // (behind the barrier: after the zeroing above)
+            // No order check in this pass (bm_count_segments stopped launching it after shuffled batches): a PROBE instead.
+            // *probe (zeroed above) = 1: descent seen.
+            if (bm_probe_descent(c.seg[0].qs, c.seg[0].nq) && threadIdx.x == 0) *probe = 1u;  // (behind its barrier: after the zeroing above)
         }
     }
     const BmSeg &sg = c.seg[blockIdx.x];

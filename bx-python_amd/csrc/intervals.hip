@@ -3239,6 +3239,16 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
             h->order_seen = seen >> 1;
             h->order_skip = h->unsorted_streak >= 2;
         }
+        if (h->order_seq == 0 && g_opt_order_skip != 0) {
+            // The handle's first large batch: nothing is known about the caller's order yet, and this call has waited for the
+            // device already (it built the index's images) -- so the probe is asked alone and its answer read back: a descent
+            // among its 8192 starts drops the exact check from this very pass (a cold pass paid 24 us of 700 for it).
+            hipLaunchKernelGGL(bm_probe_kernel, dim3(1), dim3(256), 0, st, qs[0], nq[0], unsorted);
+            unsigned seen_descent = 0;
+            BXMI_HIP(hipMemcpyAsync(&seen_descent, unsorted, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            BXMI_HIP(hipStreamSynchronize(st));
+            if (seen_descent) h->unsorted_streak = 2, h->order_skip = true;
+        }
         order_seq = ++h->order_seq;
         if (h->order_skip && g_opt_order_skip != 0) descent = unsorted, unsorted = nullptr;  // (the word is zeroed with the partial totals)
     }
