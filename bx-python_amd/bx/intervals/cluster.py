@@ -8,11 +8,13 @@ they are asked for (sort by start, running maximum of the ends, a boundary where
 `start - mincols > largest end so far`) -- for mincols >= 0 the reference's outcome does not
 depend on the insertion order, so the results are identical.
 
-A negative `mincols` is refused (ValueError on query), because the reference has no answer to reproduce
-there: with max_dist < 0 an interval can be both "to the right of" and "to the left of" a cluster
-(src/cluster.c:224-230, the first test wins), the tree stops being ordered by position, and which cluster a
-later interval meets depends on the tree's shape -- i.e. on the node priorities, which come from the process-wide
-unseeded rand() (src/cluster.c:66-69) and so on how many nodes any earlier tree in the process has created.
+`mincols = -1` ("overlap by one base or more") is answered too while every interval has a positive length: the committed
+experiment on the reference's own C (oracle/cluster_negative_distance.py, tests/golden/cluster_negative_distance.txt) finds
+one answer there, the same sweep.  Distances below -1, and -1 with zero-length intervals, are refused (ValueError on query),
+because the reference has no answer to reproduce: an interval can then be both "to the right of" and "to the left of" a
+cluster (src/cluster.c:224-230, the first test wins), the tree stops being ordered by position, and which cluster a later
+interval meets depends on the tree's shape -- i.e. on the node priorities, which come from the process-wide unseeded rand()
+(src/cluster.c:66-69) and so on how many nodes any earlier tree in the process has created.
 """
 from bxmi.intervals import IntervalIndex
 
@@ -50,8 +52,9 @@ class ClusterTree:
         if self._regions is None:
             regions = []
             if self._s:
-                if self.mincols < 0:
-                    raise ValueError("ClusterTree with a negative distance depends on the insertion order in the reference; not supported")
+                if self.mincols < -1 or (self.mincols == -1 and any(b <= a for a, b in zip(self._s, self._e))):
+                    raise ValueError("ClusterTree with a distance below -1 (or -1 and zero-length intervals) depends on the insertion "
+                                     "order and on rand() in the reference; not supported")
                 ix = IntervalIndex()
                 ix.append(self._s, self._e)
                 starts, ends, offsets, members = ix.clusters(self.mincols, self._ids)

@@ -2071,11 +2071,16 @@ struct Tree {
 // begins exactly where  start - max_dist > (largest end so far)  -- verified against the reference's extension on
 // 20 000 random trees.  The sealed index already holds the starts in order and the prefix maximum of the ends, so a
 // cluster boundary is one comparison per interval.
-__global__ void cluster_flag_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ pm, int n, int max_dist,
-                                    int32_t *__restrict__ flag)
+// (*empty = 1 when some interval has end <= start: what decides whether max_dist = -1 has an answer, see bxmi_ivl_clusters)
+__global__ void cluster_flag_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_ord, const int32_t *__restrict__ pm, int n,
+                                    int max_dist, int32_t *__restrict__ flag, int32_t *__restrict__ empty)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    bool mine = false;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         flag[i] = i == 0 || (long long)s_ord[i] - (long long)max_dist > (long long)pm[i - 1];
+        mine |= e_ord[i] <= s_ord[i];
+    }
+    if (__any(mine) && lane_id() == 0) *empty = 1;  // (ordinary stores of one value: visible at the kernel's end)
 }
 
 // cluster id of every interval (inclusive scan of the flags, minus one) -> sort key (cluster, id), and the first position
@@ -4023,8 +4028,15 @@ extern "C" int bxmi_ivl_clusters(bxmi_ivl_t *h, const int32_t *ids, int32_t max_
 {
     BXMI_TRY(need_sealed(h, "bxmi_ivl_clusters"));
     if (!n_clusters) return fail(BXMI_EINVAL, "bxmi_ivl_clusters: n_clusters is NULL");
-    if (max_dist < 0)
-        return fail(BXMI_EINVAL, "bxmi_ivl_clusters: max_dist=%d; with a negative distance the reference's result depends on the "
+    // A negative distance: the reference merges an interval into a cluster when start <= cluster end - d AND end >= cluster
+    // start + d (src/cluster.c:224-232, d = -max_dist), and an interval can then be both "right of" and "left of" a cluster: the
+    // tree stops being ordered and the regions depend on the insertion order and on rand().  The committed experiment on the
+    // reference's own C (oracle/cluster_negative_distance.py -> tests/golden/cluster_negative_distance.txt: -1 ... -8, 150 interval
+    // sets, 12 insertion orders x 12 seeds) finds ONE distance with an answer: max_dist = -1 on intervals of positive length --
+    // "overlap by at least one base", the connected components of the overlap graph, the same sweep as below -- and none
+    // for -1 with zero-length intervals or for -2 and beyond.  Those are refused.
+    if (max_dist < -1)
+        return fail(BXMI_EINVAL, "bxmi_ivl_clusters: max_dist=%d; with a distance below -1 the reference's result depends on the "
                                  "insertion order and is not reproduced", (int)max_dist);
     if (h->has_reversed) return fail(BXMI_ESTATE, "bxmi_ivl_clusters: the index holds intervals with start > end");
     *n_clusters = 0;
@@ -4045,11 +4057,15 @@ extern "C" int bxmi_ivl_clusters(bxmi_ivl_t *h, const int32_t *ids, int32_t max_
     BXMI_TRY(h->keys_b.reserve((size_t)(n + 1) * 8));
     int32_t *flag = h->q_lo.as<int32_t>(), *cid = h->q_hi.as<int32_t>();
     const int g = stream_grid(n, 256);
-    hipLaunchKernelGGL(cluster_flag_kernel, dim3(g), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->pm.as<int32_t>(), (int)n, (int)max_dist, flag);
+    int32_t *empty_dev = h->q_cnt.as<int32_t>() + n;  // (a spare word of the cluster-start buffer)
+    BXMI_HIP(hipMemsetAsync(empty_dev, 0, 4, st));
+    hipLaunchKernelGGL(cluster_flag_kernel, dim3(g), dim3(256), 0, st, h->s_ord.as<int32_t>(), h->e_ord.as<int32_t>(), h->pm.as<int32_t>(), (int)n,
+                       (int)max_dist, flag, empty_dev);
     BXMI_LAUNCH_CHECK();
     BXMI_TRY((device_scan<int32_t, int32_t, OpSum, true>(flag, cid, n, 0, nullptr, h->scan_scratch, st)));
-    int32_t nc = 0;
+    int32_t nc = 0, any_empty = 0;
     BXMI_HIP(hipMemcpyAsync(&nc, cid + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipMemcpyAsync(&any_empty, empty_dev, 4, hipMemcpyDeviceToHost, st));
     const int32_t *d_ids = nullptr;
     if (ids) {
         BXMI_HIP(hipMemcpyAsync(h->q_s.p, ids, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -4059,6 +4075,9 @@ extern "C" int bxmi_ivl_clusters(bxmi_ivl_t *h, const int32_t *ids, int32_t max_
                        h->keys_a.as<unsigned long long>(), h->q_cnt.as<int32_t>(), h->q_off.as<long long>());
     BXMI_LAUNCH_CHECK();
     BXMI_HIP(hipStreamSynchronize(st));  // nc
+    if (max_dist < 0 && any_empty)
+        return fail(BXMI_EINVAL, "bxmi_ivl_clusters: max_dist=-1 with zero-length intervals; the reference's result depends on the "
+                                 "insertion order then and is not reproduced");
     unsigned long long *sorted = nullptr;
     BXMI_TRY(radix_sort_keys<unsigned long long>(h->keys_a.as<unsigned long long>(), h->keys_b.as<unsigned long long>(), n, &sorted,
                                                  h->sort_scratch, st));

@@ -5,9 +5,9 @@
  * Reference: src/cluster.c.  An interval joins the cluster it lands in when
  *     !(start - max_dist > node->end) && !(end + max_dist < node->start)          (cluster.c:229-236)
  * and cluster_fixup (:112-147) then absorbs every neighbouring cluster the widened range reaches
- * (maxstart - minend <= max_dist, :120).  For max_dist >= 0 the final partition is the set of
- * connected components of "gap <= max_dist", independent of the insertion order; walking the
- * intervals by start it is: open a new cluster when start - max_dist > largest end so far.
+ * (maxstart - minend <= max_dist, :120).  For max_dist >= 0 (and for max_dist = -1 on intervals of positive
+ * length) the final partition is the set of connected components of "gap <= max_dist", independent of the
+ * insertion order; walking the intervals by start it is: open a new cluster when start - max_dist > largest end so far.
  * getregions() (lib/bx/intervals/cluster.pyx:74-98) lists the clusters by ascending start with their ids
  * sorted; the min_intervals filter (cluster.c:190) is applied by the caller.
  *
@@ -40,7 +40,13 @@ static int by_id(const void *a, const void *b)
 int64_t oracle_clusters(const int32_t *start, const int32_t *end, const int32_t *ids, int64_t n, int32_t max_dist,
                         int32_t *c_start, int32_t *c_end, int64_t *c_off, int32_t *members)
 {
-    if (n < 0 || max_dist < 0) return -1;
+    /* max_dist = -1 ("overlap by one base or more") has an answer while every interval has a positive length: the same
+     * sweep (oracle/cluster_negative_distance.py); below -1, or -1 with a zero-length interval, the reference's result
+     * depends on the insertion order and on rand(): -1 = bad input. */
+    if (n < 0 || max_dist < -1) return -1;
+    if (max_dist < 0)
+        for (int64_t i = 0; i < n; i++)
+            if (end[i] <= start[i]) return -1;
     if (n == 0) {
         c_off[0] = 0;
         return 0;

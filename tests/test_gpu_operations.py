@@ -159,6 +159,41 @@ def test_clustertree_matches_reference_vectors(golden):
         assert off.tolist() == np.concatenate([[0], np.cumsum([len(w[2]) for w in want])]).tolist()
 
 
+def test_clustertree_distance_minus_one():
+    """max_dist = -1 ("overlap by one base or more") on intervals of positive length: the engine against regions of the
+    reference's own C (tests/golden/cluster_minus_one.json); refused with zero-length intervals and below -1."""
+    import json
+    import os
+
+    from bx.intervals.cluster import ClusterTree
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = json.load(open(os.path.join(root, "tests", "golden", "cluster_minus_one.json")))
+    for c in doc["cases"]:
+        t = ClusterTree(-1, c["min_intervals"])
+        for a, b, i in c["triples"]:
+            t.insert(a, b, i)
+        assert sorted([a, b, sorted(ids)] for a, b, ids in t.getregions()) == c["regions"], (c["min_intervals"], len(c["triples"]))
+    t = ClusterTree(-1, 0)
+    t.insert(0, 4, 0), t.insert(4, 4, 1)
+    with pytest.raises(ValueError):
+        t.getregions()
+    t = ClusterTree(-2, 0)
+    t.insert(0, 4, 0), t.insert(3, 9, 1)
+    with pytest.raises(ValueError):
+        t.getregions()
+    from bxmi import _ffi
+    from bxmi.intervals import IntervalIndex
+
+    ix = IntervalIndex()
+    ix.append([0, 4], [4, 4])
+    with pytest.raises(_ffi.BxmiError):  # the C ABI says so itself
+        ix.clusters(-1)
+    with pytest.raises(_ffi.BxmiError):
+        ix.clusters(-2)
+    ix.close()
+
+
 def test_find_clusters_matches_the_reference(golden, mods):
     genomic, operations = mods
     make = {"nice": genomic.NiceReaderWrapper, "plain": genomic.GenomicIntervalReader}

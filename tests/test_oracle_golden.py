@@ -332,11 +332,42 @@ def test_restatement_is_clean_under_asan_and_ubsan():
     assert "passed" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
 
+def test_cluster_distance_minus_one_vectors():
+    """max_dist = -1 on intervals of positive length is the one negative distance the reference answers reproducibly
+    (oracle/cluster_negative_distance.py): the restatement against regions of the reference's own C (tests/golden/
+    cluster_minus_one.json), and its refusals."""
+    import json
+
+    from oracle import oracle as O
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = json.load(open(os.path.join(root, "tests", "golden", "cluster_minus_one.json")))
+    assert len(doc["cases"]) >= 30
+    for c in doc["cases"]:
+        s, e, ids = (np.array(x, dtype=np.int32) for x in zip(*c["triples"]))
+        got = sorted([a, b, sorted(m)] for a, b, m in O.cluster_regions(s, e, ids, -1, c["min_intervals"]))
+        assert got == c["regions"], (c["min_intervals"], len(c["triples"]))
+    with pytest.raises(ValueError):
+        O.cluster_regions([0, 5], [3, 5], None, -1)  # a zero-length interval
+    with pytest.raises(ValueError):
+        O.cluster_regions([0, 5], [3, 9], None, -2)
+    if O.have_ref_cluster():  # the restatement against the reference's C, random insertion orders
+        rng = np.random.default_rng(77)
+        for _ in range(40):
+            n = int(rng.integers(2, 150))
+            s = rng.integers(0, 400, size=n)
+            e = s + rng.integers(1, 40, size=n)
+            tri = [(int(a), int(b), i) for i, (a, b) in enumerate(zip(s, e))]
+            ref = sorted([a, b, sorted(m)] for a, b, m in O.ref_cluster_regions([tri[i] for i in rng.permutation(n)], -1, 0))
+            assert sorted([a, b, sorted(m)] for a, b, m in O.cluster_regions(s, e, None, -1, 0)) == ref
+
+
 def test_negative_cluster_distance_has_no_answer_to_reproduce():
-    """ClusterTree(max_dist < 0) is refused by the engine (BXMI_EINVAL).  The committed experiment on the reference's own
-    src/cluster.c (oracle/cluster_negative_distance.py, its table in tests/golden/cluster_negative_distance.txt) shows why:
-    for distances of -5 and below the regions depend on the insertion order AND on the rand() priorities of the treap,
-    while every non-negative distance gives one answer."""
+    """ClusterTree(max_dist < -1), and -1 with zero-length intervals, are refused by the engine (BXMI_EINVAL).  The committed
+    experiment on the reference's own src/cluster.c (oracle/cluster_negative_distance.py, its table in tests/golden/
+    cluster_negative_distance.txt: -1 ... -8 and -20, 150 interval sets of three kinds) shows why: there the regions depend on
+    the insertion order AND on the rand() priorities of the treap, while every non-negative distance -- and -1 on intervals
+    of positive length -- gives one answer, the sweep's."""
     import subprocess
     import sys
 
@@ -348,3 +379,6 @@ def test_negative_cluster_distance_has_no_answer_to_reproduce():
     r = subprocess.run([sys.executable, os.path.join(root, "oracle", "cluster_negative_distance.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "negative distances depend on order / priorities: True" in r.stdout
+    row = [l for l in r.stdout.splitlines() if l.split()[:1] == ["-1"]][0]
+    assert "| 0 of 50 / 0 of 50 / 50 of 50" in row, row  # positive lengths: one answer; with zero-length intervals: none
+    assert all("0 of 50 / 0 of 50 / 0 of 50" not in l for l in r.stdout.splitlines() if l.split()[:1] in (["-2"], ["-3"], ["-4"]))
