@@ -9,7 +9,7 @@ they are asked for (sort by start, running maximum of the ends, a boundary where
 depend on the insertion order, so the results are identical.
 
 `mincols = -1` ("overlap by one base or more") is answered too while every interval has a positive length: the committed
-experiment on the reference's own C (oracle/cluster_negative_distance.py, tests/golden/cluster_negative_distance.txt) finds
+experiment on the reference's own C (tests/golden/cluster_negative_distance.txt, with the script that made it) finds
 one answer there, the same sweep.  Distances below -1, and -1 with zero-length intervals, are refused (ValueError on query),
 because the reference has no answer to reproduce: an interval can then be both "to the right of" and "to the left of" a
 cluster (src/cluster.c:224-230, the first test wins), the tree stops being ordered by position, and which cluster a later

@@ -38,6 +38,8 @@ _SIGNATURES = {
     "bxmi_memcpy_d2h": [vp, vp, C.c_size_t],
     "bxmi_memset": [vp, C.c_int, C.c_size_t],
     "bxmi_set_option": [C.c_char_p, i64],
+    "bxmi_get_option": [C.c_char_p, _p(i64)],
+    "bxmi_option_at": [C.c_int, _p(C.c_char_p), _p(i64)],
     "bxmi_ivl_create": [_p(vp)],
     "bxmi_ivl_destroy": [vp],
     "bxmi_ivl_append": [vp, vp, vp, i64],
@@ -219,3 +221,15 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+def options():
+    """{key: current value} of every tuning knob (bxmi_option_at): read once at import it is the library's defaults."""
+    L = load()
+    out, i = {}, 0
+    while True:
+        k, v = C.c_char_p(), i64(0)
+        if L.bxmi_option_at(i, C.byref(k), C.byref(v)) != 0:
+            return out
+        out[k.value.decode()] = v.value
+        i += 1

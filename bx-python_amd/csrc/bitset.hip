@@ -594,6 +594,8 @@ __global__ void tags_group_kernel(const GroupSeg *__restrict__ sa, const GroupSe
 }
 
 static int64_t g_opt_bits_grid = 0;
+int64_t bits_get_grid() { return g_opt_bits_grid; }
+
 int bits_set_option(const char *key, int64_t value)
 {
     if (!strcmp(key, "bits.grid")) {

@@ -42,7 +42,10 @@ const DeviceProps &device_props()
 }
 
 int ivl_set_option(const char *key, int64_t value);
+int ivl_option_count();
+int ivl_option_at(int i, const char **key, int64_t *value);
 int bits_set_option(const char *key, int64_t value);
+int64_t bits_get_grid();
 
 }  // namespace bxmi
 
@@ -155,4 +158,30 @@ extern "C" int bxmi_set_option(const char *key, int64_t value)
     }
     if (ivl_set_option(key, value) || bits_set_option(key, value)) return BXMI_OK;
     return fail(BXMI_EINVAL, "bxmi_set_option: unknown key '%s'", key);
+}
+
+// every option in turn: i = 0, 1, ... until BXMI_EINVAL (the interval path's table, then bits.grid and core.poll)
+extern "C" int bxmi_option_at(int i, const char **key, int64_t *value)
+{
+    if (!key || !value) return fail(BXMI_EINVAL, "bxmi_option_at: NULL output");
+    const int n = ivl_option_count();
+    if (i >= 0 && i < n) return ivl_option_at(i, key, value) ? BXMI_OK : fail(BXMI_EINVAL, "bxmi_option_at: no option %d", i);
+    if (i == n) {
+        *key = "bits.grid", *value = bits_get_grid();
+        return BXMI_OK;
+    }
+    if (i == n + 1) {
+        *key = "core.poll", *value = bxmi::g_opt_poll ? 1 : 0;
+        return BXMI_OK;
+    }
+    return fail(BXMI_EINVAL, "bxmi_option_at: no option %d", i);
+}
+
+extern "C" int bxmi_get_option(const char *key, int64_t *value)
+{
+    if (!key || !value) return fail(BXMI_EINVAL, "bxmi_get_option: NULL argument");
+    const char *k = nullptr;
+    for (int i = 0; bxmi_option_at(i, &k, value) == BXMI_OK; i++)
+        if (!strcmp(k, key)) return BXMI_OK;
+    return fail(BXMI_EINVAL, "bxmi_get_option: unknown key '%s'", key);
 }

