@@ -477,7 +477,8 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
 // (Round 4 tried this kernel persistent and software-pipelined -- a workgroup per CU that asks for the next tile's queries
 // while it places the current one, same register count: 333 us against 322.  On 128 workgroups it takes 484 us, i.e. a tile
 // costs a CU 20 us alone and 28 us on a full chip: the kernel is bound by what the chip's DRAM gives this mix of five
-// streams per workgroup (4.5 TB/s), not by the phases of a workgroup.  Not kept.)
+// streams per workgroup (4.5 TB/s), not by the phases of a workgroup.  Not kept.  Non-temporal stores of the sorted tile
+// and of the slots, non-temporal loads of the queries: 299-321 us against 318, the pass within 1 % either way.  Not kept.)
 
 // ---------------------------------------------------------------------------
 // pass 2: the run table bucket-major, and the work plan
