@@ -52,7 +52,6 @@ _SIGNATURES = {
     "bxmi_ivl_count": [vp, vp, vp, i64, vp, _p(i64)],
     "bxmi_ivl_count_dev": [vp, vp, vp, i64, vp, vp, vp],
     "bxmi_ivl_count_multi_dev": [vp, C.c_int, vp, vp, vp, vp, vp, vp],
-    "bxmi_ivl_bitmap_state": [vp, _p(C.c_int), _p(i64)],
     "bxmi_ivl_slice_state": [vp, _p(C.c_int), vp],
     "bxmi_ivl_dense_state": [vp, _p(C.c_int), vp],
     "bxmi_ivl_flat_state": [vp, _p(C.c_int), _p(i64)],

@@ -75,13 +75,6 @@ class IntervalIndex:
         call("bxmi_ivl_has_reversed", self._h, C.byref(f))
         return bool(f.value)
 
-    def bitmap_state(self):
-        """(state, hard_cells) of the large-batch count pass: 1 = bitmap-cell pass, -1 = bucketed search, 0 = undecided."""
-        self._ready()
-        st, hc = C.c_int(0), C.c_int64(0)
-        call("bxmi_ivl_bitmap_state", self._h, C.byref(st), C.byref(hc))
-        return st.value, hc.value
-
     def slice_state(self):
         """(state, unit_keys[7]) of the slice search stage: 1 = usable, -1 = a bucket's keys do not fit the LDS, 0 = undecided."""
         self._ready()

@@ -14,36 +14,23 @@
 //                            bucket offsets.  No global histogram, no prefix over tiles, every byte coalesced;
 //   2. bm_transpose_kernel,  the (tile, bucket) run table turned bucket-major, and a plan that cuts every bucket's
 //      bm_plan_kernel        tiles into work items of ~64 Ki queries (one item per bucket on uniform input);
-//   3. bm_search_kernel      one workgroup per item.  The bucket's slice of the index sits in LDS as a BITMAP: one
-//                            8-byte cell per 32 coordinates = {bitmap of occupied coordinates, rank of the cell's first
-//                            key : 20, one duplicate descriptor : 12}.  A rank is ONE ds_read_b64, a mask, a popcount
-//                            and an add -- no search at all.  The workgroup walks the tiles, 8 lanes per (tile, bucket)
-//                            run (16 per run of a bucket PAIR: bm_search_pipe_kernel, the default), and leaves the
-//                            32-bit counts where it found the records;
+//   3. the search            one of the stages of count_dense.hpp / count_slices.hpp: a workgroup keeps a UNIT (2^f neighbouring
+//                            buckets) of the index in LDS -- cell images (a rank is ONE ds_read_b64, a mask, a popcount and an
+//                            add), dense images or staged key slices -- walks the unit's runs through the tiles and leaves the
+//                            counts beside the records;
 //   4. bm_unpermute_kernel   per tile: counts pulled through the 16-bit slots back into query order, escapes recomputed.
-// HBM bytes per query: 8 (queries) + 4 + 4 (records out and in) + 2 + 2 (slots) + 4 + 4 (counts, in place) + 4 (result) = 32, plus
-// the images (151 MB per pass) and the tables (75 MB).
-// count_slices.hpp holds a second search stage on the same exchange (sorted key slices instead of images: sparse
-// indexes, wide spans) and the two kernels that turn the pass into find().
-//
-// A cell holds exact multiplicities only when at most one of its 32 coordinates carries duplicates (<= 126 extra copies);
-// other cells are "hard": their rank is finished by a short binary search in the sorted array between the cell's and the
-// next cell's base.  bm_image_kernel counts the hard cells while it builds the images (once per sealed index) and the
-// host keeps the first-generation path for indexes where they are not rare (heavily duplicated coordinates), for spans
-// wider than 2^28 (a bucket's image must fit half a CU's LDS) and for indexes with reversed targets.
+// HBM bytes per query with cell images and 8-bit counts: 8 (queries) + 4 + 4 (records out and in) + 2 + 2 (slots) + 1 + 1 (counts)
+// + 4 (result) = 26, plus the padding of the runs (4.4 %), the images (129 MB per pass) and the tables.
+// count_slices.hpp also holds the two kernels that turn the pass into find().
 #pragma once
 
 namespace bxmi {
 
 constexpr int BM_NB = PT_NB;             // coordinate buckets (the grid of the first-generation path: same geometry)
-constexpr int BM_MARGIN = 32768;         // the starts' cells reach this far past the bucket: every record's qe is covered
-constexpr unsigned BM_LEN_ESC = 0x7FFFu;  // length field of an escape record (17-bit offsets: the image format)
 constexpr unsigned BM_REC_ESC = 0xFFFFFFFFu;
-constexpr int BM_MAX_SHIFT = 17;         // bucket width <= 131072 coordinates: (4098 + 5121) cells = 72 KiB of LDS
 constexpr int BM_MIN_SHIFT = 5;          // at least one whole cell per bucket
 constexpr int BM_GROUP_TILES = 64;       // tiles per plan group (granularity of work-item boundaries)
 constexpr int BM_CHUNK = 65536;          // queries per search work item (soft: a single group is never split)
-constexpr int BM_SEARCH_THREADS = 1024;
 constexpr int BM_HARD = 127;             // duplicate descriptor value of a hard cell
 constexpr int BM_LONG_CAP = 480;         // long runs a search workgroup remembers for its cooperative finish
 
@@ -64,10 +51,6 @@ struct BmGeom {
 
 __device__ __forceinline__ unsigned bm_len_esc(const BmGeom &g) { return (1u << (32 - g.rshift)) - 1u; }
 
-struct BmBucket {
-    int32_t eLo;  // #{ends   < bucket's first coordinate}
-    int32_t sLo;  // #{starts < bucket's first coordinate}
-};
 
 // One batch may cover several sealed indexes at once (a genome: one index per chromosome, bxmi_ivl_count_multi_dev):
 // every index with its queries is a SEGMENT.  Tiles are numbered across the whole batch, a segment owns a range of
@@ -80,10 +63,8 @@ struct BmSeg {
     int64_t nq;
     int64_t tile0, ntiles;    // first tile of the segment in the batch's numbering, tiles that hold queries
     int64_t tile_end;         // first tile of the next segment (tile0 + ntiles rounded up to a plan group)
-    const uint2 *images;
     const unsigned char *dimages;  // dense stage: the index's unit images (count_dense.hpp)
     const unsigned char *pimages;  // flat walk on cell images: the index's unit images (count_dense.hpp, bp_*)
-    const BmBucket *bmeta;
     const int4 *smeta;        // slice pass: ranks at every bucket boundary (SlMeta, count_slices.hpp)
     IndexDev ix;              // the sealed index (escapes, hard cells)
     const int32_t *e_sorted;
@@ -168,91 +149,6 @@ __device__ __forceinline__ int bm_rank_lt64(const int32_t *__restrict__ a, int n
     return l;
 }
 
-// ---------------------------------------------------------------------------
-// images: built once per sealed index
-// ---------------------------------------------------------------------------
-// One workgroup per bucket, one array at a time.  Key r of the slice sets bit (rel & 31) of cell (rel >> 5) when it is
-// the first of its coordinate and bumps the cell's duplicate bookkeeping otherwise; `first` of a non-empty cell is the
-// slice rank of its first key, empty cells inherit the next non-empty cell's (a suffix minimum), so that
-// base[c] = #{slice keys below cell c} for every c, the sentinel included.
-__global__ __launch_bounds__(1024) void bm_image_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted, int n,
-                                                        BmGeom g, uint2 *__restrict__ images, BmBucket *__restrict__ bmeta,
-                                                        unsigned *__restrict__ stats /* [0] hard cells, [1] slices too long */)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    __shared__ int s_r[2];
-    __shared__ int scan_tmp[16];
-    const int b = blockIdx.x;
-    const long long W = 1ll << g.shift;
-    const long long lo = (long long)g.cmin + (long long)b * W;
-    int r0s[2];
-    for (int arr = 0; arr < 2; arr++) {
-        const int32_t *__restrict__ A = arr == 0 ? e_sorted : s_ord;
-        const int nc = arr == 0 ? g.nce : g.ncs;
-        const long long span = arr == 0 ? W + 1 : W + BM_MARGIN;  // keys with rel in [0, span) belong to this image
-        unsigned *bm = reinterpret_cast<unsigned *>(dyn);
-        int *first = dyn + nc, *dcnt = dyn + 2 * nc, *dmin = dyn + 3 * nc, *dmax = dyn + 4 * nc;
-        if (threadIdx.x < 2) s_r[threadIdx.x] = bm_rank_lt64(A, n, threadIdx.x == 0 ? lo : lo + span);
-        __syncthreads();
-        const int r0 = s_r[0], r1 = s_r[1], ns = r1 - r0;
-        r0s[arr] = r0;
-        for (int c = threadIdx.x; c < nc; c += 1024) {
-            bm[c] = 0;
-            first[c] = ns;
-            dcnt[c] = 0;
-            dmin[c] = 32;
-            dmax[c] = -1;
-        }
-        __syncthreads();
-        for (int r = r0 + (int)threadIdx.x; r < r1; r += 1024) {
-            const int k = A[r];
-            const unsigned rel = (unsigned)((long long)k - lo);
-            const int c = (int)(rel >> 5), p = (int)(rel & 31);
-            if (r == r0 || A[r - 1] != k) {
-                atomicOr(&bm[c], 1u << p);
-                atomicMin(&first[c], r - r0);
-            } else {
-                atomicAdd(&dcnt[c], 1);
-                atomicMin(&dmin[c], p);
-                atomicMax(&dmax[c], p);
-            }
-        }
-        __syncthreads();
-        // suffix minimum of `first`: thread t owns chunk 1023 - t, so an exclusive scan in thread order covers the higher chunks
-        const int K = (nc + 1023) >> 10;
-        const int chunk = 1023 - (int)threadIdx.x;
-        const int c_lo = chunk * K, c_hi = c_lo + K < nc ? c_lo + K : nc;
-        int run = INT_MAX;
-        for (int c = c_hi - 1; c >= c_lo; c--) {
-            run = first[c] < run ? first[c] : run;
-            first[c] = run;
-        }
-        int tot;
-        const int above = block_exclusive_scan(run, OpMin(), INT_MAX, scan_tmp, &tot);
-        unsigned hard = 0;
-        uint2 *out = images + (size_t)b * g.stride + (arr == 0 ? 0 : g.nce);
-        for (int c = c_lo; c < c_hi; c++) {
-            const int base = first[c] < above ? first[c] : above;
-            unsigned meta = (unsigned)base & 0xFFFFFu;
-            if (dcnt[c] > 0) {
-                if (dmin[c] == dmax[c] && dcnt[c] < BM_HARD)
-                    meta |= ((unsigned)dmin[c] << 20) | ((unsigned)dcnt[c] << 25);
-                else {
-                    meta |= (unsigned)BM_HARD << 25;
-                    hard++;
-                }
-            }
-            out[c] = make_uint2(bm[c], meta);
-        }
-        if (hard) atomicAdd(&stats[0], hard);
-        if (threadIdx.x == 0 && ns >= (1 << 20)) atomicAdd(&stats[1], 1u);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) bmeta[b] = BmBucket{r0s[0], r0s[1]};
-}
-
-// ---------------------------------------------------------------------------
-// pass 0: is the batch already sorted by start?
 // ---------------------------------------------------------------------------
 // BED files usually arrive sorted, and a sorted batch needs no exchange at all (ivl_local_count_kernel answers it as it
 // lies).  Every kernel of this pass reads the flag this one leaves: 1 = a descent was seen, go on; 0 = sorted, stand
@@ -627,18 +523,6 @@ __global__ __launch_bounds__(BM_PLAN_THREADS) void bm_plan_kernel(const unsigned
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) const unsigned long long *lds_cell_p;  // a cell: bitmap in the low word, meta in the high word
 
-// #{keys of the slice below coordinate lo + rel}, from one cell; `odd` collects "this cell is hard".
-__device__ __forceinline__ int bm_cell_rank(lds_cell_p cells, unsigned rel, bool &odd)
-{
-    const unsigned long long c = cells[rel >> 5];
-    const unsigned bits = (unsigned)c, meta = (unsigned)(c >> 32);
-    const unsigned mask = (1u << (rel & 31u)) - 1u;  // the coordinates of the cell below rel
-    const unsigned extra = meta >> 25;
-    odd |= extra == (unsigned)BM_HARD;
-    // the duplicated coordinate counts `extra` more times when it lies below rel: bit dpos of the mask says so
-    return (int)(meta & 0xFFFFFu) + __popc(bits & mask) + (int)(extra * ((mask >> ((meta >> 20) & 31u)) & 1u));
-}
-
 __device__ __forceinline__ int bm_hard_rank(lds_cell_p cells, unsigned rel, const int32_t *__restrict__ a, int slice_lo, long long lo)
 {
     const unsigned c = rel >> 5;
@@ -648,195 +532,9 @@ __device__ __forceinline__ int bm_hard_rank(lds_cell_p cells, unsigned rel, cons
     return global_rank_lt(a, r0, r1, (int)key) - slice_lo;
 }
 
-// The count of one record (BM_REC_ESC = "ask the index again").  The common case is two LDS reads and ~30 VALU
-// instructions; a hard cell or an escape record is noticed by one flag and redone off the fast path.
-__device__ __forceinline__ unsigned bm_count_record(lds_cell_p cE, lds_cell_p cS, int eLo, int sLo, long long lo, unsigned rec,
-                                                    const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted)
-{
-    const bool esc = (rec >> 17) == BM_LEN_ESC;
-    rec = esc ? (1u << 17) : rec;  // keep the lookups of an escape record inside the image
-    const unsigned off = rec & 0x1FFFFu, len = rec >> 17;
-    const unsigned relE = off + 1u, relS = off + len;
-    bool odd = esc;
-    const int rE = bm_cell_rank(cE, relE, odd);
-    const int rS = bm_cell_rank(cS, relS, odd);
-    unsigned c = (unsigned)((sLo - eLo) + (rS - rE));
-    if (odd) {
-        if (esc) {
-            c = BM_REC_ESC;
-        } else {
-            bool e_hard = false, s_hard = false;
-            int hE = bm_cell_rank(cE, relE, e_hard), hS = bm_cell_rank(cS, relS, s_hard);
-            if (e_hard) hE = bm_hard_rank(cE, relE, e_sorted, eLo, lo);
-            if (s_hard) hS = bm_hard_rank(cS, relS, s_ord, sLo, lo);
-            c = (unsigned)((sLo - eLo) + (hS - hE));
-        }
-    }
-    return c;
-}
-
-// One workgroup per work item = one bucket (PAIR: two neighbouring buckets, both images in LDS, one workgroup per CU)
-// and a range of tiles.  L lanes (8, PAIR: 16) take one (tile, bucket) run -- the records of the item's bucket(s) in
-// that tile, contiguous in the tile-sorted array, ~8 (16) of them on shuffled input: the first L records in one pass per
-// run, what is left of the group's U runs flattened into shared passes, runs longer than 4 L left to the whole workgroup
-// at the end.  The count of a record is written over the record (the line is in L2 from the read: a separate array of
-// counts measured 2.8x write amplification, partial lines going out as 64-byte pieces).
-// EXP (diagnostics, ivl.bm_exp): 0 = the real thing; 1 = no count stores, 2 = no record loads, 3 = neither (results are
-// wrong then: the timing matrix of tools/bm_perf.py uses them to price the pieces of this kernel).
-template <bool PAIR, int U /* tile runs in flight per lane group */, int EXP = 0>
-__global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
-                                                                      const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
-                                                                      unsigned *__restrict__ recs /* records in, counts out */, int tile_log2,
-                                                                      const unsigned *__restrict__ gate)
-{
-    constexpr int L = PAIR ? 16 : 8;
-    if (gate && *gate == 0) return;
-    constexpr int NG = BM_SEARCH_THREADS / L;
-    constexpr unsigned LONG_RUN = 4 * L;  // longer runs go to the cooperative finish
-    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    __shared__ uint2 s_long[BM_LONG_CAP];  // {first record, length} of the long runs met during the walk
-    __shared__ int s_nlong;
-    // Work item of this workgroup, XCD-aware: workgroup w runs on XCD w % 8 (observed dispatch order, speed only); giving
-    // every XCD a contiguous range of items (= of buckets) lets the runs of neighbouring buckets, which share 128-byte
-    // lines of the tile-sorted array, meet in one L2.
-    const int nit = *n_items;
-    const int per_xcd = (nit + 7) >> 3;
-    const int slot = (int)(blockIdx.x >> 3);
-    const int it = (int)(blockIdx.x & 7) * per_xcd + slot;
-    if (slot >= per_xcd || it >= nit) return;
-    const int4 item = items[it];
-    const int b = item.x & 0xffff, t0 = item.y, t1 = item.z;
-    const BmSeg &sg = segs[item.x >> 16];
-    const BmGeom g = sg.g;
-    const uint2 *__restrict__ images = sg.images;
-    const BmBucket *__restrict__ bmeta = sg.bmeta;
-    const int32_t *__restrict__ s_ord = sg.ix.s_ord, *__restrict__ e_sorted = sg.e_sorted;
-    const unsigned *__restrict__ runs0 = runT + (int64_t)b * ntp;
-    const unsigned *__restrict__ runs1 = runs0 + ntp;  // PAIR only
-    const int gid = threadIdx.x / L, sub = threadIdx.x % L;
-    unsigned run[U], run2[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {  // the first round's runs travel with the image
-        const int t = t0 + u * NG + gid;
-        run[u] = t < t1 ? runs0[t] : 0u;
-        run2[u] = PAIR && t < t1 ? runs1[t] : 0u;
-    }
-    {
-        // the image(s): every load of a lane issued before its first LDS store
-        const int4 *src = reinterpret_cast<const int4 *>(images + (size_t)b * g.stride);
-        const int n4 = (PAIR ? 2 : 1) * (g.stride >> 1);
-        constexpr int SWEEPS = 5;
-        for (int i0 = 0; i0 < n4; i0 += SWEEPS * BM_SEARCH_THREADS) {
-            int4 v[SWEEPS];
-#pragma unroll
-            for (int k = 0; k < SWEEPS; k++) {
-                const int i = i0 + k * BM_SEARCH_THREADS + (int)threadIdx.x;
-                v[k] = src[i < n4 ? i : n4 - 1];  // (a valid address: no branch around the load)
-            }
-#pragma unroll
-            for (int k = 0; k < SWEEPS; k++) {
-                const int i = i0 + k * BM_SEARCH_THREADS + (int)threadIdx.x;
-                if (i < n4) reinterpret_cast<int4 *>(dyn)[i] = v[k];
-            }
-        }
-    }
-    // the item's bucket b and, PAIR, its neighbour b + 1: cell arrays in LDS, ranks and coordinate of the first position
-    const lds_cell_p cE0 = (lds_cell_p) reinterpret_cast<unsigned long long *>(dyn), cS0 = cE0 + g.nce;
-    const int cells1 = PAIR ? g.stride : 0;  // the neighbour's image follows at this many cells
-    const BmBucket bk0 = bmeta[b], bk1 = bmeta[PAIR ? b + 1 : b];
-    const long long lo0 = (long long)g.cmin + ((long long)b << g.shift), lo1 = lo0 + (PAIR ? (long long)1 << g.shift : 0ll);
-    if (threadIdx.x == 0) s_nlong = 0;
-    __syncthreads();
-    unsigned sink = 0;
-    // one record: position p of a run that starts at record `first` and whose first `len0` records belong to bucket b
-    auto answer = [&](unsigned first, unsigned p, unsigned len0, unsigned rec) {
-        const bool second = PAIR && p >= len0;
-        const int shift_cells = second ? cells1 : 0;
-        const unsigned c = (EXP & 4) ? rec + (unsigned)shift_cells  // diagnostics: the memory traffic alone
-                                     : bm_count_record(cE0 + shift_cells, cS0 + shift_cells, second ? bk1.eLo : bk0.eLo, second ? bk1.sLo : bk0.sLo,
-                                                       second ? lo1 : lo0, rec, s_ord, e_sorted);
-        if (EXP & 1)
-            sink += c;
-        else
-            recs[(size_t)first + p] = c;
-    };
-    for (int tb = t0; tb < t1; tb += NG * U) {
-        unsigned first[U], len0[U], len[U], rec[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = tb + u * NG + gid;
-            first[u] = ((unsigned)t << tile_log2) + (run[u] & 0xffffu);  // (record indices stay below 2^32: nq < 2^31)
-            len0[u] = run[u] >> 16;
-            len[u] = len0[u] + (PAIR ? run2[u] >> 16 : 0u);
-            if (EXP & 2)
-                rec[u] = run[u] & 0xfff1ffffu;  // anything valid: short, never an escape
-            else
-                rec[u] = (unsigned)sub < len[u] ? recs[(size_t)first[u] + sub] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {  // the next round's runs, in flight while this round computes
-            const int t = tb + NG * U + u * NG + gid;
-            run[u] = t < t1 ? runs0[t] : 0u;
-            run2[u] = PAIR && t < t1 ? runs1[t] : 0u;
-        }
-        // what the first pass leaves over, flattened across the group's U runs: c[u] = leftovers of runs < u
-        unsigned cum[U + 1];
-        cum[0] = 0;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            unsigned rem = len[u] > (unsigned)L ? len[u] - (unsigned)L : 0u;
-            if (len[u] > LONG_RUN) {
-                // rare on shuffled input, the rule on sorted or clumped input: a sorted batch is a handful of runs of
-                // thousands of records per bucket, and the group that met one would otherwise work alone
-                bool listed = false;
-                if (sub == 0) {
-                    const int k = atomicAdd(&s_nlong, 1);
-                    if (k < BM_LONG_CAP) {
-                        s_long[k] = make_uint2(first[u], len[u] | (len0[u] << 16));
-                        listed = true;
-                    }
-                }
-                listed = __shfl(listed, (int)(threadIdx.x & 63) - sub, 64);
-                if (listed) rem = 0;  // (a full list: the group works the run off itself, exactness never depends on it)
-            }
-            cum[u + 1] = cum[u] + rem;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if ((unsigned)sub < len[u]) answer(first[u], (unsigned)sub, len0[u], rec[u]);
-        for (unsigned base = 0; __any(base < cum[U]); base += L) {
-            const unsigned i = base + (unsigned)sub;
-            unsigned f = first[0], l0 = len0[0], lo_c = 0;
-#pragma unroll
-            for (int u = 1; u < U; u++) {
-                const bool ge = i >= cum[u];
-                f = ge ? first[u] : f;
-                l0 = ge ? len0[u] : l0;
-                lo_c = ge ? cum[u] : lo_c;
-            }
-            if (i < cum[U]) {
-                const unsigned p = (unsigned)L + (i - lo_c);
-                answer(f, p, l0, (EXP & 2) ? (f & 0xfff1ffffu) : recs[(size_t)f + p]);
-            }
-        }
-    }
-    __syncthreads();
-    {
-        const int nl = s_nlong < BM_LONG_CAP ? s_nlong : BM_LONG_CAP;
-        for (int k = 0; k < nl; k++) {
-            const uint2 e = s_long[k];
-            const unsigned ll = e.y & 0xffffu, l0 = e.y >> 16;  // (a run is at most a tile: 2^15 records)
-            for (unsigned p = (unsigned)L + threadIdx.x; p < ll; p += BM_SEARCH_THREADS) answer(e.x, p, l0, recs[(size_t)e.x + p]);
-        }
-    }
-    if ((EXP & 1) && sink == 0x12345678u) recs[0] = 1;  // keeps the work of the store-less variant alive
-}
-
-// The same walk, software-pipelined: a wave that loads, then computes, then stores leaves the memory pipe idle while
-// it computes and its SIMD idle while it waits -- with every wave slot of the CU taken (the images fill the LDS) the
-// kernel time was the SUM of the two (measured: compute 120 us + record loads 140 us + count stores 240 us).  Here
-// the records of round r + 1 are requested before round r is computed; all loads of a round, the first leftover pass
-// included, are issued together and without branches so that the waits can count instead of draining.
+// (Round 2's search kernels on images of single buckets / bucket pairs -- bm_search_kernel, bm_search_pipe_kernel -- lived here
+// until round 4: every index they served qualifies for the cell images of 2^18-coordinate units as well (count_dense.hpp,
+// bp_* / bw_*: the same 8-byte cells, runs twice as long), so no input selected them any more.)
 typedef int bm_v4i __attribute__((ext_vector_type(4)));
 
 template <int U>
@@ -850,169 +548,6 @@ struct BmRound {
     unsigned listed;    // bit u: run u is long and waits in the workgroup's list (its leftovers are not the group's)
     bool lf_second;     // that record belongs to the item's second bucket
 };
-
-template <bool PAIR, int U, bool NT /* image loads non-temporal: they stream through L2 once */>
-__global__ __launch_bounds__(BM_SEARCH_THREADS) void bm_search_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
-                                                                           const int *__restrict__ n_items, const unsigned *__restrict__ runT,
-                                                                           int64_t ntp, unsigned *__restrict__ recs /* records in, counts out */,
-                                                                           int tile_log2, const unsigned *__restrict__ gate)
-{
-    constexpr int L = PAIR ? 16 : 8;
-    if (gate && *gate == 0) return;
-    constexpr int NG = BM_SEARCH_THREADS / L;
-    constexpr unsigned LONG_RUN = 4 * L;
-    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    __shared__ uint2 s_long[BM_LONG_CAP];
-    __shared__ int s_nlong;
-    const int nit = *n_items;
-    const int per_xcd = (nit + 7) >> 3;
-    const int slot = (int)(blockIdx.x >> 3);
-    const int it = (int)(blockIdx.x & 7) * per_xcd + slot;
-    if (slot >= per_xcd || it >= nit) return;
-    const int4 item = items[it];
-    const int b = item.x & 0xffff, t0 = item.y, t1 = item.z;
-    const BmSeg &sg = segs[item.x >> 16];
-    const BmGeom g = sg.g;
-    const uint2 *__restrict__ images = sg.images;
-    const BmBucket *__restrict__ bmeta = sg.bmeta;
-    const int32_t *__restrict__ s_ord = sg.ix.s_ord, *__restrict__ e_sorted = sg.e_sorted;
-    const unsigned *__restrict__ runs0 = runT + (int64_t)b * ntp;
-    const unsigned *__restrict__ runs1 = runs0 + ntp;  // PAIR only
-    const int gid = threadIdx.x / L, sub = threadIdx.x % L;
-    unsigned run[U], run2[U];
-    auto load_runs = [&](int tb) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = tb + u * NG + gid;
-            const int tc = t < t1 ? t : t0;  // a valid address: no branch around the load
-            const unsigned a = runs0[tc], c = PAIR ? runs1[tc] : 0u;
-            run[u] = t < t1 ? a : 0u;
-            run2[u] = t < t1 ? c : 0u;
-        }
-    };
-    load_runs(t0);
-    {
-        const int4 *src = reinterpret_cast<const int4 *>(images + (size_t)b * g.stride);
-        const int n4 = (PAIR ? 2 : 1) * (g.stride >> 1);
-        constexpr int SWEEPS = 5;
-        for (int i0 = 0; i0 < n4; i0 += SWEEPS * BM_SEARCH_THREADS) {
-            int4 v[SWEEPS];
-#pragma unroll
-            for (int k = 0; k < SWEEPS; k++) {
-                const int i = i0 + k * BM_SEARCH_THREADS + (int)threadIdx.x;
-                if (NT) {
-                    const bm_v4i w = __builtin_nontemporal_load(reinterpret_cast<const bm_v4i *>(src) + (i < n4 ? i : n4 - 1));
-                    v[k] = make_int4(w.x, w.y, w.z, w.w);
-                } else {
-                    v[k] = src[i < n4 ? i : n4 - 1];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < SWEEPS; k++) {
-                const int i = i0 + k * BM_SEARCH_THREADS + (int)threadIdx.x;
-                if (i < n4) reinterpret_cast<int4 *>(dyn)[i] = v[k];
-            }
-        }
-    }
-    const lds_cell_p cE0 = (lds_cell_p) reinterpret_cast<unsigned long long *>(dyn), cS0 = cE0 + g.nce;
-    const int cells1 = PAIR ? g.stride : 0;
-    const BmBucket bk0 = bmeta[b], bk1 = bmeta[PAIR ? b + 1 : b];
-    const long long lo0 = (long long)g.cmin + ((long long)b << g.shift), lo1 = lo0 + (PAIR ? (long long)1 << g.shift : 0ll);
-    if (threadIdx.x == 0) s_nlong = 0;
-    __syncthreads();
-    auto answer = [&](unsigned at, bool second, unsigned rec) {
-        const int shift_cells = second ? cells1 : 0;
-        recs[(size_t)at] = bm_count_record(cE0 + shift_cells, cS0 + shift_cells, second ? bk1.eLo : bk0.eLo, second ? bk1.sLo : bk0.sLo,
-                                           second ? lo1 : lo0, rec, s_ord, e_sorted);
-    };
-    // round `tb`: addresses from the runs in run[] / run2[], every load of the round issued
-    auto prep = [&](BmRound<U> &R, int tb) {
-        unsigned cum = 0, lf_at = ~0u, listed_mask = 0;
-        bool lf_second = false;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = tb + u * NG + gid;
-            const unsigned first = ((unsigned)t << tile_log2) + (run[u] & 0xffffu);
-            const unsigned len0 = run[u] >> 16, len = len0 + (PAIR ? run2[u] >> 16 : 0u);
-            R.first[u] = first;
-            R.lens[u] = len0 | (len << 16);
-            R.rec[u] = recs[(size_t)((unsigned)sub < len ? first + (unsigned)sub : 0u)];
-            unsigned rem = len > (unsigned)L ? len - (unsigned)L : 0u;
-            if (len > LONG_RUN) {  // left to the whole workgroup (see bm_search_kernel)
-                bool listed = false;
-                if (sub == 0) {
-                    const int k = atomicAdd(&s_nlong, 1);
-                    if (k < BM_LONG_CAP) {
-                        s_long[k] = make_uint2(first, len | (len0 << 16));
-                        listed = true;
-                    }
-                }
-                listed = __shfl(listed, (int)(threadIdx.x & 63) - sub, 64);
-                if (listed) {
-                    rem = 0;
-                    listed_mask |= 1u << u;
-                }
-            }
-            const unsigned i = (unsigned)sub - cum;  // position among this run's leftovers, if it is this lane's turn
-            if ((unsigned)sub >= cum && i < rem) {
-                lf_at = first + (unsigned)L + i;
-                lf_second = PAIR && (unsigned)L + i >= len0;
-            }
-            cum += rem;
-        }
-        R.lf_total = cum;
-        R.listed = listed_mask;
-        R.lf_at = lf_at;
-        R.lf_second = lf_second;
-        R.lf_rec = recs[(size_t)(lf_at != ~0u ? lf_at : 0u)];
-    };
-    auto finish = [&](BmRound<U> &R) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const unsigned len0 = R.lens[u] & 0xffffu, len = R.lens[u] >> 16;
-            if ((unsigned)sub < len) answer(R.first[u] + (unsigned)sub, PAIR && (unsigned)sub >= len0, R.rec[u]);
-        }
-        if (R.lf_at != ~0u) answer(R.lf_at, R.lf_second, R.lf_rec);
-        for (unsigned base = L; __any(base < R.lf_total); base += L) {  // further leftover passes: rare
-            const unsigned i = base + (unsigned)sub;
-            unsigned cum = 0, at = ~0u;
-            bool second = false;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const unsigned len0 = R.lens[u] & 0xffffu, len = R.lens[u] >> 16;
-                const unsigned rem = len > (unsigned)L && !((R.listed >> u) & 1u) ? len - (unsigned)L : 0u;
-                const unsigned j = i - cum;
-                if (i >= cum && j < rem) {
-                    at = R.first[u] + (unsigned)L + j;
-                    second = PAIR && (unsigned)L + j >= len0;
-                }
-                cum += rem;
-            }
-            if (at != ~0u) answer(at, second, recs[(size_t)at]);
-        }
-    };
-    BmRound<U> A, B;
-    prep(A, t0);
-    load_runs(t0 + NG * U);
-    for (int tb = t0; tb < t1; tb += 2 * NG * U) {
-        prep(B, tb + NG * U);
-        load_runs(tb + 2 * NG * U);
-        finish(A);
-        prep(A, tb + 2 * NG * U);
-        load_runs(tb + 3 * NG * U);
-        finish(B);
-    }
-    __syncthreads();
-    {
-        const int nl = s_nlong < BM_LONG_CAP ? s_nlong : BM_LONG_CAP;
-        for (int k = 0; k < nl; k++) {
-            const uint2 e = s_long[k];
-            const unsigned ll = e.y & 0xffffu, l0 = e.y >> 16;
-            for (unsigned p = (unsigned)L + threadIdx.x; p < ll; p += BM_SEARCH_THREADS)
-                answer(e.x + p, PAIR && p >= l0, recs[(size_t)e.x + p]);
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------
 // pass 4: counts back into query order

@@ -2129,11 +2129,6 @@ static int64_t g_opt_find_fill = 0;    // bucketed find: 0 = hits written from b
 static int64_t g_opt_bitmap = -1;      // second-generation count pass (count_bitmap.hpp): -1 = when the index qualifies, 0 = never, 1 = same as -1
 static int64_t g_opt_bitmap_min = 2 << 20;  // auto: batches of at least this many queries take it (when the index qualifies)
 static int64_t g_opt_bm_variant = -1;  // tile kernel shape: -1 = by batch size, 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
-static int64_t g_opt_bm_u = 2;         // tile runs in flight per 8-lane group of the search kernel (2, 4 or 8)
-static int64_t g_opt_bm_pair = 1;      // 1 = a search workgroup holds two neighbouring buckets (one workgroup per CU, runs twice as long)
-static int64_t g_opt_bm_nt = 1;        // 1 = non-temporal image loads in the pipelined search kernel (also the variant without scratch: 3.5 % faster on configs[1])
-static int64_t g_opt_bm_pipe = 1;      // 1 = the software-pipelined search kernel
-static int64_t g_opt_bm_exp = 0;       // diagnostics only (wrong results): price the pieces of the search kernel, see count_bitmap.hpp
 static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
 static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by run length and LDS, else forced (tests)
@@ -2187,11 +2182,6 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.bitmap_min", &g_opt_bitmap_min, nullptr},
     {"ivl.bitmap", &g_opt_bitmap, nullptr},
     {"ivl.bm_variant", &g_opt_bm_variant, [](int64_t value) -> int64_t { return value < 0 || value > 2 ? -1 : value; }},
-    {"ivl.bm_u", &g_opt_bm_u, [](int64_t value) -> int64_t { return value == 4 || value == 8 ? value : 2; }},
-    {"ivl.bm_pair", &g_opt_bm_pair, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.bm_nt", &g_opt_bm_nt, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.bm_pipe", &g_opt_bm_pipe, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.bm_exp", &g_opt_bm_exp, nullptr},
     {"ivl.find_sliced", &g_opt_find_sliced, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.slice", &g_opt_slice, nullptr},
     {"ivl.sl_f", &g_opt_sl_f, [](int64_t value) -> int64_t { return value > SL_MAX_F ? SL_MAX_F : value; }},
@@ -2268,10 +2258,7 @@ struct bxmi_ivl {
     DevBuf slice_bounds, cell_images, cell_meta, p_hist, p_table, p_pairs, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
     // second-generation count pass (count_bitmap.hpp)
     int32_t cmax = 0;            // largest end of the sealed index
-    int bm_state = 0;            // 0 = not decided yet, 1 = images built and the index qualifies, -1 = it does not
-    int64_t bm_hard_cells = 0;   // what bm_image_kernel reported
-    BmGeom bm_geom{0, 0, 0, 0, 0, 0, 0, 17, 0};
-    DevBuf bm_images, bm_meta, bm_stats, bm_recs, bm_slots, bm_tbl, bm_runT, bm_grpcnt, bm_items, bm_params;
+    DevBuf bm_recs, bm_slots, bm_tbl, bm_runT, bm_grpcnt, bm_items, bm_params;
     // slice search (count_slices.hpp)
     int sl_state = 0;            // 0 = not decided yet, 1 = boundary table built and a single bucket's keys fit the LDS, -1 = they do not
     unsigned sl_need[SL_MAX_F + 1] = {0, 0, 0, 0, 0, 0, 0};  // most keys a unit of 2^f buckets stages
@@ -2550,42 +2537,7 @@ static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *q
     return BXMI_OK;
 }
 
-// ---- second-generation count pass (count_bitmap.hpp) ----
-// Decide once per sealed index whether it qualifies, and build the bucket images if it does.
-static int bm_prepare_index(bxmi_ivl *h, hipStream_t st)
-{
-    h->bm_state = -1;
-    const int shift = h->geom.shift;
-    if (h->has_reversed || h->n < 4096 || shift > BM_MAX_SHIFT || shift < BM_MIN_SHIFT) return BXMI_OK;
-    const int64_t W = (int64_t)1 << shift;
-    BmGeom g;
-    g.cmin = h->geom.cmin;
-    g.cmax = h->cmax;
-    g.shift = shift;
-    g.nce = (int32_t)(W >> 5) + 2;
-    g.ncs = (int32_t)((W + BM_MARGIN) >> 5) + 1;
-    g.stride = (g.nce + g.ncs + 1) & ~1;
-    g.f = 0, g.rshift = 17, g.dshift = 0;
-    BXMI_TRY(h->bm_images.reserve((size_t)BM_NB * g.stride * sizeof(uint2)));
-    BXMI_TRY(h->bm_meta.reserve(BM_NB * sizeof(BmBucket)));
-    BXMI_TRY(h->bm_stats.reserve(64));
-    BXMI_HIP(hipMemsetAsync(h->bm_stats.p, 0, 64, st));
-    const size_t lds = (size_t)5 * g.ncs * sizeof(int32_t);
-    BXMI_TRY(allow_big_lds(bm_image_kernel, lds));
-    hipLaunchKernelGGL(bm_image_kernel, dim3(BM_NB), dim3(1024), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n, g,
-                       h->bm_images.as<uint2>(), h->bm_meta.as<BmBucket>(), h->bm_stats.as<unsigned>());
-    BXMI_LAUNCH_CHECK();
-    unsigned stats[2] = {0, 0};
-    BXMI_HIP(hipMemcpyAsync(stats, h->bm_stats.p, sizeof(stats), hipMemcpyDeviceToHost, st));
-    BXMI_HIP(hipStreamSynchronize(st));
-    h->bm_geom = g;
-    h->bm_hard_cells = stats[0];
-    // cells that queries can land in: the span of the index, twice (ends and starts)
-    const int64_t cells = 2 * ((((int64_t)h->cmax - (int64_t)h->geom.cmin) >> 5) + 1);
-    if (stats[1] == 0 && (int64_t)stats[0] * 1000000 <= cells * g_opt_bm_hard_ppm) h->bm_state = 1;
-    return BXMI_OK;
-}
-
+// ---- the large-batch count pass (count_bitmap.hpp: tile sort, run table, plan, un-permute; its search stages in count_dense.hpp / count_slices.hpp) ----
 // Cell images of 2^18-coordinate units for the flat walk (count_dense.hpp, bp_*): built once per sealed index.
 static int bp_prepare_index(bxmi_ivl *h, hipStream_t st)
 {
@@ -2759,52 +2711,6 @@ static int bm_launch_tiles(const BmLaunch &L, hipStream_t st)
     }
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
-}
-
-template <bool PAIR, int U, int EXP = 0>
-static int bm_launch_search(const BmLaunch &L, unsigned grid, hipStream_t st)
-{
-    bxmi_ivl *h = L.owner;
-    BXMI_TRY(allow_big_lds((bm_search_kernel<PAIR, U, EXP>), L.search_lds));
-    hipLaunchKernelGGL((bm_search_kernel<PAIR, U, EXP>), dim3(grid), dim3(BM_SEARCH_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
-                       h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), L.tile_log2, L.gate);
-    BXMI_LAUNCH_CHECK();
-    return BXMI_OK;
-}
-
-template <bool PAIR, int U, bool NT>
-static int bm_launch_search_pipe(const BmLaunch &L, unsigned grid, hipStream_t st)
-{
-    bxmi_ivl *h = L.owner;
-    BXMI_TRY(allow_big_lds((bm_search_pipe_kernel<PAIR, U, NT>), L.search_lds));
-    hipLaunchKernelGGL((bm_search_pipe_kernel<PAIR, U, NT>), dim3(grid), dim3(BM_SEARCH_THREADS), L.search_lds, st, L.segs,
-                       h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), L.tile_log2,
-                       L.gate);
-    BXMI_LAUNCH_CHECK();
-    return BXMI_OK;
-}
-
-template <bool PAIR>
-static int bm_launch_search_u(const BmLaunch &L, unsigned grid, hipStream_t st)
-{
-    if (g_opt_bm_pipe && g_opt_bm_exp == 0) {
-        if (g_opt_bm_nt) {
-            if (g_opt_bm_u == 2) return bm_launch_search_pipe<PAIR, 2, true>(L, grid, st);
-            return bm_launch_search_pipe<PAIR, 4, true>(L, grid, st);
-        }
-        if (g_opt_bm_u == 2) return bm_launch_search_pipe<PAIR, 2, false>(L, grid, st);
-        return bm_launch_search_pipe<PAIR, 4, false>(L, grid, st);
-    }
-    if (g_opt_bm_exp == 1) return bm_launch_search<PAIR, 4, 1>(L, grid, st);
-    if (g_opt_bm_exp == 2) return bm_launch_search<PAIR, 4, 2>(L, grid, st);
-    if (g_opt_bm_exp == 3) return bm_launch_search<PAIR, 4, 3>(L, grid, st);
-    if (g_opt_bm_exp == 4) return bm_launch_search<PAIR, 4, 4>(L, grid, st);
-    if (g_opt_bm_exp == 5) return bm_launch_search<PAIR, 4, 5>(L, grid, st);
-    if (g_opt_bm_exp == 6) return bm_launch_search<PAIR, 4, 6>(L, grid, st);
-    if (g_opt_bm_exp == 7) return bm_launch_search<PAIR, 4, 7>(L, grid, st);
-    if (g_opt_bm_u == 2) return bm_launch_search<PAIR, 2>(L, grid, st);
-    if (g_opt_bm_u == 8) return bm_launch_search<PAIR, 8>(L, grid, st);
-    return bm_launch_search<PAIR, 4>(L, grid, st);
 }
 
 template <int THREADS, int ITEMS>
@@ -3013,15 +2919,17 @@ static int ensure_feedback(bxmi_ivl *h, hipStream_t st)
     return BXMI_OK;
 }
 
-// `kind`: what a search workgroup keeps in LDS -- 1 = bucket images (count_bitmap.hpp), 2 = key slices
-// (count_slices.hpp), 3 = dense unit images, 4 = cell images of units (both count_dense.hpp: the flat walk, 16-bit
-// counts out of place); every index of the batch must have qualified for it.
+// `kind`: what a search workgroup keeps in LDS -- 2 = key slices (count_slices.hpp), 3 = dense unit images, 4 = cell images of
+// units (both count_dense.hpp: the flat walk, counts out of place); every index of the batch must have qualified for it.
+// (kind 1 -- images of single buckets / bucket pairs, round 2's search -- is gone: an index it served qualifies for the cell
+// images of units as well, so no input selected it any more.)
 static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
-                             int32_t *const *counts, int64_t *const *totals_dev, hipStream_t st, int kind = 1, BmFindCtx *fx = nullptr)
+                             int32_t *const *counts, int64_t *const *totals_dev, hipStream_t st, int kind, BmFindCtx *fx = nullptr)
 {
+    if (kind < 2 || kind > 4) return fail(BXMI_EINVAL, "bm_count_segments: no such search stage (%d)", kind);
     const bool slices = kind == 2, cells = kind == 4;
     const bool slices_flat = slices && !fx && g_opt_sl_flat != 0;  // (find() needs 32-bit counts apart from the records and the tile-sorted offsets)
-    const bool dense = kind == 3 || cells || slices_flat /* the flat walk */, units = slices || dense;
+    const bool dense = kind == 3 || cells || slices_flat /* the flat walk */;
     bxmi_ivl *h = hs[0];
     int64_t nq_all = 0;
     for (int i = 0; i < n; i++) nq_all += nq[i];
@@ -3049,19 +2957,15 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
             if (run_len < sl_run) sl_run = run_len;
         } else if (cells) {
             sg.g = hs[i]->bp_geom;
-        } else if (dense) {
-            sg.g = hs[i]->bd_geom;
         } else {
-            sg.g = hs[i]->bm_geom;
+            sg.g = hs[i]->bd_geom;
         }
         sg.qs = qs[i], sg.qe = qe[i], sg.counts = counts[i];
         sg.nq = nq[i];
         sg.tile0 = ntp;
         sg.ntiles = div_up(nq[i], tile);
-        sg.images = hs[i]->bm_images.as<uint2>();
         sg.dimages = hs[i]->bd_images.as<unsigned char>();
         sg.pimages = hs[i]->bp_images.as<unsigned char>();
-        sg.bmeta = hs[i]->bm_meta.as<BmBucket>();
         sg.smeta = slices ? hs[i]->sl_meta.as<int4>() : nullptr;
         sg.ix = index_dev(hs[i]);
         sg.e_sorted = hs[i]->e_sorted.as<int32_t>();
@@ -3073,8 +2977,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (ntp == 0) return BXMI_OK;
     const int ngroups = (int)(ntp / BM_GROUP_TILES);
     // PAIR: a search workgroup holds the images of two neighbouring buckets (needs both in one CU's LDS)
-    const bool pair = !units && g_opt_bm_pair != 0 && 2 * max_stride * sizeof(uint2) + 8192 <= 160 * 1024;
-    int chunk = dense ? (g_opt_bd_chunk ? (int)g_opt_bd_chunk : (cells || slices_flat ? 2 : 4) * BM_CHUNK) : g_opt_bm_chunk ? (int)g_opt_bm_chunk : (pair ? 2 * BM_CHUNK : BM_CHUNK);
+    int chunk = dense ? (g_opt_bd_chunk ? (int)g_opt_bd_chunk : (cells || slices_flat ? 2 : 4) * BM_CHUNK) : g_opt_bm_chunk ? (int)g_opt_bm_chunk : BM_CHUNK;
     // a small batch (one rank's share of a genome on eight GPUs: 13 M queries) cut into items of 128 Ki queries is a hundred
     // workgroups on 256 CUs (measured: search 154 us of a 255 us pass); items of nq / 512, at least a tile
     // (every item stages its unit's keys again: at 25 M queries, 192 items, the smaller items already cost more than
@@ -3083,7 +2986,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         const int64_t c = nq_all / 512;
         chunk = (int)(c < 16384 ? 16384 : c);
     }
-    int64_t max_items = (int64_t)n * ((pair ? BM_NB / 2 : BM_NB) + 2) + 2 * (nq_all / chunk) + 2;
+    int64_t max_items = (int64_t)n * (BM_NB + 2) + 2 * (nq_all / chunk) + 2;
     if (dense) {  // every segment has at most BM_NB >> f units; empty workgroups of 157 KB of LDS are not free
         // (the padded layout counts up to three more slots per tile and unit as "queries" of the unit)
         int64_t pad_slots = 0;
@@ -3103,7 +3006,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (!dense) BXMI_TRY(h->bm_runT.reserve((size_t)ntp * BM_NB * 4));
     if (dense) BXMI_TRY(h->bd_unitT.reserve((size_t)ntp * (BM_NB + 1) * 2));  // (+ the row behind the last unit)
     BXMI_TRY(h->bm_grpcnt.reserve((size_t)ngroups * BM_NB * 4));
-    if (units) BXMI_TRY(h->sl_unitcnt.reserve((size_t)ngroups * BM_NB * 4));
+    BXMI_TRY(h->sl_unitcnt.reserve((size_t)ngroups * BM_NB * 4));
     if (dense) BXMI_TRY(h->bd_cnt16.reserve((size_t)ntp * tile_stride * 2));
     BXMI_TRY(h->bm_items.reserve((size_t)(max_items + 2) * sizeof(int4)));  // [0] = the item count, items from [1]
     if (fx) {  // find(): counts apart from the records, and the tile-sorted offsets
@@ -3169,7 +3072,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.tile_seg = reinterpret_cast<const unsigned short *>(h->bm_params.as<unsigned char>() + tile_off);
     L.owner = h;
     L.ntp = ntp, L.ngroups = ngroups, L.tile_log2 = tile_log2;
-    L.search_lds = slices ? sl_lds : dense ? max_stride * 16 : (size_t)(pair ? 2 : 1) * max_stride * sizeof(uint2);
+    L.search_lds = slices ? sl_lds : max_stride * 16;
     if (slices_flat && L.search_lds < 4096) L.search_lds = 4096;
     L.gate = unsorted;
     L.descent = descent;
@@ -3241,17 +3144,10 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     } else {
     hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                        tile_log2, h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
-    if (units) {
-        hipLaunchKernelGGL(sl_unit_sums_kernel, dim3((unsigned)ngroups), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), L.segs, L.tile_seg,
-                           h->sl_unitcnt.as<unsigned>(), unsorted);
-        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
-                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
-    } else if (pair)
-        hipLaunchKernelGGL(bm_plan_kernel<1>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
-                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
-    else
-        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->bm_grpcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
-                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
+    hipLaunchKernelGGL(sl_unit_sums_kernel, dim3((unsigned)ngroups), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), L.segs, L.tile_seg,
+                       h->sl_unitcnt.as<unsigned>(), unsorted);
+    hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
+                       h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     }
     BXMI_LAUNCH_CHECK();
     stage_done("transpose + plan");
@@ -3269,12 +3165,8 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         else
             BXMI_TRY(sl_launch_search<16>(L, sgrid, st, search_out));
         if (fx) fx->L = L, fx->sgrid = sgrid, fx->lanes = lanes, fx->variant = variant;
-    } else if (dense)
+    } else
         BXMI_TRY(bd_launch_search(L, sgrid, cells ? 1 : 0, any_blocks, st));
-    else if (pair)
-        BXMI_TRY(bm_launch_search_u<true>(L, sgrid, st));
-    else
-        BXMI_TRY(bm_launch_search_u<false>(L, sgrid, st));
     unsigned *loff = fx ? h->sl_loff.as<unsigned>() : nullptr;
     stage_done("search");
     if (dense) {
@@ -3360,11 +3252,6 @@ static int bm_choose_stage(bxmi_ivl *h, hipStream_t st, int *kind)
             *kind = 3;
             return BXMI_OK;
         }
-    }
-    if (h->bm_state == 0) BXMI_TRY(bm_prepare_index(h, st));
-    if (h->bm_state == 1) {
-        *kind = 1;
-        return BXMI_OK;
     }
     if (!slices_first && g_opt_slice != 0) {
         if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
@@ -3515,7 +3402,6 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         h->geom.cmin = cmin;
         h->geom.shift = shift;
         h->cmax = cmax;
-        h->bm_state = 0;
         h->sl_state = 0;
         h->bd_state = 0;
         h->bp_state = 0;
@@ -3556,14 +3442,6 @@ static int need_sealed(const bxmi_ivl *h, const char *who)
 {
     if (!h) return fail(BXMI_EINVAL, "%s: NULL handle", who);
     if (!h->sealed) return fail(BXMI_ESTATE, "%s: index not sealed (call bxmi_ivl_seal after appending)", who);
-    return BXMI_OK;
-}
-
-extern "C" int bxmi_ivl_bitmap_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells)
-{
-    BXMI_TRY(need_sealed(h, "bxmi_ivl_bitmap_state"));
-    if (state) *state = h->bm_state;
-    if (hard_cells) *hard_cells = h->bm_hard_cells;
     return BXMI_OK;
 }
 
@@ -3696,7 +3574,7 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
     if (n < 0 || (n > 0 && (!hs || !qs || !qe || !nq))) return fail(BXMI_EINVAL, "bxmi_ivl_count_multi_dev: bad arguments");
     hipStream_t st = as_stream(stream);
     // indexes whose batch can ride the bitmap-cell pass are answered together (one pass, six launches); the others one by one
-    std::vector<bxmi_ivl *> fh[4];  // [0] bucket images, [1] slices, [2] dense unit images, [3] cell images of units
+    std::vector<bxmi_ivl *> fh[4];  // by search stage (kind - 1): [1] slices, [2] dense unit images, [3] cell images of units
     std::vector<const int32_t *> fqs[4], fqe[4];
     std::vector<int64_t> fnq[4];
     std::vector<int32_t *> fc[4];

@@ -116,11 +116,7 @@ int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int6
  * the bitmap-cell pass share ONE pass: a fixed handful of launches for the whole genome instead of one set per chromosome. */
 int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
                              int32_t *const *counts, int64_t *const *totals_dev, void *stream);
-/* Which large-batch count pass serves this sealed index: *state = 0 not decided yet (no large batch so far), 1 = the
- * bitmap-cell pass (count_bitmap.hpp: its per-bucket images are built), -1 = the bucketed search pass (span wider than
- * 2^28, reversed targets, or too many coordinates carrying duplicates: *hard_cells of them).  Introspection only. */
-int bxmi_ivl_bitmap_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
-/* The same for the slice search stage (count_slices.hpp: sorted keys staged per unit of 2^f buckets; serves sparse
+/* Which search stage of the large-batch count pass can serve this sealed index -- the slice search stage (count_slices.hpp: sorted keys staged per unit of 2^f buckets; serves sparse
  * indexes and spans whose bucket image outgrows the LDS): *state = 0 not decided yet, 1 = usable, -1 = one bucket's
  * keys alone do not fit; unit_keys[0..6] = the most keys a unit of 2^f buckets stages.  Introspection only. */
 int bxmi_ivl_slice_state(const bxmi_ivl_t *h, int *state, int64_t *unit_keys);

@@ -194,7 +194,7 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
         set_opt("ivl.flat", 0)
         dn_c, dn_t = ix.count(qs, qe)  # dense unit images where the index qualifies, else as the next line
         set_opt("ivl.dense", 0)
-        bm_c, bm_t = ix.count(qs, qe)  # bitmap-cell pass where the index qualifies (else identical to the next line)
+        bm_c, bm_t = ix.count(qs, qe)  # neither kind of image: key slices where they fit (else identical to the next line)
         set_opt("ivl.bitmap", 0)       # the bucketed search pass
         got_c, got_t = ix.count(qs, qe)
         tot_only = ix.count(qs, qe, want_counts=False)[1]
@@ -210,7 +210,7 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     bad = np.nonzero(dn_c != want_c)[0]
     assert len(bad) == 0 and dn_t == want_t, ("dense pass", ix.dense_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], dn_c[bad[:5]], want_c[bad[:5]])
     bad = np.nonzero(bm_c != want_c)[0]
-    assert len(bad) == 0 and bm_t == want_t, ("bitmap pass", ix.bitmap_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
+    assert len(bad) == 0 and bm_t == want_t, ("slices / first-generation pass", ix.slice_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
     assert np.array_equal(tree_c, want_c) and tree_t == want_t, "partitioned, tree variant"
     if not ix.has_reversed:
         w_off, w_hits = t.find_batch(qs, qe)
@@ -271,7 +271,7 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
     assert np.array_equal(fl_c, want_c) and fl_t == want_t, ("flat walk on a sorted batch", ix.flat_state())
     assert np.array_equal(dn_c, want_c) and dn_t == want_t, ("dense pass on a sorted batch", ix.dense_state())
     bad = np.nonzero(bm_c != want_c)[0]
-    assert len(bad) == 0 and bm_t == want_t, ("bitmap pass", ix.bitmap_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
+    assert len(bad) == 0 and bm_t == want_t, ("slices / first-generation pass", ix.slice_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
     assert np.array_equal(loc_c, want_c) and loc_t == want_t, "sorted batch behind the bitmap pass's order check"
     bad = np.nonzero(got_c != want_c)[0]
     assert len(bad) == 0, ("sorted path", bad[:5], qs[bad[:5]], qe[bad[:5]], got_c[bad[:5]], want_c[bad[:5]])
@@ -311,8 +311,7 @@ def test_partitioned_counts_beyond_16_bits(O, IntervalIndex):
         dn, dn_total = ix.count(qs, qe)  # dense unit images refuse the index (70 000 keys in one block: more than 15 bits of rank)
         dstate = ix.dense_state()
         set_opt("ivl.dense", 0)
-        bm, bm_total = ix.count(qs, qe)  # bitmap-cell pass: the pile is one hard cell per array, its counts escape
-        state = ix.bitmap_state()
+        bm, bm_total = ix.count(qs, qe)  # neither kind of image: key slices, or the first-generation pass
         set_opt("ivl.bitmap", 0)
         got, got_total = ix.count(qs, qe)
         set_opt("ivl.count_cells", 0)
@@ -320,7 +319,6 @@ def test_partitioned_counts_beyond_16_bits(O, IntervalIndex):
     finally:
         reset_opts()
     assert int(want.max()) >= pile
-    assert state[0] == 1 and state[1] >= 2, state
     assert dstate[0] == -1 and dstate[1][0] >= pile, dstate
     assert fstate[0] == 1 and fstate[1] >= 2, fstate
     bad = np.nonzero(fl != want)[0]
@@ -352,11 +350,11 @@ def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
     ix = make_index(IntervalIndex, s, e)
     set_opt("ivl.partition", 1)
     try:
-        set_opt("ivl.bm_hard_ppm", 10**6)  # keep the bitmap-cell pass although the dense stretch is all hard cells
+        set_opt("ivl.bm_hard_ppm", 10**6)  # keep the cell images although the dense stretch is all hard cells
         set_opt("ivl.dense", 0)            # (250k keys on 4000 coordinates: far more duplicates than a unit's overflow list holds)
-        set_opt("ivl.flat", 0)
         bm, bm_total = ix.count(qs, qe)
-        state = ix.bitmap_state()
+        state = ix.flat_state()
+        set_opt("ivl.flat", 0)
         set_opt("ivl.bitmap", 0)
         got, got_total = ix.count(qs, qe)
         set_opt("ivl.count_cells", 0)
@@ -367,7 +365,7 @@ def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
         reset_opts()
     assert state[0] == 1 and state[1] > 100, state
     bad = np.nonzero(bm != want)[0]
-    assert len(bad) == 0 and bm_total == want_total, ("bitmap pass, hard cells", bad[:5], qs[bad[:5]], qe[bad[:5]], bm[bad[:5]], want[bad[:5]])
+    assert len(bad) == 0 and bm_total == want_total, ("cell images, hard cells", bad[:5], qs[bad[:5]], qe[bad[:5]], bm[bad[:5]], want[bad[:5]])
     assert np.array_equal(tree, want) and tree_total == want_total, "tree variant"
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got[bad[:5]], want[bad[:5]])
@@ -405,7 +403,7 @@ def test_incremental_append_reseals(O, IntervalIndex):
         assert np.array_equal(ix.find(qs, qe)[1], t.find_batch(qs, qe)[1])
 
 
-@pytest.mark.parametrize("stage", ["images", "slices", "dense", "flat"])
+@pytest.mark.parametrize("stage", ["slices", "dense", "flat"])
 @pytest.mark.parametrize("shape", ["uniform", "sorted", "one_bucket", "messy", "ragged_tail", "dups"])
 def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
     """The large-batch count pass (count_bitmap.hpp, and its search stages count_slices.hpp and count_dense.hpp) against the oracle
@@ -477,7 +475,7 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                     ix_blocks[0] = blocks
                 got, got_total = ix.count(qs, qe)
                 state = ix.dense_state() if stage == "dense" else ix.flat_state()
-                assert state[0] == 1 and ix.bitmap_state()[0] == 0 and ix.slice_state()[0] == 0, (state, ix.bitmap_state(), ix.slice_state())
+                assert state[0] == 1 and ix.slice_state()[0] == 0, (state, ix.slice_state())
                 assert (ix.flat_state()[0] == 0) == (stage == "dense")
                 bad = np.nonzero(got != want)[0]
                 assert len(bad) == 0, (shape, stage, variant, chunk, depth, pipe, blocks, pad, w8, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
@@ -499,28 +497,13 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                 set_opt("ivl.sl_flat", (k >> 1) & 1)  # the flat 16-byte walk of count_dense.hpp, or the lanes-per-run kernels
                 got, got_total = ix.count(qs, qe)
                 state = ix.slice_state()
-                assert state[0] == 1 and ix.bitmap_state()[0] == 0, (state, ix.bitmap_state())
+                assert state[0] == 1, state
                 bad = np.nonzero(got != want)[0]
                 assert len(bad) == 0, (shape, variant, f, lanes, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
                 assert got_total == want_total
             assert state[1][0] > 0 and all(a <= b for a, b in zip(state[1], state[1][1:]))  # keys per unit grow with the unit
             return
-        set_opt("ivl.slice", 0)
-        for k, (variant, u, pair, pipe) in enumerate(((0, 4, 0, 0), (1, 2, 1, 0), (2, 8, 0, 0), (0, 4, 1, 0), (0, 2, 0, 1), (0, 4, 0, 1), (2, 2, 1, 1),
-                                                      (1, 4, 1, 1), (-1, 2, 1, 1))):
-            set_opt("ivl.sorted_path", k % 2)  # off: a sorted batch goes through the exchange too (long runs, one bucket per tile)
-            set_opt("ivl.bm_variant", variant)
-            set_opt("ivl.bm_u", u)
-            set_opt("ivl.bm_pair", pair)  # one bucket per search workgroup, or two neighbours
-            set_opt("ivl.bm_pipe", pipe)  # the software-pipelined search kernel
-            got, got_total = ix.count(qs, qe)
-            state = ix.bitmap_state()
-            assert state[0] == 1, state
-            bad = np.nonzero(got != want)[0]
-            assert len(bad) == 0, (shape, variant, u, pair, pipe, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
-            assert got_total == want_total
-        if shape == "dups":
-            assert state[1] > 0  # the pile made hard cells
+        raise AssertionError("unknown stage " + stage)
     finally:
         reset_opts()
 
@@ -619,20 +602,16 @@ def test_bitmap_pass_is_refused_where_it_does_not_fit(O, IntervalIndex):
             for slices in (0, -1):
                 set_opt("ivl.slice", slices)
                 ix = make_index(IntervalIndex, s, e)
-                assert ix.bitmap_state()[0] == 0 and ix.slice_state()[0] == 0
+                assert ix.slice_state()[0] == 0
                 got, got_total = ix.count(qs, qe)
                 assert np.array_equal(got, want) and got_total == want_total, (name, slices)
-                bm, sl = ix.bitmap_state()[0], ix.slice_state()[0]
-                if name == "reversed":
-                    assert (bm, sl) == (0, 0)
-                elif slices == 0:
-                    assert (bm, sl) == (-1, 0), (name, bm, sl)
+                sl = ix.slice_state()[0]
+                if name == "reversed" or slices == 0:
+                    assert sl == 0, (name, sl)
                 elif name == "pile":
-                    assert (bm, sl) == (-1, -1), (name, bm, sl)
-                elif name == "wide":
-                    assert (bm, sl) == (0, 1), (name, bm, sl)     # slices first: the images are never built
+                    assert sl == -1, (name, sl)
                 else:
-                    assert (bm, sl) == (-1, 1), (name, bm, sl)    # dense index: images tried first, then slices
+                    assert sl == 1, (name, sl)
                 ix.close()
     finally:
         reset_opts()
@@ -732,15 +711,8 @@ def test_scale_1M_hash(golden_scale, IntervalIndex):
             set_opt("ivl.sl_f", (-1, 0, 3, 6)[variant])
             set_opt("ivl.sl_lanes", (0, 64, 16, 1)[variant])
             counts, total = ix.count(qs, qe)
-            assert (ix.bitmap_state()[0], ix.slice_state()[0]) == (0, 1)
+            assert ix.slice_state()[0] == 1
             assert total == pt["total"] and hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], ("slice stage", variant)
-        set_opt("ivl.slice", 0)
-        for variant in (0, 1, 2, 3):  # the bitmap-cell pass: all three tile shapes, then bucket pairs
-            set_opt("ivl.bm_variant", variant % 3)
-            set_opt("ivl.bm_pair", variant == 3)
-            counts, total = ix.count(qs, qe)
-            assert ix.bitmap_state()[0] == 1
-            assert total == pt["total"] and hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], ("bitmap pass", variant)
         set_opt("ivl.bitmap", 0)
         counts, total = ix.count(qs, qe)
     finally:
@@ -766,7 +738,7 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
         sub = counts[:: pt["stride"]]
         assert int(sub.sum(dtype=np.int64)) == pt["total"]
         assert hashlib.sha256(np.ascontiguousarray(sub).tobytes()).hexdigest() == pt["counts_sha256"]
-    assert ix.flat_state()[0] == 1 and ix.dense_state()[0] == 0 and ix.bitmap_state()[0] == 0  # the full batch above went through the flat walk on cell images
+    assert ix.flat_state()[0] == 1 and ix.dense_state()[0] == 0  # the full batch above went through the flat walk on cell images
     # the direct tree kernel and the large-batch passes agree (first 8M queries through the direct kernel)
     set_opt("ivl.partition", 0)
     try:
@@ -775,10 +747,6 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
         set_opt("ivl.flat", 0)    # the same pass on dense unit images
         img, img_total = ix.count(qs, qe)
         assert ix.dense_state()[0] == 1
-        assert np.array_equal(img, counts) and img_total == total
-        set_opt("ivl.dense", 0)   # on bucket-pair images
-        img, img_total = ix.count(qs, qe)
-        assert ix.bitmap_state()[0] == 1
         assert np.array_equal(img, counts) and img_total == total
         del img
         set_opt("ivl.bitmap", 0)  # the bucketed search pass on the whole batch
@@ -867,7 +835,7 @@ def test_sorted_kernel_shape_follows_the_order_checks(O, IntervalIndex):
     assert np.array_equal(got, first) and got_total == first_total
 
 
-@pytest.mark.parametrize("stage", ["flat", "dense", "slices", "images"])
+@pytest.mark.parametrize("stage", ["flat", "dense", "slices"])
 def test_order_check_is_dropped_and_comes_back(O, IntervalIndex, stage):
     """After two shuffled batches in a row the order check is no longer launched: a probe of 8192 starts rides on the
     parameter kernel and reports through host memory.  A batch without a descent in the probe -- sorted, or sorted but for
@@ -949,11 +917,13 @@ def test_count_width_feedback(O, IntervalIndex):
         qe = (qs + rng.integers(900, 1200, size=nq)).astype(np.int32)
         want, want_total = t.count_batch(qs, qe)
         assert (want >= 255).mean() > 0.9
-        for _ in range(4):
+        for _ in range(10):  # (the mirror in host memory is a pass or two behind the kernels that write it)
             got, got_total = ix.count(qs, qe)
             assert np.array_equal(got, want) and got_total == want_total
+            if ix.count_width()[0] == 16:
+                break
         bits, wide = ix.count_width()
-        assert bits == 16 and wide >= nq // 2, (bits, wide)  # (the mirror is a pass or two behind)
+        assert bits == 16 and wide >= nq // 2, (bits, wide)
         got, got_total = ix.count(qs, qe)
         assert np.array_equal(got, want) and got_total == want_total
     finally:
@@ -974,7 +944,7 @@ def test_clustered_distribution_differential(O, IntervalIndex):
     want, _ = t.count_batch(qs[pick], qe[pick])
     ix = make_index(IntervalIndex, ts, te)
     got, got_total = ix.count(qs, qe)
-    stages = (ix.flat_state()[0], ix.dense_state()[0], ix.bitmap_state()[0], ix.slice_state()[0])
+    stages = (ix.flat_state()[0], ix.dense_state()[0], 0, ix.slice_state()[0])
     bad = np.nonzero(got[pick] != want)[0]
     assert len(bad) == 0 and got_total == int(got.sum(dtype=np.int64)), (stages, bad[:8], qs[pick][bad[:8]], qe[pick][bad[:8]], got[pick][bad[:8]], want[bad[:8]])
     assert stages[3] == 1 or stages[0] == 1 or stages[1] == 1, stages  # one of the exchange's search stages served it
@@ -1085,13 +1055,9 @@ def test_count_multi_equals_one_index_at_a_time(O, IntervalIndex):
         for ix in ixs:
             ix.seal()  # (forget the stages chosen so far: the loop below asserts on what each setting prepares)
         set_opt("ivl.dense", 0)
-        for pair, variant, slices in ((1, -1, 0), (0, 0, 0), (1, 2, 0), (1, -1, -1), (0, 1, 1)):
-            set_opt("ivl.bm_pair", pair)
+        for variant, slices in ((-1, 0), (0, -1), (2, -1), (1, 1)):  # no image stage left: key slices where allowed, else one index at a time
             set_opt("ivl.bm_variant", variant)
-            set_opt("ivl.slice", slices)  # -1: the dense index on images, the sparse and the wide ones on slices, in the same call
-            if slices == -1:
-                assert [ix.bitmap_state()[0] for ix in ixs] == [1, 1, 1, 0, -1, 0]  # empty batch: never looked at; too wide; reversed targets
-                assert [ix.slice_state()[0] for ix in ixs] == [0] * 6
+            set_opt("ivl.slice", slices)
             totals.zero()
             IntervalIndex.count_multi_dev(ixs, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [d[3] for d in dev], [d[2].ptr for d in dev],
                                           [totals.ptr + 8 * i for i in range(len(specs))], None)
@@ -1100,7 +1066,9 @@ def test_count_multi_equals_one_index_at_a_time(O, IntervalIndex):
             for k, (wc, wt) in enumerate(want):
                 got = dev[k][2].to_numpy(np.int32, dev[k][3])
                 bad = np.nonzero(got != wc)[0]
-                assert len(bad) == 0 and int(tot[k]) == wt, (pair, variant, k, ixs[k].bitmap_state(), bad[:5], got[bad[:5]], wc[bad[:5]], int(tot[k]), wt)
+                assert len(bad) == 0 and int(tot[k]) == wt, (variant, slices, k, ixs[k].slice_state(), bad[:5], got[bad[:5]], wc[bad[:5]], int(tot[k]), wt)
+            if slices == 0:
+                assert [ix.slice_state()[0] for ix in ixs] == [0] * 6
         assert [ix.slice_state()[0] for ix in ixs] == [1, 1, 1, 0, 1, 0]
     finally:
         reset_opts()
@@ -1123,7 +1091,7 @@ def test_genome_cfg4_full_size_golden(golden_scale_doc, IntervalIndex):
         sub = np.ascontiguousarray(counts[:: g["stride"]])
         assert int(sub.sum(dtype=np.int64)) == pt["total"], chrom
         assert hashlib.sha256(sub.tobytes()).hexdigest() == pt["counts_sha256"], chrom
-        paths.add((ix.bitmap_state()[0], ix.slice_state()[0]))
+        paths.add((ix.flat_state()[0], ix.slice_state()[0]))
         grand += total
         ix.close()
     # big chromosomes through the large-batch pass -- on key slices, a chromosome has one target per ~300 coordinates --

@@ -363,7 +363,7 @@ def test_bxmi_opts_environment_applies_the_tuning_knobs():
     """BXMI_OPTS="key=value,..." is read when the library is loaded (bxmi/_ffi.py): known keys are applied through
     bxmi_set_option (no GPU call involved), an unknown key is an error at load time, not a silently ignored typo."""
     code = "from bxmi import _ffi; _ffi.load(); print('loaded')"
-    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "bx-python_amd"), BXMI_OPTS="ivl.bm_u=4, core.poll=0,ivl.sl_run_cap=128")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "bx-python_amd"), BXMI_OPTS="ivl.bm_variant=2, core.poll=0,ivl.sl_run_cap=128")
     assert subprocess.check_output([sys.executable, "-c", code], text=True, env=env).strip() == "loaded"
     env["BXMI_OPTS"] = "ivl.no_such_knob=1"
     r = subprocess.run([sys.executable, "-c", code], text=True, env=env, capture_output=True)

@@ -35,4 +35,4 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 print(json.dumps(dict(workload="configs[4] shapes, count only: %d x %d" % (NQ, NT), ms=round(ms, 3), total=first_total,
-                      counts_sum=int(counts.sum(dtype=torch.int64).item()), bitmap_state=ix.bitmap_state(), slice_state=ix.slice_state())))
+                      counts_sum=int(counts.sum(dtype=torch.int64).item()), flat_state=ix.flat_state(), slice_state=ix.slice_state())))

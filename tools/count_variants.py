@@ -71,7 +71,7 @@ for name, opts in VARIANTS:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / REPS
     print(json.dumps(dict(variant=name, opts=dict(opts), ms=round(ms, 4), gqps=round(NQ / ms / 1e6, 2), total=tot, same_as_first=same,
-                          dense=ix.dense_state(), bitmap=ix.bitmap_state()[0], slices=ix.slice_state()[0])), flush=True)
+                          dense=ix.dense_state(), flat=ix.flat_state()[0], slices=ix.slice_state()[0])), flush=True)
     if not same:
         bad = torch.nonzero(counts != ref).flatten()
         print(json.dumps(dict(mismatches=int(bad.numel()), first=bad[:8].tolist(), got=counts[bad[:8]].tolist(), want=ref[bad[:8]].tolist(),

@@ -61,7 +61,7 @@ for r in range(rounds):
     # (partition, count_cells, bitmap, slice): direct kernel, round 1's pass in both search variants, the large-batch pass
     # on images first / slices first / slices only, each with random tile shapes, unit sizes and run widths
     for part, cells, bitmap, slices in ((0, 1, 0, 0), (1, 1, 0, 0), (1, 0, 0, 0), (1, 1, -1, 0), (1, 1, -1, -1), (1, 1, -1, 1), (1, 1, -1, 1)):
-        knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64, 1])), pair=int(rng.integers(0, 2)),
+        knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64, 1])),
                      sorted_path=int(rng.integers(0, 2)))
         opt("ivl.partition", part)
         opt("ivl.count_cells", cells)
@@ -70,13 +70,12 @@ for r in range(rounds):
         opt("ivl.bm_variant", knobs["variant"])
         opt("ivl.sl_f", knobs["f"])
         opt("ivl.sl_lanes", knobs["lanes"])
-        opt("ivl.bm_pair", knobs["pair"])
         opt("ivl.sorted_path", knobs["sorted_path"])
         got_c, got_t = ix.count(qs, qe)
         if not np.array_equal(got_c, want_c) or got_t != want_t:
             bad = np.nonzero(got_c != want_c)[0][:5]
             print("MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells, bitmap=bitmap, slices=slices, **knobs),
-                  ix.bitmap_state(), ix.slice_state(), bad, qs[bad], qe[bad], got_c[bad], want_c[bad])
+                  ix.flat_state(), ix.dense_state(), ix.slice_state(), bad, qs[bad], qe[bad], got_c[bad], want_c[bad])
             sys.exit(1)
     opt("ivl.count_cells", 1)
     opt("ivl.bitmap", -1)
@@ -95,7 +94,7 @@ for r in range(rounds):
         if not (np.array_equal(off, w_off) and np.array_equal(hits, w_hits)):
             print("FIND MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, sliced=sliced, **knobs), ix.slice_state())
             sys.exit(1)
-    for k, v in (("ivl.partition", -1), ("ivl.find_sliced", 1), ("ivl.bm_variant", -1), ("ivl.sl_f", -1), ("ivl.sl_lanes", 0), ("ivl.bm_pair", 1),
+    for k, v in (("ivl.partition", -1), ("ivl.find_sliced", 1), ("ivl.bm_variant", -1), ("ivl.sl_f", -1), ("ivl.sl_lanes", 0),
                  ("ivl.sorted_path", 1)):
         opt(k, v)
     checked += 1
