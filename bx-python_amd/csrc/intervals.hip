@@ -2145,18 +2145,10 @@ static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard c
 static int64_t g_opt_flat = -1;       // the flat 16-byte walk on cell images of 2^18-coordinate units (count_dense.hpp, bp_*): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
 static int64_t g_opt_dense = -1;      // search stage on dense unit images (count_dense.hpp): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
 static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
-static int64_t g_opt_bd_nt = 1;       // 1 = non-temporal image loads in the dense search kernel
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
-static int64_t g_opt_bd_depth = 0;    // passes of records in flight per wave of the flat walk: 0 = by layout (ring of 3 on padded runs, two sets of 4 on packed runs, 2 for key slices), else 2, 3, 4 (8: ring only)
 static int64_t g_opt_bd_w8 = -1;      // 8-bit counts out of place: -1 = by index and feedback, 0 = never, 1 = whenever the layout allows
-static int64_t g_opt_bd_pad = 1;      // 1 = the units' runs of a tile on whole 16-byte slots and the walk's ring of loads (count_dense.hpp), 0 = packed runs
 static int64_t g_opt_order_skip = -1;  // -1 = stop launching the order check after two batches in a row were not sorted (a probe of 8192 starts rides on the parameter kernel then), 0 = always check
 static int64_t g_opt_stage_sync = 0;  // diagnostics: wait for every stage of the count pass and say on stderr which one finished
-static int64_t g_opt_bd_pipe = 1;     // 1 = the walk keeps two sets of passes in flight (record loads issued by hand), 0 = one set per round
-static int64_t g_opt_bd_exp = 0;      // diagnostics only (wrong results): 1 = the dense search kernel without its lookups
-static int64_t g_opt_bw = 1;          // 1 = cell images on padded runs are searched by the persistent walk (bw_search_kernel), 0 = bd_search_kernel's ring
-static int64_t g_opt_bw_grid = 256;   // workgroups of the persistent walk (a multiple of 8: one per CU)
-static int64_t g_opt_bw_depth = 3;    // passes of records in flight per wave of the persistent walk: 3, 4 or 6 (configs[1]: 0.703 / 0.711 / 0.715 ms per pass -- the memory side is bound by lines in flight per CU, not by the ring)
 static int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
 
 // The option table: every knob of the interval path, its variable and how a value is normalised.  bxmi_set_option writes through
@@ -2171,9 +2163,6 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.group_sum", &g_opt_group_sum, nullptr},
     {"ivl.lds_ints", &g_opt_lds_ints, [](int64_t value) -> int64_t { return value < 0 ? 0 : (value > LDS_TREE_INTS ? LDS_TREE_INTS : value); }},
     {"ivl.count_grid", &g_opt_count_grid, nullptr},
-    {"ivl.bw", &g_opt_bw, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.bw_grid", &g_opt_bw_grid, [](int64_t value) -> int64_t { return value >= 8 && value <= 2048 ? (value + 7) / 8 * 8 : 256; }},
-    {"ivl.bw_depth", &g_opt_bw_depth, [](int64_t value) -> int64_t { return value == 4 || value == 6 ? value : 3; }},
     {"ivl.partition", &g_opt_partition, nullptr},
     {"ivl.count_cells", &g_opt_count_cells, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.sorted_path", &g_opt_sorted_path, [](int64_t value) -> int64_t { return value != 0; }},
@@ -2198,15 +2187,10 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.flat", &g_opt_flat, nullptr},
     {"ivl.dense", &g_opt_dense, nullptr},
     {"ivl.bd_chunk", &g_opt_bd_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
-    {"ivl.bd_nt", &g_opt_bd_nt, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.bd_blocks", &g_opt_bd_blocks, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.bd_depth", &g_opt_bd_depth, [](int64_t value) -> int64_t { return value == 2 || value == 3 || value == 4 || value == 8 ? value : 0; }},
     {"ivl.bd_w8", &g_opt_bd_w8, nullptr},
-    {"ivl.bd_pad", &g_opt_bd_pad, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.order_skip", &g_opt_order_skip, nullptr},
     {"ivl.stage_sync", &g_opt_stage_sync, nullptr},
-    {"ivl.bd_pipe", &g_opt_bd_pipe, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.bd_exp", &g_opt_bd_exp, nullptr},
     {"ivl.bd_unit_log2", &g_opt_bd_unit_log2, [](int64_t value) -> int64_t { return value < 12 || value > BD_UNIT_LOG2 ? 0 : value; }},
 };
 constexpr int IVL_NOPTS = (int)(sizeof(IVL_OPTS) / sizeof(IVL_OPTS[0]));
@@ -2543,7 +2527,8 @@ static int bp_prepare_index(bxmi_ivl *h, hipStream_t st)
 {
     h->bp_state = -1;
     const int shift = h->geom.shift;
-    if (h->has_reversed || h->n < 4096 || shift > BP_UNIT_LOG2 || shift < BM_MIN_SHIFT) return BXMI_OK;
+    // (units of at least two buckets: the 1024-thread tile sorts can then start every unit's run on a whole 16-byte slot)
+    if (h->has_reversed || h->n < 4096 || shift > BP_UNIT_LOG2 - 1 || shift < BM_MIN_SHIFT) return BXMI_OK;
     BmGeom g;
     g.cmin = h->geom.cmin;
     g.cmax = h->cmax;
@@ -2817,69 +2802,33 @@ static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
     return BXMI_OK;
 }
 
-template <int FMT, bool QB, int EXP>
-static int bd_launch_search_d(const BmLaunch &L, unsigned grid, hipStream_t st)
-{
-    if (L.pad) {  // the ring of the padded layout (hand-issued loads, exact wait counts)
-        if (L.w8 && FMT == 1 && EXP == 0 && !QB) return bd_launch_search_t<1, false, 0, 3, true, true, true>(L, grid, st);
-        switch (g_opt_bd_depth) {
-        case 2: return bd_launch_search_t<FMT, QB, EXP, 2, true, true>(L, grid, st);
-        case 4: return bd_launch_search_t<FMT, QB, EXP, 4, true, true>(L, grid, st);
-        case 8: return bd_launch_search_t<FMT, QB, EXP, 8, true, true>(L, grid, st);
-        // configs[1], search kernel: packed runs 315 us; ring of 2: 270, 3: 264, 4: 269, 6: 274 (every pass of a round that
-        // lies behind the batch's end still costs a load and a store)
-        default: return bd_launch_search_t<FMT, QB, EXP, 3, true, true>(L, grid, st);
-        }
-    }
-    if (g_opt_bd_pipe) {
-        switch (g_opt_bd_depth) {
-        case 2: return bd_launch_search_t<FMT, QB, EXP, 2, true>(L, grid, st);
-        case 3: return bd_launch_search_t<FMT, QB, EXP, 3, true>(L, grid, st);
-        default: return bd_launch_search_t<FMT, QB, EXP, 4, true>(L, grid, st);
-        }
-    }
-    switch (g_opt_bd_depth) {
-    case 2: return bd_launch_search_t<FMT, QB, EXP, 2, false>(L, grid, st);
-    case 3: return bd_launch_search_t<FMT, QB, EXP, 3, false>(L, grid, st);
-    default: return bd_launch_search_t<FMT, QB, EXP, 4, false>(L, grid, st);
-    }
-}
-
 // the persistent walk on cell images (count_dense.hpp, bw_*): one workgroup per CU, items handed out per XCD
-template <bool W8, int DEPTH>
-static int bw_launch_search_t(const BmLaunch &L, hipStream_t st)
+template <bool W8>
+static int bw_launch_search(const BmLaunch &L, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
-    BXMI_TRY(allow_big_lds((bw_search_kernel<W8, DEPTH>), L.search_lds));
-    hipLaunchKernelGGL((bw_search_kernel<W8, DEPTH>), dim3((unsigned)g_opt_bw_grid), dim3(BD_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+    BXMI_TRY(allow_big_lds((bw_search_kernel<W8, 3>), L.search_lds));
+    hipLaunchKernelGGL((bw_search_kernel<W8, 3>), dim3(256), dim3(BD_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
                        h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(), h->bd_cnt16.as<unsigned short>(),
                        L.tile_log2, L.gate, L.xcd_next);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
-template <bool W8>
-static int bw_launch_search(const BmLaunch &L, hipStream_t st)
-{
-    switch (g_opt_bw_depth) {
-    case 4: return bw_launch_search_t<W8, 4>(L, st);
-    case 6: return bw_launch_search_t<W8, 6>(L, st);  // (8: spills inside the loop)
-    default: return bw_launch_search_t<W8, 3>(L, st);
-    }
-}
-
+// One shape per stage and layout (round 3 kept every ring depth, both pipelines and the diagnostics behind knobs: 66 kernels):
+//   cell images   always on padded runs (bp_prepare_index only takes geometries the tile sort can pad): the persistent walk;
+//   dense images  padded runs: the ring of three hand-issued loads; packed runs (units of a single bucket): two sets of four;
+//   key slices    the lean shape (two passes per round, compiler-issued loads: 64 registers) -- two workgroups share a CU when
+//                 the units are small, one stages its unit while the other searches (a third of a sparse index's search time).
 static int bd_launch_search(const BmLaunch &L, unsigned grid, int fmt /* 0 dense, 1 cells, 2 slices */, bool blocks, hipStream_t st)
 {
-    if (fmt == 1 && L.pad && g_opt_bw != 0 && g_opt_bd_exp == 0) return L.w8 ? bw_launch_search<true>(L, st) : bw_launch_search<false>(L, st);
-    // key slices: the lean shape (two passes per round, compiler-issued loads: 50 registers) -- two workgroups share a CU
-    // when the units are small, one stages its unit while the other searches (a third of a sparse index's search time)
-    if (fmt == 2) return g_opt_bd_depth == 4 && g_opt_bd_pipe ? bd_launch_search_t<2, false, 0, 4, true>(L, grid, st) : bd_launch_search_t<2, false, 0, 2, false>(L, grid, st);  // (never padded: see bm_count_segments)
-    const bool cells = fmt == 1;
-    if (cells && g_opt_bd_exp == 3) return bd_launch_search_d<1, false, 3>(L, grid, st);
-    if (cells) return g_opt_bd_exp == 1 ? bd_launch_search_d<1, false, 1>(L, grid, st) : bd_launch_search_d<1, false, 0>(L, grid, st);
-    if (g_opt_bd_exp == 3) return bd_launch_search_d<0, false, 3>(L, grid, st);
-    if (g_opt_bd_exp == 1) return blocks ? bd_launch_search_d<0, true, 1>(L, grid, st) : bd_launch_search_d<0, false, 1>(L, grid, st);
-    return blocks ? bd_launch_search_d<0, true, 0>(L, grid, st) : bd_launch_search_d<0, false, 0>(L, grid, st);
+    if (fmt == 1) {
+        if (!L.pad) return fail(BXMI_ESTATE, "bd_launch_search: cell images on packed runs");
+        return L.w8 ? bw_launch_search<true>(L, st) : bw_launch_search<false>(L, st);
+    }
+    if (fmt == 2) return bd_launch_search_t<2, false, 0, 2, false>(L, grid, st);  // (never padded: see bm_count_segments)
+    if (L.pad) return blocks ? bd_launch_search_t<0, true, 0, 3, true, true>(L, grid, st) : bd_launch_search_t<0, false, 0, 3, true, true>(L, grid, st);
+    return blocks ? bd_launch_search_t<0, true, 0, 4, true>(L, grid, st) : bd_launch_search_t<0, false, 0, 4, true>(L, grid, st);
 }
 
 template <int THREADS, int ITEMS>
@@ -2937,7 +2886,12 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (n > 4096) return fail(BXMI_EINVAL, "bxmi_ivl_count_multi: more than 4096 indexes in one batch");
     // tile shape: 32768-query tiles halve the number of (tile, bucket) runs the search has to fetch, but their sort
     // kernel runs one workgroup per CU and wants a grid of several hundred full tiles
-    const int variant = g_opt_bm_variant >= 0 ? (int)g_opt_bm_variant : (n == 1 && nq_all >= ((int64_t)32 << 20) ? 2 : 0);
+    int variant = g_opt_bm_variant >= 0 ? (int)g_opt_bm_variant : (n == 1 && nq_all >= ((int64_t)32 << 20) ? 2 : 0);
+    // cell images are searched on padded runs only: a unit of two buckets needs a tile sort whose threads own two buckets each
+    // (the 1024-thread shapes), the 512-thread shape owns four
+    if (cells && variant == 0)
+        for (int i = 0; i < n; i++)
+            if (hs[i]->bp_geom.f < 2) variant = 1;
     const int tile_log2 = variant == 2 ? 15 : 14;
     const int64_t tile = (int64_t)1 << tile_log2;
     // the batch's tile numbering: every segment starts on a plan-group boundary
@@ -2996,7 +2950,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     }
     // PAD: every unit's run of a tile on whole 16-byte slots (the search's load ring needs one store per pass); the tile
     // sort's scan keeps a unit inside one thread or a few neighbouring lanes
-    bool pad = (kind == 3 || cells) && g_opt_bd_pad != 0;
+    bool pad = kind == 3 || cells;
     for (int i = 0; i < n && pad; i++) pad = (1 << segs[(size_t)i].g.f) >= (variant == 0 ? 4 : 2);
     const int64_t tile_stride = tile + (pad ? BM_PAD_ROOM : 0);
     BXMI_TRY(h->bm_recs.reserve((size_t)ntp * tile_stride * 4));
@@ -3084,7 +3038,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     // prediction misses -- long queries, targets crowded into part of the span -- the feedback catches: once more than one
     // count in 64 did not fit, the index keeps 16-bit counts (worst case before that: every count recomputed, ~2 x the pass).
     L.w8 = false;
-    if (pad && cells && n == 1 && g_opt_bd_w8 != 0 && g_opt_bd_exp == 0 && g_opt_bd_depth == 0) {
+    if (pad && cells && n == 1 && g_opt_bd_w8 != 0) {
         BXMI_TRY(ensure_feedback(h, st));
         const unsigned long long wide = *reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host);
         if ((int64_t)wide * 64 > h->w8_queries && wide > 4096) h->w8_off = true;

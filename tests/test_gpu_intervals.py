@@ -455,19 +455,13 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
             set_opt("ivl.dense", 1)
             if shape == "dups" and stage == "flat":
                 set_opt("ivl.bm_hard_ppm", 10**6)  # (two cells' worth of piled-up coordinates and 60 000 repeated starts: keep the cells anyway)
-            # pad: the units' runs of a tile on whole 16-byte slots + the ring of record loads, or packed runs
-            # w8: 8-bit counts between the search and the un-permute kernel (cell images, padded layout, default depth): forced
-            # on (counts of 255 and more come back as "ask again" and are recomputed), off, or left to the density + feedback
-            for k, (variant, chunk, depth, pipe, blocks, pad, w8) in enumerate(((0, 0, 4, 1, 0, 1, 0), (1, 4096, 2, 0, 1, 0, 0), (2, 1 << 20, 3, 1, 1, 0, 0),
-                                                                               (-1, 20000, 4, 0, 0, 0, 0), (0, 1024, 2, 1, 0, 1, 0), (2, 0, 8, 1, 1, 1, 0),
-                                                                               (1, 65536, 3, 1, 0, 1, 0), (2, 4096, 4, 1, 0, 0, 0), (2, 0, 0, 1, 0, 1, 1),
-                                                                               (1, 8192, 0, 1, 0, 1, 1), (-1, 0, 0, 1, 0, 1, -1), (2, 0, 0, 1, 0, 1, 0))):
+            # w8: 8-bit counts between the search and the un-permute kernel (cell images): forced on (counts of 255 and more
+            # come back as "ask again" and are recomputed), off, or left to the density + feedback
+            for k, (variant, chunk, blocks, w8) in enumerate(((0, 0, 0, 0), (1, 4096, 1, 0), (2, 1 << 20, 1, 0), (-1, 20000, 0, 0), (0, 1024, 0, 0),
+                                                              (1, 65536, 0, 0), (2, 4096, 0, 0), (2, 0, 0, 1), (1, 8192, 0, 1), (-1, 0, 0, -1), (2, 0, 1, 0))):
                 set_opt("ivl.sorted_path", k % 2)
                 set_opt("ivl.bm_variant", variant)
                 set_opt("ivl.bd_chunk", chunk)
-                set_opt("ivl.bd_depth", depth)
-                set_opt("ivl.bd_pipe", pipe)
-                set_opt("ivl.bd_pad", pad)
                 set_opt("ivl.bd_w8", w8)
                 if stage == "dense" and blocks != ix_blocks[0]:
                     set_opt("ivl.bd_blocks", blocks)
@@ -478,7 +472,7 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                 assert state[0] == 1 and ix.slice_state()[0] == 0, (state, ix.slice_state())
                 assert (ix.flat_state()[0] == 0) == (stage == "dense")
                 bad = np.nonzero(got != want)[0]
-                assert len(bad) == 0, (shape, stage, variant, chunk, depth, pipe, blocks, pad, w8, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+                assert len(bad) == 0, (shape, stage, variant, chunk, blocks, w8, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
                 assert got_total == want_total
             if shape == "dups":
                 assert (state[1][1] > 100) if stage == "dense" else (state[1] > 0)  # overflow entries / hard cells
@@ -659,8 +653,8 @@ def test_dense_pass_limits(O, IntervalIndex):
                 assert state[1][0] > 32767
             if name == "duplicates":
                 assert state[1][1] > 5632
-            # the flat walk on cell images: spans up to 2^29; a pile is a few hard cells (finished in the sorted array),
-            # coordinates duplicated all over are too many of them (a key on every 7th coordinate and a duplicate on every
+            # the flat walk on cell images: spans up to 2^28 (units of at least two buckets: the runs are padded; the pile's
+            # index spans 2^29), coordinates duplicated all over are too many of them (a key on every 7th coordinate and a duplicate on every
             # 60th: a tenth of the cells hold two duplicated coordinates -- the dense images' overflow lists take those)
             set_opt("ivl.flat", 1)
             ix.seal()
@@ -669,9 +663,7 @@ def test_dense_pass_limits(O, IntervalIndex):
             set_opt("ivl.flat", 0)
             bad = np.nonzero(got != want)[0]
             assert len(bad) == 0 and got_total == want_total, ("flat", name, fstate, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
-            assert fstate[0] == {"wide": -1, "pile": 1, "duplicates": -1, "some_duplicates": -1, "reversed": 0}[name], (name, fstate)
-            if name == "pile":
-                assert fstate[1] > 20
+            assert fstate[0] == {"wide": -1, "pile": -1, "duplicates": -1, "some_duplicates": -1, "reversed": 0}[name], (name, fstate)
             ix.close()
     finally:
         reset_opts()
@@ -772,7 +764,7 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
 def test_padded_runs_on_many_full_tiles(O, IntervalIndex, stage):
     """The padded layout of the flat walk (every unit's run of a tile on whole 16-byte slots, ring of record loads) at the
     shape the headline uses: 32768-query tiles, all of them full but the last, batches of 64 tiles per wave, several rounds
-    of the ring per batch -- against the oracle treap, for every ring depth and against the packed layout."""
+    of the ring per batch -- against the oracle treap, with 16-bit and 8-bit counts."""
     rng = np.random.default_rng(77)
     n, span = 300_000, 60_000_000
     s = rng.integers(1000, span, size=n)
@@ -790,15 +782,13 @@ def test_padded_runs_on_many_full_tiles(O, IntervalIndex, stage):
     set_opt("ivl.flat", 1 if stage == "flat" else 0)
     set_opt("ivl.dense", 1)
     try:
-        for pad, depth, w8 in ((0, 4, 0), (1, 4, 0), (1, 8, 0), (1, 2, 0), (1, 3, 0), (1, 0, 0), (1, 0, 1), (1, 0, -1)):
-            set_opt("ivl.bd_pad", pad)
-            set_opt("ivl.bd_depth", depth)
+        for w8 in (0, 1, -1):
             set_opt("ivl.bd_w8", w8)
             got, got_total = ix.count(qs, qe)
             state = ix.dense_state() if stage == "dense" else ix.flat_state()
             assert state[0] == 1, state
             bad = np.nonzero(got != want)[0]
-            assert len(bad) == 0 and got_total == want_total, (stage, pad, depth, w8, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+            assert len(bad) == 0 and got_total == want_total, (stage, w8, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
     finally:
         reset_opts()
 
@@ -923,7 +913,7 @@ def test_count_width_feedback(O, IntervalIndex):
             if ix.count_width()[0] == 16:
                 break
         bits, wide = ix.count_width()
-        assert bits == 16 and wide >= nq // 2, (bits, wide)
+        assert bits == 16 and wide > 4096 and wide * 64 > nq, (bits, wide)  # (what makes the host give the 8 bits up)
         got, got_total = ix.count(qs, qe)
         assert np.array_equal(got, want) and got_total == want_total
     finally:
