@@ -478,5 +478,5 @@ def test_ring_kernels_keep_registers_of_loads_in_flight_untouched():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     m = re.match(r"(\d+) kernels checked, 0 with problems", last)
-    assert m and int(m.group(1)) >= 20, last
-    assert " ring " in r.stdout and "two sets" in r.stdout
+    assert m and int(m.group(1)) >= 6, last  # (one shape per stage and layout since round 4)
+    assert " ring " in r.stdout and "two sets" in r.stdout and "persistent walk W8 1 DEPTH 3" in r.stdout
