@@ -775,10 +775,8 @@ def main():
     if world > 1 and not args.no_genome:
         del qs, qe, counts
         torch.cuda.empty_cache()
-        try:
-            genome_leg = bench_genome(torch, dist, rank, world, max(5, args.steps), args.warmup, args.targets, args.queries)
-        except Exception as ex:  # (a rank that fails here would hang the others in the collective: let it surface)
-            raise
+        # (no try / except here: a rank that fails would hang the others in the collective -- let it surface)
+        genome_leg = bench_genome(torch, dist, rank, world, max(5, args.steps), args.warmup, args.targets, args.queries)
     if rank != 0:
         if world > 1:
             dist.barrier()

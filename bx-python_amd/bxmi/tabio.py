@@ -103,7 +103,7 @@ def parse_input(source, chrom_col, start_col, end_col, strand_col, prefixes):
                 source.seek(0)  # nothing taken: the per-line code reads the file itself
                 return None
         return table if table.n else None
-    except (_ffi.BxmiError, OSError, ValueError):
+    except (_ffi.BxmiError, OSError, ValueError, TypeError):  # (TypeError: a column given as None or text -- the per-line code says what is wrong with it)
         if is_file:
             try:
                 source.seek(0)

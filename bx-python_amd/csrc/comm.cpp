@@ -126,6 +126,7 @@ extern "C" int bxmi_comm_destroy(bxmi_comm_t *c)
 extern "C" int bxmi_allreduce_i64(bxmi_comm_t *c, int64_t *buf_dev, int64_t n, void *stream)
 {
     if (!c || !c->comm || n < 0 || (n > 0 && !buf_dev)) return bxmi::fail(BXMI_EINVAL, "bxmi_allreduce_i64: bad arguments");
+    // (n must be the same on every rank, as for any collective: with n == 0 everywhere nobody enters RCCL)
     if (n == 0) return BXMI_OK;
     const int rc = rccl().all_reduce(buf_dev, buf_dev, (size_t)n, /* ncclInt64 */ 4, /* ncclSum */ 0, c->comm, bxmi::as_stream(stream));
     return rc == 0 ? BXMI_OK : rccl_fail("ncclAllReduce", rc);

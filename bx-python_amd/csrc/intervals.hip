@@ -2568,6 +2568,7 @@ static int bd_prepare_index(bxmi_ivl *h, hipStream_t st)
     if (h->has_reversed || h->n < 4096 || shift > BD_MAX_SHIFT || shift < BM_MIN_SHIFT) return BXMI_OK;
     // Units of 2^19 coordinates first (runs twice as long, 12 KiB of LDS for duplicated coordinates: enough for an index
     // whose duplicates are accidents), then units of 2^18 (64 KiB: rank tables for clumped cells).
+    int tried = -1;  // unit width (log2) of the geometry tried last
     for (int ulog = g_opt_bd_unit_log2 ? (int)g_opt_bd_unit_log2 : BD_UNIT_LOG2; ulog >= 18 || ulog == (int)g_opt_bd_unit_log2; ulog--) {
         BmGeom g;
         g.cmin = h->geom.cmin;
@@ -2575,6 +2576,8 @@ static int bd_prepare_index(bxmi_ivl *h, hipStream_t st)
         g.shift = shift;
         const int f = ulog - shift;
         g.f = f < 0 ? 0 : (f > BD_MAX_F ? BD_MAX_F : f);
+        if (g.shift + g.f == tried) break;  // (buckets wider than the unit asked for: f clamps to 0, the same images again)
+        tried = g.shift + g.f;
         g.rshift = BD_RSHIFT;
         g.dshift = 0;
         const BdLayout L = bd_layout(g.shift + g.f);
@@ -2627,7 +2630,7 @@ static int sl_prepare_index(bxmi_ivl *h, hipStream_t st)
 
 // The slice geometry of one index for a batch with `tile` queries per tile: the unit grows while its keys fit, its
 // offsets leave 12 bits for the record's length, and its runs stay short enough for one pass of a wave.
-static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_t *run_len, bool flat_walk = false)
+static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_t *run_len)
 {
     BmGeom g;
     g.cmin = h->geom.cmin, g.cmax = h->cmax, g.shift = h->geom.shift;
@@ -2644,7 +2647,6 @@ static BmGeom sl_geom(const bxmi_ivl *h, int64_t tile, size_t *lds_bytes, int64_
             // (the flat walk keeps every lane busy whatever the run length, but a unit's directory has 2047 cells however
             // wide the unit is: a larger unit means more keys per cell and more halvings per lookup -- measured: the genome
             // pass 1.0 -> 2.4 ms with units as large as the LDS allows -- so the same cap serves both walks)
-            (void)flat_walk;
             if (h->sl_need[k] > (unsigned)SL_CAP || g.shift + k > g_opt_sl_rbits || (tile << k) / nb_used > g_opt_sl_run_cap) break;
             f = k;
         }
@@ -2684,12 +2686,12 @@ static int bm_launch_tiles(const BmLaunch &L, hipStream_t st)
     constexpr int TILE = THREADS * ITEMS;
     bxmi_ivl *h = L.owner;
     if (L.pad) {
-        const size_t lds = (size_t)(TILE + 3 * THREADS) * 4 + BM_NB * 4 + BM_NB * 2 + 64 + 528;  // (+ the waves' first starts: order watch)
+        const size_t lds = (size_t)(TILE + 3 * THREADS) * 4 + BM_NB * 4 + BM_NB * 2 + 64;
         BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, true>), lds));
         hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
                            h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, h->bd_tend.as<unsigned>());
     } else {
-        const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64 + 528;
+        const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64;
         BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, false>), lds));
         hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, false>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
                            h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, (unsigned *)nullptr);
@@ -2906,7 +2908,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         if (slices) {
             size_t lds = 0;
             int64_t run_len = 0;
-            sg.g = sl_geom(hs[i], tile, &lds, &run_len, slices_flat);
+            sg.g = sl_geom(hs[i], tile, &lds, &run_len);
             if (lds > sl_lds) sl_lds = lds;
             if (run_len < sl_run) sl_run = run_len;
         } else if (cells) {

@@ -270,7 +270,8 @@ const char *bxmi_tab_chrom_name(const bxmi_tab_t *b, int32_t id);
  * lib/bx/bitset_builders.py:31-45 one bitset), so a genome is sharded by chromosome with NO data-path exchange; what
  * the ranks do exchange is the vector of per-chromosome overlap totals: an int64 sum all-reduce, RCCL over xGMI.
  * rank 0 makes the 128-byte id and hands it to the others through whatever launched them; every rank then creates
- * its communicator on its CURRENT device.  bxmi_allreduce_i64 works in place on device memory, ordered on `stream`.
+ * its communicator on its CURRENT device.  bxmi_allreduce_i64 works in place on device memory, ordered on `stream`;
+ * n must be the same on every rank (n == 0 returns at once without entering the collective).
  * librccl.so is opened on first use; without it these four calls fail with BXMI_EHIP and nothing else is affected. */
 typedef struct bxmi_comm bxmi_comm_t;
 int bxmi_comm_unique_id(void *id128);
