@@ -60,13 +60,18 @@ for r in range(rounds):
     opt("ivl.bitmap_min", 1)
     # (partition, count_cells, bitmap, slice): direct kernel, round 1's pass in both search variants, the large-batch pass
     # on images first / slices first / slices only, each with random tile shapes, unit sizes and run widths
-    for part, cells, bitmap, slices in ((0, 1, 0, 0), (1, 1, 0, 0), (1, 0, 0, 0), (1, 1, -1, 0), (1, 1, -1, -1), (1, 1, -1, 1), (1, 1, -1, 1)):
+    for part, cells, bitmap, slices, flat, dense in ((0, 1, 0, 0, -1, -1), (1, 1, 0, 0, -1, -1), (1, 0, 0, 0, -1, -1), (1, 1, -1, 0, 1, 1), (1, 1, -1, 0, 0, 1),
+                                                     (1, 1, -1, -1, -1, -1), (1, 1, -1, 1, 0, 0), (1, 1, -1, 1, 0, 0), (1, 1, -1, -1, 1, 1)):
         knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64, 1])),
                      sorted_path=int(rng.integers(0, 2)))
         opt("ivl.partition", part)
         opt("ivl.count_cells", cells)
         opt("ivl.bitmap", bitmap)
         opt("ivl.slice", slices)
+        opt("ivl.flat", flat)    # 1: cell images of units wherever the index qualifies (the persistent walk)
+        opt("ivl.dense", dense)  # 1: dense unit images wherever it qualifies
+        opt("ivl.bd_w8", int(rng.integers(-1, 2)))
+        opt("ivl.bd_chunk", int(rng.choice([0, 1024, 20000])))
         opt("ivl.bm_variant", knobs["variant"])
         opt("ivl.sl_f", knobs["f"])
         opt("ivl.sl_lanes", knobs["lanes"])
@@ -74,11 +79,12 @@ for r in range(rounds):
         got_c, got_t = ix.count(qs, qe)
         if not np.array_equal(got_c, want_c) or got_t != want_t:
             bad = np.nonzero(got_c != want_c)[0][:5]
-            print("MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells, bitmap=bitmap, slices=slices, **knobs),
+            print("MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells, bitmap=bitmap, slices=slices, flat=flat, dense=dense, **knobs),
                   ix.flat_state(), ix.dense_state(), ix.slice_state(), bad, qs[bad], qe[bad], got_c[bad], want_c[bad])
             sys.exit(1)
     opt("ivl.count_cells", 1)
     opt("ivl.bitmap", -1)
+    opt("ivl.flat", -1), opt("ivl.dense", -1), opt("ivl.bd_w8", -1), opt("ivl.bd_chunk", 0)
     m = min(nq, 20000)
     w_off, w_hits = t.find_batch(qs[:m], qe[:m])
     for part, sliced in ((0, 0), (1, 0), (1, 1), (1, 1)):  # direct kernels, the bucketed find, find through the exchange (twice, other knobs)

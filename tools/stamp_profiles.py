@@ -28,8 +28,8 @@ for src, dst in (("bench.json", "_bench_line.json"), ("prof_stats.json", "_bench
     json.loads(line)
     open(os.path.join(prof, prefix + dst), "w").write(line + "\n")
 rows = {r["kernel"]: float(r["avg_ns"]) / 1e6 for r in csv.DictReader(open(os.path.join(prof, prefix + "_kernel_stats.csv")))}
-keys = [k for k in rows if k.startswith(("bm_params", "bm_sorted_check", "ivl_local_count", "bm_tile_sort", "bm_transpose", "bm_plan", "bm_search_pipe", "bm_unpermute",
-                                         "bm_fold_totals", "bd_transpose", "bd_plan", "bd_search", "bd_unpermute"))]
+keys = [k for k in rows if k.startswith(("bm_params", "bm_sorted_check", "ivl_local_count", "bm_tile_sort", "bm_transpose", "bm_plan", "bm_unpermute",
+                                         "bm_fold_totals", "bd_transpose", "bd_plan", "bd_search", "bw_search", "bd_unpermute"))]
 readme = os.path.join(prof, "README.md")
 text = open(readme).read()
 text = re.sub(r"their averages \(.*?\) are the pass time", "their averages (%s = %.3f ms) are the pass time"

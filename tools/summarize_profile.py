@@ -56,9 +56,9 @@ for k, v in dur.items():
 # FETCH_SIZE is in KiB and reads HALF of a streaming read on gfx950 (checked below on the bitset popcount, whose
 # byte count is known); WRITE_SIZE is in KiB and exact.  Correction as MI355X_MICROARCH.md prescribes.
 # the bitmap-cell pass (count_bitmap.hpp); whatever template arguments the run used
-pass_prefixes = ["bm_params_kernel", "bm_sorted_check_kernel", "ivl_local_count_kernel", "bm_tile_sort_kernel", "bm_transpose_kernel", "bm_plan_kernel",
-                 "bm_search_pipe_kernel", "bm_search_kernel", "bm_unpermute_kernel", "bm_fold_totals_kernel", "bd_transpose_kernel", "bd_plan_kernel",
-                 "bd_search_kernel", "bd_unpermute_kernel"]
+pass_prefixes = ["bm_params_kernel", "bm_probe_kernel", "bm_sorted_check_kernel", "ivl_local_count_kernel", "bm_tile_sort_kernel", "bm_transpose_kernel",
+                 "bm_plan_kernel", "bm_unpermute_kernel", "bm_fold_totals_kernel", "bd_transpose_kernel", "bd_plan_kernel", "bd_search_kernel",
+                 "bw_search_kernel", "bd_unpermute_kernel"]
 pass_kernels = [k for k in out if any(k.startswith(pre) for pre in pass_prefixes)]
 tot = 0.0
 detail = {}
