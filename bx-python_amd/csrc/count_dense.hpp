@@ -257,9 +257,18 @@ constexpr int BP_UNIT_LOG2 = 18;
 constexpr int BP_RSHIFT = 18;     // record = offset : 18 | length : 14 (16383 = escape)
 constexpr int BP_MARGIN = 16384;
 
+// A HARD cell (two or more duplicated coordinates among its 32, or more than 126 extra copies) gets a TABLE in the image's
+// overflow area: 32 16-bit words, T[p] = #{keys of the cell below position p}; its bitmap word holds the table's byte
+// offset inside the image.  Round 4: until then a hard cell's rank was finished by a binary search in the sorted array
+// in HBM -- rare (3 in 10 000 look-ups on configs[1]) but 17 % of the walk's passes met one, and the wait for those loads
+// drains the wave's whole memory pipe, record loads and count stores alike: 38 us of a 235 us kernel.  Cells beyond the
+// area's room, or with 65536 keys and more, keep the search (offset word = all ones).
+constexpr int BP_TABLES = 190;       // tables per unit image: what is left of the ninth 16 KB piece the image load moves anyway
+constexpr unsigned BP_NO_TABLE = 0xFFFFFFFFu;
+
 struct BpLayout {
     int nce, ncs;              // cells, sentinel included
-    int cellsE, cellsS, hdr, bytes;
+    int cellsE, cellsS, hdr, ov, bytes;
 };
 
 __host__ __device__ inline BpLayout bp_layout(int unit_log2)
@@ -271,7 +280,8 @@ __host__ __device__ inline BpLayout bp_layout(int unit_log2)
     L.cellsE = 0;
     L.cellsS = L.nce * 8;
     L.hdr = (L.cellsS + L.ncs * 8 + 15) & ~15;  // header: [0] eLo, [1] sLo, [2..3] first coordinate of the unit (int64)
-    L.bytes = L.hdr + 16;
+    L.ov = L.hdr + 16;                          // the hard cells' tables, 64 bytes each
+    L.bytes = L.ov + BP_TABLES * 64;
     return L;
 }
 
@@ -284,6 +294,8 @@ __global__ __launch_bounds__(BD_THREADS) void bp_image_kernel(const int32_t *__r
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     __shared__ int s_r[2];
     __shared__ int scan_tmp[16];
+    __shared__ int s_ntab;  // tables handed out so far (both arrays share the area)
+    if (threadIdx.x == 0) s_ntab = 0;
     const int unit = blockIdx.x;
     const int ulog = g.shift + g.f;
     const BpLayout L = bp_layout(ulog);
@@ -338,15 +350,32 @@ __global__ __launch_bounds__(BD_THREADS) void bp_image_kernel(const int32_t *__r
         for (int c = c_lo; c < c_hi; c++) {
             const int base = first[c] < above ? first[c] : above;
             unsigned meta = (unsigned)base & 0xFFFFFu;
+            unsigned word = bm[c];
             if (dcnt[c] > 0u) {
                 if (__popc(dmask[c]) == 1 && dcnt[c] < (unsigned)BM_HARD)
                     meta |= ((unsigned)(__ffs((int)dmask[c]) - 1) << 20) | (dcnt[c] << 25);
                 else {
                     meta |= (unsigned)BM_HARD << 25;
                     hard++;
+                    // the cell's keys are A[r0 + base .. r0 + next): its rank table, if the area has room
+                    int next = c + 1 < c_hi ? (first[c + 1] < above ? first[c + 1] : above) : above;
+                    next = next < ns ? next : ns;
+                    word = BP_NO_TABLE;
+                    if (next - base < 65536) {
+                        const int slot = atomicAdd(&s_ntab, 1);
+                        if (slot < BP_TABLES) {
+                            word = (unsigned)(L.ov + slot * 64);
+                            unsigned short *tab = reinterpret_cast<unsigned short *>(img + word);
+                            const long long cell0 = lo + (long long)c * 32;
+                            for (int p = 0; p < 32; p++) {
+                                const long long key = cell0 + p;
+                                tab[p] = (unsigned short)(key > INT_MAX ? next - base : bd_lower_bound(A, r0 + base, r0 + next, (int)key) - (r0 + base));
+                            }
+                        }
+                    }
                 }
             }
-            out[c] = make_uint2(bm[c], meta);
+            out[c] = make_uint2(word, meta);
         }
         if (threadIdx.x == 0 && ns >= (1 << 20)) atomicAdd(&stats[1], 1u);
         __syncthreads();
@@ -530,6 +559,7 @@ struct BdImage {
     unsigned off_mask;  // offsets of a record: the unit's width - 1
     // cell images (FMT 1)
     lds_cell_p cE, cS;
+    lds_u16_p img16;   // the image as 16-bit words: the hard cells' rank tables are addressed by their byte offset
     int eLo, sLo;
     long long lo;
     const int32_t *s_ord, *e_sorted;
@@ -552,6 +582,14 @@ __device__ __forceinline__ unsigned bp_cell_rank(lds_cell_p cells, unsigned rel,
     return (meta & 0xFFFFFu) + (unsigned)__popc(bits & below) + (meta >> 25) * dup;
 }
 
+// a hard cell's rank: from its table in LDS, or (no room for a table) from the sorted array
+__device__ __forceinline__ int bp_hard_rank(const BdImage &I, lds_cell_p cells, unsigned rel, const int32_t *__restrict__ a, int slice_lo)
+{
+    const bd_v2u c = __builtin_bit_cast(bd_v2u, cells[rel >> 5]);
+    if (c.x != BP_NO_TABLE) return (int)(c.y & 0xFFFFFu) + (int)I.img16[(c.x >> 1) + (rel & 31u)];
+    return bm_hard_rank(cells, rel, a, slice_lo, I.lo);
+}
+
 // the count of one record (16 bits, 0xFFFF = ask the index again)
 __device__ __forceinline__ unsigned bp_count_record(const BdImage &I, unsigned rec)
 {
@@ -563,8 +601,8 @@ __device__ __forceinline__ unsigned bp_count_record(const BdImage &I, unsigned r
     unsigned c = (unsigned)I.bias + (rS - rE);
     if ((mE > mS ? mE : mS) >= ((unsigned)BM_HARD << 25)) {  // a hard cell (rare: the index qualifies only while they are)
         int hE = (int)rE, hS = (int)rS;
-        if ((mE >> 25) == (unsigned)BM_HARD) hE = bm_hard_rank(I.cE, relE, I.e_sorted, I.eLo, I.lo);
-        if ((mS >> 25) == (unsigned)BM_HARD) hS = bm_hard_rank(I.cS, relS, I.s_ord, I.sLo, I.lo);
+        if ((mE >> 25) == (unsigned)BM_HARD) hE = bp_hard_rank(I, I.cE, relE, I.e_sorted, I.eLo);
+        if ((mS >> 25) == (unsigned)BM_HARD) hS = bp_hard_rank(I, I.cS, relS, I.s_ord, I.sLo);
         c = (unsigned)(I.bias + (hS - hE));
     }
     c = c < 0xFFFFu ? c : 0xFFFFu;
@@ -814,6 +852,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
     if (FMT == 2) {
     } else if (FMT == 1) {
         unsigned char *base = reinterpret_cast<unsigned char *>(dyn);
+        I.img16 = (lds_u16_p) reinterpret_cast<unsigned short *>(base);
         I.cE = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsE);
         I.cS = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsS);
         const unsigned *hdr = reinterpret_cast<const unsigned *>(base + LP.hdr);
@@ -1141,6 +1180,7 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
         BdImage I;
         {
             unsigned char *base = reinterpret_cast<unsigned char *>(dyn);
+            I.img16 = (lds_u16_p) reinterpret_cast<unsigned short *>(base);
             I.cE = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsE);
             I.cS = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsS);
             const unsigned *hdr = reinterpret_cast<const unsigned *>(base + LP.hdr);
