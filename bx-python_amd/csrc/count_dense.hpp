@@ -1149,14 +1149,17 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
             s_nlong = 0, s_next = B * (BD_THREADS / 64);  // (every wave starts with the batch of its number)
             s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
         }
-        unsigned a_nx, e_nx;
+        // The run table of the NEXT batch is requested by hand as well (two 16-bit loads per lane): left to the compiler they
+        // were issued where they are used, behind a full drain of the memory pipe -- record loads and count stores -- once per
+        // batch.  They travel under the batch's passes; bw_wait_runs says when they are certain to have landed.
+        unsigned a_nx = 0u, e_nx = 0u;
+        bool nx_in = false;
         auto load_runs = [&](int tbase) {
             const int t = tbase + lane;
-            const int tc = t < t1 && lane < B ? t : t0;  // a valid address: no branch around the loads
-            const unsigned a = runs0[tc];
-            const unsigned e = runs1[tc];
-            a_nx = t < t1 && lane < B ? a : 0u;
-            e_nx = t < t1 && lane < B ? e : 0u;
+            nx_in = t < t1 && lane < B;
+            const int tc = nx_in ? t : t0;  // a valid address: no branch around the loads
+            asm volatile("global_load_ushort %0, %1, off" : "=v"(a_nx) : "v"(runs0 + tc) : "memory");
+            asm volatile("global_load_ushort %0, %1, off" : "=v"(e_nx) : "v"(runs1 + tc) : "memory");
         };
         int tb_next = t0 + B * wave;
         load_runs(tb_next);
@@ -1201,7 +1204,15 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
         auto advance = [&]() -> bool {
             while (tb_next < t1) {
                 const int t = tb_next + lane;
-                const unsigned a = a_nx, e = e_nx;
+                // the runs of this batch were requested one batch ago: 2 x (its passes) memory operations followed them, so
+                // once the batch had DEPTH - 1 passes the ring's own wait count has seen them land; a shorter batch (or none:
+                // the item's first, or an empty one skipped just now) waits for everything
+                // (one statement names the registers, on every path: two of them made the compiler copy the registers in front of
+                // the waits -- reading them while the loads were in flight; tools/check_ring_isa.py follows these loads too)
+                if (((total + 63u) >> 6) < (unsigned)(DEPTH - 1)) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                asm volatile("s_waitcnt vmcnt(%2) ; runs %0 %1" : "+v"(a_nx), "+v"(e_nx) : "n"(2 * DEPTH - 2) : "memory");
+                const unsigned a = nx_in ? a_nx : 0u, e = nx_in ? e_nx : 0u;
+                total = 0u;  // (nothing of this batch has been issued yet)
                 int tn = 0;
                 if (lane == 0) tn = atomicAdd(&s_next, B);
                 tb_next = t0 + __builtin_amdgcn_readfirstlane(tn);

@@ -3,8 +3,9 @@
 the compiler cannot know: the record loads of the ring are issued by hand (inline asm), so nothing tells the register
 allocator that a destination register is still being written.  For every such kernel, in program order:
 
-  * a hand-issued `global_load_dwordx4 v[a:b]` puts v[a:b] "in flight";
-  * a hand-issued `s_waitcnt vmcnt(K) ; ring v[a:b]` lands them -- and the registers it names must BE the destination of
+  * a hand-issued `global_load_dwordx4 v[a:b]` (or `global_load_ushort vN`: the run table of the persistent walk) puts its
+    destination "in flight";
+  * a hand-issued `s_waitcnt vmcnt(K) ; ring v[a:b]` (`; runs vA vB`) lands them -- and the registers it names must BE the destination of
     a load in flight (if the compiler copied the value somewhere else in between, the copy read a register before its
     data arrived);
   * any other instruction that names a register in flight is an error.
@@ -76,7 +77,7 @@ def transfer(block, state, errors=None):
     st = dict(state)
     loads = waits = 0
     for no, kind, code, raw in block["ins"]:
-        if kind == "asm" and code.startswith("global_load_dwordx4"):
+        if kind == "asm" and (code.startswith("global_load_dwordx4") or code.startswith("global_load_ushort")):
             dest = vregs(code.split(",")[0])
             addr = vregs(",".join(code.split(",")[1:]).split(";")[0])
             bad = ((dest | addr) - (dest & addr)) & set(st) | (addr & set(st))
@@ -85,8 +86,8 @@ def transfer(block, state, errors=None):
             for r in dest:
                 st[r] = no
             loads += 1
-        elif kind == "asm" and code.startswith("s_waitcnt") and "ring" in code:
-            named = vregs(code.split("ring")[1])
+        elif kind == "asm" and code.startswith("s_waitcnt") and ("ring" in code or "runs" in code):
+            named = vregs(code.split("ring")[1] if "ring" in code else code.split("runs")[1])
             waits += 1
             if "vmcnt(0)" in code:  # (the drain behind the loop: everything lands)
                 st.clear()
