@@ -326,8 +326,8 @@ def bench_clustered(torch, reps=5, nt=10_000_000, nq=100_000_000, hot_spots=20_0
             _ffi.call("bxmi_set_option", b"ivl.partition", -1)
         out[label] = dict(ms=round(ms, 4), m_queries_per_s=round(nq / ms / 1e3, 1), frac_of_hbm_peak=round(alg_bytes_of(nq, nt) / ms / 1e6 / HBM_PEAK_GBS, 4),
                           same_as_direct_kernel=bool(torch.equal(counts[:m], ref)))
-    out["search_stage_of_this_index"] = dict(zip(("flat_walk_on_cell_images", "dense_unit_images", "key_slices"),
-                                                 (ix.flat_state()[0], ix.dense_state()[0], ix.slice_state()[0])))
+    out["search_stage_of_this_index"] = dict(zip(("flat_walk_on_cell_images", "dense_unit_images", "key_slices", "offset_cell_images"),
+                                                 (ix.flat_state()[0], ix.dense_state()[0], ix.slice_state()[0], ix.sparse_state()[0])))
     ix.close()
     return out
 
@@ -767,8 +767,8 @@ def main():
                         first_sorted_pass_after_shuffled_ms=round(first_sorted_ms, 4))
         del sqs, sqe, scounts
 
-    stages = dict(zip(("flat_walk_on_cell_images", "dense_unit_images", "key_slices"),
-                      (ix.flat_state()[0], ix.dense_state()[0], ix.slice_state()[0])))
+    stages = dict(zip(("flat_walk_on_cell_images", "dense_unit_images", "key_slices", "offset_cell_images"),
+                      (ix.flat_state()[0], ix.dense_state()[0], ix.slice_state()[0], ix.sparse_state()[0])))
     # configs[3] on all the ranks of this job (strong scaling, chromosomes dealt by LPT, totals all-reduced): a collective
     # leg, so every rank walks through it; rank 0 keeps the result for the line
     genome_leg = None

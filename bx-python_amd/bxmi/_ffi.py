@@ -55,6 +55,7 @@ _SIGNATURES = {
     "bxmi_ivl_slice_state": [vp, _p(C.c_int), vp],
     "bxmi_ivl_dense_state": [vp, _p(C.c_int), vp],
     "bxmi_ivl_flat_state": [vp, _p(C.c_int), _p(i64)],
+    "bxmi_ivl_sparse_state": [vp, _p(C.c_int), _p(i64), _p(C.c_int)],
     "bxmi_ivl_count_width": [vp, _p(C.c_int), _p(i64)],
     "bxmi_ivl_order_state": [vp, _p(C.c_int), _p(i64)],
     "bxmi_ivl_find": [vp, vp, vp, i64, vp, vp, i64, _p(i64)],

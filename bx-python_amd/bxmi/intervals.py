@@ -89,6 +89,14 @@ class IntervalIndex:
         call("bxmi_ivl_flat_state", self._h, C.byref(st), C.byref(hc))
         return st.value, hc.value
 
+    def sparse_state(self):
+        """(state, hard_cells, cell_log2) of the offset-cell images a sparse index takes: 1 = usable, -1 = the index does not
+        qualify, 0 = undecided; cell_log2 = the cell width chosen from the density (6..8)."""
+        self._ready()
+        st, hc, k = C.c_int(0), C.c_int64(0), C.c_int(0)
+        call("bxmi_ivl_sparse_state", self._h, C.byref(st), C.byref(hc), C.byref(k))
+        return st.value, hc.value, k.value
+
     def count_width(self):
         """(bits, wide_counts): 8 or 16 bits per count between the search and the un-permute kernel of a flat-walk pass, and how
         many counts did not fit 8 bits so far (as last mirrored to the host)."""

@@ -34,6 +34,7 @@
 //
 // count(q) = (sLo + rankS(off + len)) - (eLo + rankE(off + 1))        (intersection.pyx:180-189)
 #pragma once
+#include "offset_cells.hpp"
 
 namespace bxmi {
 
@@ -271,17 +272,20 @@ struct BpLayout {
     int cellsE, cellsS, hdr, ov, bytes;
 };
 
-__host__ __device__ inline BpLayout bp_layout(int unit_log2)
+// cell_log2: 5 = bitmap cells; 6..8 = offset cells (offset_cells.hpp: same 8 bytes per cell, same header, a smaller overflow
+// area; the starts' margin is the longest query the record format holds)
+__host__ __device__ inline BpLayout bp_layout(int unit_log2, int cell_log2 = 5)
 {
     BpLayout L;
     const int UW = 1 << unit_log2;
-    L.nce = (UW >> 5) + 2;
-    L.ncs = ((UW + BP_MARGIN) >> 5) + 1;
+    const int margin = cell_log2 == 5 ? BP_MARGIN : bo_margin(cell_log2);
+    L.nce = (UW >> cell_log2) + 2;
+    L.ncs = ((UW + margin) >> cell_log2) + 1;
     L.cellsE = 0;
     L.cellsS = L.nce * 8;
     L.hdr = (L.cellsS + L.ncs * 8 + 15) & ~15;  // header: [0] eLo, [1] sLo, [2..3] first coordinate of the unit (int64)
     L.ov = L.hdr + 16;                          // the hard cells' tables, 64 bytes each
-    L.bytes = L.ov + BP_TABLES * 64;
+    L.bytes = L.ov + (cell_log2 == 5 ? BP_TABLES : BO_TABLES) * 64;
     return L;
 }
 
@@ -376,6 +380,85 @@ __global__ __launch_bounds__(BD_THREADS) void bp_image_kernel(const int32_t *__r
                 }
             }
             out[c] = make_uint2(word, meta);
+        }
+        if (threadIdx.x == 0 && ns >= (1 << 20)) atomicAdd(&stats[1], 1u);
+        __syncthreads();
+    }
+    if (hard) atomicAdd(&stats[0], hard);
+    if (threadIdx.x == 0) {
+        unsigned *hdr = reinterpret_cast<unsigned *>(img + L.hdr);
+        hdr[0] = (unsigned)r0s[0], hdr[1] = (unsigned)r0s[1];
+        hdr[2] = (unsigned)(unsigned long long)lo, hdr[3] = (unsigned)((unsigned long long)lo >> 32);
+    }
+}
+
+// Offset cells (offset_cells.hpp; g.dshift = cell width - 5): one workgroup per unit, one array at a time -- the keys of
+// every cell counted with LDS atomics, a block scan for the cells' bases, then every cell packs its (at most five) keys
+// straight from the sorted array; cells with more keys get a list in the overflow area while it has room.
+// stats: [0] hard cells, [1] units whose slice holds 2^20 keys or more
+__global__ __launch_bounds__(BD_THREADS) void bo_image_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted, int n,
+                                                              BmGeom g, unsigned char *__restrict__ images, unsigned *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ int s_r[2];
+    __shared__ int scan_tmp[16];
+    __shared__ int s_ntab;  // lists handed out so far (both arrays share the area)
+    if (threadIdx.x == 0) s_ntab = 0;
+    const int unit = blockIdx.x;
+    const int k = 5 + g.dshift;
+    const int ulog = g.shift + g.f;
+    const BpLayout L = bp_layout(ulog, k);
+    const long long UW = 1ll << ulog;
+    const long long lo = (long long)g.cmin + (long long)unit * UW;
+    unsigned char *__restrict__ img = images + (size_t)unit * L.bytes;
+    unsigned hard = 0;
+    int r0s[2];
+    for (int arr = 0; arr < 2; arr++) {
+        const int32_t *__restrict__ A = arr == 0 ? e_sorted : s_ord;
+        const int nc = arr == 0 ? L.nce : L.ncs;
+        const long long span = arr == 0 ? UW + 1 : UW + bo_margin(k);  // keys with rel in [0, span) belong to this image
+        unsigned *cnt = reinterpret_cast<unsigned *>(dyn);
+        if (threadIdx.x < 2) s_r[threadIdx.x] = bm_rank_lt64(A, n, threadIdx.x == 0 ? lo : lo + span);
+        for (int c = threadIdx.x; c < nc; c += BD_THREADS) cnt[c] = 0u;
+        __syncthreads();
+        const int r0 = s_r[0], r1 = s_r[1], ns = r1 - r0;
+        r0s[arr] = r0;
+        for (int r = r0 + (int)threadIdx.x; r < r1; r += BD_THREADS) {
+            const unsigned rel = (unsigned)((long long)A[r] - lo);
+            atomicAdd(&cnt[rel >> k], 1u);
+        }
+        __syncthreads();
+        const int K = (nc + BD_THREADS - 1) / BD_THREADS;
+        const int c_lo = (int)threadIdx.x * K < nc ? (int)threadIdx.x * K : nc, c_hi = c_lo + K < nc ? c_lo + K : nc;
+        int sum = 0;
+        for (int c = c_lo; c < c_hi; c++) sum += (int)cnt[c];
+        int tot;
+        int base = block_exclusive_scan(sum, OpSum(), 0, scan_tmp, &tot);
+        uint2 *out = reinterpret_cast<uint2 *>(img + (arr == 0 ? L.cellsE : L.cellsS));
+        for (int c = c_lo; c < c_hi; c++) {
+            const int m = (int)cnt[c];
+            const long long cell0 = lo + ((long long)c << k);
+            const int32_t *keys = A + r0 + base;  // the cell's keys: A is sorted, the cells partition the coordinates
+            unsigned lo_w, hi_w;
+            if (m <= BO_INLINE) {
+                unsigned char offs[BO_INLINE];
+#pragma unroll
+                for (int i = 0; i < BO_INLINE; i++) offs[i] = i < m ? (unsigned char)((long long)keys[i] - cell0) : (unsigned char)0xFF;
+                bo_pack(offs, m, (unsigned)base, lo_w, hi_w);
+            } else {
+                hard++;
+                lo_w = BP_NO_TABLE, hi_w = ((unsigned)base & 0xFFFFFu) | BO_HARD;
+                if (m <= BO_LIST) {
+                    const int slot = atomicAdd(&s_ntab, 1);
+                    if (slot < BO_TABLES) {
+                        lo_w = (unsigned)(L.ov + slot * 64);
+                        unsigned char *list = img + lo_w;
+                        for (int i = 0; i < BO_LIST; i++) list[i] = i < m ? (unsigned char)((long long)keys[i] - cell0) : (unsigned char)0xFF;
+                    }
+                }
+            }
+            out[c] = make_uint2(lo_w, hi_w);
+            base += m;
         }
         if (threadIdx.x == 0 && ns >= (1 << 20)) atomicAdd(&stats[1], 1u);
         __syncthreads();
@@ -550,6 +633,7 @@ typedef unsigned bd_v4u __attribute__((ext_vector_type(4)));
 typedef unsigned bd_v2u __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const bd_v4u *lds_v4u_p;
 typedef __attribute__((address_space(3))) const unsigned *lds_u32_p;
+typedef __attribute__((address_space(3))) const unsigned char *lds_u8_p;
 
 struct BdImage {
     lds_v4u_p bitsE, bitsS;
@@ -560,6 +644,10 @@ struct BdImage {
     // cell images (FMT 1)
     lds_cell_p cE, cS;
     lds_u16_p img16;   // the image as 16-bit words: the hard cells' rank tables are addressed by their byte offset
+    // offset cells (offset_cells.hpp): the image as bytes (the hard cells' lists), the record's length shift, the cell width
+    lds_u8_p img8;
+    int rshift, cell_log2;
+    unsigned cell_mask;
     int eLo, sLo;
     long long lo;
     const int32_t *s_ord, *e_sorted;
@@ -1095,6 +1183,72 @@ __device__ __forceinline__ void bp_count_slot(const BdImage &I, bd_v4u v, unsign
     }
 }
 
+// ---- offset cells (offset_cells.hpp) ----
+// a hard cell's rank: from its list in LDS, or (no room for a list, more than 64 keys) from the sorted array
+__device__ __forceinline__ int bo_hard_rank(const BdImage &I, lds_cell_p cells, unsigned rel, const int32_t *__restrict__ a, int slice_lo)
+{
+    const unsigned ci = rel >> I.cell_log2, p = rel & I.cell_mask;
+    const bd_v2u c = __builtin_bit_cast(bd_v2u, cells[ci]);
+    const unsigned base = c.y & 0xFFFFFu, next = (unsigned)(cells[ci + 1u] >> 32) & 0xFFFFFu;  // (every cell carries its base, hard or not)
+    if (c.x != BP_NO_TABLE) {
+        unsigned r = base;
+        for (unsigned i = 0; i < next - base; i++) r += (unsigned)I.img8[c.x + i] < p ? 1u : 0u;
+        return (int)r;
+    }
+    const long long key = I.lo + (long long)rel;
+    if (key > INT_MAX) return (int)next;  // every int32 key is below it
+    return global_rank_lt(a, slice_lo + (int)base, slice_lo + (int)next, (int)key) - slice_lo;
+}
+
+// the count of one record whose cells may be hard (16 bits, 0xFFFF = ask the index again)
+__device__ __forceinline__ unsigned bo_count_record(const BdImage &I, unsigned rec)
+{
+    const unsigned off = rec & I.off_mask, len = rec >> I.rshift;
+    const unsigned relE = off + 1u, relS = off + len;
+    const bd_v2u ce = __builtin_bit_cast(bd_v2u, I.cE[relE >> I.cell_log2]), cs = __builtin_bit_cast(bd_v2u, I.cS[relS >> I.cell_log2]);
+    const int rE = ce.y >= BO_HARD ? bo_hard_rank(I, I.cE, relE, I.e_sorted, I.eLo) : (int)bo_rank(ce.x, ce.y, relE & I.cell_mask);
+    const int rS = cs.y >= BO_HARD ? bo_hard_rank(I, I.cS, relS, I.s_ord, I.sLo) : (int)bo_rank(cs.x, cs.y, relS & I.cell_mask);
+    unsigned c = (unsigned)(I.bias + (rS - rE));
+    c = c < 0xFFFFu ? c : 0xFFFFu;
+    return rec == BM_REC_ESC ? 0xFFFFu : c;
+}
+
+// the four counts of a slot: all eight cells read before the first is used, hard cells noticed once per slot (bp_count_slot's shape)
+__device__ __forceinline__ void bo_count_slot(const BdImage &I, bd_v4u v, unsigned (&c)[4])
+{
+    const unsigned rec[4] = {v.x, v.y, v.z, v.w};
+    unsigned relE[4], relS[4];
+    unsigned long long cellE[4], cellS[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const unsigned off = rec[j] & I.off_mask;
+        relE[j] = off + 1u, relS[j] = off + (rec[j] >> I.rshift);
+        cellE[j] = I.cE[relE[j] >> I.cell_log2];
+        cellS[j] = I.cS[relS[j] >> I.cell_log2];
+    }
+    unsigned worst = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bd_v2u ce = __builtin_bit_cast(bd_v2u, cellE[j]), cs = __builtin_bit_cast(bd_v2u, cellS[j]);
+        const unsigned rE = bo_rank(ce.x, ce.y, relE[j] & I.cell_mask), rS = bo_rank(cs.x, cs.y, relS[j] & I.cell_mask);
+        c[j] = (unsigned)I.bias + (rS - rE);
+        const unsigned m = ce.y > cs.y ? ce.y : cs.y;
+        worst = worst > m ? worst : m;
+    }
+    if (worst >= BO_HARD) {  // some hard cell among the eight (rare): those records again, one by one
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned mE = __builtin_bit_cast(bd_v2u, cellE[j]).y, mS = __builtin_bit_cast(bd_v2u, cellS[j]).y;
+            if ((mE > mS ? mE : mS) >= BO_HARD) c[j] = bo_count_record(I, rec[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        c[j] = c[j] < 0xFFFFu ? c[j] : 0xFFFFu;
+        c[j] = rec[j] == BM_REC_ESC ? 0xFFFFu : c[j];
+    }
+}
+
 template <bool W8>
 __device__ __forceinline__ void bw_store_slot(unsigned short *__restrict__ out, unsigned idx4, const unsigned (&c)[4])
 {
@@ -1111,8 +1265,14 @@ __device__ __forceinline__ void bw_store_slot(unsigned short *__restrict__ out, 
     }
 }
 
-template <bool W8, int DEPTH>
-__global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
+// WIDE: the unit images are offset cells (sparse indexes; the cell width travels in the segment's geometry, g.dshift) --
+// units of up to 2^20 coordinates, so a (tile, unit) run can be hundreds of slots long: a wave's batch is then fewer tiles
+// (the run-end bitmap holds 4096 slots whatever their number), and a run is "long" from 4096 / B slots on.
+// THREADS: 1024 = one workgroup per CU (bitmap cells: a unit's image is 147 KB); 512 = two per CU (offset cells: 72 KB) -- one
+// loads its next image while the other looks records up.  (Measured on configs[3] with one workgroup per CU and units of 2^21:
+// 13.7 us of every 41 us item were image load, ring start and drain, with the vector units idle.)
+template <bool W8, int DEPTH, bool WIDE = false, int THREADS = BD_THREADS>
+__global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                const int *__restrict__ n_items, const unsigned short *__restrict__ unitT, int64_t ntp,
                                                                const unsigned *__restrict__ recs /* tile-sorted records, padded runs */,
                                                                unsigned short *__restrict__ out /* their counts, same order */, int tile_log2,
@@ -1120,9 +1280,11 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
 {
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    __shared__ uint2 s_long[BD_LONG_CAP];  // {first record, length} of the long runs met during the walk
+    constexpr int LONG_CAP = THREADS == BD_THREADS ? BD_LONG_CAP : BD_LONG_CAP / 2;
+    constexpr int PF = THREADS == BD_THREADS ? BW_PF : 10;  // 16-byte pieces per thread of an image (10 x 512 x 16 = 80 KB)
+    __shared__ uint2 s_long[LONG_CAP];  // {first record, length} of the long runs met during the walk
     __shared__ int s_nlong, s_next, s_item_next;
-    __shared__ __attribute__((aligned(8))) unsigned s_mask[BD_THREADS / 64][BW_MASK_WORDS];
+    __shared__ __attribute__((aligned(8))) unsigned s_mask[THREADS / 64][BW_MASK_WORDS];
     const int nit = *n_items;
     const int per_xcd = (nit + 7) >> 3;
     const int xcd = (int)(blockIdx.x & 7);
@@ -1140,13 +1302,19 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
         const int unit = item.x & 0xffff, t0 = item.y, t1 = item.z;
         const BmSeg &sg = segs[item.x >> 16];
         const BmGeom g = sg.g;
-        const BpLayout LP = bp_layout(g.shift + g.f);
+        const int cell_log2 = WIDE ? 5 + g.dshift : 5;
+        const BpLayout LP = bp_layout(g.shift + g.f, cell_log2);
         const unsigned short *__restrict__ runs0 = unitT + (int64_t)unit * ntp;
         const unsigned short *__restrict__ runs1 = runs0 + ntp;  // (the next unit's first slots, or the row behind the last unit)
         int B = BW_B;
-        while (B > 8 && (t1 - t0) < 2 * (BD_THREADS / 64) * B) B >>= 1;
+        while (B > 8 && (t1 - t0) < 2 * (THREADS / 64) * B) B >>= 1;
+        if (WIDE) {  // one and a half times the item's mean run, B times, has to fit the bitmap
+            const int mean4 = item.w / (t1 - t0) / 4 + 2;
+            while (B > 8 && B * (mean4 + (mean4 >> 1)) > BW_MASK_WORDS * 32) B >>= 1;
+        }
+        const unsigned long_slots = WIDE ? (unsigned)(BW_MASK_WORDS * 32 / B) : (unsigned)BD_LONG_SLOTS;
         if (threadIdx.x == 0) {
-            s_nlong = 0, s_next = B * (BD_THREADS / 64);  // (every wave starts with the batch of its number)
+            s_nlong = 0, s_next = B * (THREADS / 64);  // (every wave starts with the batch of its number)
             s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
         }
         // The run table of the NEXT batch is requested by hand as well (two 16-bit loads per lane): left to the compiler they
@@ -1164,17 +1332,21 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
         int tb_next = t0 + B * wave;
         load_runs(tb_next);
         {   // the image (streams through L2 once: non-temporal loads); every load of a lane issued before its first LDS store
+            // (Requested one item ahead instead -- into registers, in front of the barrier at the end of the item before, so that
+            // the loads travel while the slower waves finish: the 36 registers are live across the loop's back edge and the
+            // allocator spills five of the nine pieces beside the 1024-thread walk's 127 -- search 204 -> 245 us on configs[1];
+            // the 512-thread walk keeps them (126 registers) and gains 0.5-2 %: its CU's other workgroup hides the load already.)
             const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.pimages + (size_t)unit * LP.bytes);
             const int n4 = LP.bytes >> 4;
-            bm_v4i v[BW_PF];
+            bm_v4i v[PF];
 #pragma unroll
-            for (int k = 0; k < BW_PF; k++) {
-                const int i = k * BD_THREADS + (int)threadIdx.x;
+            for (int k = 0; k < PF; k++) {
+                const int i = k * THREADS + (int)threadIdx.x;
                 v[k] = __builtin_nontemporal_load(src + (i < n4 ? i : n4 - 1));
             }
 #pragma unroll
-            for (int k = 0; k < BW_PF; k++) {
-                const int i = k * BD_THREADS + (int)threadIdx.x;
+            for (int k = 0; k < PF; k++) {
+                const int i = k * THREADS + (int)threadIdx.x;
                 if (i < n4) reinterpret_cast<bm_v4i *>(dyn)[i] = v[k];
             }
         }
@@ -1192,6 +1364,8 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
             I.lo = (long long)((unsigned long long)hdr[2] | ((unsigned long long)hdr[3] << 32));
             I.s_ord = sg.ix.s_ord, I.e_sorted = sg.e_sorted;
             I.off_mask = (1u << (g.shift + g.f)) - 1u;
+            I.img8 = (lds_u8_p)base;
+            I.rshift = g.rshift, I.cell_log2 = cell_log2, I.cell_mask = (1u << cell_log2) - 1u;
         }
         // a slot no query owns (the end of a tile's room, past every unit's padding): where the ring's idle passes store
         unsigned *const nobody = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(out) +
@@ -1218,10 +1392,10 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
                 tb_next = t0 + __builtin_amdgcn_readfirstlane(tn);
                 load_runs(tb_next);
                 unsigned n4 = e > a ? ((e + 3u) >> 2) - (a >> 2) : 0u;  // 16-byte slots that hold the run
-                if (n4 > (unsigned)BD_LONG_SLOTS) {  // sorted / clumped input: left to the whole workgroup
+                if (n4 > long_slots) {  // sorted / clumped input: left to the whole workgroup
                     const int k = atomicAdd(&s_nlong, 1);
                     const unsigned first = ((unsigned)t * tile_slots << 2) + a;
-                    if (k < BD_LONG_CAP) {
+                    if (k < LONG_CAP) {
                         s_long[k] = make_uint2(first, e - a);
                     } else {  // (a full list: the run's counts say "ask the index again" -- exactness never depends on the list)
                         const unsigned esc[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
@@ -1298,6 +1472,8 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
                         }
                         if (BW_EXP & 1)
                             c[0] = rv.x & 0xffu, c[1] = rv.y & 0xffu, c[2] = rv.z & 0xffu, c[3] = rv.w & 0xffu;
+                        else if (WIDE)
+                            bo_count_slot(I, rv, c);
                         else
                             bp_count_slot(I, rv, c);
                         if (!(BW_EXP & 2) || (c[0] & c[1] & c[2] & c[3]) == 0x12345u) bw_store_slot<W8>(out, ring_idx[d], c);
@@ -1315,13 +1491,16 @@ __global__ __launch_bounds__(BD_THREADS) void bw_search_kernel(const BmSeg *__re
         for (int d = 0; d < DEPTH; d++) bd_wait<0>(ring_v[d]);
         __syncthreads();
         {
-            const int nl = s_nlong < BD_LONG_CAP ? s_nlong : BD_LONG_CAP;
+            const int nl = s_nlong < LONG_CAP ? s_nlong : LONG_CAP;
             for (int k = 0; k < nl; k++) {
                 const uint2 lr = s_long[k];
                 const unsigned q0 = lr.x >> 2, nq4 = ((lr.x + lr.y + 3u) >> 2) - q0;  // (padded runs: whole slots)
-                for (unsigned q = threadIdx.x; q < nq4; q += BD_THREADS) {
+                for (unsigned q = threadIdx.x; q < nq4; q += THREADS) {
                     unsigned c[4];
-                    bp_count_slot(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
+                    if (WIDE)
+                        bo_count_slot(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
+                    else
+                        bp_count_slot(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
                     bw_store_slot<W8>(out, q0 + q, c);
                 }
             }

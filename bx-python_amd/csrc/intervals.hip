@@ -2143,6 +2143,9 @@ static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most th
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
 static int64_t g_opt_flat = -1;       // the flat 16-byte walk on cell images of 2^18-coordinate units (count_dense.hpp, bp_*): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
+static int64_t g_opt_sparse = -1;     // offset-cell images for sparse indexes (offset_cells.hpp; the persistent walk): -1 = sparse indexes that qualify, batches that bring enough queries per unit; 0 = never; 1 = whatever the batch size
+static int64_t g_opt_bo_cell_log2 = 0;  // their cell width: 0 = from the index's density, 6..8 = forced
+static int64_t g_opt_bo_min_per_unit = 4096;  // queries per unit image a batch must bring (an image is 72 KB to load whatever the batch)
 static int64_t g_opt_dense = -1;      // search stage on dense unit images (count_dense.hpp): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
 static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
@@ -2186,6 +2189,9 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.bm_hard_ppm", &g_opt_bm_hard_ppm, nullptr},
     {"ivl.flat", &g_opt_flat, nullptr},
     {"ivl.dense", &g_opt_dense, nullptr},
+    {"ivl.sparse", &g_opt_sparse, nullptr},
+    {"ivl.bo_cell_log2", &g_opt_bo_cell_log2, [](int64_t value) -> int64_t { return value < BO_MIN_K || value > BO_MAX_K ? 0 : value; }},
+    {"ivl.bo_min_per_unit", &g_opt_bo_min_per_unit, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
     {"ivl.bd_chunk", &g_opt_bd_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
     {"ivl.bd_blocks", &g_opt_bd_blocks, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.bd_w8", &g_opt_bd_w8, nullptr},
@@ -2255,6 +2261,10 @@ struct bxmi_ivl {
     int64_t bp_hard_cells = 0;
     BmGeom bp_geom{0, 0, 0, 0, 0, 0, 0, BP_RSHIFT, 0};
     DevBuf bp_images, bp_stats;
+    int bo_state = 0;            // offset-cell images of units (sparse indexes): 0 = not decided yet, 1 = built and the index qualifies, -1 = it does not
+    int64_t bo_hard_cells = 0;
+    BmGeom bo_geom{0, 0, 0, 0, 0, 0, 0, BP_RSHIFT, 0};  // dshift = cell width - 5
+    DevBuf bo_images;
     bool bd_blocks = false;      // the images' ranks are relative to blocks of 1024 cells (more than 32767 keys in some unit's slice)
     DevBuf bd_images, bd_stats, bd_cnt16, bd_unitT, bd_tend;
     // 8-bit counts between the search and the un-permute kernel (bm_count_segments): the un-permute kernel keeps a running
@@ -2560,6 +2570,46 @@ static int bp_prepare_index(bxmi_ivl *h, hipStream_t st)
     return BXMI_OK;
 }
 
+// Offset-cell images (offset_cells.hpp) for a sparse index: the cell width from the density, units of 4096 cells (fewer when the
+// span is small: a unit is at most 2^BD_MAX_F buckets), built once per sealed index.
+static int bo_prepare_index(bxmi_ivl *h, hipStream_t st)
+{
+    h->bo_state = -1;
+    const int shift = h->geom.shift;
+    int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin + 1;
+    const int k = g_opt_bo_cell_log2 ? (int)g_opt_bo_cell_log2 : bo_cell_log2_for(span, h->n);
+    // (units of at least two buckets, as for bitmap cells: the tile sort can then start every unit's run on a whole slot)
+    if (h->has_reversed || h->n < 4096 || k == 0 || shift > bo_rshift(k) - 1 || shift < BM_MIN_SHIFT) return BXMI_OK;
+    BmGeom g;
+    g.cmin = h->geom.cmin;
+    g.cmax = h->cmax;
+    g.shift = shift;
+    const int f = bo_rshift(k) - shift;
+    g.f = f > BD_MAX_F ? BD_MAX_F : f;
+    g.rshift = bo_rshift(k);
+    g.dshift = k - 5;
+    const BpLayout L = bp_layout(g.shift + g.f, k);
+    g.nce = L.nce, g.ncs = L.ncs;
+    g.stride = L.bytes >> 4;
+    const int units = BM_NB >> g.f;
+    BXMI_TRY(h->bo_images.reserve((size_t)units * L.bytes));
+    BXMI_TRY(h->bp_stats.reserve(64));
+    BXMI_HIP(hipMemsetAsync(h->bp_stats.p, 0, 64, st));
+    const size_t lds = (size_t)L.ncs * sizeof(int32_t);
+    BXMI_TRY(allow_big_lds(bo_image_kernel, lds));
+    hipLaunchKernelGGL(bo_image_kernel, dim3((unsigned)units), dim3(BD_THREADS), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n, g,
+                       h->bo_images.as<unsigned char>(), h->bp_stats.as<unsigned>());
+    BXMI_LAUNCH_CHECK();
+    unsigned stats[2] = {0, 0};
+    BXMI_HIP(hipMemcpyAsync(stats, h->bp_stats.p, sizeof(stats), hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    h->bo_geom = g;
+    h->bo_hard_cells = stats[0];
+    const int64_t cells = 2 * ((span >> k) + 1);  // cells that queries can land in: the span of the index, ends and starts
+    if (stats[1] == 0 && (int64_t)stats[0] * 1000000 <= cells * g_opt_bm_hard_ppm) h->bo_state = 1;
+    return BXMI_OK;
+}
+
 // Dense unit images (count_dense.hpp): built once per sealed index; the kernel reports whether the index fits the format.
 static int bd_prepare_index(bxmi_ivl *h, hipStream_t st)
 {
@@ -2676,6 +2726,7 @@ struct BmLaunch {
     const unsigned *gate;
     bool pad = false;  // the units' runs on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): tile stride TILE + BM_PAD_ROOM
     bool w8 = false;   // 8-bit counts between the search and the un-permute kernel (padded layout, cell images)
+    bool wide = false; // the cell images are offset cells (sparse indexes)
     unsigned *descent = nullptr;  // no order check in this pass: bm_params_kernel's probe raises this word when it sees a descent
     unsigned *xcd_next = nullptr;  // eight item counters of the persistent search, zeroed with the partial totals
 };
@@ -2805,12 +2856,13 @@ static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
 }
 
 // the persistent walk on cell images (count_dense.hpp, bw_*): one workgroup per CU, items handed out per XCD
-template <bool W8>
+template <bool W8, bool WIDE>
 static int bw_launch_search(const BmLaunch &L, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
-    BXMI_TRY(allow_big_lds((bw_search_kernel<W8, 3>), L.search_lds));
-    hipLaunchKernelGGL((bw_search_kernel<W8, 3>), dim3(256), dim3(BD_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+    constexpr int THREADS = WIDE ? BD_THREADS / 2 : BD_THREADS;  // offset cells: two workgroups per CU
+    BXMI_TRY(allow_big_lds((bw_search_kernel<W8, 3, WIDE, THREADS>), L.search_lds));
+    hipLaunchKernelGGL((bw_search_kernel<W8, 3, WIDE, THREADS>), dim3(WIDE ? 512 : 256), dim3(THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
                        h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(), h->bd_cnt16.as<unsigned short>(),
                        L.tile_log2, L.gate, L.xcd_next);
     BXMI_LAUNCH_CHECK();
@@ -2826,7 +2878,8 @@ static int bd_launch_search(const BmLaunch &L, unsigned grid, int fmt /* 0 dense
 {
     if (fmt == 1) {
         if (!L.pad) return fail(BXMI_ESTATE, "bd_launch_search: cell images on packed runs");
-        return L.w8 ? bw_launch_search<true>(L, st) : bw_launch_search<false>(L, st);
+        if (L.wide) return L.w8 ? bw_launch_search<true, true>(L, st) : bw_launch_search<false, true>(L, st);
+        return L.w8 ? bw_launch_search<true, false>(L, st) : bw_launch_search<false, false>(L, st);
     }
     if (fmt == 2) return bd_launch_search_t<2, false, 0, 2, false>(L, grid, st);  // (never padded: see bm_count_segments)
     if (L.pad) return blocks ? bd_launch_search_t<0, true, 0, 3, true, true>(L, grid, st) : bd_launch_search_t<0, false, 0, 3, true, true>(L, grid, st);
@@ -2877,8 +2930,9 @@ static int ensure_feedback(bxmi_ivl *h, hipStream_t st)
 static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *qs, const int32_t *const *qe, const int64_t *nq,
                              int32_t *const *counts, int64_t *const *totals_dev, hipStream_t st, int kind, BmFindCtx *fx = nullptr)
 {
-    if (kind < 2 || kind > 4) return fail(BXMI_EINVAL, "bm_count_segments: no such search stage (%d)", kind);
-    const bool slices = kind == 2, cells = kind == 4;
+    if (kind < 2 || kind > 5) return fail(BXMI_EINVAL, "bm_count_segments: no such search stage (%d)", kind);
+    const bool wide = kind == 5;  // offset cells: the cell images of sparse indexes
+    const bool slices = kind == 2, cells = kind == 4 || wide;
     const bool slices_flat = slices && !fx && g_opt_sl_flat != 0;  // (find() needs 32-bit counts apart from the records and the tile-sorted offsets)
     const bool dense = kind == 3 || cells || slices_flat /* the flat walk */;
     bxmi_ivl *h = hs[0];
@@ -2888,12 +2942,14 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (n > 4096) return fail(BXMI_EINVAL, "bxmi_ivl_count_multi: more than 4096 indexes in one batch");
     // tile shape: 32768-query tiles halve the number of (tile, bucket) runs the search has to fetch, but their sort
     // kernel runs one workgroup per CU and wants a grid of several hundred full tiles
-    int variant = g_opt_bm_variant >= 0 ? (int)g_opt_bm_variant : (n == 1 && nq_all >= ((int64_t)32 << 20) ? 2 : 0);
+    // (a batch over several indexes: every segment starts on a group of 64 tiles, so the big tiles only where the segments are
+    // big too -- a genome of 100 M queries, not its eighth on one of eight GPUs)
+    int variant = g_opt_bm_variant >= 0 ? (int)g_opt_bm_variant : (nq_all >= ((int64_t)32 << 20) * (n == 1 ? 1 : 2) ? 2 : 0);
     // cell images are searched on padded runs only: a unit of two buckets needs a tile sort whose threads own two buckets each
     // (the 1024-thread shapes), the 512-thread shape owns four
     if (cells && variant == 0)
         for (int i = 0; i < n; i++)
-            if (hs[i]->bp_geom.f < 2) variant = 1;
+            if ((wide ? hs[i]->bo_geom : hs[i]->bp_geom).f < 2) variant = 1;
     const int tile_log2 = variant == 2 ? 15 : 14;
     const int64_t tile = (int64_t)1 << tile_log2;
     // the batch's tile numbering: every segment starts on a plan-group boundary
@@ -2912,7 +2968,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
             if (lds > sl_lds) sl_lds = lds;
             if (run_len < sl_run) sl_run = run_len;
         } else if (cells) {
-            sg.g = hs[i]->bp_geom;
+            sg.g = wide ? hs[i]->bo_geom : hs[i]->bp_geom;
         } else {
             sg.g = hs[i]->bd_geom;
         }
@@ -2921,7 +2977,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         sg.tile0 = ntp;
         sg.ntiles = div_up(nq[i], tile);
         sg.dimages = hs[i]->bd_images.as<unsigned char>();
-        sg.pimages = hs[i]->bp_images.as<unsigned char>();
+        sg.pimages = wide ? hs[i]->bo_images.as<unsigned char>() : hs[i]->bp_images.as<unsigned char>();
         sg.smeta = slices ? hs[i]->sl_meta.as<int4>() : nullptr;
         sg.ix = index_dev(hs[i]);
         sg.e_sorted = hs[i]->e_sorted.as<int32_t>();
@@ -3033,6 +3089,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.gate = unsorted;
     L.descent = descent;
     L.pad = pad;
+    L.wide = wide;
     L.xcd_next = reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS + 4);
     // 8-bit counts (0xFF = recomputed by the un-permute kernel, exact either way): half the bytes of the second exchange
     // when the counts are small.  Cell images only serve indexes without piled-up coordinates, so the density says what to
@@ -3040,13 +3097,18 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     // prediction misses -- long queries, targets crowded into part of the span -- the feedback catches: once more than one
     // count in 64 did not fit, the index keeps 16-bit counts (worst case before that: every count recomputed, ~2 x the pass).
     L.w8 = false;
-    if (pad && cells && n == 1 && g_opt_bd_w8 != 0) {
+    // (a batch over several indexes -- a genome -- keeps the feedback with its first index: every index has to be sparse enough,
+    // none may have switched the narrow counts off)
+    if (pad && cells && g_opt_bd_w8 != 0) {
         BXMI_TRY(ensure_feedback(h, st));
-        const unsigned long long wide = *reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host);
-        if ((int64_t)wide * 64 > h->w8_queries && wide > 4096) h->w8_off = true;
-        const int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin + 1;
-        const bool sparse_enough = (int64_t)h->n * 2048 < span * 128;
-        L.w8 = g_opt_bd_w8 > 0 || (!h->w8_off && sparse_enough);
+        const unsigned long long wide_counts = *reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host);
+        if ((int64_t)wide_counts * 64 > h->w8_queries && wide_counts > 4096) h->w8_off = true;
+        bool narrow = true;
+        for (int i = 0; i < n; i++) {
+            const int64_t span = (int64_t)hs[i]->cmax - (int64_t)hs[i]->geom.cmin + 1;
+            narrow = narrow && !hs[i]->w8_off && (int64_t)hs[i]->n * 2048 < span * 128;
+        }
+        L.w8 = g_opt_bd_w8 > 0 || narrow;
         if (L.w8) h->w8_queries += nq_all;
     }
     if (unsorted) {
@@ -3181,12 +3243,26 @@ static int ivl_find_sliced(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, in
 // Which search stage serves a sealed index in the large-batch pass: 0 = neither (older paths), 1 = bucket images,
 // 2 = key slices, 3 = dense unit images (dense indexes try them before the bucket images).  Images cost 0.5 B per coordinate of the span and win on dense indexes; sparse ones (fewer than one
 // target per 64 coordinates) and spans whose bucket image outgrows the LDS take slices.  Prepared on first use.
-static int bm_choose_stage(bxmi_ivl *h, hipStream_t st, int *kind)
+static int bm_choose_stage(bxmi_ivl *h, hipStream_t st, int *kind, int64_t nq)
 {
     *kind = 0;
     if (h->has_reversed || h->n < 4096) return BXMI_OK;
     int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin;
     if (span < 0) span = 0;
+    // Sparse indexes: offset-cell images on the persistent walk, when the batch brings enough queries per unit image (a unit's
+    // image is 72 KB to load however few queries it serves; key slices stage a few KB)
+    // (ivl.flat / ivl.dense / ivl.slice set to force or forbid a stage leave this one out, ivl.sparse = 1 forces it)
+    if ((g_opt_sparse > 0 || (g_opt_sparse < 0 && g_opt_flat < 0 && g_opt_dense < 1 && g_opt_slice < 1)) &&
+        (g_opt_bo_cell_log2 || bo_cell_log2_for(span + 1, h->n))) {
+        if (h->bo_state == 0) BXMI_TRY(bo_prepare_index(h, st));
+        if (h->bo_state == 1) {
+            const int64_t units = (span >> (h->bo_geom.shift + h->bo_geom.f)) + 1;
+            if (g_opt_sparse > 0 || nq >= units * g_opt_bo_min_per_unit) {
+                *kind = 5;
+                return BXMI_OK;
+            }
+        }
+    }
     const bool slices_first = g_opt_dense != 1 && g_opt_flat != 1 && (g_opt_slice == 1 || (g_opt_slice < 0 && (span / h->n >= 64 || h->geom.shift > BD_MAX_SHIFT)));
     if (slices_first) {
         if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
@@ -3361,6 +3437,7 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         h->sl_state = 0;
         h->bd_state = 0;
         h->bp_state = 0;
+        h->bo_state = 0;
         h->w8_off = false, h->w8_queries = 0;  // (the feedback of the 8-bit counts belongs to the index that was)
         if (h->bd_fb_host) {
             BXMI_HIP(hipMemsetAsync(h->bd_fb.p, 0, 64, st));
@@ -3406,6 +3483,15 @@ extern "C" int bxmi_ivl_flat_state(const bxmi_ivl_t *h, int *state, int64_t *har
     BXMI_TRY(need_sealed(h, "bxmi_ivl_flat_state"));
     if (state) *state = h->bp_state;
     if (hard_cells) *hard_cells = h->bp_hard_cells;
+    return BXMI_OK;
+}
+
+extern "C" int bxmi_ivl_sparse_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells, int *cell_log2)
+{
+    BXMI_TRY(need_sealed(h, "bxmi_ivl_sparse_state"));
+    if (state) *state = h->bo_state;
+    if (hard_cells) *hard_cells = h->bo_hard_cells;
+    if (cell_log2) *cell_log2 = h->bo_state == 1 ? 5 + h->bo_geom.dshift : 0;
     return BXMI_OK;
 }
 
@@ -3497,7 +3583,7 @@ extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_
                         (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_bitmap_min));
     if (bitmap) {
         int kind = 0;
-        BXMI_TRY(bm_choose_stage(h, st, &kind));
+        BXMI_TRY(bm_choose_stage(h, st, &kind, nq));
         if (kind) return bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &total_dev, st, kind);
     }
     if (partition) return ivl_count_partitioned(h, qs, qe, nq, counts, total_dev, st);
@@ -3530,11 +3616,11 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
     if (n < 0 || (n > 0 && (!hs || !qs || !qe || !nq))) return fail(BXMI_EINVAL, "bxmi_ivl_count_multi_dev: bad arguments");
     hipStream_t st = as_stream(stream);
     // indexes whose batch can ride the bitmap-cell pass are answered together (one pass, six launches); the others one by one
-    std::vector<bxmi_ivl *> fh[4];  // by search stage (kind - 1): [1] slices, [2] dense unit images, [3] cell images of units
-    std::vector<const int32_t *> fqs[4], fqe[4];
-    std::vector<int64_t> fnq[4];
-    std::vector<int32_t *> fc[4];
-    std::vector<int64_t *> ft[4];
+    std::vector<bxmi_ivl *> fh[5];  // by search stage (kind - 1): [1] slices, [2] dense unit images, [3] cell images of units, [4] offset cells
+    std::vector<const int32_t *> fqs[5], fqe[5];
+    std::vector<int64_t> fnq[5];
+    std::vector<int32_t *> fc[5];
+    std::vector<int64_t *> ft[5];
     std::vector<int> rest;
     int64_t nq_all = 0;
     for (int i = 0; i < n; i++) {
@@ -3552,7 +3638,7 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
         // a segment occupies whole groups of 64 tiles of scratch whatever its size: in a batch over hundreds of indexes
         // (a scaffold-level assembly) the ones with a handful of queries are answered one by one instead
         const bool tiny = n > 256 && nq[i] < 65536;
-        if (fused && counts[i] && !tiny) BXMI_TRY(bm_choose_stage(h, st, &kind));
+        if (fused && counts[i] && !tiny) BXMI_TRY(bm_choose_stage(h, st, &kind, nq[i]));
         if (kind) {
             const int k = kind - 1;
             fh[k].push_back(h), fqs[k].push_back(qs[i]), fqe[k].push_back(qe[i]), fnq[k].push_back(nq[i]), fc[k].push_back(counts[i]);
@@ -3561,7 +3647,7 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
             rest.push_back(i);
         }
     }
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 5; k++)
         if (!fh[k].empty())
             BXMI_TRY(bm_count_segments(fh[k].data(), (int)fh[k].size(), fqs[k].data(), fqe[k].data(), fnq[k].data(), fc[k].data(), ft[k].data(), st,
                                        k + 1));

@@ -131,6 +131,12 @@ int bxmi_ivl_dense_state(const bxmi_ivl_t *h, int *state, int64_t *worst);
  * index does not qualify (span wider than 2^29, reversed targets, too many cells with several duplicated coordinates:
  * *hard_cells of them).  This is the stage a dense index takes first.  Introspection only. */
 int bxmi_ivl_flat_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
+/* The same for the cell images of SPARSE indexes (offset_cells.hpp: a cell of 2^k coordinates, k = 6..8 from the index's
+ * density, holds the offsets of up to five keys; units of up to 2^20 coordinates on the same persistent walk, two workgroups per CU): *state = 0
+ * not decided yet, 1 = usable, -1 = the index does not qualify (too dense, reversed targets, too many cells with more than
+ * five keys: *hard_cells of them); *cell_log2 = k when usable.  A sparse index takes this stage when a batch brings enough
+ * queries per unit image (ivl.bo_min_per_unit), key slices otherwise.  Introspection only. */
+int bxmi_ivl_sparse_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells, int *cell_log2);
 /* The width of the counts a flat-walk pass over cell images hands from its search to its un-permute kernel: *bits = 8
  * while the index is sparse enough for small counts (fewer than 128 targets per 2048 coordinates) and fewer than one count
  * in 64 of the passes so far came back as "does not fit" (*wide_counts of them, as last mirrored to the host; such counts

@@ -403,7 +403,7 @@ def test_incremental_append_reseals(O, IntervalIndex):
         assert np.array_equal(ix.find(qs, qe)[1], t.find_batch(qs, qe)[1])
 
 
-@pytest.mark.parametrize("stage", ["slices", "dense", "flat"])
+@pytest.mark.parametrize("stage", ["slices", "dense", "flat", "sparse"])
 @pytest.mark.parametrize("shape", ["uniform", "sorted", "one_bucket", "messy", "ragged_tail", "dups"])
 def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
     """The large-batch count pass (count_bitmap.hpp, and its search stages count_slices.hpp and count_dense.hpp) against the oracle
@@ -476,6 +476,34 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                 assert got_total == want_total
             if shape == "dups":
                 assert (state[1][1] > 100) if stage == "dense" else (state[1] > 0)  # overflow entries / hard cells
+            return
+        if stage == "sparse":
+            # offset-cell images (one target per 333 coordinates: cells of 256 by the density; narrower ones forced): tile shapes,
+            # work items of every size, both count widths; queries longer than the record's length field (4095 at cells of
+            # 256) are escapes; "dups": cells with more than five keys -- lists in LDS, and two cells with a thousand keys each
+            # that are finished by a search in the sorted array
+            set_opt("ivl.sparse", 1)
+            if shape == "dups":
+                set_opt("ivl.bm_hard_ppm", 10**6)
+            width = [0]
+            for k, (variant, chunk, w8, cell) in enumerate(((0, 0, 0, 0), (1, 4096, 0, 7), (2, 1 << 20, 1, 6), (-1, 20000, -1, 8), (0, 1024, 1, 0),
+                                                            (2, 0, -1, 7), (1, 65536, 0, 6))):
+                set_opt("ivl.sorted_path", k % 2)
+                set_opt("ivl.bm_variant", variant)
+                set_opt("ivl.bd_chunk", chunk)
+                set_opt("ivl.bd_w8", w8)
+                if cell != width[0]:
+                    set_opt("ivl.bo_cell_log2", cell)
+                    ix.seal()  # (the cell width is decided when the index is prepared)
+                    width[0] = cell
+                got, got_total = ix.count(qs, qe)
+                state = ix.sparse_state()
+                assert state[0] == 1 and state[2] == (cell or 8) and ix.slice_state()[0] == 0 and ix.flat_state()[0] == 0, (state, ix.slice_state())
+                bad = np.nonzero(got != want)[0]
+                assert len(bad) == 0, (shape, stage, variant, chunk, w8, cell, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+                assert got_total == want_total
+            if shape == "dups":
+                assert state[1] > 0  # hard cells
             return
         set_opt("ivl.dense", 0)
         set_opt("ivl.flat", 0)
@@ -760,7 +788,7 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
     assert (wide >= counts[:1_000_000]).all()
 
 
-@pytest.mark.parametrize("stage", ["dense", "flat"])
+@pytest.mark.parametrize("stage", ["dense", "flat", "sparse"])
 def test_padded_runs_on_many_full_tiles(O, IntervalIndex, stage):
     """The padded layout of the flat walk (every unit's run of a tile on whole 16-byte slots, ring of record loads) at the
     shape the headline uses: 32768-query tiles, all of them full but the last, batches of 64 tiles per wave, several rounds
@@ -779,13 +807,16 @@ def test_padded_runs_on_many_full_tiles(O, IntervalIndex, stage):
     ix = make_index(IntervalIndex, s, e)
     set_opt("ivl.partition", 1)
     set_opt("ivl.bm_variant", 2)
-    set_opt("ivl.flat", 1 if stage == "flat" else 0)
-    set_opt("ivl.dense", 1)
+    if stage == "sparse":  # offset cells of 128 coordinates, units of 2^19: runs of ~280 records, batches of 32 tiles per wave
+        set_opt("ivl.sparse", 1)
+    else:
+        set_opt("ivl.flat", 1 if stage == "flat" else 0)
+        set_opt("ivl.dense", 1)
     try:
         for w8 in (0, 1, -1):
             set_opt("ivl.bd_w8", w8)
             got, got_total = ix.count(qs, qe)
-            state = ix.dense_state() if stage == "dense" else ix.flat_state()
+            state = ix.dense_state() if stage == "dense" else (ix.flat_state() if stage == "flat" else ix.sparse_state())
             assert state[0] == 1, state
             bad = np.nonzero(got != want)[0]
             assert len(bad) == 0 and got_total == want_total, (stage, w8, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
@@ -1031,6 +1062,18 @@ def test_count_multi_equals_one_index_at_a_time(O, IntervalIndex):
             assert len(bad) == 0 and int(tot[k]) == wt, ("defaults", k, ixs[k].dense_state(), bad[:5], got[bad[:5]], wc[bad[:5]], int(tot[k]), wt)
         assert [ix.flat_state()[0] for ix in ixs] == [1, 0, 1, 0, 0, 0], [ix.flat_state() for ix in ixs]
         assert [ix.slice_state()[0] for ix in ixs] == [0, 1, 0, 0, 1, 0]
+        set_opt("ivl.sparse", 1)  # the sparse ones on offset-cell images however small their batches (one pass for the two of them)
+        totals.zero()
+        IntervalIndex.count_multi_dev(ixs, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [d[3] for d in dev], [d[2].ptr for d in dev],
+                                      [totals.ptr + 8 * i for i in range(len(specs))], None)
+        _ffi.call("bxmi_synchronize", None)
+        tot = totals.to_numpy(np.int64, len(specs))
+        for k, (wc, wt) in enumerate(want):
+            got = dev[k][2].to_numpy(np.int32, dev[k][3])
+            bad = np.nonzero(got != wc)[0]
+            assert len(bad) == 0 and int(tot[k]) == wt, ("sparse", k, ixs[k].sparse_state(), bad[:5], got[bad[:5]], wc[bad[:5]], int(tot[k]), wt)
+        assert [ix.sparse_state()[0] for ix in ixs] == [0, 1, 0, 0, 1, 0], [ix.sparse_state() for ix in ixs]
+        set_opt("ivl.sparse", -1)
         set_opt("ivl.flat", 0)  # the same on dense unit images
         totals.zero()
         IntervalIndex.count_multi_dev(ixs, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [d[3] for d in dev], [d[2].ptr for d in dev],
@@ -1081,12 +1124,12 @@ def test_genome_cfg4_full_size_golden(golden_scale_doc, IntervalIndex):
         sub = np.ascontiguousarray(counts[:: g["stride"]])
         assert int(sub.sum(dtype=np.int64)) == pt["total"], chrom
         assert hashlib.sha256(sub.tobytes()).hexdigest() == pt["counts_sha256"], chrom
-        paths.add((ix.flat_state()[0], ix.slice_state()[0]))
+        paths.add((ix.flat_state()[0], ix.slice_state()[0], ix.sparse_state()[0]))
         grand += total
         ix.close()
-    # big chromosomes through the large-batch pass -- on key slices, a chromosome has one target per ~300 coordinates --
+    # big chromosomes through the large-batch pass -- on offset-cell images, a chromosome has one target per ~300 coordinates --
     # small ones (< 2 Mi queries) through the direct kernel
-    assert paths == {(0, 1), (0, 0)}, paths
+    assert paths == {(0, 0, 1), (0, 0, 0)}, paths
     assert grand > 0
 
 

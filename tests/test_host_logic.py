@@ -480,3 +480,16 @@ def test_ring_kernels_keep_registers_of_loads_in_flight_untouched():
     m = re.match(r"(\d+) kernels checked, 0 with problems", last)
     assert m and int(m.group(1)) >= 6, last  # (one shape per stage and layout since round 4)
     assert " ring " in r.stdout and "two sets" in r.stdout and "persistent walk W8 1 DEPTH 3" in r.stdout
+    assert "persistent walk W8 1 DEPTH 3 offset cells" in r.stdout and "persistent walk W8 0 DEPTH 3 offset cells" in r.stdout
+
+
+def test_offset_cells_encoding_and_unit_model(tmp_path):
+    """bx-python_amd/csrc/offset_cells.hpp is plain C++ as well as device code: tests/cpp/offset_cells_test.cpp checks the
+    cell encoding (pack / rank at every position), the record format and the density rule against brute force, and a
+    scalar model of one unit's two images -- built the way bo_image_kernel builds them, asked the way the search kernel asks
+    -- against the definition of an overlap (repeated coordinates, cells with more than five keys, units of 16..128 cells)."""
+    exe = str(tmp_path / "offset_cells_test")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "bx-python_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "cpp", "offset_cells_test.cpp"), "-o", exe])
+    out = subprocess.check_output([exe], text=True, timeout=300)
+    assert out.strip().endswith("offset cells ok"), out

@@ -158,8 +158,8 @@ def main():
     failed = 0
     for name, lines in kernels.items():
         if "bw_search_kernel" in name:  # the persistent walk: bw_search_kernel<W8, DEPTH>
-            t = re.search(r"ILb(\d)ELi(\d)E", name)
-            tag = "persistent walk W8 %s DEPTH %s" % t.groups()
+            t = re.search(r"ILb(\d)ELi(\d)ELb(\d)E", name)
+            tag = "persistent walk W8 %s DEPTH %s%s" % (t.group(1), t.group(2), " offset cells" if t.group(3) == "1" else "")
         else:
             t = re.search(r"ILi(\d)ELb(\d)ELi(\d)ELi(\d)ELb(\d)ELb(\d)E", name)
             fmt, qb, exp, depth, pipe, pad = (int(x) for x in t.groups())

@@ -28,6 +28,7 @@ rng = np.random.default_rng(int(os.environ.get("SEED", 12345)))
 rounds = int(os.environ.get("ROUNDS", 20))
 MAX_HITS = 20_000_000
 checked = 0
+sparse_served = 0
 for r in range(rounds):
     n = int(rng.choice([5000, 20000, 100000, 400000]))
     nq = int(rng.choice([3000, 20000, 70000]))
@@ -60,10 +61,18 @@ for r in range(rounds):
     opt("ivl.bitmap_min", 1)
     # (partition, count_cells, bitmap, slice): direct kernel, round 1's pass in both search variants, the large-batch pass
     # on images first / slices first / slices only, each with random tile shapes, unit sizes and run widths
-    for part, cells, bitmap, slices, flat, dense in ((0, 1, 0, 0, -1, -1), (1, 1, 0, 0, -1, -1), (1, 0, 0, 0, -1, -1), (1, 1, -1, 0, 1, 1), (1, 1, -1, 0, 0, 1),
-                                                     (1, 1, -1, -1, -1, -1), (1, 1, -1, 1, 0, 0), (1, 1, -1, 1, 0, 0), (1, 1, -1, -1, 1, 1)):
+    # sparse = 1: offset-cell images whatever the density (with ivl.bm_hard_ppm opened up: cells with more than five keys, their
+    # lists and the searches behind them are then the rule, not the exception)
+    for part, cells, bitmap, slices, flat, dense, sparse in ((0, 1, 0, 0, -1, -1, -1), (1, 1, 0, 0, -1, -1, -1), (1, 0, 0, 0, -1, -1, -1), (1, 1, -1, 0, 1, 1, -1),
+                                                             (1, 1, -1, 0, 0, 1, -1), (1, 1, -1, -1, -1, -1, -1), (1, 1, -1, 1, 0, 0, -1), (1, 1, -1, 1, 0, 0, -1),
+                                                             (1, 1, -1, -1, 1, 1, -1), (1, 1, -1, -1, -1, -1, 1), (1, 1, -1, -1, -1, -1, 1)):
         knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64, 1])),
-                     sorted_path=int(rng.integers(0, 2)))
+                     sorted_path=int(rng.integers(0, 2)), cell_log2=int(rng.choice([0, 6, 7, 8])))
+        opt("ivl.sparse", sparse)
+        opt("ivl.bo_cell_log2", knobs["cell_log2"] if sparse == 1 else 0)
+        opt("ivl.bm_hard_ppm", 1000000 if sparse == 1 and rng.random() < 0.7 else 2000)
+        if sparse == 1:
+            ix.seal()  # (the images are built once per sealed index: another width needs them again)
         opt("ivl.partition", part)
         opt("ivl.count_cells", cells)
         opt("ivl.bitmap", bitmap)
@@ -79,12 +88,15 @@ for r in range(rounds):
         got_c, got_t = ix.count(qs, qe)
         if not np.array_equal(got_c, want_c) or got_t != want_t:
             bad = np.nonzero(got_c != want_c)[0][:5]
-            print("MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells, bitmap=bitmap, slices=slices, flat=flat, dense=dense, **knobs),
-                  ix.flat_state(), ix.dense_state(), ix.slice_state(), bad, qs[bad], qe[bad], got_c[bad], want_c[bad])
+            print("MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells, bitmap=bitmap, slices=slices, flat=flat, dense=dense,
+                                            sparse=sparse, **knobs),
+                  ix.flat_state(), ix.dense_state(), ix.slice_state(), ix.sparse_state(), bad, qs[bad], qe[bad], got_c[bad], want_c[bad])
             sys.exit(1)
     opt("ivl.count_cells", 1)
     opt("ivl.bitmap", -1)
     opt("ivl.flat", -1), opt("ivl.dense", -1), opt("ivl.bd_w8", -1), opt("ivl.bd_chunk", 0)
+    opt("ivl.sparse", -1), opt("ivl.bo_cell_log2", 0), opt("ivl.bm_hard_ppm", 2000)
+    sparse_served += ix.sparse_state()[0] == 1
     m = min(nq, 20000)
     w_off, w_hits = t.find_batch(qs[:m], qe[:m])
     for part, sliced in ((0, 0), (1, 0), (1, 1), (1, 1)):  # direct kernels, the bucketed find, find through the exchange (twice, other knobs)
@@ -105,4 +117,4 @@ for r in range(rounds):
         opt(k, v)
     checked += 1
     ix.close()
-print("fuzz: %d rounds, all counts and hit lists equal the oracle" % checked)
+print("fuzz: %d rounds (%d with offset-cell images), all counts and hit lists equal the oracle" % (checked, sparse_served))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ / LDS counters of the flat-walk search kernel (tools/count_variants.py, one variant); OUT dir as $1
+# SQ / LDS counters of the search kernel of the count pass (tools/count_variants.py, one variant); OUT dir as $1
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 REPO=$PWD
@@ -32,7 +32,7 @@ for l in open(os.path.join(O, 'pmc_index.txt')):
     if f:
         for r in csv.DictReader(open(f[0])):
             kn = r['Kernel_Name']
-            if 'bd_search' in kn:
+            if 'bd_search' in kn or 'bw_search' in kn:
                 acc[kn.split('(')[0].replace('void ', '').replace('bxmi::', '')[:36] + ' ' + r['Counter_Name']].append(float(r['Counter_Value']))
     out.write(l.strip() + '\n')
     for k, v in sorted(acc.items()):
