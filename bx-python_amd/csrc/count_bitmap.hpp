@@ -157,9 +157,31 @@ __device__ __forceinline__ int bm_rank_lt64(const int32_t *__restrict__ a, int n
 // The flag is read and written with ORDINARY accesses on purpose: raising it with device-scope (write-through) stores
 // from 2048 workgroups serialises them at the memory side (measured: 76 us for a shuffled batch); ordinary stores of the
 // same value meet in each XCD's L2 and are written back at the kernel boundary, which is all the next kernel needs.
-__global__ __launch_bounds__(256) void bm_sorted_check_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ unsorted)
+// BOUNDS (a sorted batch on cell images, count_dense.hpp bs_*): the same read of the starts also says where every UNIT's
+// queries begin -- bounds[u] = first query whose start is not below the unit's first coordinate, u = 0 .. units (the last
+// one: where the grid ends).  In a sorted batch every boundary lies between exactly one pair of neighbouring starts (or in
+// front of the first / behind the last), so every entry is written exactly once; an unsorted batch leaves garbage nobody reads.
+struct BmBounds {
+    unsigned *bounds;  // NULL: not asked for
+    int cmin, ulog, units;
+};
+// boundaries at or below x: u = 0 .. result - 1
+__device__ __forceinline__ int bm_bounds_upto(const BmBounds &B, int x)
+{
+    if (x < B.cmin) return 0;
+    const unsigned u = (((unsigned)x - (unsigned)B.cmin) >> B.ulog) + 1u;
+    return u < (unsigned)(B.units + 1) ? (int)u : B.units + 1;
+}
+
+template <bool BOUNDS>
+__global__ __launch_bounds__(256) void bm_sorted_check_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ unsorted, BmBounds B)
 {
     constexpr int CH = 256 * 16;
+    if (BOUNDS && blockIdx.x == 0 && threadIdx.x == 0) {  // in front of the first start, behind the last
+        const int first = bm_bounds_upto(B, qs[0]), last = bm_bounds_upto(B, qs[nq - 1]);
+        for (int u = 0; u < first; u++) B.bounds[u] = 0u;
+        for (int u = last; u <= B.units; u++) B.bounds[u] = (unsigned)nq;
+    }
     for (int64_t c = blockIdx.x; c * CH < nq; c += gridDim.x) {
         if (__hip_atomic_load(unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
         const int64_t base = c * CH + 16 * (int64_t)threadIdx.x;
@@ -170,8 +192,18 @@ __global__ __launch_bounds__(256) void bm_sorted_check_kernel(const int32_t *__r
             const int nxt = qs[base + 16];
             descent = a.x > a.y || a.y > a.z || a.z > a.w || a.w > b.x || b.x > b.y || b.y > b.z || b.z > b.w || b.w > d.x || d.x > d.y ||
                       d.y > d.z || d.z > d.w || d.w > e.x || e.x > e.y || e.y > e.z || e.z > e.w || e.w > nxt;
+            if (BOUNDS && !descent && bm_bounds_upto(B, a.x) != bm_bounds_upto(B, nxt)) {  // (rare: a unit is ~100 000 queries wide)
+                const int v[17] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w, nxt};
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    for (int u = bm_bounds_upto(B, v[i]); u < bm_bounds_upto(B, v[i + 1]); u++) B.bounds[u] = (unsigned)(base + i + 1);
+            }
         } else {
-            for (int64_t i = base; i + 1 < nq && i < base + 16; i++) descent |= qs[i] > qs[i + 1];
+            for (int64_t i = base; i + 1 < nq && i < base + 16; i++) {
+                descent |= qs[i] > qs[i + 1];
+                if (BOUNDS && qs[i] <= qs[i + 1])
+                    for (int u = bm_bounds_upto(B, qs[i]); u < bm_bounds_upto(B, qs[i + 1]); u++) B.bounds[u] = (unsigned)(i + 1);
+            }
         }
         if (__syncthreads_or(descent)) {
             if (threadIdx.x == 0) __hip_atomic_store(unsorted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

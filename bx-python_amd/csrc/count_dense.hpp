@@ -1129,6 +1129,9 @@ constexpr unsigned BW_IDLE = 0xFFFFFFFFu;
 #ifndef BW_B
 #define BW_B 64  // tiles per batch of a wave, at most
 #endif
+#ifndef BS_UNROLL
+#define BS_UNROLL 1  // sorted batches: groups of four queries per lane whose loads are issued together (measured on configs[1]: 1: 0.393 ms per pass, 2: 0.426, 4: 0.524 -- the walk streams at 4.7 TB/s as it is)
+#endif
 
 __device__ __forceinline__ unsigned bw_wave_inclusive_sum(unsigned v)
 {
@@ -1508,6 +1511,176 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
         __syncthreads();
         it = it_nx;
     }
+}
+
+// ---------------------------------------------------------------------------
+// sorted batches on cell images ("bs_*"): no exchange at all
+// ---------------------------------------------------------------------------
+// A batch sorted by start (the usual BED file) has every unit's queries in ONE stretch of the query arrays, and the order
+// check that detects it has just read every start: bm_sorted_check_kernel<true> leaves the stretches' bounds.  A workgroup
+// then takes a unit's image into LDS and answers the stretch as it lies -- 16 bytes of starts, 16 of ends in, 16 bytes of
+// counts out per lane, the same look-ups as the walk above -- 12 bytes of HBM traffic per query and no scratch, where the
+// first-generation kernel for sorted batches (ivl_local_count_kernel: per 4096 queries a walk down the index's global trees,
+// two slices staged as LDS search trees, two tree searches per query) is bound by the latency chain of its setup.
+// bs_plan_kernel: stretches longer than `chunk` queries are cut (a batch crowded into a few units), the queries left of the grid
+// and right of it become items of unit -1 (answered from the sealed index, like every escape record).
+// items[i] = {unit or -1, first query, last query + 1, 0}
+__global__ __launch_bounds__(1024) void bs_plan_kernel(const unsigned *__restrict__ bounds /* [units + 1] */, int units, unsigned nq, unsigned chunk,
+                                                       int4 *__restrict__ items, int *__restrict__ n_items, const unsigned *__restrict__ gate)
+{
+    __shared__ int scan_tmp[16];
+    if (gate && *gate != 0) return;  // not sorted: the exchange answers the batch
+    int carry = 0;
+    // stretch s = -1: queries in front of unit 0; s = units: behind the last unit
+    for (int s0 = -1; s0 <= units; s0 += 1024) {
+        const int s = s0 + (int)threadIdx.x;
+        unsigned lo = 0u, hi = 0u;
+        if (s <= units) {
+            lo = s < 0 ? 0u : bounds[s];
+            hi = s == units ? nq : bounds[s + 1];
+        }
+        const unsigned n = hi > lo ? hi - lo : 0u;
+        const int cnt = (int)((n + chunk - 1u) / chunk);
+        int tot;
+        const int at = carry + block_exclusive_scan(cnt, OpSum(), 0, scan_tmp, &tot);
+        for (int k = 0; k < cnt; k++) {
+            const unsigned a = lo + (unsigned)k * chunk, b = a + chunk < hi ? a + chunk : hi;
+            items[at + k] = make_int4(s >= 0 && s < units ? s : -1, (int)a, (int)b, 0);
+        }
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *n_items = carry;
+}
+
+template <bool WIDE, int THREADS>
+__global__ __launch_bounds__(THREADS) void bs_walk_kernel(BmSeg sg, const int4 *__restrict__ items, const int *__restrict__ n_items,
+                                                          unsigned long long *__restrict__ total_slots, const unsigned *__restrict__ gate,
+                                                          unsigned *__restrict__ xcd_next /* [8], zero */,
+                                                          unsigned long long *__restrict__ order_host, unsigned long long seq)
+{
+    // what the order check found, into host memory (as ivl_local_count_kernel reports it: pass number << 1 | 1 = not sorted)
+    if (order_host && blockIdx.x == 0 && threadIdx.x == 0) *order_host = (seq << 1) | (*gate != 0 ? 1ull : 0ull);
+    if (*gate != 0) return;
+    constexpr int PF = THREADS == BD_THREADS ? BW_PF : 10;
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ int s_item_next;
+    __shared__ long long red[THREADS / 64];
+    const int nit = *n_items;
+    const int per_xcd = (nit + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7);
+    const int it_lo = xcd * per_xcd, it_hi = it_lo + per_xcd < nit ? it_lo + per_xcd : nit;  // neighbouring stretches on one XCD
+    const BmGeom g = sg.g;
+    const int cell_log2 = WIDE ? 5 + g.dshift : 5;
+    const BpLayout LP = bp_layout(g.shift + g.f, cell_log2);
+    const int64_t nq = sg.nq;
+    long long acc = 0;
+    int loaded = -1;  // the unit whose image the LDS holds
+    if (threadIdx.x == 0) s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
+    __syncthreads();
+    int it = s_item_next;
+    __syncthreads();
+    while (it < it_hi) {
+        const int4 item = items[it];
+        const int unit = item.x;
+        if (threadIdx.x == 0) s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
+        if (unit >= 0 && unit != loaded) {  // (the barrier at the end of the item before: nobody reads the old image any more)
+            const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.pimages + (size_t)unit * LP.bytes);
+            const int n4 = LP.bytes >> 4;
+            bm_v4i v[PF];
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int i = k * THREADS + (int)threadIdx.x;
+                v[k] = __builtin_nontemporal_load(src + (i < n4 ? i : n4 - 1));
+            }
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int i = k * THREADS + (int)threadIdx.x;
+                if (i < n4) reinterpret_cast<bm_v4i *>(dyn)[i] = v[k];
+            }
+            loaded = unit;
+        }
+        __syncthreads();
+        const int it_nx = s_item_next;
+        BdImage I;
+        {
+            unsigned char *base = reinterpret_cast<unsigned char *>(dyn);
+            I.img16 = (lds_u16_p) reinterpret_cast<unsigned short *>(base);
+            I.cE = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsE);
+            I.cS = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsS);
+            const unsigned *hdr = reinterpret_cast<const unsigned *>(base + LP.hdr);
+            I.eLo = (int)hdr[0], I.sLo = (int)hdr[1];
+            I.bias = I.sLo - I.eLo;
+            I.lo = (long long)((unsigned long long)hdr[2] | ((unsigned long long)hdr[3] << 32));
+            I.s_ord = sg.ix.s_ord, I.e_sorted = sg.e_sorted;
+            I.off_mask = (1u << (g.shift + g.f)) - 1u;
+            I.img8 = (lds_u8_p)base;
+            I.rshift = g.rshift, I.cell_log2 = cell_log2, I.cell_mask = (1u << cell_log2) - 1u;
+        }
+        // groups of four consecutive queries (the arrays are 16-byte aligned): [4 q, 4 q + 4) for q in [q0, q1)
+        const int64_t lo = (unsigned)item.y, hi = (unsigned)item.z;
+        const int64_t q0 = lo >> 2, q1 = (hi + 3) >> 2;
+        // BS_UNROLL groups per lane and round: their loads are issued together
+        for (int64_t qb = q0 + threadIdx.x; qb < q1; qb += (int64_t)BS_UNROLL * THREADS) {
+            int s[BS_UNROLL][4], e[BS_UNROLL][4];
+            bool whole[BS_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BS_UNROLL; u++) {
+                const int64_t q = qb + (int64_t)u * THREADS, k0 = 4 * q;
+                whole[u] = q < q1 && k0 >= lo && k0 + 4 <= hi;  // (hi <= nq: a whole group never reads past the arrays)
+                if (whole[u]) {
+                    const int4 vs = reinterpret_cast<const int4 *>(sg.qs)[q], ve = reinterpret_cast<const int4 *>(sg.qe)[q];
+                    s[u][0] = vs.x, s[u][1] = vs.y, s[u][2] = vs.z, s[u][3] = vs.w;
+                    e[u][0] = ve.x, e[u][1] = ve.y, e[u][2] = ve.z, e[u][3] = ve.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool in = q < q1 && k0 + j >= lo && k0 + j < hi;
+                        s[u][j] = in ? sg.qs[k0 + j] : 0, e[u][j] = in ? sg.qe[k0 + j] : 0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BS_UNROLL; u++) {
+                const int64_t q = qb + (int64_t)u * THREADS, k0 = 4 * q;
+                if (q >= q1) break;
+                unsigned c[4];
+                if (unit >= 0) {
+                    bd_v4u rec;
+                    rec.x = bm_record_of(s[u][0], e[u][0], g), rec.y = bm_record_of(s[u][1], e[u][1], g);
+                    rec.z = bm_record_of(s[u][2], e[u][2], g), rec.w = bm_record_of(s[u][3], e[u][3], g);
+                    if (WIDE)
+                        bo_count_slot(I, rec, c);
+                    else
+                        bp_count_slot(I, rec, c);
+                } else {
+                    c[0] = c[1] = c[2] = c[3] = 0xFFFFu;
+                }
+                // (0xFFFF: an escape record -- improper, off the grid, longer than a record holds -- or a count that does not fit 16 bits)
+                if (c[0] == 0xFFFFu || c[1] == 0xFFFFu || c[2] == 0xFFFFu || c[3] == 0xFFFFu || !whole[u]) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const bool in = k0 + j >= lo && k0 + j < hi;
+                        if (in && c[j] == 0xFFFFu) c[j] = (unsigned)bm_escape_count(sg.ix, sg.e_sorted, g, s[u][j], e[u][j]);
+                        if (!in) c[j] = 0u;
+                    }
+                }
+                if (sg.counts) {
+                    if (whole[u]) {
+                        reinterpret_cast<int4 *>(sg.counts)[q] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (k0 + j >= lo && k0 + j < hi) sg.counts[k0 + j] = (int)c[j];
+                    }
+                }
+                acc += (long long)c[0] + c[1] + c[2] + c[3];
+            }
+        }
+        __syncthreads();  // (thread 0 writes the next item's number, the next image may replace this one)
+        it = it_nx;
+    }
+    (void)nq;
+    if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
 }
 
 // ---------------------------------------------------------------------------

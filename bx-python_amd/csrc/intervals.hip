@@ -2146,6 +2146,7 @@ static int64_t g_opt_flat = -1;       // the flat 16-byte walk on cell images of
 static int64_t g_opt_sparse = -1;     // offset-cell images for sparse indexes (offset_cells.hpp; the persistent walk): -1 = sparse indexes that qualify, batches that bring enough queries per unit; 0 = never; 1 = whatever the batch size
 static int64_t g_opt_bo_cell_log2 = 0;  // their cell width: 0 = from the index's density, 6..8 = forced
 static int64_t g_opt_bo_min_per_unit = 4096;  // queries per unit image a batch must bring (an image is 72 KB to load whatever the batch)
+static int64_t g_opt_sorted_cells = 1;  // sorted batches on indexes with cell images: 1 = answered from the images stretch by stretch (bs_*), 0 = the first-generation kernel for sorted batches
 static int64_t g_opt_dense = -1;      // search stage on dense unit images (count_dense.hpp): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
 static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
@@ -2190,6 +2191,7 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.flat", &g_opt_flat, nullptr},
     {"ivl.dense", &g_opt_dense, nullptr},
     {"ivl.sparse", &g_opt_sparse, nullptr},
+    {"ivl.sorted_cells", &g_opt_sorted_cells, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.bo_cell_log2", &g_opt_bo_cell_log2, [](int64_t value) -> int64_t { return value < BO_MIN_K || value > BO_MAX_K ? 0 : value; }},
     {"ivl.bo_min_per_unit", &g_opt_bo_min_per_unit, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
     {"ivl.bd_chunk", &g_opt_bd_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
@@ -2265,6 +2267,7 @@ struct bxmi_ivl {
     int64_t bo_hard_cells = 0;
     BmGeom bo_geom{0, 0, 0, 0, 0, 0, 0, BP_RSHIFT, 0};  // dshift = cell width - 5
     DevBuf bo_images;
+    DevBuf bs_plan;              // sorted batches on cell images: [unit bounds][item count][items]
     bool bd_blocks = false;      // the images' ranks are relative to blocks of 1024 cells (more than 32767 keys in some unit's slice)
     DevBuf bd_images, bd_stats, bd_cnt16, bd_unitT, bd_tend;
     // 8-bit counts between the search and the un-permute kernel (bm_count_segments): the un-permute kernel keeps a running
@@ -3114,7 +3117,34 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (unsorted) {
         // one index, its batch possibly sorted by start already: one pass over the queries as they lie then, and every
         // kernel below stands down (the local kernel exits at once otherwise)
-        hipLaunchKernelGGL(bm_sorted_check_kernel, dim3(2048), dim3(256), 0, st, qs[0], nq[0], unsorted);
+        // Cell images (bitmap or offset cells): a sorted batch is answered straight from them, stretch by stretch (count_dense.hpp,
+        // bs_*): the order check leaves where every unit's queries begin, a plan cuts long stretches, the walk loads a unit's
+        // image and answers its queries as they lie.  Other stages keep the first-generation kernel for sorted batches below.
+        const bool sorted_on_cells = cells && pad && g_opt_sorted_cells != 0 && nq[0] < ((int64_t)1 << 32) - 8;
+        if (sorted_on_cells) {
+            const BmGeom &g0 = segs[0].g;
+            const int units = BM_NB >> g0.f;
+            const unsigned chunk = (unsigned)(g_opt_bd_chunk ? g_opt_bd_chunk : (wide ? 1 : 2) * BM_CHUNK);
+            const size_t max_sorted_items = (size_t)units + 4 + (size_t)(nq[0] / chunk);
+            BXMI_TRY(h->bs_plan.reserve((size_t)(units + 2) * 4 + 16 + (max_sorted_items + 1) * sizeof(int4)));
+            BmBounds B;
+            B.bounds = h->bs_plan.as<unsigned>(), B.cmin = g0.cmin, B.ulog = g0.shift + g0.f, B.units = units;
+            int *n_sorted = reinterpret_cast<int *>(B.bounds + units + 2);
+            int4 *sorted_items = reinterpret_cast<int4 *>(h->bs_plan.as<unsigned char>() + (((size_t)(units + 2) * 4 + 16 + 15) & ~(size_t)15));
+            hipLaunchKernelGGL(bm_sorted_check_kernel<true>, dim3(2048), dim3(256), 0, st, qs[0], nq[0], unsorted, B);
+            hipLaunchKernelGGL(bs_plan_kernel, dim3(1), dim3(1024), 0, st, B.bounds, units, (unsigned)nq[0], chunk, sorted_items, n_sorted, unsorted);
+            if (wide) {
+                BXMI_TRY(allow_big_lds((bs_walk_kernel<true, BD_THREADS / 2>), L.search_lds));
+                hipLaunchKernelGGL((bs_walk_kernel<true, BD_THREADS / 2>), dim3(512), dim3(BD_THREADS / 2), L.search_lds, st, segs[0], sorted_items, n_sorted, tslots,
+                                   unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
+            } else {
+                BXMI_TRY(allow_big_lds((bs_walk_kernel<false, BD_THREADS>), L.search_lds));
+                hipLaunchKernelGGL((bs_walk_kernel<false, BD_THREADS>), dim3(256), dim3(BD_THREADS), L.search_lds, st, segs[0], sorted_items, n_sorted, tslots,
+                                   unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
+            }
+            BXMI_LAUNCH_CHECK();
+        } else {
+        hipLaunchKernelGGL(bm_sorted_check_kernel<false>, dim3(2048), dim3(256), 0, st, qs[0], nq[0], unsorted, BmBounds{nullptr, 0, 0, 0});
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
         const int64_t nchunks = div_up(nq[0], LC_CHUNK);
@@ -3135,6 +3165,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
             hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(),
                                qs[0], qe[0], nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->bd_fb_host + 1, seq);
         BXMI_LAUNCH_CHECK();
+        }
     }
     if (variant == 2)
         BXMI_TRY((bm_launch_tiles<1024, 32>(L, st)));
