@@ -763,7 +763,10 @@ def main():
         same = int(scounts.sum(dtype=torch.int64).item()) == local_total
         sorted_q = dict(value=round(nq / s_ms / 1e3, 1), unit="M queries/s", ms_per_pass=round(s_ms, 4),
                         frac_of_hbm_peak=round(alg_bytes_of(nq, args.targets) / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        same_total_as_unsorted=bool(same), kernel="bm_sorted_check (detects the order) + ivl_local_count_kernel",
+                        same_total_as_unsorted=bool(same),
+                        kernel=("bm_sorted_check (detects the order, leaves every unit's stretch of the query arrays) + bs_plan + bs_walk (a unit's cell image in LDS, "
+                                "its queries answered as they lie: no exchange)" if ix.flat_state()[0] == 1 or ix.sparse_state()[0] == 1
+                                else "bm_sorted_check (detects the order) + ivl_local_count_kernel"),
                         first_sorted_pass_after_shuffled_ms=round(first_sorted_ms, 4))
         del sqs, sqe, scounts
 

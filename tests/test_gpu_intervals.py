@@ -284,6 +284,60 @@ def test_sorted_batches_skip_the_bucketing(O, IntervalIndex, n, nq, span, lmax):
     assert np.array_equal(u_c, want2_c) and u_t == want2_t
 
 
+@pytest.mark.parametrize("stage", ["flat", "sparse"])
+def test_sorted_batches_on_cell_images(O, IntervalIndex, stage):
+    """A sorted batch on an index with cell images is answered straight from the images, stretch by stretch (bs_plan / bs_walk):
+    a batch crowded into one unit (stretches cut into several items), queries left and right of the grid, longer than a record
+    holds, zero-length and reversed ones, a pile of 70 000 identical targets (counts beyond 16 bits), a length that is not a
+    multiple of four, totals without counts -- against the oracle treap, and against the first-generation kernel for sorted
+    batches (ivl.sorted_cells = 0)."""
+    rng = np.random.default_rng(1234 + (stage == "sparse"))
+    n, span = (300_000, 6_000_000) if stage == "flat" else (200_000, 80_000_000)
+    s = rng.integers(1000, span, size=n)
+    e = s + rng.integers(1, 1500, size=n)
+    s[:70_000] = span // 3
+    e[:70_000] = span // 3 + 40
+    nq = 400_003
+    qs = rng.integers(-5000, span + 20_000, size=nq)
+    qs[: nq // 2] = rng.integers(span // 3 - 3000, span // 3 + 3000, size=nq // 2)  # half of the batch in one unit, on the pile
+    qe = qs + rng.integers(1, 3000, size=nq)
+    qe[::7] = qs[::7]                                            # zero-length
+    qe[::11] = qs[::11] - rng.integers(1, 50, size=len(qs[::11]))  # reversed
+    qe[::13] = qs[::13] + rng.integers(20_000, 3_000_000, size=len(qs[::13]))  # longer than a record holds
+    o = np.argsort(qs, kind="stable")
+    qs, qe = qs[o], qe[o]
+    s, e, qs, qe = (np.clip(a, -(2**31), 2**31 - 1).astype(np.int32) for a in (s, e, qs, qe))
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    pick = np.arange(0, nq, 3)  # (a query on the pile costs the treap 70 000 steps: every third one is checked against it)
+    want, _ = t.count_batch(qs[pick], qe[pick])
+    ix = make_index(IntervalIndex, s, e)
+    set_opt("ivl.partition", 1)
+    if stage == "flat":
+        set_opt("ivl.flat", 1)
+        set_opt("ivl.bm_hard_ppm", 10**6)
+    else:
+        set_opt("ivl.sparse", 1)
+    try:
+        results = []
+        for chunk, sorted_cells in ((0, 1), (4096, 1), (50_000, 1), (0, 0)):
+            set_opt("ivl.bd_chunk", chunk)
+            set_opt("ivl.sorted_cells", sorted_cells)
+            got, got_total = ix.count(qs, qe)
+            state = ix.flat_state() if stage == "flat" else ix.sparse_state()
+            assert state[0] == 1, state
+            bad = np.nonzero(got[pick] != want)[0]
+            assert len(bad) == 0, (stage, chunk, sorted_cells, bad[:8], qs[pick][bad[:8]], qe[pick][bad[:8]], got[pick][bad[:8]], want[bad[:8]])
+            assert got_total == int(got.sum(dtype=np.int64))
+            assert ix.count(qs, qe, want_counts=False)[1] == got_total
+            results.append(got)
+        assert all(np.array_equal(results[0], r) for r in results[1:])
+        assert int(results[0].max()) >= 70_000
+        assert ix.order_state()[0] >= 0  # (the pass reported what its order check found)
+    finally:
+        reset_opts()
+
+
 def test_partitioned_counts_beyond_16_bits(O, IntervalIndex):
     """Counts ride back to query order as 16 bits; a pile-up of >= 65535 overlapping targets takes the escape
     (recomputed from the index in the gather) -- regular, zero-length and reversed queries, both search variants."""

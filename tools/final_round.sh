@@ -11,6 +11,7 @@ timeout 400 bash tools/profile.sh > gpurun_out/profile.log 2>&1; tail -3 gpurun_
 PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum" timeout 300 bash tools/pmc_find.sh > gpurun_out/pmc_find.log 2>&1; grep -c "" gpurun_out/pmc_find/summary.txt
 WORLDS=1,2,4,8 timeout 300 python tools/rank_share.py > gpurun_out/share_all.json 2> gpurun_out/share_all.err
 timeout 300 bash tools/pmc_flat.sh search_sq > gpurun_out/search_sq.log 2>&1
+ROUNDS=40 SEED=2024 timeout 400 python tools/fuzz_intervals.py > gpurun_out/fuzz.log 2>&1; tail -1 gpurun_out/fuzz.log
 cd /tmp
 WORLDS=8 timeout 200 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/share -o s --output-format csv -- python $REPO/tools/rank_share.py > $REPO/gpurun_out/share.json 2> $REPO/gpurun_out/share.err
 cd $REPO
