@@ -520,7 +520,7 @@ def source_stamps():
 
     csrc = os.path.join(ROOT, "bx-python_amd", "csrc")
     kernels = [os.path.join(csrc, f) for f in ("common.hpp", "primitives.hpp", "count_bitmap.hpp", "count_slices.hpp", "count_dense.hpp",
-                                               "intervals.hip")]  # what the count pass is made of
+                                               "offset_cells.hpp", "intervals.hip")]  # what the count pass is made of
     return dict(bench_sha16=sha([os.path.join(ROOT, "bench.py")]), kernel_sha16=sha(kernels))
 
 
