@@ -2865,8 +2865,9 @@ static int bw_launch_search(const BmLaunch &L, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
     constexpr int THREADS = WIDE ? BD_THREADS / 2 : BD_THREADS;  // offset cells: two workgroups per CU
-    BXMI_TRY(allow_big_lds((bw_search_kernel<W8, 3, WIDE, THREADS>), L.search_lds));
-    hipLaunchKernelGGL((bw_search_kernel<W8, 3, WIDE, THREADS>), dim3(WIDE ? 512 : 256), dim3(THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+    constexpr int DEPTH = 3;  // (offset cells with rings of 2 / 3 / 4: genome pass 0.719 / 0.722 / 0.705 ms, an eighth of it 0.150 / 0.150 / 0.152)
+    BXMI_TRY(allow_big_lds((bw_search_kernel<W8, DEPTH, WIDE, THREADS>), L.search_lds));
+    hipLaunchKernelGGL((bw_search_kernel<W8, DEPTH, WIDE, THREADS>), dim3(WIDE ? 512 : 256), dim3(THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
                        h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(), h->bd_cnt16.as<unsigned short>(),
                        L.tile_log2, L.gate, L.xcd_next);
     BXMI_LAUNCH_CHECK();
