@@ -166,6 +166,10 @@ int bxmi_ivl_find_one(bxmi_ivl_t *h, int32_t qs, int32_t qe, int32_t *hits, int6
  * dir < 0: reverse in-order, keep 0 <= (position-1) - end   < max_dist
  * dir > 0: in-order,         keep 0 <= start - (position+1) < max_dist
  * Writes up to cap insertion indices; *n_out = number of candidates.
+ * An index that holds REVERSED intervals (start > end) reports, for dir < 0, every interval whose end qualifies: the
+ * reference prunes by subtree (`minstart > position`), so which of those it reports depends on its treap's random shape;
+ * this is the superset of every such run, found by one scan of the candidates above the window's lower end (O(n) for
+ * such an index; proper indexes scan the window only).
  *                                                  intersection.pyx:192-260 */
 int bxmi_ivl_neighbors(bxmi_ivl_t *h, int32_t position, int32_t max_dist, int dir, int32_t *out, int64_t cap,
                        int64_t *n_out);
