@@ -748,7 +748,7 @@ __device__ __forceinline__ unsigned bd_count16(int bias, int rS, int rE, unsigne
 // same -- any 32-bit word is a safe argument, the offset is masked to the unit and the length cannot leave the margin --
 // and not stored)
 // EXP (diagnostics, ivl.bd_exp; wrong results): 1 = no lookups at all -- the price of the walk and of its memory traffic alone
-// FMT: 0 = dense unit image, 1 = cell image, 2 = staged key slices
+// FMT: 0 = dense unit image, 2 = staged key slices (cell images, once FMT 1 of this kernel, have the persistent walk below: bw_search_kernel)
 // W8: the counts are 8 bits wide (0xFF = "ask the index again": escape records and counts of 255 and more) -- half the bytes
 // for indexes whose counts are small; the host decides per batch (bm_count_segments).
 template <int FMT, bool QB, int EXP, bool W8 = false>
@@ -760,9 +760,6 @@ __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short 
     if (EXP == 1) {
 #pragma unroll
         for (int j = 0; j < 4; j++) c[j] = rec[j] & 0xffu;
-    } else if (FMT == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) c[j] = bp_count_record(I, rec[j]);
     } else if (FMT == 2) {
         // (a neighbouring unit's record is a valid argument: its offset lies inside the unit's width, the directory
         // lookups stay inside the staged arrays)
@@ -882,8 +879,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
     const BmSeg &sg = segs[item.x >> 16];
     const BmGeom g = sg.g;
     const BdLayout L = bd_layout(g.shift + g.f);
-    const BpLayout LP = bp_layout(g.shift + g.f);
-    const int image_bytes = FMT == 1 ? LP.bytes : L.bytes;
+    const int image_bytes = L.bytes;
     const unsigned short *__restrict__ runs0 = unitT + (int64_t)unit * ntp;
     const unsigned short *__restrict__ runs1 = runs0 + ntp;  // (the next unit's first slots, or the row behind the last unit)
     const int lane = lane_id();
@@ -912,8 +908,8 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         I.g = g;
     } else {
         // the image (streams through L2 once: non-temporal loads); every load of a lane issued before its first LDS store
-        const bm_v4i *src = reinterpret_cast<const bm_v4i *>((FMT == 1 ? sg.pimages : sg.dimages) + (size_t)unit * image_bytes);
-        const int n4 = (FMT == 1 ? image_bytes : L.ov) >> 4;  // (dense images: the overflow area follows, as much of it as is used)
+        const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.dimages + (size_t)unit * image_bytes);
+        const int n4 = L.ov >> 4;  // (the overflow area follows, as much of it as is used)
         constexpr int SWEEPS = 5;
         for (int i0 = 0; i0 < n4; i0 += SWEEPS * BD_THREADS) {
             bm_v4i v[SWEEPS];
@@ -938,17 +934,6 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         __syncthreads();
     }
     if (FMT == 2) {
-    } else if (FMT == 1) {
-        unsigned char *base = reinterpret_cast<unsigned char *>(dyn);
-        I.img16 = (lds_u16_p) reinterpret_cast<unsigned short *>(base);
-        I.cE = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsE);
-        I.cS = (lds_cell_p) reinterpret_cast<unsigned long long *>(base + LP.cellsS);
-        const unsigned *hdr = reinterpret_cast<const unsigned *>(base + LP.hdr);
-        I.eLo = (int)hdr[0], I.sLo = (int)hdr[1];
-        I.bias = I.sLo - I.eLo;
-        I.lo = (long long)((unsigned long long)hdr[2] | ((unsigned long long)hdr[3] << 32));
-        I.s_ord = sg.ix.s_ord, I.e_sorted = sg.e_sorted;
-        I.off_mask = (1u << (g.shift + g.f)) - 1u;
     } else {
         unsigned char *base = reinterpret_cast<unsigned char *>(dyn);
         I.bitsE = (lds_v4u_p) reinterpret_cast<bd_v4u *>(base + L.bitsE);
