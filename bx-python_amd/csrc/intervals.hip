@@ -1774,6 +1774,96 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_walk_kernel(const int2
     }
 }
 
+// The same walk with both of its memory sides made FLAT (round 4).  The kernel above reads the pairs and writes the hits one
+// lane at a time: a wave's 64 queries own one contiguous stretch of the CSR list (~320 hits) and one contiguous window of the
+// pairs (~100), but every store instruction scatters 64 4-byte pieces over the stretch's ten lines and every load is a lane's own
+// dependent step.  Here a wave first copies the window [wbase, kmax) of the pairs into LDS (coalesced 512-byte loads), the
+// lanes walk down inside LDS and drop their hits into an LDS image of the wave's stretch, and the stretch goes out as whole
+// 256-byte stores, lane i taking positions i, i + 64, ...  A batch whose stretch is longer than FF_HITS (queries on a pile) or
+// whose lanes leave the staged window keeps the direct loads / stores for those accesses: exact either way.
+// (measured on configs[4] sorted by start, find() end to end: the kernel above 2.42 ms; FF_HITS / FF_PAIRS = 1024 / 256: 1.81 ms,
+// 768 / 256: 1.71, 512 / 128: 1.64 -- less LDS per wave, more workgroups per CU)
+constexpr int FF_HITS = 512;    // hits of a wave's 64 queries staged in LDS (mean 320 on configs[4])
+constexpr int FF_PAIRS = 128;   // pairs below the wave's highest `hi` staged in LDS
+__global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2 *__restrict__ eid /* at index 0 */, const int32_t *__restrict__ qs_arr,
+                                                                     int64_t nq, const int32_t *__restrict__ his, const int32_t *__restrict__ cnt,
+                                                                     const long long *__restrict__ offs, int32_t *__restrict__ hits)
+{
+    __shared__ int2 s_pairs[FIND_THREADS / 64][FF_PAIRS];
+    __shared__ int32_t s_hits[FIND_THREADS / 64][FF_HITS];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    int2 *const wp = s_pairs[wave];
+    int32_t *const wh = s_hits[wave];
+    const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
+    const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
+    for (int64_t qb = q0 + 64 * wave; qb < q1; qb += FIND_THREADS) {  // (waves are on their own: no workgroup barrier in here)
+        const int64_t q = qb + lane;
+        const bool live = q < q1;
+        int c = live ? cnt[q] : 0;
+        const int hi = live && c ? his[q] : 0;
+        int k = hi - 1;
+        const int qs = live ? qs_arr[q] : 0;
+        const long long off = live ? offs[q] : 0;
+        // the wave's stretch of the list: from its first live query's offset, as long as the sum of its counts
+        const long long base_off = __shfl(off, 0, 64);  // (lane 0 is live whenever the batch exists)
+        long long total64 = c;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) total64 += __shfl_xor(total64, d, 64);
+        const bool flat = total64 <= FF_HITS;
+        const int total = flat ? (int)total64 : 0;
+        const int rel = flat ? (int)(off - base_off) : 0;
+        int32_t *__restrict__ dst = hits + off;
+        // the window of the pairs: FF_PAIRS below the highest hi of the wave
+        const int kmax = wave_max_i32(hi);
+        const int wbase = kmax > FF_PAIRS ? kmax - FF_PAIRS : 0;
+#pragma unroll
+        for (int j = 0; j < FF_PAIRS / 64; j++) {
+            const int kk = wbase + 64 * j + lane;
+            if (kk < kmax) wp[64 * j + lane] = eid[kk];
+        }
+        auto pair_at = [&](int kk) -> int2 { return kk >= wbase ? wp[kk - wbase] : eid[kk]; };
+        for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
+            const int2 p = pair_at(k);
+            if (p.x > qs) {
+                --c;
+                if (flat)
+                    wh[rel + c] = p.y;
+                else
+                    dst[c] = p.y;
+            }
+        }
+        unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            int C = __shfl(c, src, 64), K = __shfl(k, src, 64);
+            const int S = __shfl(qs, src, 64);
+            const int R = __shfl(rel, src, 64);
+            int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
+            while (C > 0 && K >= 0) {
+                const int kk = K - lane;
+                int2 p = make_int2(INT_MIN, 0);
+                if (kk >= 0) p = pair_at(kk);
+                const bool f = kk >= 0 && p.x > S;
+                const unsigned long long fm = __ballot(f);
+                // hits at higher indices come later in the list: lane 0 (the highest index of the step) takes the last free slot
+                const int before = __popcll(fm & ((1ull << lane) - 1ull));
+                if (f && before < C) {
+                    if (flat)
+                        wh[R + C - 1 - before] = p.y;
+                    else
+                        D[C - 1 - before] = p.y;
+                }
+                C -= __popcll(fm);
+                K -= 64;
+            }
+        }
+        for (int i = lane; i < total; i += 64) hits[base_off + i] = wh[i];
+    }
+}
+
 __global__ void part_fold_total_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
 {
     unsigned long long v = threadIdx.x < PT_SLOTS ? slots[threadIdx.x] : 0ull;
@@ -2146,6 +2236,7 @@ static int64_t g_opt_flat = -1;       // the flat 16-byte walk on cell images of
 static int64_t g_opt_sparse = -1;     // offset-cell images for sparse indexes (offset_cells.hpp; the persistent walk): -1 = sparse indexes that qualify, batches that bring enough queries per unit; 0 = never; 1 = whatever the batch size
 static int64_t g_opt_bo_cell_log2 = 0;  // their cell width: 0 = from the index's density, 6..8 = forced
 static int64_t g_opt_bo_min_per_unit = 4096;  // queries per unit image a batch must bring (an image is 72 KB to load whatever the batch)
+static int64_t g_opt_find_flat = 1;     // find() on a sorted batch: 1 = the fill that stages a wave's pairs and hits in LDS (part_fill_flat_kernel), 0 = one lane per query straight on HBM
 static int64_t g_opt_sorted_cells = 1;  // sorted batches on indexes with cell images: 1 = answered from the images stretch by stretch (bs_*), 0 = the first-generation kernel for sorted batches
 static int64_t g_opt_dense = -1;      // search stage on dense unit images (count_dense.hpp): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
 static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
@@ -2191,6 +2282,7 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.flat", &g_opt_flat, nullptr},
     {"ivl.dense", &g_opt_dense, nullptr},
     {"ivl.sparse", &g_opt_sparse, nullptr},
+    {"ivl.find_flat", &g_opt_find_flat, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.sorted_cells", &g_opt_sorted_cells, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.bo_cell_log2", &g_opt_bo_cell_log2, [](int64_t value) -> int64_t { return value < BO_MIN_K || value > BO_MAX_K ? 0 : value; }},
     {"ivl.bo_min_per_unit", &g_opt_bo_min_per_unit, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
@@ -2456,8 +2548,12 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     int fgrid = device_props().cus * 8;
     if (walk) {
         BXMI_TRY(sl_ensure_eid(h, st));
-        hipLaunchKernelGGL(part_fill_walk_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq, h->p_hi.as<int32_t>(),
-                           h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
+        if (g_opt_find_flat)
+            hipLaunchKernelGGL(part_fill_flat_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq, h->p_hi.as<int32_t>(),
+                               h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
+        else
+            hipLaunchKernelGGL(part_fill_walk_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq, h->p_hi.as<int32_t>(),
+                               h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
     } else {
         hipLaunchKernelGGL(part_fill_lane_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->p_lo.as<int32_t>(),
                            h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (const int2 *)nullptr);
