@@ -1241,6 +1241,41 @@ def test_genome_two_ranks_real_engine(tmp_path):
     assert "rank0-ok" in p.stdout and "rank1-ok" in p.stdout, p.stdout[-2000:]
 
 
+def test_find_on_sorted_batches_flat_fill(O, IntervalIndex):
+    """find() on a batch sorted by start: the fill that stages a wave's window of pairs and its stretch of the hit list in LDS
+    (part_fill_flat_kernel) against the oracle's hit lists and against the lane-per-query kernel it replaced (ivl.find_flat = 0) --
+    ordinary stretches, queries on a pile (a wave's stretch beyond the LDS image: direct stores), a few very long targets far
+    below the queries' windows (lanes that leave the staged pairs, walks handed to the whole wave), queries without hits."""
+    rng = np.random.default_rng(4242)
+    n, span = 400_000, 8_000_000
+    s = rng.integers(0, span, size=n)
+    e = s + rng.integers(1, 200, size=n)
+    s[:3000] = span // 2 + rng.integers(0, 40, size=3000)      # a pile: queries there see thousands of hits
+    e[:3000] = s[:3000] + 100
+    e[3000:3040] = s[3000:3040] + rng.integers(500_000, 4_000_000, size=40)  # long targets: hits far below hi
+    nq = 300_001
+    qs = np.sort(rng.integers(-1000, span + 1000, size=nq))
+    qe = qs + rng.integers(0, 300, size=nq)                     # (zero-length ones included)
+    qe[::17] = qs[::17] - 5                                     # reversed
+    s, e, qs, qe = (a.astype(np.int32) for a in (s, e, qs, qe))
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    w_off, w_hits = t.find_batch(qs, qe)
+    ix = make_index(IntervalIndex, s, e)
+    set_opt("ivl.partition", 1)
+    try:
+        got = {}
+        for flat in (1, 0):
+            set_opt("ivl.find_flat", flat)
+            got[flat] = ix.find(qs, qe)
+            assert np.array_equal(got[flat][0], w_off), ("offsets", flat)
+            bad = np.nonzero(got[flat][1] != w_hits)[0]
+            assert len(bad) == 0, ("hits", flat, bad[:8], got[flat][1][bad[:8]], w_hits[bad[:8]])
+        assert int(np.diff(w_off).max()) > 3000 and len(w_hits) > 5 * nq  # the pile and the long targets are really in play
+    finally:
+        reset_opts()
+
+
 def test_find_join_scale_properties(IntervalIndex):
     """configs[4] shape at 4M x 4M (the 50M x 50M run is tools/bench_find.py): CSR consistency, every hit overlaps,
     hits of a query in tree order, and agreement with the count path."""
