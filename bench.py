@@ -598,8 +598,8 @@ def main():
                            "no data-path collective, per-chromosome int64 totals all-reduced (RCCL) every step", "lpt": g["lpt"]},
                 "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                              "frac": round(achieved / (HBM_PEAK_GBS * world), 4), "traffic": None,
-                             "kernel": "all of a rank's chromosomes in one bxmi_ivl_count_multi_dev pass (tile sort, run table, plan, slice search "
-                                       "-- a chromosome has one target per ~300 coordinates -- un-permute); slowest rank", "kernel_ms": g["kernel_ms_slowest_rank"],
+                             "kernel": "all of a rank's chromosomes in one bxmi_ivl_count_multi_dev pass (tile sort, run table, plan, the persistent walk on "
+                                       "offset-cell images -- a chromosome has one target per ~300 coordinates -- un-permute); slowest rank", "kernel_ms": g["kernel_ms_slowest_rank"],
                              "algorithmic_bytes_per_launch": alg, "peak_note": "n_gpus x 8 TB/s",
                              "timed_with": "HIP events on the launch stream around every rank's chromosomes; the slowest rank's mean"},
                 "collective": g["collective"], "parity": g["parity"], "index_build_s": g["build_s"], "device": name.value.decode(),

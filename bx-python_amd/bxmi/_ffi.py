@@ -31,6 +31,7 @@ _SIGNATURES = {
     "bxmi_set_device": [C.c_int],
     "bxmi_get_device": [_p(C.c_int)],
     "bxmi_device_info": [C.c_int, C.c_char_p, C.c_int, _p(C.c_int), _p(i64)],
+    "bxmi_mem_info": [_p(i64), _p(i64)],
     "bxmi_synchronize": [vp],
     "bxmi_malloc": [_p(vp), C.c_size_t],
     "bxmi_free": [vp],
@@ -129,7 +130,7 @@ def load():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
-        # BXMI_OPTS="ivl.bm_u=4,bits.grid=512": tuning knobs for A/B runs of unmodified scripts (results never depend on them).
+        # BXMI_OPTS="ivl.bm_variant=1,bits.grid=512": tuning knobs for A/B runs of unmodified scripts (results never depend on them).
         # All of them are parsed and applied before the library is published: a malformed entry fails every load().
         for kv in filter(None, (x.strip() for x in os.environ.get("BXMI_OPTS", "").split(","))):
             key, eq, value = kv.partition("=")

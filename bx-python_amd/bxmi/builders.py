@@ -14,6 +14,8 @@ import numpy as np
 
 from bx.bitset import MAX, BinnedBitSet
 
+from . import _ffi
+
 
 def _check_range(size, start, count):
     """bitset.pyx:184-189 (bb_check_range_count), evaluated at parse time so errors keep file order."""
@@ -216,7 +218,25 @@ def as_group(bitsets, mutated=False):
 # A group launch works on whole word arrays: it makes every member allocate its full size (64 MiB for a default-sized set),
 # where the per-set calls leave untouched bins unallocated.  Fine for a genome's chromosomes; a scaffold-level assembly
 # with thousands of sequence names keeps the per-set loop (tests/test_gpu_bitset.py::test_thousands_of_default_sized_sets_stay_small).
+# The gate is BYTES, not members: the word arrays the group would materialise (all operands) must fit a quarter of what
+# the device has free right now, and a group that still runs out of memory falls back to the per-set loop.
 GROUP_MAX_MEMBERS = 128
+GROUP_MAX_FRACTION_OF_FREE = 0.25
+
+
+def group_bytes(*operands):
+    """Bytes of dense words a group launch over these sets would make resident (every member whole)."""
+    return sum((b.size + 7) // 8 for members in operands for b in members)
+
+
+def group_fits(*operands):
+    """May these sets go through one group launch?  Few enough members, and their whole word arrays small against the
+    device memory that is free now (bxmi_mem_info)."""
+    if not operands or not operands[0] or any(len(m) > GROUP_MAX_MEMBERS for m in operands):
+        return False
+    free = _ffi.i64(0)
+    _ffi.call("bxmi_mem_info", _ffi.C.byref(free), None)
+    return group_bytes(*operands) <= GROUP_MAX_FRACTION_OF_FREE * free.value
 
 
 def group_coverage(bitsets):
@@ -224,19 +244,31 @@ def group_coverage(bitsets):
     members = list(bitsets)
     if not members:
         return 0
-    if len(members) > GROUP_MAX_MEMBERS:
-        return sum(b.count_range(0, b.size) for b in members)
-    return int(as_group(members).popcounts().sum())
+    if group_fits(members):
+        try:
+            return int(as_group(members).popcounts().sum())
+        except _ffi.BxmiError as e:  # the estimate was taken before the allocations: another process may have won the race
+            if e.code != _ffi.ENOMEM:
+                raise
+    return sum(b.count_range(0, b.size) for b in members)
 
 
 def group_iand(targets, others):
     """targets[i].iand(others[i]) for all i -- bed_intersect_basewise.py:25-28 -- as one launch."""
     targets, others = list(targets), list(others)
-    if len(targets) > GROUP_MAX_MEMBERS:
-        for a, b in zip(targets, others):
-            a.iand(b)
-    elif targets:
-        as_group(targets, mutated=True).iand(as_group(others))
+    if not targets:
+        return
+    if group_fits(targets, others):
+        try:
+            # (both groups exist before the first word changes: running out of memory leaves every set as it was)
+            gt, go = as_group(targets, mutated=True), as_group(others)
+            gt.iand(go)
+            return
+        except _ffi.BxmiError as e:
+            if e.code != _ffi.ENOMEM:
+                raise
+    for a, b in zip(targets, others):
+        a.iand(b)
 
 
 def _c_int(v):

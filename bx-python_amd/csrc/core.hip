@@ -93,6 +93,15 @@ extern "C" int bxmi_device_info(int device, char *name, int name_len, int *compu
     return BXMI_OK;
 }
 
+extern "C" int bxmi_mem_info(int64_t *free_bytes, int64_t *total_bytes)
+{
+    size_t f = 0, t = 0;
+    BXMI_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return BXMI_OK;
+}
+
 extern "C" int bxmi_synchronize(void *stream)
 {
     BXMI_HIP(hipStreamSynchronize(as_stream(stream)));
@@ -180,8 +189,17 @@ extern "C" int bxmi_option_at(int i, const char **key, int64_t *value)
 extern "C" int bxmi_get_option(const char *key, int64_t *value)
 {
     if (!key || !value) return fail(BXMI_EINVAL, "bxmi_get_option: NULL argument");
-    const char *k = nullptr;
-    for (int i = 0; bxmi_option_at(i, &k, value) == BXMI_OK; i++)
-        if (!strcmp(k, key)) return BXMI_OK;
+    // (a local: an unknown key must leave *value alone; the loop is bounded by the table, so no failing call overwrites
+    // the thread's error text before the real message is set)
+    const int n = ivl_option_count() + 2;
+    for (int i = 0; i < n; i++) {
+        const char *k = nullptr;
+        int64_t v = 0;
+        if (bxmi_option_at(i, &k, &v) != BXMI_OK) break;
+        if (!strcmp(k, key)) {
+            *value = v;
+            return BXMI_OK;
+        }
+    }
     return fail(BXMI_EINVAL, "bxmi_get_option: unknown key '%s'", key);
 }

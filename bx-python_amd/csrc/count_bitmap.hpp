@@ -678,14 +678,14 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
                 for (int u = 0; u < 4; u++)
                     if (c[u] == BM_REC_ESC) c[u] = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k0 + u], qe_arr[k0 + u]);
             }
-            o4[j * THREADS + threadIdx.x] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);
+            if (sg.counts) o4[j * THREADS + threadIdx.x] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);  // (NULL: the caller wants the total only)
             acc += (long long)c[0] + c[1] + c[2] + c[3];
         }
     } else {
         for (int k = threadIdx.x; k < n; k += THREADS) {
             unsigned c = vals[slots[base + k]];
             if (c == BM_REC_ESC) c = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[base + k], qe_arr[base + k]);
-            out[base + k] = (int)c;
+            if (sg.counts) out[base + k] = (int)c;
             acc += c;
         }
     }

@@ -1823,6 +1823,9 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
             const int kk = wbase + 64 * j + lane;
             if (kk < kmax) wp[64 * j + lane] = eid[kk];
         }
+        // (lanes read what OTHER lanes staged: wave-level release + barrier, not just in-order DS issue)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         auto pair_at = [&](int kk) -> int2 { return kk >= wbase ? wp[kk - wbase] : eid[kk]; };
         for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
             const int2 p = pair_at(k);
@@ -1860,7 +1863,11 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
                 K -= 64;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < total; i += 64) hits[base_off + i] = wh[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next batch overwrites both images)
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -2360,7 +2367,6 @@ struct bxmi_ivl {
     BmGeom bo_geom{0, 0, 0, 0, 0, 0, 0, BP_RSHIFT, 0};  // dshift = cell width - 5
     DevBuf bo_images;
     DevBuf bs_plan;              // sorted batches on cell images: [unit bounds][item count][items]
-    DevBuf tot_scratch;          // counts nobody asked for (a large batch that wants its total only)
     bool bd_blocks = false;      // the images' ranks are relative to blocks of 1024 cells (more than 32767 keys in some unit's slice)
     DevBuf bd_images, bd_stats, bd_cnt16, bd_unitT, bd_tend;
     // 8-bit counts between the search and the un-permute kernel (bm_count_segments): the un-permute kernel keeps a running
@@ -2872,7 +2878,7 @@ static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hip
 
 // The bitmap-cell pass over a batch of n segments (n sealed, qualifying indexes with their queries): [order check ->]
 // tile sort -> run table + plan -> search -> un-permute -> totals, all on `st`, six launches whatever n is.
-// counts[i] must not be NULL; totals_dev[i] may be.  The scratch of hs[0] serves the whole batch.
+// counts[i] may be NULL (total only: nothing is stored per query); totals_dev[i] may be.  The scratch of hs[0] serves the whole batch.
 template <int LANES>
 static int sl_launch_search(const BmLaunch &L, unsigned grid, hipStream_t st, unsigned *out)
 {
@@ -3716,10 +3722,7 @@ extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_
         int kind = 0;
         BXMI_TRY(bm_choose_stage(h, st, &kind, nq));
         if (kind) {
-            if (!counts) {
-                BXMI_TRY(h->tot_scratch.reserve((size_t)(nq + 4) * 4));
-                counts = h->tot_scratch.as<int32_t>();
-            }
+            // (counts == NULL: the same pass, its un-permute kernel sums without storing -- no scratch array of counts)
             return bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &total_dev, st, kind);
         }
     }
@@ -3767,7 +3770,7 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
             return fail(BXMI_EINVAL, "bxmi_ivl_count_multi_dev: query/count arrays must be 16-byte aligned");
         nq_all += nq[i];
     }
-    const bool fused = g_opt_bitmap != 0 && counts && (g_opt_partition == 1 || (g_opt_partition < 0 && nq_all >= g_opt_bitmap_min));
+    const bool fused = g_opt_bitmap != 0 && (counts || totals_dev) && (g_opt_partition == 1 || (g_opt_partition < 0 && nq_all >= g_opt_bitmap_min));
     for (int i = 0; i < n; i++) {
         bxmi_ivl *h = hs[i];
         if (nq[i] == 0) continue;
@@ -3775,10 +3778,12 @@ extern "C" int bxmi_ivl_count_multi_dev(bxmi_ivl_t *const *hs, int n, const int3
         // a segment occupies whole groups of 64 tiles of scratch whatever its size: in a batch over hundreds of indexes
         // (a scaffold-level assembly) the ones with a handful of queries are answered one by one instead
         const bool tiny = n > 256 && nq[i] < 65536;
-        if (fused && counts[i] && !tiny) BXMI_TRY(bm_choose_stage(h, st, &kind, nq[i]));
+        // (an index whose caller wants neither counts nor a total has nothing to compute; total-only segments ride the same pass)
+        const bool wanted = (counts && counts[i]) || (totals_dev && totals_dev[i]);
+        if (fused && wanted && !tiny) BXMI_TRY(bm_choose_stage(h, st, &kind, nq[i]));
         if (kind) {
             const int k = kind - 1;
-            fh[k].push_back(h), fqs[k].push_back(qs[i]), fqe[k].push_back(qe[i]), fnq[k].push_back(nq[i]), fc[k].push_back(counts[i]);
+            fh[k].push_back(h), fqs[k].push_back(qs[i]), fqe[k].push_back(qe[i]), fnq[k].push_back(nq[i]), fc[k].push_back(counts ? counts[i] : nullptr);
             ft[k].push_back(totals_dev ? totals_dev[i] : nullptr);
         } else {
             rest.push_back(i);

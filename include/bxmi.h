@@ -49,6 +49,9 @@ int bxmi_device_count(int *n);
 int bxmi_set_device(int device);
 int bxmi_get_device(int *device);
 int bxmi_device_info(int device, char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+/* Free and total bytes of the current device's memory (hipMemGetInfo): what the host side sizes group launches against
+ * (a group makes every member allocate its whole word array).  No reference counterpart. */
+int bxmi_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 int bxmi_synchronize(void *stream);
 
 /* Raw HBM staging for hosts that do not bring their own allocator. */
@@ -58,18 +61,32 @@ int bxmi_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int bxmi_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int bxmi_memset(void *dst_dev, int value, size_t bytes);
 
-/* Tuning / A-B knobs (process-wide), key -> value.  Results never depend on them (the GPU tests run both sides).
- *   ivl.partition      -1 auto (batches >= ivl.partition_min queries take the bucketed path), 0 never, 1 always
+/* Tuning / A-B knobs (process-wide), key -> value.  Results never depend on them (the GPU tests run both sides).  The
+ * authoritative list with the defaults is what bxmi_option_at enumerates (the IVL_OPTS table of csrc/intervals.hip);
+ * the ones a caller may want:
+ *   ivl.partition      -1 auto (batches >= ivl.partition_min queries take the large-batch passes), 0 never, 1 always
  *   ivl.partition_min  threshold of the auto mode (default 4 Mi queries)
- *   ivl.sorted_path    1 (default): a batch whose starts are already non-decreasing skips the bucketing
- *   ivl.count_cells    1 (default): bucket search by direct-addressed cells; 0: LDS search trees
- *   ivl.bitmap         -1 (default): large batches with per-query counts take the bitmap-cell pass when the index qualifies; 0 never
- *   ivl.bm_variant, ivl.bm_u, ivl.bm_hard_ppm   tile shape / runs in flight / qualification threshold of that pass
- *   ivl.slice          -1 (default): that pass searches staged key slices instead of bucket images where the index is
- *                      sparse or its span too wide for images; 0 never; 1 wherever the slices fit
- *   ivl.sl_f, ivl.sl_lanes   buckets per slice unit (2^f) / lanes per run of the slice search (tests)
+ *   ivl.sorted_path    1 (default): a batch whose starts are already non-decreasing is answered as it lies
+ *   ivl.sorted_cells   1 (default): ... from the cell images, stretch by stretch (count_dense.hpp, bs_*); 0: first-generation kernel
+ *   ivl.bitmap         -1 (default): large batches take the exchange (tile sort -> search on unit images -> un-permute)
+ *                      when the index qualifies; 0 never (round 1's bucketed pass)
+ *   ivl.bitmap_min     smallest batch that takes the exchange (default 2 Mi queries)
+ *   ivl.flat / ivl.dense / ivl.slice / ivl.sparse   force (1), forbid (0) or leave to the index's shape (-1, default) the
+ *                      search stage: bitmap-cell images / dense unit images / staged key slices / offset-cell images
+ *   ivl.bo_cell_log2, ivl.bo_min_per_unit   offset cells: coordinates per cell (6..8, 0 = from the density) and the
+ *                      queries per unit image a batch must bring before the images pay
+ *   ivl.bm_variant     tile shape of the exchange (-1 auto, 0 = 512 x 32, 1 = 1024 x 16, 2 = 1024 x 32 queries per tile)
+ *   ivl.bm_chunk, ivl.bd_chunk   queries per search work item (0 = default)
+ *   ivl.bd_w8          8-bit counts between the search and the un-permute kernel (-1 auto from the density + feedback)
+ *   ivl.order_skip     1 (default): the exact order check is dropped after two shuffled batches (a probe stands in)
+ *   ivl.find_sliced    1 (default): find() on large unsorted batches goes through the exchange (count_slices.hpp)
+ *   ivl.find_flat      1 (default): sorted find() stages the candidate window and the hit stretch of a wave in LDS
+ *   ivl.find_fused     1 (default): sorted find() counts, scans (decoupled look-back) and fills in one kernel
+ *   ivl.fx_fill        1 (default): the exchange's fill half on LDS-staged (end, index) windows of sub-bucket pieces
+ *   ivl.sl_f, ivl.sl_lanes, ivl.sl_flat, ivl.sl_rbits, ivl.sl_run_cap   geometry of the slice stage (tests, A/B tools)
  *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search
  *   ivl.lds_ints, ivl.count_grid   staging budget / grid of the direct count kernel
+ *   ivl.stage_sync     1: synchronise and report after every stage of the exchange (debugging)
  *   bits.grid          grid of the per-bitset kernels
  *   core.poll          1 (default): the one-call paths (bxmi_ivl_find_one, short bxmi_bits_count_range) poll a completion
  *                      word their kernel writes to host memory; 0: they wait for the stream
@@ -178,8 +195,9 @@ int bxmi_ivl_neighbors(bxmi_ivl_t *h, int32_t position, int32_t max_dist, int di
  * most max_dist (>= 0).  All clusters in ascending start order: starts[c], ends[c], and members[offsets[c] ..
  * offsets[c+1]) = the member ids in ascending order, where an interval's id is ids[insertion index] (or the insertion
  * index itself when ids is NULL).  starts/ends/members need n entries, offsets n + 1 (n = bxmi_ivl_size).  The caller
- * applies ClusterTree's min_intervals filter.  max_dist < 0 -> BXMI_EINVAL (the reference's result then depends on
- * the insertion order). */
+ * applies ClusterTree's min_intervals filter.  max_dist = -1 is accepted when no interval is empty (the reference is
+ * deterministic there: tests/golden/cluster_negative_distance.txt); -1 with an empty interval and every max_dist < -1
+ * -> BXMI_EINVAL (the reference's result then depends on the insertion order and on unseeded rand() priorities). */
 int bxmi_ivl_clusters(bxmi_ivl_t *h, const int32_t *ids, int32_t max_dist, int64_t *n_clusters, int32_t *starts, int32_t *ends,
                       int64_t *offsets, int32_t *members);
 

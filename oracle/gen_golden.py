@@ -11,9 +11,10 @@ Only inputs + expected outputs are written (data, never reference source).
 
 --scale additionally runs the 10M-target / 1M-query-subsample point of cfg 2
 through the reference treap (about 5 minutes, ~2 GB) and records its hash.
---only genome | join | calibration add, to tests/golden/scale.json, the per-chromosome
+--only genome | join | calibration | bitsets_genome add, to tests/golden/scale.json, the per-chromosome
 hashes of configs[3] (synth.cfg4), the hit-list hash of configs[4] at 50M targets
-(~10 GB, ~30 min) and the reference-vs-port timing BASELINE.md 4 asks for.
+(~10 GB, ~30 min), the reference-vs-port timing BASELINE.md 4 asks for, and the per-chromosome popcounts /
+run-list hashes of configs[2] (two hg19-sized dicts of BinnedBitSets) from the real bx.bitset.
 """
 import argparse
 import hashlib
@@ -451,6 +452,42 @@ def calibration_point(n_targets=10_000_000, n_queries_total=100_000_000, stride=
                      "its callers use it); port = oracle/ivtree.c count_batch; same arrays, same machine, one thread")
 
 
+def bitsets_genome_point():
+    """BASELINE configs[2] (synth.genome_ranges(1_500_000, 301 / 302)): two hg19-sized dicts of BinnedBitSets through the
+    real bx.bitset -- per chromosome popcount(A), popcount(B), popcount(A & B), popcount(A | B), the number of runs of
+    A & B and the sha256 of its run list (int64 starts then int64 ends, from next_set / next_clear as bed_intersect_basewise
+    walks them, scripts/bed_intersect_basewise.py:39-51)."""
+    ra, rb_ = synth.genome_ranges(1_500_000, 301), synth.genome_ranges(1_500_000, 302)
+    out = {}
+    for chrom, size in synth.HG19_SIZES.items():
+        sets = []
+        for r in (ra, rb_, ra):
+            bs = rb.BinnedBitSet(size)
+            sr = bs.set_range
+            for s, n in zip(r[chrom][0].tolist(), r[chrom][1].tolist()):
+                sr(s, n)
+            sets.append(bs)
+        a, b, a2 = sets
+        ca, cb = a.count_range(0, size), b.count_range(0, size)
+        a2.ior(b)
+        c_or = a2.count_range(0, size)
+        a.iand(b)
+        c_and = a.count_range(0, size)
+        starts, ends = [], []
+        end = 0
+        while True:
+            start = a.next_set(end)
+            if start == size:
+                break
+            end = a.next_clear(start)
+            starts.append(start), ends.append(end)
+        runs = np.concatenate([np.array(starts, dtype=np.int64), np.array(ends, dtype=np.int64)])
+        out[chrom] = dict(size=size, pop_a=ca, pop_b=cb, pop_and=c_and, pop_or=c_or, n_runs=len(starts), runs_sha256=sha(runs))
+        print(chrom, out[chrom], flush=True)
+    return dict(workload="synth.genome_ranges(1_500_000, 301) / (.., 302): one BinnedBitSet(size) per hg19 chromosome and set",
+                source="bx.bitset.BinnedBitSet (reference 0.14.0): set_range, ior, iand, count_range, next_set / next_clear", chroms=out)
+
+
 def gen_extra(which):
     path = os.path.join(GOLD, "scale.json")
     doc = json.load(open(path))
@@ -460,10 +497,12 @@ def gen_extra(which):
         doc["cfg5_join"] = join_point()
     elif which == "calibration":
         doc["calibration"] = calibration_point()
+    elif which == "bitsets_genome":
+        doc["cfg3_bitsets"] = bitsets_genome_point()
     # another generator may have rewritten the file meanwhile: merge on the freshest copy
     fresh = json.load(open(path))
-    for k in ("cfg4_genome", "cfg5_join", "calibration"):
-        if k in doc and (k == {"genome": "cfg4_genome", "join": "cfg5_join", "calibration": "calibration"}[which]):
+    for k in ("cfg4_genome", "cfg5_join", "calibration", "cfg3_bitsets"):
+        if k in doc and (k == {"genome": "cfg4_genome", "join": "cfg5_join", "calibration": "calibration", "bitsets_genome": "cfg3_bitsets"}[which]):
             fresh[k] = doc[k]
     dump("scale.json", fresh)
 
@@ -501,6 +540,6 @@ if __name__ == "__main__":
         gen_cli_crlf()
     if "scale" in todo:
         gen_scale(a.scale)
-    for which in ("genome", "join", "calibration"):  # --only genome | join | calibration: long-running extras of scale.json
+    for which in ("genome", "join", "calibration", "bitsets_genome"):  # --only genome | join | calibration | bitsets_genome: long-running extras of scale.json
         if which in todo and a.only:
             gen_extra(which)

@@ -333,25 +333,43 @@ def test_batch_errors_match_reference_messages():
 
 
 # --------------------------------------------------------- full-size properties --
-def test_cfg3_genome_scale_properties(O):
-    """BASELINE configs[2]: two hg19-sized (3.1 Gbp, 24 chromosomes) bitsets, iand + count_range.
-    chr21 and chrY are checked bit-for-bit against the oracle, every chromosome through identities."""
-    from bxmi.bitset import DeviceBitSet
+def _runs_sha(rs, re):
+    import hashlib
 
+    return hashlib.sha256(np.concatenate([np.asarray(rs, dtype=np.int64), np.asarray(re, dtype=np.int64)]).tobytes()).hexdigest()
+
+
+def test_cfg3_genome_scale_properties(O, golden_scale_doc):
+    """BASELINE configs[2]: two hg19-sized (3.1 Gbp, 24 chromosomes) bitsets, iand + count_range.
+    EVERY chromosome against the real bx.bitset.BinnedBitSet (tests/golden/scale.json "cfg3_bitsets", made by
+    oracle/gen_golden.py --only bitsets_genome: popcounts of A, B, A & B, A | B and the sha256 of the run list of A & B),
+    once through the per-chromosome calls of the drop-in classes and once through BitSetGroup (one launch per genome: the
+    path bench.py quotes); chr21 and chrY also bit-for-bit against the oracle, every chromosome through identities."""
+    from bxmi.bitset import BitSetGroup, DeviceBitSet
+
+    g = golden_scale_doc.get("cfg3_bitsets")
+    assert g, "tests/golden/scale.json has no cfg3_bitsets point: the reference check of configs[2] must not vanish silently"
+    gold = g["chroms"]
+    assert list(gold) == list(synth.HG19_SIZES)
     ra = synth.genome_ranges(1_500_000, 301)
     rb = synth.genome_ranges(1_500_000, 302)
     tot_a = tot_b = tot_and = tot_or = 0
     for chrom, size in synth.HG19_SIZES.items():
+        want = gold[chrom]
+        assert want["size"] == size
         a, b, a2 = DeviceBitSet(size), DeviceBitSet(size), DeviceBitSet(size)
         a.set_ranges(*ra[chrom]), b.set_ranges(*rb[chrom]), a2.set_ranges(*ra[chrom])
         ca, cb = a.count_range(0, size), b.count_range(0, size)
+        assert (ca, cb) == (want["pop_a"], want["pop_b"]), chrom
         a2.ior(b)
         c_or = a2.count_range(0, size)
         c_and = a.and_count(b)  # fused iand + popcount
+        assert (c_and, c_or) == (want["pop_and"], want["pop_or"]), chrom
         assert c_and == a.count_range(0, size)
         assert c_and + c_or == ca + cb  # inclusion-exclusion
         rs, re = a.runs()
         assert int((re - rs).sum()) == c_and and (rs[1:] > re[:-1]).all()
+        assert len(rs) == want["n_runs"] and _runs_sha(rs, re) == want["runs_sha256"], chrom
         # per-range counts against the full count: consecutive windows tile the chromosome
         edges = np.linspace(0, size, 2001).astype(np.int64)
         win = a.count_ranges(edges[:-1], np.diff(edges))
@@ -373,3 +391,25 @@ def test_cfg3_genome_scale_properties(O):
             d.close()
     assert tot_and + tot_or == tot_a + tot_b
     assert 0.30 < tot_a / 3_095_677_412 < 0.45  # ~38 % coverage per set
+    # the same genome through ONE launch per operation (BitSetGroup): popcounts, iand with counts, ior, the run lists
+    chroms = list(synth.HG19_SIZES)
+    A = [DeviceBitSet(synth.HG19_SIZES[c]) for c in chroms]
+    B = [DeviceBitSet(synth.HG19_SIZES[c]) for c in chroms]
+    A2 = [DeviceBitSet(synth.HG19_SIZES[c]) for c in chroms]
+    for c, a, b, a2 in zip(chroms, A, B, A2):
+        a.set_ranges(*ra[c]), b.set_ranges(*rb[c]), a2.set_ranges(*ra[c])
+    gA, gB, gA2 = BitSetGroup(A), BitSetGroup(B), BitSetGroup(A2)
+    assert gA.popcounts().tolist() == [gold[c]["pop_a"] for c in chroms]
+    assert gB.popcounts().tolist() == [gold[c]["pop_b"] for c in chroms]
+    gA2.ior(gB)
+    assert gA2.popcounts().tolist() == [gold[c]["pop_or"] for c in chroms]
+    assert gA.iand(gB, want_counts=True).tolist() == [gold[c]["pop_and"] for c in chroms]
+    assert gA.popcounts().tolist() == [gold[c]["pop_and"] for c in chroms]
+    assert gB.popcounts().tolist() == [gold[c]["pop_b"] for c in chroms]  # the other operand is untouched
+    for c, a in zip(chroms, A):
+        rs, re = a.runs()
+        assert len(rs) == gold[c]["n_runs"] and _runs_sha(rs, re) == gold[c]["runs_sha256"], c
+    for grp in (gA, gB, gA2):
+        grp.close()
+    for d in A + B + A2:
+        d.close()

@@ -807,11 +807,11 @@ def test_scale_cfg2_full_size_properties(golden_scale, IntervalIndex):
     ix = make_index(IntervalIndex, ts, te)
     counts, total = ix.count(qs, qe)
     assert total == int(counts.sum(dtype=np.int64))
-    if key in golden_scale:
-        pt = golden_scale[key]
-        sub = counts[:: pt["stride"]]
-        assert int(sub.sum(dtype=np.int64)) == pt["total"]
-        assert hashlib.sha256(np.ascontiguousarray(sub).tobytes()).hexdigest() == pt["counts_sha256"]
+    assert key in golden_scale, "tests/golden/scale.json lost its %r point: the reference check of configs[1] must not vanish silently" % key
+    pt = golden_scale[key]
+    sub = counts[:: pt["stride"]]
+    assert int(sub.sum(dtype=np.int64)) == pt["total"]
+    assert hashlib.sha256(np.ascontiguousarray(sub).tobytes()).hexdigest() == pt["counts_sha256"]
     assert ix.flat_state()[0] == 1 and ix.dense_state()[0] == 0  # the full batch above went through the flat walk on cell images
     # the direct tree kernel and the large-batch passes agree (first 8M queries through the direct kernel)
     set_opt("ivl.partition", 0)
@@ -1311,8 +1311,7 @@ def test_find_join_cfg5_full_size_golden(golden_scale_doc, IntervalIndex):
     "cfg5_join", made by oracle/gen_golden.py --only join), both for the batch as generated (bucketed find) and sorted by
     start (local find); the whole result against the count pass."""
     g = golden_scale_doc.get("cfg5_join")
-    if not g:
-        pytest.skip("tests/golden/scale.json has no cfg5_join point")
+    assert g, "tests/golden/scale.json has no cfg5_join point: the reference check of configs[4] must not vanish silently"
     (ts, te), (qs, qe) = synth.cfg5(g["n_targets"], g["n_queries_total"])
     ix = make_index(IntervalIndex, ts, te)
     offs, hits = ix.find(qs, qe, cap_hint=6 * len(qs))

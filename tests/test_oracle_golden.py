@@ -157,8 +157,7 @@ def test_scale_1M_hash(golden_scale):
 @pytest.mark.slow
 def test_scale_10M_hash(golden_scale):
     key = "10M x 1M (cfg2 subsample)"
-    if key not in golden_scale:
-        pytest.skip("10M point not generated")
+    assert key in golden_scale, "tests/golden/scale.json lost its %r point" % key
     pt = golden_scale[key]
     counts, total = _scale_counts(pt)
     assert total == pt["total"]
@@ -169,6 +168,27 @@ def test_scale_10M_hash(golden_scale):
 def test_binnedbitset_matches_reference_vectors(golden_bitsets):
     for case in golden_bitsets["cases"]:
         replay(case, O.OracleBinnedBitSet)
+
+
+def test_binnedbitset_genome_scale_vectors(golden_scale_doc):
+    """configs[2] at scale: the restatement against the real bx.bitset on the three smallest chromosomes of the cfg 3
+    genome (tests/golden/scale.json "cfg3_bitsets": popcounts of A, B, A & B, A | B and the run list of A & B)."""
+    g = golden_scale_doc.get("cfg3_bitsets")
+    assert g, "tests/golden/scale.json has no cfg3_bitsets point"
+    ra, rb = synth.genome_ranges(1_500_000, 301), synth.genome_ranges(1_500_000, 302)
+    for chrom in ("chr21", "chr22", "chrY"):
+        want, size = g["chroms"][chrom], synth.HG19_SIZES[chrom]
+        a, b, a2 = O.OracleBinnedBitSet(size), O.OracleBinnedBitSet(size), O.OracleBinnedBitSet(size)
+        a.set_ranges(*ra[chrom]), b.set_ranges(*rb[chrom]), a2.set_ranges(*ra[chrom])
+        assert (a.count_range(0, size), b.count_range(0, size)) == (want["pop_a"], want["pop_b"])
+        a2.ior(b)
+        assert a2.count_range(0, size) == want["pop_or"]
+        a.iand(b)
+        assert a.count_range(0, size) == want["pop_and"]
+        rs, re = a.runs()
+        assert len(rs) == want["n_runs"]
+        runs = np.concatenate([np.asarray(rs, dtype=np.int64), np.asarray(re, dtype=np.int64)])
+        assert hashlib.sha256(runs.tobytes()).hexdigest() == want["runs_sha256"]
 
 
 def test_binnedbitset_big_sizes(golden_bitsets):
