@@ -14,7 +14,7 @@ pids=()
 for f in core intervals bitset bedparse comm; do
   src="$HERE/$f.hip"; [ -f "$src" ] || src="$HERE/$f.cpp"
   if [ ! -f "$OBJ/$f.o" ] || [ "$src" -nt "$OBJ/$f.o" ] || [ "$HERE/common.hpp" -nt "$OBJ/$f.o" ] \
-     || [ "$HERE/primitives.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_bitmap.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_slices.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_dense.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/bxmi.h" -nt "$OBJ/$f.o" ]; then
+     || [ "$HERE/primitives.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_bitmap.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_slices.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_dense.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/find_exchange.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/offset_cells.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/bxmi.h" -nt "$OBJ/$f.o" ]; then
     $HIPCC $FLAGS -c "$src" -o "$OBJ/$f.o" &
     pids+=($!)
   fi

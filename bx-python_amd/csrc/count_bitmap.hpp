@@ -222,6 +222,18 @@ __device__ __forceinline__ unsigned bm_bucket_of(int qs, const BmGeom &g)
     return b < (unsigned)(BM_NB - 1) ? b : (unsigned)(BM_NB - 1);
 }
 
+// SUB = 2 (find() through the exchange, find_exchange.hpp): the tile is ordered by HALF buckets -- 2 * BM_NB keys, the same
+// grid one bit finer -- so that a (tile, bucket) run is itself ordered by half and the fill half can serve every half
+// bucket from its own LDS window of (end, index) pairs.  Needs g.shift >= 1.
+template <int SUB>
+__device__ __forceinline__ unsigned bm_sort_key_of(int qs, const BmGeom &g)
+{
+    if (SUB == 1) return bm_bucket_of(qs, g);
+    if (qs < g.cmin) return 0;
+    const unsigned b = ((unsigned)qs - (unsigned)g.cmin) >> (g.shift - 1);
+    return b < (unsigned)(2 * BM_NB - 1) ? b : (unsigned)(2 * BM_NB - 1);
+}
+
 // The record of a query the search kernel can answer from its bucket's image; anything else becomes an escape record.
 __device__ __forceinline__ unsigned bm_record_of(int qs, int qe, const BmGeom &g)
 {
@@ -246,25 +258,28 @@ constexpr int BM_PAD_ROOM = 4096 + 544;
 #define BM_TS_EXP 0
 #endif
 
-template <int THREADS, int ITEMS, bool PAD = false>
+template <int THREADS, int ITEMS, bool PAD = false, int SUB = 1>
 __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
                                                                unsigned *__restrict__ recs /* [ntiles][TILE (+ BM_PAD_ROOM)], tile-sorted */,
                                                                unsigned short *__restrict__ slots /* [nq] slot of every query in its tile */,
                                                                unsigned short *__restrict__ tbl /* [ntiles][BM_NB] first slot of every bucket */,
                                                                const unsigned *__restrict__ gate /* NULL, or 0 = sorted batch: stand down */,
-                                                               unsigned *__restrict__ tend = nullptr /* PAD: [ntiles] slots used */)
+                                                               unsigned *__restrict__ tend = nullptr /* PAD: [ntiles] slots used */,
+                                                               unsigned short *__restrict__ tbl2 = nullptr /* SUB = 2: [ntiles][2 * BM_NB] first slot of every half bucket */)
 {
     constexpr int TILE = THREADS * ITEMS;
     if (gate && *gate == 0) return;
-    constexpr int BPT = BM_NB / THREADS;  // buckets per thread in the scan
-    static_assert(BM_NB % THREADS == 0 && (BPT == 2 || BPT == 4), "2 or 4 buckets per thread");
+    constexpr int NBK = BM_NB * SUB;     // sort keys: buckets, or half buckets
+    constexpr int BPT = NBK / THREADS;   // keys per thread in the scan
+    static_assert(NBK % THREADS == 0 && (BPT == 2 || BPT == 4), "2 or 4 buckets per thread");
+    static_assert(SUB == 1 || (SUB == 2 && !PAD && BPT == 4), "half buckets: packed runs, 1024-thread shapes");
     constexpr int STAGED = PAD ? TILE + 3 * THREADS : TILE;  // (at most one unit per thread: three pad slots each)
     constexpr int STRIDE = PAD ? TILE + BM_PAD_ROOM : TILE;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     unsigned *staged = reinterpret_cast<unsigned *>(dyn);                          // [STAGED] records in sorted order
-    unsigned *cnt = staged + STAGED;                                               // [BM_NB]
-    unsigned short *toff = reinterpret_cast<unsigned short *>(cnt + BM_NB);        // [BM_NB]
-    unsigned *scan_tmp = reinterpret_cast<unsigned *>(toff + BM_NB);               // [16]
+    unsigned *cnt = staged + STAGED;                                               // [NBK]
+    unsigned short *toff = reinterpret_cast<unsigned short *>(cnt + NBK);          // [NBK]
+    unsigned *scan_tmp = reinterpret_cast<unsigned *>(toff + NBK);                 // [16]
     const int64_t tile = blockIdx.x;
     const BmSeg &sg = segs[tile_seg[tile]];
     const int64_t ltile = tile - sg.tile0;
@@ -276,7 +291,7 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
     const int64_t base = 0;
     const int n = (int)(nq < TILE ? nq : TILE);
     int n_out = n;  // slots of the sorted tile (PAD: the units' gaps included)
-    for (int i = threadIdx.x; i < BM_NB; i += THREADS) cnt[i] = 0;
+    for (int i = threadIdx.x; i < NBK; i += THREADS) cnt[i] = 0;
     __syncthreads();
     unsigned br[ITEMS];  // bucket << 16 | rank inside the (tile, bucket) run
     int4 vs[ITEMS / 4], ve[ITEMS / 4];
@@ -288,7 +303,8 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
         for (int j = 0; j < ITEMS / 4; j++) ve[j] = e4[j * THREADS + threadIdx.x];
 #pragma unroll
         for (int j = 0; j < ITEMS / 4; j++) {
-            const unsigned bx = bm_bucket_of(vs[j].x, g), by = bm_bucket_of(vs[j].y, g), bz = bm_bucket_of(vs[j].z, g), bw = bm_bucket_of(vs[j].w, g);
+            const unsigned bx = bm_sort_key_of<SUB>(vs[j].x, g), by = bm_sort_key_of<SUB>(vs[j].y, g), bz = bm_sort_key_of<SUB>(vs[j].z, g),
+                           bw = bm_sort_key_of<SUB>(vs[j].w, g);
             // a sorted batch puts the wave's 256 consecutive queries in one bucket: one lane adds for all of them
             // (256 same-address LDS atomics serialise otherwise)
             const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bx);
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
         for (int j = 0; j < ITEMS; j++) {
             const int k = j * THREADS + threadIdx.x;
             if (k < n) {
-                const unsigned b = bm_bucket_of(qs[base + k], g);
+                const unsigned b = bm_sort_key_of<SUB>(qs[base + k], g);
                 br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
             }
         }
@@ -362,11 +378,18 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
             toff[BPT * threadIdx.x + u] = o[u];
             exc += c[u];
         }
+        if (SUB == 2) {
+            // the thread's four half buckets are two whole buckets: the bucket table as every other kernel reads it, and the finer one
+            *reinterpret_cast<unsigned *>(tbl + tile * BM_NB + 2 * threadIdx.x) = (unsigned)o[0] | ((unsigned)o[2 % BPT] << 16);
+            *reinterpret_cast<uint2 *>(tbl2 + tile * NBK + BPT * threadIdx.x) =
+                make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2 % BPT] | ((unsigned)o[BPT - 1] << 16));
+        } else {
         unsigned short *row = tbl + tile * BM_NB + BPT * threadIdx.x;
         if (BPT == 4)
             *reinterpret_cast<uint2 *>(row) = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[BPT - 1] << 16));
         else
             *reinterpret_cast<unsigned *>(row) = (unsigned)o[0] | ((unsigned)o[1] << 16);
+        }
     }
     __syncthreads();
     if (n == TILE) {
@@ -413,10 +436,12 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
 // ---------------------------------------------------------------------------
 // tbl[tile][bucket] (16-bit first slots) -> runT[bucket][tile] = first slot | length << 16, a 64 x 64 patch per workgroup;
 // grpcnt[group][bucket] = queries of the bucket in the 64 tiles of the group.
+// (NBK = 2 * BM_NB, grpcnt = NULL: the same transposition of the half-bucket table of find(), find_exchange.hpp)
+template <int NBK = BM_NB>
 __global__ __launch_bounds__(256) void bm_transpose_kernel(const unsigned short *__restrict__ tbl, const BmSeg *__restrict__ segs,
                                                            const unsigned short *__restrict__ tile_seg, int tile_log2,
-                                                           unsigned *__restrict__ runT /* [BM_NB][ntp] */, int64_t ntp,
-                                                           unsigned *__restrict__ grpcnt /* [ngroups][BM_NB] */, const unsigned *__restrict__ gate)
+                                                           unsigned *__restrict__ runT /* [NBK][ntp] */, int64_t ntp,
+                                                           unsigned *__restrict__ grpcnt /* [ngroups][NBK], may be NULL */, const unsigned *__restrict__ gate)
 {
     __shared__ unsigned short t[BM_GROUP_TILES][66];
     if (gate && *gate == 0) return;
@@ -428,7 +453,7 @@ __global__ __launch_bounds__(256) void bm_transpose_kernel(const unsigned short 
         const bool live = tile - sg.tile0 < sg.ntiles;
         const int64_t left = sg.nq - ((tile - sg.tile0) << tile_log2);
         const unsigned ntile = !live ? 0u : (left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2);
-        const unsigned short *row = tbl + tile * BM_NB + b0 + 16 * q;
+        const unsigned short *row = tbl + tile * NBK + b0 + 16 * q;
         uint4 a = make_uint4(0, 0, 0, 0), c = a;
         if (live) {
             a = *reinterpret_cast<const uint4 *>(row);
@@ -441,7 +466,7 @@ __global__ __launch_bounds__(256) void bm_transpose_kernel(const unsigned short 
             t[r][16 * q + 2 * i + 1] = (unsigned short)(w[i] >> 16);
         }
         // (a full tile's total is 1 << 16 when the tile has 65536 queries: lengths are taken modulo 2^16 below, see host)
-        if (q == 3) t[r][64] = (unsigned short)(b0 + 64 < BM_NB ? (live ? row[16] : 0) : ntile);
+        if (q == 3) t[r][64] = (unsigned short)(b0 + 64 < NBK ? (live ? row[16] : 0) : ntile);
     }
     __syncthreads();
     {
@@ -459,7 +484,7 @@ __global__ __launch_bounds__(256) void bm_transpose_kernel(const unsigned short 
         for (int i = 0; i < 4; i++) reinterpret_cast<uint4 *>(dst)[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
         sum += __shfl_xor(sum, 1, 64);
         sum += __shfl_xor(sum, 2, 64);
-        if (q == 0) grpcnt[(int64_t)grp * BM_NB + b0 + c] = sum;
+        if (q == 0 && grpcnt) grpcnt[(int64_t)grp * NBK + b0 + c] = sum;
     }
 }
 
@@ -595,18 +620,30 @@ __device__ __forceinline__ int bm_escape_count(const IndexDev &ix, const int32_t
 // FIND: also leave loff[tile-sorted position] = exclusive prefix of the counts inside the tile, in tile-sorted order
 // (bit 31 = escape record, which contributes nothing): where the record's hits go in the tile's scratch region
 // (count_slices.hpp, sl_fill_pipe_kernel).
-template <int THREADS, int ITEMS, bool FIND = false>
+// FIND = 2 (find_exchange.hpp): additionally, in QUERY order, svq[query] = that offset of the query's record (so that the hit
+// copy streams it instead of gathering it through the slot), and the sums of the counts of every BM_PART_Q consecutive
+// queries (`parts`) and of the tile (`tile_tot`): the CSR offsets are then one scan over the TILES away -- the copy kernel
+// finishes them inside each part -- instead of a three-kernel scan over all queries.
+constexpr int BM_PART_Q = 1024;
+template <int THREADS, int ITEMS, int FIND = 0>
 __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *__restrict__ cnt /* tile-sorted: the records array after the search */,
                                                                const unsigned short *__restrict__ slots, const BmSeg *__restrict__ segs,
                                                                const unsigned short *__restrict__ tile_seg,
                                                                unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS], may be NULL */,
-                                                               const unsigned *__restrict__ gate, unsigned *__restrict__ loff = nullptr)
+                                                               const unsigned *__restrict__ gate, unsigned *__restrict__ loff = nullptr,
+                                                               unsigned *__restrict__ svq = nullptr /* FIND 2: [ntp][TILE] */,
+                                                               unsigned long long *__restrict__ parts = nullptr /* FIND 2: [ntp][TILE / BM_PART_Q] */,
+                                                               unsigned long long *__restrict__ tile_tot = nullptr /* FIND 2: [ntp] */)
 {
     constexpr int TILE = THREADS * ITEMS;
+    constexpr int PARTS = TILE / BM_PART_Q;
+    static_assert(FIND != 2 || (THREADS == 1024 && TILE % BM_PART_Q == 0), "parts of 1024 queries = 256 threads' four-query groups");
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     if (gate && *gate == 0) return;
     unsigned *vals = reinterpret_cast<unsigned *>(dyn);  // [TILE]
     __shared__ long long red[THREADS / 64];
+    __shared__ unsigned long long s_part[FIND == 2 ? PARTS : 1];
+    if (FIND == 2 && threadIdx.x < PARTS) s_part[threadIdx.x] = 0ull;
     const int64_t tile = blockIdx.x;
     const int seg_id = tile_seg[tile];
     const BmSeg &sg = segs[seg_id];
@@ -635,9 +672,45 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
         }
     }
     __syncthreads();
+    long long acc = 0;
+    if (n == TILE) {
+        const uint2 *l4 = reinterpret_cast<const uint2 *>(slots + base);
+        int4 *o4 = reinterpret_cast<int4 *>(out + base);
+        uint2 sl[ITEMS / 4];
+#pragma unroll
+        for (int j = 0; j < ITEMS / 4; j++) sl[j] = l4[j * THREADS + threadIdx.x];
+#pragma unroll
+        for (int j = 0; j < ITEMS / 4; j++) {
+            unsigned c[4] = {vals[sl[j].x & 0xffffu], vals[sl[j].x >> 16], vals[sl[j].y & 0xffffu], vals[sl[j].y >> 16]};
+            if (c[0] == BM_REC_ESC || c[1] == BM_REC_ESC || c[2] == BM_REC_ESC || c[3] == BM_REC_ESC) {
+                const int64_t k0 = base + 4 * (int64_t)(j * THREADS + threadIdx.x);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (c[u] == BM_REC_ESC) c[u] = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k0 + u], qe_arr[k0 + u]);
+            }
+            if (sg.counts) o4[j * THREADS + threadIdx.x] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);  // (NULL: the caller wants the total only)
+            acc += (long long)c[0] + c[1] + c[2] + c[3];
+            if (FIND == 2) {  // the four queries 4 (j THREADS + t) ..: part 4 j + t / 256 -- one part per wave and j
+                unsigned long long ws = (unsigned long long)c[0] + c[1] + c[2] + c[3];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) ws += __shfl_down(ws, off, 64);
+                if (lane_id() == 0 && ws) atomicAdd(&s_part[j * (THREADS / 256) + (int)(threadIdx.x >> 8)], ws);
+            }
+        }
+    } else {
+        for (int k = threadIdx.x; k < n; k += THREADS) {
+            unsigned c = vals[slots[base + k]];
+            if (c == BM_REC_ESC) c = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[base + k], qe_arr[base + k]);
+            if (sg.counts) out[base + k] = (int)c;
+            acc += c;
+            if (FIND == 2 && c) atomicAdd(&s_part[k / BM_PART_Q], (unsigned long long)c);
+        }
+    }
+    constexpr int NW = THREADS / 64, PER_WAVE = TILE / NW, CH = FIND ? PER_WAVE / 64 : 1;
     if (FIND) {
+        // (after the counts were picked: the offsets take their place in LDS below, and `e` is not live across the loop above)
+        __syncthreads();
         // every wave scans its contiguous share of the tile, 64 positions at a time
-        constexpr int NW = THREADS / 64, PER_WAVE = TILE / NW, CH = PER_WAVE / 64;
         __shared__ unsigned s_wtot[NW];
         const int w = threadIdx.x >> 6, lane = lane_id();
         unsigned e[CH], carry = 0;
@@ -659,34 +732,31 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
 #pragma unroll
         for (int c = 0; c < CH; c++) {
             const int idx = w * PER_WAVE + c * 64 + lane;
-            lo_out[idx] = ((e[c] & 0x7FFFFFFFu) + wbase) | (e[c] & 0x80000000u);
+            const unsigned v = ((e[c] & 0x7FFFFFFFu) + wbase) | (e[c] & 0x80000000u);
+            lo_out[idx] = v;
+            if (FIND == 2) vals[idx] = v;  // (this lane read the count of the same position above)
         }
     }
-    long long acc = 0;
-    if (n == TILE) {
-        const uint2 *l4 = reinterpret_cast<const uint2 *>(slots + base);
-        int4 *o4 = reinterpret_cast<int4 *>(out + base);
-        uint2 sl[ITEMS / 4];
-#pragma unroll
-        for (int j = 0; j < ITEMS / 4; j++) sl[j] = l4[j * THREADS + threadIdx.x];
-#pragma unroll
-        for (int j = 0; j < ITEMS / 4; j++) {
-            unsigned c[4] = {vals[sl[j].x & 0xffffu], vals[sl[j].x >> 16], vals[sl[j].y & 0xffffu], vals[sl[j].y >> 16]};
-            if (c[0] == BM_REC_ESC || c[1] == BM_REC_ESC || c[2] == BM_REC_ESC || c[3] == BM_REC_ESC) {
-                const int64_t k0 = base + 4 * (int64_t)(j * THREADS + threadIdx.x);
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (c[u] == BM_REC_ESC) c[u] = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k0 + u], qe_arr[k0 + u]);
-            }
-            if (sg.counts) o4[j * THREADS + threadIdx.x] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);  // (NULL: the caller wants the total only)
-            acc += (long long)c[0] + c[1] + c[2] + c[3];
+    if (FIND == 2) {
+        __syncthreads();  // the tile-sorted offsets have taken the counts' place in LDS, every part sum is complete
+        if (threadIdx.x < PARTS) parts[tile * PARTS + threadIdx.x] = s_part[threadIdx.x];
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int i = 0; i < PARTS; i++) t += s_part[i];
+            tile_tot[tile] = t;
         }
-    } else {
-        for (int k = threadIdx.x; k < n; k += THREADS) {
-            unsigned c = vals[slots[base + k]];
-            if (c == BM_REC_ESC) c = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[base + k], qe_arr[base + k]);
-            if (sg.counts) out[base + k] = (int)c;
-            acc += c;
+        // ... and are picked through the slots like the counts were
+        unsigned *sv_out = svq + tile * TILE;
+        if (n == TILE) {
+            const uint2 *l4 = reinterpret_cast<const uint2 *>(slots + base);  // (a second read of the tile's 64 KB of slots: L2 hits)
+#pragma unroll
+            for (int j = 0; j < ITEMS / 4; j++) {
+                const uint2 sl = l4[j * THREADS + threadIdx.x];
+                reinterpret_cast<uint4 *>(sv_out)[j * THREADS + threadIdx.x] =
+                    make_uint4(vals[sl.x & 0xffffu], vals[sl.x >> 16], vals[sl.y & 0xffffu], vals[sl.y >> 16]);
+            }
+        } else {
+            for (int k = threadIdx.x; k < n; k += THREADS) sv_out[k] = vals[slots[base + k]];
         }
     }
     if (total_slots) block_accumulate_i64(acc, red, total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)));

@@ -218,6 +218,20 @@ __device__ __forceinline__ unsigned sl_count_record(const SlUnit &U, const BmGeo
     return (unsigned)((U.sLo - U.eLo) + (rS - rE));
 }
 
+// find() through the exchange (find_exchange.hpp): the count and, packed for the fill half, `hc` = min(count, 0xFFFF) |
+// (rank of qe among the unit's staged starts) << 16 -- the fill walks down from hi = sLo + that rank and never looks a key up.
+__device__ __forceinline__ unsigned sl_count_record_hc(const SlUnit &U, const BmGeom &g, unsigned rec, unsigned &hc)
+{
+    const unsigned len = rec >> g.rshift, off = rec & ((1u << g.rshift) - 1u);
+    hc = 0u;
+    if (len == bm_len_esc(g)) return BM_REC_ESC;
+    const int rE = sl_rank(U.lowE, U.dirE, off + 1u, g.dshift, U.steps);
+    const int rS = sl_rank(U.lowS, U.dirS, off + len, g.dshift, U.steps);
+    const unsigned c = (unsigned)((U.sLo - U.eLo) + (rS - rE));
+    hc = (c < 0xFFFFu ? c : 0xFFFFu) | ((unsigned)rS << 16);
+    return c;
+}
+
 // The four records of a 16-byte slot at once (the flat walk of count_dense.hpp): the eight ranks advance in step -- their
 // directory reads, then every halving's eight key reads, are in flight together -- instead of one rank after the other,
 // each a chain of 2 + steps dependent LDS reads (round 4: the slice search of a genome share spent its time waiting for
@@ -280,7 +294,7 @@ template <int L, int U, bool APART>
 __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void sl_search_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                     const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
                                                                     unsigned *__restrict__ recs, unsigned *__restrict__ out_apart, int tile_log2,
-                                                                    const unsigned *__restrict__ gate)
+                                                                    const unsigned *__restrict__ gate, unsigned *__restrict__ hc_out = nullptr /* APART: see sl_count_record_hc */)
 {
     unsigned *const out = APART ? out_apart : recs;  // (based on one of the two restrict parameters)
     if (gate && *gate == 0) return;
@@ -324,7 +338,14 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const SlUnit UN = sl_stage_unit(sg, unit, dyn, s_tmp);
     if (threadIdx.x == 0) s_nlong = 0;
     __syncthreads();
-    auto answer = [&](unsigned at, unsigned rec) { out[(size_t)at] = sl_count_record(UN, g, rec); };
+    auto answer = [&](unsigned at, unsigned rec) {
+        if (APART && hc_out) {
+            unsigned hc;
+            out[(size_t)at] = sl_count_record_hc(UN, g, rec, hc);
+            hc_out[(size_t)at] = hc;
+        } else
+            out[(size_t)at] = sl_count_record(UN, g, rec);
+    };
     auto prep = [&](BmRound<U> &R, int tb) {
         unsigned cum = 0, lf_at = ~0u, listed_mask = 0;
 #pragma unroll

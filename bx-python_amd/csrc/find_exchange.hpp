@@ -1,0 +1,328 @@
+// find_exchange.hpp -- the fill half of find() through the exchange, second generation ("fx_*" kernels).  Included by
+// intervals.hip after count_slices.hpp, whose count half (tile sort, run table, plan, slice search, un-permute) it keeps.
+//
+// IntervalTree.find for a large unsorted batch (intersection.pyx:400-406 -> :180-189; scripts/interval_join.py:16-30), hits
+// as CSR in query order.  Round 2's fill half (count_slices.hpp: sl_fill_pipe_kernel, sl_hits_copy_kernel) is bound by the
+// number of requests the CUs send to the L2, not by bytes: measured on configs[4] (profiles/r04_find_pmc.txt) the fill sends
+// 93 M read and 139 M write requests for 50 M records -- every record drags its own 128-byte line of (end, index) pairs from
+// HBM (5.9 GB for 0.4 GB of index) and leaves its ~5 hits as single 4-byte stores -- and the copy another 118 M; both run at the
+// same ~135 G requests per second.  What changes here:
+//   1. The tile sort orders a tile by HALF buckets (bm_tile_sort_kernel<.., SUB = 2>): a (tile, bucket) run is itself sorted
+//      by half, and the table of half-bucket runs is transposed like the bucket table (runT2[half][tile]).
+//   2. The index is cut, once per sealed index and unit size, into PIECES: consecutive half buckets of one unit whose
+//      candidates -- every rank a record of the piece can reach walking down from hi = #{start < qe} -- fit one LDS WINDOW of
+//      FX_CAPW (end, index) pairs.  A fill workgroup stages the piece's window once (coalesced), then walks the piece's
+//      records of ALL tiles as one flat sequence (a wave takes 64 tiles' runs at a time, laid end to end under a prefix sum):
+//      no index line is fetched twice, no lookup: `hi` and the count come from the count half (`hc`, sl_count_record_hc).
+//   3. A wave's hits are collected in LDS and leave as 16-byte stores per record (20 bytes per record on configs[4]: two
+//      stores instead of five, and neighbouring lanes = neighbouring records of a run write neighbouring bytes).
+//   4. The CSR offsets need no scan over the queries: the un-permute kernel leaves the sum of every 1024 queries' counts and of
+//      every tile (bm_unpermute_kernel<.., FIND = 2>), one workgroup scans the TILE sums (fx_tile_scan_kernel), and the copy
+//      kernel finishes the offsets of its 1024 queries itself while it moves their hits (fx_hits_copy_kernel).  It also reads
+//      the scratch offset of a query from a query-order array the un-permute kernel wrote, instead of gathering it by slot.
+// A record whose walk leaves the staged window (long targets far below, piles larger than the window) reads the pairs from HBM
+// as before: exact either way.  ivl.fx_fill = 0 keeps round 2's kernels.
+#pragma once
+
+namespace bxmi {
+
+constexpr int FX_NBK = 2 * BM_NB;     // half buckets
+constexpr int FX_CAPW = 15360;        // (end, index) pairs of one piece's window in LDS (120 KB)
+constexpr int FX_BACK = 512;          // pairs staged below the lowest `hi` of a piece: the walk of an ordinary record ends inside
+constexpr int FX_HCAP = 512;          // hits a wave collects in LDS per pass of 64 records (mean 320 on configs[4])
+constexpr int FX_THREADS = 1024;
+constexpr int FX_NW = FX_THREADS / 64;
+constexpr size_t FX_LDS_BYTES = (size_t)FX_CAPW * 8 + (size_t)FX_NW * (FX_HCAP * 4 + 64 * 4);
+
+// ranks at half-bucket boundary sb (first coordinate x = cmin + sb * W / 2), sb = 0 .. FX_NBK:
+//   x = #{start < x}, y = #{start < x + SL_MARGIN} (no record's qe reaches further: its length is below 2^(32 - rshift) <= SL_MARGIN)
+__global__ __launch_bounds__(256) void fx_meta_kernel(const int32_t *__restrict__ s_ord, int n, int32_t cmin, int shift, int2 *__restrict__ meta2)
+{
+    const int sb = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (sb > FX_NBK) return;
+    const long long x = (long long)cmin + ((long long)sb << (shift - 1));
+    meta2[sb] = make_int2(bm_rank_lt64(s_ord, n, x), bm_rank_lt64(s_ord, n, x + SL_MARGIN));
+}
+
+// A piece: half buckets [sb0, sb1) of one unit, its window = the ranks [wlo, whi) of the start-ordered index.
+struct FxPiece {
+    int sb0, sb1, wlo, whi;
+};
+
+// Exclusive scan of the tiles' hit totals (one workgroup): tile_base[t] = hits of the tiles before t, tile_base[ntp] = all
+// hits, also written to the caller's offsets[nq].
+__global__ __launch_bounds__(1024) void fx_tile_scan_kernel(const unsigned long long *__restrict__ tile_tot, int64_t ntp, long long *__restrict__ tile_base,
+                                                            long long *__restrict__ grand_total)
+{
+    __shared__ long long lds[16];
+    long long carry = 0;
+    for (int64_t base = 0; base < ntp; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const long long v = i < ntp ? (long long)tile_tot[i] : 0ll;
+        long long total;
+        const long long exc = block_exclusive_scan(v, OpSum(), 0ll, lds, &total);
+        if (i < ntp) tile_base[i] = carry + exc;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        tile_base[ntp] = carry;
+        if (grand_total) *grand_total = carry;
+    }
+}
+
+typedef int fx_v4a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// #{i in [0, 64) : ends[i] <= s}, ends non-decreasing (a wave's inclusive prefix sums in LDS): six halvings.
+__device__ __forceinline__ unsigned fx_locate(const unsigned *ends, unsigned s)
+{
+    unsigned r = 0u;
+#pragma unroll
+    for (unsigned step = 32u; step >= 1u; step >>= 1)
+        if (ends[r + step - 1u] <= s) r += step;
+    return r < 63u ? r : 63u;
+}
+
+// The fill.  Persistent workgroups (one per CU: the window takes 120 KB of its LDS) draw (piece, tile chunk) pairs from a
+// counter.  recs / hc / cnt / loff are in tile-sorted order (tile t's slots at t << tile_log2); tile_base[t] = first hit of
+// tile t's region in tmp_hits.
+__global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__restrict__ segs, const FxPiece *__restrict__ pieces, int npieces, int nchunks,
+                                                            int tiles_per_chunk, const unsigned *__restrict__ runT2 /* [FX_NBK][ntp] */, int64_t ntp,
+                                                            const unsigned *__restrict__ recs, const unsigned *__restrict__ hc,
+                                                            const unsigned *__restrict__ cnt, const unsigned *__restrict__ loff,
+                                                            const long long *__restrict__ tile_base, const int2 *__restrict__ eid /* at index 0 */,
+                                                            const int2 *__restrict__ meta2, int32_t *__restrict__ tmp_hits, int tile_log2,
+                                                            unsigned *__restrict__ work_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ int s_work;
+    int2 *const s_win = reinterpret_cast<int2 *>(dyn);                                  // [FX_CAPW]
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    int32_t *const st = dyn + 2 * FX_CAPW + wave * (FX_HCAP + 64);                       // [FX_HCAP] this wave's hits
+    unsigned *const re = reinterpret_cast<unsigned *>(st + FX_HCAP);                    // [64] where each run of the wave's batch ends
+    const BmSeg &sg = segs[0];
+    const BmGeom g = sg.g;
+    const int ntiles = (int)sg.ntiles;
+    const unsigned omask = (1u << g.rshift) - 1u;
+    const int nwork = npieces * nchunks;
+    for (;;) {
+        if (threadIdx.x == 0) s_work = (int)atomicAdd(work_counter, 1u);
+        __syncthreads();
+        const int work = s_work;
+        if (work >= nwork) break;
+        const FxPiece pc = pieces[work / nchunks];
+        const int t0 = (work % nchunks) * tiles_per_chunk;
+        const int t1 = t0 + tiles_per_chunk < ntiles ? t0 + tiles_per_chunk : ntiles;
+        const int wlo = pc.wlo, whi = pc.whi;
+        // the piece's unit: its first coordinate and the rank of that coordinate among the starts
+        const int unit = pc.sb0 >> (g.f + 1);
+        const long long lo_u = (long long)g.cmin + ((long long)unit << (g.shift + g.f));
+        const int sLo = meta2[unit << (g.f + 1)].x;
+        // stage the window: two pairs per 16-byte load
+        {
+            const int nw = whi - wlo;
+            const int2 *__restrict__ src = eid + wlo;
+            for (int i = 2 * (int)threadIdx.x; i < nw; i += 2 * FX_THREADS) {
+                if (i + 1 < nw) {
+                    const sl_v4a8 v = *reinterpret_cast<const sl_v4a8 *>(src + i);
+                    *reinterpret_cast<int4 *>(s_win + i) = make_int4(v.x, v.y, v.z, v.w);
+                } else
+                    s_win[i] = src[i];
+            }
+        }
+        __syncthreads();
+        auto pair_at = [&](int k) -> int2 { return (k >= wlo && k < whi) ? s_win[k - wlo] : eid[k]; };
+        const unsigned *__restrict__ runs0 = runT2 + (int64_t)pc.sb0 * ntp;
+        const unsigned *__restrict__ runs1 = runT2 + (int64_t)(pc.sb1 - 1) * ntp;
+        for (int tb = t0 + 64 * wave; tb < t1; tb += 64 * FX_NW) {
+            // one run per lane: the piece's records of tile tb + lane
+            const int t = tb + lane;
+            unsigned a = 0u, rlen = 0u;
+            long long tbase = 0;
+            if (t < t1) {
+                const unsigned r0 = runs0[t], r1 = runs1[t];
+                a = r0 & 0xffffu;
+                rlen = (r1 & 0xffffu) + (r1 >> 16) - a;
+                tbase = tile_base[t];
+            }
+            const unsigned rincl = wave_inclusive_scan(rlen, OpSum());
+            const unsigned T = (unsigned)__builtin_amdgcn_readlane((int)rincl, 63);
+            const unsigned rdelta = ((unsigned)t << tile_log2) + a - (rincl - rlen);  // + s = the tile-sorted position of the batch's record s
+            re[lane] = rincl;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (unsigned p0 = 0; p0 < T; p0 += 64u) {
+                const unsigned s = p0 + (unsigned)lane;
+                const bool act = s < T;
+                const unsigned r = fx_locate(re, s);
+                const unsigned at = act ? (unsigned)__shfl((int)rdelta, (int)r, 64) + s : ((unsigned)tb << tile_log2);
+                const long long tb_r = __shfl(tbase, (int)r, 64);
+                const unsigned rec = recs[(size_t)at], h = hc[(size_t)at], lo = loff[(size_t)at];
+                const bool esc = (lo >> 31) != 0u;
+                unsigned n = act && !esc ? (h & 0xffffu) : 0u;
+                if (n == 0xffffu) n = cnt[(size_t)at];  // (a count that did not fit the packed word)
+                const int hi = sLo + (int)(h >> 16);
+                const int qs = (int)(lo_u + (long long)(rec & omask));
+                int32_t *__restrict__ dst = tmp_hits + tb_r + (long long)(lo & 0x7FFFFFFFu);
+                // (prefix sums of the counts clamped to "does not fit": a pile's counts cannot overflow them, and what fits is exact)
+                const unsigned nc = n <= (unsigned)FX_HCAP ? n : (unsigned)FX_HCAP + 1u;
+                const unsigned hincl = wave_inclusive_scan(nc, OpSum());
+                if (__builtin_amdgcn_readlane((int)hincl, 63) == 0) continue;  // (wave-uniform: nothing to emit in this pass)
+                // sub-batches of lanes whose hits fit the wave's LDS image together (normally: all 64 at once)
+                int first = 0;
+                unsigned hbase = 0u;
+                while (first < 64) {
+                    const bool fits = lane >= first && hincl - hbase <= (unsigned)FX_HCAP;
+                    const int k = __popcll(__ballot(fits));  // (hincl is monotone: the lanes that fit are first .. first + k - 1)
+                    const bool direct = k == 0;              // lane `first` alone has more hits than the image holds: straight to HBM
+                    const int cntl = direct ? 1 : k;
+                    const bool in = lane >= first && lane < first + cntl;
+                    const unsigned my_off = hincl - nc - hbase;
+                    int c = in ? (int)n : 0;
+                    int kk = hi - 1;
+                    if (!direct) {
+                        for (int step = 0; step < LANE_WINDOW && c > 0 && kk >= 0; step++, kk--) {
+                            const int2 p = pair_at(kk);
+                            if (p.x > qs) {
+                                --c;
+                                st[my_off + (unsigned)c] = p.y;
+                            }
+                        }
+                    }
+                    unsigned long long m = __ballot(c > 0);  // long walks, and the record that goes straight to HBM: the wave takes them one by one
+                    while (m) {
+                        const int src = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        int C = __shfl(c, src, 64), K = __shfl(kk, src, 64);
+                        const int S = __shfl(qs, src, 64);
+                        const unsigned R = (unsigned)__shfl((int)my_off, src, 64);
+                        int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
+                        while (C > 0 && K >= 0) {
+                            const int kx = K - lane;
+                            int2 p = make_int2(INT_MIN, 0);
+                            if (kx >= 0) p = pair_at(kx);
+                            const bool f = kx >= 0 && p.x > S;
+                            const unsigned long long fm = __ballot(f);
+                            // hits at higher ranks come later in the list: lane 0 (the highest rank of the step) takes the last free slot
+                            const int before = __popcll(fm & ((1ull << lane) - 1ull));
+                            if (f && before < C) {
+                                if (direct)
+                                    D[C - 1 - before] = p.y;
+                                else
+                                    st[R + (unsigned)(C - 1 - before)] = p.y;
+                            }
+                            C -= __popcll(fm);
+                            K -= 64;
+                        }
+                    }
+                    if (!direct) {
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        // every record's hits as 16-byte stores (its place in the tile's region is only 4-byte aligned)
+                        const unsigned nn = in ? n : 0u;
+                        for (unsigned j = 0; __any(j < nn); j += 4u) {
+                            if (j + 4u <= nn) {
+                                fx_v4a4 v;
+                                v.x = st[my_off + j], v.y = st[my_off + j + 1u], v.z = st[my_off + j + 2u], v.w = st[my_off + j + 3u];
+                                *reinterpret_cast<fx_v4a4 *>(dst + j) = v;
+                            } else if (j < nn) {
+                                for (unsigned u = j; u < nn; u++) dst[u] = st[my_off + u];
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next sub-batch / pass overwrites the image)
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    first += cntl;
+                    hbase = (unsigned)__builtin_amdgcn_readlane((int)hincl, first - 1);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (`re` is rewritten by the next batch)
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();  // the next piece's window replaces this one; thread 0 draws the next number
+    }
+}
+
+// The hit copy (sl_hits_copy_kernel's layout: a workgroup takes BM_PART_Q consecutive queries of a tile, the workgroups of a
+// tile follow each other on one XCD) with the CSR offsets finished on the way: offset(query) = tile_base[tile] + the parts
+// of the tile before this one + an exclusive scan of the workgroup's own 1024 counts.  The scratch offset of a query comes
+// from the query-order array `svq` (bit 31 = escape record: answered here from the sealed index).
+template <int TILE>
+__global__ __launch_bounds__(BM_PART_Q) void fx_hits_copy_kernel(const BmSeg *__restrict__ segs, const unsigned *__restrict__ svq,
+                                                                const long long *__restrict__ tile_base, const unsigned long long *__restrict__ parts,
+                                                                const int32_t *__restrict__ tmp_hits, long long *__restrict__ offsets,
+                                                                int32_t *__restrict__ hits, int64_t ntp)
+{
+    constexpr int PARTS = TILE / BM_PART_Q;
+    __shared__ unsigned s_ends[BM_PART_Q / 64][64];  // per wave: where each query's hits end in the wave's stretch
+    __shared__ long long s_scan[16];
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int64_t unit = (int64_t)(blockIdx.x >> 3), units = ((ntp + 7 - xcd) >> 3) * PARTS;  // of this XCD's tiles
+    if (unit >= units) return;
+    const BmSeg &sg = segs[0];
+    const int64_t tile = (unit / PARTS) * 8 + xcd;
+    const int part = (int)(unit % PARTS);
+    if (tile >= sg.ntiles) return;  // padding up to the next plan group
+    const int lane = lane_id();
+    const int64_t q0 = tile * TILE;
+    const int64_t left = sg.nq - q0;
+    const int n = (int)(left < TILE ? left : TILE);
+    const int k = part * BM_PART_Q + (int)threadIdx.x;
+    if (part * BM_PART_Q >= n) return;  // (uniform)
+    const bool live = k < n;
+    const int64_t q = q0 + k;
+    // the part's first CSR offset: the tile's, plus the parts before this one (at most 31 values)
+    long long part_base = tile_base[tile];
+    {
+        long long v = lane < part ? (long long)parts[tile * PARTS + lane] : 0ll;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        part_base += v;
+    }
+    const unsigned my_c = live ? (unsigned)__builtin_nontemporal_load(sg.counts + q) : 0u;
+    const unsigned my_sv = live ? __builtin_nontemporal_load(svq + q) : 0u;  // (find() is one segment: the tile numbering is the query numbering)
+    long long total;
+    const long long o = part_base + block_exclusive_scan((long long)my_c, OpSum(), 0ll, s_scan, &total);
+    if (live) __builtin_nontemporal_store(o, offsets + q);
+    const int32_t *__restrict__ region = tmp_hits + tile_base[tile];
+    // the wave's 64 consecutive queries own one stretch of the CSR list (escape records leave holes in it, filled by their own
+    // lanes); it is copied as ONE flat sequence, lane i taking positions i, i + 64, ... (see sl_hits_copy_kernel)
+    const unsigned n_me = (my_sv >> 31) ? 0u : my_c;
+    const unsigned incl = wave_inclusive_scan(n_me, OpSum());
+    const unsigned wtotal = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    const long long o_first = __shfl(o, 0, 64);
+    int32_t *__restrict__ out = hits + o_first;
+    const unsigned d_src = my_sv - (incl - n_me);                     // + s = the hit's place in the tile's region
+    const unsigned d_dst = (unsigned)(o - o_first) - (incl - n_me);   // + s = its place behind the wave's first CSR offset
+    unsigned *ends = s_ends[threadIdx.x >> 6];
+    ends[lane] = incl;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (unsigned s0 = 0; s0 < wtotal; s0 += 256u) {  // four passes at a time: their loads in flight together
+        unsigned dst[4];
+        bool act[4];
+        int v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (s0 + 64u * j < wtotal) {  // (wave-uniform)
+                const unsigned s = s0 + 64u * j + (unsigned)lane;
+                const unsigned r = fx_locate(ends, s);
+                act[j] = s < wtotal;
+                const unsigned src = (unsigned)__shfl((int)d_src, (int)r, 64) + s;
+                dst[j] = (unsigned)__shfl((int)d_dst, (int)r, 64) + s;
+                v[j] = region[act[j] ? src : 0u];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (s0 + 64u * j < wtotal && act[j]) out[dst[j]] = v[j];
+    }
+    if ((my_sv >> 31) && my_c) {  // escape record: rare, answered from the sealed index by its own lane
+        const IndexDev ix = sg.ix;
+        const int qs = sg.qs[q], qe = sg.qe[q];
+        int cc = (int)my_c;
+        int32_t *__restrict__ dst = hits + o;
+        for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; cc > 0 && j >= 0; j--)
+            if (ix.e_ord[j] > qs) dst[--cc] = ix.idx[j];
+    }
+}
+
+}  // namespace bxmi

@@ -1351,6 +1351,7 @@ __device__ __forceinline__ int count_one_global(const IndexDev &ix, const int32_
 }  // namespace bxmi
 #include "count_bitmap.hpp"
 #include "count_slices.hpp"
+#include "find_exchange.hpp"
 #include "count_dense.hpp"
 namespace bxmi {
 
@@ -2226,6 +2227,7 @@ static int64_t g_opt_find_fill = 0;    // bucketed find: 0 = hits written from b
 static int64_t g_opt_bitmap = -1;      // second-generation count pass (count_bitmap.hpp): -1 = when the index qualifies, 0 = never, 1 = same as -1
 static int64_t g_opt_bitmap_min = 2 << 20;  // auto: batches of at least this many queries take it (when the index qualifies)
 static int64_t g_opt_bm_variant = -1;  // tile kernel shape: -1 = by batch size, 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
+static int64_t g_opt_fx_fill = 1;      // find() through the exchange: 1 = the fill half on LDS windows of half-bucket pieces (find_exchange.hpp), 0 = round 2's fill and copy
 static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
 static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by run length and LDS, else forced (tests)
@@ -2274,6 +2276,7 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.bitmap", &g_opt_bitmap, nullptr},
     {"ivl.bm_variant", &g_opt_bm_variant, [](int64_t value) -> int64_t { return value < 0 || value > 2 ? -1 : value; }},
     {"ivl.find_sliced", &g_opt_find_sliced, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.fx_fill", &g_opt_fx_fill, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.slice", &g_opt_slice, nullptr},
     {"ivl.sl_f", &g_opt_sl_f, [](int64_t value) -> int64_t { return value > SL_MAX_F ? SL_MAX_F : value; }},
     {"ivl.bm_chunk", &g_opt_bm_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
@@ -2354,6 +2357,12 @@ struct bxmi_ivl {
     int sl_state = 0;            // 0 = not decided yet, 1 = boundary table built and a single bucket's keys fit the LDS, -1 = they do not
     unsigned sl_need[SL_MAX_F + 1] = {0, 0, 0, 0, 0, 0, 0};  // most keys a unit of 2^f buckets stages
     DevBuf sl_meta, sl_stats, sl_unitcnt, sl_cnt, sl_loff, sl_hits, sl_eid;
+    // find() through the exchange, second generation (find_exchange.hpp)
+    int fx_state = 0;            // 0 = not decided yet, 1 = the half-bucket ranks are built, -1 = the grid has no half buckets (shift 0)
+    std::vector<int2> fx_meta2_host;   // the ranks at the half-bucket boundaries (read back once per sealed index)
+    std::vector<FxPiece> fx_pieces_host;
+    int fx_pieces_f = -1;        // the unit size (2^f buckets) the piece list was cut for
+    DevBuf fx_meta2, fx_pieces, fx_tbl2, fx_runT2, fx_hc, fx_svq, fx_parts, fx_tile_tot, fx_tile_base, fx_work;
     // dense unit images (count_dense.hpp)
     int bd_state = 0;            // 0 = not decided yet, 1 = images built and the index qualifies, -1 = it does not
     unsigned bd_worst[2] = {0, 0};  // what bd_image_kernel reported: most keys of one block, most overflow entries of one unit
@@ -2838,10 +2847,22 @@ struct BmLaunch {
 };
 
 template <int THREADS, int ITEMS>
-static int bm_launch_tiles(const BmLaunch &L, hipStream_t st)
+static int bm_launch_tiles(const BmLaunch &L, hipStream_t st, bool sub = false)
 {
     constexpr int TILE = THREADS * ITEMS;
     bxmi_ivl *h = L.owner;
+    if (sub) {  // find(): ordered by half buckets, both tables (find_exchange.hpp)
+        if (THREADS != 1024 || L.pad) return fail(BXMI_ESTATE, "bm_launch_tiles: half buckets need a 1024-thread shape on packed runs");
+        constexpr int T2 = THREADS == 1024 ? THREADS : 1024;  // (only the 1024-thread shapes instantiate the kernel)
+        constexpr int I2 = TILE / T2;
+        const size_t lds = (size_t)TILE * 4 + FX_NBK * 4 + FX_NBK * 2 + 64;
+        BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<T2, I2, false, 2>), lds));
+        hipLaunchKernelGGL((bm_tile_sort_kernel<T2, I2, false, 2>), dim3((unsigned)L.ntp), dim3(T2), lds, st, L.segs, L.tile_seg,
+                           h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, (unsigned *)nullptr,
+                           h->fx_tbl2.as<unsigned short>());
+        BXMI_LAUNCH_CHECK();
+        return BXMI_OK;
+    }
     if (L.pad) {
         const size_t lds = (size_t)(TILE + 3 * THREADS) * 4 + BM_NB * 4 + BM_NB * 2 + 64;
         BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, true>), lds));
@@ -2858,14 +2879,20 @@ static int bm_launch_tiles(const BmLaunch &L, hipStream_t st)
 }
 
 template <int THREADS, int ITEMS>
-static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st, const unsigned *cnt = nullptr, unsigned *loff = nullptr)
+static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st, const unsigned *cnt = nullptr, unsigned *loff = nullptr,
+                               bool fx = false)
 {
     bxmi_ivl *h = L.owner;
     const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);
     if (!cnt) cnt = h->bm_recs.as<unsigned>();
-    if (loff) {
-        BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS, true>), lds));
-        hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
+    if (loff && fx) {
+        BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS, 2>), lds));
+        hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS, 2>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, loff, h->fx_svq.as<unsigned>(),
+                           h->fx_parts.as<unsigned long long>(), h->fx_tile_tot.as<unsigned long long>());
+    } else if (loff) {
+        BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS, 1>), lds));
+        hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS, 1>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
                            h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, loff);
     } else {
         BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS>), lds));
@@ -2880,13 +2907,13 @@ static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hip
 // tile sort -> run table + plan -> search -> un-permute -> totals, all on `st`, six launches whatever n is.
 // counts[i] may be NULL (total only: nothing is stored per query); totals_dev[i] may be.  The scratch of hs[0] serves the whole batch.
 template <int LANES>
-static int sl_launch_search(const BmLaunch &L, unsigned grid, hipStream_t st, unsigned *out)
+static int sl_launch_search(const BmLaunch &L, unsigned grid, hipStream_t st, unsigned *out, unsigned *hc = nullptr)
 {
     bxmi_ivl *h = L.owner;
     if (out != h->bm_recs.as<unsigned>()) {
         BXMI_TRY(allow_big_lds((sl_search_pipe_kernel<LANES, 2, true>), L.search_lds));
         hipLaunchKernelGGL((sl_search_pipe_kernel<LANES, 2, true>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
-                           h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), out, L.tile_log2, L.gate);
+                           h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), out, L.tile_log2, L.gate, hc);
     } else {
         BXMI_TRY(allow_big_lds((sl_search_pipe_kernel<LANES, 2, false>), L.search_lds));
         hipLaunchKernelGGL((sl_search_pipe_kernel<LANES, 2, false>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
@@ -2937,6 +2964,9 @@ struct BmFindCtx {
     unsigned sgrid;
     int lanes;       // 16 or 64
     int variant;     // tile shape
+    bool sub = false;  // in: the tile sort orders by half buckets and everything find_exchange.hpp needs is left behind
+    int f = 0;         // out: the unit size the slice geometry picked (2^f buckets)
+    int64_t ntiles = 0;
 };
 
 static int sl_launch_search_flat(const BmLaunch &L, unsigned grid, hipStream_t st)
@@ -3057,6 +3087,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (cells && variant == 0)
         for (int i = 0; i < n; i++)
             if ((wide ? hs[i]->bo_geom : hs[i]->bp_geom).f < 2) variant = 1;
+    const bool fxsub = fx && fx->sub;
+    if (fxsub && (n != 1 || !slices)) return fail(BXMI_ESTATE, "bm_count_segments: the half-bucket order serves find() on one index's slices");
+    if (fxsub && variant == 0) variant = 1;  // (the half-bucket tile sort has the 1024-thread shapes only)
     const int tile_log2 = variant == 2 ? 15 : 14;
     const int64_t tile = (int64_t)1 << tile_log2;
     // the batch's tile numbering: every segment starts on a plan-group boundary
@@ -3131,6 +3164,17 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (fx) {  // find(): counts apart from the records, and the tile-sorted offsets
         BXMI_TRY(h->sl_cnt.reserve((size_t)ntp * tile * 4));
         BXMI_TRY(h->sl_loff.reserve((size_t)ntp * tile * 4));
+    }
+    if (fxsub) {  // ... and what find_exchange.hpp's fill and copy read
+        BXMI_TRY(h->fx_tbl2.reserve((size_t)ntp * FX_NBK * 2));
+        BXMI_TRY(h->fx_runT2.reserve((size_t)ntp * FX_NBK * 4));
+        BXMI_TRY(h->fx_hc.reserve((size_t)ntp * tile * 4));
+        BXMI_TRY(h->fx_svq.reserve((size_t)ntp * tile * 4));
+        BXMI_TRY(h->fx_parts.reserve((size_t)ntp * (tile / BM_PART_Q) * 8));
+        BXMI_TRY(h->fx_tile_tot.reserve((size_t)ntp * 8));
+        BXMI_TRY(h->fx_tile_base.reserve((size_t)(ntp + 1) * 8));
+        fx->f = segs[0].g.f;
+        fx->ntiles = segs[0].ntiles;
     }
     unsigned *search_out = fx ? h->sl_cnt.as<unsigned>() : h->bm_recs.as<unsigned>();
     // parameter block in HBM: [segments][totals pointers][tile -> segment], written by bm_params_kernel from its arguments
@@ -3272,11 +3316,16 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         }
     }
     if (variant == 2)
-        BXMI_TRY((bm_launch_tiles<1024, 32>(L, st)));
+        BXMI_TRY((bm_launch_tiles<1024, 32>(L, st, fxsub)));
     else if (variant == 1)
-        BXMI_TRY((bm_launch_tiles<1024, 16>(L, st)));
+        BXMI_TRY((bm_launch_tiles<1024, 16>(L, st, fxsub)));
     else
         BXMI_TRY((bm_launch_tiles<512, 32>(L, st)));
+    if (fxsub) {  // the half-bucket run table, half-major (nobody needs its group counts: the fill has its own plan)
+        hipLaunchKernelGGL(bm_transpose_kernel<FX_NBK>, dim3((unsigned)ngroups, FX_NBK / 64), dim3(256), 0, st, h->fx_tbl2.as<unsigned short>(), L.segs,
+                           L.tile_seg, tile_log2, h->fx_runT2.as<unsigned>(), ntp, (unsigned *)nullptr, unsorted);
+        BXMI_LAUNCH_CHECK();
+    }
     auto stage_done = [&](const char *what) {
         if (!g_opt_stage_sync) return;
         const hipError_t e = hipStreamSynchronize(st);
@@ -3295,7 +3344,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
             hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg,
                                chunk, h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     } else {
-    hipLaunchKernelGGL(bm_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
+    hipLaunchKernelGGL(bm_transpose_kernel<BM_NB>, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                        tile_log2, h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
     hipLaunchKernelGGL(sl_unit_sums_kernel, dim3((unsigned)ngroups), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), L.segs, L.tile_seg,
                        h->sl_unitcnt.as<unsigned>(), unsorted);
@@ -3314,9 +3363,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         if (lanes == 0)
             BXMI_TRY(sl_launch_search_flat(L, sgrid, st));
         else if (lanes == 64)
-            BXMI_TRY(sl_launch_search<64>(L, sgrid, st, search_out));
+            BXMI_TRY(sl_launch_search<64>(L, sgrid, st, search_out, fxsub ? h->fx_hc.as<unsigned>() : nullptr));
         else
-            BXMI_TRY(sl_launch_search<16>(L, sgrid, st, search_out));
+            BXMI_TRY(sl_launch_search<16>(L, sgrid, st, search_out, fxsub ? h->fx_hc.as<unsigned>() : nullptr));
         if (fx) fx->L = L, fx->sgrid = sgrid, fx->lanes = lanes, fx->variant = variant;
     } else
         BXMI_TRY(bd_launch_search(L, sgrid, cells ? 1 : 0, any_blocks, st));
@@ -3328,9 +3377,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         else
             BXMI_TRY((bd_launch_unpermute<1024, 16>(L, tslots, st)));
     } else if (variant == 2)
-        BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff)));
+        BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff, fxsub)));
     else
-        BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff)));
+        BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff, fxsub)));
     stage_done("unpermute");
     if (any_total || descent) {
         hipLaunchKernelGGL(bm_fold_totals_kernel, dim3((unsigned)n), dim3(64), 0, st, slots,
@@ -3338,6 +3387,109 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
                            (const unsigned *)descent, descent ? h->bd_fb_host + 1 : nullptr, order_seq);
         BXMI_LAUNCH_CHECK();
     }
+    return BXMI_OK;
+}
+
+// The ranks at the half-bucket boundaries (find_exchange.hpp), once per sealed index, with a copy on the host: the piece
+// lists are cut there.
+static int fx_prepare_index(bxmi_ivl *h, hipStream_t st)
+{
+    h->fx_state = -1;
+    if (h->has_reversed || h->n < 1 || h->geom.shift < 1) return BXMI_OK;
+    BXMI_TRY(h->fx_meta2.reserve((size_t)(FX_NBK + 1) * sizeof(int2)));
+    BXMI_TRY(h->fx_work.reserve(64));
+    hipLaunchKernelGGL(fx_meta_kernel, dim3((FX_NBK + 1 + 255) / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), (int)h->n, h->geom.cmin, h->geom.shift,
+                       h->fx_meta2.as<int2>());
+    BXMI_LAUNCH_CHECK();
+    h->fx_meta2_host.resize((size_t)FX_NBK + 1);
+    BXMI_HIP(hipMemcpyAsync(h->fx_meta2_host.data(), h->fx_meta2.p, (size_t)(FX_NBK + 1) * sizeof(int2), hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    h->fx_pieces_f = -1;
+    h->fx_state = 1;
+    return BXMI_OK;
+}
+
+// The piece list for units of 2^f buckets: consecutive half buckets of one unit while the ranks their records can reach --
+// [#{start < first coordinate} - FX_BACK, #{start < last coordinate + SL_MARGIN}) -- fit one LDS window.  A single half
+// bucket that does not fit (a pile) is a piece of its own: the window holds the top of its range, the rest is read from HBM.
+// The upload is stream-ordered and the caller synchronises `st` before the next call can change the host list.
+static int fx_ensure_pieces(bxmi_ivl *h, int f, hipStream_t st)
+{
+    if (h->fx_pieces_f == f) return BXMI_OK;
+    const std::vector<int2> &m = h->fx_meta2_host;
+    std::vector<FxPiece> &out = h->fx_pieces_host;
+    out.clear();
+    const int per_unit = 1 << (f + 1);
+    for (int u0 = 0; u0 < FX_NBK; u0 += per_unit) {
+        const int u1 = u0 + per_unit < FX_NBK ? u0 + per_unit : FX_NBK;
+        int sb = u0;
+        while (sb < u1) {
+            const int lo = m[(size_t)sb].x > FX_BACK ? m[(size_t)sb].x - FX_BACK : 0;
+            int e = sb + 1;
+            while (e < u1 && m[(size_t)e + 1].y - lo <= FX_CAPW) e++;
+            FxPiece pc;
+            pc.sb0 = sb, pc.sb1 = e;
+            pc.whi = m[(size_t)e].y;
+            pc.wlo = pc.whi - lo > FX_CAPW ? pc.whi - FX_CAPW : lo;
+            out.push_back(pc);
+            sb = e;
+        }
+    }
+    BXMI_TRY(h->fx_pieces.reserve(out.size() * sizeof(FxPiece)));
+    BXMI_HIP(hipMemcpyAsync(h->fx_pieces.p, out.data(), out.size() * sizeof(FxPiece), hipMemcpyHostToDevice, st));
+    h->fx_pieces_f = f;
+    return BXMI_OK;
+}
+
+// find() through the exchange, second generation (find_exchange.hpp): the count half on a tile order by half buckets, the
+// CSR offsets from one scan over the tiles' totals, the fill on LDS windows, the copy that finishes the offsets.
+static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits, int64_t cap,
+                       int64_t *total_host, hipStream_t st)
+{
+    BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
+    BmFindCtx fx;
+    fx.sub = true;
+    int32_t *counts = h->q_cnt.as<int32_t>();
+    int64_t *no_total = nullptr;
+    BXMI_TRY(bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &no_total, st, 2, &fx));
+    const int64_t ntp = fx.L.ntp;
+    hipLaunchKernelGGL(fx_tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->fx_tile_tot.as<unsigned long long>(), ntp, h->fx_tile_base.as<long long>(),
+                       reinterpret_cast<long long *>(offsets) + nq);
+    BXMI_LAUNCH_CHECK();
+    BXMI_TRY(fx_ensure_pieces(h, fx.f, st));
+    BXMI_HIP(hipMemsetAsync(h->fx_work.p, 0, 64, st));
+    int64_t total = 0;
+    BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    if (total_host) *total_host = total;
+    if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
+    if (total == 0) {  // (the copy kernel writes the offsets: nothing to copy, so they are zeroed here)
+        BXMI_HIP(hipMemsetAsync(offsets, 0, (size_t)(nq + 1) * 8, st));
+        return BXMI_OK;
+    }
+    BXMI_TRY(h->sl_hits.reserve((size_t)(total + 16) * 4));
+    BXMI_TRY(sl_ensure_eid(h, st));
+    const int npieces = (int)h->fx_pieces_host.size();
+    // enough (piece, tile chunk) pairs to balance 256 persistent workgroups; a chunk is whole groups of 64 tiles (a wave's batch)
+    int64_t nchunks = div_up(2048, npieces);
+    if (nchunks > div_up(fx.ntiles, 64)) nchunks = div_up(fx.ntiles, 64);
+    if (nchunks < 1) nchunks = 1;
+    const int64_t tiles_per_chunk = div_up(div_up(fx.ntiles, nchunks), 64) * 64;
+    nchunks = div_up(fx.ntiles, tiles_per_chunk);
+    BXMI_TRY(allow_big_lds(fx_fill_kernel, FX_LDS_BYTES));
+    hipLaunchKernelGGL(fx_fill_kernel, dim3((unsigned)device_props().cus), dim3(FX_THREADS), FX_LDS_BYTES, st, fx.L.segs, h->fx_pieces.as<FxPiece>(), npieces,
+                       (int)nchunks, (int)tiles_per_chunk, h->fx_runT2.as<unsigned>(), ntp, h->bm_recs.as<unsigned>(), h->fx_hc.as<unsigned>(),
+                       h->sl_cnt.as<unsigned>(), h->sl_loff.as<unsigned>(), h->fx_tile_base.as<long long>(), h->sl_eid.as<int2>() + SL_WALK,
+                       h->fx_meta2.as<int2>(), h->sl_hits.as<int32_t>(), fx.L.tile_log2, h->fx_work.as<unsigned>());
+    BXMI_LAUNCH_CHECK();
+    const unsigned cgrid = (unsigned)(div_up(ntp, 8) * 8 * (((int64_t)1 << fx.L.tile_log2) / BM_PART_Q));
+    if (fx.variant == 2)
+        hipLaunchKernelGGL((fx_hits_copy_kernel<32768>), dim3(cgrid), dim3(BM_PART_Q), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(), h->fx_tile_base.as<long long>(),
+                           h->fx_parts.as<unsigned long long>(), h->sl_hits.as<int32_t>(), reinterpret_cast<long long *>(offsets), hits, ntp);
+    else
+        hipLaunchKernelGGL((fx_hits_copy_kernel<16384>), dim3(cgrid), dim3(BM_PART_Q), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(), h->fx_tile_base.as<long long>(),
+                           h->fx_parts.as<unsigned long long>(), h->sl_hits.as<int32_t>(), reinterpret_cast<long long *>(offsets), hits, ntp);
+    BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
 
@@ -3570,6 +3722,7 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         h->geom.shift = shift;
         h->cmax = cmax;
         h->sl_state = 0;
+        h->fx_state = 0, h->fx_pieces_f = -1;
         h->bd_state = 0;
         h->bp_state = 0;
         h->bo_state = 0;
@@ -3857,6 +4010,10 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
         if (g_opt_find_sliced && g_opt_bitmap != 0 && g_opt_slice != 0 && h->n >= 4096 && nq >= g_opt_bitmap_min &&
             !(((uintptr_t)qs | (uintptr_t)qe) & 15)) {
             if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
+            if (h->sl_state == 1 && g_opt_fx_fill) {
+                if (h->fx_state == 0) BXMI_TRY(fx_prepare_index(h, st));
+                if (h->fx_state == 1) return ivl_find_fx(h, qs, qe, nq, offsets, hits, cap, total_host, st);
+            }
             if (h->sl_state == 1) return ivl_find_sliced(h, qs, qe, nq, offsets, hits, cap, total_host, st);
         }
         return ivl_find_partitioned(h, qs, qe, nq, offsets, hits, cap, total_host, st);

@@ -227,6 +227,65 @@ def test_group_ops_match_per_member_ops(O):
         assert d.count_range(0, d.size) == o.count_range(0, o.size)
 
 
+def test_group_launches_are_gated_on_bytes(B, monkeypatch):
+    """bxmi.builders.group_coverage / group_iand (what bed_coverage / bed_intersect_basewise / bed_subtract_basewise call):
+    a group launch makes every member allocate its whole word array (64 MiB for a default-sized set), so the gate is the
+    bytes that would become resident against the device memory free right now (bxmi_mem_info) -- 100 default-sized sets with
+    a few ranges each must NOT grow to 6.4 GB when memory is tight (here: the allowed fraction turned down), give the same
+    answers through either path, and an out-of-memory group falls back to the per-set loop."""
+    import gc
+
+    from bxmi import _ffi, builders
+
+    def free_bytes():
+        free = _ffi.i64(0)
+        _ffi.call("bxmi_mem_info", _ffi.C.byref(free), None)
+        return free.value
+
+    rng = np.random.default_rng(77)
+    gc.collect()
+    B.BinnedBitSet(100).count_range(0, 10)
+
+    def make(n):
+        out = []
+        for _ in range(n):
+            b = B.BinnedBitSet()
+            for s, c in zip(rng.integers(0, 2_000_000, size=4).tolist(), rng.integers(1, 500, size=4).tolist()):
+                b.set_range(s, c)
+            out.append(b)
+        return out
+
+    xs, ys = make(100), make(100)
+    want_cov = sum(b.count_range(0, b.size) for b in xs)
+    assert builders.group_bytes(xs, ys) == 200 * ((xs[0].size + 7) // 8)
+    free0 = free_bytes()
+    monkeypatch.setattr(builders, "GROUP_MAX_FRACTION_OF_FREE", 1e-4)  # "memory is tight"
+    assert not builders.group_fits(xs) and not builders.group_fits(xs, ys)
+    assert builders.group_coverage(xs) == want_cov
+    ands = [B.BinnedBitSet() for _ in xs]
+    for a, x in zip(ands, xs):
+        a.ior(x)
+    builders.group_iand(ands, ys)
+    want_and = [a.count_range(0, a.size) for a in ands]
+    assert free0 - free_bytes() < (1 << 30), "the per-set loop must leave untouched bins unallocated"
+    monkeypatch.setattr(builders, "GROUP_MAX_FRACTION_OF_FREE", 0.25)
+    assert builders.group_fits(xs, ys)  # 12.8 GB against a 288 GB device
+    assert builders.group_coverage(xs) == want_cov
+    ands2 = [B.BinnedBitSet() for _ in xs]
+    for a, x in zip(ands2, xs):
+        a.ior(x)
+    builders.group_iand(ands2, ys)
+    assert [a.count_range(0, a.size) for a in ands2] == want_and
+
+    # a group that runs out of memory falls back to the loop
+    def boom(*a, **k):
+        raise _ffi.BxmiError(_ffi.ENOMEM, "no room (test)")
+
+    monkeypatch.setattr(builders, "as_group", boom)
+    assert builders.group_coverage(xs) == want_cov
+    assert not builders.group_fits([B.BinnedBitSet(64)] * (builders.GROUP_MAX_MEMBERS + 1))
+
+
 def test_thousands_of_default_sized_sets_stay_small(O, B):
     """bitset_builders.py:31-45 creates one BinnedBitSet(MAX) per sequence name; a scaffold-level assembly has thousands.
     The reference allocates 64 KiB bins on first touch; here the dense words grow lazily to the highest bit needed, so

@@ -584,19 +584,23 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
         reset_opts()
 
 
-@pytest.mark.parametrize("shape", ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target"])
+@pytest.mark.parametrize("shape", ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target", "pile"])
 def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
-    """find() on large unsorted batches (count_slices.hpp: count half, CSR offsets, fill half, hits back to query order)
-    against the oracle treap's find: same offsets, same hits in the same order.  Escapes (zero-length / reversed /
-    off-grid / over-long queries), duplicated coordinates, a tile that is not full, one target spanning everything,
-    all tile shapes, unit sizes and run widths; and the bucketed find of the first generation on the same input."""
-    shapes = ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target"]
+    """find() on large unsorted batches (count_slices.hpp: count half, CSR offsets, fill half, hits back to query order;
+    find_exchange.hpp: the fill on LDS windows of half-bucket pieces, ivl.fx_fill) against the oracle treap's find: same
+    offsets, same hits in the same order.  Escapes (zero-length / reversed / off-grid / over-long queries), duplicated
+    coordinates (queries with more hits than a wave's LDS image holds), a tile that is not full, one target spanning
+    everything (walks that leave the staged window), a pile of targets larger than a piece's window, all tile shapes, unit
+    sizes and run widths, both generations of the fill half; and the bucketed find of the first generation on the same input."""
+    shapes = ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target", "pile"]
     rng = np.random.default_rng(70 + shapes.index(shape))
     n, span = 100_000, 30_000_000
     s = rng.integers(1000, span, size=n)
     if shape == "dups":
         s[: n // 2] = rng.choice(s[n // 2:], size=n // 2)
         s[:1500] = rng.integers(5_000_000, 5_000_040, size=1500)
+    if shape == "pile":
+        s[:25_000] = rng.integers(5_001_000, 5_003_000, size=25_000)  # one half bucket holds more pairs than an LDS window
     e = s + rng.integers(0, 1200, size=n)
     if shape == "long_target":
         s[0], e[0] = 2000, span - 5  # every query meets it, and the walk down from hi passes thousands of candidates
@@ -604,6 +608,9 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
     nq = {"ragged_tail": 16384 * 2 + 311}.get(shape, 50_000)
     qs = rng.integers(0, span + 2000, size=nq)
     qe = qs + rng.integers(1, 2500, size=nq)
+    if shape == "pile":
+        qs[:300] = rng.integers(4_999_000, 5_004_000, size=300)
+        qe[:300] = qs[:300] + rng.integers(1, 400, size=300)
     if shape == "sorted":
         o = np.argsort(qs, kind="stable")
         qs, qe = qs[o], qe[o]
@@ -627,15 +634,18 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
     set_opt("ivl.bitmap_min", 1)
     try:
         for k, (variant, f, lanes, sorted_path) in enumerate(((0, -1, 0, 0), (1, 0, 16, 0), (2, 2, 64, 0), (0, 6, 16, 0), (2, 6, 64, 0), (-1, -1, 0, 1))):
-            set_opt("ivl.sorted_path", sorted_path)
-            set_opt("ivl.bm_variant", variant)
-            set_opt("ivl.sl_f", f)
-            set_opt("ivl.sl_lanes", lanes)
-            off, hits = ix.find(qs, qe)
-            assert ix.slice_state()[0] == 1
-            assert np.array_equal(off, want_off), (shape, variant, f, lanes, np.nonzero(np.diff(off) != np.diff(want_off))[0][:8])
-            bad = np.nonzero(hits != want_hits)[0]
-            assert len(bad) == 0, (shape, variant, f, lanes, bad[:8], hits[bad[:8]], want_hits[bad[:8]])
+            for fx_fill in (1, 0):
+                set_opt("ivl.fx_fill", fx_fill)
+                set_opt("ivl.sorted_path", sorted_path)
+                set_opt("ivl.bm_variant", variant)
+                set_opt("ivl.sl_f", f)
+                set_opt("ivl.sl_lanes", lanes)
+                off, hits = ix.find(qs, qe)
+                assert ix.slice_state()[0] == 1
+                assert np.array_equal(off, want_off), (shape, variant, f, lanes, fx_fill, np.nonzero(np.diff(off) != np.diff(want_off))[0][:8])
+                bad = np.nonzero(hits != want_hits)[0]
+                assert len(bad) == 0, (shape, variant, f, lanes, fx_fill, bad[:8], hits[bad[:8]], want_hits[bad[:8]])
+        set_opt("ivl.fx_fill", 1)
         set_opt("ivl.find_sliced", 0)
         off, hits = ix.find(qs, qe)
         assert np.array_equal(off, want_off) and np.array_equal(hits, want_hits), "bucketed find"
@@ -1287,9 +1297,13 @@ def test_find_join_scale_properties(IntervalIndex):
     finally:
         set_opt("ivl.partition", 1)
     try:
-        offs, hits = ix.find(qs, qe, cap_hint=8 * len(qs))      # bucketed path
+        offs, hits = ix.find(qs, qe, cap_hint=8 * len(qs))      # through the exchange, the fill on LDS windows (244 tiles, several tile chunks per piece)
+        set_opt("ivl.fx_fill", 0)
+        o_offs, o_hits = ix.find(qs, qe, cap_hint=8 * len(qs))  # round 2's fill and copy
+        assert np.array_equal(o_offs, offs) and np.array_equal(o_hits, hits)
+        del o_offs, o_hits
     finally:
-        set_opt("ivl.partition", -1)
+        reset_opts()
     assert np.array_equal(d_offs, offs) and np.array_equal(d_hits, hits)
     counts, total = ix.count(qs, qe)
     assert offs[-1] == total == len(hits) and np.array_equal(np.diff(offs).astype(np.int32), counts)
