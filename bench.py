@@ -496,6 +496,39 @@ def bench_genome(torch, dist, rank, world, steps, warmup, n_targets, n_queries, 
                         reduced_totals_equal_sum_of_owner_counts_every_step=bool(flags[1].item()),
                         overlaps_per_step=int(own_tot.sum().item())),
             build_s=round(mine.index_s, 4), data_generation_and_build_s=round(build_s, 2))
+    if not collective and rank == 0 and not os.environ.get("BENCH_PER_CHROM"):
+        # side legs on one GPU (never `value`): (1) the caller wants the per-chromosome TOTALS only (configs[3]'s "all-reduce on counts"
+        # shape, scripts/bed_count_overlapping.py consumes len(find()) only): no count is stored per query; (2) every chromosome's
+        # queries sorted by start, as a sorted BED file brings them: the walk on cell images answers them as they lie
+        # (count_dense.hpp: bs_check_multi / bs_plan_multi / bs_walk over the segments), no exchange.
+        class TotalsOnly:
+            owned = mine.owned
+
+            def step(self, row):
+                own = mine.owned
+                IntervalIndex.count_multi_dev([mine.ix[c] for c in own], [mine.q[c][0].data_ptr() for c in own], [mine.q[c][1].data_ptr() for c in own],
+                                              [mine.q[c][0].numel() for c in own], [None for c in own], [row[chroms.index(c):].data_ptr() for c in own], stream)
+
+        e2, k2, rows2 = timed(TotalsOnly(), steps, warmup, False)
+        out["total_only"] = dict(ms_per_step=round(e2 / steps * 1e3, 4), kernel_ms=round(k2, 4),
+                                 totals_equal_counts_pass=bool((rows2 == own_tot.unsqueeze(0)).all().item()))
+        for c in mine.owned:
+            qs_c, qe_c = mine.q[c]
+            o = torch.argsort(qs_c, stable=True)
+            mine.q[c] = (qs_c[o].contiguous(), qe_c[o].contiguous())
+            del o
+        warm_rows = torch.zeros((4, len(chroms)), dtype=torch.int64, device="cuda")
+        for k in range(4):  # (the exact order check comes back one call after the probe saw no descent: let the answers arrive)
+            mine.step(warm_rows[k])
+            torch.cuda.synchronize()
+        e3, k3, rows3 = timed(mine, steps, 1, False)
+        sorted_counts_ok = True
+        for c in mine.owned[:3]:  # (three chromosomes' counts against the shuffled pass, as multisets per chromosome total)
+            sorted_counts_ok = sorted_counts_ok and int(mine.counts[c].sum(dtype=torch.int64).item()) == int(own_tot[chroms.index(c)].item())
+        out["sorted_queries"] = dict(ms_per_step=round(e3 / steps * 1e3, 4), kernel_ms=round(k3, 4), value=round(total_q * steps / e3 / 1e6, 2),
+                                     roofline_frac=round(alg_bytes_of(total_q, sum(tsz.values())) / (k3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     totals_equal_shuffled_pass=bool((rows3 == own_tot.unsqueeze(0)).all().item()) and sorted_counts_ok,
+                                     note="every chromosome's queries sorted by start; one bxmi_ivl_count_multi_dev call per step, answered by the sorted walk over segments")
     # the same genome on ONE GPU, in the same run (rank 0 alone; the others wait): what the speed-up is measured against
     if collective and single_gpu_reference:
         if rank == 0:

@@ -173,38 +173,51 @@ __device__ __forceinline__ int bm_bounds_upto(const BmBounds &B, int x)
     return u < (unsigned)(B.units + 1) ? (int)u : B.units + 1;
 }
 
+// One chunk of 256 x 16 starts (thread t: starts [base + 16 t, base + 16 t + 16] incl. the neighbour behind them): does this thread see a descent?
+// BOUNDS: also write the unit boundaries that lie between two of its starts.
+constexpr int BM_CHECK_CH = 256 * 16;
+template <bool BOUNDS>
+__device__ __forceinline__ bool bm_check_chunk(const int32_t *__restrict__ qs, int64_t nq, int64_t c, const BmBounds &B)
+{
+    const int64_t base = c * BM_CHECK_CH + 16 * (int64_t)threadIdx.x;
+    bool descent = false;
+    if (base + 17 <= nq) {
+        const int4 *p = reinterpret_cast<const int4 *>(qs + base);
+        const int4 a = p[0], b = p[1], d = p[2], e = p[3];
+        const int nxt = qs[base + 16];
+        descent = a.x > a.y || a.y > a.z || a.z > a.w || a.w > b.x || b.x > b.y || b.y > b.z || b.z > b.w || b.w > d.x || d.x > d.y ||
+                  d.y > d.z || d.z > d.w || d.w > e.x || e.x > e.y || e.y > e.z || e.z > e.w || e.w > nxt;
+        if (BOUNDS && !descent && bm_bounds_upto(B, a.x) != bm_bounds_upto(B, nxt)) {  // (rare: a unit is ~100 000 queries wide)
+            const int v[17] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w, nxt};
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                for (int u = bm_bounds_upto(B, v[i]); u < bm_bounds_upto(B, v[i + 1]); u++) B.bounds[u] = (unsigned)(base + i + 1);
+        }
+    } else {
+        for (int64_t i = base; i + 1 < nq && i < base + 16; i++) {
+            descent |= qs[i] > qs[i + 1];
+            if (BOUNDS && qs[i] <= qs[i + 1])
+                for (int u = bm_bounds_upto(B, qs[i]); u < bm_bounds_upto(B, qs[i + 1]); u++) B.bounds[u] = (unsigned)(i + 1);
+        }
+    }
+    return descent;
+}
+
+// in front of the first start, behind the last (one thread)
+__device__ __forceinline__ void bm_bounds_outer(const int32_t *__restrict__ qs, int64_t nq, const BmBounds &B)
+{
+    const int first = bm_bounds_upto(B, qs[0]), last = bm_bounds_upto(B, qs[nq - 1]);
+    for (int u = 0; u < first; u++) B.bounds[u] = 0u;
+    for (int u = last; u <= B.units; u++) B.bounds[u] = (unsigned)nq;
+}
+
 template <bool BOUNDS>
 __global__ __launch_bounds__(256) void bm_sorted_check_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ unsorted, BmBounds B)
 {
-    constexpr int CH = 256 * 16;
-    if (BOUNDS && blockIdx.x == 0 && threadIdx.x == 0) {  // in front of the first start, behind the last
-        const int first = bm_bounds_upto(B, qs[0]), last = bm_bounds_upto(B, qs[nq - 1]);
-        for (int u = 0; u < first; u++) B.bounds[u] = 0u;
-        for (int u = last; u <= B.units; u++) B.bounds[u] = (unsigned)nq;
-    }
-    for (int64_t c = blockIdx.x; c * CH < nq; c += gridDim.x) {
+    if (BOUNDS && blockIdx.x == 0 && threadIdx.x == 0) bm_bounds_outer(qs, nq, B);
+    for (int64_t c = blockIdx.x; c * BM_CHECK_CH < nq; c += gridDim.x) {
         if (__hip_atomic_load(unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
-        const int64_t base = c * CH + 16 * (int64_t)threadIdx.x;
-        bool descent = false;
-        if (base + 17 <= nq) {
-            const int4 *p = reinterpret_cast<const int4 *>(qs + base);
-            const int4 a = p[0], b = p[1], d = p[2], e = p[3];
-            const int nxt = qs[base + 16];
-            descent = a.x > a.y || a.y > a.z || a.z > a.w || a.w > b.x || b.x > b.y || b.y > b.z || b.z > b.w || b.w > d.x || d.x > d.y ||
-                      d.y > d.z || d.z > d.w || d.w > e.x || e.x > e.y || e.y > e.z || e.z > e.w || e.w > nxt;
-            if (BOUNDS && !descent && bm_bounds_upto(B, a.x) != bm_bounds_upto(B, nxt)) {  // (rare: a unit is ~100 000 queries wide)
-                const int v[17] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w, nxt};
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    for (int u = bm_bounds_upto(B, v[i]); u < bm_bounds_upto(B, v[i + 1]); u++) B.bounds[u] = (unsigned)(base + i + 1);
-            }
-        } else {
-            for (int64_t i = base; i + 1 < nq && i < base + 16; i++) {
-                descent |= qs[i] > qs[i + 1];
-                if (BOUNDS && qs[i] <= qs[i + 1])
-                    for (int u = bm_bounds_upto(B, qs[i]); u < bm_bounds_upto(B, qs[i + 1]); u++) B.bounds[u] = (unsigned)(i + 1);
-            }
-        }
+        const bool descent = bm_check_chunk<BOUNDS>(qs, nq, c, B);
         if (__syncthreads_or(descent)) {
             if (threadIdx.x == 0) __hip_atomic_store(unsorted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return;

@@ -1537,9 +1537,74 @@ __global__ __launch_bounds__(1024) void bs_plan_kernel(const unsigned *__restric
     if (threadIdx.x == 0) *n_items = carry;
 }
 
+// A batch over SEVERAL indexes (a sorted BED file against a genome: one index per chromosome, bxmi_ivl_count_multi_dev;
+// scripts/interval_join.py:21-28 loops over the chromosomes, lib/bx/bitset_builders.py:31-45 keeps one set per chromosome): the
+// order check and the plan per SEGMENT, one walk over all segments' items.  A workgroup checks one tile of the batch's tile
+// numbering (every segment starts on a group of 64 tiles) and leaves the bounds of its segment's units in the segment's row of
+// `bounds_all`; ONE descent anywhere sends the whole batch through the exchange (a sorted file is sorted in every chromosome).
+constexpr int BS_BOUNDS_ROW = BM_NB + 2;
+__global__ __launch_bounds__(256) void bs_check_multi_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg, int64_t ntp, int tile_log2,
+                                                             unsigned *__restrict__ unsorted, unsigned *__restrict__ bounds_all)
+{
+    for (int64_t tile = blockIdx.x; tile < ntp; tile += gridDim.x) {
+        if (__hip_atomic_load(unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
+        const int seg = tile_seg[tile];
+        const BmSeg &sg = segs[seg];
+        const int64_t ltile = tile - sg.tile0;
+        if (ltile >= sg.ntiles) continue;  // padding up to the next plan group
+        BmBounds B;
+        B.bounds = bounds_all + (int64_t)seg * BS_BOUNDS_ROW, B.cmin = sg.g.cmin, B.ulog = sg.g.shift + sg.g.f, B.units = BM_NB >> sg.g.f;
+        if (ltile == 0 && threadIdx.x == 0) bm_bounds_outer(sg.qs, sg.nq, B);
+        const int64_t c0 = (ltile << tile_log2) / BM_CHECK_CH, c1 = ((ltile + 1) << tile_log2) / BM_CHECK_CH;
+        bool descent = false;
+        for (int64_t c = c0; c < c1 && c * BM_CHECK_CH < sg.nq; c++) descent |= bm_check_chunk<true>(sg.qs, sg.nq, c, B);
+        if (__syncthreads_or(descent)) {
+            if (threadIdx.x == 0) __hip_atomic_store(unsorted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+    }
+}
+
+// bs_plan_kernel per segment (a workgroup each): items[i] = {unit or -1, first query, last query + 1, segment}; room is
+// reserved in the shared list 1024 stretches at a time (n_items zeroed by the host).
+__global__ __launch_bounds__(1024) void bs_plan_multi_kernel(const BmSeg *__restrict__ segs, const unsigned *__restrict__ bounds_all, unsigned chunk,
+                                                             int4 *__restrict__ items, int *__restrict__ n_items, const unsigned *__restrict__ gate)
+{
+    __shared__ int scan_tmp[16];
+    __shared__ int s_at;
+    if (gate && *gate != 0) return;  // not sorted: the exchange answers the batch
+    const int seg = blockIdx.x;
+    const BmSeg &sg = segs[seg];
+    const int units = BM_NB >> sg.g.f;
+    const unsigned nq = (unsigned)sg.nq;
+    if (nq == 0u) return;
+    const unsigned *bounds = bounds_all + (int64_t)seg * BS_BOUNDS_ROW;
+    for (int s0 = -1; s0 <= units; s0 += 1024) {
+        const int s = s0 + (int)threadIdx.x;
+        unsigned lo = 0u, hi = 0u;
+        if (s <= units) {
+            lo = s < 0 ? 0u : bounds[s];
+            hi = s == units ? nq : bounds[s + 1];
+        }
+        const unsigned n = hi > lo ? hi - lo : 0u;
+        const int cnt = (int)((n + chunk - 1u) / chunk);
+        int tot;
+        const int rel = block_exclusive_scan(cnt, OpSum(), 0, scan_tmp, &tot);
+        if (threadIdx.x == 0) s_at = tot ? atomicAdd(n_items, tot) : 0;
+        __syncthreads();
+        const int at = s_at + rel;
+        for (int k = 0; k < cnt; k++) {
+            const unsigned a = lo + (unsigned)k * chunk, b = a + chunk < hi ? a + chunk : hi;
+            items[at + k] = make_int4(s >= 0 && s < units ? s : -1, (int)a, (int)b, seg);
+        }
+        __syncthreads();
+    }
+}
+
+// (items carry their segment in .w: one walk serves a batch over several indexes; a plain call is segment 0 of its parameter block)
 template <bool WIDE, int THREADS>
-__global__ __launch_bounds__(THREADS) void bs_walk_kernel(BmSeg sg, const int4 *__restrict__ items, const int *__restrict__ n_items,
-                                                          unsigned long long *__restrict__ total_slots, const unsigned *__restrict__ gate,
+__global__ __launch_bounds__(THREADS) void bs_walk_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items, const int *__restrict__ n_items,
+                                                          unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS] */, const unsigned *__restrict__ gate,
                                                           unsigned *__restrict__ xcd_next /* [8], zero */,
                                                           unsigned long long *__restrict__ order_host, unsigned long long seq)
 {
@@ -1554,12 +1619,9 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(BmSeg sg, const int4 *
     const int per_xcd = (nit + 7) >> 3;
     const int xcd = (int)(blockIdx.x & 7);
     const int it_lo = xcd * per_xcd, it_hi = it_lo + per_xcd < nit ? it_lo + per_xcd : nit;  // neighbouring stretches on one XCD
-    const BmGeom g = sg.g;
-    const int cell_log2 = WIDE ? 5 + g.dshift : 5;
-    const BpLayout LP = bp_layout(g.shift + g.f, cell_log2);
-    const int64_t nq = sg.nq;
     long long acc = 0;
-    int loaded = -1;  // the unit whose image the LDS holds
+    int acc_seg = -1;  // whose total `acc` belongs to
+    int loaded = -1;   // segment << 16 | unit of the image the LDS holds
     if (threadIdx.x == 0) s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
     __syncthreads();
     int it = s_item_next;
@@ -1567,8 +1629,20 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(BmSeg sg, const int4 *
     while (it < it_hi) {
         const int4 item = items[it];
         const int unit = item.x;
+        const int seg = item.w;
+        if (seg != acc_seg) {  // (item-uniform) the totals are per segment
+            if (acc_seg >= 0 && total_slots) {
+                block_accumulate_i64(acc, red, total_slots + (int64_t)acc_seg * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)));
+                __syncthreads();
+            }
+            acc = 0, acc_seg = seg;
+        }
+        const BmSeg &sg = segs[seg];
+        const BmGeom g = sg.g;
+        const int cell_log2 = WIDE ? 5 + g.dshift : 5;
+        const BpLayout LP = bp_layout(g.shift + g.f, cell_log2);
         if (threadIdx.x == 0) s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
-        if (unit >= 0 && unit != loaded) {  // (the barrier at the end of the item before: nobody reads the old image any more)
+        if (unit >= 0 && ((seg << 16) | unit) != loaded) {  // (the barrier at the end of the item before: nobody reads the old image any more)
             const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.pimages + (size_t)unit * LP.bytes);
             const int n4 = LP.bytes >> 4;
             bm_v4i v[PF];
@@ -1582,7 +1656,7 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(BmSeg sg, const int4 *
                 const int i = k * THREADS + (int)threadIdx.x;
                 if (i < n4) reinterpret_cast<bm_v4i *>(dyn)[i] = v[k];
             }
-            loaded = unit;
+            loaded = (seg << 16) | unit;
         }
         __syncthreads();
         const int it_nx = s_item_next;
@@ -1664,8 +1738,7 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(BmSeg sg, const int4 *
         __syncthreads();  // (thread 0 writes the next item's number, the next image may replace this one)
         it = it_nx;
     }
-    (void)nq;
-    if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
+    if (total_slots && acc_seg >= 0) block_accumulate_i64(acc, red, total_slots + (int64_t)acc_seg * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)));
 }
 
 // ---------------------------------------------------------------------------

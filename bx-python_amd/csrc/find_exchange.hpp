@@ -33,6 +33,13 @@ constexpr int FX_HCAP = 512;          // hits a wave collects in LDS per pass of
 constexpr int FX_THREADS = 1024;
 constexpr int FX_NW = FX_THREADS / 64;
 constexpr size_t FX_LDS_BYTES = (size_t)FX_CAPW * 8 + (size_t)FX_NW * (FX_HCAP * 4 + 64 * 4);
+// (experiments of round 5, compile time)
+#ifndef FX_STORE4
+#define FX_STORE4 0   // 1: the hits leave as 4-byte stores
+#endif
+#ifndef FX_XCD
+#define FX_XCD 1      // 1: neighbouring pieces are handed out on ONE XCD (eight counters), 0: one counter for the chip
+#endif
 
 // ranks at half-bucket boundary sb (first coordinate x = cmin + sb * W / 2), sb = 0 .. FX_NBK:
 //   x = #{start < x}, y = #{start < x + SL_MARGIN} (no record's qe reaches further: its length is below 2^(32 - rshift) <= SL_MARGIN)
@@ -104,11 +111,16 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
     const int ntiles = (int)sg.ntiles;
     const unsigned omask = (1u << g.rshift) - 1u;
     const int nwork = npieces * nchunks;
+    // neighbouring pieces write neighbouring bytes of every tile's region: they are handed out on ONE XCD (blockIdx -> XCD is
+    // round robin), so that a line shared by two pieces is merged in one L2
+    const int xcd = FX_XCD ? (int)(blockIdx.x & 7u) : 0;
+    const int per_xcd = FX_XCD ? (nwork + 7) >> 3 : nwork;
+    const int w_lo = xcd * per_xcd, w_hi = w_lo + per_xcd < nwork ? w_lo + per_xcd : nwork;
     for (;;) {
-        if (threadIdx.x == 0) s_work = (int)atomicAdd(work_counter, 1u);
+        if (threadIdx.x == 0) s_work = w_lo + (int)atomicAdd(work_counter + xcd, 1u);
         __syncthreads();
         const int work = s_work;
-        if (work >= nwork) break;
+        if (work >= w_hi) break;
         const FxPiece pc = pieces[work / nchunks];
         const int t0 = (work % nchunks) * tiles_per_chunk;
         const int t1 = t0 + tiles_per_chunk < ntiles ? t0 + tiles_per_chunk : ntiles;
@@ -154,8 +166,11 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                 const unsigned s = p0 + (unsigned)lane;
                 const bool act = s < T;
                 const unsigned r = fx_locate(re, s);
-                const unsigned at = act ? (unsigned)__shfl((int)rdelta, (int)r, 64) + s : ((unsigned)tb << tile_log2);
+                // (every lane takes part in the shuffles: a lane that is switched off answers a ds_bpermute with ZERO, and in the
+                // batch's last pass the lane that owns the last run is usually beyond the pass's records)
+                const unsigned rd_r = (unsigned)__shfl((int)rdelta, (int)r, 64);
                 const long long tb_r = __shfl(tbase, (int)r, 64);
+                const unsigned at = act ? rd_r + s : ((unsigned)tb << tile_log2);
                 const unsigned rec = recs[(size_t)at], h = hc[(size_t)at], lo = loff[(size_t)at];
                 const bool esc = (lo >> 31) != 0u;
                 unsigned n = act && !esc ? (h & 0xffffu) : 0u;
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                         // every record's hits as 16-byte stores (its place in the tile's region is only 4-byte aligned)
                         const unsigned nn = in ? n : 0u;
                         for (unsigned j = 0; __any(j < nn); j += 4u) {
-                            if (j + 4u <= nn) {
+                            if (!FX_STORE4 && j + 4u <= nn) {
                                 fx_v4a4 v;
                                 v.x = st[my_off + j], v.y = st[my_off + j + 1u], v.z = st[my_off + j + 2u], v.w = st[my_off + j + 3u];
                                 *reinterpret_cast<fx_v4a4 *>(dst + j) = v;

@@ -1086,30 +1086,13 @@ constexpr int LC_TREE_KEYS = (1 << 12) - 1;      // two trees of 4096 slots = 32
 // LOOP: a workgroup takes LC_LOOP consecutive chunks instead of one: a quarter of the workgroups to dismiss when the batch
 // is NOT sorted (the stand-down of 24 000 workgroups cost 12 us per 100 M queries, 1.5 % of the unsorted pass).
 constexpr int LC_LOOP = 4;
-template <bool LOOP>
-__global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
-                                                                     const int32_t *__restrict__ qs_arr,
-                                                                     const int32_t *__restrict__ qe_arr, int64_t nq,
-                                                                     int32_t *__restrict__ counts /* may be NULL */,
-                                                                     unsigned long long *__restrict__ total_slots,
-                                                                     const unsigned *__restrict__ gate,
-                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */,
-                                                                     unsigned long long *__restrict__ order_host = nullptr, unsigned long long seq = 0)
+// One chunk of LC_CHUNK consecutive queries from `base` on: the workgroup's queries are k = j * LC_THREADS + thread, and
+// emit(j, k, live, count, #{start < qe}, qs) is called once per (thread, j) with j a compile-time constant after unrolling.
+template <typename Emit>
+__device__ __forceinline__ void lc_chunk_counts(const TreeDev &S, const TreeDev &E, const IndexDev &ix, const int32_t *__restrict__ e_sorted,
+                                                const int32_t *__restrict__ qs_arr, const int32_t *__restrict__ qe_arr, int64_t base, int n, int32_t *lds,
+                                                int (*s_mm)[LC_THREADS / 64], int *s_slice, Emit emit)
 {
-    __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
-    __shared__ int s_mm[3][LC_THREADS / 64];
-    __shared__ int s_slice[6];  // eLo, eHi, sLo, sHi, qeLo, qeHi
-    __shared__ long long red[LC_THREADS / 64];
-    // what the order check found, into host memory: the host picks the shape of THIS kernel for later batches by it
-    // (bm_count_segments; pass number << 1 | 1 = not sorted)
-    if (order_host && blockIdx.x == 0 && threadIdx.x == 0) *order_host = (seq << 1) | (gate && *gate != 0 ? 1ull : 0ull);
-    if (gate && *gate != 0) return;  // unsorted batch: the bucketed path answers it
-    long long acc = 0;
-    const int64_t chunk0 = (int64_t)blockIdx.x * (LOOP ? LC_LOOP : 1);
-    for (int64_t chunk = chunk0; chunk < chunk0 + (LOOP ? LC_LOOP : 1) && chunk * LC_CHUNK < nq; chunk++) {
-    if (LOOP && chunk != chunk0) __syncthreads();  // the shared arrays of the chunk before are done with
-    const int64_t base = chunk * LC_CHUNK;
-    const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
     int qs[LC_ITEMS], qe[LC_ITEMS];
     int mn = INT_MAX, mx = INT_MIN, emx = INT_MIN;
 #pragma unroll
@@ -1207,24 +1190,55 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
 #pragma unroll
         for (int j = 0; j < PT_ILP; j++) {
             const int k = (j0 + j) * LC_THREADS + threadIdx.x;
-            if (k >= n) continue;
+            const bool live = k < n;
+            int c = 0, s_rank = 0;
             const int s = qs[j0 + j], e = qe[j0 + j];
-            const bool in_slice = e >= qeLo && e <= qeHi;
-            const int s_rank = in_slice ? sLo + rS[j] : global_rank_lt(ix.s_ord, 0, ix.n, e);
-            int c;
-            if (s < e) {
-                const int e_rank = s == INT_MAX ? ix.n : eLo + rE[j];
-                c = s_rank - e_rank;
-            } else {  // zero-length / reversed query: exact predicate over the candidate window
-                int lo = first_pm_gt(ix.pm, ix.n, s);
-                c = 0;
-                for (int t = lo; t < s_rank; t++) c += ix.e_ord[t] > s;
+            if (live) {
+                const bool in_slice = e >= qeLo && e <= qeHi;
+                s_rank = in_slice ? sLo + rS[j] : global_rank_lt(ix.s_ord, 0, ix.n, e);
+                if (s < e) {
+                    const int e_rank = s == INT_MAX ? ix.n : eLo + rE[j];
+                    c = s_rank - e_rank;
+                } else {  // zero-length / reversed query: exact predicate over the candidate window
+                    int lo = first_pm_gt(ix.pm, ix.n, s);
+                    for (int t = lo; t < s_rank; t++) c += ix.e_ord[t] > s;
+                }
             }
+            emit(j0 + j, k, live, c, s_rank, s);
+        }
+    }
+}
+
+template <bool LOOP>
+__global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
+                                                                     const int32_t *__restrict__ qs_arr,
+                                                                     const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                                     int32_t *__restrict__ counts /* may be NULL */,
+                                                                     unsigned long long *__restrict__ total_slots,
+                                                                     const unsigned *__restrict__ gate,
+                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */,
+                                                                     unsigned long long *__restrict__ order_host = nullptr, unsigned long long seq = 0)
+{
+    __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
+    __shared__ int s_mm[3][LC_THREADS / 64];
+    __shared__ int s_slice[6];  // eLo, eHi, sLo, sHi, qeLo, qeHi
+    __shared__ long long red[LC_THREADS / 64];
+    // what the order check found, into host memory: the host picks the shape of THIS kernel for later batches by it
+    // (bm_count_segments; pass number << 1 | 1 = not sorted)
+    if (order_host && blockIdx.x == 0 && threadIdx.x == 0) *order_host = (seq << 1) | (gate && *gate != 0 ? 1ull : 0ull);
+    if (gate && *gate != 0) return;  // unsorted batch: the bucketed path answers it
+    long long acc = 0;
+    const int64_t chunk0 = (int64_t)blockIdx.x * (LOOP ? LC_LOOP : 1);
+    for (int64_t chunk = chunk0; chunk < chunk0 + (LOOP ? LC_LOOP : 1) && chunk * LC_CHUNK < nq; chunk++) {
+        if (LOOP && chunk != chunk0) __syncthreads();  // the shared arrays of the chunk before are done with
+        const int64_t base = chunk * LC_CHUNK;
+        const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
+        lc_chunk_counts(S, E, ix, e_sorted, qs_arr, qe_arr, base, n, lds, s_mm, s_slice, [&](int, int k, bool live, int c, int s_rank, int) {
+            if (!live) return;
             if (counts) counts[base + k] = c;
             if (his) his[base + k] = s_rank;
             acc += c;
-        }
-    }
+        });
     }
     if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
 }
@@ -1786,6 +1800,79 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_walk_kernel(const int2
 // 768 / 256: 1.71, 512 / 128: 1.64 -- less LDS per wave, more workgroups per CU)
 constexpr int FF_HITS = 512;    // hits of a wave's 64 queries staged in LDS (mean 320 on configs[4])
 constexpr int FF_PAIRS = 128;   // pairs below the wave's highest `hi` staged in LDS
+
+// One wave, 64 consecutive queries (a lane each: `c` hits to find below rank `hi`, its CSR offset `off`): see the kernel below.
+// wp / wh: the wave's LDS images of the pairs and of its stretch of the list.
+__device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *__restrict__ eid /* at index 0 */, int c, const int hi, const int qs,
+                                             const long long off, int32_t *__restrict__ hits)
+{
+    const int lane = lane_id();
+    int k = hi - 1;
+    // the wave's stretch of the list: from its first query's offset, as long as the sum of its counts
+    const long long base_off = __shfl(off, 0, 64);
+    long long total64 = c;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) total64 += __shfl_xor(total64, d, 64);
+    if (total64 == 0) return;  // (wave-uniform)
+    const bool flat = total64 <= FF_HITS;
+    const int total = flat ? (int)total64 : 0;
+    const int rel = flat ? (int)(off - base_off) : 0;
+    int32_t *__restrict__ dst = hits + off;
+    // the window of the pairs: FF_PAIRS below the highest hi of the wave
+    const int kmax = wave_max_i32(c ? hi : 0);
+    const int wbase = kmax > FF_PAIRS ? kmax - FF_PAIRS : 0;
+#pragma unroll
+    for (int j = 0; j < FF_PAIRS / 64; j++) {
+        const int kk = wbase + 64 * j + lane;
+        if (kk < kmax) wp[64 * j + lane] = eid[kk];
+    }
+    // (lanes read what OTHER lanes staged: wave-level release + barrier, not just in-order DS issue)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto pair_at = [&](int kk) -> int2 { return kk >= wbase ? wp[kk - wbase] : eid[kk]; };
+    for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
+        const int2 p = pair_at(k);
+        if (p.x > qs) {
+            --c;
+            if (flat)
+                wh[rel + c] = p.y;
+            else
+                dst[c] = p.y;
+        }
+    }
+    unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        int C = __shfl(c, src, 64), K = __shfl(k, src, 64);
+        const int S = __shfl(qs, src, 64);
+        const int R = __shfl(rel, src, 64);
+        int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
+        while (C > 0 && K >= 0) {
+            const int kk = K - lane;
+            int2 p = make_int2(INT_MIN, 0);
+            if (kk >= 0) p = pair_at(kk);
+            const bool f = kk >= 0 && p.x > S;
+            const unsigned long long fm = __ballot(f);
+            // hits at higher indices come later in the list: lane 0 (the highest index of the step) takes the last free slot
+            const int before = __popcll(fm & ((1ull << lane) - 1ull));
+            if (f && before < C) {
+                if (flat)
+                    wh[R + C - 1 - before] = p.y;
+                else
+                    D[C - 1 - before] = p.y;
+            }
+            C -= __popcll(fm);
+            K -= 64;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < total; i += 64) hits[base_off + i] = wh[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next batch overwrites both images)
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2 *__restrict__ eid /* at index 0 */, const int32_t *__restrict__ qs_arr,
                                                                      int64_t nq, const int32_t *__restrict__ his, const int32_t *__restrict__ cnt,
                                                                      const long long *__restrict__ offs, int32_t *__restrict__ hits)
@@ -1793,8 +1880,6 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
     __shared__ int2 s_pairs[FIND_THREADS / 64][FF_PAIRS];
     __shared__ int32_t s_hits[FIND_THREADS / 64][FF_HITS];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    int2 *const wp = s_pairs[wave];
-    int32_t *const wh = s_hits[wave];
     const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
     const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
@@ -1802,74 +1887,115 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
     for (int64_t qb = q0 + 64 * wave; qb < q1; qb += FIND_THREADS) {  // (waves are on their own: no workgroup barrier in here)
         const int64_t q = qb + lane;
         const bool live = q < q1;
-        int c = live ? cnt[q] : 0;
+        const int c = live ? cnt[q] : 0;
         const int hi = live && c ? his[q] : 0;
-        int k = hi - 1;
         const int qs = live ? qs_arr[q] : 0;
-        const long long off = live ? offs[q] : 0;
-        // the wave's stretch of the list: from its first live query's offset, as long as the sum of its counts
-        const long long base_off = __shfl(off, 0, 64);  // (lane 0 is live whenever the batch exists)
-        long long total64 = c;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) total64 += __shfl_xor(total64, d, 64);
-        const bool flat = total64 <= FF_HITS;
-        const int total = flat ? (int)total64 : 0;
-        const int rel = flat ? (int)(off - base_off) : 0;
-        int32_t *__restrict__ dst = hits + off;
-        // the window of the pairs: FF_PAIRS below the highest hi of the wave
-        const int kmax = wave_max_i32(hi);
-        const int wbase = kmax > FF_PAIRS ? kmax - FF_PAIRS : 0;
-#pragma unroll
-        for (int j = 0; j < FF_PAIRS / 64; j++) {
-            const int kk = wbase + 64 * j + lane;
-            if (kk < kmax) wp[64 * j + lane] = eid[kk];
-        }
-        // (lanes read what OTHER lanes staged: wave-level release + barrier, not just in-order DS issue)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        auto pair_at = [&](int kk) -> int2 { return kk >= wbase ? wp[kk - wbase] : eid[kk]; };
-        for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
-            const int2 p = pair_at(k);
-            if (p.x > qs) {
-                --c;
-                if (flat)
-                    wh[rel + c] = p.y;
-                else
-                    dst[c] = p.y;
-            }
-        }
-        unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            int C = __shfl(c, src, 64), K = __shfl(k, src, 64);
-            const int S = __shfl(qs, src, 64);
-            const int R = __shfl(rel, src, 64);
-            int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
-            while (C > 0 && K >= 0) {
-                const int kk = K - lane;
-                int2 p = make_int2(INT_MIN, 0);
-                if (kk >= 0) p = pair_at(kk);
-                const bool f = kk >= 0 && p.x > S;
-                const unsigned long long fm = __ballot(f);
-                // hits at higher indices come later in the list: lane 0 (the highest index of the step) takes the last free slot
-                const int before = __popcll(fm & ((1ull << lane) - 1ull));
-                if (f && before < C) {
-                    if (flat)
-                        wh[R + C - 1 - before] = p.y;
-                    else
-                        D[C - 1 - before] = p.y;
-                }
-                C -= __popcll(fm);
-                K -= 64;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < total; i += 64) hits[base_off + i] = wh[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next batch overwrites both images)
-        __builtin_amdgcn_wave_barrier();
+        // (a dead lane carries the offset behind the last live query of the wave's stretch: lane 0 is live whenever the batch exists)
+        const long long off = offs[live ? q : q1 - 1];
+        ff_wave_fill(s_pairs[wave], s_hits[wave], eid, c, hi, qs, off, hits);
     }
+}
+
+// find() on a SORTED batch in ONE kernel (round 5): count, CSR offsets and fill per chunk of LC_CHUNK consecutive queries.
+// Round 4 ran ivl_local_count_kernel (counts and `hi` to HBM) -> a three-kernel scan over the counts -> part_fill_flat_kernel
+// (counts, `hi`, offsets and the starts read again): 36 bytes per query moved only to carry a chunk's numbers from one launch to
+// the next.  Here a chunk's counts stay in registers: the workgroup scans them (wave scans + one wave over the 64 (row, wave)
+// totals), gets the hits of all chunks before it by a DECOUPLED LOOK-BACK over per-chunk words (chunks are numbered by a ticket
+// in dispatch order, so every predecessor has started and none waits for a successor; a word carries flag : 2 | value : 62,
+// 1 = the chunk's own total, 2 = the inclusive prefix), writes the offsets, and its eight waves fill their 64-query stretches
+// exactly as part_fill_flat_kernel does (the LDS trees of the count half are dead by then: the images live in the same bytes).
+// A chunk whose stretch would pass `cap` writes no hits (the host reports BXMI_ERANGE from the total, as before).
+// state[nchunks] and the ticket are zeroed by the host before the launch.
+constexpr unsigned long long LF_FLAG_AGG = 1ull << 62, LF_FLAG_PREFIX = 2ull << 62, LF_VALUE = (1ull << 62) - 1ull;
+
+__global__ __launch_bounds__(LC_THREADS) void ivl_local_find_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
+                                                                    const int32_t *__restrict__ qs_arr, const int32_t *__restrict__ qe_arr, int64_t nq,
+                                                                    const int2 *__restrict__ eid /* at index 0 */, long long *__restrict__ offsets,
+                                                                    int32_t *__restrict__ hits, long long cap, unsigned long long *__restrict__ state,
+                                                                    unsigned *__restrict__ ticket)
+{
+    constexpr int NW = LC_THREADS / 64;
+    static_assert(NW * LC_ITEMS == 64, "one wave scans the (row, wave) totals of a chunk");
+    static_assert((size_t)NW * (FF_PAIRS * 8 + FF_HITS * 4) <= (size_t)2 * (LC_TREE_KEYS + 1) * 4, "the fill's images fit the trees' LDS");
+    __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
+    __shared__ int s_mm[3][LC_THREADS / 64];
+    __shared__ int s_slice[6];
+    __shared__ long long s_tot[64];
+    __shared__ long long s_base[2];  // hits before the chunk, hits of the chunk
+    __shared__ unsigned s_chunk;
+    if (threadIdx.x == 0) s_chunk = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int64_t chunk = s_chunk;
+    const int64_t base = chunk * LC_CHUNK;
+    if (base >= nq) return;
+    const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    int cc[LC_ITEMS], hh[LC_ITEMS], ss[LC_ITEMS];
+    lc_chunk_counts(S, E, ix, e_sorted, qs_arr, qe_arr, base, n, lds, s_mm, s_slice, [&](int j, int, bool live, int c, int s_rank, int s) {
+        cc[j] = live ? c : 0, hh[j] = s_rank, ss[j] = s;
+    });
+    // the chunk's exclusive scan in query order: row j, thread t is query j * LC_THREADS + t
+    long long incl[LC_ITEMS];
+#pragma unroll
+    for (int j = 0; j < LC_ITEMS; j++) {
+        incl[j] = wave_inclusive_scan((long long)cc[j], OpSum());
+        if (lane == 63) s_tot[j * NW + wave] = incl[j];
+    }
+    __syncthreads();  // (also: every lookup in the LDS trees is over)
+    if (wave == 0) {
+        const long long v = s_tot[lane];
+        const long long inc = wave_inclusive_scan(v, OpSum());
+        s_tot[lane] = inc - v;
+        const long long total = __shfl(inc, 63, 64);
+        // decoupled look-back
+        long long before = 0;
+        if (chunk == 0) {
+            if (lane == 0) __hip_atomic_store(state, LF_FLAG_PREFIX | (unsigned long long)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(state + chunk, LF_FLAG_AGG | (unsigned long long)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t p = chunk - 1;  // the nearest predecessor not yet accounted for
+            for (;;) {
+                const int64_t idx = p - lane;
+                const unsigned long long w = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : LF_FLAG_PREFIX;
+                const unsigned flag = (unsigned)(w >> 62);
+                const unsigned long long m_empty = __ballot(flag == 0u), m_prefix = __ballot(flag == 2u);
+                const int first_prefix = m_prefix ? __ffsll((long long)m_prefix) - 1 : 64;
+                const int first_empty = m_empty ? __ffsll((long long)m_empty) - 1 : 64;
+                if (first_empty < first_prefix) {  // a predecessor nearer than any finished prefix has not published yet
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                long long contrib = lane <= first_prefix ? (long long)(w & LF_VALUE) : 0ll;  // (first_prefix = 64: all 64 are plain totals)
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                before += contrib;
+                if (first_prefix < 64) break;
+                p -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(state + chunk, LF_FLAG_PREFIX | (unsigned long long)(before + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_base[0] = before, s_base[1] = total;
+            if (base + n == nq) offsets[nq] = before + total;  // the last chunk: the batch's total
+        }
+    }
+    __syncthreads();
+    const long long before = s_base[0];
+    const bool fits = before + s_base[1] <= cap;
+    long long off[LC_ITEMS];
+#pragma unroll
+    for (int j = 0; j < LC_ITEMS; j++) {
+        const int k = j * LC_THREADS + (int)threadIdx.x;
+        off[j] = before + s_tot[j * NW + wave] + incl[j] - cc[j];
+        if (k < n) offsets[base + k] = off[j];
+    }
+    if (!fits || s_base[1] == 0) return;
+    // the fill: wave w's row j is 64 consecutive queries
+    int2 *wp = reinterpret_cast<int2 *>(lds) + wave * FF_PAIRS;
+    int32_t *wh = lds + NW * FF_PAIRS * 2 + wave * FF_HITS;
+#pragma unroll
+    for (int j = 0; j < LC_ITEMS; j++) ff_wave_fill(wp, wh, eid, cc[j], hh[j], ss[j], off[j], hits);
 }
 
 __global__ void part_fold_total_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
@@ -2227,6 +2353,7 @@ static int64_t g_opt_find_fill = 0;    // bucketed find: 0 = hits written from b
 static int64_t g_opt_bitmap = -1;      // second-generation count pass (count_bitmap.hpp): -1 = when the index qualifies, 0 = never, 1 = same as -1
 static int64_t g_opt_bitmap_min = 2 << 20;  // auto: batches of at least this many queries take it (when the index qualifies)
 static int64_t g_opt_bm_variant = -1;  // tile kernel shape: -1 = by batch size, 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
+static int64_t g_opt_find_fused = 1;   // find() on a sorted batch: 1 = count, offsets (decoupled look-back) and fill in one kernel (ivl_local_find_kernel), 0 = round 4's three stages
 static int64_t g_opt_fx_fill = 1;      // find() through the exchange: 1 = the fill half on LDS windows of half-bucket pieces (find_exchange.hpp), 0 = round 2's fill and copy
 static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
@@ -2277,6 +2404,7 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.bm_variant", &g_opt_bm_variant, [](int64_t value) -> int64_t { return value < 0 || value > 2 ? -1 : value; }},
     {"ivl.find_sliced", &g_opt_find_sliced, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.fx_fill", &g_opt_fx_fill, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.find_fused", &g_opt_find_fused, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.slice", &g_opt_slice, nullptr},
     {"ivl.sl_f", &g_opt_sl_f, [](int64_t value) -> int64_t { return value > SL_MAX_F ? SL_MAX_F : value; }},
     {"ivl.bm_chunk", &g_opt_bm_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
@@ -2362,6 +2490,7 @@ struct bxmi_ivl {
     std::vector<int2> fx_meta2_host;   // the ranks at the half-bucket boundaries (read back once per sealed index)
     std::vector<FxPiece> fx_pieces_host;
     int fx_pieces_f = -1;        // the unit size (2^f buckets) the piece list was cut for
+    DevBuf lf_state;             // sorted find() in one kernel: the chunks' look-back words and the ticket
     DevBuf fx_meta2, fx_pieces, fx_tbl2, fx_runT2, fx_hc, fx_svq, fx_parts, fx_tile_tot, fx_tile_base, fx_work;
     // dense unit images (count_dense.hpp)
     int bd_state = 0;            // 0 = not decided yet, 1 = images built and the index qualifies, -1 = it does not
@@ -2535,10 +2664,28 @@ static int sl_ensure_eid(bxmi_ivl *h, hipStream_t st)
 static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits, int64_t cap,
                           int64_t *total_host, hipStream_t st)
 {
+    const bool walk = g_opt_find_pairs != 0;  // (hi, count) from the sorted-batch count kernel, then a walk down the pairs
+    if (walk && g_opt_find_flat && g_opt_find_fused) {  // count, offsets and fill in one kernel
+        const int64_t nchunks = div_up(nq, LC_CHUNK);
+        BXMI_TRY(h->lf_state.reserve((size_t)(nchunks + 2) * 8));
+        BXMI_HIP(hipMemsetAsync(h->lf_state.p, 0, (size_t)(nchunks + 2) * 8, st));
+        BXMI_TRY(sl_ensure_eid(h, st));
+        TreeDev S = h->treeS.dev, E = h->treeE.dev;
+        S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
+        hipLaunchKernelGGL(ivl_local_find_kernel, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(), qs, qe, nq,
+                           h->sl_eid.as<int2>() + SL_WALK, reinterpret_cast<long long *>(offsets), hits, (long long)cap, h->lf_state.as<unsigned long long>(),
+                           reinterpret_cast<unsigned *>(h->lf_state.as<unsigned long long>() + nchunks));
+        BXMI_LAUNCH_CHECK();
+        int64_t total = 0;
+        BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
+        BXMI_HIP(hipStreamSynchronize(st));
+        if (total_host) *total_host = total;
+        if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
+        return BXMI_OK;
+    }
     BXMI_TRY(h->p_lo.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_hi.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
-    const bool walk = g_opt_find_pairs != 0;  // (hi, count) from the sorted-batch count kernel, then a walk down the pairs
     if (walk) {
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
@@ -3184,7 +3331,10 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     // [segments][PT_SLOTS partial totals], then the flag: 1 = the starts are NOT sorted
     BXMI_TRY(h->p_slots.reserve(((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long)));
     unsigned long long *slots = h->p_slots.as<unsigned long long>();
-    unsigned *unsorted = g_opt_sorted_path && n == 1 && !fx ? reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS) : nullptr;
+    // (several indexes: only the walk on cell images has a sorted-batch form over segments)
+    bool multi_sorted = n > 1 && !fx && g_opt_sorted_path && g_opt_sorted_cells != 0 && cells && pad;
+    for (int i = 0; i < n && multi_sorted; i++) multi_sorted = nq[i] < ((int64_t)1 << 32) - 8;
+    unsigned *unsorted = g_opt_sorted_path && (n == 1 || multi_sorted) && !fx ? reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS) : nullptr;
     // The order check and the stand-down of the sorted-batch kernel cost a shuffled batch 24 us (of 750).  What the order
     // checks find is mirrored into host memory (ivl_local_count_kernel / bm_fold_totals_kernel write it, nobody waits for
     // it): after two batches in a row that were NOT sorted the check is no longer launched -- every kernel of the exchange
@@ -3269,7 +3419,30 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         // bs_*): the order check leaves where every unit's queries begin, a plan cuts long stretches, the walk loads a unit's
         // image and answers its queries as they lie.  Other stages keep the first-generation kernel for sorted batches below.
         const bool sorted_on_cells = cells && pad && g_opt_sorted_cells != 0 && nq[0] < ((int64_t)1 << 32) - 8;
-        if (sorted_on_cells) {
+        if (multi_sorted) {
+            // a batch over several indexes: order check and plan per segment, one walk (count_dense.hpp, bs_*_multi)
+            const unsigned chunk = (unsigned)(g_opt_bd_chunk ? g_opt_bd_chunk : (wide ? 1 : 2) * BM_CHUNK);
+            size_t max_sorted_items = 4;
+            for (int i = 0; i < n; i++) max_sorted_items += (size_t)(BM_NB >> segs[(size_t)i].g.f) + 4 + (size_t)(nq[i] / chunk);
+            const size_t bounds_bytes = ((size_t)n * BS_BOUNDS_ROW * 4 + 16 + 15) & ~(size_t)15;
+            BXMI_TRY(h->bs_plan.reserve(bounds_bytes + (max_sorted_items + 1) * sizeof(int4)));
+            unsigned *bounds_all = h->bs_plan.as<unsigned>();
+            int *n_sorted = reinterpret_cast<int *>(bounds_all + (size_t)n * BS_BOUNDS_ROW);
+            int4 *sorted_items = reinterpret_cast<int4 *>(h->bs_plan.as<unsigned char>() + bounds_bytes);
+            BXMI_HIP(hipMemsetAsync(n_sorted, 0, sizeof(int), st));
+            hipLaunchKernelGGL(bs_check_multi_kernel, dim3((unsigned)(ntp < 2048 ? ntp : 2048)), dim3(256), 0, st, L.segs, L.tile_seg, ntp, tile_log2, unsorted, bounds_all);
+            hipLaunchKernelGGL(bs_plan_multi_kernel, dim3((unsigned)n), dim3(1024), 0, st, L.segs, bounds_all, chunk, sorted_items, n_sorted, unsorted);
+            if (wide) {
+                BXMI_TRY(allow_big_lds((bs_walk_kernel<true, BD_THREADS / 2>), L.search_lds));
+                hipLaunchKernelGGL((bs_walk_kernel<true, BD_THREADS / 2>), dim3(512), dim3(BD_THREADS / 2), L.search_lds, st, L.segs, sorted_items, n_sorted, tslots,
+                                   unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
+            } else {
+                BXMI_TRY(allow_big_lds((bs_walk_kernel<false, BD_THREADS>), L.search_lds));
+                hipLaunchKernelGGL((bs_walk_kernel<false, BD_THREADS>), dim3(256), dim3(BD_THREADS), L.search_lds, st, L.segs, sorted_items, n_sorted, tslots,
+                                   unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
+            }
+            BXMI_LAUNCH_CHECK();
+        } else if (sorted_on_cells) {
             const BmGeom &g0 = segs[0].g;
             const int units = BM_NB >> g0.f;
             const unsigned chunk = (unsigned)(g_opt_bd_chunk ? g_opt_bd_chunk : (wide ? 1 : 2) * BM_CHUNK);
@@ -3283,11 +3456,11 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
             hipLaunchKernelGGL(bs_plan_kernel, dim3(1), dim3(1024), 0, st, B.bounds, units, (unsigned)nq[0], chunk, sorted_items, n_sorted, unsorted);
             if (wide) {
                 BXMI_TRY(allow_big_lds((bs_walk_kernel<true, BD_THREADS / 2>), L.search_lds));
-                hipLaunchKernelGGL((bs_walk_kernel<true, BD_THREADS / 2>), dim3(512), dim3(BD_THREADS / 2), L.search_lds, st, segs[0], sorted_items, n_sorted, tslots,
+                hipLaunchKernelGGL((bs_walk_kernel<true, BD_THREADS / 2>), dim3(512), dim3(BD_THREADS / 2), L.search_lds, st, L.segs, sorted_items, n_sorted, tslots,
                                    unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
             } else {
                 BXMI_TRY(allow_big_lds((bs_walk_kernel<false, BD_THREADS>), L.search_lds));
-                hipLaunchKernelGGL((bs_walk_kernel<false, BD_THREADS>), dim3(256), dim3(BD_THREADS), L.search_lds, st, segs[0], sorted_items, n_sorted, tslots,
+                hipLaunchKernelGGL((bs_walk_kernel<false, BD_THREADS>), dim3(256), dim3(BD_THREADS), L.search_lds, st, L.segs, sorted_items, n_sorted, tslots,
                                    unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
             }
             BXMI_LAUNCH_CHECK();
@@ -3453,7 +3626,8 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     int64_t *no_total = nullptr;
     BXMI_TRY(bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &no_total, st, 2, &fx));
     const int64_t ntp = fx.L.ntp;
-    hipLaunchKernelGGL(fx_tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->fx_tile_tot.as<unsigned long long>(), ntp, h->fx_tile_base.as<long long>(),
+    // (only the tiles that hold queries: the un-permute kernel leaves the padding up to the plan group alone)
+    hipLaunchKernelGGL(fx_tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->fx_tile_tot.as<unsigned long long>(), fx.ntiles, h->fx_tile_base.as<long long>(),
                        reinterpret_cast<long long *>(offsets) + nq);
     BXMI_LAUNCH_CHECK();
     BXMI_TRY(fx_ensure_pieces(h, fx.f, st));
@@ -4052,6 +4226,34 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
+
+#ifdef BXMI_DEBUG_PEEK
+// (debug builds only, never in the shipped library: a look at the scratch a find() left behind)
+extern "C" int bxmi_debug_peek(bxmi_ivl_t *h, const char *name, void *host, size_t bytes)
+{
+    const DevBuf *b = nullptr;
+    const std::string n(name);
+    if (n == "recs") b = &h->bm_recs;
+    else if (n == "slots") b = &h->bm_slots;
+    else if (n == "hc") b = &h->fx_hc;
+    else if (n == "cnt") b = &h->sl_cnt;
+    else if (n == "loff") b = &h->sl_loff;
+    else if (n == "svq") b = &h->fx_svq;
+    else if (n == "tile_base") b = &h->fx_tile_base;
+    else if (n == "runT2") b = &h->fx_runT2;
+    else if (n == "tbl2") b = &h->fx_tbl2;
+    else if (n == "tmp_hits") b = &h->sl_hits;
+    else if (n == "meta2") b = &h->fx_meta2;
+    else if (n == "pieces") b = &h->fx_pieces;
+    else if (n == "eid") b = &h->sl_eid;
+    else if (n == "qcnt") b = &h->q_cnt;
+    if (!b) return fail(BXMI_EINVAL, "peek: no such buffer");
+    if (bytes > b->cap) bytes = b->cap;
+    BXMI_HIP(hipDeviceSynchronize());
+    BXMI_HIP(hipMemcpy(host, b->p, bytes, hipMemcpyDeviceToHost));
+    return (int)0;
+}
+#endif
 
 extern "C" int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits,
                              int64_t cap, int64_t *total)

@@ -1084,6 +1084,86 @@ def test_genome_sharded_count_single_rank():
         assert totals[chrom] == int(want.sum())
 
 
+def test_count_multi_on_sorted_batches(O, IntervalIndex):
+    """A sorted BED file against a genome (scripts/interval_join.py:21-28 loops over the chromosomes): bxmi_ivl_count_multi_dev
+    with every chromosome's queries sorted by start is answered by the walk on cell images as the queries lie (count_dense.hpp:
+    bs_check_multi_kernel / bs_plan_multi_kernel / bs_walk_kernel over segments) -- against the oracle, for sparse indexes on
+    offset cells and dense ones on bitmap cells, with escapes, a chromosome without queries, queries left and right of the grid,
+    totals only; one chromosome in reversed or partly shuffled order sends the whole batch through the exchange, same answers."""
+    from bxmi import _ffi
+
+    rng = np.random.default_rng(515)
+    for density, opt in (("sparse", ("ivl.sparse", 1)), ("dense", ("ivl.flat", 1))):
+        specs = [(150_000, 50_000_000, 400_001), (260_000, 90_000_000, 700_000), (90_000, 30_000_000, 0), (200_000, 70_000_000, 250_000),
+                 (120_000, 40_000_000, 16384 * 9)]
+        if density == "dense":
+            specs = [(n * 4, span // 3, nq) for n, span, nq in specs]  # (configs[1]'s density: one target per ~28 coordinates)
+        ixs, host, want = [], [], []
+        for k, (n, span, nq) in enumerate(specs):
+            s = rng.integers(1000, span, size=n)
+            e = s + rng.integers(1, 1000, size=n)
+            qs = np.sort(rng.integers(-5000, span + 8000, size=nq))
+            qe = qs + rng.integers(0, 1500, size=nq)
+            if nq:
+                qe[::97] = qs[::97] + 40_000  # longer than a record holds
+                qe[::89] = qs[::89] - 3       # reversed
+            s, e, qs, qe = (a.astype(np.int32) for a in (s, e, qs, qe))
+            t = O.OracleIntervalTree()
+            t.insert_many_arrays(s, e)
+            want.append(t.count_batch(qs, qe))
+            ixs.append(make_index(IntervalIndex, s, e))
+            host.append((qs, qe))
+        totals = _ffi.DeviceArray(8 * len(specs))
+
+        def run(queries, with_counts=True):
+            dev = [(_ffi.DeviceArray.from_numpy(a), _ffi.DeviceArray.from_numpy(b), _ffi.DeviceArray(4 * max(len(a), 4))) for a, b in queries]
+            totals.zero()
+            IntervalIndex.count_multi_dev(ixs, [d[0].ptr for d in dev], [d[1].ptr for d in dev], [len(q[0]) for q in queries],
+                                          [d[2].ptr if with_counts else None for d in dev], [totals.ptr + 8 * i for i in range(len(specs))], None)
+            _ffi.call("bxmi_synchronize", None)
+            return [d[2].to_numpy(np.int32, len(q[0])) for d, q in zip(dev, queries)], totals.to_numpy(np.int64, len(specs))
+
+        set_opt("ivl.partition", 1)
+        set_opt("ivl.bitmap_min", 1)
+        set_opt(*opt)
+        try:
+            for variant in (-1, 1):
+                set_opt("ivl.bm_variant", variant)
+                got, tot = run(host)  # every chromosome sorted
+                for k, (wc, wt) in enumerate(want):
+                    bad = np.nonzero(got[k] != wc)[0]
+                    assert len(bad) == 0 and int(tot[k]) == wt, (density, "sorted", variant, k, bad[:5], got[k][bad[:5]], wc[bad[:5]], int(tot[k]), wt)
+                _, tot = run(host, with_counts=False)  # totals only
+                assert [int(x) for x in tot] == [wt for _, wt in want], (density, "totals only", variant)
+            set_opt("ivl.bm_variant", -1)
+            # one chromosome reversed, then one with a shuffled stretch in its middle: the exchange answers the whole batch
+            for what in ("reversed", "partly"):
+                queries, perm = list(host), None
+                qs, qe = host[3]
+                if what == "reversed":
+                    perm = np.arange(len(qs))[::-1].copy()
+                else:
+                    perm = np.arange(len(qs))
+                    perm[100_000:100_050] = perm[100_000:100_050][::-1]
+                queries[3] = (np.ascontiguousarray(qs[perm]), np.ascontiguousarray(qe[perm]))
+                got, tot = run(queries)
+                for k, (wc, wt) in enumerate(want):
+                    w = wc[perm] if k == 3 else wc
+                    bad = np.nonzero(got[k] != w)[0]
+                    assert len(bad) == 0 and int(tot[k]) == wt, (density, what, k, bad[:5], got[k][bad[:5]], w[bad[:5]])
+            # and the sorted walk switched off (every batch through the exchange) agrees
+            set_opt("ivl.sorted_cells", 0)
+            got, tot = run(host)
+            for k, (wc, wt) in enumerate(want):
+                assert np.array_equal(got[k], wc) and int(tot[k]) == wt, (density, "sorted_cells off", k)
+        finally:
+            reset_opts()
+        if density == "sparse":
+            assert [ix.sparse_state()[0] for ix in ixs if ix is not ixs[2]] == [1, 1, 1, 1], [ix.sparse_state() for ix in ixs]
+        else:
+            assert [ix.flat_state()[0] for ix in ixs if ix is not ixs[2]] == [1, 1, 1, 1], [ix.flat_state() for ix in ixs]
+
+
 def test_count_multi_equals_one_index_at_a_time(O, IntervalIndex):
     """bxmi_ivl_count_multi_dev (one fused bitmap-cell pass over several indexes = a dict of per-chromosome trees) against
     the oracle and against per-index calls: indexes of different spans (bucket widths 2^10 .. 2^17), one with reversed
@@ -1274,14 +1354,23 @@ def test_find_on_sorted_batches_flat_fill(O, IntervalIndex):
     ix = make_index(IntervalIndex, s, e)
     set_opt("ivl.partition", 1)
     try:
-        got = {}
-        for flat in (1, 0):
+        # fused: count, offsets (decoupled look-back over 74 chunks) and fill in ONE kernel (ivl_local_find_kernel); then round 4's
+        # three stages with the flat fill, then with the lane-per-query fill
+        for fused, flat in ((1, 1), (0, 1), (0, 0)):
+            set_opt("ivl.find_fused", fused)
             set_opt("ivl.find_flat", flat)
-            got[flat] = ix.find(qs, qe)
-            assert np.array_equal(got[flat][0], w_off), ("offsets", flat)
-            bad = np.nonzero(got[flat][1] != w_hits)[0]
-            assert len(bad) == 0, ("hits", flat, bad[:8], got[flat][1][bad[:8]], w_hits[bad[:8]])
+            got = ix.find(qs, qe)
+            assert np.array_equal(got[0], w_off), ("offsets", fused, flat, np.nonzero(got[0] != w_off)[0][:8])
+            bad = np.nonzero(got[1] != w_hits)[0]
+            assert len(bad) == 0, ("hits", fused, flat, bad[:8], got[1][bad[:8]], w_hits[bad[:8]])
         assert int(np.diff(w_off).max()) > 3000 and len(w_hits) > 5 * nq  # the pile and the long targets are really in play
+        # a buffer that is too small: the fused kernel writes no hit past it, the total comes back, the wrapper retries
+        set_opt("ivl.find_fused", 1)
+        set_opt("ivl.find_flat", 1)
+        got = ix.find(qs, qe, cap_hint=len(w_hits) // 3)
+        assert np.array_equal(got[0], w_off) and np.array_equal(got[1], w_hits), "after BXMI_ERANGE"
+        got = ix.find(qs, qe, cap_hint=len(w_hits))  # exactly enough
+        assert np.array_equal(got[0], w_off) and np.array_equal(got[1], w_hits)
     finally:
         reset_opts()
 

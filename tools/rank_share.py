@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""configs[3] as ONE rank of WORLD sees it (the heaviest rank of the LPT deal), on this GPU: its fused count pass alone.
-Predicts the strong-scaling curve without the other GPUs (no collective here).  WORLD env (default 8)."""
+"""configs[3] as ONE rank of WORLD sees it (the heaviest rank of the LPT deal), on this GPU: its fused count pass alone, the same
+followed by a bxmi_allreduce_i64 of the 24 per-chromosome totals (a communicator of ONE rank: it prices the launch and the RCCL
+entry, not the wire -- RCCL refuses two ranks on one device), and the share with every chromosome's queries sorted by start.
+Predicts the strong-scaling curve without the other GPUs; NO curve has been measured on hardware.  WORLDS env (default 1,2,4,8)."""
 import json
 import os
 import sys
@@ -12,6 +14,27 @@ import torch
 
 from bxmi import shard, synth
 from bxmi.intervals import IntervalIndex
+
+comm = None
+try:
+    comm = shard.Comm(0, 1, lambda raw: raw)
+except Exception as ex:  # (no RCCL in reach: the share is reported without the collective)
+    print("no communicator: %r" % (ex,), file=sys.stderr)
+red = torch.zeros(24, dtype=torch.int64, device="cuda")
+
+
+def timed(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
 
 out = {}
 for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
@@ -35,17 +58,24 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
         IntervalIndex.count_multi_dev(ixs, [x.data_ptr() for x in qs], [x.data_ptr() for x in qe], [x.numel() for x in qs], [x.data_ptr() for x in cnt],
                                       [tot[i:].data_ptr() for i in range(len(mine))], stream)
 
-    for _ in range(3):
+    ms = timed(step)
+    out[world] = dict(chromosomes=len(mine), queries=int(sum(x.numel() for x in qs)), ms=round(ms, 4))
+    if comm is not None:
+        def step_reduce():
+            step()
+            red[: len(mine)].copy_(tot, non_blocking=True)
+            comm.allreduce_i64(red.data_ptr(), 24, stream)
+
+        out[world]["ms_with_allreduce_world_of_one"] = round(timed(step_reduce), 4)
+    # the same share with every chromosome's queries sorted by start (the sorted walk over segments, no exchange)
+    for i in range(len(qs)):
+        o = torch.argsort(qs[i], stable=True)
+        qs[i], qe[i] = qs[i][o].contiguous(), qe[i][o].contiguous()
+        del o
+    for _ in range(4):  # (the exact order check comes back one call after the probe saw no descent)
         step()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    e0.record()
-    for _ in range(reps):
-        step()
-    e1.record()
-    torch.cuda.synchronize()
-    out[world] = dict(chromosomes=len(mine), queries=int(sum(x.numel() for x in qs)), ms=round(e0.elapsed_time(e1) / reps, 4))
+        torch.cuda.synchronize()
+    out[world]["ms_sorted_queries"] = round(timed(step, warm=1), 4)
     for ix in ixs:
         ix.close()
     del qs, qe, cnt
@@ -53,4 +83,7 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
 base = out[min(out)]["ms"]
 for w in out:
     out[w]["speedup_without_collective"] = round(base / out[w]["ms"], 2)
+    if "ms_with_allreduce_world_of_one" in out[w]:
+        out[w]["speedup_with_allreduce_world_of_one"] = round(base / out[w]["ms_with_allreduce_world_of_one"], 2)
+    out[w]["speedup_sorted_vs_sorted"] = round(out[min(out)]["ms_sorted_queries"] / out[w]["ms_sorted_queries"], 2)
 print(json.dumps(out))
