@@ -30,6 +30,7 @@ constexpr int FX_NBK = 2 * BM_NB;     // half buckets
 constexpr int FX_CAPW = 15360;        // (end, index) pairs of one piece's window in LDS (120 KB)
 constexpr int FX_BACK = 512;          // pairs staged below the lowest `hi` of a piece: the walk of an ordinary record ends inside
 constexpr int FX_HCAP = 512;          // hits a wave collects in LDS per pass of 64 records (mean 320 on configs[4])
+constexpr int FX_BT = 32;            // tiles of a wave's batch (one run per lane; 64 left 16 waves with 24 batches on configs[4])
 constexpr int FX_THREADS = 1024;
 constexpr int FX_NW = FX_THREADS / 64;
 constexpr size_t FX_LDS_BYTES = (size_t)FX_CAPW * 8 + (size_t)FX_NW * (FX_HCAP * 4 + 64 * 4);
@@ -129,49 +130,92 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
         const int unit = pc.sb0 >> (g.f + 1);
         const long long lo_u = (long long)g.cmin + ((long long)unit << (g.shift + g.f));
         const int sLo = meta2[unit << (g.f + 1)].x;
-        // stage the window: two pairs per 16-byte load
+        // stage the window: two pairs per 16-byte load, ALL of a thread's loads requested before the first is written to LDS
+        // (one load, one wait, one LDS store per round made the staging eight dependent round trips to HBM per piece)
         {
             const int nw = whi - wlo;
             const int2 *__restrict__ src = eid + wlo;
-            for (int i = 2 * (int)threadIdx.x; i < nw; i += 2 * FX_THREADS) {
-                if (i + 1 < nw) {
-                    const sl_v4a8 v = *reinterpret_cast<const sl_v4a8 *>(src + i);
-                    *reinterpret_cast<int4 *>(s_win + i) = make_int4(v.x, v.y, v.z, v.w);
-                } else
-                    s_win[i] = src[i];
+            constexpr int ROUNDS = (FX_CAPW + 2 * FX_THREADS - 1) / (2 * FX_THREADS);
+            sl_v4a8 v[ROUNDS];
+#pragma unroll
+            for (int r = 0; r < ROUNDS; r++) {
+                const int i = 2 * ((int)threadIdx.x + r * FX_THREADS);
+                // (the pair behind the window's last one is read with it when the window's length is odd: the pair array ends
+                // with SL_WALK spare entries... in front; behind, a valid address is all that is needed -- clamp)
+                const int ia = i + 1 < nw ? i : (nw >= 2 ? nw - 2 : 0);
+                v[r] = *reinterpret_cast<const sl_v4a8 *>(src + ia);
+            }
+#pragma unroll
+            for (int r = 0; r < ROUNDS; r++) {
+                const int i = 2 * ((int)threadIdx.x + r * FX_THREADS);
+                if (i + 1 < nw)
+                    *reinterpret_cast<int4 *>(s_win + i) = make_int4(v[r].x, v[r].y, v[r].z, v[r].w);
+                else if (i < nw)  // the last pair of an odd window: it is the SECOND pair of the clamped load (pairs nw - 2, nw - 1)
+                    s_win[i] = nw >= 2 ? make_int2(v[r].z, v[r].w) : src[i];
             }
         }
         __syncthreads();
         auto pair_at = [&](int k) -> int2 { return (k >= wlo && k < whi) ? s_win[k - wlo] : eid[k]; };
         const unsigned *__restrict__ runs0 = runT2 + (int64_t)pc.sb0 * ntp;
         const unsigned *__restrict__ runs1 = runT2 + (int64_t)(pc.sb1 - 1) * ntp;
-        for (int tb = t0 + 64 * wave; tb < t1; tb += 64 * FX_NW) {
-            // one run per lane: the piece's records of tile tb + lane
+        // A wave takes FX_BT tiles at a time (one run per lane), and the kernel is a chain of dependent loads -- run table ->
+        // records -> stores -- on ONE workgroup per CU: the next batch's runs and the next pass's records are requested before
+        // the current ones are worked on.
+        struct Run {
+            unsigned a, rlen;
+            long long tbase;
+        };
+        auto load_run = [&](int tb, Run &R) {  // the piece's records of tile tb + lane
             const int t = tb + lane;
-            unsigned a = 0u, rlen = 0u;
-            long long tbase = 0;
-            if (t < t1) {
+            R.a = 0u, R.rlen = 0u, R.tbase = 0;
+            if (lane < FX_BT && t < t1) {
                 const unsigned r0 = runs0[t], r1 = runs1[t];
-                a = r0 & 0xffffu;
-                rlen = (r1 & 0xffffu) + (r1 >> 16) - a;
-                tbase = tile_base[t];
+                R.a = r0 & 0xffffu;
+                R.rlen = (r1 & 0xffffu) + (r1 >> 16) - R.a;
+                R.tbase = tile_base[t];
             }
+        };
+        Run cur_run;
+        load_run(t0 + FX_BT * wave, cur_run);
+        for (int tb = t0 + FX_BT * wave; tb < t1; tb += FX_BT * FX_NW) {
+            Run next_run;
+            load_run(tb + FX_BT * FX_NW, next_run);  // (past t1: nothing is loaded)
+            const unsigned a = cur_run.a, rlen = cur_run.rlen;
+            const long long tbase = cur_run.tbase;
+            const int t = tb + lane;
             const unsigned rincl = wave_inclusive_scan(rlen, OpSum());
             const unsigned T = (unsigned)__builtin_amdgcn_readlane((int)rincl, 63);
             const unsigned rdelta = ((unsigned)t << tile_log2) + a - (rincl - rlen);  // + s = the tile-sorted position of the batch's record s
             re[lane] = rincl;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (unsigned p0 = 0; p0 < T; p0 += 64u) {
+            struct Rec {
+                unsigned at, rec, h, lo;
+                long long tb_r;
+                bool act;
+            };
+            auto fetch = [&](unsigned p0, Rec &R) {
                 const unsigned s = p0 + (unsigned)lane;
-                const bool act = s < T;
+                R.act = s < T;
                 const unsigned r = fx_locate(re, s);
                 // (every lane takes part in the shuffles: a lane that is switched off answers a ds_bpermute with ZERO, and in the
                 // batch's last pass the lane that owns the last run is usually beyond the pass's records)
                 const unsigned rd_r = (unsigned)__shfl((int)rdelta, (int)r, 64);
-                const long long tb_r = __shfl(tbase, (int)r, 64);
-                const unsigned at = act ? rd_r + s : ((unsigned)tb << tile_log2);
-                const unsigned rec = recs[(size_t)at], h = hc[(size_t)at], lo = loff[(size_t)at];
+                R.tb_r = __shfl(tbase, (int)r, 64);
+                R.at = R.act ? rd_r + s : ((unsigned)tb << tile_log2);
+                R.rec = recs[(size_t)R.at], R.h = hc[(size_t)R.at], R.lo = loff[(size_t)R.at];
+            };
+            Rec nxt;
+            if (T) fetch(0u, nxt);
+            for (unsigned p0 = 0; p0 < T; p0 += 64u) {
+                Rec R = nxt;
+                // (the pass's records must have ARRIVED before the next pass's are requested: the counter of outstanding memory
+                // operations retires in order, so a wait placed after the new requests would wait for them as well)
+                asm volatile("; records of the pass %0 %1 %2" : "+v"(R.rec), "+v"(R.h), "+v"(R.lo) : : "memory");
+                if (p0 + 64u < T) fetch(p0 + 64u, nxt);  // (wave-uniform)
+                const bool act = R.act;
+                const unsigned at = R.at, rec = R.rec, h = R.h, lo = R.lo;
+                const long long tb_r = R.tb_r;
                 const bool esc = (lo >> 31) != 0u;
                 unsigned n = act && !esc ? (h & 0xffffu) : 0u;
                 if (n == 0xffffu) n = cnt[(size_t)at];  // (a count that did not fit the packed word)
@@ -195,11 +239,28 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                     int c = in ? (int)n : 0;
                     int kk = hi - 1;
                     if (!direct) {
-                        for (int step = 0; step < LANE_WINDOW && c > 0 && kk >= 0; step++, kk--) {
-                            const int2 p = pair_at(kk);
+                        auto take = [&](const int2 p) {
                             if (p.x > qs) {
                                 --c;
                                 st[my_off + (unsigned)c] = p.y;
+                            }
+                        };
+                        // The kernel is bound by vector instructions as much as by memory (402 per pass of 64 records, measured:
+                        // profiles/r05_find_pmc.txt), half of them this loop: when every lane's first LANE_WINDOW candidates lie
+                        // inside the window -- the rule -- the steps carry no bounds checks at all.
+                        if (__all(c <= 0 || (hi <= whi && hi - LANE_WINDOW >= wlo))) {
+                            const int2 *wp = s_win + (c > 0 ? kk - wlo : LANE_WINDOW);
+                            int step = 0;
+                            for (; step < LANE_WINDOW && c > 0; step++) take(wp[-step]);
+                            kk -= step;
+                        } else {
+                            for (int step = 0; step < LANE_WINDOW && c > 0 && kk >= 0; step++, kk--) {
+                                // (two self-contained arms: where an LDS read and an HBM load meet in one value the compiler waits
+                                // for ALL outstanding memory operations at every step -- the next pass's records included)
+                                if (__all(kk >= wlo && kk < whi))
+                                    take(s_win[kk - wlo]);
+                                else
+                                    take(pair_at(kk));
                             }
                         }
                     }
@@ -209,7 +270,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                         m &= m - 1;
                         int C = __shfl(c, src, 64), K = __shfl(kk, src, 64);
                         const int S = __shfl(qs, src, 64);
-                        const unsigned R = (unsigned)__shfl((int)my_off, src, 64);
+                        const unsigned Rr = (unsigned)__shfl((int)my_off, src, 64);
                         int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
                         while (C > 0 && K >= 0) {
                             const int kx = K - lane;
@@ -223,7 +284,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                                 if (direct)
                                     D[C - 1 - before] = p.y;
                                 else
-                                    st[R + (unsigned)(C - 1 - before)] = p.y;
+                                    st[Rr + (unsigned)(C - 1 - before)] = p.y;
                             }
                             C -= __popcll(fm);
                             K -= 64;
@@ -240,7 +301,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                                 v.x = st[my_off + j], v.y = st[my_off + j + 1u], v.z = st[my_off + j + 2u], v.w = st[my_off + j + 3u];
                                 *reinterpret_cast<fx_v4a4 *>(dst + j) = v;
                             } else if (j < nn) {
-                                for (unsigned u = j; u < nn; u++) dst[u] = st[my_off + u];
+                                for (unsigned u = j; u < nn && u < j + 4u; u++) dst[u] = st[my_off + u];
                             }
                         }
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next sub-batch / pass overwrites the image)
@@ -252,6 +313,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (`re` is rewritten by the next batch)
             __builtin_amdgcn_wave_barrier();
+            cur_run = next_run;
         }
         __syncthreads();  // the next piece's window replaces this one; thread 0 draws the next number
     }
@@ -312,12 +374,13 @@ __global__ __launch_bounds__(BM_PART_Q) void fx_hits_copy_kernel(const BmSeg *__
     ends[lane] = incl;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (unsigned s0 = 0; s0 < wtotal; s0 += 256u) {  // four passes at a time: their loads in flight together
-        unsigned dst[4];
-        bool act[4];
-        int v[4];
+    constexpr int FL = 6;  // passes whose loads are in flight together (a wave's stretch is ~320 hits on configs[4]: one round)
+    for (unsigned s0 = 0; s0 < wtotal; s0 += 64u * FL) {
+        unsigned dst[FL];
+        bool act[FL];
+        int v[FL];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < FL; j++)
             if (s0 + 64u * j < wtotal) {  // (wave-uniform)
                 const unsigned s = s0 + 64u * j + (unsigned)lane;
                 const unsigned r = fx_locate(ends, s);
@@ -327,7 +390,7 @@ __global__ __launch_bounds__(BM_PART_Q) void fx_hits_copy_kernel(const BmSeg *__
                 v[j] = region[act[j] ? src : 0u];
             }
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < FL; j++)
             if (s0 + 64u * j < wtotal && act[j]) out[dst[j]] = v[j];
     }
     if ((my_sv >> 31) && my_c) {  // escape record: rare, answered from the sealed index by its own lane

@@ -1217,12 +1217,14 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
                                                                      unsigned long long *__restrict__ total_slots,
                                                                      const unsigned *__restrict__ gate,
                                                                      int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */,
-                                                                     unsigned long long *__restrict__ order_host = nullptr, unsigned long long seq = 0)
+                                                                     unsigned long long *__restrict__ order_host = nullptr, unsigned long long seq = 0,
+                                                                     unsigned long long *__restrict__ chunk_tot = nullptr /* find(): the sum of every chunk's counts */)
 {
     __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
     __shared__ int s_mm[3][LC_THREADS / 64];
     __shared__ int s_slice[6];  // eLo, eHi, sLo, sHi, qeLo, qeHi
     __shared__ long long red[LC_THREADS / 64];
+    __shared__ long long red2[LC_THREADS / 64];
     // what the order check found, into host memory: the host picks the shape of THIS kernel for later batches by it
     // (bm_count_segments; pass number << 1 | 1 = not sorted)
     if (order_host && blockIdx.x == 0 && threadIdx.x == 0) *order_host = (seq << 1) | (gate && *gate != 0 ? 1ull : 0ull);
@@ -1233,12 +1235,24 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, 
         if (LOOP && chunk != chunk0) __syncthreads();  // the shared arrays of the chunk before are done with
         const int64_t base = chunk * LC_CHUNK;
         const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
+        long long cacc = 0;
         lc_chunk_counts(S, E, ix, e_sorted, qs_arr, qe_arr, base, n, lds, s_mm, s_slice, [&](int, int k, bool live, int c, int s_rank, int) {
             if (!live) return;
             if (counts) counts[base + k] = c;
             if (his) his[base + k] = s_rank;
-            acc += c;
+            cacc += c;
         });
+        acc += cacc;
+        if (chunk_tot) {  // (find(): the CSR offsets are then one scan over the CHUNKS away, ivl_find_local)
+            const long long w = wave_sum_i64(cacc);
+            if (lane_id() == 0) red2[threadIdx.x >> 6] = w;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                long long t = 0;
+                for (int i = 0; i < LC_THREADS / 64; i++) t += red2[i];
+                chunk_tot[chunk] = (unsigned long long)t;
+            }
+        }
     }
     if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
 }
@@ -1801,10 +1815,31 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_walk_kernel(const int2
 constexpr int FF_HITS = 512;    // hits of a wave's 64 queries staged in LDS (mean 320 on configs[4])
 constexpr int FF_PAIRS = 128;   // pairs below the wave's highest `hi` staged in LDS
 
+// The pairs a wave's 64 queries will walk: [wbase, kmax) = the FF_PAIRS ranks below the highest `hi` of the wave, requested into
+// registers ahead of time -- all at once (round 4 issued them one after the other behind a branch each: two dependent round trips
+// to HBM per batch, after two more for the queries' numbers; the kernel's time was those four latencies), and by the callers one
+// batch EARLY, while the batch before is being walked.
+struct FfStage {
+    int2 pv[FF_PAIRS / 64];
+    int wbase, kmax;
+};
+__device__ __forceinline__ void ff_load(const int2 *__restrict__ eid /* at index 0 */, int c, int hi, FfStage &S)
+{
+    const int lane = lane_id();
+    S.kmax = wave_max_i32(c ? hi : 0);
+    S.wbase = S.kmax > FF_PAIRS ? S.kmax - FF_PAIRS : 0;
+    const int last = S.kmax > 0 ? S.kmax - 1 : 0;
+#pragma unroll
+    for (int j = 0; j < FF_PAIRS / 64; j++) {
+        const int kk = S.wbase + 64 * j + lane;
+        S.pv[j] = eid[kk < S.kmax ? kk : last];  // (a valid address: no branch around the loads)
+    }
+}
+
 // One wave, 64 consecutive queries (a lane each: `c` hits to find below rank `hi`, its CSR offset `off`): see the kernel below.
-// wp / wh: the wave's LDS images of the pairs and of its stretch of the list.
-__device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *__restrict__ eid /* at index 0 */, int c, const int hi, const int qs,
-                                             const long long off, int32_t *__restrict__ hits)
+// wp / wh: the wave's LDS images of the pairs and of its stretch of the list; S: what ff_load brought for these queries.
+__device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *__restrict__ eid /* at index 0 */, const FfStage &S, int c, const int hi,
+                                             const int qs, const long long off, int32_t *__restrict__ hits)
 {
     const int lane = lane_id();
     int k = hi - 1;
@@ -1819,19 +1854,17 @@ __device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *
     const int rel = flat ? (int)(off - base_off) : 0;
     int32_t *__restrict__ dst = hits + off;
     // the window of the pairs: FF_PAIRS below the highest hi of the wave
-    const int kmax = wave_max_i32(c ? hi : 0);
-    const int wbase = kmax > FF_PAIRS ? kmax - FF_PAIRS : 0;
+    const int kmax = S.kmax, wbase = S.wbase;
 #pragma unroll
     for (int j = 0; j < FF_PAIRS / 64; j++) {
         const int kk = wbase + 64 * j + lane;
-        if (kk < kmax) wp[64 * j + lane] = eid[kk];
+        if (kk < kmax) wp[64 * j + lane] = S.pv[j];
     }
     // (lanes read what OTHER lanes staged: wave-level release + barrier, not just in-order DS issue)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     auto pair_at = [&](int kk) -> int2 { return kk >= wbase ? wp[kk - wbase] : eid[kk]; };
-    for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
-        const int2 p = pair_at(k);
+    auto take = [&](const int2 p) {
         if (p.x > qs) {
             --c;
             if (flat)
@@ -1839,6 +1872,14 @@ __device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *
             else
                 dst[c] = p.y;
         }
+    };
+    for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
+        // (two self-contained arms: where an LDS read and an HBM load meet in one value the compiler waits for ALL outstanding
+        // memory operations at every step -- the next batch's numbers and pairs included)
+        if (__all(k >= wbase))
+            take(wp[k - wbase]);
+        else
+            take(pair_at(k));
     }
     unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
     while (m) {
@@ -1884,15 +1925,67 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
     const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
     const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
-    for (int64_t qb = q0 + 64 * wave; qb < q1; qb += FIND_THREADS) {  // (waves are on their own: no workgroup barrier in here)
+    struct Q {
+        int c, hi, qs;
+        long long off;
+    };
+    auto load_q = [&](int64_t qb, Q &x) {  // (independent loads: one round trip)
         const int64_t q = qb + lane;
         const bool live = q < q1;
-        const int c = live ? cnt[q] : 0;
-        const int hi = live && c ? his[q] : 0;
-        const int qs = live ? qs_arr[q] : 0;
-        // (a dead lane carries the offset behind the last live query of the wave's stretch: lane 0 is live whenever the batch exists)
-        const long long off = offs[live ? q : q1 - 1];
-        ff_wave_fill(s_pairs[wave], s_hits[wave], eid, c, hi, qs, off, hits);
+        const int64_t qa = live ? q : q1 - 1;  // (a dead lane: valid addresses, no hits; its offset is the one behind the stretch's last query)
+        x.c = cnt[qa], x.hi = his[qa], x.qs = qs_arr[qa], x.off = offs[qa];
+        if (!live) x.c = 0;
+    };
+    if (q0 + 64 * wave >= q1) return;
+    Q cur;
+    load_q(q0 + 64 * wave, cur);
+    for (int64_t qb = q0 + 64 * wave; qb < q1; qb += FIND_THREADS) {  // (waves are on their own: no workgroup barrier in here)
+        FfStage S;
+        ff_load(eid, cur.c, cur.hi, S);
+        Q nxt = cur;
+        if (qb + FIND_THREADS < q1) load_q(qb + FIND_THREADS, nxt);  // the next batch's numbers travel while this one is walked
+        ff_wave_fill(s_pairs[wave], s_hits[wave], eid, S, cur.c, cur.hi, cur.qs, cur.off, hits);
+        cur = nxt;
+    }
+}
+
+// CSR offsets of a sorted find(): offsets[q] = chunk_base[chunk of q] + the exclusive prefix of the chunk's counts -- one read of
+// the counts, one write of the offsets (the three-kernel scan read the counts twice and took 0.25 ms per 50 M).
+__global__ __launch_bounds__(LC_THREADS) void lf_offsets_kernel(const int32_t *__restrict__ cnt, const long long *__restrict__ chunk_base, int64_t nq,
+                                                                long long *__restrict__ offsets)
+{
+    __shared__ long long lds[16];
+    const int64_t base = (int64_t)blockIdx.x * LC_CHUNK + (int64_t)threadIdx.x * LC_ITEMS;
+    int c[LC_ITEMS];
+    if (base + LC_ITEMS <= nq) {
+        const int4 a = *reinterpret_cast<const int4 *>(cnt + base), b = *reinterpret_cast<const int4 *>(cnt + base + 4);
+        c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < LC_ITEMS; j++) c[j] = base + j < nq ? cnt[base + j] : 0;
+    }
+    long long run = 0;
+#pragma unroll
+    for (int j = 0; j < LC_ITEMS; j++) run += c[j];
+    long long total;
+    long long off = chunk_base[blockIdx.x] + block_exclusive_scan(run, OpSum(), 0ll, lds, &total);
+    static_assert(LC_ITEMS == 8, "eight consecutive counts per thread");
+    if (base + LC_ITEMS <= nq) {
+        long long o[LC_ITEMS];
+#pragma unroll
+        for (int j = 0; j < LC_ITEMS; j++) {
+            o[j] = off;
+            off += c[j];
+        }
+#pragma unroll
+        for (int j = 0; j < LC_ITEMS; j += 2)
+            *reinterpret_cast<longlong2 *>(offsets + base + j) = make_longlong2(o[j], o[j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < LC_ITEMS; j++) {
+            if (base + j < nq) offsets[base + j] = off;
+            off += c[j];
+        }
     }
 }
 
@@ -1902,7 +1995,9 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
 // the next.  Here a chunk's counts stay in registers: the workgroup scans them (wave scans + one wave over the 64 (row, wave)
 // totals), gets the hits of all chunks before it by a DECOUPLED LOOK-BACK over per-chunk words (chunks are numbered by a ticket
 // in dispatch order, so every predecessor has started and none waits for a successor; a word carries flag : 2 | value : 62,
-// 1 = the chunk's own total, 2 = the inclusive prefix), writes the offsets, and its eight waves fill their 64-query stretches
+// 1 = the chunk's own total, 2 = the inclusive prefix; RELAXED agent-scope accesses -- the word is the whole message, and on this
+// part an agent-scope release / acquire is a write-back / invalidation of the XCD's L2: the first version, with them, took 3.1 ms
+// where the three launches took 1.9), writes the offsets, and its eight waves fill their 64-query stretches
 // exactly as part_fill_flat_kernel does (the LDS trees of the count half are dead by then: the images live in the same bytes).
 // A chunk whose stretch would pass `cap` writes no hits (the host reports BXMI_ERANGE from the total, as before).
 // state[nchunks] and the ticket are zeroed by the host before the launch.
@@ -1950,13 +2045,13 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_find_kernel(TreeDev S, T
         // decoupled look-back
         long long before = 0;
         if (chunk == 0) {
-            if (lane == 0) __hip_atomic_store(state, LF_FLAG_PREFIX | (unsigned long long)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(state, LF_FLAG_PREFIX | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            if (lane == 0) __hip_atomic_store(state + chunk, LF_FLAG_AGG | (unsigned long long)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(state + chunk, LF_FLAG_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int64_t p = chunk - 1;  // the nearest predecessor not yet accounted for
             for (;;) {
                 const int64_t idx = p - lane;
-                const unsigned long long w = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : LF_FLAG_PREFIX;
+                const unsigned long long w = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LF_FLAG_PREFIX;
                 const unsigned flag = (unsigned)(w >> 62);
                 const unsigned long long m_empty = __ballot(flag == 0u), m_prefix = __ballot(flag == 2u);
                 const int first_prefix = m_prefix ? __ffsll((long long)m_prefix) - 1 : 64;
@@ -1973,7 +2068,7 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_find_kernel(TreeDev S, T
                 p -= 64;
             }
             if (lane == 0)
-                __hip_atomic_store(state + chunk, LF_FLAG_PREFIX | (unsigned long long)(before + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(state + chunk, LF_FLAG_PREFIX | (unsigned long long)(before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane == 0) {
             s_base[0] = before, s_base[1] = total;
@@ -1994,8 +2089,15 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_find_kernel(TreeDev S, T
     // the fill: wave w's row j is 64 consecutive queries
     int2 *wp = reinterpret_cast<int2 *>(lds) + wave * FF_PAIRS;
     int32_t *wh = lds + NW * FF_PAIRS * 2 + wave * FF_HITS;
+    FfStage stg;
+    ff_load(eid, cc[0], hh[0], stg);
 #pragma unroll
-    for (int j = 0; j < LC_ITEMS; j++) ff_wave_fill(wp, wh, eid, cc[j], hh[j], ss[j], off[j], hits);
+    for (int j = 0; j < LC_ITEMS; j++) {
+        FfStage nstg = stg;
+        if (j + 1 < LC_ITEMS) ff_load(eid, cc[j + 1], hh[j + 1], nstg);  // the next row's pairs travel while this one is walked
+        ff_wave_fill(wp, wh, eid, stg, cc[j], hh[j], ss[j], off[j], hits);
+        stg = nstg;
+    }
 }
 
 __global__ void part_fold_total_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
@@ -2353,7 +2455,9 @@ static int64_t g_opt_find_fill = 0;    // bucketed find: 0 = hits written from b
 static int64_t g_opt_bitmap = -1;      // second-generation count pass (count_bitmap.hpp): -1 = when the index qualifies, 0 = never, 1 = same as -1
 static int64_t g_opt_bitmap_min = 2 << 20;  // auto: batches of at least this many queries take it (when the index qualifies)
 static int64_t g_opt_bm_variant = -1;  // tile kernel shape: -1 = by batch size, 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
-static int64_t g_opt_find_fused = 1;   // find() on a sorted batch: 1 = count, offsets (decoupled look-back) and fill in one kernel (ivl_local_find_kernel), 0 = round 4's three stages
+static int64_t g_opt_find_fused = 0;   // find() on a sorted batch: 1 = count, offsets (decoupled look-back) and fill in one kernel (ivl_local_find_kernel: measured 2.65 ms
+                                       // against 1.58 for the stages -- the count half is a long chain of dependent loads that lives on four workgroups per CU, the
+                                       // fused kernel's registers leave two), 0 = the stages (default)
 static int64_t g_opt_fx_fill = 1;      // find() through the exchange: 1 = the fill half on LDS windows of half-bucket pieces (find_exchange.hpp), 0 = round 2's fill and copy
 static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
@@ -2686,12 +2790,22 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     BXMI_TRY(h->p_lo.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_hi.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
+    const bool chunk_scan = walk && ((uintptr_t)offsets & 15) == 0;  // the offsets from one scan over the chunks' totals
     if (walk) {
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
-        hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
+        const int64_t nchunks = div_up(nq, LC_CHUNK);
+        if (chunk_scan) BXMI_TRY(h->lf_state.reserve((size_t)(2 * nchunks + 4) * 8));
+        hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
                            h->e_sorted.as<int32_t>(), qs, qe, nq, h->q_cnt.as<int32_t>(), (unsigned long long *)nullptr, (const unsigned *)nullptr,
-                           h->p_hi.as<int32_t>());
+                           h->p_hi.as<int32_t>(), (unsigned long long *)nullptr, 0ull, chunk_scan ? h->lf_state.as<unsigned long long>() : nullptr);
+        if (chunk_scan) {
+            long long *chunk_base = h->lf_state.as<long long>() + nchunks;  // [nchunks + 1]
+            hipLaunchKernelGGL(fx_tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->lf_state.as<unsigned long long>(), nchunks, chunk_base,
+                               reinterpret_cast<long long *>(offsets) + nq);
+            hipLaunchKernelGGL(lf_offsets_kernel, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, h->q_cnt.as<int32_t>(), chunk_base, nq,
+                               reinterpret_cast<long long *>(offsets));
+        }
     } else {
         TreeDev S = h->treeS.dev, P = h->treeP.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, P.lds_from = P.nlev, P.lds_ints = 0;  // walk the global levels only
@@ -2699,8 +2813,9 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
                            h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
     }
     BXMI_LAUNCH_CHECK();
-    BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
-                                                           reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
+    if (!chunk_scan)
+        BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
+                                                               reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
     int64_t total = 0;
     BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
     BXMI_HIP(hipStreamSynchronize(st));
@@ -4174,11 +4289,20 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
             // one cheap look at the starts decides the path on the host (find() synchronises for the total anyway)
             BXMI_TRY(h->p_slots.reserve((size_t)PT_MAX_SUB * PT_SLOT_STRIDE * sizeof(unsigned long long)));
             unsigned *flag = reinterpret_cast<unsigned *>(h->p_slots.as<unsigned long long>() + PT_SLOTS);
-            unsigned unsorted = 1;
-            BXMI_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
-            hipLaunchKernelGGL(ivl_sorted_check_kernel, dim3(stream_grid(nq, 256)), dim3(256), 0, st, qs, nq, flag);
-            BXMI_HIP(hipMemcpyAsync(&unsorted, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-            BXMI_HIP(hipStreamSynchronize(st));
+            unsigned unsorted = 0;
+            // (a probe of 8192 starts first: a descent among them says "shuffled" for certain and saves the full read of the
+            // starts -- 55 us per 50 M -- which only a batch that passes the probe pays)
+            if (nq >= (1 << 20)) {
+                hipLaunchKernelGGL(bm_probe_kernel, dim3(1), dim3(256), 0, st, qs, nq, flag);
+                BXMI_HIP(hipMemcpyAsync(&unsorted, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                BXMI_HIP(hipStreamSynchronize(st));
+            }
+            if (!unsorted) {
+                BXMI_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
+                hipLaunchKernelGGL(ivl_sorted_check_kernel, dim3(stream_grid(nq, 256)), dim3(256), 0, st, qs, nq, flag);
+                BXMI_HIP(hipMemcpyAsync(&unsorted, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                BXMI_HIP(hipStreamSynchronize(st));
+            }
             if (!unsorted) return ivl_find_local(h, qs, qe, nq, offsets, hits, cap, total_host, st);
         }
         if (g_opt_find_sliced && g_opt_bitmap != 0 && g_opt_slice != 0 && h->n >= 4096 && nq >= g_opt_bitmap_min &&

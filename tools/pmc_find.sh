@@ -35,7 +35,7 @@ for l in open('gpurun_out/pmc_find/index.txt'):
     if f:
         for r in csv.DictReader(open(f[0])):
             kn = r['Kernel_Name']
-            if 'sl_' in kn or 'bm_' in kn or 'scan_' in kn:
+            if any(k in kn for k in ("sl_", "bm_", "scan_", "fx_", "ivl_local", "part_fill")):
                 acc[kn.split('(')[0].replace('void ', '').replace('bxmi::', '')[:34] + ' ' + r['Counter_Name']].append(float(r['Counter_Value']))
     out.write(l.strip() + '\n')
     for k, v in sorted(acc.items()):
