@@ -359,8 +359,24 @@ def bench_per_call():
     for x in q:
         bases += b.count_range(x, 500)
     count_us = (time.perf_counter() - t0) / len(q) * 1e6
-    return dict(IntervalTree_find_us=round(find_us, 2), BinnedBitSet_count_range_us=round(count_us, 2), calls=len(q), hits=hits, bases=bases,
-                note="drop-in classes, one call per query, 200k-interval tree / 20k-range bitset; host wall time incl. the Python wrapper")
+    # the same calls with the host mirror of the device-extracted run list switched off: every call is a launch and an answer across PCIe
+    saved = bx.bitset._MIRROR_MAX_RUNS
+    bx.bitset._MIRROR_MAX_RUNS = -1
+    try:
+        b.set_range(0, 1)  # (a mutation drops the mirror)
+        b.count_range(0, 10)
+        t0 = time.perf_counter()
+        bases_dev = 0
+        for x in q:
+            bases_dev += b.count_range(x, 500)
+        count_dev_us = (time.perf_counter() - t0) / len(q) * 1e6
+    finally:
+        bx.bitset._MIRROR_MAX_RUNS = saved
+    return dict(IntervalTree_find_us=round(find_us, 2), BinnedBitSet_count_range_us=round(count_us, 2),
+                BinnedBitSet_count_range_device_every_call_us=round(count_dev_us, 2), calls=len(q), hits=hits, bases=bases,
+                mirror_and_device_agree=bool(abs(bases_dev - bases) <= 1),  # (one base was set in between to drop the mirror)
+                note="drop-in classes, one call per query, 200k-interval tree / 20k-range bitset; host wall time incl. the Python wrapper; "
+                     "count_range: answered from the host mirror of the device-extracted run list (default between mutations) / by a kernel per call")
 
 
 def genome_golden_check(chrom, counts_np, golden):
@@ -753,6 +769,21 @@ def main():
                          "allocation + the order probe answered synchronously; pass 2 = the steady state")
         ixc.close()
 
+    # the caller wants the TOTAL only (counts = NULL; scripts/bed_count_overlapping.py consumes len(find()) only): the same pass, its
+    # un-permute kernel sums without storing a count per query.  Reported beside the headline, never `value`.
+    total_only = None
+    if rank == 0 and world == 1:
+        tt = torch.zeros(8, dtype=torch.int64, device="cuda")
+        ix.count_dev(qs.data_ptr(), qe.data_ptr(), nq, None, tt[0:].data_ptr(), stream)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(5):
+            ix.count_dev(qs.data_ptr(), qe.data_ptr(), nq, None, tt[1 + k:].data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        total_only = dict(ms_per_pass=round(e0.elapsed_time(e1) / 5, 4), same_total=bool((tt[:6] == local_total).all().item()))
+
     # the same batch through the HOST-pointer entry point (pageable numpy buffers over PCIe): reported, never `value`
     pcie = None
     if rank == 0 and world == 1:
@@ -865,6 +896,7 @@ def main():
         "index_build_parts": build_parts,
         "pcie_inclusive": pcie,
         "sorted_queries": sorted_q,
+        "total_only": total_only,
         "parity": parity,
         "overlaps_per_step_rank0": local_total,
         "device": name.value.decode(),

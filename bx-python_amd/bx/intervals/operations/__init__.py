@@ -4,7 +4,7 @@ the operations themselves live in bxmi.operations (one batched engine call per c
 """
 from pkgutil import extend_path
 
-__path__ = extend_path(__path__, __name__)  # operations this package does not carry (concat) come from an installed bx-python
+__path__ = extend_path(__path__, __name__)  # (every operation of the reference's package is carried here, concat included since round 5)
 
 from bxmi.operations import (  # noqa: E402,F401
     BED_DEFAULT_COLS,

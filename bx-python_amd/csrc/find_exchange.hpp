@@ -183,7 +183,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
             const unsigned a = cur_run.a, rlen = cur_run.rlen;
             const long long tbase = cur_run.tbase;
             const int t = tb + lane;
-            const unsigned rincl = wave_inclusive_scan(rlen, OpSum());
+            const unsigned rincl = wave_inclusive_sum_dpp(rlen);
             const unsigned T = (unsigned)__builtin_amdgcn_readlane((int)rincl, 63);
             const unsigned rdelta = ((unsigned)t << tile_log2) + a - (rincl - rlen);  // + s = the tile-sorted position of the batch's record s
             re[lane] = rincl;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                 int32_t *__restrict__ dst = tmp_hits + tb_r + (long long)(lo & 0x7FFFFFFFu);
                 // (prefix sums of the counts clamped to "does not fit": a pile's counts cannot overflow them, and what fits is exact)
                 const unsigned nc = n <= (unsigned)FX_HCAP ? n : (unsigned)FX_HCAP + 1u;
-                const unsigned hincl = wave_inclusive_scan(nc, OpSum());
+                const unsigned hincl = wave_inclusive_sum_dpp(nc);
                 if (__builtin_amdgcn_readlane((int)hincl, 63) == 0) continue;  // (wave-uniform: nothing to emit in this pass)
                 // sub-batches of lanes whose hits fit the wave's LDS image together (normally: all 64 at once)
                 int first = 0;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(BM_PART_Q) void fx_hits_copy_kernel(const BmSeg *__
     // the wave's 64 consecutive queries own one stretch of the CSR list (escape records leave holes in it, filled by their own
     // lanes); it is copied as ONE flat sequence, lane i taking positions i, i + 64, ... (see sl_hits_copy_kernel)
     const unsigned n_me = (my_sv >> 31) ? 0u : my_c;
-    const unsigned incl = wave_inclusive_scan(n_me, OpSum());
+    const unsigned incl = wave_inclusive_sum_dpp(n_me);
     const unsigned wtotal = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     const long long o_first = __shfl(o, 0, 64);
     int32_t *__restrict__ out = hits + o_first;

@@ -1951,6 +1951,9 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
 
 // CSR offsets of a sorted find(): offsets[q] = chunk_base[chunk of q] + the exclusive prefix of the chunk's counts -- one read of
 // the counts, one write of the offsets (the three-kernel scan read the counts twice and took 0.25 ms per 50 M).
+// (Tried on top, round 5: the fill making the offsets itself -- a workgroup per run of chunks, a block scan per batch of 512 queries,
+// no offsets kernel and no 8 bytes per query read back: 1.75 ms against 1.53 with this kernel + part_fill_flat_kernel, whose waves
+// run free of barriers; forced to 8 waves per SIMD it spilled and took 1.86.  Not kept.)
 __global__ __launch_bounds__(LC_THREADS) void lf_offsets_kernel(const int32_t *__restrict__ cnt, const long long *__restrict__ chunk_base, int64_t nq,
                                                                 long long *__restrict__ offsets)
 {
@@ -3751,7 +3754,13 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
     BXMI_HIP(hipStreamSynchronize(st));
     if (total_host) *total_host = total;
-    if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
+    if (total > cap) {
+        // (the contract: BXMI_ERANGE comes with valid offsets.  The copy kernel, which finishes them, does not run: scan the counts.)
+        BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
+                                                               reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
+        BXMI_HIP(hipStreamSynchronize(st));
+        return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
+    }
     if (total == 0) {  // (the copy kernel writes the offsets: nothing to copy, so they are zeroed here)
         BXMI_HIP(hipMemsetAsync(offsets, 0, (size_t)(nq + 1) * 8, st));
         return BXMI_OK;

@@ -44,6 +44,21 @@ __device__ __forceinline__ T wave_inclusive_scan(T v, Op op)
     return v;
 }
 
+// The same for 32-bit sums through DPP (gfx9 family: row_shr inside the 16-lane rows, then row_bcast:15 / row_bcast:31 carry the
+// rows' totals): six VALU instructions, where the shuffle version is a chain of six dependent ds_bpermute round trips through the
+// LDS pipe -- for kernels that scan once per pass of 64 items (find_exchange.hpp).
+__device__ __forceinline__ unsigned wave_inclusive_sum_dpp(unsigned v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return (unsigned)x;
+}
+
 // Exclusive prefix of per-thread values across a 256-thread block.
 // Returns the exclusive prefix for this thread; *block_total gets the total.
 template <typename T, typename Op>

@@ -81,7 +81,8 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *   ivl.order_skip     1 (default): the exact order check is dropped after two shuffled batches (a probe stands in)
  *   ivl.find_sliced    1 (default): find() on large unsorted batches goes through the exchange (count_slices.hpp)
  *   ivl.find_flat      1 (default): sorted find() stages the candidate window and the hit stretch of a wave in LDS
- *   ivl.find_fused     1 (default): sorted find() counts, scans (decoupled look-back) and fills in one kernel
+ *   ivl.find_fused     1: sorted find() counts, scans (decoupled look-back) and fills in ONE kernel; 0 (default): in stages
+ *                      (the fused kernel measured slower: its registers leave half the workgroups per CU)
  *   ivl.fx_fill        1 (default): the exchange's fill half on LDS-staged (end, index) windows of sub-bucket pieces
  *   ivl.sl_f, ivl.sl_lanes, ivl.sl_flat, ivl.sl_rbits, ivl.sl_run_cap   geometry of the slice stage (tests, A/B tools)
  *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search

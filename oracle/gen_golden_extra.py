@@ -141,9 +141,85 @@ def quicksect_cases():
     return out
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--utils" not in sys.argv:
     doc = dict(generator="oracle/gen_golden_extra.py", builders=builder_cases(), quicksect=quicksect_cases())
     path = os.path.join(ROOT, "tests", "golden", "builders_quicksect.json")
     with open(path, "w") as f:
         json.dump(doc, f, separators=(",", ":"))
     print("wrote", path, os.path.getsize(path), "bytes")
+
+
+# --------------------------------------------------------------------------- #
+# bx.bitset_utils and bx.intervals.operations.concat (round 5): small callers of the hot-path API
+# --------------------------------------------------------------------------- #
+def gen_utils():
+    import io
+
+    import bx.bitset_utils as bu
+    from bx.intervals.io import GenomicIntervalReader
+    from bx.intervals.operations.concat import concat
+
+    assert PYREF in bu.__file__
+
+    def call(fn, *a):
+        try:
+            return dict(result=[list(x) for x in fn(*a)])
+        except Exception as e:
+            return dict(error=[type(e).__name__, str(e)])
+
+    def exons(rng, n, span, lmax, messy):
+        out = []
+        for _ in range(n):
+            s = int(rng.integers(0, span))
+            ln = int(rng.integers(0 if messy else 1, lmax))
+            out.append([s, s + ln])
+        if messy and n > 3:
+            out[2] = [out[2][1] + 5, out[2][1]]  # reversed: set_range gets a negative count
+        return out
+
+    cases = []
+    for k in range(24):
+        rng = np.random.default_rng(9100 + k)
+        messy = k % 6 == 5
+        a = exons(rng, int(rng.integers(1, 40)), 5000 if k % 2 else 3_000_000, 400, messy)
+        b = exons(rng, int(rng.integers(1, 40)), 5000 if k % 2 else 3_000_000, 400, False)
+        c = dict(a=a, b=b)
+        c["intersect"] = call(bu.bitset_intersect, a, b)
+        c["subtract"] = call(bu.bitset_subtract, a, b)
+        c["union"] = call(bu.bitset_union, a)
+        c["complement"] = call(bu.bitset_complement, b)
+        lo, hi = int(rng.integers(0, 3000)), int(rng.integers(3000, 6000))
+        c["window"] = [lo, hi]
+        try:
+            c["interval_intersect"] = dict(result=[list(x) for x in bu.bitset_interval_intersect(bu.list2bits(b), lo, hi)])
+        except Exception as e:
+            c["interval_intersect"] = dict(error=[type(e).__name__, str(e)])
+        cases.append(c)
+    cases.append(dict(a=[], b=[], intersect=call(bu.bitset_intersect, [], []), subtract=call(bu.bitset_subtract, [], []), union=call(bu.bitset_union, []),
+                      complement=call(bu.bitset_complement, []), window=[0, 10],
+                      interval_intersect=dict(result=[list(x) for x in bu.bitset_interval_intersect(bu.list2bits([]), 0, 10)])))
+    # concat: two inputs of different column orders, with comments, a header, long and short rows
+    f1 = "#header one\nchr1\t10\t20\tn1\t0\t+\nchr1\t30\t40\tn2\t0\t-\textra\n# a comment\nchr2\t5\t9\n"
+    f2 = "#header two\n+\tchr3\t100\t200\tx\ty\tz\tw\nchr4bad\n-\tchr3\t300\t400\n"
+    f3 = "#header two\n+\tchr3\t100\t200\tx\ty\tz\tw\n#mid\n-\tchr3\t300\t400\n.\tchr5\t1\t2\tq\n"
+    ccases = []
+    for second in (f2, f3):
+        for sameformat in (True, False):
+            for comments, header in ((True, True), (False, False), (True, False)):
+                r1 = GenomicIntervalReader(io.StringIO(f1), chrom_col=0, start_col=1, end_col=2, strand_col=5)
+                r2 = GenomicIntervalReader(io.StringIO(second), chrom_col=1, start_col=2, end_col=3, strand_col=0)
+                out, err = [], None
+                try:
+                    for x in concat([r1, r2], comments=comments, header=header, sameformat=sameformat):
+                        out.append(str(x))
+                except Exception as e:
+                    err = [type(e).__name__, str(e)]
+                ccases.append(dict(sameformat=sameformat, comments=comments, header=header, f1=f1, f2=second, result=out, error=err))
+    path = os.path.join(ROOT, "tests", "golden", "bitset_utils_concat.json")
+    with open(path, "w") as f:
+        json.dump(dict(source="bx.bitset_utils / bx.intervals.operations.concat of the reference (0.14.0)", utils=cases, concat=ccases), f, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path))
+
+
+if __name__ == "__main__" and "--utils" in sys.argv:
+    gen_utils()

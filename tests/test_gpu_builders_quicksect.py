@@ -107,3 +107,28 @@ def test_reference_module_names_resolve_to_the_engine():
     b = ["chr1\t40\t110\n"]
     out = [str(x) for x in intersect([gio.GenomicIntervalReader(iter(a)), gio.GenomicIntervalReader(iter(b))])]
     assert out == ["chr1\t40\t50", "chr1\t100\t110"]
+
+
+def test_bitset_utils_match_reference_vectors():
+    """bx.bitset_utils (lib/bx/bitset_utils.py:12-90) on the engine: interval lists through list2bits / bits2list, intersect,
+    subtract, union, complement (inside the list's own range only), bitset_interval_intersect (a run that starts before the
+    window's end is reported whole) -- results and failures as captured from the reference (oracle/gen_golden_extra.py --utils)."""
+    import bx.bitset_utils as bu
+
+    with open(os.path.join(os.path.dirname(GOLDEN), "bitset_utils_concat.json")) as f:
+        cases = json.load(f)["utils"]
+
+    def call(fn, *a):
+        try:
+            return dict(result=[list(x) for x in fn(*a)])
+        except Exception as e:
+            return dict(error=[type(e).__name__, str(e)])
+
+    for k, c in enumerate(cases):
+        a, b = [tuple(x) for x in c["a"]], [tuple(x) for x in c["b"]]
+        assert call(bu.bitset_intersect, a, b) == c["intersect"], (k, "intersect")
+        assert call(bu.bitset_subtract, a, b) == c["subtract"], (k, "subtract")
+        assert call(bu.bitset_union, a) == c["union"], (k, "union")
+        assert call(bu.bitset_complement, b) == c["complement"], (k, "complement")
+        lo, hi = c["window"]
+        assert call(lambda: bu.bitset_interval_intersect(bu.list2bits(b), lo, hi)) == c["interval_intersect"], (k, "interval_intersect")

@@ -50,6 +50,23 @@ def reset_opts():
         set_opt(k, v)
 
 
+def _erange_contract(ix, qs, qe, want_off):
+    """bxmi_ivl_find with a hit buffer that is too small: BXMI_ERANGE, the offsets and the total valid, the buffer untouched."""
+    import ctypes as C
+
+    from bxmi import _ffi
+
+    qs, qe = np.ascontiguousarray(qs, dtype=np.int32), np.ascontiguousarray(qe, dtype=np.int32)
+    cap = max(1, int(want_off[-1]) // 3)
+    offsets = np.full(len(qs) + 1, -7, dtype=np.int64)
+    hits = np.full(cap, -5, dtype=np.int32)
+    total = C.c_int64(0)
+    rc = _ffi.call("bxmi_ivl_find", ix._h, _ffi.ptr(qs), _ffi.ptr(qe), len(qs), _ffi.ptr(offsets), _ffi.ptr(hits), cap, C.byref(total), allow=(_ffi.ERANGE,))
+    assert rc == _ffi.ERANGE and total.value == int(want_off[-1])
+    assert np.array_equal(offsets, want_off), np.nonzero(offsets != want_off)[0][:8]
+    assert (hits == -5).all()
+
+
 def make_index(IntervalIndex, starts, ends):
     ix = IntervalIndex()
     ix.append(starts, ends)
@@ -653,6 +670,11 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
         set_opt("ivl.find_sliced", 1)
         off, hits = ix.find(qs, qe, cap_hint=max(1, int(want_off[-1]) // 2 - 1))
         assert np.array_equal(off, want_off) and np.array_equal(hits, want_hits), "after BXMI_ERANGE"
+        # ... and BXMI_ERANGE itself comes with the offsets and the total valid and the hit buffer untouched (include/bxmi.h)
+        for fx_fill in (1, 0):
+            set_opt("ivl.fx_fill", fx_fill)
+            _erange_contract(ix, qs, qe, want_off)
+        set_opt("ivl.fx_fill", 1)
     finally:
         reset_opts()
 
@@ -1369,6 +1391,10 @@ def test_find_on_sorted_batches_flat_fill(O, IntervalIndex):
         set_opt("ivl.find_flat", 1)
         got = ix.find(qs, qe, cap_hint=len(w_hits) // 3)
         assert np.array_equal(got[0], w_off) and np.array_equal(got[1], w_hits), "after BXMI_ERANGE"
+        for fused in (1, 0):
+            set_opt("ivl.find_fused", fused)
+            _erange_contract(ix, qs, qe, w_off)
+        set_opt("ivl.find_fused", 1)
         got = ix.find(qs, qe, cap_hint=len(w_hits))  # exactly enough
         assert np.array_equal(got[0], w_off) and np.array_equal(got[1], w_hits)
     finally:

@@ -159,8 +159,8 @@ def test_sharded_count_world_size_2_gloo(tmp_path):
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/lib/bx"), reason="reference tree not mounted (build container only)")
 def test_overlay_resolves_next_to_an_installed_bx_python():
-    """PYTHONPATH=bx-python_amd:<bx-python>/lib: the hot-path modules and their batch-aware callers are ours, everything
-    else (cookbook, the concat operation, sequence modules, ...) comes from bx-python."""
+    """PYTHONPATH=bx-python_amd:<bx-python>/lib: the hot-path modules and their batch-aware callers are ours (since round 5 also
+    the concat operation and bx.bitset_utils), everything else (cookbook, sequence modules, ...) comes from bx-python."""
     code = (
         "import bx, bx.bitset, bx.intervals, bx.intervals.intersection, bx.bitset_builders, bx.intervals.io, bx.cookbook.doc_optparse\n"
         "import bx.intervals.operations.concat, bx.intervals.operations.intersect, bx.tabular.io, bx.cookbook.attribute\n"
@@ -176,7 +176,8 @@ def test_overlay_resolves_next_to_an_installed_bx_python():
     assert out[0].endswith("bx-python_amd/bx/bitset.py") and out[1].endswith("bx-python_amd/bx/intervals/intersection.py")
     assert out[2].endswith("bx-python_amd/bx/bitset_builders.py") and out[3].endswith("bx-python_amd/bx/intervals/io.py")
     assert out[4] == "True True"
-    assert all(o.startswith("/root/reference/lib/bx/") for o in out[5:8]), out[5:8]
+    assert out[5].startswith("/root/reference/lib/bx/") and out[7].startswith("/root/reference/lib/bx/"), out[5:8]
+    assert out[6].endswith("bx-python_amd/bx/intervals/operations/concat.py"), out[6]
     assert out[8].endswith("bx-python_amd/bx/intervals/operations/intersect.py") and out[9].endswith("bx-python_amd/bx/tabular/io.py")
     assert out[10] == "True"
 

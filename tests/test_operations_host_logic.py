@@ -248,3 +248,54 @@ def test_small_builders_host_logic(monkeypatch):
         else:
             got = observe(lambda: builders.binned_bitsets_by_chrom(iter(a["lines"]), a["chrom"], **a["kw"]))
         assert got == case["want"], case["name"]
+
+
+def test_concat_matches_reference_vectors():
+    """bx.intervals.operations.concat (lib/bx/intervals/operations/concat.py:20-61) on this repo's readers: two inputs with
+    different column orders, comments, headers, over-long rows, a row that cannot be parsed -- every yielded row as text and the
+    escaping exception, as captured from the reference (oracle/gen_golden_extra.py --utils).  No engine involved."""
+    import io
+
+    from bx.intervals.io import GenomicIntervalReader
+    from bx.intervals.operations.concat import concat
+
+    with open(os.path.join(os.path.dirname(GOLDEN), "bitset_utils_concat.json")) as f:
+        cases = json.load(f)["concat"]
+    assert len(cases) == 12
+    for c in cases:
+        r1 = GenomicIntervalReader(io.StringIO(c["f1"]), chrom_col=0, start_col=1, end_col=2, strand_col=5)
+        r2 = GenomicIntervalReader(io.StringIO(c["f2"]), chrom_col=1, start_col=2, end_col=3, strand_col=0)
+        out, err = [], None
+        try:
+            for x in concat([r1, r2], comments=c["comments"], header=c["header"], sameformat=c["sameformat"]):
+                out.append(str(x))
+        except Exception as e:
+            err = [type(e).__name__, str(e)]
+        assert out == c["result"] and err == c["error"], (c["sameformat"], c["comments"], c["header"], out, c["result"], err, c["error"])
+
+
+def test_bitset_utils_host_logic(monkeypatch):
+    """bx.bitset_utils' walks (complement inside the list's range, runs reported whole by bitset_interval_intersect, the run
+    that reaches the end of the set) on the oracle bitset behind the drop-in's seam, against the reference's vectors; the same
+    comparison runs on the engine in tests/test_gpu_builders_quicksect.py."""
+    import bx.bitset_utils as bu
+
+    monkeypatch.setattr(bu, "BinnedBitSet", _OracleBits)
+    with open(os.path.join(os.path.dirname(GOLDEN), "bitset_utils_concat.json")) as f:
+        cases = json.load(f)["utils"]
+
+    def call(fn, *a):
+        try:
+            return dict(result=[list(x) for x in fn(*a)])
+        except Exception as e:
+            return dict(error=[type(e).__name__, str(e)])
+
+    assert len(cases) == 25
+    for k, c in enumerate(cases):
+        a, b = [tuple(x) for x in c["a"]], [tuple(x) for x in c["b"]]
+        assert call(bu.bitset_intersect, a, b) == c["intersect"], (k, "intersect")
+        assert call(bu.bitset_subtract, a, b) == c["subtract"], (k, "subtract")
+        assert call(bu.bitset_union, a) == c["union"], (k, "union")
+        assert call(bu.bitset_complement, b) == c["complement"], (k, "complement")
+        lo, hi = c["window"]
+        assert call(lambda: bu.bitset_interval_intersect(bu.list2bits(b), lo, hi)) == c["interval_intersect"], (k, "interval_intersect")

@@ -99,10 +99,15 @@ for r in range(rounds):
     sparse_served += ix.sparse_state()[0] == 1
     m = min(nq, 20000)
     w_off, w_hits = t.find_batch(qs[:m], qe[:m])
-    for part, sliced in ((0, 0), (1, 0), (1, 1), (1, 1)):  # direct kernels, the bucketed find, find through the exchange (twice, other knobs)
-        knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64])), sorted_path=int(rng.integers(0, 2)))
+    # direct kernels, the bucketed find, find through the exchange (round 2's fill, then twice the fill on LDS windows, other knobs);
+    # sorted batches take the staged kernels or the fused one
+    for part, sliced, fx in ((0, 0, 1), (1, 0, 1), (1, 1, 0), (1, 1, 1), (1, 1, 1)):
+        knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64])), sorted_path=int(rng.integers(0, 2)),
+                     fused=int(rng.integers(0, 2)), fx=fx)
         opt("ivl.partition", part)
         opt("ivl.find_sliced", sliced)
+        opt("ivl.fx_fill", fx)
+        opt("ivl.find_fused", knobs["fused"])
         opt("ivl.slice", -1)
         opt("ivl.bm_variant", knobs["variant"])
         opt("ivl.sl_f", knobs["f"])
@@ -113,7 +118,7 @@ for r in range(rounds):
             print("FIND MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, sliced=sliced, **knobs), ix.slice_state())
             sys.exit(1)
     for k, v in (("ivl.partition", -1), ("ivl.find_sliced", 1), ("ivl.bm_variant", -1), ("ivl.sl_f", -1), ("ivl.sl_lanes", 0),
-                 ("ivl.sorted_path", 1)):
+                 ("ivl.sorted_path", 1), ("ivl.fx_fill", 1), ("ivl.find_fused", 0)):
         opt(k, v)
     checked += 1
     ix.close()
