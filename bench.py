@@ -772,7 +772,7 @@ def main():
     # the caller wants the TOTAL only (counts = NULL; scripts/bed_count_overlapping.py consumes len(find()) only): the same pass, its
     # un-permute kernel sums without storing a count per query.  Reported beside the headline, never `value`.
     total_only = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_sorted:  # (a side leg like `sorted_queries`: tools/profile.sh leaves both out)
         tt = torch.zeros(8, dtype=torch.int64, device="cuda")
         ix.count_dev(qs.data_ptr(), qe.data_ptr(), nq, None, tt[0:].data_ptr(), stream)
         torch.cuda.synchronize()

@@ -13,6 +13,9 @@ timeout 1500 python -m pytest tests/test_gpu_bitset.py -m gpu -q --timeout 900 -
 if [ -f tests/test_gpu_cli.py ]; then
 timeout 900 python -m pytest tests/test_gpu_cli.py -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/test_cli.log 2>&1; echo "cli rc=$?" >> gpurun_out/smoke.log
 fi
+if [ -f tests/test_gpu_builders_quicksect.py ]; then
+timeout 600 python -m pytest tests/test_gpu_builders_quicksect.py -m gpu -q --timeout 500 -p no:cacheprovider > gpurun_out/test_builders.log 2>&1; echo "builders rc=$?" >> gpurun_out/smoke.log
+fi
 if [ -f tests/test_gpu_operations.py ]; then
 timeout 900 python -m pytest tests/test_gpu_operations.py -m gpu -q --timeout 600 -p no:cacheprovider > gpurun_out/test_operations.log 2>&1; echo "operations rc=$?" >> gpurun_out/smoke.log
 fi
