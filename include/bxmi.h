@@ -125,7 +125,10 @@ int bxmi_ivl_order_dev(const bxmi_ivl_t *h, const int32_t **idx_dev, const int32
  * including zero-length, reversed and negative ones.
  *                                                  intersection.pyx:169-189,400-406 */
 int bxmi_ivl_count(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total);
-/* Device variant: *total_dev (device int64) is ACCUMULATED into (zero it first). */
+/* Device variant: *total_dev (device int64) is ACCUMULATED into (zero it first).  counts = NULL: the total only -- nothing is
+ * stored per query.  Stream-ordered, with ONE exception: a handle's FIRST large batch (>= ivl.bitmap_min queries) builds the
+ * index's unit images and answers the order probe synchronously -- it waits for `stream` once (and cannot be captured into a
+ * hipGraph); every later call only enqueues. */
 int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts,
                        int64_t *total_dev, void *stream);
 /* A dict of per-chromosome trees queried in one go (scripts/interval_join.py:21-28 keeps {chrom: Intersecter}; a genome-wide
@@ -170,7 +173,8 @@ int bxmi_ivl_order_state(const bxmi_ivl_t *h, int *skipping, int64_t *answers_se
 /* IntervalTree.find for a batch, as CSR: offsets[nq+1] (int64) and, for query
  * i, hits[offsets[i]..offsets[i+1]) = insertion indices in the reference's
  * result order.  If the hit list needs more than `cap` entries the call
- * returns BXMI_ERANGE with offsets and *total valid and hits untouched. */
+ * returns BXMI_ERANGE with offsets and *total valid and hits untouched (bxmi_ivl_find_dev with ivl.find_fused = 1: the
+ * part of the list that fits may already have been written to the device buffer). */
 int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,
                   int32_t *hits, int64_t cap, int64_t *total);
 int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Stage-by-stage check of find() through the exchange (debug build with bxmi_debug_peek)."""
+"""Stage-by-stage check of find() through the exchange against the oracle: counts, query-order and tile-sorted scratch offsets, `hc`,
+the half-bucket run table and every record's hits in the scratch list, read back through bxmi_debug_peek -- a symbol only DEBUG builds
+export: tools/build_variant.sh peek "-DBXMI_DEBUG_PEEK=1", then copy build_variants/libbxmi_peek.so over bx-python_amd/bxmi/libbxmi.so
+for the run.  (How round 5 found the shuffle that ran inside a divergent select: DESIGN.md 3.2.)"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "bx-python_amd"))
