@@ -1799,6 +1799,47 @@ __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned sh
     __syncthreads();
     long long acc = 0;
     unsigned wide = 0;  // W8: counts of this thread that came back as "ask again"
+    if (PAD && W8 && !sg.counts) {
+        // TOTAL ONLY (the caller passed no counts array): the tile's total is the sum of its count bytes -- no slot is needed -- unless
+        // a REAL query's count came back as "ask again".  The tile sort's padding comes back as 0xFF too, but how many pad slots
+        // the tile has is known (tend - n): if exactly that many bytes are 0xFF, none belongs to a query and the 0.2 GB of slots
+        // stay unread; otherwise the tile takes the ordinary path below.
+        const int n8 = ((int)tend[tile] + 15) >> 4;
+        unsigned sum = 0, nff = 0;
+        for (int i = threadIdx.x; i < n8; i += THREADS) {
+            const int4 v = reinterpret_cast<const int4 *>(vals)[i];
+            const unsigned w[4] = {(unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // bytes beyond the tile's used slots (the last vector's tail) are whatever the search left there: mask them out
+                const int first = 16 * i + 4 * k, used = (int)tend[tile] - first;
+                const unsigned keep = used >= 4 ? 0xFFFFFFFFu : (used <= 0 ? 0u : (1u << (8 * used)) - 1u);
+                const unsigned x = w[k] & keep;
+                const unsigned ff = ((x & 0x7F7F7F7Fu) + 0x01010101u) & x & 0x80808080u;  // bit 7 of every byte that is 0xFF
+                const unsigned c = (unsigned)__popc(ff);
+                nff += c;
+                sum += __builtin_amdgcn_sad_u8(x, 0u, 0u) - 255u * c;
+            }
+        }
+        __shared__ unsigned s_tot[2];
+        if (threadIdx.x < 2) s_tot[threadIdx.x] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum += (unsigned)__shfl_down((int)sum, off, 64);
+            nff += (unsigned)__shfl_down((int)nff, off, 64);
+        }
+        if (lane_id() == 0) {
+            atomicAdd(&s_tot[0], sum);
+            atomicAdd(&s_tot[1], nff);
+        }
+        __syncthreads();
+        if (s_tot[1] == tend[tile] - (unsigned)n) {  // (block-uniform) every 0xFF is padding
+            if (total_slots && threadIdx.x == 0 && s_tot[0])
+                atomicAdd(total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)), (unsigned long long)s_tot[0]);
+            return;
+        }
+    }
     if (n == TILE) {
         const uint2 *l4 = reinterpret_cast<const uint2 *>(slots);
         int4 *o4 = reinterpret_cast<int4 *>(out);

@@ -30,7 +30,13 @@ constexpr int FX_NBK = 2 * BM_NB;     // half buckets
 constexpr int FX_CAPW = 15360;        // (end, index) pairs of one piece's window in LDS (120 KB)
 constexpr int FX_BACK = 512;          // pairs staged below the lowest `hi` of a piece: the walk of an ordinary record ends inside
 constexpr int FX_HCAP = 512;          // hits a wave collects in LDS per pass of 64 records (mean 320 on configs[4])
-constexpr int FX_BT = 32;            // tiles of a wave's batch (one run per lane; 64 left 16 waves with 24 batches on configs[4])
+#ifndef FX_BT_V
+#define FX_BT_V 32
+#endif
+#ifndef FX_FL_V
+#define FX_FL_V 6
+#endif
+constexpr int FX_BT = FX_BT_V;       // tiles of a wave's batch (one run per lane; 64 left 16 waves with 24 batches on configs[4])
 constexpr int FX_THREADS = 1024;
 constexpr int FX_NW = FX_THREADS / 64;
 constexpr size_t FX_LDS_BYTES = (size_t)FX_CAPW * 8 + (size_t)FX_NW * (FX_HCAP * 4 + 64 * 4);
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(BM_PART_Q) void fx_hits_copy_kernel(const BmSeg *__
     ends[lane] = incl;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    constexpr int FL = 6;  // passes whose loads are in flight together (a wave's stretch is ~320 hits on configs[4]: one round)
+    constexpr int FL = FX_FL_V;  // passes whose loads are in flight together (a wave's stretch is ~320 hits on configs[4]: one round)
     for (unsigned s0 = 0; s0 < wtotal; s0 += 64u * FL) {
         unsigned dst[FL];
         bool act[FL];

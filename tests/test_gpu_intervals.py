@@ -995,6 +995,67 @@ def test_order_check_is_dropped_and_comes_back(O, IntervalIndex, stage):
         reset_opts()
 
 
+def test_total_only_batches(O, IntervalIndex):
+    """bxmi_ivl_count_dev / _multi_dev with counts = NULL (scripts/bed_count_overlapping.py consumes len(find()) only; configs[3]'s
+    "all-reduce on counts"): the same pass, nothing stored per query.  On 8-bit counts the un-permute kernel sums a tile's count
+    bytes without reading a slot when every 0xFF byte is the tile sort's padding, and takes the ordinary path for a tile where a
+    real query came back as "ask again" -- escapes (reversed, over-long, off-grid queries) and counts of 255 and more.  Totals
+    against the oracle on every search stage that serves the index, shuffled and sorted."""
+    from bxmi import _ffi
+
+    rng = np.random.default_rng(77)
+    span = 30_000_000
+    s = np.concatenate([rng.integers(1000, span, size=400_000), rng.integers(5_000_000, 5_400_000, size=150_000)])
+    e = s + rng.integers(1, 300, size=len(s))
+    s, e = s.astype(np.int32), e.astype(np.int32)
+    ix = make_index(IntervalIndex, s, e)
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    nq = 32768 * 66 + 77
+    batches = {}
+    qs = rng.integers(6_000_000, span, size=nq)
+    batches["plain"] = (qs, qs + rng.integers(1, 800, size=nq))            # no tile holds an escape: sums of bytes only
+    qe = qs + rng.integers(1, 800, size=nq)
+    k = np.arange(0, nq, 40_000)                                          # an escape in every other tile or so
+    qe = qe.copy()
+    qe[k[0::3]] = qs[k[0::3]] - 4
+    qe[k[1::3]] = qs[k[1::3]] + 50_000
+    qs2 = qs.copy()
+    qs2[k[2::3]] = -5000
+    qe[k[2::3]] = -4000
+    batches["escapes"] = (qs2, qe)
+    qs = rng.integers(5_000_000, 5_400_000, size=nq)                       # the crowd: counts of 255 and more in every tile
+    batches["crowd"] = (qs, qs + rng.integers(900, 1200, size=nq))
+    total = _ffi.DeviceArray(8)
+    set_opt("ivl.partition", 1)
+    try:
+        for stage in (("ivl.flat", 1), ("ivl.dense", 1), ("ivl.slice", 1)):
+            reset_opts()
+            set_opt("ivl.partition", 1)
+            set_opt("ivl.bm_hard_ppm", 10**6)
+            set_opt(stage[0], stage[1])
+            if stage[0] != "ivl.flat":
+                set_opt("ivl.flat", 0)
+            if stage[0] == "ivl.slice":
+                set_opt("ivl.dense", 0)
+            for name, (a, b) in batches.items():
+                for order in ("shuffled", "sorted"):
+                    if order == "sorted":
+                        o = np.argsort(a, kind="stable")
+                        a, b = a[o], b[o]
+                    a32, b32 = a.astype(np.int32), b.astype(np.int32)
+                    want = t.count_batch(a32, b32)[1]
+                    dq, de = _ffi.DeviceArray.from_numpy(a32), _ffi.DeviceArray.from_numpy(b32)
+                    for rep in range(2):  # (the second pass of the crowd may already run on 16-bit counts)
+                        total.zero()
+                        ix.count_dev(dq.ptr, de.ptr, nq, None, total.ptr, None)
+                        _ffi.call("bxmi_synchronize", None)
+                        got = int(total.to_numpy(np.int64, 1)[0])
+                        assert got == want, (stage, name, order, rep, got, want)
+    finally:
+        reset_opts()
+
+
 def test_count_width_feedback(O, IntervalIndex):
     """8-bit counts between the search and the un-permute kernel of the flat walk.  The index is sparse as a whole (the host
     starts with 8 bits) but 150 000 of its targets crowd into 400 000 coordinates; queries elsewhere have small counts,
