@@ -380,6 +380,9 @@ __global__ __launch_bounds__(BM_PART_Q) void fx_hits_copy_kernel(const BmSeg *__
     ends[lane] = incl;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // (measured on configs[4], round 5: 4 / 6 / 8 passes in flight 3.20 / 3.18 / 3.21 ms for the whole find; the position -> query look-up
+    // by scattered marks and a DPP running sum instead of the six-step search over the 64 ends: no difference, 3.18 -- the kernel
+    // waits for its gathers of ~20-byte runs, not for the look-up; batches of 16 / 32 / 64 tiles in the fill: 3.28 / 3.18 / 3.31)
     constexpr int FL = FX_FL_V;  // passes whose loads are in flight together (a wave's stretch is ~320 hits on configs[4]: one round)
     for (unsigned s0 = 0; s0 < wtotal; s0 += 64u * FL) {
         unsigned dst[FL];
