@@ -637,6 +637,10 @@ __device__ __forceinline__ int bm_escape_count(const IndexDev &ix, const int32_t
 // copy streams it instead of gathering it through the slot), and the sums of the counts of every BM_PART_Q consecutive
 // queries (`parts`) and of the tile (`tile_tot`): the CSR offsets are then one scan over the TILES away -- the copy kernel
 // finishes them inside each part -- instead of a three-kernel scan over all queries.
+// FIND = 3 (find_exchange.hpp, the fill straight into the CSR list): loff[tile-sorted position] and svq[query] are instead the
+// exclusive prefix of the counts in QUERY order inside the tile -- tile base + that = the query's CSR offset, so the fill
+// writes every record's hits where they belong and no copy follows.  Escape queries take part in the prefix (their hits are
+// written by fx_offsets_kernel); bit 31 marks them as before.
 constexpr int BM_PART_Q = 1024;
 template <int THREADS, int ITEMS, int FIND = 0>
 __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *__restrict__ cnt /* tile-sorted: the records array after the search */,
@@ -650,13 +654,13 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int PARTS = TILE / BM_PART_Q;
-    static_assert(FIND != 2 || (THREADS == 1024 && TILE % BM_PART_Q == 0), "parts of 1024 queries = 256 threads' four-query groups");
+    static_assert(FIND < 2 || (THREADS == 1024 && TILE % BM_PART_Q == 0), "parts of 1024 queries = 256 threads' four-query groups");
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     if (gate && *gate == 0) return;
     unsigned *vals = reinterpret_cast<unsigned *>(dyn);  // [TILE]
     __shared__ long long red[THREADS / 64];
-    __shared__ unsigned long long s_part[FIND == 2 ? PARTS : 1];
-    if (FIND == 2 && threadIdx.x < PARTS) s_part[threadIdx.x] = 0ull;
+    __shared__ unsigned long long s_part[FIND >= 2 ? PARTS : 1];
+    if (FIND >= 2 && threadIdx.x < PARTS) s_part[threadIdx.x] = 0ull;
     const int64_t tile = blockIdx.x;
     const int seg_id = tile_seg[tile];
     const BmSeg &sg = segs[seg_id];
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
             }
             if (sg.counts) o4[j * THREADS + threadIdx.x] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);  // (NULL: the caller wants the total only)
             acc += (long long)c[0] + c[1] + c[2] + c[3];
-            if (FIND == 2) {  // the four queries 4 (j THREADS + t) ..: part 4 j + t / 256 -- one part per wave and j
+            if (FIND >= 2) {  // the four queries 4 (j THREADS + t) ..: part 4 j + t / 256 -- one part per wave and j
                 unsigned long long ws = (unsigned long long)c[0] + c[1] + c[2] + c[3];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) ws += __shfl_down(ws, off, 64);
@@ -716,11 +720,40 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
             if (c == BM_REC_ESC) c = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[base + k], qe_arr[base + k]);
             if (sg.counts) out[base + k] = (int)c;
             acc += c;
-            if (FIND == 2 && c) atomicAdd(&s_part[k / BM_PART_Q], (unsigned long long)c);
+            if (FIND >= 2 && c) atomicAdd(&s_part[k / BM_PART_Q], (unsigned long long)c);
         }
     }
     constexpr int NW = THREADS / 64, PER_WAVE = TILE / NW, CH = FIND ? PER_WAVE / 64 : 1;
-    if (FIND) {
+    if (FIND == 3) {
+        static_assert(FIND != 3 || PER_WAVE % BM_PART_Q == 0, "a wave's share of the tile is whole parts");
+        __syncthreads();  // every count picked (LDS still holds the tile-sorted counts), every part sum complete, `out` written
+        const int w = threadIdx.x >> 6, lane = lane_id();
+        unsigned carry = 0;  // the hits of the queries before this wave's share
+        for (int i = 0; i < w * (PER_WAVE / BM_PART_Q); i++) carry += (unsigned)s_part[i];
+        unsigned *sv_out = svq + tile * TILE;
+        for (int c = 0; c < PER_WAVE / 64; c++) {
+            const int idx = w * PER_WAVE + c * 64 + lane;
+            unsigned x = 0u, slot = 0u;
+            if (idx < n) x = (unsigned)out[base + idx], slot = slots[base + idx];  // (the counts this workgroup has just stored: escapes recomputed)
+            const unsigned inc = wave_inclusive_scan(x, OpSum());
+            if (idx < n) {
+                const unsigned v = (carry + inc - x) | (vals[slot] == BM_REC_ESC ? 0x80000000u : 0u);
+                sv_out[idx] = v;
+                vals[slot] = v;  // (the slot is this query's alone)
+            }
+            carry += (unsigned)__shfl((int)inc, 63, 64);
+        }
+        __syncthreads();
+        if (threadIdx.x < PARTS) parts[tile * PARTS + threadIdx.x] = s_part[threadIdx.x];
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int i = 0; i < PARTS; i++) t += s_part[i];
+            tile_tot[tile] = t;
+        }
+        int4 *lo4 = reinterpret_cast<int4 *>(loff + tile * TILE);
+        const int n4 = (n + 3) >> 2;  // (the scratch is padded to whole tiles)
+        for (int i = threadIdx.x; i < n4; i += THREADS) lo4[i] = reinterpret_cast<const int4 *>(vals)[i];
+    } else if (FIND) {
         // (after the counts were picked: the offsets take their place in LDS below, and `e` is not live across the loop above)
         __syncthreads();
         // every wave scans its contiguous share of the tile, 64 positions at a time

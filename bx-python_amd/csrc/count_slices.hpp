@@ -232,6 +232,51 @@ __device__ __forceinline__ unsigned sl_count_record_hc(const SlUnit &U, const Bm
     return c;
 }
 
+// N records of a lane at once for find(): their 2 N ranks advance in step (sl_count_slot's shape) -- one after the other they are
+// 2 N chains of 2 + steps dependent LDS reads, and with one workgroup per CU (configs[4]: 120 KB of keys) nothing else hides them.
+// Same answers as sl_count_record_hc record by record.
+#ifndef SL_HC_JOINT
+#define SL_HC_JOINT 1  // 0: record by record (round 5's first version; A/B: see DESIGN.md 3.2)
+#endif
+template <int N>
+__device__ __forceinline__ void sl_count_records_hc(const SlUnit &U, const BmGeom &g, const unsigned (&rec)[N], unsigned (&c)[N], unsigned (&hc)[N])
+{
+    const unsigned omask = (1u << g.rshift) - 1u, dmask = (1u << g.dshift) - 1u, esc_len = bm_len_esc(g);
+    constexpr int K = 2 * N;
+    unsigned lo[K], hi[K], xl[K];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const unsigned len = rec[j] >> g.rshift, off = rec[j] & omask;
+        const bool esc = len == esc_len;
+        const unsigned xe = esc ? 0u : off + 1u, xs = esc ? 0u : off + len;  // (an escape record's look-ups stay inside the unit)
+        const unsigned ce = xe >> g.dshift, cs = xs >> g.dshift;
+        xl[2 * j] = xe & dmask, xl[2 * j + 1] = xs & dmask;
+        lo[2 * j] = U.dirE[ce], hi[2 * j] = U.dirE[ce + 1];
+        lo[2 * j + 1] = U.dirS[cs], hi[2 * j + 1] = U.dirS[cs + 1];
+    }
+    for (int i = 0; i < U.steps; i++) {
+        unsigned mid[K], key[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            mid[k] = (lo[k] + hi[k]) >> 1;
+            key[k] = (k & 1) ? (unsigned)U.lowS[mid[k]] : (unsigned)U.lowE[mid[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool go = lo[k] < hi[k] && key[k] < xl[k];
+            lo[k] = go ? mid[k] + 1 : lo[k];
+            hi[k] = go ? hi[k] : mid[k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        const bool esc = (rec[j] >> g.rshift) == esc_len;
+        const unsigned x = (unsigned)((U.sLo - U.eLo) + ((int)lo[2 * j + 1] - (int)lo[2 * j]));
+        c[j] = esc ? BM_REC_ESC : x;
+        hc[j] = esc ? 0u : ((x < 0xFFFFu ? x : 0xFFFFu) | (lo[2 * j + 1] << 16));
+    }
+}
+
 // The four records of a 16-byte slot at once (the flat walk of count_dense.hpp): the eight ranks advance in step -- their
 // directory reads, then every halving's eight key reads, are in flight together -- instead of one rank after the other,
 // each a chain of 2 + steps dependent LDS reads (round 4: the slice search of a genome share spent its time waiting for
@@ -243,7 +288,7 @@ __device__ __forceinline__ unsigned sl_count_record_hc(const SlUnit &U, const Bm
 #ifndef SL_SLOT_RECS
 #define SL_SLOT_RECS 2  // records of a slot whose ranks advance together (4: 73 registers in the flat walk -- one workgroup per CU: genome pass 1.18 ms; 2: 0.96; 1: 0.96; one rank after the other: 1.04)
 #endif
-__device__ __forceinline__ void sl_count_slot(const SlUnit &U, const BmGeom &g, const unsigned (&rec)[4], unsigned (&c)[4])
+__device__ __forceinline__ void sl_count_slot(const SlUnit &U, const BmGeom &g, const unsigned (&rec)[4], unsigned (&c)[4], unsigned *hc = nullptr /* [4]: find()'s packed word, see sl_count_record_hc */)
 {
     const unsigned omask = (1u << g.rshift) - 1u, dmask = (1u << g.dshift) - 1u, esc_len = bm_len_esc(g);
     constexpr int R = SL_SLOT_RECS, K = 2 * R;
@@ -277,7 +322,9 @@ __device__ __forceinline__ void sl_count_slot(const SlUnit &U, const BmGeom &g, 
 #pragma unroll
         for (int j = 0; j < R; j++) {
             const unsigned x = (unsigned)((U.sLo - U.eLo) + ((int)lo[2 * j + 1] - (int)lo[2 * j]));
-            c[j0 + j] = (rec[j0 + j] >> g.rshift) == esc_len ? BM_REC_ESC : x;
+            const bool esc = (rec[j0 + j] >> g.rshift) == esc_len;
+            c[j0 + j] = esc ? BM_REC_ESC : x;
+            if (hc) hc[j0 + j] = esc ? 0u : ((x < 0xFFFFu ? x : 0xFFFFu) | (lo[2 * j + 1] << 16));
         }
     }
 }
@@ -291,7 +338,7 @@ __device__ __forceinline__ void sl_count_slot(const SlUnit &U, const BmGeom &g, 
 // (8 waves per SIMD = at most 64 VGPRs: two workgroups per CU when the unit's keys leave room, so that one stages its
 // unit while the other searches -- sparse indexes have small units and many work items)
 template <int L, int U, bool APART>
-__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void sl_search_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
+__global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(APART ? 4 : 8, APART ? 4 : 8))) void sl_search_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                     const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
                                                                     unsigned *__restrict__ recs, unsigned *__restrict__ out_apart, int tile_log2,
                                                                     const unsigned *__restrict__ gate, unsigned *__restrict__ hc_out = nullptr /* APART: see sl_count_record_hc */)
@@ -338,6 +385,9 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const SlUnit UN = sl_stage_unit(sg, unit, dyn, s_tmp);
     if (threadIdx.x == 0) s_nlong = 0;
     __syncthreads();
+#if defined(SL_EXP) && (SL_EXP & 1)  // diagnostics (wrong results): staging only
+    if (UN.steps < 100) return;
+#endif
     auto answer = [&](unsigned at, unsigned rec) {
         if (APART && hc_out) {
             unsigned hc;
@@ -383,10 +433,30 @@ __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         R.lf_rec = recs[(size_t)(lf_at != ~0u ? lf_at : 0u)];
     };
     auto finish = [&](BmRound<U> &R) {
+        if (SL_HC_JOINT && APART && hc_out) {  // find(): the round's records of a lane together (every lane holds valid records: prep)
+            unsigned rr[U + 1], cc[U + 1], hh[U + 1];
+#pragma unroll
+            for (int u = 0; u < U; u++) rr[u] = R.rec[u];
+            rr[U] = R.lf_rec;
+#if defined(SL_EXP) && (SL_EXP & 2)  // diagnostics (wrong results): no look-ups
+#pragma unroll
+            for (int u = 0; u <= U; u++) cc[u] = rr[u] & 0xffu, hh[u] = rr[u] >> 8;
+#else
+            sl_count_records_hc<U + 1>(UN, g, rr, cc, hh);
+#endif
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if ((unsigned)sub < R.lens[u]) {
+                    const size_t at = (size_t)R.first[u] + (unsigned)sub;
+                    out[at] = cc[u], hc_out[at] = hh[u];
+                }
+            if (R.lf_at != ~0u) out[(size_t)R.lf_at] = cc[U], hc_out[(size_t)R.lf_at] = hh[U];
+        } else {
 #pragma unroll
         for (int u = 0; u < U; u++)
             if ((unsigned)sub < R.lens[u]) answer(R.first[u] + (unsigned)sub, R.rec[u]);
         if (R.lf_at != ~0u) answer(R.lf_at, R.lf_rec);
+        }
         for (unsigned base = L; __any(base < R.lf_total); base += L) {  // further leftover passes
             const unsigned i = base + (unsigned)sub;
             unsigned cum = 0, at = ~0u;

@@ -412,4 +412,42 @@ __global__ __launch_bounds__(BM_PART_Q) void fx_hits_copy_kernel(const BmSeg *__
     }
 }
 
+// The fill straight into the CSR list (bm_unpermute_kernel<.., FIND = 3>): what is left of the copy -- the int64 offsets
+// (tile base + the query-order prefix inside the tile) and the hits of escape queries, from the sealed index by their own lanes.
+// The escapes' hits are only written when the whole list fits the caller's buffer (tile_base[ntiles] = all hits): BXMI_ERANGE
+// leaves the buffer alone.
+__global__ __launch_bounds__(256) void fx_offsets_kernel(const BmSeg *__restrict__ segs, const unsigned *__restrict__ svq, const long long *__restrict__ tile_base,
+                                                         int64_t ntiles, int tile_log2, long long *__restrict__ offsets, int32_t *__restrict__ hits, int64_t cap)
+{
+    const BmSeg &sg = segs[0];
+    const int64_t nq = sg.nq;
+    const int64_t q0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q0 >= nq) return;
+    const bm_v4i v4 = __builtin_nontemporal_load(reinterpret_cast<const bm_v4i *>(svq + q0));  // (padded to whole tiles)
+    const long long tb = tile_base[q0 >> tile_log2];
+    const unsigned v[4] = {(unsigned)v4.x, (unsigned)v4.y, (unsigned)v4.z, (unsigned)v4.w};
+    long long o[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) o[u] = tb + (long long)(v[u] & 0x7FFFFFFFu);
+    if (q0 + 4 <= nq) {
+        typedef long long fx_v2ll __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(fx_v2ll{o[0], o[1]}, reinterpret_cast<fx_v2ll *>(offsets + q0));
+        __builtin_nontemporal_store(fx_v2ll{o[2], o[3]}, reinterpret_cast<fx_v2ll *>(offsets + q0 + 2));
+    } else {
+        for (int u = 0; u < 4 && q0 + u < nq; u++) offsets[q0 + u] = o[u];
+    }
+    if (((v[0] | v[1] | v[2] | v[3]) >> 31) && hits && tile_base[ntiles] <= cap) {  // escape records: rare
+        const IndexDev ix = sg.ix;
+        for (int u = 0; u < 4 && q0 + u < nq; u++) {
+            if (!(v[u] >> 31)) continue;
+            int cc = sg.counts[q0 + u];
+            if (cc <= 0) continue;
+            const int qs = sg.qs[q0 + u], qe = sg.qe[q0 + u];
+            int32_t *__restrict__ dst = hits + o[u];
+            for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; cc > 0 && j >= 0; j--)
+                if (ix.e_ord[j] > qs) dst[--cc] = ix.idx[j];
+        }
+    }
+}
+
 }  // namespace bxmi

@@ -2461,6 +2461,9 @@ static int64_t g_opt_bm_variant = -1;  // tile kernel shape: -1 = by batch size,
 static int64_t g_opt_find_fused = 0;   // find() on a sorted batch: 1 = count, offsets (decoupled look-back) and fill in one kernel (ivl_local_find_kernel: measured 2.65 ms
                                        // against 1.58 for the stages -- the count half is a long chain of dependent loads that lives on four workgroups per CU, the
                                        // fused kernel's registers leave two), 0 = the stages (default)
+static int64_t g_opt_fx_flat = 0;      // find() through the exchange: 1 = the count half as the flat walk on key slices (measured on configs[4]: 531 us against 474 for the lane groups per run, the default)
+static int64_t g_opt_fx_direct = -1;   // find() through the exchange: 1 = the fill writes straight into the CSR list (query-order prefixes from the un-permute
+                                       // kernel, no copy), 0 = scratch + copy, -1 = by the size of the list the handle expects (see ivl_find_fx)
 static int64_t g_opt_fx_fill = 1;      // find() through the exchange: 1 = the fill half on LDS windows of half-bucket pieces (find_exchange.hpp), 0 = round 2's fill and copy
 static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
@@ -2512,6 +2515,8 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.find_sliced", &g_opt_find_sliced, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.fx_fill", &g_opt_fx_fill, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.find_fused", &g_opt_find_fused, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.fx_flat", &g_opt_fx_flat, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.fx_direct", &g_opt_fx_direct, [](int64_t value) -> int64_t { return value < 0 ? -1 : value != 0; }},
     {"ivl.slice", &g_opt_slice, nullptr},
     {"ivl.sl_f", &g_opt_sl_f, [](int64_t value) -> int64_t { return value > SL_MAX_F ? SL_MAX_F : value; }},
     {"ivl.bm_chunk", &g_opt_bm_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
@@ -2597,6 +2602,7 @@ struct bxmi_ivl {
     std::vector<int2> fx_meta2_host;   // the ranks at the half-bucket boundaries (read back once per sealed index)
     std::vector<FxPiece> fx_pieces_host;
     int fx_pieces_f = -1;        // the unit size (2^f buckets) the piece list was cut for
+    double fx_hits_per_q = -1.0; // hits per query of the handle's latest find() through the exchange (predicts the next list's size), < 0 = none yet
     DevBuf lf_state;             // sorted find() in one kernel: the chunks' look-back words and the ticket
     DevBuf fx_meta2, fx_pieces, fx_tbl2, fx_runT2, fx_hc, fx_svq, fx_parts, fx_tile_tot, fx_tile_base, fx_work;
     // dense unit images (count_dense.hpp)
@@ -3145,12 +3151,17 @@ static int bm_launch_tiles(const BmLaunch &L, hipStream_t st, bool sub = false)
 
 template <int THREADS, int ITEMS>
 static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st, const unsigned *cnt = nullptr, unsigned *loff = nullptr,
-                               bool fx = false)
+                               int fx = 0 /* 0, or FIND = 2 / 3 */)
 {
     bxmi_ivl *h = L.owner;
     const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);
     if (!cnt) cnt = h->bm_recs.as<unsigned>();
-    if (loff && fx) {
+    if (loff && fx == 3) {
+        BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS, 3>), lds));
+        hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS, 3>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, loff, h->fx_svq.as<unsigned>(),
+                           h->fx_parts.as<unsigned long long>(), h->fx_tile_tot.as<unsigned long long>());
+    } else if (loff && fx) {
         BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS, 2>), lds));
         hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS, 2>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
                            h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, loff, h->fx_svq.as<unsigned>(),
@@ -3171,13 +3182,20 @@ static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hip
 // The bitmap-cell pass over a batch of n segments (n sealed, qualifying indexes with their queries): [order check ->]
 // tile sort -> run table + plan -> search -> un-permute -> totals, all on `st`, six launches whatever n is.
 // counts[i] may be NULL (total only: nothing is stored per query); totals_dev[i] may be.  The scratch of hs[0] serves the whole batch.
+#ifndef FX_FLAT_DEPTH
+#define FX_FLAT_DEPTH 2
+#define FX_FLAT_PIPE false
+#endif
+#ifndef SL_FIND_U
+#define SL_FIND_U 2  // runs per lane group and round of find()'s count half
+#endif
 template <int LANES>
 static int sl_launch_search(const BmLaunch &L, unsigned grid, hipStream_t st, unsigned *out, unsigned *hc = nullptr)
 {
     bxmi_ivl *h = L.owner;
     if (out != h->bm_recs.as<unsigned>()) {
-        BXMI_TRY(allow_big_lds((sl_search_pipe_kernel<LANES, 2, true>), L.search_lds));
-        hipLaunchKernelGGL((sl_search_pipe_kernel<LANES, 2, true>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+        BXMI_TRY(allow_big_lds((sl_search_pipe_kernel<LANES, SL_FIND_U, true>), L.search_lds));
+        hipLaunchKernelGGL((sl_search_pipe_kernel<LANES, SL_FIND_U, true>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
                            h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), out, L.tile_log2, L.gate, hc);
     } else {
         BXMI_TRY(allow_big_lds((sl_search_pipe_kernel<LANES, 2, false>), L.search_lds));
@@ -3230,6 +3248,7 @@ struct BmFindCtx {
     int lanes;       // 16 or 64
     int variant;     // tile shape
     bool sub = false;  // in: the tile sort orders by half buckets and everything find_exchange.hpp needs is left behind
+    bool direct = false;  // in (with sub): the offsets the un-permute kernel leaves are query-order prefixes (FIND = 3)
     int f = 0;         // out: the unit size the slice geometry picked (2^f buckets)
     int64_t ntiles = 0;
 };
@@ -3335,7 +3354,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (kind < 2 || kind > 5) return fail(BXMI_EINVAL, "bm_count_segments: no such search stage (%d)", kind);
     const bool wide = kind == 5;  // offset cells: the cell images of sparse indexes
     const bool slices = kind == 2, cells = kind == 4 || wide;
-    const bool slices_flat = slices && !fx && g_opt_sl_flat != 0;  // (find() needs 32-bit counts apart from the records and the tile-sorted offsets)
+    const bool fxsub = fx && fx->sub;
+    // (find() needs 32-bit counts apart from the records and the tile-sorted offsets: the flat walk has that form for find_exchange.hpp only)
+    const bool slices_flat = slices && ((!fx && g_opt_sl_flat != 0) || (fxsub && g_opt_fx_flat != 0));
     const bool dense = kind == 3 || cells || slices_flat /* the flat walk */;
     bxmi_ivl *h = hs[0];
     int64_t nq_all = 0;
@@ -3352,7 +3373,6 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (cells && variant == 0)
         for (int i = 0; i < n; i++)
             if ((wide ? hs[i]->bo_geom : hs[i]->bp_geom).f < 2) variant = 1;
-    const bool fxsub = fx && fx->sub;
     if (fxsub && (n != 1 || !slices)) return fail(BXMI_ESTATE, "bm_count_segments: the half-bucket order serves find() on one index's slices");
     if (fxsub && variant == 0) variant = 1;  // (the half-bucket tile sort has the 1024-thread shapes only)
     const int tile_log2 = variant == 2 ? 15 : 14;
@@ -3424,7 +3444,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     if (dense) BXMI_TRY(h->bd_unitT.reserve((size_t)ntp * (BM_NB + 1) * 2));  // (+ the row behind the last unit)
     BXMI_TRY(h->bm_grpcnt.reserve((size_t)ngroups * BM_NB * 4));
     BXMI_TRY(h->sl_unitcnt.reserve((size_t)ngroups * BM_NB * 4));
-    if (dense) BXMI_TRY(h->bd_cnt16.reserve((size_t)ntp * tile_stride * 2));
+    if (dense && !fxsub) BXMI_TRY(h->bd_cnt16.reserve((size_t)ntp * tile_stride * 2));
     BXMI_TRY(h->bm_items.reserve((size_t)(max_items + 2) * sizeof(int4)));  // [0] = the item count, items from [1]
     if (fx) {  // find(): counts apart from the records, and the tile-sorted offsets
         BXMI_TRY(h->sl_cnt.reserve((size_t)ntp * tile * 4));
@@ -3645,7 +3665,14 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     BXMI_LAUNCH_CHECK();
     stage_done("transpose + plan");
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
-    if (slices_flat)
+    if (slices_flat && fxsub) {
+        BXMI_TRY(allow_big_lds((bd_search_kernel<2, false, 0, FX_FLAT_DEPTH, FX_FLAT_PIPE, false, false, true>), L.search_lds));
+        hipLaunchKernelGGL((bd_search_kernel<2, false, 0, FX_FLAT_DEPTH, FX_FLAT_PIPE, false, false, true>), dim3(sgrid), dim3(BD_THREADS), L.search_lds, st, L.segs,
+                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(),
+                           (unsigned short *)nullptr, L.tile_log2, L.gate, search_out, h->fx_hc.as<unsigned>());
+        BXMI_LAUNCH_CHECK();
+        fx->L = L, fx->sgrid = sgrid, fx->lanes = 16, fx->variant = variant;
+    } else if (slices_flat)
         BXMI_TRY(bd_launch_search(L, sgrid, 2, false, st));
     else if (slices) {
         // long runs (sparse index, big units): the flat walk; else L lanes per run
@@ -3662,15 +3689,15 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY(bd_launch_search(L, sgrid, cells ? 1 : 0, any_blocks, st));
     unsigned *loff = fx ? h->sl_loff.as<unsigned>() : nullptr;
     stage_done("search");
-    if (dense) {
+    if (dense && !fxsub) {
         if (variant == 2)
             BXMI_TRY((bd_launch_unpermute<1024, 32>(L, tslots, st)));
         else
             BXMI_TRY((bd_launch_unpermute<1024, 16>(L, tslots, st)));
     } else if (variant == 2)
-        BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff, fxsub)));
+        BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff, fxsub ? (fx->direct ? 3 : 2) : 0)));
     else
-        BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff, fxsub)));
+        BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff, fxsub ? (fx->direct ? 3 : 2) : 0)));
     stage_done("unpermute");
     if (any_total || descent) {
         hipLaunchKernelGGL(bm_fold_totals_kernel, dim3((unsigned)n), dim3(64), 0, st, slots,
@@ -3740,6 +3767,15 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
     BmFindCtx fx;
     fx.sub = true;
+    // Straight into the CSR list, a record's ~20 bytes of hits land anywhere in its tile's 0.6 MB of the list: lines that are
+    // completed by other pieces much later.  While the whole list stays in the memory-side cache that is free and the copy is
+    // saved (configs[4]'s index, 8 M / 16 M queries: 0.76 / 1.27 ms against 0.84 / 1.37); beyond it every partial line costs HBM
+    // a read-modify-write (24 M: equal; 50 M: 3.70 ms against 3.04).  The size of the list is only known after the count half,
+    // which has to know the layout -- so the handle's previous batch predicts it (hits per query; 5 before the first).
+    {
+        const double per_q = h->fx_hits_per_q >= 0.0 ? h->fx_hits_per_q : 5.0;
+        fx.direct = g_opt_fx_direct < 0 ? per_q * (double)nq * 4.0 <= 400e6 : g_opt_fx_direct != 0;
+    }
     int32_t *counts = h->q_cnt.as<int32_t>();
     int64_t *no_total = nullptr;
     BXMI_TRY(bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &no_total, st, 2, &fx));
@@ -3750,10 +3786,17 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     BXMI_LAUNCH_CHECK();
     BXMI_TRY(fx_ensure_pieces(h, fx.f, st));
     BXMI_HIP(hipMemsetAsync(h->fx_work.p, 0, 64, st));
+    if (fx.direct) {  // the offsets are final before the capacity is known to the host; the escapes' hits wait for it on the device
+        hipLaunchKernelGGL(fx_offsets_kernel, dim3((unsigned)div_up(nq, 1024)), dim3(256), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(),
+                           h->fx_tile_base.as<long long>(), fx.ntiles, fx.L.tile_log2, reinterpret_cast<long long *>(offsets), hits, cap);
+        BXMI_LAUNCH_CHECK();
+    }
     int64_t total = 0;
     BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
     BXMI_HIP(hipStreamSynchronize(st));
     if (total_host) *total_host = total;
+    h->fx_hits_per_q = (double)total / (double)nq;
+    if (total > cap && fx.direct) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     if (total > cap) {
         // (the contract: BXMI_ERANGE comes with valid offsets.  The copy kernel, which finishes them, does not run: scan the counts.)
         BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
@@ -3762,10 +3805,10 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
         return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     }
     if (total == 0) {  // (the copy kernel writes the offsets: nothing to copy, so they are zeroed here)
-        BXMI_HIP(hipMemsetAsync(offsets, 0, (size_t)(nq + 1) * 8, st));
+        if (!fx.direct) BXMI_HIP(hipMemsetAsync(offsets, 0, (size_t)(nq + 1) * 8, st));
         return BXMI_OK;
     }
-    BXMI_TRY(h->sl_hits.reserve((size_t)(total + 16) * 4));
+    if (!fx.direct) BXMI_TRY(h->sl_hits.reserve((size_t)(total + 16) * 4));
     BXMI_TRY(sl_ensure_eid(h, st));
     const int npieces = (int)h->fx_pieces_host.size();
     // enough (piece, tile chunk) pairs to balance 256 persistent workgroups; a chunk is whole groups of 64 tiles (a wave's batch)
@@ -3778,8 +3821,9 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     hipLaunchKernelGGL(fx_fill_kernel, dim3((unsigned)device_props().cus), dim3(FX_THREADS), FX_LDS_BYTES, st, fx.L.segs, h->fx_pieces.as<FxPiece>(), npieces,
                        (int)nchunks, (int)tiles_per_chunk, h->fx_runT2.as<unsigned>(), ntp, h->bm_recs.as<unsigned>(), h->fx_hc.as<unsigned>(),
                        h->sl_cnt.as<unsigned>(), h->sl_loff.as<unsigned>(), h->fx_tile_base.as<long long>(), h->sl_eid.as<int2>() + SL_WALK,
-                       h->fx_meta2.as<int2>(), h->sl_hits.as<int32_t>(), fx.L.tile_log2, h->fx_work.as<unsigned>());
+                       h->fx_meta2.as<int2>(), fx.direct ? hits : h->sl_hits.as<int32_t>(), fx.L.tile_log2, h->fx_work.as<unsigned>());
     BXMI_LAUNCH_CHECK();
+    if (fx.direct) return BXMI_OK;  // (every record's hits went where the CSR offsets say)
     const unsigned cgrid = (unsigned)(div_up(ntp, 8) * 8 * (((int64_t)1 << fx.L.tile_log2) / BM_PART_Q));
     if (fx.variant == 2)
         hipLaunchKernelGGL((fx_hits_copy_kernel<32768>), dim3(cgrid), dim3(BM_PART_Q), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(), h->fx_tile_base.as<long long>(),

@@ -651,8 +651,12 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
     set_opt("ivl.bitmap_min", 1)
     try:
         for k, (variant, f, lanes, sorted_path) in enumerate(((0, -1, 0, 0), (1, 0, 16, 0), (2, 2, 64, 0), (0, 6, 16, 0), (2, 6, 64, 0), (-1, -1, 0, 1))):
-            for fx_fill in (1, 0):
-                set_opt("ivl.fx_fill", fx_fill)
+            # 1: the fill on LDS windows straight into the CSR list; 2: behind the flat count half (ivl.fx_flat); 3: into scratch, then the
+            # copy (ivl.fx_direct = 0); 0: round 2's fill and copy
+            for fx_fill in (1, 2, 3, 0):
+                set_opt("ivl.fx_fill", 1 if fx_fill else 0)
+                set_opt("ivl.fx_flat", 1 if fx_fill == 2 else 0)
+                set_opt("ivl.fx_direct", 0 if fx_fill == 3 else 1)
                 set_opt("ivl.sorted_path", sorted_path)
                 set_opt("ivl.bm_variant", variant)
                 set_opt("ivl.sl_f", f)
@@ -663,6 +667,8 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
                 bad = np.nonzero(hits != want_hits)[0]
                 assert len(bad) == 0, (shape, variant, f, lanes, fx_fill, bad[:8], hits[bad[:8]], want_hits[bad[:8]])
         set_opt("ivl.fx_fill", 1)
+        set_opt("ivl.fx_flat", 0)
+        set_opt("ivl.fx_direct", 1)
         set_opt("ivl.find_sliced", 0)
         off, hits = ix.find(qs, qe)
         assert np.array_equal(off, want_off) and np.array_equal(hits, want_hits), "bucketed find"
@@ -671,10 +677,12 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
         off, hits = ix.find(qs, qe, cap_hint=max(1, int(want_off[-1]) // 2 - 1))
         assert np.array_equal(off, want_off) and np.array_equal(hits, want_hits), "after BXMI_ERANGE"
         # ... and BXMI_ERANGE itself comes with the offsets and the total valid and the hit buffer untouched (include/bxmi.h)
-        for fx_fill in (1, 0):
+        for fx_fill, direct in ((1, 1), (1, 0), (0, 0)):
             set_opt("ivl.fx_fill", fx_fill)
+            set_opt("ivl.fx_direct", direct)
             _erange_contract(ix, qs, qe, want_off)
         set_opt("ivl.fx_fill", 1)
+        set_opt("ivl.fx_direct", 1)
     finally:
         reset_opts()
 
