@@ -176,6 +176,23 @@ __device__ __forceinline__ void tree_rank_lt(const TreeDev &t, const int32_t *ld
     }
 }
 
+// One key per 8-lane group, each group walking ONE of two trees of the same depth (global levels only): the walks of the
+// sorted-batch kernels' slice bounds -- two keys in each of two trees -- are four groups of one wave side by side, instead of
+// one tree after the other (a chunk's set-up is a chain of dependent loads: twelve of them became six).
+template <bool DPP>
+__device__ __forceinline__ int tree_rank_lt_either(const TreeDev &a, const TreeDev &b, bool use_b, int key, int sub)
+{
+    int rank = 0;
+    for (int l = a.nlev - 1; l >= 0; --l) {  // (a.nlev == b.nlev: the caller's business)
+        // (both pointers as scalars first: a select between the two STRUCTS' members sends the structs to scratch memory)
+        const int32_t *pa = a.lev[l], *pb = b.lev[l];
+        const int4 *lev = reinterpret_cast<const int4 *>(use_b ? pb : pa) + sub;
+        const int4 v = lev[(int64_t)rank * (FAN / 4)];
+        rank = rank * FAN + node_count_lt<DPP>(v, key);
+    }
+    return rank;
+}
+
 // Plain lower bound on the monotone prefix-max array: first k with pm[k] > qs.
 __device__ __forceinline__ int first_pm_gt(const int32_t *__restrict__ pm, int n, int qs)
 {
@@ -1078,10 +1095,19 @@ __global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev i
 // and 4 B written per query, no scratch.  Nothing in here relies on the order for correctness -- an unsorted chunk
 // would just get long (sampled) slices and be slow -- the flag computed by part_hist_kernel only decides which of
 // the two paths does the work.
-constexpr int LC_THREADS = 512;
+#ifndef LC_THREADS_V
+#define LC_THREADS_V 512
+#endif
+constexpr int LC_THREADS = LC_THREADS_V;
 constexpr int LC_ITEMS = 8;
 constexpr int LC_CHUNK = LC_THREADS * LC_ITEMS;  // 4096 consecutive queries per workgroup
-constexpr int LC_TREE_KEYS = (1 << 12) - 1;      // two trees of 4096 slots = 32 KiB of LDS: four workgroups per CU
+#ifndef LC_WALK_BOTH
+#define LC_WALK_BOTH 1  // the slice bounds of a chunk: both trees walked side by side (0: one after the other)
+#endif
+#ifndef LC_TREE_LOG2
+#define LC_TREE_LOG2 12
+#endif
+constexpr int LC_TREE_KEYS = (1 << LC_TREE_LOG2) - 1;  // two trees of 4096 slots = 32 KiB of LDS: four workgroups per CU
 
 // LOOP: a workgroup takes LC_LOOP consecutive chunks instead of one: a quarter of the workgroups to dismiss when the batch
 // is NOT sorted (the stand-down of 24 000 workgroups cost 12 us per 100 M queries, 1.5 % of the unsorted pass).
@@ -1127,6 +1153,18 @@ __device__ __forceinline__ void lc_chunk_counts(const TreeDev &S, const TreeDev 
         if (s_hi_key < a) s_hi_key = a;
         const int sub = threadIdx.x & 7, upper = (threadIdx.x >> 3) & 1;
         const int qs_key = upper ? b : a;
+#if LC_WALK_BOTH
+        {   // (both trees stand on n keys: the same depth) groups 0 / 1: the ends' bounds, 2 / 3: the starts', side by side
+            const bool starts = ((threadIdx.x >> 4) & 1) != 0;
+            const int key = starts ? (upper ? s_hi_key : a) : (qs_key == INT_MAX ? INT_MAX : qs_key + 1);
+            int r = tree_rank_lt_either<true>(E, S, starts, key, sub);
+            if (!starts && qs_key == INT_MAX) r = ix.n;  // every end is <= INT_MAX
+            if (sub == 0 && threadIdx.x < 32) {
+                s_slice[(starts ? 2 : 0) + upper] = r;
+                if (starts) s_slice[4 + upper] = upper ? s_hi_key : a;
+            }
+        }
+#else
         int keyE[1] = {qs_key == INT_MAX ? INT_MAX : qs_key + 1};
         int keyS[1] = {upper ? s_hi_key : a};
         int rE[1], rS[1];
@@ -1138,6 +1176,7 @@ __device__ __forceinline__ void lc_chunk_counts(const TreeDev &S, const TreeDev 
             s_slice[2 + upper] = rS[0];
             s_slice[4 + upper] = upper ? s_hi_key : a;
         }
+#endif
     }
     __syncthreads();
     const int eLo = s_slice[0], eHi = s_slice[1], sLo = s_slice[2], sHi = s_slice[3], qeLo = s_slice[4], qeHi = s_slice[5];
@@ -1209,8 +1248,10 @@ __device__ __forceinline__ void lc_chunk_counts(const TreeDev &S, const TreeDev 
     }
 }
 
+// (eight waves per SIMD = four workgroups per CU: the kernel lives on the chunks it keeps in flight -- said out loud, the compiler
+// took 70 registers for a build that needed 64)
 template <bool LOOP>
-__global__ __launch_bounds__(LC_THREADS) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
+__global__ __launch_bounds__(LC_THREADS) __attribute__((amdgpu_waves_per_eu(LOOP ? 4 : 8))) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
                                                                      const int32_t *__restrict__ qs_arr,
                                                                      const int32_t *__restrict__ qe_arr, int64_t nq,
                                                                      int32_t *__restrict__ counts /* may be NULL */,
@@ -2013,7 +2054,7 @@ __global__ __launch_bounds__(LC_THREADS) void ivl_local_find_kernel(TreeDev S, T
                                                                     unsigned *__restrict__ ticket)
 {
     constexpr int NW = LC_THREADS / 64;
-    static_assert(NW * LC_ITEMS == 64, "one wave scans the (row, wave) totals of a chunk");
+    static_assert(NW * LC_ITEMS <= 64, "one wave scans the (row, wave) totals of a chunk");
     static_assert((size_t)NW * (FF_PAIRS * 8 + FF_HITS * 4) <= (size_t)2 * (LC_TREE_KEYS + 1) * 4, "the fill's images fit the trees' LDS");
     __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
     __shared__ int s_mm[3][LC_THREADS / 64];

@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 kernel stats of tools/bench_clustered.py
+cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_cl -o f --output-format csv -- python $R/tools/bench_clustered.py > $R/gpurun_out/clustered.json 2>/dev/null
+python - <<PY
+import csv,glob
+f=glob.glob('$R/gpurun_out/prof_cl/**/*kernel_stats.csv',recursive=True)
+for r in list(csv.DictReader(open(f[0])))[:40]:
+    if 'bxmi' in r['Name']: print("%-72s calls=%-4s avg=%9.1f us" % (r['Name'].split('(')[0][-72:], r['Calls'], float(r['AverageNs'])/1e3))
+PY
+cut -c1-700 $R/gpurun_out/clustered.json
+rm -rf $R/gpurun_out/prof_cl
