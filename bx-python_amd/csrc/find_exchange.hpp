@@ -412,6 +412,136 @@ __global__ __launch_bounds__(BM_PART_Q) void fx_hits_copy_kernel(const BmSeg *__
     }
 }
 
+// The same copy with QPL (2 or 4) consecutive queries per lane: a wave owns the stretch of 64 QPL queries (~320 QPL hits on
+// configs[4]) and has QPL times the gathers in flight -- the kernel is a chain of three round trips to memory per workgroup
+// (counts, gathers, stores) at the CU's full complement of waves either way, so the work per round trip is what counts.
+// 1024 / QPL threads per part of 1024 queries.
+#ifndef FX_FL2_V
+#define FX_FL2_V 10
+#endif
+template <int TILE, int QPL>
+__global__ __launch_bounds__(BM_PART_Q / QPL) __attribute__((amdgpu_waves_per_eu(8))) void fx_hits_copy2_kernel(
+    const BmSeg *__restrict__ segs, const unsigned *__restrict__ svq, const long long *__restrict__ tile_base, const unsigned long long *__restrict__ parts,
+    const int32_t *__restrict__ tmp_hits, long long *__restrict__ offsets, int32_t *__restrict__ hits, int64_t ntp)
+{
+    static_assert(QPL == 2 || QPL == 4, "a lane's queries are one 8- or 16-byte load");
+    constexpr int PARTS = TILE / BM_PART_Q, THREADS = BM_PART_Q / QPL, NW = THREADS / 64, WQ = 64 * QPL;
+    __shared__ unsigned s_ends[NW][WQ];  // per wave: where each query's hits end in the wave's stretch
+    __shared__ unsigned s_dsrc[NW][WQ], s_ddst[NW][WQ];
+    __shared__ long long s_scan[16];
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int64_t unit = (int64_t)(blockIdx.x >> 3), units = ((ntp + 7 - xcd) >> 3) * PARTS;  // of this XCD's tiles
+    if (unit >= units) return;
+    const BmSeg &sg = segs[0];
+    const int64_t tile = (unit / PARTS) * 8 + xcd;
+    const int part = (int)(unit % PARTS);
+    if (tile >= sg.ntiles) return;  // padding up to the next plan group
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int64_t q0 = tile * TILE;
+    const int64_t left = sg.nq - q0;
+    const int n = (int)(left < TILE ? left : TILE);
+    const int k = part * BM_PART_Q + QPL * (int)threadIdx.x;  // this lane's queries: k .. k + QPL - 1
+    if (part * BM_PART_Q >= n) return;  // (uniform)
+    const int64_t q = q0 + k;
+    long long part_base = tile_base[tile];
+    {
+        long long v = lane < part ? (long long)parts[tile * PARTS + lane] : 0ll;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        part_base += v;
+    }
+    // (q is a multiple of QPL and the arrays are aligned: a lane whose last query is live reads its counts and scratch offsets as one load)
+    typedef unsigned fx_vqu __attribute__((ext_vector_type(QPL)));
+    unsigned c[QPL], sv[QPL];
+#pragma unroll
+    for (int u = 0; u < QPL; u++) c[u] = 0u, sv[u] = 0u;
+    if (k + QPL <= n) {
+        const fx_vqu cv = __builtin_nontemporal_load(reinterpret_cast<const fx_vqu *>(sg.counts + q));
+        const fx_vqu sq = __builtin_nontemporal_load(reinterpret_cast<const fx_vqu *>(svq + q));
+#pragma unroll
+        for (int u = 0; u < QPL; u++) c[u] = cv[u], sv[u] = sq[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < QPL; u++)
+            if (k + u < n) c[u] = (unsigned)sg.counts[q + u], sv[u] = svq[q + u];
+    }
+    long long mine = 0;
+#pragma unroll
+    for (int u = 0; u < QPL; u++) mine += (long long)c[u];
+    long long total;
+    long long o[QPL + 1];
+    o[0] = part_base + block_exclusive_scan(mine, OpSum(), 0ll, s_scan, &total);
+#pragma unroll
+    for (int u = 0; u < QPL; u++) o[u + 1] = o[u] + (long long)c[u];
+    if (k + QPL <= n) {
+        typedef long long fx_v2ll __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int u = 0; u < QPL; u += 2) __builtin_nontemporal_store(fx_v2ll{o[u], o[u + 1]}, reinterpret_cast<fx_v2ll *>(offsets + q + u));
+    } else {
+#pragma unroll
+        for (int u = 0; u < QPL; u++)
+            if (k + u < n) offsets[q + u] = o[u];
+    }
+    const int32_t *__restrict__ region = tmp_hits + tile_base[tile];
+    unsigned nn[QPL], mine_n = 0u;  // (escape records leave holes in the stretch, filled by their own lanes)
+#pragma unroll
+    for (int u = 0; u < QPL; u++) nn[u] = (sv[u] >> 31) ? 0u : c[u], mine_n += nn[u];
+    const unsigned incl = wave_inclusive_sum_dpp(mine_n);
+    const unsigned wtotal = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    const long long o_first = __shfl(o[0], 0, 64);
+    int32_t *__restrict__ out = hits + o_first;
+    unsigned *ends = s_ends[wave], *dsrc = s_dsrc[wave], *ddst = s_ddst[wave];
+    {
+        unsigned b = incl - mine_n;  // hits of the stretch before the lane's first query
+#pragma unroll
+        for (int u = 0; u < QPL; u++) {
+            dsrc[QPL * lane + u] = sv[u] - b;                            // + s = the hit's place in the tile's region
+            ddst[QPL * lane + u] = (unsigned)(o[u] - o_first) - b;       // + s = its place behind the wave's first CSR offset
+            b += nn[u];
+            ends[QPL * lane + u] = b;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    constexpr int FL = FX_FL2_V;
+    for (unsigned s0 = 0; s0 < wtotal; s0 += 64u * FL) {
+        unsigned dst[FL];
+        bool act[FL];
+        int v[FL];
+#pragma unroll
+        for (int j = 0; j < FL; j++)
+            if (s0 + 64u * j < wtotal) {  // (wave-uniform)
+                const unsigned s = s0 + 64u * j + (unsigned)lane;
+                unsigned r = 0u;  // #{i in [0, WQ) : ends[i] <= s}, at most WQ - 1
+#pragma unroll
+                for (unsigned step = WQ / 2; step >= 1u; step >>= 1)
+                    if (ends[r + step - 1u] <= s) r += step;
+                r = r < (unsigned)(WQ - 1) ? r : (unsigned)(WQ - 1);
+                act[j] = s < wtotal;
+                dst[j] = ddst[r] + s;
+                v[j] = region[act[j] ? dsrc[r] + s : 0u];
+            }
+#pragma unroll
+        for (int j = 0; j < FL; j++)
+            if (s0 + 64u * j < wtotal && act[j]) out[dst[j]] = v[j];
+    }
+    bool any_esc = false;
+#pragma unroll
+    for (int u = 0; u < QPL; u++) any_esc |= (sv[u] >> 31) != 0u;
+    if (any_esc) {  // escape records: rare, answered from the sealed index by their own lane
+        const IndexDev ix = sg.ix;
+#pragma unroll
+        for (int u = 0; u < QPL; u++) {
+            int cc = (int)c[u];
+            if (!(sv[u] >> 31) || cc <= 0) continue;
+            const int qs = sg.qs[q + u], qe = sg.qe[q + u];
+            int32_t *__restrict__ d = hits + o[u];
+            for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; cc > 0 && j >= 0; j--)
+                if (ix.e_ord[j] > qs) d[--cc] = ix.idx[j];
+        }
+    }
+}
+
 // The fill straight into the CSR list (bm_unpermute_kernel<.., FIND = 3>): what is left of the copy -- the int64 offsets
 // (tile base + the query-order prefix inside the tile) and the hits of escape queries, from the sealed index by their own lanes.
 // The escapes' hits are only written when the whole list fits the caller's buffer (tile_base[ntiles] = all hits): BXMI_ERANGE

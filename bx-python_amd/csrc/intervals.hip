@@ -2505,6 +2505,7 @@ static int64_t g_opt_find_fused = 0;   // find() on a sorted batch: 1 = count, o
 static int64_t g_opt_fx_flat = 0;      // find() through the exchange: 1 = the count half as the flat walk on key slices (measured on configs[4]: 531 us against 474 for the lane groups per run, the default)
 static int64_t g_opt_fx_direct = -1;   // find() through the exchange: 1 = the fill writes straight into the CSR list (query-order prefixes from the un-permute
                                        // kernel, no copy), 0 = scratch + copy, -1 = by the size of the list the handle expects (see ivl_find_fx)
+static int64_t g_opt_fx_copy2 = 2;     // find() through the exchange, the copy: queries per lane -- 2 / 4 (fx_hits_copy2_kernel), 0 = one (fx_hits_copy_kernel)
 static int64_t g_opt_fx_fill = 1;      // find() through the exchange: 1 = the fill half on LDS windows of half-bucket pieces (find_exchange.hpp), 0 = round 2's fill and copy
 static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
@@ -2557,6 +2558,7 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.fx_fill", &g_opt_fx_fill, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.find_fused", &g_opt_find_fused, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.fx_flat", &g_opt_fx_flat, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.fx_copy2", &g_opt_fx_copy2, [](int64_t value) -> int64_t { return value == 4 ? 4 : value != 0 ? 2 : 0; }},
     {"ivl.fx_direct", &g_opt_fx_direct, [](int64_t value) -> int64_t { return value < 0 ? -1 : value != 0; }},
     {"ivl.slice", &g_opt_slice, nullptr},
     {"ivl.sl_f", &g_opt_sl_f, [](int64_t value) -> int64_t { return value > SL_MAX_F ? SL_MAX_F : value; }},
@@ -3866,6 +3868,19 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     BXMI_LAUNCH_CHECK();
     if (fx.direct) return BXMI_OK;  // (every record's hits went where the CSR offsets say)
     const unsigned cgrid = (unsigned)(div_up(ntp, 8) * 8 * (((int64_t)1 << fx.L.tile_log2) / BM_PART_Q));
+    if (g_opt_fx_copy2 != 0) {  // several queries per lane
+        auto launch = [&](auto kern, int qpl) {
+            hipLaunchKernelGGL(kern, dim3(cgrid), dim3(BM_PART_Q / qpl), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(), h->fx_tile_base.as<long long>(),
+                               h->fx_parts.as<unsigned long long>(), h->sl_hits.as<int32_t>(), reinterpret_cast<long long *>(offsets), hits, ntp);
+        };
+        if (g_opt_fx_copy2 == 4) {
+            if (fx.variant == 2) launch(fx_hits_copy2_kernel<32768, 4>, 4); else launch(fx_hits_copy2_kernel<16384, 4>, 4);
+        } else {
+            if (fx.variant == 2) launch(fx_hits_copy2_kernel<32768, 2>, 2); else launch(fx_hits_copy2_kernel<16384, 2>, 2);
+        }
+        BXMI_LAUNCH_CHECK();
+        return BXMI_OK;
+    }
     if (fx.variant == 2)
         hipLaunchKernelGGL((fx_hits_copy_kernel<32768>), dim3(cgrid), dim3(BM_PART_Q), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(), h->fx_tile_base.as<long long>(),
                            h->fx_parts.as<unsigned long long>(), h->sl_hits.as<int32_t>(), reinterpret_cast<long long *>(offsets), hits, ntp);

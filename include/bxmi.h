@@ -84,6 +84,10 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *   ivl.find_fused     1: sorted find() counts, scans (decoupled look-back) and fills in ONE kernel; 0 (default): in stages
  *                      (the fused kernel measured slower: its registers leave half the workgroups per CU)
  *   ivl.fx_fill        1 (default): the exchange's fill half on LDS-staged (end, index) windows of sub-bucket pieces
+ *   ivl.fx_direct      that fill writes straight into the CSR list (1) or into scratch, followed by a copy (0); -1 (default):
+ *                      straight while the list the handle expects (hits per query of its previous batch) stays under 400 MB
+ *   ivl.fx_copy2       queries per lane of that copy: 2 (default) / 4 / 0 = one (round 5's first version)
+ *   ivl.fx_flat        1: find()'s count half through the exchange as the flat walk on key slices; 0 (default): lane groups per run
  *   ivl.sl_f, ivl.sl_lanes, ivl.sl_flat, ivl.sl_rbits, ivl.sl_run_cap   geometry of the slice stage (tests, A/B tools)
  *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search
  *   ivl.lds_ints, ivl.count_grid   staging budget / grid of the direct count kernel

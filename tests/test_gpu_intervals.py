@@ -651,12 +651,13 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
     set_opt("ivl.bitmap_min", 1)
     try:
         for k, (variant, f, lanes, sorted_path) in enumerate(((0, -1, 0, 0), (1, 0, 16, 0), (2, 2, 64, 0), (0, 6, 16, 0), (2, 6, 64, 0), (-1, -1, 0, 1))):
-            # 1: the fill on LDS windows straight into the CSR list; 2: behind the flat count half (ivl.fx_flat); 3: into scratch, then the
-            # copy (ivl.fx_direct = 0); 0: round 2's fill and copy
-            for fx_fill in (1, 2, 3, 0):
+            # 1: the fill on LDS windows straight into the CSR list; 2: behind the flat count half (ivl.fx_flat); 3 / 4 / 5: into scratch,
+            # then the copy with two / one / four queries per lane (ivl.fx_direct = 0, ivl.fx_copy2); 0: round 2's fill and copy
+            for fx_fill in (1, 2, 3, 4, 5, 0):
                 set_opt("ivl.fx_fill", 1 if fx_fill else 0)
                 set_opt("ivl.fx_flat", 1 if fx_fill == 2 else 0)
-                set_opt("ivl.fx_direct", 0 if fx_fill == 3 else 1)
+                set_opt("ivl.fx_direct", 0 if fx_fill in (3, 4, 5) else 1)
+                set_opt("ivl.fx_copy2", {4: 0, 5: 4}.get(fx_fill, 2))
                 set_opt("ivl.sorted_path", sorted_path)
                 set_opt("ivl.bm_variant", variant)
                 set_opt("ivl.sl_f", f)

@@ -103,12 +103,13 @@ for r in range(rounds):
     # sorted batches take the staged kernels or the fused one
     for part, sliced, fx in ((0, 0, 1), (1, 0, 1), (1, 1, 0), (1, 1, 1), (1, 1, 1)):
         knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64])), sorted_path=int(rng.integers(0, 2)),
-                     fused=int(rng.integers(0, 2)), fx=fx, flat=int(rng.integers(0, 2)), direct=int(rng.integers(0, 2)))
+                     fused=int(rng.integers(0, 2)), fx=fx, flat=int(rng.integers(0, 2)), direct=int(rng.integers(0, 2)), copy2=int(rng.choice([0, 2, 4])))
         opt("ivl.partition", part)
         opt("ivl.find_sliced", sliced)
         opt("ivl.fx_fill", fx)
         opt("ivl.fx_flat", knobs["flat"])
         opt("ivl.fx_direct", knobs["direct"])
+        opt("ivl.fx_copy2", knobs["copy2"])
         opt("ivl.find_fused", knobs["fused"])
         opt("ivl.slice", -1)
         opt("ivl.bm_variant", knobs["variant"])
@@ -120,7 +121,7 @@ for r in range(rounds):
             print("FIND MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, sliced=sliced, **knobs), ix.slice_state())
             sys.exit(1)
     for k, v in (("ivl.partition", -1), ("ivl.find_sliced", 1), ("ivl.bm_variant", -1), ("ivl.sl_f", -1), ("ivl.sl_lanes", 0),
-                 ("ivl.sorted_path", 1), ("ivl.fx_fill", 1), ("ivl.fx_flat", 0), ("ivl.fx_direct", 1), ("ivl.find_fused", 0)):
+                 ("ivl.sorted_path", 1), ("ivl.fx_fill", 1), ("ivl.fx_flat", 0), ("ivl.fx_direct", -1), ("ivl.fx_copy2", 2), ("ivl.find_fused", 0)):
         opt(k, v)
     checked += 1
     ix.close()
