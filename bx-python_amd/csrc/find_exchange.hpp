@@ -20,6 +20,9 @@
 //      every tile (bm_unpermute_kernel<.., FIND = 2>), one workgroup scans the TILE sums (fx_tile_scan_kernel), and the copy
 //      kernel finishes the offsets of its 1024 queries itself while it moves their hits (fx_hits_copy_kernel).  It also reads
 //      the scratch offset of a query from a query-order array the un-permute kernel wrote, instead of gathering it by slot.
+//      Two consecutive queries per lane (fx_hits_copy2_kernel): twice the gathers in flight per wave.
+//   5. Lists that fit the memory-side cache skip the scratch and the copy (ivl.fx_direct): the un-permute kernel leaves prefixes
+//      in QUERY order (FIND = 3), the fill writes straight into the CSR list, fx_offsets_kernel turns the prefixes into offsets.
 // A record whose walk leaves the staged window (long targets far below, piles larger than the window) reads the pairs from HBM
 // as before: exact either way.  ivl.fx_fill = 0 keeps round 2's kernels.
 #pragma once
