@@ -47,6 +47,10 @@ constexpr size_t FX_LDS_BYTES = (size_t)FX_CAPW * 8 + (size_t)FX_NW * (FX_HCAP *
 #ifndef FX_STORE4
 #define FX_STORE4 0   // 1: the hits leave as 4-byte stores
 #endif
+#ifndef FX_EXP
+#define FX_EXP 0      // diagnostics (wrong results): bit 0 = the hits are not stored, bit 1 = no walk (nothing to store either), bit 2 = no window staging
+                      // (configs[4], round 5: 1.16 ms whole, 0.78 without the stores, 0.36 without the walk as well, 0.32 without the staging too)
+#endif
 #ifndef FX_XCD
 #define FX_XCD 1      // 1: neighbouring pieces are handed out on ONE XCD (eight counters), 0: one counter for the chip
 #endif
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
             constexpr int ROUNDS = (FX_CAPW + 2 * FX_THREADS - 1) / (2 * FX_THREADS);
             sl_v4a8 v[ROUNDS];
 #pragma unroll
-            for (int r = 0; r < ROUNDS; r++) {
+            for (int r = 0; r < ((FX_EXP & 4) ? 0 : ROUNDS); r++) {
                 const int i = 2 * ((int)threadIdx.x + r * FX_THREADS);
                 // (the pair behind the window's last one is read with it when the window's length is odd: the pair array ends
                 // with SL_WALK spare entries... in front; behind, a valid address is all that is needed -- clamp)
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                 const unsigned at = R.at, rec = R.rec, h = R.h, lo = R.lo;
                 const long long tb_r = R.tb_r;
                 const bool esc = (lo >> 31) != 0u;
-                unsigned n = act && !esc ? (h & 0xffffu) : 0u;
+                unsigned n = act && !esc && !(FX_EXP & 2) ? (h & 0xffffu) : 0u;
                 if (n == 0xffffu) n = cnt[(size_t)at];  // (a count that did not fit the packed word)
                 const int hi = sLo + (int)(h >> 16);
                 const int qs = (int)(lo_u + (long long)(rec & omask));
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                         __builtin_amdgcn_wave_barrier();
                         // every record's hits as 16-byte stores (its place in the tile's region is only 4-byte aligned)
                         const unsigned nn = in ? n : 0u;
-                        for (unsigned j = 0; __any(j < nn); j += 4u) {
+                        for (unsigned j = 0; !(FX_EXP & 1) && __any(j < nn); j += 4u) {
                             if (!FX_STORE4 && j + 4u <= nn) {
                                 fx_v4a4 v;
                                 v.x = st[my_off + j], v.y = st[my_off + j + 1u], v.z = st[my_off + j + 2u], v.w = st[my_off + j + 3u];
