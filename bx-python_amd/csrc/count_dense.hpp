@@ -44,7 +44,11 @@ constexpr int BD_MARGIN = 8192;      // the starts' cells reach this far past th
 constexpr int BD_MAX_F = 6;          // buckets per unit = 2^f
 constexpr int BD_MAX_SHIFT = 19;     // bucket width <= 2^19: spans up to 2^30
 constexpr int BD_OV_MAX = 32704;     // 16-bit overflow entries per unit, at most (a cell's 15-bit index must reach them)
-constexpr int BD_TABLE_FROM = 6;     // list entries from which a cell gets a rank table
+// list entries from which a cell gets a rank table: tried in this order per unit width (bd_prepare_index).  A table is 66 or 130
+// overflow words where a short list is 3-6, but a wave whose lanes meet plain cells, lists AND tables runs all three paths:
+// measured on the clustered leg of bench.py (every look-up near a hot spot) 1.19 ms with tables from 6 entries, 1.08 / 1.05 /
+// 1.01 from 4 / 3 / 2; from 1 the overflow area no longer fits the LDS and the index falls to the key slices (1.43).
+constexpr int BD_TABLE_FROM_FIRST = 2, BD_TABLE_FROM_LAST = 6;
 constexpr int BD_THREADS = 1024;
 constexpr int BD_LONG_SLOTS = 64;    // runs of more 16-byte slots than this go to the cooperative finish
 constexpr int BD_LONG_CAP = 320;
@@ -92,7 +96,7 @@ __device__ __forceinline__ int bd_lower_bound(const int32_t *__restrict__ a, int
 
 // stats: [0] most keys in one block of 2^bshift cells, [1] most overflow entries of one unit
 __global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted, int n,
-                                                              BmGeom g, int bshift, unsigned char *__restrict__ images, unsigned *__restrict__ stats)
+                                                              BmGeom g, int bshift, unsigned char *__restrict__ images, unsigned *__restrict__ stats, int table_from)
 {
     const int bmask = (1 << bshift) - 1;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
@@ -143,9 +147,9 @@ __global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__r
         const int K = (nc + BD_THREADS - 1) / BD_THREADS;
         const int c_lo = (int)threadIdx.x * K, c_hi = c_lo + K < nc ? c_lo + K : nc;
         // overflow words of a cell: none, {base, entry, entry or zero}, or {base, 128 ranks}
-        auto ov_words = [](unsigned entries, unsigned keys) {
+        auto ov_words = [table_from](unsigned entries, unsigned keys) {
             if (entries == 0u) return 0u;
-            if (entries >= (unsigned)BD_TABLE_FROM) return keys < 256u ? 66u : 130u;
+            if (entries >= (unsigned)table_from) return keys < 256u ? 66u : 130u;
             return 1u + (entries > 2u ? entries : 2u);
         };
         unsigned ksum = 0, osum = 0;
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__r
             if (ecnt[c]) {
                 const unsigned at = ov_base + ovoff[c];
                 m = 0x8000u | (at & 0x7FFFu);
-                const unsigned table = ecnt[c] >= (unsigned)BD_TABLE_FROM ? 0x8000u : 0u;
+                const unsigned table = ecnt[c] >= (unsigned)table_from ? 0x8000u : 0u;
                 if (at < (unsigned)L.ov_cap) ov[at] = (unsigned short)((base & 0x7FFFu) | table);
                 if (ecnt[c] == 1u && at + 2u < (unsigned)L.ov_cap) ov[at + 2u] = 0;  // the zero after a lone entry
             }
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__r
         // rank tables: 128 threads per clumped cell, T[p] = #{keys of the cell below position p} (the cell's keys are
         // a contiguous range of the sorted array)
         for (int c = (int)(threadIdx.x >> 7); c < nc; c += BD_THREADS >> 7) {
-            if (ecnt[c] < (unsigned)BD_TABLE_FROM) continue;
+            if (ecnt[c] < (unsigned)table_from) continue;
             const unsigned p = threadIdx.x & 127u;
             const int k0 = r0 + (int)cnt[c], k1 = r0 + (int)(c + 1 < nc ? cnt[c + 1] : ktot);
             const long long key = lo + (long long)c * 128 + (long long)p;
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_image_kernel(const int32_t *__r
             if (last && !first) {
                 const unsigned rel = (unsigned)((long long)k - lo);
                 const unsigned c = rel >> 7, p = rel & 127u;
-                if (ecnt[c] >= (unsigned)BD_TABLE_FROM) continue;  // (a table cell has no list)
+                if (ecnt[c] >= (unsigned)table_from) continue;  // (a table cell has no list)
                 unsigned extras = (unsigned)(r - bd_lower_bound(A, r0, r, k));
                 const unsigned ne = (extras + 254u) / 255u;
                 unsigned j = atomicAdd(&ecur[c], ne);

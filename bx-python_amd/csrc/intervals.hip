@@ -2528,6 +2528,7 @@ static int64_t g_opt_find_flat = 1;     // find() on a sorted batch: 1 = the fil
 static int64_t g_opt_sorted_cells = 1;  // sorted batches on indexes with cell images: 1 = answered from the images stretch by stretch (bs_*), 0 = the first-generation kernel for sorted batches
 static int64_t g_opt_dense = -1;      // search stage on dense unit images (count_dense.hpp): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
 static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
+static int64_t g_opt_bd_table_from = 0;  // dense images: overflow entries from which a cell gets a rank table (read when an index is prepared); 0 = 2 where the overflow area has the room, else 6
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
 static int64_t g_opt_bd_w8 = -1;      // 8-bit counts out of place: -1 = by index and feedback, 0 = never, 1 = whenever the layout allows
 static int64_t g_opt_order_skip = -1;  // -1 = stop launching the order check after two batches in a row were not sorted (a probe of 8192 starts rides on the parameter kernel then), 0 = always check
@@ -2581,6 +2582,7 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.bo_min_per_unit", &g_opt_bo_min_per_unit, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
     {"ivl.bd_chunk", &g_opt_bd_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
     {"ivl.bd_blocks", &g_opt_bd_blocks, [](int64_t value) -> int64_t { return value != 0; }},
+    {"ivl.bd_table_from", &g_opt_bd_table_from, [](int64_t value) -> int64_t { return value < 1 || value > 64 ? 0 : value; }},
     {"ivl.bd_w8", &g_opt_bd_w8, nullptr},
     {"ivl.order_skip", &g_opt_order_skip, nullptr},
     {"ivl.stage_sync", &g_opt_stage_sync, nullptr},
@@ -3070,10 +3072,14 @@ static int bd_prepare_index(bxmi_ivl *h, hipStream_t st)
         h->bd_geom = g;
         // ranks relative to the whole unit when every slice holds fewer than 2^15 keys (no table read per lookup), else
         // relative to blocks of 1024 cells
+        // rank tables for every cell with two duplicated coordinates where the overflow area has the room, else from six (count_dense.hpp)
+        const int tf_first = g_opt_bd_table_from ? (int)g_opt_bd_table_from : BD_TABLE_FROM_FIRST;
+        const int tf_last = g_opt_bd_table_from ? (int)g_opt_bd_table_from : BD_TABLE_FROM_LAST;
+        for (int table_from = tf_first; table_from <= tf_last; table_from += BD_TABLE_FROM_LAST - BD_TABLE_FROM_FIRST)
         for (int bshift = g_opt_bd_blocks ? 10 : 13; bshift >= 10; bshift -= 3) {
             BXMI_HIP(hipMemsetAsync(h->bd_stats.p, 0, 64, st));
             hipLaunchKernelGGL(bd_image_kernel, dim3((unsigned)units), dim3(BD_THREADS), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(),
-                               (int)h->n, g, bshift, h->bd_images.as<unsigned char>(), h->bd_stats.as<unsigned>());
+                               (int)h->n, g, bshift, h->bd_images.as<unsigned char>(), h->bd_stats.as<unsigned>(), table_from);
             BXMI_LAUNCH_CHECK();
             BXMI_HIP(hipMemcpyAsync(h->bd_worst, h->bd_stats.p, sizeof(h->bd_worst), hipMemcpyDeviceToHost, st));
             BXMI_HIP(hipStreamSynchronize(st));

@@ -92,6 +92,7 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search
  *   ivl.lds_ints, ivl.count_grid   staging budget / grid of the direct count kernel
  *   ivl.stage_sync     1: synchronise and report after every stage of the exchange (debugging)
+ *   ivl.bd_table_from  dense images: duplicated coordinates from which a cell gets a rank table (0 = 2 where the LDS has the room, else 6)
  *   ivl.bm_hard_ppm, ivl.bd_unit_log2, ivl.bd_blocks, ivl.count_cells, ivl.find_fill, ivl.find_pairs, ivl.lc_loop,
  *   ivl.sl_hcopy, ivl.sl_hu_parts   shapes of older / alternative kernels the tests and A/B tools still select (see the table)
  *   bits.grid          grid of the per-bitset kernels

@@ -515,7 +515,7 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
     t.insert_many_arrays(s, e)
     want, want_total = t.count_batch(qs, qe)
     ix = make_index(IntervalIndex, s, e)
-    ix_blocks = [0]
+    ix_blocks = [(0, 0)]
     set_opt("ivl.partition", 1)
     try:
         if stage in ("dense", "flat"):
@@ -528,16 +528,19 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                 set_opt("ivl.bm_hard_ppm", 10**6)  # (two cells' worth of piled-up coordinates and 60 000 repeated starts: keep the cells anyway)
             # w8: 8-bit counts between the search and the un-permute kernel (cell images): forced on (counts of 255 and more
             # come back as "ask again" and are recomputed), off, or left to the density + feedback
-            for k, (variant, chunk, blocks, w8) in enumerate(((0, 0, 0, 0), (1, 4096, 1, 0), (2, 1 << 20, 1, 0), (-1, 20000, 0, 0), (0, 1024, 0, 0),
-                                                              (1, 65536, 0, 0), (2, 4096, 0, 0), (2, 0, 0, 1), (1, 8192, 0, 1), (-1, 0, 0, -1), (2, 0, 1, 0))):
+            # tf: duplicated coordinates from which a cell of the dense images gets a rank table (0 = two where the LDS has the room, else six)
+            for k, (variant, chunk, blocks, w8, tf) in enumerate(((0, 0, 0, 0, 0), (1, 4096, 1, 0, 6), (2, 1 << 20, 1, 0, 6), (-1, 20000, 0, 0, 2),
+                                                                  (0, 1024, 0, 0, 2), (1, 65536, 0, 0, 3), (2, 4096, 0, 0, 3), (2, 0, 0, 1, 0),
+                                                                  (1, 8192, 0, 1, 0), (-1, 0, 0, -1, 0), (2, 0, 1, 0, 2))):
                 set_opt("ivl.sorted_path", k % 2)
                 set_opt("ivl.bm_variant", variant)
                 set_opt("ivl.bd_chunk", chunk)
                 set_opt("ivl.bd_w8", w8)
-                if stage == "dense" and blocks != ix_blocks[0]:
+                if stage == "dense" and (blocks, tf) != ix_blocks[0]:
                     set_opt("ivl.bd_blocks", blocks)
-                    ix.seal()  # (the rank base of the images is decided when the index is prepared)
-                    ix_blocks[0] = blocks
+                    set_opt("ivl.bd_table_from", tf)
+                    ix.seal()  # (the rank base and the tables of the images are decided when the index is prepared)
+                    ix_blocks[0] = (blocks, tf)
                 got, got_total = ix.count(qs, qe)
                 state = ix.dense_state() if stage == "dense" else ix.flat_state()
                 assert state[0] == 1 and ix.slice_state()[0] == 0, (state, ix.slice_state())
