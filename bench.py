@@ -440,7 +440,7 @@ def bench_genome(torch, dist, rank, world, steps, warmup, n_targets, n_queries, 
         for k in range(k_warm):
             sh.step(rows[k])
             if collective:
-                dist.all_reduce(rows[k])
+                all_reduce(dist, rows[k])
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k_steps)]
         if collective:
             dist.barrier()
@@ -455,7 +455,7 @@ def bench_genome(torch, dist, rank, world, steps, warmup, n_targets, n_queries, 
                 # RCCL over xGMI: 24 x int64, the path's only collective.  Asynchronous: step k + 1 does not need step k's
                 # reduced totals, so its kernels may run while the 192 bytes travel; every reduction is waited for inside
                 # the timed region.
-                pending.append(dist.all_reduce(rows[k_warm + k], async_op=True))
+                pending.append(all_reduce(dist, rows[k_warm + k], async_op=True))
         for w in pending:
             w.wait()
         torch.cuda.synchronize()
@@ -473,7 +473,7 @@ def bench_genome(torch, dist, rank, world, steps, warmup, n_targets, n_queries, 
     elapsed, kernel_ms, rows = timed(mine, steps, warmup, collective)
     if collective:
         t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(dist, t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0].item()), float(t[1].item())
     # parity on what was just measured: owner-side golden hashes, and the reduced totals against the owners' counts
     ok_hash, ok_sum = [], []
@@ -485,14 +485,14 @@ def bench_genome(torch, dist, rank, world, steps, warmup, n_targets, n_queries, 
             ok_hash.append(bool(g))
         own_tot[chroms.index(c)] = int(cn.sum(dtype=np.int64))
     if collective:
-        dist.all_reduce(own_tot)
+        all_reduce(dist, own_tot)
     same_every_step = bool((rows == own_tot.unsqueeze(0)).all().item())
     flags = torch.tensor([int(all(ok_hash)) if ok_hash else 1, int(same_every_step), len(ok_hash)], dtype=torch.int64, device="cuda")
     if collective:
         red = flags.clone()
-        dist.all_reduce(red, op=dist.ReduceOp.MIN)
+        all_reduce(dist, red, op=dist.ReduceOp.MIN)
         cnt = flags[2:].clone()
-        dist.all_reduce(cnt)
+        all_reduce(dist, cnt)
         flags = torch.tensor([int(red[0]), int(red[1]), int(cnt[0])], device="cuda")
     total_q = sum(qsz.values())
     value = total_q * steps / elapsed / 1e6
@@ -577,6 +577,51 @@ def alg_bytes_of(nq, nt):
     """8 B in + 4 B out per query, the sorted starts + ends read once."""
     return nq * 12 + nt * 8
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def all_reduce(dist, t, op=None, async_op=False):
+    """dist.all_reduce on a device tensor.  Under BENCH_DRY_MULTI=1 the backend is gloo and every rank sits on one GPU: the
+    tensor goes through host memory (the rehearsal must not depend on gloo having been built with device support)."""
+    kw = {} if op is None else {"op": op}
+    if os.environ.get("BENCH_DRY_MULTI") == "1":
+        h = t.detach().cpu()
+        dist.all_reduce(h, **kw)
+        t.copy_(h)
+        return _Done() if async_op else None
+    return dist.all_reduce(t, async_op=async_op, **kw)
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks here, one per device, the way the
+    contract's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` would, and
+    return its exit code.  Fewer than N devices is an error (exit 2), never a silent one-rank run; BENCH_DRY_MULTI=1
+    (every rank on cuda:0, gloo) is the rehearsal of this path on a one-GPU box."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("BENCH_DRY_MULTI") == "1":
+        if have < 1:
+            log("bench.py: BENCH_DRY_MULTI=1 still needs one HIP device; none visible")
+            return 2
+    elif have < n:
+        log("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to run fewer ranks than asked "
+            "(BENCH_DRY_MULTI=1 rehearses the N-rank code path on one device)" % (n, have))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -600,11 +645,14 @@ def main():
     ap.add_argument("--no-genome", action="store_true", help="skip the configs[3] leg")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but the launcher set WORLD_SIZE=%d: refusing to print a line for a job of another size"
+                         % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
@@ -627,6 +675,15 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # the world the collective library itself reports: an all-reduce of ones over the job's communicator
+    coll = dict(world=1, backend="none (one rank)")
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.int64, device="cuda")
+        all_reduce(dist, ones)
+        coll = dict(world=dist.get_world_size(), backend=dist.get_backend(), ranks_counted_by_all_reduce_of_ones=int(ones.item()),
+                    devices_visible=torch.cuda.device_count(), device_of_rank0=local_rank)
+        if coll["ranks_counted_by_all_reduce_of_ones"] != args.gpus:
+            raise SystemExit("bench.py: the collective counted %d ranks, --gpus %d" % (coll["ranks_counted_by_all_reduce_of_ones"], args.gpus))
 
     # The top-level line is configs[1] at every N (a 1 -> 8 curve must compare one workload with itself).
     workload = "count" if args.workload == "auto" else args.workload
@@ -651,7 +708,7 @@ def main():
                                        "offset-cell images -- a chromosome has one target per ~300 coordinates -- un-permute); slowest rank", "kernel_ms": g["kernel_ms_slowest_rank"],
                              "algorithmic_bytes_per_launch": alg, "peak_note": "n_gpus x 8 TB/s",
                              "timed_with": "HIP events on the launch stream around every rank's chromosomes; the slowest rank's mean"},
-                "collective": g["collective"], "parity": g["parity"], "index_build_s": g["build_s"], "device": name.value.decode(),
+                "collective": dict(coll, per_step=g["collective"]), "parity": g["parity"], "index_build_s": g["build_s"], "device": name.value.decode(),
             }
             for k in ("single_gpu_same_run", "speedup_vs_1gpu"):
                 if k in g:
@@ -709,7 +766,7 @@ def main():
         if ev:
             ev[1].record()
         if world > 1 and args.allreduce_total:
-            dist.all_reduce(slot)  # RCCL over xGMI: 8 bytes, the path's only collective
+            all_reduce(dist, slot)  # RCCL over xGMI: 8 bytes, the path's only collective
 
     for _ in range(args.warmup):
         step()
@@ -726,7 +783,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(dist, t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
 
@@ -739,6 +796,15 @@ def main():
     parity = "sum-of-counts == total: %s" % sum_ok
     if world == 1:
         parity += "; every timed step produced that total: %s" % bool((totals[: args.steps + args.warmup] == local_total).all().item())
+    job_total = local_total
+    if world > 1:
+        # every rank's own total, summed by the collective: what each timed step's all-reduced slot must hold
+        lt = torch.tensor([local_total], dtype=torch.int64, device="cuda")
+        all_reduce(dist, lt)
+        job_total = int(lt.item())
+        if args.allreduce_total:
+            parity += "; every timed step's all-reduced total == sum of the ranks' totals: %s" % bool(
+                (totals[: args.steps + args.warmup] == job_total).all().item())
     golden_path = os.path.join(ROOT, "tests", "golden", "scale.json")
     if rank == 0 and args.queries == 100_000_000 and args.targets == 10_000_000 and os.path.exists(golden_path):
         pt = json.load(open(golden_path))["points"].get("10M x 1M (cfg2 subsample)")
@@ -899,6 +965,7 @@ def main():
         "total_only": total_only,
         "parity": parity,
         "overlaps_per_step_rank0": local_total,
+        "overlaps_per_step_all_ranks": job_total,
         "device": name.value.decode(),
     }
     # HBM bytes per launch from the PMC counters: taken in their own rocprofv3 runs (tools/profile.sh), so this run can only
@@ -962,6 +1029,11 @@ def main():
             line["genome"] = {"error": repr(ex)}
     if genome_leg is not None:
         line["genome"] = genome_leg
+        # configs[3] is the strong-scaling leg: the same genome on rank 0 alone, in this run, is what it is measured against
+        line["speedup_vs_1gpu"] = genome_leg.get("speedup_vs_1gpu")
+    line["collective"] = coll
+    if dry:
+        line["dry_run"] = "BENCH_DRY_MULTI=1: every rank on cuda:0, gloo instead of RCCL -- a rehearsal of the code path, not a measurement"
     if world == 1 and not args.no_find:
         try:
             torch.cuda.empty_cache()

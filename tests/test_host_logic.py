@@ -494,3 +494,27 @@ def test_offset_cells_encoding_and_unit_model(tmp_path):
                            os.path.join(ROOT, "tests", "cpp", "offset_cells_test.cpp"), "-o", exe])
     out = subprocess.check_output([exe], text=True, timeout=300)
     assert out.strip().endswith("offset cells ok"), out
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` launches its own N ranks (the driver's command shape carries no launcher); with fewer than N
+    devices visible it must exit non-zero with a message, never run one rank and print n_gpus 1."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_DRY_MULTI"):
+        env.pop(k, None)
+    import torch
+
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 7
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert "refusing to run fewer ranks than asked" in p.stderr, p.stderr[-2000:]
+    assert not p.stdout.strip(), p.stdout[-500:]   # no bench line for a job that did not run
+
+
+def test_bench_refuses_a_launcher_of_another_size():
+    """WORLD_SIZE from a launcher that disagrees with --gpus: no line for a job of another size."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr, p.stderr[-2000:]
