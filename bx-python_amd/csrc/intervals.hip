@@ -4398,7 +4398,11 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
         if (total_host) *total_host = 0;
         return BXMI_OK;
     }
-    if (!h->has_reversed && h->n > 0 && (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_partition_min && h->n >= 4096)))
+    // The batch passes read the queries 16 bytes per lane: a query array that is not aligned for that (a slice of a device
+    // array; legal per bxmi.h) is answered by the direct kernels below, which read it element by element.
+    const bool q_aligned = ((((uintptr_t)qs | (uintptr_t)qe) & 15) == 0);
+    if (q_aligned && !h->has_reversed && h->n > 0 &&
+        (g_opt_partition == 1 || (g_opt_partition < 0 && nq >= g_opt_partition_min && h->n >= 4096)))
     {
         if (g_opt_sorted_path) {
             // one cheap look at the starts decides the path on the host (find() synchronises for the total anyway)
@@ -4421,7 +4425,7 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
             if (!unsorted) return ivl_find_local(h, qs, qe, nq, offsets, hits, cap, total_host, st);
         }
         if (g_opt_find_sliced && g_opt_bitmap != 0 && g_opt_slice != 0 && h->n >= 4096 && nq >= g_opt_bitmap_min &&
-            !(((uintptr_t)qs | (uintptr_t)qe) & 15)) {
+            !((uintptr_t)offsets & 15)) {  // (fx_offsets / fx_hits_copy2 store the offsets 16 bytes at a time)
             if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
             if (h->sl_state == 1 && g_opt_fx_fill) {
                 if (h->fx_state == 0) BXMI_TRY(fx_prepare_index(h, st));

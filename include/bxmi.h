@@ -184,6 +184,10 @@ int bxmi_ivl_order_state(const bxmi_ivl_t *h, int *skipping, int64_t *answers_se
  * part of the list that fits may already have been written to the device buffer). */
 int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,
                   int32_t *hits, int64_t cap, int64_t *total);
+/* bxmi_ivl_find_dev: device pointers of any natural alignment (4 bytes for qs / qe / hits, 8 for offsets) are legal; the
+ * batch passes need qs, qe and offsets on 16-byte boundaries (what every allocator hands out) and a slice that is not is
+ * answered by the direct tree kernels instead -- same results, ~8 x slower.  Blocks until the offsets and the total are
+ * known (one stream synchronisation); the hits may still be in flight on `stream` when it returns. */
 int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,
                       int32_t *hits, int64_t cap, int64_t *total_host, void *stream);
 
