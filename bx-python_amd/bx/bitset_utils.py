@@ -19,7 +19,24 @@ def list2bits(ex):
 def _runs_from(bits, begin):
     """The maximal runs of set bits that end after `begin`, in order, as two lists; the first one is clipped to `begin`
     exactly as next_set(begin) would report it."""
-    rs, re = bits.runs(begin) if begin < bits.size else ([], [])
+    if begin >= bits.size:
+        return [], []
+    runs = getattr(bits, "runs", None)
+    if runs is None:
+        # any next_set / next_clear duck type (the flat bx.bitset.BitSet): the reference's own walk, lib/bx/bitset_utils.py:35-44
+        rs, re, pos = [], [], begin
+        while True:
+            s = bits.next_set(pos)
+            if s >= bits.size:
+                break
+            e = bits.next_clear(s)
+            rs.append(int(s))
+            re.append(int(e))
+            if e >= bits.size:
+                break
+            pos = e
+        return rs, re
+    rs, re = runs(begin)
     return [int(x) for x in rs], [int(x) for x in re]
 
 
@@ -96,4 +113,7 @@ def bitset_interval_intersect(bits, istart, iend):
     # of the set, where next_set raises
     if pos >= bits.size:
         bits.next_set(pos)
+    if iend > bits.size:
+        # next_set answered `size`, which is still below iend: the reference goes on to next_clear(size) -- IndexError
+        bits.next_clear(bits.size)
     return rval

@@ -86,7 +86,7 @@ __device__ __forceinline__ bool bm_probe_descent(const int32_t *__restrict__ qs,
 #pragma unroll
     for (int part = 1; part <= 2; part++) {
         const int64_t at = ((nq / 3 * part) & ~(int64_t)15) + 16 * (int64_t)threadIdx.x;
-        if (at + 17 <= nq) {
+        if (threadIdx.x < 256 && at + 17 <= nq) {  // (256 threads look; a wider workgroup joins the barrier only)
             const int4 *p = reinterpret_cast<const int4 *>(qs + at);
             const int4 a = p[0], b = p[1], d = p[2], e = p[3];
             const int nxt = qs[at + 16];
@@ -104,19 +104,62 @@ __global__ __launch_bounds__(256) void bm_probe_kernel(const int32_t *__restrict
     if (threadIdx.x == 0) *answer = d ? 1u : 0u;
 }
 
+// Where the parameter block of a batch goes (device memory), and what is zeroed with it.
+struct BmParOut {
+    BmSeg *segs;
+    unsigned long long **totals;
+    unsigned short *tile_seg;
+    unsigned long long *zero_u64;  // the segments' partial totals, the order flag, the item counters
+    int n_zero;
+    int *n_items;
+    unsigned *probe;               // NULL, or where the order probe leaves "descent seen"
+    unsigned long long *order_host;  // ... and, in host memory for the next calls, (order_seq << 1) | descent seen
+    unsigned long long order_seq;
+};
+
+// A batch of at most BM_PAR_CHUNK segments whose first kernel is the tile sort (no order check in front of it) needs no
+// parameter kernel: the tile sort takes the segments BY VALUE, every workgroup finds its own in the kernel arguments, and the
+// first workgroup writes the block for the kernels behind it (they start after the tile sort has ended), zeroes what they
+// accumulate into and asks the order probe -- bm_params_kernel's work, 5.7 us of launch on a 0.67 ms pass (a quarter of an
+// eight-GPU share's fixed costs), on the side of one workgroup of 3052.
+__device__ __forceinline__ void bm_write_params(const BmSegChunk &c, int npar, const BmParOut &po)
+{
+    const int T = (int)blockDim.x;
+    for (int i = threadIdx.x; i < po.n_zero; i += T) po.zero_u64[i] = 0ull;
+    if (threadIdx.x == 0) *po.n_items = 0;
+    if (po.probe) {
+        const bool d = bm_probe_descent(c.seg[0].qs, c.seg[0].nq);
+        if (threadIdx.x == 0) {
+            if (d) *po.probe = 1u;  // (behind the probe's barrier: after the zeroing above)
+            if (po.order_host) *po.order_host = (po.order_seq << 1) | (d ? 1ull : 0ull);
+        }
+    }
+    if ((int)threadIdx.x < npar) {
+        po.segs[threadIdx.x] = c.seg[threadIdx.x];
+        po.totals[threadIdx.x] = c.total[threadIdx.x];
+    }
+    for (int i = 0; i < npar; i++)
+        for (int64_t t = c.seg[i].tile0 + threadIdx.x; t < c.seg[i].tile_end; t += T) po.tile_seg[t] = (unsigned short)i;
+}
+
 // The first launch of a batch also zeroes what the later kernels accumulate into (the segments' partial totals with the
 // order flag behind them, the plan's item count): two memsets less on the stream.
 __global__ __launch_bounds__(256) void bm_params_kernel(BmSegChunk c, int first, BmSeg *__restrict__ segs, unsigned long long **__restrict__ totals,
                                                         unsigned short *__restrict__ tile_seg, unsigned long long *__restrict__ zero_u64, int n_zero,
-                                                        int *__restrict__ n_items, unsigned *__restrict__ probe = nullptr)
+                                                        int *__restrict__ n_items, unsigned *__restrict__ probe = nullptr,
+                                                        unsigned long long *__restrict__ order_host = nullptr, unsigned long long order_seq = 0)
 {
     if (first == 0 && blockIdx.x == 0) {
         for (int i = threadIdx.x; i < n_zero; i += 256) zero_u64[i] = 0ull;
         if (threadIdx.x == 0) *n_items = 0;
         if (probe) {
             // No order check in this pass (bm_count_segments stopped launching it after shuffled batches): a PROBE instead.
-            // *probe (zeroed above) = 1: descent seen.
-            if (bm_probe_descent(c.seg[0].qs, c.seg[0].nq) && threadIdx.x == 0) *probe = 1u;  // (behind its barrier: after the zeroing above)
+            // *probe (zeroed above) = 1: descent seen; the same into host memory, for the next calls on the handle.
+            const bool d = bm_probe_descent(c.seg[0].qs, c.seg[0].nq);
+            if (threadIdx.x == 0) {
+                if (d) *probe = 1u;  // (behind the probe's barrier: after the zeroing above)
+                if (order_host) *order_host = (order_seq << 1) | (d ? 1ull : 0ull);
+            }
         }
     }
     const BmSeg &sg = c.seg[blockIdx.x];
@@ -277,8 +320,9 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
                                                                unsigned short *__restrict__ slots /* [nq] slot of every query in its tile */,
                                                                unsigned short *__restrict__ tbl /* [ntiles][BM_NB] first slot of every bucket */,
                                                                const unsigned *__restrict__ gate /* NULL, or 0 = sorted batch: stand down */,
-                                                               unsigned *__restrict__ tend = nullptr /* PAD: [ntiles] slots used */,
-                                                               unsigned short *__restrict__ tbl2 = nullptr /* SUB = 2: [ntiles][2 * BM_NB] first slot of every half bucket */)
+                                                               unsigned *__restrict__ tend /* PAD: [ntiles] slots used */,
+                                                               unsigned short *__restrict__ tbl2 /* SUB = 2: [ntiles][2 * BM_NB] first slot of every half bucket */,
+                                                               const BmSegChunk par, const int npar /* 0: segs / tile_seg are in memory already */, const BmParOut po)
 {
     constexpr int TILE = THREADS * ITEMS;
     if (gate && *gate == 0) return;
@@ -294,12 +338,25 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
     unsigned short *toff = reinterpret_cast<unsigned short *>(cnt + NBK);          // [NBK]
     unsigned *scan_tmp = reinterpret_cast<unsigned *>(toff + NBK);                 // [16]
     const int64_t tile = blockIdx.x;
-    const BmSeg &sg = segs[tile_seg[tile]];
-    const int64_t ltile = tile - sg.tile0;
-    if (ltile >= sg.ntiles) return;  // padding up to the next plan group
-    const BmGeom g = sg.g;
-    const int32_t *__restrict__ qs = sg.qs + ltile * TILE, *__restrict__ qe = sg.qe + ltile * TILE;  // this tile's queries
-    const int64_t nq = sg.nq - ltile * TILE;
+    BmGeom g;
+    const int32_t *__restrict__ qs, *__restrict__ qe;  // this tile's queries
+    int64_t nq, ltile, ntiles_seg;
+    if (npar) {
+        if (blockIdx.x == 0) bm_write_params(par, npar, po);  // (nothing below depends on it: later kernels read the block)
+        int i = 0;
+        while (i + 1 < npar && tile >= par.seg[i].tile_end) i++;
+        g = par.seg[i].g;
+        ltile = tile - par.seg[i].tile0, ntiles_seg = par.seg[i].ntiles;
+        qs = par.seg[i].qs + ltile * TILE, qe = par.seg[i].qe + ltile * TILE;
+        nq = par.seg[i].nq - ltile * TILE;
+    } else {
+        const BmSeg &sg = segs[tile_seg[tile]];
+        g = sg.g;
+        ltile = tile - sg.tile0, ntiles_seg = sg.ntiles;
+        qs = sg.qs + ltile * TILE, qe = sg.qe + ltile * TILE;
+        nq = sg.nq - ltile * TILE;
+    }
+    if (ltile >= ntiles_seg) return;  // padding up to the next plan group
     recs += tile * STRIDE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
     const int64_t base = 0;
     const int n = (int)(nq < TILE ? nq : TILE);
@@ -810,13 +867,8 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
 
 // the segments' partial totals, folded into the caller's int64 per segment (accumulated, like bxmi_ivl_count_dev's total)
 __global__ void bm_fold_totals_kernel(const unsigned long long *__restrict__ slots /* [segments][PT_SLOTS] */,
-                                      unsigned long long *const *__restrict__ totals /* [segments] */,
-                                      const unsigned *__restrict__ probe = nullptr, unsigned long long *__restrict__ order_host = nullptr,
-                                      unsigned long long seq = 0)
+                                      unsigned long long *const *__restrict__ totals /* [segments] */)
 {
-    // (what the probe of bm_params_kernel saw, into host memory for the next calls: see bm_count_segments)
-    if (order_host && blockIdx.x == 0 && threadIdx.x == 0) *order_host = (seq << 1) | (*probe != 0 ? 1ull : 0ull);
-    if (!totals) return;
     unsigned long long v = threadIdx.x < PT_SLOTS ? slots[(int64_t)blockIdx.x * PT_SLOTS + threadIdx.x] : 0ull;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

@@ -556,24 +556,44 @@ __global__ __launch_bounds__(256) void bd_transpose_kernel(const unsigned short 
     }
 }
 
-// The plan of a batch of ONE index (bm_plan_kernel<2> walks every column twice, three dependent batches of loads each
-// time, from eight workgroups that reserve their room with an atomic: 20 us for 100 M queries).  One workgroup, a thread
-// per unit, the column's group counts pulled 16 at a time with independent loads, the items of a unit kept in registers
-// (up to six; a unit cut into more is walked a second time), one block scan for their places: units stay in order, which
-// is what the search's XCD-aware item mapping wants.
-// items[i] = {unit, first tile, last tile + 1, queries}; *n_items = number of items.
-__global__ __launch_bounds__(1024) void bd_plan_kernel(const unsigned *__restrict__ unitcnt /* [ngroups][BM_NB] */, int ngroups, int nunits,
-                                                       const BmSeg *__restrict__ segs, int chunk, int4 *__restrict__ items, int *__restrict__ n_items,
-                                                       const unsigned *__restrict__ gate)
+// The plan of a batch over up to BD_PLAN_SEGS indexes (bm_plan_kernel<2> walks every column twice, three dependent batches of loads
+// each time, from eight workgroups that reserve their room with an atomic: 20 us for 100 M queries, 13 us for a rank's three
+// chromosomes).  One workgroup; a thread per (segment, unit), the column's group counts of ITS segment pulled 16 at a time with
+// independent loads, the items of a unit kept in registers (up to six; a unit cut into more is walked a second time), one
+// block scan for their places: segments and units stay in order, which is what the search's XCD-aware item mapping wants.
+// items[i] = {unit | segment << 16, first tile, last tile + 1, queries}; *n_items = number of items.
+// (Tried in round 6: run table and plan in ONE launch, the plan made by the workgroup that draws the last ticket, the unit
+// counts written through as agent-scope atomics -- 21.5 us against 8.2 + 10.3 for one index: every workgroup waits for its
+// stores and a returning atomic, and the planner reads the counts from beyond the L2.  With __threadfence() instead: 153 us --
+// an agent-scope release writes the XCD's whole L2 back.)
+constexpr int BD_PLAN_SEGS = 16;
+__global__ __launch_bounds__(1024) void bd_plan_kernel(const unsigned *__restrict__ unitcnt /* [ngroups][BM_NB] */, int n_segs, const BmSeg *__restrict__ segs,
+                                                       int chunk, int4 *__restrict__ items, int *__restrict__ n_items, const unsigned *__restrict__ gate)
 {
     __shared__ int scan_tmp[16];
+    __shared__ int s_first[BD_PLAN_SEGS + 1], s_glo[BD_PLAN_SEGS], s_ghi[BD_PLAN_SEGS], s_tlast[BD_PLAN_SEGS];
     if (gate && *gate == 0) return;
-    const int t_last = (int)(segs[0].tile0 + segs[0].ntiles);
+    if (threadIdx.x == 0) {
+        int at = 0;
+        for (int i = 0; i < n_segs; i++) {
+            s_first[i] = at;
+            at += segs[i].tile_end > segs[i].tile0 ? (BM_NB >> segs[i].g.f) : 0;  // (an index without queries in this batch: no units)
+            s_glo[i] = (int)(segs[i].tile0 / BM_GROUP_TILES), s_ghi[i] = (int)(segs[i].tile_end / BM_GROUP_TILES);
+            s_tlast[i] = (int)(segs[i].tile0 + segs[i].ntiles);
+        }
+        s_first[n_segs] = at;
+    }
+    __syncthreads();
+    const int total_units = s_first[n_segs];
     int carry = 0;
-    for (int u0 = 0; u0 < nunits; u0 += 1024) {
-        const int u = u0 + (int)threadIdx.x;
-        const bool live = u < nunits;
-        const unsigned *__restrict__ col = unitcnt + (live ? u : 0);
+    for (int j0 = 0; j0 < total_units; j0 += 1024) {
+        const int j = j0 + (int)threadIdx.x;
+        const bool live = j < total_units;
+        int seg = 0;
+        while (seg + 1 < n_segs && (live ? j : 0) >= s_first[seg + 1]) seg++;
+        const int u = live ? j - s_first[seg] : 0;
+        const int g_lo = s_glo[seg], ng = live ? s_ghi[seg] - g_lo : 0, t_last = s_tlast[seg];
+        const unsigned *__restrict__ col = unitcnt + (int64_t)g_lo * BM_NB + u;
         int fb[6], fe[6];
         unsigned fq[6];
         int cnt = 0;
@@ -582,34 +602,34 @@ __global__ __launch_bounds__(1024) void bd_plan_kernel(const unsigned *__restric
             int g_first = 0, k = 0;
             auto close = [&](int g_end) {
                 if (emit) {
-                    const int t_end = g_end * BM_GROUP_TILES;
-                    items[at + k] = make_int4(u, g_first * BM_GROUP_TILES, t_end < t_last ? t_end : t_last, (int)acc);
+                    const int t_end = (g_lo + g_end) * BM_GROUP_TILES;
+                    items[at + k] = make_int4(u | (seg << 16), (g_lo + g_first) * BM_GROUP_TILES, t_end < t_last ? t_end : t_last, (int)acc);
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 6; j++)
-                        if (k == j) fb[j] = g_first, fe[j] = g_end, fq[j] = acc;
+                    for (int i = 0; i < 6; i++)
+                        if (k == i) fb[i] = g_first, fe[i] = g_end, fq[i] = acc;
                 }
                 k++;
                 acc = 0;
             };
-            for (int g0 = 0; g0 < ngroups; g0 += 16) {
+            for (int g0 = 0; g0 < ng; g0 += 16) {
                 unsigned v[16];
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    const int gi = g0 + i < ngroups ? g0 + i : ngroups - 1;  // a valid address: no branch around the loads
+                    const int gi = g0 + i < ng ? g0 + i : ng - 1;  // a valid address: no branch around the loads
                     v[i] = col[(int64_t)gi * BM_NB];
                 }
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const int gi = g0 + i;
-                    if (gi >= ngroups) break;
-                    const unsigned c = live ? v[i] : 0u;
+                    if (gi >= ng) break;
+                    const unsigned c = v[i];
                     if (acc > 0 && acc + c > (unsigned)chunk) close(gi);
                     if (acc == 0) g_first = gi;
                     acc += c;
                 }
             }
-            if (acc > 0) close(ngroups);
+            if (acc > 0) close(ng);
             return k;
         };
         cnt = walk(false, 0);
@@ -617,10 +637,10 @@ __global__ __launch_bounds__(1024) void bd_plan_kernel(const unsigned *__restric
         const int at = carry + block_exclusive_scan(cnt, OpSum(), 0, scan_tmp, &tot);
         if (cnt <= 6) {
 #pragma unroll
-            for (int j = 0; j < 6; j++)
-                if (j < cnt) {
-                    const int t_end = fe[j] * BM_GROUP_TILES;
-                    items[at + j] = make_int4(u, fb[j] * BM_GROUP_TILES, t_end < t_last ? t_end : t_last, (int)fq[j]);
+            for (int i = 0; i < 6; i++)
+                if (i < cnt) {
+                    const int t_end = (g_lo + fe[i]) * BM_GROUP_TILES;
+                    items[at + i] = make_int4(u | (seg << 16), (g_lo + fb[i]) * BM_GROUP_TILES, t_end < t_last ? t_end : t_last, (int)fq[i]);
                 }
         } else {
             (void)walk(true, at);
@@ -1769,14 +1789,15 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(const BmSeg *__restric
 // ---------------------------------------------------------------------------
 // bm_unpermute_kernel for 16-bit counts: half the bytes to read, half the LDS (two workgroups share a CU).
 // 0xFFFF = recompute from the sealed index (escape records, counts of 65535 and more).
-template <int THREADS, int ITEMS, bool PAD = false, bool W8 = false>
-__global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned short *__restrict__ cnt /* tile-sorted; W8: bytes */,
-                                                               const unsigned short *__restrict__ slots, const BmSeg *__restrict__ segs,
-                                                               const unsigned short *__restrict__ tile_seg,
-                                                               unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS], may be NULL */,
-                                                               const unsigned *__restrict__ gate, const unsigned *__restrict__ tend = nullptr,
-                                                               unsigned long long *__restrict__ fb_dev = nullptr /* W8: counts that did not fit, ever */,
-                                                               unsigned long long *__restrict__ fb_host = nullptr /* its copy in host memory */)
+template <int THREADS, int ITEMS, bool PAD, bool W8>
+__device__ __forceinline__ void bd_unpermute_tile(const unsigned short *__restrict__ cnt /* tile-sorted; W8: bytes */,
+                                                  const unsigned short *__restrict__ slots, const BmSeg *__restrict__ segs,
+                                                  const unsigned short *__restrict__ tile_seg,
+                                                  unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS], may be NULL */,
+                                                  const unsigned *__restrict__ gate, const unsigned *__restrict__ tend,
+                                                  unsigned long long *__restrict__ fb_dev /* W8: counts that did not fit, ever */,
+                                                  unsigned long long *__restrict__ fb_host /* its copy in host memory */,
+                                                  unsigned long long *const *__restrict__ direct)
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int STRIDE = PAD ? TILE + BM_PAD_ROOM : TILE;  // slots between two tiles of the count array (PAD: gaps between the units)
@@ -1790,6 +1811,8 @@ __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned sh
     const BmSeg &sg = segs[seg_id];
     const int64_t ltile = tile - sg.tile0;
     if (ltile >= sg.ntiles) return;  // padding up to the next plan group
+    // where this tile's sum goes: the caller's word of its segment, or one of the segment's partial totals (folded later)
+    unsigned long long *const acc_to = direct ? direct[seg_id] : (total_slots ? total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)) : nullptr);
     const IndexDev ix = sg.ix;
     const BmGeom g = sg.g;
     const int32_t *__restrict__ e_sorted = sg.e_sorted;
@@ -1858,8 +1881,7 @@ __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned sh
         }
         __syncthreads();
         if (s_tot[1] == tend[tile] - (unsigned)n) {  // (block-uniform) every 0xFF is padding
-            if (total_slots && threadIdx.x == 0 && s_tot[0])
-                atomicAdd(total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)), (unsigned long long)s_tot[0]);
+            if (acc_to && threadIdx.x == 0 && s_tot[0]) atomicAdd(acc_to, (unsigned long long)s_tot[0]);
             return;
         }
     }
@@ -1902,7 +1924,7 @@ __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned sh
             acc += c;
         }
     }
-    if (total_slots) block_accumulate_i64(acc, red, total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)));
+    if (acc_to) block_accumulate_i64(acc, red, acc_to);
     if (W8 && fb_dev) {
         // feedback for the host's choice of the count width (bm_count_segments): a running total of the counts that did
         // not fit 8 bits, and -- from whichever workgroup comes first -- its value so far into host memory, where the
@@ -1915,6 +1937,22 @@ __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned sh
         }
         if (blockIdx.x == 0 && threadIdx.x == 0 && fb_host) *fb_host = __hip_atomic_load(fb_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// The kernel: a workgroup per tile.  `direct` set: a workgroup adds its tile's sum straight to the caller's int64 of the tile's
+// segment (one fire-and-forget atomic per workgroup) instead of to one of the segment's 64 partial totals -- no fold behind the
+// kernel (bm_fold_totals_kernel: 4.5 us of launch) and nothing for a workgroup to wait for.  (Tried first: the partial totals kept,
+// folded by the workgroup that draws the last ticket -- every workgroup then waits for its stores and a returning atomic while it
+// holds half a CU: 123 -> 147 us.)
+template <int THREADS, int ITEMS, bool PAD = false, bool W8 = false>
+__global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned short *__restrict__ cnt, const unsigned short *__restrict__ slots,
+                                                               const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
+                                                               unsigned long long *__restrict__ total_slots, const unsigned *__restrict__ gate,
+                                                               const unsigned *__restrict__ tend, unsigned long long *__restrict__ fb_dev,
+                                                               unsigned long long *__restrict__ fb_host,
+                                                               unsigned long long *const *__restrict__ direct /* [segments], or NULL */)
+{
+    bd_unpermute_tile<THREADS, ITEMS, PAD, W8>(cnt, slots, segs, tile_seg, total_slots, gate, tend, fb_dev, fb_host, direct);
 }
 
 }  // namespace bxmi

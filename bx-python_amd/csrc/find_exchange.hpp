@@ -73,21 +73,29 @@ struct FxPiece {
 // Exclusive scan of the tiles' hit totals (one workgroup): tile_base[t] = hits of the tiles before t, tile_base[ntp] = all
 // hits, also written to the caller's offsets[nq].
 __global__ __launch_bounds__(1024) void fx_tile_scan_kernel(const unsigned long long *__restrict__ tile_tot, int64_t ntp, long long *__restrict__ tile_base,
-                                                            long long *__restrict__ grand_total)
+                                                            long long *__restrict__ grand_total, long long *__restrict__ max_tile = nullptr)
 {
     __shared__ long long lds[16];
-    long long carry = 0;
+    __shared__ unsigned long long s_max;
+    if (threadIdx.x == 0) s_max = 0ull;
+    long long carry = 0, mine = 0;
     for (int64_t base = 0; base < ntp; base += 1024) {
         const int64_t i = base + threadIdx.x;
         const long long v = i < ntp ? (long long)tile_tot[i] : 0ll;
+        mine = v > mine ? v : mine;
         long long total;
         const long long exc = block_exclusive_scan(v, OpSum(), 0ll, lds, &total);
         if (i < ntp) tile_base[i] = carry + exc;
         carry += total;
     }
+    // the largest tile total rides behind the grand total: the prefixes INSIDE a tile are 31-bit (bit 31 marks an escape), so a
+    // tile with 2^31 hits or more sends the batch to the bucketed find (ivl_find_fx)
+    if (max_tile && mine) atomicMax(&s_max, (unsigned long long)mine);
+    __syncthreads();
     if (threadIdx.x == 0) {
         tile_base[ntp] = carry;
         if (grand_total) *grand_total = carry;
+        if (max_tile) *max_tile = (long long)s_max;
     }
 }
 

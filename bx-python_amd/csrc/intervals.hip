@@ -3164,6 +3164,12 @@ struct BmLaunch {
     bool wide = false; // the cell images are offset cells (sparse indexes)
     unsigned *descent = nullptr;  // no order check in this pass: bm_params_kernel's probe raises this word when it sees a descent
     unsigned *xcd_next = nullptr;  // eight item counters of the persistent search, zeroed with the partial totals
+    // the parameter block written by the tile sort's first workgroup (count_bitmap.hpp: bm_write_params) instead of bm_params_kernel
+    BmSegChunk par;
+    int npar = 0;
+    BmParOut par_out;
+    unsigned long long *const *totals = nullptr;  // device: the callers' int64 words, one per segment, when the un-permute kernel adds to them itself
+    int n_segs = 1;
 };
 
 template <int THREADS, int ITEMS>
@@ -3179,7 +3185,7 @@ static int bm_launch_tiles(const BmLaunch &L, hipStream_t st, bool sub = false)
         BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<T2, I2, false, 2>), lds));
         hipLaunchKernelGGL((bm_tile_sort_kernel<T2, I2, false, 2>), dim3((unsigned)L.ntp), dim3(T2), lds, st, L.segs, L.tile_seg,
                            h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, (unsigned *)nullptr,
-                           h->fx_tbl2.as<unsigned short>());
+                           h->fx_tbl2.as<unsigned short>(), L.par, L.npar, L.par_out);
         BXMI_LAUNCH_CHECK();
         return BXMI_OK;
     }
@@ -3187,12 +3193,14 @@ static int bm_launch_tiles(const BmLaunch &L, hipStream_t st, bool sub = false)
         const size_t lds = (size_t)(TILE + 3 * THREADS) * 4 + BM_NB * 4 + BM_NB * 2 + 64;
         BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, true>), lds));
         hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
-                           h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, h->bd_tend.as<unsigned>());
+                           h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, h->bd_tend.as<unsigned>(),
+                           (unsigned short *)nullptr, L.par, L.npar, L.par_out);
     } else {
         const size_t lds = (size_t)TILE * 4 + BM_NB * 4 + BM_NB * 2 + 64;
         BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, false>), lds));
         hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, false>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
-                           h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, (unsigned *)nullptr);
+                           h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, (unsigned *)nullptr,
+                           (unsigned short *)nullptr, L.par, L.npar, L.par_out);
     }
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
@@ -3360,22 +3368,25 @@ template <int THREADS, int ITEMS>
 static int bd_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
+    unsigned long long *const *fold = L.totals;  // set: the tiles' sums go straight to the callers' totals (slots unused)
     if (L.pad && L.w8) {
         const size_t lds = (size_t)(THREADS * ITEMS + BM_PAD_ROOM);
         BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, true, true>), lds));
         hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, true, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
                            h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, h->bd_tend.as<unsigned>(),
-                           h->bd_fb.as<unsigned long long>(), h->bd_fb_host);
+                           h->bd_fb.as<unsigned long long>(), h->bd_fb_host, fold);
     } else if (L.pad) {
         const size_t lds = (size_t)(THREADS * ITEMS + BM_PAD_ROOM) * sizeof(unsigned short);
         BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, true>), lds));
         hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
-                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, h->bd_tend.as<unsigned>());
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, h->bd_tend.as<unsigned>(),
+                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, fold);
     } else {
         const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned short);
         BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, false>), lds));
         hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, false>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
-                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, (const unsigned *)nullptr);
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, (const unsigned *)nullptr,
+                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, fold);
     }
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
@@ -3506,7 +3517,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY(h->fx_svq.reserve((size_t)ntp * tile * 4));
         BXMI_TRY(h->fx_parts.reserve((size_t)ntp * (tile / BM_PART_Q) * 8));
         BXMI_TRY(h->fx_tile_tot.reserve((size_t)ntp * 8));
-        BXMI_TRY(h->fx_tile_base.reserve((size_t)(ntp + 1) * 8));
+        BXMI_TRY(h->fx_tile_base.reserve((size_t)(ntp + 2) * 8));  // (+ the grand total, + the largest tile total)
         fx->f = segs[0].g.f;
         fx->ntiles = segs[0].ntiles;
     }
@@ -3516,6 +3527,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     const size_t tile_off = (seg_bytes + tot_bytes + 15) & ~(size_t)15, par_bytes = tile_off + (size_t)ntp * sizeof(unsigned short);
     BXMI_TRY(h->bm_params.reserve(par_bytes));
     // [segments][PT_SLOTS partial totals], then the flag: 1 = the starts are NOT sorted
+    // ([+0] the order flag, [+4 .. +8) the search's item counters)
     BXMI_TRY(h->p_slots.reserve(((size_t)n * PT_SLOTS + 8) * sizeof(unsigned long long)));
     unsigned long long *slots = h->p_slots.as<unsigned long long>();
     // (several indexes: only the walk on cell images has a sorted-batch form over segments)
@@ -3523,7 +3535,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     for (int i = 0; i < n && multi_sorted; i++) multi_sorted = nq[i] < ((int64_t)1 << 32) - 8;
     unsigned *unsorted = g_opt_sorted_path && (n == 1 || multi_sorted) && !fx ? reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS) : nullptr;
     // The order check and the stand-down of the sorted-batch kernel cost a shuffled batch 24 us (of 750).  What the order
-    // checks find is mirrored into host memory (ivl_local_count_kernel / bm_fold_totals_kernel write it, nobody waits for
+    // checks find is mirrored into host memory (ivl_local_count_kernel, bs_walk_kernel or the workgroup that runs the probe write it, nobody waits for
     // it): after two batches in a row that were NOT sorted the check is no longer launched -- every kernel of the exchange
     // runs unconditionally -- and a PROBE rides on the parameter kernel instead: 8192 consecutive starts; a descent among
     // them says "shuffled" for certain, none brings the exact check back with the next call.  A sorted batch that arrives
@@ -3552,7 +3564,27 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         order_seq = ++h->order_seq;
         if (h->order_skip && g_opt_order_skip != 0) descent = unsorted, unsorted = nullptr;  // (the word is zeroed with the partial totals)
     }
-    for (int first = 0; first < n; first += BM_PAR_CHUNK) {
+    BmLaunch L;
+    memset(&L.par, 0, sizeof(L.par));
+    // Folded: whenever the tile sort is the batch's first kernel.  With the order check in front (a handle's first batches, sorted
+    // input) or more than BM_PAR_CHUNK segments (a whole genome on one GPU) the parameter kernel stays a launch of its own.
+    const bool fold_params = n <= BM_PAR_CHUNK && !unsorted;
+    const int n_zero = n * PT_SLOTS + 8;
+    if (fold_params) {
+        for (int i = 0; i < n; i++) {
+            L.par.seg[i] = segs[(size_t)i];
+            L.par.total[i] = totals_dev ? reinterpret_cast<unsigned long long *>(totals_dev[i]) : nullptr;
+        }
+        L.npar = n;
+        L.par_out.segs = h->bm_params.as<BmSeg>();
+        L.par_out.totals = reinterpret_cast<unsigned long long **>(h->bm_params.as<unsigned char>() + seg_bytes);
+        L.par_out.tile_seg = reinterpret_cast<unsigned short *>(h->bm_params.as<unsigned char>() + tile_off);
+        L.par_out.zero_u64 = slots, L.par_out.n_zero = n_zero;
+        L.par_out.n_items = h->bm_items.as<int>();
+        L.par_out.probe = descent;
+        L.par_out.order_host = descent ? h->bd_fb_host + 1 : nullptr, L.par_out.order_seq = order_seq;
+    }
+    for (int first = 0; first < n && !fold_params; first += BM_PAR_CHUNK) {
         BmSegChunk c;
         memset(&c, 0, sizeof(c));
         const int cnt = n - first < BM_PAR_CHUNK ? n - first : BM_PAR_CHUNK;
@@ -3562,12 +3594,12 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         }
         hipLaunchKernelGGL(bm_params_kernel, dim3((unsigned)cnt), dim3(256), 0, st, c, first, h->bm_params.as<BmSeg>(),
                            reinterpret_cast<unsigned long long **>(h->bm_params.as<unsigned char>() + seg_bytes),
-                           reinterpret_cast<unsigned short *>(h->bm_params.as<unsigned char>() + tile_off), slots, n * PT_SLOTS + 8,
-                           h->bm_items.as<int>(), first == 0 ? descent : (unsigned *)nullptr);
+                           reinterpret_cast<unsigned short *>(h->bm_params.as<unsigned char>() + tile_off), slots, n_zero,
+                           h->bm_items.as<int>(), first == 0 ? descent : (unsigned *)nullptr, descent ? h->bd_fb_host + 1 : (unsigned long long *)nullptr,
+                           order_seq);
     }
     BXMI_LAUNCH_CHECK();
     unsigned long long *tslots = any_total ? slots : nullptr;
-    BmLaunch L;
     L.segs = h->bm_params.as<BmSeg>();
     L.tile_seg = reinterpret_cast<const unsigned short *>(h->bm_params.as<unsigned char>() + tile_off);
     L.owner = h;
@@ -3579,6 +3611,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.pad = pad;
     L.wide = wide;
     L.xcd_next = reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS + 4);
+    L.n_segs = n;
     // 8-bit counts (0xFF = recomputed by the un-permute kernel, exact either way): half the bytes of the second exchange
     // when the counts are small.  Cell images only serve indexes without piled-up coordinates, so the density says what to
     // expect: fewer than 128 targets per 2048 coordinates (configs[1]: 82; a count of 255 needs a query of ~6000).  What the
@@ -3697,9 +3730,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         hipLaunchKernelGGL(bd_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                            tile_log2, h->bd_unitT.as<unsigned short>(), ntp, h->sl_unitcnt.as<unsigned>(), unsorted,
                            pad ? h->bd_tend.as<unsigned>() : (const unsigned *)nullptr);
-        if (n == 1)
-            hipLaunchKernelGGL(bd_plan_kernel, dim3(1), dim3(1024), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, BM_NB >> segs[0].g.f, L.segs, chunk,
-                               h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
+        if (n <= BD_PLAN_SEGS)
+            hipLaunchKernelGGL(bd_plan_kernel, dim3(1), dim3(1024), 0, st, h->sl_unitcnt.as<unsigned>(), n, L.segs, chunk, h->bm_items.as<int4>() + 1,
+                               h->bm_items.as<int>(), unsorted);
         else
             hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg,
                                chunk, h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
@@ -3738,20 +3771,23 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY(bd_launch_search(L, sgrid, cells ? 1 : 0, any_blocks, st));
     unsigned *loff = fx ? h->sl_loff.as<unsigned>() : nullptr;
     stage_done("search");
+    // No sorted-batch kernels in front (they leave partial totals of their own): the un-permute kernel adds every tile's sum straight
+    // to the caller's total of its segment and the probe has reported to the host itself -- nothing is left to fold.
+    const bool direct_totals = dense && !fxsub && !unsorted;
+    L.totals = direct_totals && any_total ? reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes) : nullptr;
     if (dense && !fxsub) {
         if (variant == 2)
-            BXMI_TRY((bd_launch_unpermute<1024, 32>(L, tslots, st)));
+            BXMI_TRY((bd_launch_unpermute<1024, 32>(L, direct_totals ? nullptr : tslots, st)));
         else
-            BXMI_TRY((bd_launch_unpermute<1024, 16>(L, tslots, st)));
+            BXMI_TRY((bd_launch_unpermute<1024, 16>(L, direct_totals ? nullptr : tslots, st)));
     } else if (variant == 2)
         BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff, fxsub ? (fx->direct ? 3 : 2) : 0)));
     else
         BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff, fxsub ? (fx->direct ? 3 : 2) : 0)));
     stage_done("unpermute");
-    if (any_total || descent) {
+    if (any_total && !direct_totals) {
         hipLaunchKernelGGL(bm_fold_totals_kernel, dim3((unsigned)n), dim3(64), 0, st, slots,
-                           any_total ? reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes) : nullptr,
-                           (const unsigned *)descent, descent ? h->bd_fb_host + 1 : nullptr, order_seq);
+                           reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes));
         BXMI_LAUNCH_CHECK();
     }
     return BXMI_OK;
@@ -3831,7 +3867,7 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     const int64_t ntp = fx.L.ntp;
     // (only the tiles that hold queries: the un-permute kernel leaves the padding up to the plan group alone)
     hipLaunchKernelGGL(fx_tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->fx_tile_tot.as<unsigned long long>(), fx.ntiles, h->fx_tile_base.as<long long>(),
-                       reinterpret_cast<long long *>(offsets) + nq);
+                       reinterpret_cast<long long *>(offsets) + nq, h->fx_tile_base.as<long long>() + fx.ntiles + 1);
     BXMI_LAUNCH_CHECK();
     BXMI_TRY(fx_ensure_pieces(h, fx.f, st));
     BXMI_HIP(hipMemsetAsync(h->fx_work.p, 0, 64, st));
@@ -3845,6 +3881,14 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     BXMI_HIP(hipStreamSynchronize(st));
     if (total_host) *total_host = total;
     h->fx_hits_per_q = (double)total / (double)nq;
+    if (total >= ((int64_t)1 << 31)) {
+        // The scratch offsets inside a tile are 31-bit prefixes: a tile of 16 Ki / 32 Ki queries with 2^31 hits or more (queries
+        // that each cover a pile of targets) does not fit them.  Only a list this long can hold such a tile: one more word to read then.
+        long long max_tile = 0;
+        BXMI_HIP(hipMemcpyAsync(&max_tile, h->fx_tile_base.as<long long>() + fx.ntiles + 1, 8, hipMemcpyDeviceToHost, st));
+        BXMI_HIP(hipStreamSynchronize(st));
+        if (max_tile >= ((long long)1 << 31)) return ivl_find_partitioned(h, qs, qe, nq, offsets, hits, cap, total_host, st);
+    }
     if (total > cap && fx.direct) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     if (total > cap) {
         // (the contract: BXMI_ERANGE comes with valid offsets.  The copy kernel, which finishes them, does not run: scan the counts.)

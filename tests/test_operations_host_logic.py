@@ -29,7 +29,17 @@ class _OracleBits(O.OracleBinnedBitSet):
         self._check_range_count(start, count)
 
     def runs(self, start=0):
-        return O.OracleBinnedBitSet.runs(self)
+        """The engine's contract (bxmi.bitset.DeviceBitSet.runs): the runs that end after `start`, the first one clipped to it;
+        start == size gives none, anything else out of range raises like an index."""
+        if start == self.size:
+            return np.empty(0, np.int32), np.empty(0, np.int32)
+        self._check_index(start)
+        rs, re = O.OracleBinnedBitSet.runs(self)
+        keep = re > start
+        rs, re = rs[keep].copy(), re[keep].copy()
+        if len(rs) and rs[0] < start:
+            rs[0] = start
+        return rs, re
 
 
 class _OracleIndex:
@@ -299,3 +309,52 @@ def test_bitset_utils_host_logic(monkeypatch):
         assert call(bu.bitset_complement, b) == c["complement"], (k, "complement")
         lo, hi = c["window"]
         assert call(lambda: bu.bitset_interval_intersect(bu.list2bits(b), lo, hi)) == c["interval_intersect"], (k, "interval_intersect")
+
+
+def test_bitset_interval_intersect_windows_past_the_end_and_duck_types():
+    """bitset_interval_intersect on SMALL sets (the reference vectors are all MAX-sized): a window whose end lies beyond the set
+    raises what the reference's walk raises (next_set answers `size` < iend, next_clear(size) is an IndexError,
+    lib/bx/bitset_utils.py:73-85), negative / out-of-range starts raise, and an object that only has next_set / next_clear
+    (the flat BitSet) is walked the reference's way.  The run-list walk and the reference's loop agree on every case."""
+    import bx.bitset_utils as bu
+
+    class Plain:  # the reference's duck type: no runs()
+        def __init__(self, b):
+            self._b, self.size = b, b.size
+            self.next_set, self.next_clear = b.next_set, b.next_clear
+
+    def reference_walk(bits, istart, iend):  # lib/bx/bitset_utils.py:73-85, as written there
+        rval, end = [], istart
+        while True:
+            start = bits.next_set(end)
+            if start >= iend:
+                break
+            end = bits.next_clear(start)
+            if start != end:
+                rval.append((start, end))
+            if end >= iend:
+                break
+        return rval
+
+    def call(fn, *a):
+        try:
+            return ("ok", fn(*a))
+        except IndexError as e:
+            return ("IndexError", str(e))
+
+    rng = np.random.default_rng(77)
+    seen = set()
+    for _ in range(300):
+        size = int(rng.integers(50, 400))
+        b = _OracleBits(size, int(rng.choice([1, 3, 16, 1024])))
+        for _ in range(int(rng.integers(0, 6))):
+            s = int(rng.integers(0, size))
+            b.set_range(s, int(rng.integers(0, size - s + 1)))
+        lo = int(rng.integers(-3, size + 3))
+        hi = int(rng.integers(lo, size + 40))
+        want = call(reference_walk, b, lo, hi)
+        assert call(bu.bitset_interval_intersect, b, lo, hi) == want, (size, lo, hi)
+        assert call(bu.bitset_interval_intersect, Plain(b), lo, hi) == want, (size, lo, hi, "duck type")
+        seen.add((want[0], hi > size, lo < 0))
+        assert call(bu.bits2list, Plain(b)) == call(bu.bits2list, b)
+    assert ("IndexError", True, False) in seen and ("ok", False, False) in seen and ("IndexError", False, True) in seen

@@ -60,6 +60,12 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
 
     ms = timed(step)
     out[world] = dict(chromosomes=len(mine), queries=int(sum(x.numel() for x in qs)), ms=round(ms, 4))
+    if os.environ.get("PLAIN_ONLY"):  # (profiling runs: only the shuffled share's steady-state passes in the kernel list)
+        for ix in ixs:
+            ix.close()
+        del qs, qe, cnt
+        torch.cuda.empty_cache()
+        continue
     if comm is not None:
         def step_reduce():
             step()
@@ -82,6 +88,8 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
     torch.cuda.empty_cache()
 base = out[min(out)]["ms"]
 for w in out:
+    if "ms_sorted_queries" not in out[w]:
+        continue
     out[w]["speedup_without_collective"] = round(base / out[w]["ms"], 2)
     if "ms_with_allreduce_world_of_one" in out[w]:
         out[w]["speedup_with_allreduce_world_of_one"] = round(base / out[w]["ms_with_allreduce_world_of_one"], 2)
