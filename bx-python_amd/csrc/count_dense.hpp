@@ -678,8 +678,6 @@ struct BdImage {
     // key slices (FMT 2: count_slices.hpp's staged unit; sparse indexes, duplicated coordinates of any kind)
     SlUnit sl;
     BmGeom g;
-    // find() on key slices (FIND): 32-bit counts and the packed word of count_slices.hpp's sl_count_record_hc, at the records' positions
-    unsigned *find_cnt, *find_hc;
 };
 
 // FMT 1: a rank from a unit's cell image (bm_cell_rank written for the instruction count: the walk is bound by vector
@@ -777,25 +775,12 @@ __device__ __forceinline__ unsigned bd_count16(int bias, int rS, int rE, unsigne
 // FMT: 0 = dense unit image, 2 = staged key slices (cell images, once FMT 1 of this kernel, have the persistent walk below: bw_search_kernel)
 // W8: the counts are 8 bits wide (0xFF = "ask the index again": escape records and counts of 255 and more) -- half the bytes
 // for indexes whose counts are small; the host decides per batch (bm_count_segments).
-template <int FMT, bool QB, int EXP, bool W8 = false, bool FIND = false>
+template <int FMT, bool QB, int EXP, bool W8 = false>
 __device__ __forceinline__ void bd_answer_slot(const BdImage &I, unsigned short *__restrict__ out, unsigned idx4, unsigned valid, bd_v4u v)
 {
     if (valid == 0u) return;
     const unsigned rec[4] = {v.x, v.y, v.z, v.w};
     unsigned c[4];
-    if (FIND) {  // (FMT 2 only) the counts as they are, and the rank of qe beside them
-        unsigned hc[4];
-        sl_count_slot(I.sl, I.g, rec, c, hc);
-        if (valid == 15u) {
-            reinterpret_cast<bd_v4u *>(I.find_cnt)[idx4] = bd_v4u{c[0], c[1], c[2], c[3]};
-            reinterpret_cast<bd_v4u *>(I.find_hc)[idx4] = bd_v4u{hc[0], hc[1], hc[2], hc[3]};
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (valid & (1u << j)) I.find_cnt[4 * (size_t)idx4 + j] = c[j], I.find_hc[4 * (size_t)idx4 + j] = hc[j];
-        }
-        return;
-    }
     if (EXP == 1) {
 #pragma unroll
         for (int j = 0; j < 4; j++) c[j] = rec[j] & 0xffu;
@@ -896,16 +881,13 @@ __device__ __forceinline__ void bd_dummy_store(unsigned short *slot)
 // PAD: the tile sort left every unit's run on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): no slot is shared with a
 // neighbouring unit, every answered pass is exactly one store, and the walk keeps a RING of DEPTH passes in flight all
 // the time -- the wait in front of a pass counts the DEPTH - 1 younger loads and the DEPTH - 1 stores issued since.
-// FIND (FMT 2, packed runs): find()'s count half -- 32-bit counts to find_cnt and the packed word to find_hc instead of `out`.
-template <int FMT, bool QB, int EXP = 0, int DEPTH = 2, bool PIPE = false, bool PAD = false, bool W8 = false, bool FIND = false>
+template <int FMT, bool QB, int EXP = 0, int DEPTH = 2, bool PIPE = false, bool PAD = false, bool W8 = false>
 __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                const int *__restrict__ n_items, const unsigned short *__restrict__ unitT, int64_t ntp,
                                                                const unsigned *__restrict__ recs /* tile-sorted records */,
                                                                unsigned short *__restrict__ out /* their counts, same order */, int tile_log2,
-                                                               const unsigned *__restrict__ gate, unsigned *__restrict__ find_cnt = nullptr,
-                                                               unsigned *__restrict__ find_hc = nullptr)
+                                                               const unsigned *__restrict__ gate)
 {
-    static_assert(!FIND || (FMT == 2 && !PAD), "find()'s count half walks packed runs on key slices");
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     __shared__ uint2 s_long[BD_LONG_CAP];  // {first record, length} of the long runs met during the walk
@@ -945,7 +927,6 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
     };
     load_runs(tb);
     BdImage I;
-    I.find_cnt = find_cnt, I.find_hc = find_hc;
     if (FMT == 2) {
         I.sl = sl_stage_unit(sg, unit, dyn, s_tmp);
         I.g = g;
@@ -1067,7 +1048,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
                 for (int d = 0; d < DEPTH; d++) {
                     bd_wait<2 * DEPTH - 2>(ring_v[d]);
                     if (s0 + 64u * d < total)
-                        bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
+                        bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
                     else
                         bd_dummy_store(nobody);
                     prep(s0 + 64u * (d + DEPTH), ring_idx[d], ring_valid[d], ring_v[d], true);
@@ -1088,16 +1069,16 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
             for (unsigned s0 = 0; s0 < total; s0 += 128u * DEPTH) {
 #pragma unroll
                 for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * (DEPTH + d), y_idx[d], y_valid[d], y_v[d], true);
-                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(ring_v[0]); bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, ring_idx[0], ring_valid[0], ring_v[0]); }
-                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(ring_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, ring_idx[1 % DEPTH], ring_valid[1 % DEPTH], ring_v[1 % DEPTH]); }
-                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(ring_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, ring_idx[2 % DEPTH], ring_valid[2 % DEPTH], ring_v[2 % DEPTH]); }
-                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(ring_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, ring_idx[3 % DEPTH], ring_valid[3 % DEPTH], ring_v[3 % DEPTH]); }
+                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(ring_v[0]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[0], ring_valid[0], ring_v[0]); }
+                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(ring_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[1 % DEPTH], ring_valid[1 % DEPTH], ring_v[1 % DEPTH]); }
+                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(ring_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[2 % DEPTH], ring_valid[2 % DEPTH], ring_v[2 % DEPTH]); }
+                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(ring_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[3 % DEPTH], ring_valid[3 % DEPTH], ring_v[3 % DEPTH]); }
 #pragma unroll
                 for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * (2 * DEPTH + d), ring_idx[d], ring_valid[d], ring_v[d], true);
-                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(y_v[0]); bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, y_idx[0], y_valid[0], y_v[0]); }
-                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(y_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, y_idx[1 % DEPTH], y_valid[1 % DEPTH], y_v[1 % DEPTH]); }
-                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(y_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, y_idx[2 % DEPTH], y_valid[2 % DEPTH], y_v[2 % DEPTH]); }
-                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(y_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, y_idx[3 % DEPTH], y_valid[3 % DEPTH], y_v[3 % DEPTH]); }
+                if (DEPTH > 0) { bd_wait<2 * DEPTH - 1>(y_v[0]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, y_idx[0], y_valid[0], y_v[0]); }
+                if (DEPTH > 1) { bd_wait<2 * DEPTH - 2>(y_v[1 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, y_idx[1 % DEPTH], y_valid[1 % DEPTH], y_v[1 % DEPTH]); }
+                if (DEPTH > 2) { bd_wait<2 * DEPTH - 3>(y_v[2 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, y_idx[2 % DEPTH], y_valid[2 % DEPTH], y_v[2 % DEPTH]); }
+                if (DEPTH > 3) { bd_wait<2 * DEPTH - 4>(y_v[3 % DEPTH]); bd_answer_slot<FMT, QB, EXP, W8>(I, out, y_idx[3 % DEPTH], y_valid[3 % DEPTH], y_v[3 % DEPTH]); }
             }
             // the loads of the round after the last are still on their way: nothing may reuse their registers before they land
 #pragma unroll
@@ -1107,7 +1088,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
 #pragma unroll
             for (int d = 0; d < DEPTH; d++) prep(s0 + 64u * d, ring_idx[d], ring_valid[d], ring_v[d]);
 #pragma unroll
-            for (int d = 0; d < DEPTH; d++) bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
+            for (int d = 0; d < DEPTH; d++) bd_answer_slot<FMT, QB, EXP, W8>(I, out, ring_idx[d], ring_valid[d], ring_v[d]);
         }
         tb = tn;
     }
@@ -1120,7 +1101,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
             const unsigned q0 = first >> 2, nq4 = ((end + 3u) >> 2) - q0;
             for (unsigned q = threadIdx.x; q < nq4; q += BD_THREADS) {
                 const unsigned idx4 = q0 + q;
-                bd_answer_slot<FMT, QB, EXP, W8, FIND>(I, out, idx4, bd_valid_mask(4u * idx4, first, end), reinterpret_cast<const bd_v4u *>(recs)[idx4]);
+                bd_answer_slot<FMT, QB, EXP, W8>(I, out, idx4, bd_valid_mask(4u * idx4, first, end), reinterpret_cast<const bd_v4u *>(recs)[idx4]);
             }
         }
     }

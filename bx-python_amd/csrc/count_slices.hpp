@@ -567,32 +567,11 @@ __global__ __launch_bounds__(SL_THREADS) void sl_search_flat_kernel(const BmSeg 
 }
 
 // ---------------------------------------------------------------------------
-// find(): the hit lists through the same exchange
+// find(): what the fill half of find_exchange.hpp shares with the sorted-batch fill
 // ---------------------------------------------------------------------------
-// IntervalTree.find for a batch (intersection.pyx:400-406 -> :180-189), hits as CSR in query order.  The count pass
-// above runs first with its counts written APART from the records (the records are needed again) and its un-permute
-// kernel also leaves, per tile, the exclusive prefix of the counts in TILE-SORTED order (`loff`, bit 31 = escape
-// record).  After the CSR offsets are known (scan over the query-order counts) the search walk runs a second time:
-//   sl_fill_pipe_kernel   per record: hi = #{start < qe} and the count again from the staged slices, then the
-//                         candidates hi-1, hi-2, ... of the start-ordered index are tested (end > qs) until `count`
-//                         hits are found, and written -- ascending -- into the TILE's region of a scratch hit list at
-//                         the record's tile-sorted offset.  The index reads stay inside the unit's lines (all records
-//                         of the workgroup lie in one unit), the writes inside the run's few hundred bytes.
-//   sl_hits_unpermute_kernel   per tile: every query copies its hits from the tile's scratch region (offset through
-//                         its 16-bit slot) to its CSR position.  The reads are random 20-byte runs, but confined to
-//                         the tile's region (~0.6 MB), the writes stream.  Escape records (improper, off-grid,
-//                         over-long queries) are answered here from the sealed index.
-// Compared with the bucketed find of the first generation (window kernel + random 20-byte hit writes or reads over
-// the whole 1 GB hit list): configs[4] 9.1 -> 4.7 ms (with what was tried on the two hit-moving kernels).
+// (Round 2's fill and copy on this file's lane groups -- sl_fill_pipe_kernel, sl_hits_unpermute_kernel / sl_hits_copy_kernel:
+// configs[4] 9.1 -> 4.7 ms against the bucketed find -- were replaced by find_exchange.hpp in round 5 (2.9 ms) and removed in round 6.)
 constexpr int SL_WALK = 8;
-
-template <int U>
-struct SlFillRound {
-    unsigned first[U], lens[U], rec[U], lo[U];
-    long long tbase[U];  // first hit of the run's tile in the scratch list
-    unsigned lf_at, lf_rec, lf_lo, lf_total, listed;
-    long long lf_tbase;
-};
 
 // (end, insertion index) of every target in start order, interleaved: one candidate = one 8-byte read, a step of the walk
 // = 64 contiguous bytes.  SL_WALK dummy pairs (end = INT_MIN: never a hit) lie in front, so a walk may step past index 0.
@@ -603,368 +582,6 @@ __global__ void sl_pack_eid_kernel(const int32_t *__restrict__ e_ord, const int3
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x) - SL_WALK;
     if (i >= n) return;
     eid[i + SL_WALK] = i < 0 ? make_int2(INT_MIN, 0) : make_int2(e_ord[i], idx[i]);
-}
-
-// One record: its hits, ascending in index order, to dst[0 .. count).
-__device__ __forceinline__ void sl_emit_record(const SlUnit &U, const BmGeom &g, long long lo_u, const int2 *__restrict__ eid /* at index 0 */,
-                                               unsigned rec, unsigned lo, int32_t *__restrict__ dst)
-{
-    if (lo >> 31) return;  // escape record: answered by the hit un-permute kernel
-    const unsigned len = rec >> g.rshift, off = rec & ((1u << g.rshift) - 1u);
-    const int rE = sl_rank(U.lowE, U.dirE, off + 1u, g.dshift, U.steps);
-    const int rS = sl_rank(U.lowS, U.dirS, off + len, g.dshift, U.steps);
-    int c = (U.sLo - U.eLo) + (rS - rE);
-    const int qs = (int)(lo_u + (long long)off);
-    dst += (lo & 0x7FFFFFFFu);
-    // SL_WALK candidates per step, from the top of the window down; most windows end within the first step.  Candidates
-    // below the last hit are read for nothing, never stored.
-    for (int top = U.sLo + rS; c > 0 && top > 0; top -= SL_WALK) {
-        const sl_v4a8 *p = reinterpret_cast<const sl_v4a8 *>(eid + (top - SL_WALK));
-        const sl_v4a8 a = p[0], b = p[1], d = p[2], f = p[3];
-        const int e[SL_WALK] = {a.x, a.z, b.x, b.z, d.x, d.z, f.x, f.z}, id[SL_WALK] = {a.y, a.w, b.y, b.w, d.y, d.w, f.y, f.w};
-#pragma unroll
-        for (int j = SL_WALK - 1; j >= 0; j--)
-            if (c > 0 && e[j] > qs) dst[--c] = id[j];
-    }
-}
-
-template <int L, int U>
-__global__ __launch_bounds__(SL_THREADS) void sl_fill_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
-                                                                  const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
-                                                                  const unsigned *__restrict__ recs, const unsigned *__restrict__ loff,
-                                                                  const long long *__restrict__ offsets /* CSR offsets of the segment's queries */,
-                                                                  const int2 *__restrict__ eid, int32_t *__restrict__ tmp_hits, int tile_log2)
-{
-    constexpr int NG = SL_THREADS / L;
-    constexpr unsigned LONG_RUN = 4 * L;
-    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    __shared__ uint2 s_long[BM_LONG_CAP];
-    __shared__ int s_nlong;
-    __shared__ int s_tmp[20];
-    const int nit = *n_items;
-    const int per_xcd = (nit + 7) >> 3;
-    const int slot = (int)(blockIdx.x >> 3);
-    const int it = (int)(blockIdx.x & 7) * per_xcd + slot;
-    if (slot >= per_xcd || it >= nit) return;
-    const int4 item = items[it];
-    const int unit = item.x & 0xffff, t0 = item.y, t1 = item.z;
-    const BmSeg &sg = segs[item.x >> 16];
-    const BmGeom g = sg.g;
-    const int b0 = unit << g.f, b1 = b0 + (1 << g.f);
-    const bool open_end = b1 >= BM_NB;
-    const unsigned *__restrict__ runs0 = runT + (int64_t)b0 * ntp;
-    const unsigned *__restrict__ runs1 = runT + (int64_t)(open_end ? b0 : b1) * ntp;
-    const int64_t seg_t0 = sg.tile0, seg_nq = sg.nq;
-    const long long lo_u = (long long)g.cmin + ((long long)b0 << g.shift);
-    const int gid = threadIdx.x / L, sub = threadIdx.x % L;
-    unsigned run[U];
-    long long tb[U];
-    auto load_runs = [&](int tbs) {
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = tbs + u * NG + gid;
-            const int tc = t < t1 ? t : t0;
-            const unsigned a = runs0[tc] & 0xffffu;
-            unsigned e = runs1[tc] & 0xffffu;
-            if (open_end) {
-                const int64_t left = seg_nq - (((int64_t)tc - seg_t0) << tile_log2);
-                e = left < ((int64_t)1 << tile_log2) ? (unsigned)left : 1u << tile_log2;
-            }
-            run[u] = t < t1 ? (a | ((e - a) << 16)) : 0u;
-            tb[u] = offsets[((int64_t)tc - seg_t0) << tile_log2];
-        }
-    };
-    load_runs(t0);
-    const SlUnit UN = sl_stage_unit(sg, unit, dyn, s_tmp);
-    if (threadIdx.x == 0) s_nlong = 0;
-    __syncthreads();
-    auto emit = [&](long long tbase, unsigned rec, unsigned lo) { sl_emit_record(UN, g, lo_u, eid, rec, lo, tmp_hits + tbase); };
-    auto prep = [&](SlFillRound<U> &R, int tbs) {
-        unsigned cum = 0, lf_at = ~0u, listed_mask = 0;
-        long long lf_tbase = 0;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int t = tbs + u * NG + gid;
-            const unsigned first = ((unsigned)t << tile_log2) + (run[u] & 0xffffu);
-            const unsigned len = run[u] >> 16;
-            R.first[u] = first;
-            R.lens[u] = len;
-            R.tbase[u] = tb[u];
-            const size_t a0 = (size_t)((unsigned)sub < len ? first + (unsigned)sub : 0u);
-            R.rec[u] = recs[a0];
-            R.lo[u] = loff[a0];
-            unsigned rem = len > (unsigned)L ? len - (unsigned)L : 0u;
-            if (len > LONG_RUN) {
-                bool listed = false;
-                if (sub == 0) {
-                    const int k = atomicAdd(&s_nlong, 1);
-                    if (k < BM_LONG_CAP) {
-                        s_long[k] = make_uint2(first, len);
-                        listed = true;
-                    }
-                }
-                listed = __shfl(listed, (int)(threadIdx.x & 63) - sub, 64);
-                if (listed) {
-                    rem = 0;
-                    listed_mask |= 1u << u;
-                }
-            }
-            const unsigned i = (unsigned)sub - cum;
-            if ((unsigned)sub >= cum && i < rem) {
-                lf_at = first + (unsigned)L + i;
-                lf_tbase = tb[u];
-            }
-            cum += rem;
-        }
-        R.lf_total = cum;
-        R.listed = listed_mask;
-        R.lf_at = lf_at;
-        R.lf_tbase = lf_tbase;
-        const size_t a1 = (size_t)(lf_at != ~0u ? lf_at : 0u);
-        R.lf_rec = recs[a1];
-        R.lf_lo = loff[a1];
-    };
-    auto finish = [&](SlFillRound<U> &R) {
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if ((unsigned)sub < R.lens[u]) emit(R.tbase[u], R.rec[u], R.lo[u]);
-        if (R.lf_at != ~0u) emit(R.lf_tbase, R.lf_rec, R.lf_lo);
-        for (unsigned base = L; __any(base < R.lf_total); base += L) {
-            const unsigned i = base + (unsigned)sub;
-            unsigned cum = 0, at = ~0u;
-            long long tbase = 0;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const unsigned len = R.lens[u];
-                const unsigned rem = len > (unsigned)L && !((R.listed >> u) & 1u) ? len - (unsigned)L : 0u;
-                const unsigned j = i - cum;
-                if (i >= cum && j < rem) {
-                    at = R.first[u] + (unsigned)L + j;
-                    tbase = R.tbase[u];
-                }
-                cum += rem;
-            }
-            if (at != ~0u) emit(tbase, recs[(size_t)at], loff[(size_t)at]);
-        }
-    };
-    SlFillRound<U> A, B;
-    prep(A, t0);
-    load_runs(t0 + NG * U);
-    for (int tbs = t0; tbs < t1; tbs += 2 * NG * U) {
-        prep(B, tbs + NG * U);
-        load_runs(tbs + 2 * NG * U);
-        finish(A);
-        prep(A, tbs + 2 * NG * U);
-        load_runs(tbs + 3 * NG * U);
-        finish(B);
-    }
-    __syncthreads();
-    {
-        const int nl = s_nlong < BM_LONG_CAP ? s_nlong : BM_LONG_CAP;
-        for (int k = 0; k < nl; k++) {
-            const uint2 e = s_long[k];
-            const long long tbase = offsets[((int64_t)(e.x >> tile_log2) - seg_t0) << tile_log2];
-            for (unsigned p = (unsigned)L + threadIdx.x; p < e.y; p += SL_THREADS) emit(tbase, recs[(size_t)e.x + p], loff[(size_t)e.x + p]);
-        }
-    }
-}
-
-// Per tile: hits from the tile's scratch region (tile-sorted order) to CSR order; escapes answered from the index.
-// The tile's scratch offsets (by tile-sorted slot) sit in LDS.  An 8-lane group takes 8 CONSECUTIVE queries: lane u
-// fetches query u's CSR range and scratch offset (coalesced reads of `offsets` and `slots`), the group shares them by
-// shuffles, then copies the eight runs, lane j the j-th hit of each -- eight loads in flight per thread, and the
-// group's stores cover one contiguous stretch of the CSR list.  No staging through LDS and no barrier inside the
-// tile: a version that staged 2048 queries' offsets per barrier interval spent its time waiting at the barriers
-// (1.55 ms on configs[4]; proportional to 1 / workgroups when the grid was cut, i.e. not bound by memory).
-template <int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void sl_hits_unpermute_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
-                                                                    const unsigned *__restrict__ loff, const unsigned short *__restrict__ slots,
-                                                                    const long long *__restrict__ offsets, const int32_t *__restrict__ tmp_hits,
-                                                                    int32_t *__restrict__ hits, int64_t ntp, int parts)
-{
-    constexpr int TILE = THREADS * ITEMS;
-    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    unsigned *lo_s = reinterpret_cast<unsigned *>(dyn);  // [TILE] scratch offsets by tile-sorted slot
-    // `parts` workgroups share a tile, one after the other on the SAME XCD (blockIdx -> XCD is round robin): only a few
-    // tiles' regions are live in an XCD's 4 MB of L2 at a time, so a line of a region is fetched from HBM once, not
-    // once per run that lies in it.  Each of them stages the whole tile's offsets (L2 hits after the first).
-    const int xcd = (int)(blockIdx.x & 7u), seq = (int)(blockIdx.x >> 3);
-    const int part = seq % parts;
-    {
-        const int64_t tile = (int64_t)(seq / parts) * 8 + xcd;
-        if (tile >= ntp) return;
-        const BmSeg &sg = segs[tile_seg[tile]];
-        const int64_t ltile = tile - sg.tile0;
-        if (ltile >= sg.ntiles) return;
-        const IndexDev ix = sg.ix;
-        const int64_t q0 = ltile * TILE;
-        const int64_t left = sg.nq - q0;
-        const int n = (int)(left < TILE ? left : TILE);
-        const int k_lo = part * (TILE / parts), k_hi = k_lo + TILE / parts < n ? k_lo + TILE / parts : n;
-        if (k_lo >= n) return;
-        {
-            const int4 *src = reinterpret_cast<const int4 *>(loff + tile * TILE);
-            const int n4 = (n + 3) >> 2;
-            for (int i = threadIdx.x; i < n4; i += THREADS) reinterpret_cast<int4 *>(lo_s)[i] = src[i];
-        }
-        __syncthreads();
-        const long long *__restrict__ off_t = offsets + q0;
-        const unsigned short *__restrict__ sl_t = slots + tile * TILE;
-        const int32_t *__restrict__ region = tmp_hits + off_t[0];
-        const int sub = (int)(threadIdx.x & 7u), lane0 = (int)(threadIdx.x & 63u) - sub;
-        for (int kb = k_lo + (int)(threadIdx.x >> 3) * 8; kb < k_hi; kb += THREADS) {
-            const int k = kb + sub;
-            const bool live = k < k_hi;
-            const long long my_o = off_t[live ? k : 0];
-            const unsigned my_c = live ? (unsigned)(off_t[k + 1] - my_o) : 0u;
-            const unsigned my_sv = lo_s[sl_t[live ? k : 0]];
-            long long o[8];
-            unsigned c[8], sv[8];
-            int v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                o[u] = __shfl(my_o, lane0 + u, 64);
-                c[u] = (unsigned)__shfl((int)my_c, lane0 + u, 64);
-                sv[u] = (unsigned)__shfl((int)my_sv, lane0 + u, 64);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = region[(unsigned)sub < c[u] && !(sv[u] >> 31) ? sv[u] + (unsigned)sub : 0u];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if ((unsigned)sub < c[u] && !(sv[u] >> 31)) hits[o[u] + sub] = v[u];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (!(sv[u] >> 31))
-                    for (unsigned j = 8 + (unsigned)sub; j < c[u]; j += 8) hits[o[u] + j] = region[sv[u] + j];
-            if ((my_sv >> 31) && my_c) {  // escape record: rare, answered from the sealed index by its own lane
-                const int qs = sg.qs[q0 + k], qe = sg.qe[q0 + k];
-                int cc = (int)my_c;
-                int32_t *__restrict__ dst = hits + my_o;
-                for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; cc > 0; j--)
-                    if (ix.e_ord[j] > qs) dst[--cc] = ix.idx[j];
-            }
-        }
-    }
-}
-
-// The same copy laid out for the L2: a run of ~20 bytes drags a 128-byte line of the tile's region from HBM, and with one
-// workgroup per tile (32 tiles = 21 MB of regions per XCD against 4 MB of L2) the line is gone before the next run in it
-// is asked for -- measured 6.8 GB fetched for 1 GB of hits (TCC_MISS = one per query).  Here the unit of work is HC_Q
-// CONSECUTIVE queries of a tile, and the units of an XCD's tiles (tile = 8 i + xcd; blockIdx -> XCD is round robin) are
-// taken in order by the XCD's 64 resident workgroups: two or three tiles' regions, offsets and CSR windows are live in an
-// XCD's L2 at a time (measured: 1.7 GB fetched, the regions once + the offsets, slots and scratch offsets).  No LDS: the
-// scratch offset of a query comes from the tile's `loff` array by its slot (an L2 hit after the first touch); the
-// streaming inputs are read with non-temporal loads so that they do not push the regions out.
-// One workgroup per unit, in unit order (two of 1024 threads per CU = 64 units in flight per XCD; units of 256 queries
-// and eight workgroups per CU: the same 0.92 ms).  Persistent workgroups that spread the three dependent reads of a unit
-// (offsets + slot -> scratch offset -> hits) over three rounds of a loop were slower both times they were tried
-// (1.31 ms with 64 x 1024 threads per XCD, 1.17 ms with 256 x 256 and nothing consumed in the round that loads it).
-constexpr int HC_Q = 1024;  // queries per unit = threads per workgroup
-
-struct HcUnit {  // one unit as a thread sees it
-    const int32_t *region;  // the tile's region of the scratch list
-    const unsigned *lo_t;   // the tile's scratch offsets by slot
-    const BmSeg *sg;
-    int64_t q;              // the thread's query (in its segment)
-    long long o, o_next;    // its CSR range
-    bool live;              // (not past the end of the tile)
-    unsigned slot;
-};
-
-template <int TILE>
-__global__ __launch_bounds__(HC_Q) void sl_hits_copy_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
-                                                            const unsigned *__restrict__ loff, const unsigned short *__restrict__ slots,
-                                                            const long long *__restrict__ offsets, const int32_t *__restrict__ tmp_hits,
-                                                            int32_t *__restrict__ hits, int64_t ntp)
-{
-    constexpr int PARTS = TILE / HC_Q;
-    __shared__ unsigned s_ends[HC_Q / 64][64];  // per wave: where each query's hits end in the wave's stretch
-    const int xcd = (int)(blockIdx.x & 7u);
-    const int64_t unit = (int64_t)(blockIdx.x >> 3), units = ((ntp + 7 - xcd) >> 3) * PARTS;  // of this XCD's tiles
-    const int lane = lane_id();
-    // stage 1: where the unit lies, the thread's CSR range and slot (all loads independent of each other)
-    auto stage1 = [&](int64_t u, HcUnit &m) {
-        m.live = false, m.slot = 0u, m.o = 0, m.o_next = 0, m.q = 0, m.sg = segs, m.region = tmp_hits, m.lo_t = loff;
-        if (u >= units) return;
-        const int64_t tile = (u / PARTS) * 8 + xcd;
-        const int part = (int)(u % PARTS);
-        const BmSeg *sg = segs + tile_seg[tile];
-        const int64_t ltile = tile - sg->tile0;
-        if (ltile >= sg->ntiles) return;  // padding up to the next plan group
-        const int64_t q0 = ltile * TILE;
-        const int64_t left = sg->nq - q0;
-        const int n = (int)(left < TILE ? left : TILE);
-        const int k = part * HC_Q + (int)threadIdx.x;
-        const long long *__restrict__ off_t = offsets + q0;
-        m.sg = sg;
-        m.region = tmp_hits + off_t[0];
-        m.lo_t = loff + tile * TILE;
-        if (k >= n) return;
-        m.q = q0 + k;
-        m.live = true;
-        m.o = __builtin_nontemporal_load(off_t + k);
-        m.o_next = __builtin_nontemporal_load(off_t + k + 1);
-        m.slot = __builtin_nontemporal_load(slots + tile * TILE + k);
-    };
-    // stage 3: the wave's 64 consecutive queries own one stretch of the CSR list (escape records leave holes in it,
-    // filled by their own lanes).  The stretch is copied as ONE flat sequence: position s of it belongs to query
-    // r = #{queries whose hits end at or before s}; lane i takes positions i, i + 64, ... -- a store instruction writes
-    // 256 contiguous bytes instead of one 20-byte piece per query (measured on configs[4] for eight lanes per query:
-    // 66 M write and 101 M read requests at the L2 for 50 M queries).
-    auto copy = [&](const HcUnit &m, unsigned my_sv) {
-        const unsigned my_c = m.live ? (unsigned)(m.o_next - m.o) : 0u;
-        const unsigned n_me = (my_sv >> 31) ? 0u : my_c;
-        const unsigned incl = wave_inclusive_scan(n_me, OpSum());
-        const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-        const long long o_first = __shfl(m.o, 0, 64);
-        int32_t *__restrict__ out = hits + o_first;
-        const int32_t *__restrict__ region = m.region;
-        const unsigned d_src = my_sv - (incl - n_me);                       // + s = the hit's place in the tile's region
-        const unsigned d_dst = (unsigned)(m.o - o_first) - (incl - n_me);   // + s = its place behind the wave's first CSR offset
-        // r by six halvings over the wave's 64 prefix sums in LDS (walking them with readlane, as the count pass's flat walk
-        // does for its 16-byte slots, cost 540 scalar + 380 vector instructions per wave here: a pass of 64 hits spans ~13 queries)
-        unsigned *ends = s_ends[threadIdx.x >> 6];
-        ends[lane] = incl;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        auto locate = [&](unsigned s0, unsigned &src, unsigned &dst, bool &active) {
-            const unsigned s = s0 + (unsigned)lane;
-            unsigned r = 0u;
-#pragma unroll
-            for (unsigned step = 32u; step >= 1u; step >>= 1)
-                if (ends[r + step - 1u] <= s) r += step;
-            r = r < 63u ? r : 63u;
-            active = s < total;
-            src = (unsigned)__shfl((int)d_src, (int)r, 64) + s;
-            dst = (unsigned)__shfl((int)d_dst, (int)r, 64) + s;
-        };
-        for (unsigned s0 = 0; s0 < total; s0 += 256u) {  // four passes at a time: their loads in flight together
-            unsigned src[4], dst[4];
-            bool act[4];
-            int v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (s0 + 64u * j < total) {  // (wave-uniform)
-                    locate(s0 + 64u * j, src[j], dst[j], act[j]);
-                    v[j] = region[act[j] ? src[j] : 0u];
-                }
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (s0 + 64u * j < total && act[j]) out[dst[j]] = v[j];
-        }
-        if ((my_sv >> 31) && my_c) {  // escape record: rare, answered from the sealed index by its own lane
-            const IndexDev ix = m.sg->ix;
-            const int qs = m.sg->qs[m.q], qe = m.sg->qe[m.q];
-            int cc = (int)my_c;
-            int32_t *__restrict__ dst = hits + m.o;
-            for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; cc > 0; j--)
-                if (ix.e_ord[j] > qs) dst[--cc] = ix.idx[j];
-        }
-    };
-    if (unit >= units) return;
-    HcUnit a;
-    stage1(unit, a);
-    copy(a, a.lo_t[a.slot]);
 }
 
 }  // namespace bxmi

@@ -18,13 +18,13 @@
 //      stores instead of five, and neighbouring lanes = neighbouring records of a run write neighbouring bytes).
 //   4. The CSR offsets need no scan over the queries: the un-permute kernel leaves the sum of every 1024 queries' counts and of
 //      every tile (bm_unpermute_kernel<.., FIND = 2>), one workgroup scans the TILE sums (fx_tile_scan_kernel), and the copy
-//      kernel finishes the offsets of its 1024 queries itself while it moves their hits (fx_hits_copy_kernel).  It also reads
+//      kernel finishes the offsets of its 1024 queries itself while it moves their hits (fx_hits_copy2_kernel).  It also reads
 //      the scratch offset of a query from a query-order array the un-permute kernel wrote, instead of gathering it by slot.
 //      Two consecutive queries per lane (fx_hits_copy2_kernel): twice the gathers in flight per wave.
 //   5. Lists that fit the memory-side cache skip the scratch and the copy (ivl.fx_direct): the un-permute kernel leaves prefixes
 //      in QUERY order (FIND = 3), the fill writes straight into the CSR list, fx_offsets_kernel turns the prefixes into offsets.
 // A record whose walk leaves the staged window (long targets far below, piles larger than the window) reads the pairs from HBM
-// as before: exact either way.  ivl.fx_fill = 0 keeps round 2's kernels.
+// as before: exact either way.
 #pragma once
 
 namespace bxmi {
@@ -340,97 +340,13 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
     }
 }
 
-// The hit copy (sl_hits_copy_kernel's layout: a workgroup takes BM_PART_Q consecutive queries of a tile, the workgroups of a
-// tile follow each other on one XCD) with the CSR offsets finished on the way: offset(query) = tile_base[tile] + the parts
-// of the tile before this one + an exclusive scan of the workgroup's own 1024 counts.  The scratch offset of a query comes
-// from the query-order array `svq` (bit 31 = escape record: answered here from the sealed index).
-template <int TILE>
-__global__ __launch_bounds__(BM_PART_Q) void fx_hits_copy_kernel(const BmSeg *__restrict__ segs, const unsigned *__restrict__ svq,
-                                                                const long long *__restrict__ tile_base, const unsigned long long *__restrict__ parts,
-                                                                const int32_t *__restrict__ tmp_hits, long long *__restrict__ offsets,
-                                                                int32_t *__restrict__ hits, int64_t ntp)
-{
-    constexpr int PARTS = TILE / BM_PART_Q;
-    __shared__ unsigned s_ends[BM_PART_Q / 64][64];  // per wave: where each query's hits end in the wave's stretch
-    __shared__ long long s_scan[16];
-    const int xcd = (int)(blockIdx.x & 7u);
-    const int64_t unit = (int64_t)(blockIdx.x >> 3), units = ((ntp + 7 - xcd) >> 3) * PARTS;  // of this XCD's tiles
-    if (unit >= units) return;
-    const BmSeg &sg = segs[0];
-    const int64_t tile = (unit / PARTS) * 8 + xcd;
-    const int part = (int)(unit % PARTS);
-    if (tile >= sg.ntiles) return;  // padding up to the next plan group
-    const int lane = lane_id();
-    const int64_t q0 = tile * TILE;
-    const int64_t left = sg.nq - q0;
-    const int n = (int)(left < TILE ? left : TILE);
-    const int k = part * BM_PART_Q + (int)threadIdx.x;
-    if (part * BM_PART_Q >= n) return;  // (uniform)
-    const bool live = k < n;
-    const int64_t q = q0 + k;
-    // the part's first CSR offset: the tile's, plus the parts before this one (at most 31 values)
-    long long part_base = tile_base[tile];
-    {
-        long long v = lane < part ? (long long)parts[tile * PARTS + lane] : 0ll;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        part_base += v;
-    }
-    const unsigned my_c = live ? (unsigned)__builtin_nontemporal_load(sg.counts + q) : 0u;
-    const unsigned my_sv = live ? __builtin_nontemporal_load(svq + q) : 0u;  // (find() is one segment: the tile numbering is the query numbering)
-    long long total;
-    const long long o = part_base + block_exclusive_scan((long long)my_c, OpSum(), 0ll, s_scan, &total);
-    if (live) __builtin_nontemporal_store(o, offsets + q);
-    const int32_t *__restrict__ region = tmp_hits + tile_base[tile];
-    // the wave's 64 consecutive queries own one stretch of the CSR list (escape records leave holes in it, filled by their own
-    // lanes); it is copied as ONE flat sequence, lane i taking positions i, i + 64, ... (see sl_hits_copy_kernel)
-    const unsigned n_me = (my_sv >> 31) ? 0u : my_c;
-    const unsigned incl = wave_inclusive_sum_dpp(n_me);
-    const unsigned wtotal = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    const long long o_first = __shfl(o, 0, 64);
-    int32_t *__restrict__ out = hits + o_first;
-    const unsigned d_src = my_sv - (incl - n_me);                     // + s = the hit's place in the tile's region
-    const unsigned d_dst = (unsigned)(o - o_first) - (incl - n_me);   // + s = its place behind the wave's first CSR offset
-    unsigned *ends = s_ends[threadIdx.x >> 6];
-    ends[lane] = incl;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // (measured on configs[4], round 5: 4 / 6 / 8 passes in flight 3.20 / 3.18 / 3.21 ms for the whole find; the position -> query look-up
-    // by scattered marks and a DPP running sum instead of the six-step search over the 64 ends: no difference, 3.18 -- the kernel
-    // waits for its gathers of ~20-byte runs, not for the look-up; batches of 16 / 32 / 64 tiles in the fill: 3.28 / 3.18 / 3.31)
-    constexpr int FL = FX_FL_V;  // passes whose loads are in flight together (a wave's stretch is ~320 hits on configs[4]: one round)
-    for (unsigned s0 = 0; s0 < wtotal; s0 += 64u * FL) {
-        unsigned dst[FL];
-        bool act[FL];
-        int v[FL];
-#pragma unroll
-        for (int j = 0; j < FL; j++)
-            if (s0 + 64u * j < wtotal) {  // (wave-uniform)
-                const unsigned s = s0 + 64u * j + (unsigned)lane;
-                const unsigned r = fx_locate(ends, s);
-                act[j] = s < wtotal;
-                const unsigned src = (unsigned)__shfl((int)d_src, (int)r, 64) + s;
-                dst[j] = (unsigned)__shfl((int)d_dst, (int)r, 64) + s;
-                v[j] = region[act[j] ? src : 0u];
-            }
-#pragma unroll
-        for (int j = 0; j < FL; j++)
-            if (s0 + 64u * j < wtotal && act[j]) out[dst[j]] = v[j];
-    }
-    if ((my_sv >> 31) && my_c) {  // escape record: rare, answered from the sealed index by its own lane
-        const IndexDev ix = sg.ix;
-        const int qs = sg.qs[q], qe = sg.qe[q];
-        int cc = (int)my_c;
-        int32_t *__restrict__ dst = hits + o;
-        for (int j = global_rank_lt(ix.s_ord, 0, ix.n, qe) - 1; cc > 0 && j >= 0; j--)
-            if (ix.e_ord[j] > qs) dst[--cc] = ix.idx[j];
-    }
-}
-
-// The same copy with QPL (2 or 4) consecutive queries per lane: a wave owns the stretch of 64 QPL queries (~320 QPL hits on
-// configs[4]) and has QPL times the gathers in flight -- the kernel is a chain of three round trips to memory per workgroup
-// (counts, gathers, stores) at the CU's full complement of waves either way, so the work per round trip is what counts.
-// 1024 / QPL threads per part of 1024 queries.
+// The hit copy: a workgroup takes BM_PART_Q consecutive queries of a tile, the workgroups of a tile follow each other on one XCD,
+// and the CSR offsets are finished on the way: offset(query) = tile_base[tile] + the parts of the tile before this one + an
+// exclusive scan of the workgroup's own 1024 counts.  The scratch offset of a query comes from the query-order array `svq`
+// (bit 31 = escape record: answered here from the sealed index).  QPL consecutive queries per lane: a wave owns the stretch of
+// 64 QPL queries (~320 QPL hits on configs[4]) and has QPL times the gathers in flight -- the kernel is a chain of three round
+// trips to memory per workgroup (counts, gathers, stores) at the CU's full complement of waves either way, so the work per round
+// trip is what counts (one query per lane 0.91 ms, two 0.78, four 0.85: two is what ships).  1024 / QPL threads per part.
 #ifndef FX_FL2_V
 #define FX_FL2_V 10
 #endif

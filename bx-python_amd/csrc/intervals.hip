@@ -723,105 +723,6 @@ __device__ __forceinline__ int group_rank_lt(const int32_t *__restrict__ a, int 
     return c;
 }
 
-template <typename CT>
-__global__ __launch_bounds__(PT_THREADS) void part_count_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
-                                                                const SliceBound *__restrict__ bounds,
-                                                                const int32_t *__restrict__ wg_first,
-                                                                const unsigned *__restrict__ table /* row 0 = bucket offsets */,
-                                                                const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
-                                                                CT *__restrict__ counts /* bucket order, may be NULL */,
-                                                                unsigned long long *__restrict__ total_slots,
-                                                                const unsigned *__restrict__ gate)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    __shared__ int s_bucket;
-    __shared__ long long red[PT_THREADS / 64];
-    int b;
-    int64_t q_begin, q_end;
-    const unsigned go = gate ? *gate : 1u;  // 0 = sorted batch, answered by ivl_local_count_kernel
-    if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end) || go == 0) return;
-    const SliceBound sb = bounds[b];
-    const int nE = sb.eHi - sb.eLo, nS = sb.sHi - sb.sLo;
-    // The two slices are staged as PERFECT binary search trees in breadth-first (Eytzinger)
-    // order, padded with INT_MAX: tree[1] is the root, children of i are 2i and 2i+1.  A search
-    // is "i = 2i + (tree[i] < key)" -- one LDS read and three VALU ops per level -- the probes of
-    // one level fall in one contiguous block (no power-of-two bank pile-up), and after k levels
-    // i - 2^k is exactly the number of keys < key.
-    // A slice too long for LDS (dense region, or a 50M-target index) is staged SAMPLED: the tree holds the last key
-    // of every group of `stride` keys, the descent yields the group, and a 1-3 step search inside that group (global
-    // memory, but the bucket's own few lines) finishes the rank.
-    int32_t *treeE = lds, *treeS = lds + (1 << sb.kE);
-    {
-        const int total = (1 << sb.kE) + (1 << sb.kS);
-        for (int i = threadIdx.x; i < total; i += PT_THREADS) lds[i] = INT_MAX;
-        __syncthreads();
-        part_stage_tree<PT_THREADS>(treeE, sb.kE, e_sorted + sb.eLo, nE, sb.strideE);
-        part_stage_tree<PT_THREADS>(treeS, sb.kS, ix.s_ord + sb.sLo, nS, sb.strideS);
-    }
-    __syncthreads();
-    long long acc = 0;
-    for (int64_t i0 = q_begin + threadIdx.x; i0 < q_end; i0 += PT_THREADS * PT_ILP) {
-        int qs[PT_ILP], qe[PT_ILP], rS[PT_ILP], rE[PT_ILP];
-        bool live[PT_ILP];
-#pragma unroll
-        for (int j = 0; j < PT_ILP; j++) {
-            int64_t i = i0 + (int64_t)j * PT_THREADS;
-            live[j] = i < q_end;
-            const int2 v = live[j] ? pairs[i] : make_int2(0, 0);
-            qs[j] = v.x;
-            qe[j] = v.y;
-            rS[j] = rE[j] = 1;
-        }
-        // PT_ILP x 2 independent descents in lockstep (same trees => same depth)
-        for (int it = 0; it < sb.kS; it++) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) rS[j] = 2 * rS[j] + (treeS[rS[j]] < qe[j]);  // #{start samples < qe}
-        }
-        for (int it = 0; it < sb.kE; it++) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) rE[j] = 2 * rE[j] + (treeE[rE[j]] <= qs[j] && qs[j] != INT_MAX);  // #{end samples <= qs}
-        }
-#pragma unroll
-        for (int j = 0; j < PT_ILP; j++) {
-            rS[j] = (rS[j] - (1 << sb.kS)) * sb.strideS;
-            rE[j] = (rE[j] - (1 << sb.kE)) * sb.strideE;
-        }
-        if (sb.strideS > 1) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) {
-                int hi = rS[j] + sb.strideS < nS ? rS[j] + sb.strideS : nS;
-                rS[j] = group_rank_lt(ix.s_ord + sb.sLo, rS[j], hi, qe[j]);
-            }
-        }
-        if (sb.strideE > 1) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) {
-                int hi = rE[j] + sb.strideE < nE ? rE[j] + sb.strideE : nE;
-                rE[j] = qs[j] == INT_MAX ? 0 : group_rank_lt(e_sorted + sb.eLo, rE[j], hi, qs[j] + 1);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PT_ILP; j++) {
-            if (!live[j]) continue;
-            const bool in_slice = qe[j] >= sb.qeLo && qe[j] <= sb.qeHi;
-            const int s_rank = in_slice ? sb.sLo + rS[j] : global_rank_lt(ix.s_ord, 0, ix.n, qe[j]);
-            int c;
-            if (qs[j] < qe[j]) {  // regular query (the index has no reversed targets on this path)
-                const int e_rank = qs[j] == INT_MAX ? ix.n : sb.eLo + rE[j];
-                c = s_rank - e_rank;
-            } else {  // zero-length / reversed query: exact predicate over the candidate window
-                int lo = first_pm_gt(ix.pm, ix.n, qs[j]);
-                c = 0;
-                for (int k = lo; k < s_rank; k++) c += ix.e_ord[k] > qs[j];
-            }
-            int64_t i = i0 + (int64_t)j * PT_THREADS;
-            if (counts) store_count(counts, i, c);
-            acc += c;
-        }
-    }
-    if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
-}
-
 __device__ __forceinline__ int wave_min_i32(int v)
 {
 #pragma unroll
@@ -1109,9 +1010,6 @@ constexpr int LC_CHUNK = LC_THREADS * LC_ITEMS;  // 4096 consecutive queries per
 #endif
 constexpr int LC_TREE_KEYS = (1 << LC_TREE_LOG2) - 1;  // two trees of 4096 slots = 32 KiB of LDS: four workgroups per CU
 
-// LOOP: a workgroup takes LC_LOOP consecutive chunks instead of one: a quarter of the workgroups to dismiss when the batch
-// is NOT sorted (the stand-down of 24 000 workgroups cost 12 us per 100 M queries, 1.5 % of the unsorted pass).
-constexpr int LC_LOOP = 4;
 // One chunk of LC_CHUNK consecutive queries from `base` on: the workgroup's queries are k = j * LC_THREADS + thread, and
 // emit(j, k, live, count, #{start < qe}, qs) is called once per (thread, j) with j a compile-time constant after unrolling.
 template <typename Emit>
@@ -1250,8 +1148,7 @@ __device__ __forceinline__ void lc_chunk_counts(const TreeDev &S, const TreeDev 
 
 // (eight waves per SIMD = four workgroups per CU: the kernel lives on the chunks it keeps in flight -- said out loud, the compiler
 // took 70 registers for a build that needed 64)
-template <bool LOOP>
-__global__ __launch_bounds__(LC_THREADS) __attribute__((amdgpu_waves_per_eu(LOOP ? 4 : 8))) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
+__global__ __launch_bounds__(LC_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
                                                                      const int32_t *__restrict__ qs_arr,
                                                                      const int32_t *__restrict__ qe_arr, int64_t nq,
                                                                      int32_t *__restrict__ counts /* may be NULL */,
@@ -1271,9 +1168,8 @@ __global__ __launch_bounds__(LC_THREADS) __attribute__((amdgpu_waves_per_eu(LOOP
     if (order_host && blockIdx.x == 0 && threadIdx.x == 0) *order_host = (seq << 1) | (gate && *gate != 0 ? 1ull : 0ull);
     if (gate && *gate != 0) return;  // unsorted batch: the bucketed path answers it
     long long acc = 0;
-    const int64_t chunk0 = (int64_t)blockIdx.x * (LOOP ? LC_LOOP : 1);
-    for (int64_t chunk = chunk0; chunk < chunk0 + (LOOP ? LC_LOOP : 1) && chunk * LC_CHUNK < nq; chunk++) {
-        if (LOOP && chunk != chunk0) __syncthreads();  // the shared arrays of the chunk before are done with
+    {
+        const int64_t chunk = blockIdx.x;
         const int64_t base = chunk * LC_CHUNK;
         const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
         long long cacc = 0;
@@ -1547,69 +1443,6 @@ __global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, co
     window_queries<PT_THREADS, true, false>(ix, w, treeP, treeS, q_begin, q_end, reinterpret_cast<const int32_t *>(pairs), nullptr, win_lo, win_hi, counts);
 }
 
-// find() on a batch whose starts are already sorted: the windows of 4096 consecutive queries as they lie (same idea
-// as ivl_local_count_kernel); lo / hi / counts come out in query order, so the CSR offsets are one scan away and the
-// fill pass writes neighbouring queries' hits to neighbouring addresses.
-__global__ __launch_bounds__(LC_THREADS) void ivl_local_window_kernel(TreeDev S, TreeDev P, IndexDev ix,
-                                                                      const int32_t *__restrict__ qs_arr,
-                                                                      const int32_t *__restrict__ qe_arr, int64_t nq,
-                                                                      int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
-                                                                      int32_t *__restrict__ counts)
-{
-    __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
-    __shared__ int s_mm[3][LC_THREADS / 64];
-    __shared__ int s_slice[6];  // pLo, pHi, sLo, sHi, qeLo, qeHi
-    const int64_t base = (int64_t)blockIdx.x * LC_CHUNK;
-    const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
-    int mn = INT_MAX, mx = INT_MIN, emx = INT_MIN;
-    for (int k = threadIdx.x; k < n; k += LC_THREADS) {
-        int s = qs_arr[base + k], e = qe_arr[base + k];
-        mn = s < mn ? s : mn;
-        mx = s > mx ? s : mx;
-        emx = e > emx ? e : emx;
-    }
-    mn = wave_min_i32(mn), mx = wave_max_i32(mx), emx = wave_max_i32(emx);
-    if (lane_id() == 0) s_mm[0][threadIdx.x >> 6] = mn, s_mm[1][threadIdx.x >> 6] = mx, s_mm[2][threadIdx.x >> 6] = emx;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        int a = INT_MAX, b = INT_MIN, c = INT_MIN;
-#pragma unroll
-        for (int i = 0; i < LC_THREADS / 64; i++) {
-            a = s_mm[0][i] < a ? s_mm[0][i] : a;
-            b = s_mm[1][i] > b ? s_mm[1][i] : b;
-            c = s_mm[2][i] > c ? s_mm[2][i] : c;
-        }
-        long long cap = (long long)b + 4 * ((long long)b - (long long)a) + 65536;  // see ivl_local_count_kernel
-        if (cap > INT_MAX) cap = INT_MAX;
-        int s_hi_key = (long long)c < cap ? c : (int)cap;
-        if (s_hi_key < a) s_hi_key = a;
-        const int sub = threadIdx.x & 7, upper = (threadIdx.x >> 3) & 1;
-        const int qs_key = upper ? b : a;
-        int keyP[1] = {qs_key == INT_MAX ? INT_MAX : qs_key + 1};  // #{pm <= qs}
-        int keyS[1] = {upper ? s_hi_key : a};
-        int rP[1], rS[1];
-        tree_rank_lt<true, 1>(P, lds, keyP, rP, sub);
-        tree_rank_lt<true, 1>(S, lds, keyS, rS, sub);
-        if (qs_key == INT_MAX || rP[0] > ix.n) rP[0] = ix.n;
-        if (sub == 0 && threadIdx.x < 16) {
-            s_slice[0 + upper] = rP[0];
-            s_slice[2 + upper] = rS[0];
-            s_slice[4 + upper] = upper ? s_hi_key : a;
-        }
-    }
-    __syncthreads();
-    WindowSlices w;
-    w.pLo = s_slice[0], w.nP = s_slice[1] - s_slice[0], w.sLo = s_slice[2], w.nS = s_slice[3] - s_slice[2];
-    w.qeLo = s_slice[4], w.qeHi = s_slice[5];
-    w.strideP = w.nP / LC_TREE_KEYS + 1, w.strideS = w.nS / LC_TREE_KEYS + 1;
-    w.kP = w.kS = 0;
-    while ((1 << w.kP) - 1 < w.nP / w.strideP) w.kP++;
-    while ((1 << w.kS) - 1 < w.nS / w.strideS) w.kS++;
-    int32_t *treeP, *treeS;
-    window_stage<LC_THREADS>(ix, w, lds, treeP, treeS);
-    window_queries<LC_THREADS, false, true>(ix, w, treeP, treeS, base, base + n, qs_arr, qe_arr, win_lo, win_hi, counts);
-}
-
 // Are the starts non-decreasing?  (find path: decided on the host before anything else is launched)
 __global__ void ivl_sorted_check_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ unsorted)
 {
@@ -1735,110 +1568,6 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_kernel(IndexDev ix, co
                 int4 v = *reinterpret_cast<const int4 *>(ix.e_ord + kb);
                 int4 id = *reinterpret_cast<const int4 *>(ix.idx + kb);
                 base[j] += fill_step(v, id, kb, lo[j], hi[j], qs[j], base[j], hits, gshift, below);
-            }
-        }
-    }
-}
-
-// Fill pass for SORTED batches, one LANE per query: neighbouring queries have neighbouring windows of a handful of
-// candidates, so a wave's loads of e_ord[k] / idx[k] fall in a few lines and its stores in a few more, and a short
-// per-lane loop needs ~2 wave-instructions per query where the 8-lanes-per-query kernel above needs ~25 (most of its
-// lanes idle on 5-10-candidate windows): 50M x 50M sorted, 5.9 -> 3.0 ms.  A window longer than LANE_WINDOW is
-// scanned by the whole wave with ballot compaction, so one long window cannot stall 63 other lanes.  NOT for bucket
-// order: inside a bucket the queries are unordered, every lane touches its own lines (measured 8.9 -> 15.8 ms).
-__global__ __launch_bounds__(FIND_THREADS) void part_fill_lane_kernel(IndexDev ix, const int32_t *__restrict__ qs_arr,
-                                                                     int qs_stride /* 2: (qs, qe) pairs */, int64_t nq,
-                                                                     const int32_t *__restrict__ win_lo,
-                                                                     const int32_t *__restrict__ win_hi,
-                                                                     const int32_t *__restrict__ cnt,
-                                                                     const long long *__restrict__ boffs,
-                                                                     int32_t *__restrict__ hits,
-                                                                     const int2 *__restrict__ eid /* (end, index) pairs in start order, or NULL */)
-{
-    const int lane = lane_id();
-    // contiguous block of queries per workgroup, XCD-aware: neighbours in bucket order share lines
-    const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
-    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
-    const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
-    for (int64_t qb = q0; qb < q1; qb += FIND_THREADS) {
-        const int64_t q = qb + threadIdx.x;
-        const bool live = q < q1 && cnt[q] != 0;
-        const int lo = live ? win_lo[q] : 0, hi = live ? win_hi[q] : 0;
-        const int qs = live ? qs_arr[q * qs_stride] : 0;
-        int64_t off = live ? boffs[q] : 0;
-        const bool wide = hi - lo > LANE_WINDOW;
-        if (!wide) {
-            if (eid) {  // one 8-byte read per candidate instead of two 4-byte reads from two arrays
-                for (int k = lo; k < hi; k++) {
-                    const int2 p = eid[k];
-                    if (p.x > qs) hits[off++] = p.y;
-                }
-            } else {
-                for (int k = lo; k < hi; k++) {
-                    const int e = ix.e_ord[k], id = ix.idx[k];
-                    if (e > qs) hits[off++] = id;
-                }
-            }
-        }
-        unsigned long long m = __ballot(wide);
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int L = __shfl(lo, src, 64), H = __shfl(hi, src, 64), S = __shfl(qs, src, 64);
-            int64_t o = __shfl((long long)off, src, 64);
-            for (int k0 = L; k0 < H; k0 += 64) {
-                const int k = k0 + lane;
-                const bool f = k < H && ix.e_ord[k] > S;
-                const unsigned long long fm = __ballot(f);
-                if (f) hits[o + __popcll(fm & ((1ull << lane) - 1ull))] = ix.idx[k];
-                o += __popcll(fm);
-            }
-        }
-    }
-}
-
-// Fill pass for sorted batches from (hi, count) instead of a window [lo, hi): every hit has index < hi = #{start < qe},
-// and the count is known exactly, so a lane walks DOWN from hi - 1 through the (end, index) pairs until it has found its
-// `count` hits, writing them from the end of its CSR range (ascending order is kept).  No prefix-max array, no window
-// kernel: the count pass for sorted batches (ivl_local_count_kernel) supplies both numbers.  A lane that has not finished
-// after LANE_WINDOW candidates hands its walk to the whole wave (64 candidates per step, ballot-compacted from the end).
-__global__ __launch_bounds__(FIND_THREADS) void part_fill_walk_kernel(const int2 *__restrict__ eid /* at index 0 */, const int32_t *__restrict__ qs_arr,
-                                                                     int64_t nq, const int32_t *__restrict__ his, const int32_t *__restrict__ cnt,
-                                                                     const long long *__restrict__ offs, int32_t *__restrict__ hits)
-{
-    const int lane = lane_id();
-    const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
-    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
-    const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
-    for (int64_t qb = q0; qb < q1; qb += FIND_THREADS) {
-        const int64_t q = qb + threadIdx.x;
-        const bool live = q < q1;
-        int c = live ? cnt[q] : 0;
-        int k = (live && c ? his[q] : 0) - 1;
-        const int qs = live ? qs_arr[q] : 0;
-        int32_t *__restrict__ dst = hits + (live ? offs[q] : 0);
-        for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
-            const int2 p = eid[k];
-            if (p.x > qs) dst[--c] = p.y;
-        }
-        unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            int C = __shfl(c, src, 64), K = __shfl(k, src, 64);
-            const int S = __shfl(qs, src, 64);
-            int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
-            while (C > 0 && K >= 0) {
-                const int kk = K - lane;
-                const bool f = kk >= 0 && eid[kk > 0 ? kk : 0].x > S;
-                const unsigned long long fm = __ballot(f);
-                // hits at higher indices come later in the list: lane 0 (the highest index of the step) takes the last free slot
-                const int before = __popcll(fm & ((1ull << lane) - 1ull));
-                if (f && before < C) D[C - 1 - before] = eid[kk].y;
-                C -= __popcll(fm);
-                K -= 64;
             }
         }
     }
@@ -2033,117 +1762,9 @@ __global__ __launch_bounds__(LC_THREADS) void lf_offsets_kernel(const int32_t *_
     }
 }
 
-// find() on a SORTED batch in ONE kernel (round 5): count, CSR offsets and fill per chunk of LC_CHUNK consecutive queries.
-// Round 4 ran ivl_local_count_kernel (counts and `hi` to HBM) -> a three-kernel scan over the counts -> part_fill_flat_kernel
-// (counts, `hi`, offsets and the starts read again): 36 bytes per query moved only to carry a chunk's numbers from one launch to
-// the next.  Here a chunk's counts stay in registers: the workgroup scans them (wave scans + one wave over the 64 (row, wave)
-// totals), gets the hits of all chunks before it by a DECOUPLED LOOK-BACK over per-chunk words (chunks are numbered by a ticket
-// in dispatch order, so every predecessor has started and none waits for a successor; a word carries flag : 2 | value : 62,
-// 1 = the chunk's own total, 2 = the inclusive prefix; RELAXED agent-scope accesses -- the word is the whole message, and on this
-// part an agent-scope release / acquire is a write-back / invalidation of the XCD's L2: the first version, with them, took 3.1 ms
-// where the three launches took 1.9), writes the offsets, and its eight waves fill their 64-query stretches
-// exactly as part_fill_flat_kernel does (the LDS trees of the count half are dead by then: the images live in the same bytes).
-// A chunk whose stretch would pass `cap` writes no hits (the host reports BXMI_ERANGE from the total, as before).
-// state[nchunks] and the ticket are zeroed by the host before the launch.
-constexpr unsigned long long LF_FLAG_AGG = 1ull << 62, LF_FLAG_PREFIX = 2ull << 62, LF_VALUE = (1ull << 62) - 1ull;
-
-__global__ __launch_bounds__(LC_THREADS) void ivl_local_find_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
-                                                                    const int32_t *__restrict__ qs_arr, const int32_t *__restrict__ qe_arr, int64_t nq,
-                                                                    const int2 *__restrict__ eid /* at index 0 */, long long *__restrict__ offsets,
-                                                                    int32_t *__restrict__ hits, long long cap, unsigned long long *__restrict__ state,
-                                                                    unsigned *__restrict__ ticket)
-{
-    constexpr int NW = LC_THREADS / 64;
-    static_assert(NW * LC_ITEMS <= 64, "one wave scans the (row, wave) totals of a chunk");
-    static_assert((size_t)NW * (FF_PAIRS * 8 + FF_HITS * 4) <= (size_t)2 * (LC_TREE_KEYS + 1) * 4, "the fill's images fit the trees' LDS");
-    __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
-    __shared__ int s_mm[3][LC_THREADS / 64];
-    __shared__ int s_slice[6];
-    __shared__ long long s_tot[64];
-    __shared__ long long s_base[2];  // hits before the chunk, hits of the chunk
-    __shared__ unsigned s_chunk;
-    if (threadIdx.x == 0) s_chunk = atomicAdd(ticket, 1u);
-    __syncthreads();
-    const int64_t chunk = s_chunk;
-    const int64_t base = chunk * LC_CHUNK;
-    if (base >= nq) return;
-    const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
-    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
-    int cc[LC_ITEMS], hh[LC_ITEMS], ss[LC_ITEMS];
-    lc_chunk_counts(S, E, ix, e_sorted, qs_arr, qe_arr, base, n, lds, s_mm, s_slice, [&](int j, int, bool live, int c, int s_rank, int s) {
-        cc[j] = live ? c : 0, hh[j] = s_rank, ss[j] = s;
-    });
-    // the chunk's exclusive scan in query order: row j, thread t is query j * LC_THREADS + t
-    long long incl[LC_ITEMS];
-#pragma unroll
-    for (int j = 0; j < LC_ITEMS; j++) {
-        incl[j] = wave_inclusive_scan((long long)cc[j], OpSum());
-        if (lane == 63) s_tot[j * NW + wave] = incl[j];
-    }
-    __syncthreads();  // (also: every lookup in the LDS trees is over)
-    if (wave == 0) {
-        const long long v = s_tot[lane];
-        const long long inc = wave_inclusive_scan(v, OpSum());
-        s_tot[lane] = inc - v;
-        const long long total = __shfl(inc, 63, 64);
-        // decoupled look-back
-        long long before = 0;
-        if (chunk == 0) {
-            if (lane == 0) __hip_atomic_store(state, LF_FLAG_PREFIX | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0) __hip_atomic_store(state + chunk, LF_FLAG_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int64_t p = chunk - 1;  // the nearest predecessor not yet accounted for
-            for (;;) {
-                const int64_t idx = p - lane;
-                const unsigned long long w = idx >= 0 ? __hip_atomic_load(state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LF_FLAG_PREFIX;
-                const unsigned flag = (unsigned)(w >> 62);
-                const unsigned long long m_empty = __ballot(flag == 0u), m_prefix = __ballot(flag == 2u);
-                const int first_prefix = m_prefix ? __ffsll((long long)m_prefix) - 1 : 64;
-                const int first_empty = m_empty ? __ffsll((long long)m_empty) - 1 : 64;
-                if (first_empty < first_prefix) {  // a predecessor nearer than any finished prefix has not published yet
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                long long contrib = lane <= first_prefix ? (long long)(w & LF_VALUE) : 0ll;  // (first_prefix = 64: all 64 are plain totals)
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
-                before += contrib;
-                if (first_prefix < 64) break;
-                p -= 64;
-            }
-            if (lane == 0)
-                __hip_atomic_store(state + chunk, LF_FLAG_PREFIX | (unsigned long long)(before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) {
-            s_base[0] = before, s_base[1] = total;
-            if (base + n == nq) offsets[nq] = before + total;  // the last chunk: the batch's total
-        }
-    }
-    __syncthreads();
-    const long long before = s_base[0];
-    const bool fits = before + s_base[1] <= cap;
-    long long off[LC_ITEMS];
-#pragma unroll
-    for (int j = 0; j < LC_ITEMS; j++) {
-        const int k = j * LC_THREADS + (int)threadIdx.x;
-        off[j] = before + s_tot[j * NW + wave] + incl[j] - cc[j];
-        if (k < n) offsets[base + k] = off[j];
-    }
-    if (!fits || s_base[1] == 0) return;
-    // the fill: wave w's row j is 64 consecutive queries
-    int2 *wp = reinterpret_cast<int2 *>(lds) + wave * FF_PAIRS;
-    int32_t *wh = lds + NW * FF_PAIRS * 2 + wave * FF_HITS;
-    FfStage stg;
-    ff_load(eid, cc[0], hh[0], stg);
-#pragma unroll
-    for (int j = 0; j < LC_ITEMS; j++) {
-        FfStage nstg = stg;
-        if (j + 1 < LC_ITEMS) ff_load(eid, cc[j + 1], hh[j + 1], nstg);  // the next row's pairs travel while this one is walked
-        ff_wave_fill(wp, wh, eid, stg, cc[j], hh[j], ss[j], off[j], hits);
-        stg = nstg;
-    }
-}
-
+// (Round 5's fused variant -- count, CSR offsets by decoupled look-back and fill in ONE kernel -- measured 2.65 ms against 1.45 for the
+// stages: the count half is a chain of dependent loads that lives on four workgroups per CU, the fused kernel's registers left two.
+// Removed in round 6; HISTORY.md has its design.)
 __global__ void part_fold_total_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
 {
     unsigned long long v = threadIdx.x < PT_SLOTS ? slots[threadIdx.x] : 0ull;
@@ -2486,36 +2107,21 @@ __global__ void cluster_finish_kernel(const unsigned long long *__restrict__ key
     }
 }
 
-static int64_t g_opt_group_sum = 0;   // 0 = DPP, 1 = ds_bpermute shuffles
-static int64_t g_opt_lds_ints = LDS_TREE_INTS;
-static int64_t g_opt_count_grid = 0;  // 0 = one workgroup per CU
 static int64_t g_opt_partition = -1;  // -1 = auto (large batches), 0 = never, 1 = always
 static int64_t g_opt_partition_min = 4 << 20;  // auto: partition batches of at least this many queries
 constexpr int PT_MAX_SUB = 1;  // scratch regions are addressed per sub-batch; one region since sub-batch pipelining was dropped
 constexpr int PT_SLOT_STRIDE = PT_SLOTS + 8;  // per sub-batch: the partial totals, then the "unsorted" flag
-static int64_t g_opt_count_cells = 1;  // 1 = direct-addressed cells in the bucket search, 0 = LDS search trees
 static int64_t g_opt_sorted_path = 1;  // 1 = batches whose starts are already sorted skip the bucketing (detected on the device)
-static int64_t g_opt_find_fill = 0;    // bucketed find: 0 = hits written from bucket order, 1 / 2 = from query order (8 lanes / 1 lane per window)
 static int64_t g_opt_bitmap = -1;      // second-generation count pass (count_bitmap.hpp): -1 = when the index qualifies, 0 = never, 1 = same as -1
 static int64_t g_opt_bitmap_min = 2 << 20;  // auto: batches of at least this many queries take it (when the index qualifies)
 static int64_t g_opt_bm_variant = -1;  // tile kernel shape: -1 = by batch size, 0 = 512 threads x 32 queries, 1 = 1024 x 16, 2 = 1024 x 32 (32768-query tiles)
-static int64_t g_opt_find_fused = 0;   // find() on a sorted batch: 1 = count, offsets (decoupled look-back) and fill in one kernel (ivl_local_find_kernel: measured 2.65 ms
-                                       // against 1.58 for the stages -- the count half is a long chain of dependent loads that lives on four workgroups per CU, the
-                                       // fused kernel's registers leave two), 0 = the stages (default)
-static int64_t g_opt_fx_flat = 0;      // find() through the exchange: 1 = the count half as the flat walk on key slices (measured on configs[4]: 531 us against 474 for the lane groups per run, the default)
 static int64_t g_opt_fx_direct = -1;   // find() through the exchange: 1 = the fill writes straight into the CSR list (query-order prefixes from the un-permute
                                        // kernel, no copy), 0 = scratch + copy, -1 = by the size of the list the handle expects (see ivl_find_fx)
-static int64_t g_opt_fx_copy2 = 2;     // find() through the exchange, the copy: queries per lane -- 2 / 4 (fx_hits_copy2_kernel), 0 = one (fx_hits_copy_kernel)
-static int64_t g_opt_fx_fill = 1;      // find() through the exchange: 1 = the fill half on LDS windows of half-bucket pieces (find_exchange.hpp), 0 = round 2's fill and copy
 static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
 static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by run length and LDS, else forced (tests)
 static int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_CHUNK, twice that for bucket pairs)
-static int64_t g_opt_sl_hcopy = 1;     // hit un-permute: 1 = sl_hits_copy_kernel (1024 consecutive queries per workgroup, a tile's workgroups on one XCD), 0 = one workgroup per tile
-static int64_t g_opt_sl_hu_parts = 1;  // hit un-permute: workgroups per tile (1, 2, 4, 8, 16), run back to back on one XCD
 static int64_t g_opt_sl_run_cap = 160;  // a slice unit grows only while its expected (tile, unit) run stays within this many records
-static int64_t g_opt_find_pairs = 1;   // sorted find(): the fill reads (end, index) pairs (one array) instead of the two index arrays
-static int64_t g_opt_lc_loop = 0;      // the sorted-batch kernel behind the order check: 0 = a workgroup per chunk, 1 = four chunks per workgroup, -1 = by what the handle's earlier order checks found (bm_count_segments; see there why it is not the default)
 static int64_t g_opt_sl_flat = 1;      // 1 = count-only passes on key slices take the flat 16-byte walk of count_dense.hpp (16-bit counts, unit run table), 0 = the 16 / 64 lanes-per-run kernels of count_slices.hpp
 static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
@@ -2524,7 +2130,6 @@ static int64_t g_opt_flat = -1;       // the flat 16-byte walk on cell images of
 static int64_t g_opt_sparse = -1;     // offset-cell images for sparse indexes (offset_cells.hpp; the persistent walk): -1 = sparse indexes that qualify, batches that bring enough queries per unit; 0 = never; 1 = whatever the batch size
 static int64_t g_opt_bo_cell_log2 = 0;  // their cell width: 0 = from the index's density, 6..8 = forced
 static int64_t g_opt_bo_min_per_unit = 4096;  // queries per unit image a batch must bring (an image is 72 KB to load whatever the batch)
-static int64_t g_opt_find_flat = 1;     // find() on a sorted batch: 1 = the fill that stages a wave's pairs and hits in LDS (part_fill_flat_kernel), 0 = one lane per query straight on HBM
 static int64_t g_opt_sorted_cells = 1;  // sorted batches on indexes with cell images: 1 = answered from the images stretch by stretch (bs_*), 0 = the first-generation kernel for sorted batches
 static int64_t g_opt_dense = -1;      // search stage on dense unit images (count_dense.hpp): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
 static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
@@ -2532,7 +2137,6 @@ static int64_t g_opt_bd_table_from = 0;  // dense images: overflow entries from 
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
 static int64_t g_opt_bd_w8 = -1;      // 8-bit counts out of place: -1 = by index and feedback, 0 = never, 1 = whenever the layout allows
 static int64_t g_opt_order_skip = -1;  // -1 = stop launching the order check after two batches in a row were not sorted (a probe of 8192 starts rides on the parameter kernel then), 0 = always check
-static int64_t g_opt_stage_sync = 0;  // diagnostics: wait for every stage of the count pass and say on stderr which one finished
 static int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
 
 // The option table: every knob of the interval path, its variable and how a value is normalised.  bxmi_set_option writes through
@@ -2544,31 +2148,18 @@ struct IvlOpt {
     int64_t (*norm)(int64_t);
 };
 static const IvlOpt IVL_OPTS[] = {
-    {"ivl.group_sum", &g_opt_group_sum, nullptr},
-    {"ivl.lds_ints", &g_opt_lds_ints, [](int64_t value) -> int64_t { return value < 0 ? 0 : (value > LDS_TREE_INTS ? LDS_TREE_INTS : value); }},
-    {"ivl.count_grid", &g_opt_count_grid, nullptr},
     {"ivl.partition", &g_opt_partition, nullptr},
-    {"ivl.count_cells", &g_opt_count_cells, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.sorted_path", &g_opt_sorted_path, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.partition_min", &g_opt_partition_min, nullptr},
-    {"ivl.find_fill", &g_opt_find_fill, nullptr},
     {"ivl.bitmap_min", &g_opt_bitmap_min, nullptr},
     {"ivl.bitmap", &g_opt_bitmap, nullptr},
     {"ivl.bm_variant", &g_opt_bm_variant, [](int64_t value) -> int64_t { return value < 0 || value > 2 ? -1 : value; }},
     {"ivl.find_sliced", &g_opt_find_sliced, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.fx_fill", &g_opt_fx_fill, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.find_fused", &g_opt_find_fused, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.fx_flat", &g_opt_fx_flat, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.fx_copy2", &g_opt_fx_copy2, [](int64_t value) -> int64_t { return value == 4 ? 4 : value != 0 ? 2 : 0; }},
     {"ivl.fx_direct", &g_opt_fx_direct, [](int64_t value) -> int64_t { return value < 0 ? -1 : value != 0; }},
     {"ivl.slice", &g_opt_slice, nullptr},
     {"ivl.sl_f", &g_opt_sl_f, [](int64_t value) -> int64_t { return value > SL_MAX_F ? SL_MAX_F : value; }},
     {"ivl.bm_chunk", &g_opt_bm_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
-    {"ivl.sl_hcopy", &g_opt_sl_hcopy, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.sl_hu_parts", &g_opt_sl_hu_parts, [](int64_t value) -> int64_t { return value == 2 || value == 4 || value == 8 || value == 16 ? value : 1; }},
     {"ivl.sl_run_cap", &g_opt_sl_run_cap, [](int64_t value) -> int64_t { return value < 8 ? 8 : value; }},
-    {"ivl.find_pairs", &g_opt_find_pairs, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.lc_loop", &g_opt_lc_loop, [](int64_t value) -> int64_t { return value < 0 ? -1 : (value != 0); }},
     {"ivl.sl_flat", &g_opt_sl_flat, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.sl_rbits", &g_opt_sl_rbits, [](int64_t value) -> int64_t { return value < 17 ? 17 : (value > 24 ? 24 : value); }},
     {"ivl.sl_lanes", &g_opt_sl_lanes, [](int64_t value) -> int64_t { return value == 16 || value == 64 ? value : (value == 1 ? -1 : 0); /* 1 = the flat walk */ }},
@@ -2576,7 +2167,6 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.flat", &g_opt_flat, nullptr},
     {"ivl.dense", &g_opt_dense, nullptr},
     {"ivl.sparse", &g_opt_sparse, nullptr},
-    {"ivl.find_flat", &g_opt_find_flat, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.sorted_cells", &g_opt_sorted_cells, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.bo_cell_log2", &g_opt_bo_cell_log2, [](int64_t value) -> int64_t { return value < BO_MIN_K || value > BO_MAX_K ? 0 : value; }},
     {"ivl.bo_min_per_unit", &g_opt_bo_min_per_unit, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
@@ -2585,7 +2175,6 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.bd_table_from", &g_opt_bd_table_from, [](int64_t value) -> int64_t { return value < 1 || value > 64 ? 0 : value; }},
     {"ivl.bd_w8", &g_opt_bd_w8, nullptr},
     {"ivl.order_skip", &g_opt_order_skip, nullptr},
-    {"ivl.stage_sync", &g_opt_stage_sync, nullptr},
     {"ivl.bd_unit_log2", &g_opt_bd_unit_log2, [](int64_t value) -> int64_t { return value < 12 || value > BD_UNIT_LOG2 ? 0 : value; }},
 };
 constexpr int IVL_NOPTS = (int)(sizeof(IVL_OPTS) / sizeof(IVL_OPTS[0]));
@@ -2754,19 +2343,14 @@ static int ivl_count_part_sub(bxmi_ivl *h, int sub, int64_t q0, const int32_t *q
         // sorted batch: one pass over the queries as they lie (exits at once otherwise)
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
-        hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
+        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
                            h->e_sorted.as<int32_t>(), qs, qe, nq, counts, total_dev ? slots : nullptr, unsorted);
     }
     const unsigned grid = (unsigned)(div_up(nq, PT_CHUNK) + PT_NB);
     unsigned short *cnt16 = counts ? h->p_cnt.as<unsigned short>() + q0 : nullptr;  // counts in bucket order, 16 bits + escape
-    if (g_opt_count_cells)
-        hipLaunchKernelGGL(part_count_cells_kernel<unsigned short>, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
-                           h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), h->cell_images.as<int32_t>(),
-                           h->cell_meta.as<CellsMeta>(), pp.plan, pp.table, pp.bq, nq, h->geom, cnt16, total_dev ? slots : nullptr, unsorted);
-    else
-        hipLaunchKernelGGL(part_count_kernel<unsigned short>, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
-                           h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), pp.plan, pp.table, pp.bq, nq, cnt16,
-                           total_dev ? slots : nullptr, unsorted);
+    hipLaunchKernelGGL(part_count_cells_kernel<unsigned short>, dim3(grid), dim3(PT_THREADS), (size_t)PT_LDS_INTS * 4, st, index_dev(h),
+                       h->e_sorted.as<int32_t>(), h->slice_bounds.as<SliceBound>(), h->cell_images.as<int32_t>(),
+                       h->cell_meta.as<CellsMeta>(), pp.plan, pp.table, pp.bq, nq, h->geom, cnt16, total_dev ? slots : nullptr, unsorted);
     BXMI_LAUNCH_CHECK();
     if (counts) {
         hipLaunchKernelGGL(part_gather_kernel<unsigned short>, dim3(pp.tgrid), dim3(PT_THREADS), 0, st, cnt16, pp.lpos, pp.table, pp.ntiles, nq,
@@ -2788,9 +2372,8 @@ static int ivl_count_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *
 {
     if (nq >= ((int64_t)1 << 31)) return fail(BXMI_EINVAL, "bxmi_ivl_count: more than 2^31 queries in one batch");
     BXMI_TRY(part_reserve(h, nq, counts != nullptr));
-    BXMI_TRY(allow_big_lds(part_count_kernel<unsigned short>, (size_t)PT_LDS_INTS * 4));
     BXMI_TRY(allow_big_lds(part_count_cells_kernel<unsigned short>, (size_t)PT_LDS_INTS * 4));
-    if (g_opt_count_cells && !h->images_ready) {
+    if (!h->images_ready) {
         // LDS images of every bucket for the search (159 MB, a property of the sealed index): built by the first large
         // batch, so the many small per-chromosome trees of the drop-in classes never pay for them
         BXMI_TRY(h->cell_images.reserve((size_t)PT_NB * PT_LDS_INTS * sizeof(int32_t)));
@@ -2822,35 +2405,17 @@ static int sl_ensure_eid(bxmi_ivl *h, hipStream_t st)
 static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits, int64_t cap,
                           int64_t *total_host, hipStream_t st)
 {
-    const bool walk = g_opt_find_pairs != 0;  // (hi, count) from the sorted-batch count kernel, then a walk down the pairs
-    if (walk && g_opt_find_flat && g_opt_find_fused) {  // count, offsets and fill in one kernel
-        const int64_t nchunks = div_up(nq, LC_CHUNK);
-        BXMI_TRY(h->lf_state.reserve((size_t)(nchunks + 2) * 8));
-        BXMI_HIP(hipMemsetAsync(h->lf_state.p, 0, (size_t)(nchunks + 2) * 8, st));
-        BXMI_TRY(sl_ensure_eid(h, st));
-        TreeDev S = h->treeS.dev, E = h->treeE.dev;
-        S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
-        hipLaunchKernelGGL(ivl_local_find_kernel, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(), qs, qe, nq,
-                           h->sl_eid.as<int2>() + SL_WALK, reinterpret_cast<long long *>(offsets), hits, (long long)cap, h->lf_state.as<unsigned long long>(),
-                           reinterpret_cast<unsigned *>(h->lf_state.as<unsigned long long>() + nchunks));
-        BXMI_LAUNCH_CHECK();
-        int64_t total = 0;
-        BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
-        BXMI_HIP(hipStreamSynchronize(st));
-        if (total_host) *total_host = total;
-        if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
-        return BXMI_OK;
-    }
     BXMI_TRY(h->p_lo.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_hi.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
-    const bool chunk_scan = walk && ((uintptr_t)offsets & 15) == 0;  // the offsets from one scan over the chunks' totals
-    if (walk) {
+    // (hi, count) from the sorted-batch count kernel, the offsets from one scan over the chunks' totals, then a walk down the pairs
+    const bool chunk_scan = ((uintptr_t)offsets & 15) == 0;  // (lf_offsets_kernel stores 16 bytes at a time)
+    {
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
         const int64_t nchunks = div_up(nq, LC_CHUNK);
         if (chunk_scan) BXMI_TRY(h->lf_state.reserve((size_t)(2 * nchunks + 4) * 8));
-        hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
+        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
                            h->e_sorted.as<int32_t>(), qs, qe, nq, h->q_cnt.as<int32_t>(), (unsigned long long *)nullptr, (const unsigned *)nullptr,
                            h->p_hi.as<int32_t>(), (unsigned long long *)nullptr, 0ull, chunk_scan ? h->lf_state.as<unsigned long long>() : nullptr);
         if (chunk_scan) {
@@ -2860,11 +2425,6 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
             hipLaunchKernelGGL(lf_offsets_kernel, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, h->q_cnt.as<int32_t>(), chunk_base, nq,
                                reinterpret_cast<long long *>(offsets));
         }
-    } else {
-        TreeDev S = h->treeS.dev, P = h->treeP.dev;
-        S.lds_from = S.nlev, S.lds_ints = 0, P.lds_from = P.nlev, P.lds_ints = 0;  // walk the global levels only
-        hipLaunchKernelGGL(ivl_local_window_kernel, dim3((unsigned)div_up(nq, LC_CHUNK)), dim3(LC_THREADS), 0, st, S, P, index_dev(h), qs, qe, nq,
-                           h->p_lo.as<int32_t>(), h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
     }
     BXMI_LAUNCH_CHECK();
     if (!chunk_scan)
@@ -2876,19 +2436,9 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     if (total_host) *total_host = total;
     if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     if (total == 0) return BXMI_OK;
-    int fgrid = device_props().cus * 8;
-    if (walk) {
-        BXMI_TRY(sl_ensure_eid(h, st));
-        if (g_opt_find_flat)
-            hipLaunchKernelGGL(part_fill_flat_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq, h->p_hi.as<int32_t>(),
-                               h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
-        else
-            hipLaunchKernelGGL(part_fill_walk_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq, h->p_hi.as<int32_t>(),
-                               h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
-    } else {
-        hipLaunchKernelGGL(part_fill_lane_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->p_lo.as<int32_t>(),
-                           h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (const int2 *)nullptr);
-    }
+    BXMI_TRY(sl_ensure_eid(h, st));
+    hipLaunchKernelGGL(part_fill_flat_kernel, dim3(device_props().cus * 8), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq,
+                       h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -2929,27 +2479,6 @@ static int ivl_find_partitioned(bxmi_ivl *h, const int32_t *qs, const int32_t *q
     if (total_host) *total_host = total;
     if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     if (total == 0) return BXMI_OK;
-    if (g_opt_find_fill) {
-        // Hits written in QUERY order: the windows go back to query order like the counts did (two more gathers), and the fill
-        // then reads the index at random places but stores to consecutive ones -- instead of the other way round below.
-        BXMI_TRY(h->q_lo.reserve((size_t)(nq + 4) * 4));
-        BXMI_TRY(h->q_hi.reserve((size_t)(nq + 4) * 4));
-        hipLaunchKernelGGL(part_gather_kernel<int32_t>, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_lo.as<int32_t>(), lpos, table, ntiles, nq,
-                           h->q_lo.as<int32_t>(), (const unsigned *)nullptr, index_dev(h), (const int32_t *)nullptr, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr);
-        hipLaunchKernelGGL(part_gather_kernel<int32_t>, dim3(tgrid), dim3(PT_THREADS), 0, st, h->p_hi.as<int32_t>(), lpos, table, ntiles, nq,
-                           h->q_hi.as<int32_t>(), (const unsigned *)nullptr, index_dev(h), (const int32_t *)nullptr, (const int32_t *)nullptr,
-                           (const int32_t *)nullptr);
-        const int fgrid = device_props().cus * 8;
-        if (g_opt_find_fill == 2)
-            hipLaunchKernelGGL(part_fill_lane_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->q_lo.as<int32_t>(),
-                               h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (const int2 *)nullptr);
-        else
-            hipLaunchKernelGGL(part_fill_kernel, dim3(fgrid), dim3(FIND_THREADS), 0, st, index_dev(h), qs, 1, nq, h->q_lo.as<int32_t>(),
-                               h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
-        BXMI_LAUNCH_CHECK();
-        return BXMI_OK;
-    }
     const size_t perm_lds = (size_t)PT_TILE * 8 + (PT_NB + 2) * 2 + PT_NB * 4 + 64;
     BXMI_TRY(allow_big_lds(part_permute_i64_kernel, perm_lds));
     hipLaunchKernelGGL(part_permute_i64_kernel, dim3(tgrid), dim3(PT_THREADS), perm_lds, st, reinterpret_cast<const long long *>(offsets), lpos,
@@ -3223,10 +2752,6 @@ static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hip
         hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS, 2>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
                            h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, loff, h->fx_svq.as<unsigned>(),
                            h->fx_parts.as<unsigned long long>(), h->fx_tile_tot.as<unsigned long long>());
-    } else if (loff) {
-        BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS, 1>), lds));
-        hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS, 1>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
-                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, loff);
     } else {
         BXMI_TRY(allow_big_lds((bm_unpermute_kernel<THREADS, ITEMS>), lds));
         hipLaunchKernelGGL((bm_unpermute_kernel<THREADS, ITEMS>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, cnt,
@@ -3237,12 +2762,10 @@ static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hip
 }
 
 // The bitmap-cell pass over a batch of n segments (n sealed, qualifying indexes with their queries): [order check ->]
-// tile sort -> run table + plan -> search -> un-permute -> totals, all on `st`, six launches whatever n is.
+// tile sort (with the batch's parameter block) -> run table -> plan -> search -> un-permute (the tiles' sums straight to the callers'
+// totals), all on `st`, five launches for up to 16 segments; with the order check in front or more segments the parameter kernel
+// and the fold of the partial totals are launches of their own.
 // counts[i] may be NULL (total only: nothing is stored per query); totals_dev[i] may be.  The scratch of hs[0] serves the whole batch.
-#ifndef FX_FLAT_DEPTH
-#define FX_FLAT_DEPTH 2
-#define FX_FLAT_PIPE false
-#endif
 #ifndef SL_FIND_U
 #define SL_FIND_U 2  // runs per lane group and round of find()'s count half
 #endif
@@ -3259,41 +2782,6 @@ static int sl_launch_search(const BmLaunch &L, unsigned grid, hipStream_t st, un
         hipLaunchKernelGGL((sl_search_pipe_kernel<LANES, 2, false>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
                            h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), (unsigned *)nullptr, L.tile_log2, L.gate);
     }
-    BXMI_LAUNCH_CHECK();
-    return BXMI_OK;
-}
-
-template <int LANES>
-static int sl_launch_fill(const BmLaunch &L, unsigned grid, hipStream_t st, const unsigned *loff, const long long *offsets, const int2 *eid,
-                          int32_t *tmp_hits)
-{
-    bxmi_ivl *h = L.owner;
-    BXMI_TRY(allow_big_lds((sl_fill_pipe_kernel<LANES, 2>), L.search_lds));
-    hipLaunchKernelGGL((sl_fill_pipe_kernel<LANES, 2>), dim3(grid), dim3(SL_THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
-                       h->bm_items.as<int>(), h->bm_runT.as<unsigned>(), L.ntp, h->bm_recs.as<unsigned>(), loff, offsets, eid, tmp_hits, L.tile_log2);
-    BXMI_LAUNCH_CHECK();
-    return BXMI_OK;
-}
-
-template <int THREADS, int ITEMS>
-static int sl_launch_hits_unpermute(const BmLaunch &L, hipStream_t st, const unsigned *loff, const long long *offsets, const int32_t *tmp_hits,
-                                    int32_t *hits)
-{
-    bxmi_ivl *h = L.owner;
-    if (g_opt_sl_hcopy) {
-        constexpr int TILE = THREADS * ITEMS;
-        const unsigned grid = (unsigned)(div_up(L.ntp, 8) * 8 * (TILE / HC_Q));
-        hipLaunchKernelGGL((sl_hits_copy_kernel<TILE>), dim3(grid), dim3(HC_Q), 0, st, L.segs, L.tile_seg, loff, h->bm_slots.as<unsigned short>(), offsets,
-                           tmp_hits, hits, L.ntp);
-        BXMI_LAUNCH_CHECK();
-        return BXMI_OK;
-    }
-    const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned);
-    BXMI_TRY(allow_big_lds((sl_hits_unpermute_kernel<THREADS, ITEMS>), lds));
-    const int parts = g_opt_sl_hu_parts > 0 ? (int)g_opt_sl_hu_parts : 1;
-    const unsigned grid = (unsigned)(div_up(L.ntp, 8) * 8 * parts);
-    hipLaunchKernelGGL((sl_hits_unpermute_kernel<THREADS, ITEMS>), dim3(grid), dim3(THREADS), lds, st, L.segs, L.tile_seg, loff,
-                       h->bm_slots.as<unsigned short>(), offsets, tmp_hits, hits, L.ntp, parts);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -3416,7 +2904,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     const bool slices = kind == 2, cells = kind == 4 || wide;
     const bool fxsub = fx && fx->sub;
     // (find() needs 32-bit counts apart from the records and the tile-sorted offsets: the flat walk has that form for find_exchange.hpp only)
-    const bool slices_flat = slices && ((!fx && g_opt_sl_flat != 0) || (fxsub && g_opt_fx_flat != 0));
+    const bool slices_flat = slices && !fx && g_opt_sl_flat != 0;
     const bool dense = kind == 3 || cells || slices_flat /* the flat walk */;
     bxmi_ivl *h = hs[0];
     int64_t nq_all = 0;
@@ -3430,6 +2918,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     int variant = g_opt_bm_variant >= 0 ? (int)g_opt_bm_variant : (nq_all >= ((int64_t)32 << 20) * (n == 1 ? 1 : 2) ? 2 : 0);
     // cell images are searched on padded runs only: a unit of two buckets needs a tile sort whose threads own two buckets each
     // (the 1024-thread shapes), the 512-thread shape owns four
+    // ... and the 1024-thread shape is the faster sort for cell images whatever the unit (a rank's share of a genome, offset cells,
+    // f >= 2: 0.413 / 0.241 / 0.138 ms for 50 / 25 / 13 M queries against 0.432 / 0.259 / 0.147 with 512 threads x 32 queries)
+    if (cells && variant == 0 && g_opt_bm_variant < 0) variant = 1;
     if (cells && variant == 0)
         for (int i = 0; i < n; i++)
             if ((wide ? hs[i]->bo_geom : hs[i]->bp_geom).f < 2) variant = 1;
@@ -3689,22 +3180,8 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         TreeDev S = h->treeS.dev, E = h->treeE.dev;
         S.lds_from = S.nlev, S.lds_ints = 0, E.lds_from = E.nlev, E.lds_ints = 0;  // walk the global levels only
         const int64_t nchunks = div_up(nq[0], LC_CHUNK);
-        // The kernel for sorted batches has two shapes: a workgroup per chunk (0.64 ms for 100 M sorted queries, but 24 000
-        // workgroups to dismiss when the batch is NOT sorted: 12 us) or LC_LOOP chunks per workgroup (5 us to dismiss, 0.89 ms
-        // when it does run).  Which one is launched follows what the order checks of the handle's earlier passes found
-        // (read from host memory, no synchronisation, possibly a few passes late): after two answers "not sorted" in a
-        // row the second shape, after one "sorted" the first again.  The results never depend on it.
-        // NOT the default (ivl.lc_loop = -1 asks for it): a caller that enqueues passes back to back is many passes ahead of
-        // the answers, so the first sorted batches after shuffled ones ALL meet the slow shape (bench.py's sorted leg: 0.88
-        // instead of 0.64 ms) -- 7 us per shuffled pass do not pay for that.
-        const unsigned long long seq = order_seq;
-        const bool loop = g_opt_lc_loop > 0 || (g_opt_lc_loop < 0 && h->unsorted_streak >= 2);
-        if (loop && nchunks >= 4096)
-            hipLaunchKernelGGL(ivl_local_count_kernel<true>, dim3((unsigned)div_up(nchunks, LC_LOOP)), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
-                               h->e_sorted.as<int32_t>(), qs[0], qe[0], nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->bd_fb_host + 1, seq);
-        else
-            hipLaunchKernelGGL(ivl_local_count_kernel<false>, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(),
-                               qs[0], qe[0], nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->bd_fb_host + 1, seq);
+        hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h), h->e_sorted.as<int32_t>(),
+                           qs[0], qe[0], nq[0], counts[0], tslots, unsorted, (int32_t *)nullptr, h->bd_fb_host + 1, order_seq);
         BXMI_LAUNCH_CHECK();
         }
     }
@@ -3719,13 +3196,6 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
                            L.tile_seg, tile_log2, h->fx_runT2.as<unsigned>(), ntp, (unsigned *)nullptr, unsorted);
         BXMI_LAUNCH_CHECK();
     }
-    auto stage_done = [&](const char *what) {
-        if (!g_opt_stage_sync) return;
-        const hipError_t e = hipStreamSynchronize(st);
-        fprintf(stderr, "[bxmi] count pass: %s %s (ntp %lld, pad %d, variant %d, chunk %d)\n", what, e == hipSuccess ? "done" : hipGetErrorString(e),
-                (long long)ntp, (int)pad, variant, chunk);
-    };
-    stage_done("tile sort");
     if (dense) {
         hipLaunchKernelGGL(bd_transpose_kernel, dim3((unsigned)ngroups, BM_NB / 64), dim3(256), 0, st, h->bm_tbl.as<unsigned short>(), L.segs, L.tile_seg,
                            tile_log2, h->bd_unitT.as<unsigned short>(), ntp, h->sl_unitcnt.as<unsigned>(), unsorted,
@@ -3745,16 +3215,8 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
                        h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     }
     BXMI_LAUNCH_CHECK();
-    stage_done("transpose + plan");
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
-    if (slices_flat && fxsub) {
-        BXMI_TRY(allow_big_lds((bd_search_kernel<2, false, 0, FX_FLAT_DEPTH, FX_FLAT_PIPE, false, false, true>), L.search_lds));
-        hipLaunchKernelGGL((bd_search_kernel<2, false, 0, FX_FLAT_DEPTH, FX_FLAT_PIPE, false, false, true>), dim3(sgrid), dim3(BD_THREADS), L.search_lds, st, L.segs,
-                           h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(),
-                           (unsigned short *)nullptr, L.tile_log2, L.gate, search_out, h->fx_hc.as<unsigned>());
-        BXMI_LAUNCH_CHECK();
-        fx->L = L, fx->sgrid = sgrid, fx->lanes = 16, fx->variant = variant;
-    } else if (slices_flat)
+    if (slices_flat)
         BXMI_TRY(bd_launch_search(L, sgrid, 2, false, st));
     else if (slices) {
         // long runs (sparse index, big units): the flat walk; else L lanes per run
@@ -3770,7 +3232,6 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     } else
         BXMI_TRY(bd_launch_search(L, sgrid, cells ? 1 : 0, any_blocks, st));
     unsigned *loff = fx ? h->sl_loff.as<unsigned>() : nullptr;
-    stage_done("search");
     // No sorted-batch kernels in front (they leave partial totals of their own): the un-permute kernel adds every tile's sum straight
     // to the caller's total of its segment and the probe has reported to the host itself -- nothing is left to fold.
     const bool direct_totals = dense && !fxsub && !unsorted;
@@ -3784,7 +3245,6 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff, fxsub ? (fx->direct ? 3 : 2) : 0)));
     else
         BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff, fxsub ? (fx->direct ? 3 : 2) : 0)));
-    stage_done("unpermute");
     if (any_total && !direct_totals) {
         hipLaunchKernelGGL(bm_fold_totals_kernel, dim3((unsigned)n), dim3(64), 0, st, slots,
                            reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes));
@@ -3918,60 +3378,14 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     BXMI_LAUNCH_CHECK();
     if (fx.direct) return BXMI_OK;  // (every record's hits went where the CSR offsets say)
     const unsigned cgrid = (unsigned)(div_up(ntp, 8) * 8 * (((int64_t)1 << fx.L.tile_log2) / BM_PART_Q));
-    if (g_opt_fx_copy2 != 0) {  // several queries per lane
-        auto launch = [&](auto kern, int qpl) {
-            hipLaunchKernelGGL(kern, dim3(cgrid), dim3(BM_PART_Q / qpl), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(), h->fx_tile_base.as<long long>(),
+    {  // two consecutive queries per lane (one: 0.91 ms on configs[4], two: 0.78, four: 0.85)
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(cgrid), dim3(BM_PART_Q / 2), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(), h->fx_tile_base.as<long long>(),
                                h->fx_parts.as<unsigned long long>(), h->sl_hits.as<int32_t>(), reinterpret_cast<long long *>(offsets), hits, ntp);
         };
-        if (g_opt_fx_copy2 == 4) {
-            if (fx.variant == 2) launch(fx_hits_copy2_kernel<32768, 4>, 4); else launch(fx_hits_copy2_kernel<16384, 4>, 4);
-        } else {
-            if (fx.variant == 2) launch(fx_hits_copy2_kernel<32768, 2>, 2); else launch(fx_hits_copy2_kernel<16384, 2>, 2);
-        }
-        BXMI_LAUNCH_CHECK();
-        return BXMI_OK;
+        if (fx.variant == 2) launch(fx_hits_copy2_kernel<32768, 2>); else launch(fx_hits_copy2_kernel<16384, 2>);
     }
-    if (fx.variant == 2)
-        hipLaunchKernelGGL((fx_hits_copy_kernel<32768>), dim3(cgrid), dim3(BM_PART_Q), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(), h->fx_tile_base.as<long long>(),
-                           h->fx_parts.as<unsigned long long>(), h->sl_hits.as<int32_t>(), reinterpret_cast<long long *>(offsets), hits, ntp);
-    else
-        hipLaunchKernelGGL((fx_hits_copy_kernel<16384>), dim3(cgrid), dim3(BM_PART_Q), 0, st, fx.L.segs, h->fx_svq.as<unsigned>(), h->fx_tile_base.as<long long>(),
-                           h->fx_parts.as<unsigned long long>(), h->sl_hits.as<int32_t>(), reinterpret_cast<long long *>(offsets), hits, ntp);
     BXMI_LAUNCH_CHECK();
-    return BXMI_OK;
-}
-
-// find() for a large unsorted batch on an index the slice stage serves: count half (counts in query order, tile-sorted
-// offsets), CSR offsets, capacity check on the host, fill half, hits back to query order.  See count_slices.hpp.
-static int ivl_find_sliced(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits, int64_t cap,
-                           int64_t *total_host, hipStream_t st)
-{
-    BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
-    BmFindCtx fx;
-    int32_t *counts = h->q_cnt.as<int32_t>();
-    int64_t *no_total = nullptr;
-    BXMI_TRY(bm_count_segments(&h, 1, &qs, &qe, &nq, &counts, &no_total, st, 2, &fx));
-    BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
-                                                           reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
-    int64_t total = 0;
-    BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
-    BXMI_HIP(hipStreamSynchronize(st));
-    if (total_host) *total_host = total;
-    if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
-    if (total == 0) return BXMI_OK;
-    BXMI_TRY(h->sl_hits.reserve((size_t)(total + 16) * 4));
-    BXMI_TRY(sl_ensure_eid(h, st));
-    const unsigned *loff = h->sl_loff.as<unsigned>();
-    const long long *offs = reinterpret_cast<const long long *>(offsets);
-    const int2 *eid = h->sl_eid.as<int2>() + SL_WALK;
-    if (fx.lanes == 64)
-        BXMI_TRY(sl_launch_fill<64>(fx.L, fx.sgrid, st, loff, offs, eid, h->sl_hits.as<int32_t>()));
-    else
-        BXMI_TRY(sl_launch_fill<16>(fx.L, fx.sgrid, st, loff, offs, eid, h->sl_hits.as<int32_t>()));
-    if (fx.variant == 2)
-        BXMI_TRY((sl_launch_hits_unpermute<1024, 32>(fx.L, st, loff, offs, h->sl_hits.as<int32_t>(), hits)));
-    else
-        BXMI_TRY((sl_launch_hits_unpermute<1024, 16>(fx.L, st, loff, offs, h->sl_hits.as<int32_t>(), hits)));
     return BXMI_OK;
 }
 
@@ -4329,24 +3743,13 @@ extern "C" int bxmi_ivl_count_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_
     }
     if (partition) return ivl_count_partitioned(h, qs, qe, nq, counts, total_dev, st);
     TreeDev S = h->treeS.dev, E = h->treeE.dev;
-    Tree tS = Tree(), tE = Tree();
-    if (g_opt_lds_ints != LDS_TREE_INTS) {  // A/B knob: restage fewer levels
-        tS.dev = S, tE.dev = E;
-        tS.set_lds_budget(g_opt_lds_ints), tE.set_lds_budget(g_opt_lds_ints);
-        S = tS.dev, E = tE.dev;
-    }
     size_t lds_bytes = (size_t)(S.lds_ints + E.lds_ints) * 4 + (CNT_THREADS / 64) * sizeof(long long);
-    int grid = g_opt_count_grid > 0 ? (int)g_opt_count_grid : device_props().cus;
+    int grid = device_props().cus;
     int64_t need = div_up(nq, (int64_t)(CNT_THREADS / 8) * CNT_Q);
     if (need < grid) grid = (int)need;
     unsigned long long *tot = reinterpret_cast<unsigned long long *>(total_dev);
-    if (g_opt_group_sum == 0) {
-        BXMI_TRY(allow_big_lds(ivl_count_kernel<true>, lds_bytes));
-        hipLaunchKernelGGL(ivl_count_kernel<true>, dim3(grid), dim3(CNT_THREADS), lds_bytes, st, S, E, index_dev(h), qs, qe, nq, counts, tot);
-    } else {
-        BXMI_TRY(allow_big_lds(ivl_count_kernel<false>, lds_bytes));
-        hipLaunchKernelGGL(ivl_count_kernel<false>, dim3(grid), dim3(CNT_THREADS), lds_bytes, st, S, E, index_dev(h), qs, qe, nq, counts, tot);
-    }
+    BXMI_TRY(allow_big_lds(ivl_count_kernel<true>, lds_bytes));
+    hipLaunchKernelGGL(ivl_count_kernel<true>, dim3(grid), dim3(CNT_THREADS), lds_bytes, st, S, E, index_dev(h), qs, qe, nq, counts, tot);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -4471,11 +3874,10 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
         if (g_opt_find_sliced && g_opt_bitmap != 0 && g_opt_slice != 0 && h->n >= 4096 && nq >= g_opt_bitmap_min &&
             !((uintptr_t)offsets & 15)) {  // (fx_offsets / fx_hits_copy2 store the offsets 16 bytes at a time)
             if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
-            if (h->sl_state == 1 && g_opt_fx_fill) {
+            if (h->sl_state == 1) {
                 if (h->fx_state == 0) BXMI_TRY(fx_prepare_index(h, st));
                 if (h->fx_state == 1) return ivl_find_fx(h, qs, qe, nq, offsets, hits, cap, total_host, st);
             }
-            if (h->sl_state == 1) return ivl_find_sliced(h, qs, qe, nq, offsets, hits, cap, total_host, st);
         }
         return ivl_find_partitioned(h, qs, qe, nq, offsets, hits, cap, total_host, st);
     }
@@ -4488,15 +3890,9 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
     int grid = device_props().cus * 2;
     int64_t need = div_up(nq, (int64_t)(FIND_THREADS / 8) * FIND_Q);
     if (need < grid) grid = (int)need;
-    if (g_opt_group_sum == 0) {
-        BXMI_TRY(allow_big_lds(ivl_find_count_kernel<true>, lds_bytes));
-        hipLaunchKernelGGL(ivl_find_count_kernel<true>, dim3(grid), dim3(FIND_THREADS), lds_bytes, st, S, P, ix, qs, qe, nq,
-                           h->q_lo.as<int32_t>(), h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
-    } else {
-        BXMI_TRY(allow_big_lds(ivl_find_count_kernel<false>, lds_bytes));
-        hipLaunchKernelGGL(ivl_find_count_kernel<false>, dim3(grid), dim3(FIND_THREADS), lds_bytes, st, S, P, ix, qs, qe, nq,
-                           h->q_lo.as<int32_t>(), h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
-    }
+    BXMI_TRY(allow_big_lds(ivl_find_count_kernel<true>, lds_bytes));
+    hipLaunchKernelGGL(ivl_find_count_kernel<true>, dim3(grid), dim3(FIND_THREADS), lds_bytes, st, S, P, ix, qs, qe, nq,
+                       h->q_lo.as<int32_t>(), h->q_hi.as<int32_t>(), h->q_cnt.as<int32_t>());
     BXMI_LAUNCH_CHECK();
     // offsets[0..nq) = exclusive sum of counts, offsets[nq] = total
     BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,

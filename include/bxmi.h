@@ -80,21 +80,11 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *   ivl.bd_w8          8-bit counts between the search and the un-permute kernel (-1 auto from the density + feedback)
  *   ivl.order_skip     1 (default): the exact order check is dropped after two shuffled batches (a probe stands in)
  *   ivl.find_sliced    1 (default): find() on large unsorted batches goes through the exchange (count_slices.hpp)
- *   ivl.find_flat      1 (default): sorted find() stages the candidate window and the hit stretch of a wave in LDS
- *   ivl.find_fused     1: sorted find() counts, scans (decoupled look-back) and fills in ONE kernel; 0 (default): in stages
- *                      (the fused kernel measured slower: its registers leave half the workgroups per CU)
- *   ivl.fx_fill        1 (default): the exchange's fill half on LDS-staged (end, index) windows of sub-bucket pieces
- *   ivl.fx_direct      that fill writes straight into the CSR list (1) or into scratch, followed by a copy (0); -1 (default):
+ *   ivl.fx_direct      the exchange's fill writes straight into the CSR list (1) or into scratch, followed by a copy (0); -1 (default):
  *                      straight while the list the handle expects (hits per query of its previous batch) stays under 400 MB
- *   ivl.fx_copy2       queries per lane of that copy: 2 (default) / 4 / 0 = one (round 5's first version)
- *   ivl.fx_flat        1: find()'s count half through the exchange as the flat walk on key slices; 0 (default): lane groups per run
  *   ivl.sl_f, ivl.sl_lanes, ivl.sl_flat, ivl.sl_rbits, ivl.sl_run_cap   geometry of the slice stage (tests, A/B tools)
- *   ivl.group_sum      0 DPP (default) / 1 ds_bpermute shuffles in the 8-lane node search
- *   ivl.lds_ints, ivl.count_grid   staging budget / grid of the direct count kernel
- *   ivl.stage_sync     1: synchronise and report after every stage of the exchange (debugging)
  *   ivl.bd_table_from  dense images: duplicated coordinates from which a cell gets a rank table (0 = 2 where the LDS has the room, else 6)
- *   ivl.bm_hard_ppm, ivl.bd_unit_log2, ivl.bd_blocks, ivl.count_cells, ivl.find_fill, ivl.find_pairs, ivl.lc_loop,
- *   ivl.sl_hcopy, ivl.sl_hu_parts   shapes of older / alternative kernels the tests and A/B tools still select (see the table)
+ *   ivl.bm_hard_ppm, ivl.bd_unit_log2, ivl.bd_blocks   thresholds / shapes of the unit images (tests)
  *   bits.grid          grid of the per-bitset kernels
  *   core.poll          1 (default): the one-call paths (bxmi_ivl_find_one, short bxmi_bits_count_range) poll a completion
  *                      word their kernel writes to host memory; 0: they wait for the stream
@@ -180,8 +170,7 @@ int bxmi_ivl_order_state(const bxmi_ivl_t *h, int *skipping, int64_t *answers_se
 /* IntervalTree.find for a batch, as CSR: offsets[nq+1] (int64) and, for query
  * i, hits[offsets[i]..offsets[i+1]) = insertion indices in the reference's
  * result order.  If the hit list needs more than `cap` entries the call
- * returns BXMI_ERANGE with offsets and *total valid and hits untouched (bxmi_ivl_find_dev with ivl.find_fused = 1: the
- * part of the list that fits may already have been written to the device buffer). */
+ * returns BXMI_ERANGE with offsets and *total valid and hits untouched. */
 int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,
                   int32_t *hits, int64_t cap, int64_t *total);
 /* bxmi_ivl_find_dev: device pointers of any natural alignment (4 bytes for qs / qe / hits, 8 for offsets) are legal; the

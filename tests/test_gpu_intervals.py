@@ -81,10 +81,8 @@ def test_order_matches_reference_traverse(golden_trees, IntervalIndex):
         assert ix.order().tolist() == case["order"], (case["mode"], case["n"])
 
 
-@pytest.mark.parametrize("group_sum", [0, 1])
-def test_count_and_find_match_reference_vectors(golden_trees, IntervalIndex, group_sum):
-    set_opt("ivl.group_sum", group_sum)
-    try:
+def test_count_and_find_match_reference_vectors(golden_trees, IntervalIndex):
+    for _once in (0,):
         for case in golden_trees:
             ix = make_index(IntervalIndex, case["starts"], case["ends"])
             q = np.array(case["queries"], dtype=np.int32)
@@ -104,8 +102,6 @@ def test_count_and_find_match_reference_vectors(golden_trees, IntervalIndex, gro
             offs, hits = ix.find(q[:, 0], q[:, 1])
             assert offs.tolist() == np.concatenate([[0], np.cumsum(want)]).tolist()
             assert hits.tolist() == [x for h in case["hits"] for x in h], (case["mode"], case["n"])
-    finally:
-        set_opt("ivl.group_sum", 0)
 
 
 def test_neighbours_match_reference_vectors(golden_trees, IntervalIndex):
@@ -215,9 +211,6 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
         set_opt("ivl.bitmap", 0)       # the bucketed search pass
         got_c, got_t = ix.count(qs, qe)
         tot_only = ix.count(qs, qe, want_counts=False)[1]
-        set_opt("ivl.count_cells", 0)  # the LDS-search-tree variant of the bucket search
-        tree_c, tree_t = ix.count(qs, qe)
-        set_opt("ivl.count_cells", 1)
         if not ix.has_reversed:
             p_off, p_hits = ix.find(qs, qe)
     finally:
@@ -228,7 +221,6 @@ def test_random_differential(O, IntervalIndex, n, span, zero, rev, lmax):
     assert len(bad) == 0 and dn_t == want_t, ("dense pass", ix.dense_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], dn_c[bad[:5]], want_c[bad[:5]])
     bad = np.nonzero(bm_c != want_c)[0]
     assert len(bad) == 0 and bm_t == want_t, ("slices / first-generation pass", ix.slice_state(), bad[:5], qs[bad[:5]], qe[bad[:5]], bm_c[bad[:5]], want_c[bad[:5]])
-    assert np.array_equal(tree_c, want_c) and tree_t == want_t, "partitioned, tree variant"
     if not ix.has_reversed:
         w_off, w_hits = t.find_batch(qs, qe)
         assert np.array_equal(p_off, w_off) and np.array_equal(p_hits, w_hits), "partitioned find"
@@ -385,8 +377,6 @@ def test_partitioned_counts_beyond_16_bits(O, IntervalIndex):
         bm, bm_total = ix.count(qs, qe)  # neither kind of image: key slices, or the first-generation pass
         set_opt("ivl.bitmap", 0)
         got, got_total = ix.count(qs, qe)
-        set_opt("ivl.count_cells", 0)
-        tree, tree_total = ix.count(qs, qe)
     finally:
         reset_opts()
     assert int(want.max()) >= pile
@@ -400,7 +390,7 @@ def test_partitioned_counts_beyond_16_bits(O, IntervalIndex):
     assert len(bad) == 0 and bm_total == want_total, ("bitmap pass", bad[:5], qs[bad[:5]], qe[bad[:5]], bm[bad[:5]], want[bad[:5]])
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got[bad[:5]], want[bad[:5]])
-    assert got_total == want_total == tree_total and np.array_equal(tree, want)
+    assert got_total == want_total
 
 
 def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
@@ -428,16 +418,12 @@ def test_partitioned_path_dense_bucket_is_sampled(O, IntervalIndex):
         set_opt("ivl.flat", 0)
         set_opt("ivl.bitmap", 0)
         got, got_total = ix.count(qs, qe)
-        set_opt("ivl.count_cells", 0)
-        tree, tree_total = ix.count(qs, qe)
-        set_opt("ivl.count_cells", 1)
         p_off, p_hits = ix.find(qs[:20000], qe[:20000])
     finally:
         reset_opts()
     assert state[0] == 1 and state[1] > 100, state
     bad = np.nonzero(bm != want)[0]
     assert len(bad) == 0 and bm_total == want_total, ("cell images, hard cells", bad[:5], qs[bad[:5]], qe[bad[:5]], bm[bad[:5]], want[bad[:5]])
-    assert np.array_equal(tree, want) and tree_total == want_total, "tree variant"
     bad = np.nonzero(got != want)[0]
     assert len(bad) == 0, (bad[:5], qs[bad[:5]], qe[bad[:5]], got[bad[:5]], want[bad[:5]])
     assert got_total == want_total
@@ -606,12 +592,12 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
 
 @pytest.mark.parametrize("shape", ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target", "pile"])
 def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
-    """find() on large unsorted batches (count_slices.hpp: count half, CSR offsets, fill half, hits back to query order;
-    find_exchange.hpp: the fill on LDS windows of half-bucket pieces, ivl.fx_fill) against the oracle treap's find: same
+    """find() on large unsorted batches (count_slices.hpp: count half; find_exchange.hpp: CSR offsets, the fill on LDS windows of
+    half-bucket pieces, hits back to query order) against the oracle treap's find: same
     offsets, same hits in the same order.  Escapes (zero-length / reversed / off-grid / over-long queries), duplicated
     coordinates (queries with more hits than a wave's LDS image holds), a tile that is not full, one target spanning
     everything (walks that leave the staged window), a pile of targets larger than a piece's window, all tile shapes, unit
-    sizes and run widths, both generations of the fill half; and the bucketed find of the first generation on the same input."""
+    sizes and run widths, with and without the copy; and the bucketed find of the first generation on the same input."""
     shapes = ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target", "pile"]
     rng = np.random.default_rng(70 + shapes.index(shape))
     n, span = 100_000, 30_000_000
@@ -654,13 +640,9 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
     set_opt("ivl.bitmap_min", 1)
     try:
         for k, (variant, f, lanes, sorted_path) in enumerate(((0, -1, 0, 0), (1, 0, 16, 0), (2, 2, 64, 0), (0, 6, 16, 0), (2, 6, 64, 0), (-1, -1, 0, 1))):
-            # 1: the fill on LDS windows straight into the CSR list; 2: behind the flat count half (ivl.fx_flat); 3 / 4 / 5: into scratch,
-            # then the copy with two / one / four queries per lane (ivl.fx_direct = 0, ivl.fx_copy2); 0: round 2's fill and copy
-            for fx_fill in (1, 2, 3, 4, 5, 0):
-                set_opt("ivl.fx_fill", 1 if fx_fill else 0)
-                set_opt("ivl.fx_flat", 1 if fx_fill == 2 else 0)
-                set_opt("ivl.fx_direct", 0 if fx_fill in (3, 4, 5) else 1)
-                set_opt("ivl.fx_copy2", {4: 0, 5: 4}.get(fx_fill, 2))
+            # the fill on LDS windows straight into the CSR list (1), or into scratch and then the copy (0)
+            for fx_fill in (1, 0):
+                set_opt("ivl.fx_direct", fx_fill)
                 set_opt("ivl.sorted_path", sorted_path)
                 set_opt("ivl.bm_variant", variant)
                 set_opt("ivl.sl_f", f)
@@ -670,8 +652,6 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
                 assert np.array_equal(off, want_off), (shape, variant, f, lanes, fx_fill, np.nonzero(np.diff(off) != np.diff(want_off))[0][:8])
                 bad = np.nonzero(hits != want_hits)[0]
                 assert len(bad) == 0, (shape, variant, f, lanes, fx_fill, bad[:8], hits[bad[:8]], want_hits[bad[:8]])
-        set_opt("ivl.fx_fill", 1)
-        set_opt("ivl.fx_flat", 0)
         set_opt("ivl.fx_direct", 1)
         set_opt("ivl.find_sliced", 0)
         off, hits = ix.find(qs, qe)
@@ -681,11 +661,9 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
         off, hits = ix.find(qs, qe, cap_hint=max(1, int(want_off[-1]) // 2 - 1))
         assert np.array_equal(off, want_off) and np.array_equal(hits, want_hits), "after BXMI_ERANGE"
         # ... and BXMI_ERANGE itself comes with the offsets and the total valid and the hit buffer untouched (include/bxmi.h)
-        for fx_fill, direct in ((1, 1), (1, 0), (0, 0)):
-            set_opt("ivl.fx_fill", fx_fill)
+        for direct in (1, 0):
             set_opt("ivl.fx_direct", direct)
             _erange_contract(ix, qs, qe, want_off)
-        set_opt("ivl.fx_fill", 1)
         set_opt("ivl.fx_direct", 1)
     finally:
         reset_opts()
@@ -802,12 +780,9 @@ def test_scale_1M_hash(golden_scale, IntervalIndex):
     qs, qe = synth.uniform_intervals(pt["n_queries_total"], 202)
     qs, qe = qs[:: pt["stride"]].copy(), qe[:: pt["stride"]].copy()
     ix = make_index(IntervalIndex, ts, te)
-    for lds_ints in (18688, 1024, 0):  # 3 / 2 / 0 LDS-resident levels must agree
-        set_opt("ivl.lds_ints", lds_ints)
-        counts, total = ix.count(qs, qe)
-        assert total == pt["total"]
-        assert hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"], lds_ints
-    set_opt("ivl.lds_ints", 18688)
+    counts, total = ix.count(qs, qe)
+    assert total == pt["total"]
+    assert hashlib.sha256(counts.tobytes()).hexdigest() == pt["counts_sha256"]
     set_opt("ivl.partition", 1)
     try:
         set_opt("ivl.flat", 1)  # the flat walk on cell images although the index is sparse
@@ -922,10 +897,9 @@ def test_padded_runs_on_many_full_tiles(O, IntervalIndex, stage):
         reset_opts()
 
 
-def test_sorted_kernel_shape_follows_the_order_checks(O, IntervalIndex):
-    """The kernel for sorted batches is launched in one of two shapes, by what the order checks of the handle's earlier
-    passes found (mirrored to host memory): after shuffled batches the four-chunks-per-workgroup shape is the one that
-    meets the first sorted batch, after that the chunk-per-workgroup shape again.  Same counts every time."""
+def test_sorted_batches_after_shuffled_ones_with_the_order_check_kept(O, IntervalIndex):
+    """With the exact order check on every pass (ivl.order_skip = 0) shuffled batches stand the sorted-batch kernel down and a
+    sorted batch right after them is answered by it: same counts every time."""
     rng = np.random.default_rng(93)
     n, span, nq = 200_000, 50_000_000, 4096 * 4200 + 77
     s = rng.integers(1000, span, size=n)
@@ -938,7 +912,6 @@ def test_sorted_kernel_shape_follows_the_order_checks(O, IntervalIndex):
     t.insert_many_arrays(s, e)
     pick = rng.integers(0, nq, size=300_000)
     want, _ = t.count_batch(qs[pick], qe[pick])
-    set_opt("ivl.lc_loop", -1)  # (opt-in: see bm_count_segments)
     set_opt("ivl.order_skip", 0)  # (or the check itself would be dropped after the shuffled batches)
     first, first_total = ix.count(qs, qe)
     assert np.array_equal(first[pick], want)
@@ -946,7 +919,7 @@ def test_sorted_kernel_shape_follows_the_order_checks(O, IntervalIndex):
         got, got_total = ix.count(qs, qe)
         assert np.array_equal(got, first) and got_total == first_total
     o = np.argsort(qs, kind="stable")
-    for _ in range(3):  # the first of these meets the looping shape, the others the plain one
+    for _ in range(3):
         got, got_total = ix.count(qs[o], qe[o])
         assert np.array_equal(got, first[o]) and got_total == first_total
     got, got_total = ix.count(qs, qe)
@@ -1428,7 +1401,7 @@ def test_genome_two_ranks_real_engine(tmp_path):
 
 def test_find_on_sorted_batches_flat_fill(O, IntervalIndex):
     """find() on a batch sorted by start: the fill that stages a wave's window of pairs and its stretch of the hit list in LDS
-    (part_fill_flat_kernel) against the oracle's hit lists and against the lane-per-query kernel it replaced (ivl.find_flat = 0) --
+    (part_fill_flat_kernel) against the oracle's hit lists --
     ordinary stretches, queries on a pile (a wave's stretch beyond the LDS image: direct stores), a few very long targets far
     below the queries' windows (lanes that leave the staged pairs, walks handed to the whole wave), queries without hits."""
     rng = np.random.default_rng(4242)
@@ -1449,25 +1422,15 @@ def test_find_on_sorted_batches_flat_fill(O, IntervalIndex):
     ix = make_index(IntervalIndex, s, e)
     set_opt("ivl.partition", 1)
     try:
-        # fused: count, offsets (decoupled look-back over 74 chunks) and fill in ONE kernel (ivl_local_find_kernel); then round 4's
-        # three stages with the flat fill, then with the lane-per-query fill
-        for fused, flat in ((1, 1), (0, 1), (0, 0)):
-            set_opt("ivl.find_fused", fused)
-            set_opt("ivl.find_flat", flat)
-            got = ix.find(qs, qe)
-            assert np.array_equal(got[0], w_off), ("offsets", fused, flat, np.nonzero(got[0] != w_off)[0][:8])
-            bad = np.nonzero(got[1] != w_hits)[0]
-            assert len(bad) == 0, ("hits", fused, flat, bad[:8], got[1][bad[:8]], w_hits[bad[:8]])
+        got = ix.find(qs, qe)
+        assert np.array_equal(got[0], w_off), ("offsets", np.nonzero(got[0] != w_off)[0][:8])
+        bad = np.nonzero(got[1] != w_hits)[0]
+        assert len(bad) == 0, ("hits", bad[:8], got[1][bad[:8]], w_hits[bad[:8]])
         assert int(np.diff(w_off).max()) > 3000 and len(w_hits) > 5 * nq  # the pile and the long targets are really in play
-        # a buffer that is too small: the fused kernel writes no hit past it, the total comes back, the wrapper retries
-        set_opt("ivl.find_fused", 1)
-        set_opt("ivl.find_flat", 1)
+        # a buffer that is too small: the total comes back, the wrapper retries
         got = ix.find(qs, qe, cap_hint=len(w_hits) // 3)
         assert np.array_equal(got[0], w_off) and np.array_equal(got[1], w_hits), "after BXMI_ERANGE"
-        for fused in (1, 0):
-            set_opt("ivl.find_fused", fused)
-            _erange_contract(ix, qs, qe, w_off)
-        set_opt("ivl.find_fused", 1)
+        _erange_contract(ix, qs, qe, w_off)
         got = ix.find(qs, qe, cap_hint=len(w_hits))  # exactly enough
         assert np.array_equal(got[0], w_off) and np.array_equal(got[1], w_hits)
     finally:
@@ -1486,8 +1449,11 @@ def test_find_join_scale_properties(IntervalIndex):
         set_opt("ivl.partition", 1)
     try:
         offs, hits = ix.find(qs, qe, cap_hint=8 * len(qs))      # through the exchange, the fill on LDS windows (244 tiles, several tile chunks per piece)
-        set_opt("ivl.fx_fill", 0)
-        o_offs, o_hits = ix.find(qs, qe, cap_hint=8 * len(qs))  # round 2's fill and copy
+        set_opt("ivl.fx_direct", 0)
+        o_offs, o_hits = ix.find(qs, qe, cap_hint=8 * len(qs))  # the fill into scratch, then the copy
+        assert np.array_equal(o_offs, offs) and np.array_equal(o_hits, hits)
+        set_opt("ivl.find_sliced", 0)
+        o_offs, o_hits = ix.find(qs, qe, cap_hint=8 * len(qs))  # the bucketed find of the first generation
         assert np.array_equal(o_offs, offs) and np.array_equal(o_hits, hits)
         del o_offs, o_hits
     finally:

@@ -59,7 +59,7 @@ for r in range(rounds):
     ix = IntervalIndex()
     ix.append(s, e)
     opt("ivl.bitmap_min", 1)
-    # (partition, count_cells, bitmap, slice): direct kernel, round 1's pass in both search variants, the large-batch pass
+    # (partition, -, bitmap, slice): direct kernel, round 1's pass, the large-batch pass
     # on images first / slices first / slices only, each with random tile shapes, unit sizes and run widths
     # sparse = 1: offset-cell images whatever the density (with ivl.bm_hard_ppm opened up: cells with more than five keys, their
     # lists and the searches behind them are then the rule, not the exception)
@@ -74,7 +74,6 @@ for r in range(rounds):
         if sparse == 1:
             ix.seal()  # (the images are built once per sealed index: another width needs them again)
         opt("ivl.partition", part)
-        opt("ivl.count_cells", cells)
         opt("ivl.bitmap", bitmap)
         opt("ivl.slice", slices)
         opt("ivl.flat", flat)    # 1: cell images of units wherever the index qualifies (the persistent walk)
@@ -92,25 +91,20 @@ for r in range(rounds):
                                             sparse=sparse, **knobs),
                   ix.flat_state(), ix.dense_state(), ix.slice_state(), ix.sparse_state(), bad, qs[bad], qe[bad], got_c[bad], want_c[bad])
             sys.exit(1)
-    opt("ivl.count_cells", 1)
     opt("ivl.bitmap", -1)
     opt("ivl.flat", -1), opt("ivl.dense", -1), opt("ivl.bd_w8", -1), opt("ivl.bd_chunk", 0)
     opt("ivl.sparse", -1), opt("ivl.bo_cell_log2", 0), opt("ivl.bm_hard_ppm", 2000)
     sparse_served += ix.sparse_state()[0] == 1
     m = min(nq, 20000)
     w_off, w_hits = t.find_batch(qs[:m], qe[:m])
-    # direct kernels, the bucketed find, find through the exchange (round 2's fill, then twice the fill on LDS windows, other knobs);
-    # sorted batches take the staged kernels or the fused one
-    for part, sliced, fx in ((0, 0, 1), (1, 0, 1), (1, 1, 0), (1, 1, 1), (1, 1, 1)):
+    # direct kernels, the bucketed find, find through the exchange (the fill straight into the list or through scratch and the copy,
+    # other tile shapes and unit sizes); sorted batches take the staged kernels
+    for part, sliced in ((0, 0), (1, 0), (1, 1), (1, 1), (1, 1)):
         knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64])), sorted_path=int(rng.integers(0, 2)),
-                     fused=int(rng.integers(0, 2)), fx=fx, flat=int(rng.integers(0, 2)), direct=int(rng.integers(0, 2)), copy2=int(rng.choice([0, 2, 4])))
+                     direct=int(rng.integers(0, 2)))
         opt("ivl.partition", part)
         opt("ivl.find_sliced", sliced)
-        opt("ivl.fx_fill", fx)
-        opt("ivl.fx_flat", knobs["flat"])
         opt("ivl.fx_direct", knobs["direct"])
-        opt("ivl.fx_copy2", knobs["copy2"])
-        opt("ivl.find_fused", knobs["fused"])
         opt("ivl.slice", -1)
         opt("ivl.bm_variant", knobs["variant"])
         opt("ivl.sl_f", knobs["f"])
@@ -121,7 +115,7 @@ for r in range(rounds):
             print("FIND MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, sliced=sliced, **knobs), ix.slice_state())
             sys.exit(1)
     for k, v in (("ivl.partition", -1), ("ivl.find_sliced", 1), ("ivl.bm_variant", -1), ("ivl.sl_f", -1), ("ivl.sl_lanes", 0),
-                 ("ivl.sorted_path", 1), ("ivl.fx_fill", 1), ("ivl.fx_flat", 0), ("ivl.fx_direct", -1), ("ivl.fx_copy2", 2), ("ivl.find_fused", 0)):
+                 ("ivl.sorted_path", 1), ("ivl.fx_direct", -1)):
         opt(k, v)
     checked += 1
     ix.close()
