@@ -1777,8 +1777,7 @@ __device__ __forceinline__ void bd_unpermute_tile(const unsigned short *__restri
                                                   unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS], may be NULL */,
                                                   const unsigned *__restrict__ gate, const unsigned *__restrict__ tend,
                                                   unsigned long long *__restrict__ fb_dev /* W8: counts that did not fit, ever */,
-                                                  unsigned long long *__restrict__ fb_host /* its copy in host memory */,
-                                                  unsigned long long *const *__restrict__ direct)
+                                                  unsigned long long *__restrict__ fb_host /* its copy in host memory */)
 {
     constexpr int TILE = THREADS * ITEMS;
     constexpr int STRIDE = PAD ? TILE + BM_PAD_ROOM : TILE;  // slots between two tiles of the count array (PAD: gaps between the units)
@@ -1792,8 +1791,10 @@ __device__ __forceinline__ void bd_unpermute_tile(const unsigned short *__restri
     const BmSeg &sg = segs[seg_id];
     const int64_t ltile = tile - sg.tile0;
     if (ltile >= sg.ntiles) return;  // padding up to the next plan group
-    // where this tile's sum goes: the caller's word of its segment, or one of the segment's partial totals (folded later)
-    unsigned long long *const acc_to = direct ? direct[seg_id] : (total_slots ? total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)) : nullptr);
+    // (one of the segment's 64 partial totals; bm_fold_totals_kernel adds them up.  Straight to the caller's word instead -- no fold
+    // launch -- was tried in round 6: 3052 atomics on ONE address per pass stretch this kernel from 124 to 136 us, the fold costs 4.5;
+    // folding by the workgroup that draws the last ticket: 147 us, every workgroup waits for a returning atomic while it holds half a CU.)
+    unsigned long long *const acc_to = total_slots ? total_slots + (int64_t)seg_id * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)) : nullptr;
     const IndexDev ix = sg.ix;
     const BmGeom g = sg.g;
     const int32_t *__restrict__ e_sorted = sg.e_sorted;
@@ -1920,20 +1921,14 @@ __device__ __forceinline__ void bd_unpermute_tile(const unsigned short *__restri
     }
 }
 
-// The kernel: a workgroup per tile.  `direct` set: a workgroup adds its tile's sum straight to the caller's int64 of the tile's
-// segment (one fire-and-forget atomic per workgroup) instead of to one of the segment's 64 partial totals -- no fold behind the
-// kernel (bm_fold_totals_kernel: 4.5 us of launch) and nothing for a workgroup to wait for.  (Tried first: the partial totals kept,
-// folded by the workgroup that draws the last ticket -- every workgroup then waits for its stores and a returning atomic while it
-// holds half a CU: 123 -> 147 us.)
 template <int THREADS, int ITEMS, bool PAD = false, bool W8 = false>
 __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned short *__restrict__ cnt, const unsigned short *__restrict__ slots,
                                                                const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
                                                                unsigned long long *__restrict__ total_slots, const unsigned *__restrict__ gate,
-                                                               const unsigned *__restrict__ tend, unsigned long long *__restrict__ fb_dev,
-                                                               unsigned long long *__restrict__ fb_host,
-                                                               unsigned long long *const *__restrict__ direct /* [segments], or NULL */)
+                                                               const unsigned *__restrict__ tend = nullptr, unsigned long long *__restrict__ fb_dev = nullptr,
+                                                               unsigned long long *__restrict__ fb_host = nullptr)
 {
-    bd_unpermute_tile<THREADS, ITEMS, PAD, W8>(cnt, slots, segs, tile_seg, total_slots, gate, tend, fb_dev, fb_host, direct);
+    bd_unpermute_tile<THREADS, ITEMS, PAD, W8>(cnt, slots, segs, tile_seg, total_slots, gate, tend, fb_dev, fb_host);
 }
 
 }  // namespace bxmi

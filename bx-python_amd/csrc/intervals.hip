@@ -2697,7 +2697,6 @@ struct BmLaunch {
     BmSegChunk par;
     int npar = 0;
     BmParOut par_out;
-    unsigned long long *const *totals = nullptr;  // device: the callers' int64 words, one per segment, when the un-permute kernel adds to them itself
     int n_segs = 1;
 };
 
@@ -2762,9 +2761,9 @@ static int bm_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hip
 }
 
 // The bitmap-cell pass over a batch of n segments (n sealed, qualifying indexes with their queries): [order check ->]
-// tile sort (with the batch's parameter block) -> run table -> plan -> search -> un-permute (the tiles' sums straight to the callers'
-// totals), all on `st`, five launches for up to 16 segments; with the order check in front or more segments the parameter kernel
-// and the fold of the partial totals are launches of their own.
+// tile sort (with the batch's parameter block) -> run table -> plan -> search -> un-permute -> totals, all on `st`, six launches
+// for up to 16 segments (five when nobody asks for totals); with the order check in front or more segments the parameter kernel
+// is a launch of its own.
 // counts[i] may be NULL (total only: nothing is stored per query); totals_dev[i] may be.  The scratch of hs[0] serves the whole batch.
 #ifndef SL_FIND_U
 #define SL_FIND_U 2  // runs per lane group and round of find()'s count half
@@ -2856,25 +2855,22 @@ template <int THREADS, int ITEMS>
 static int bd_launch_unpermute(const BmLaunch &L, unsigned long long *slots, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
-    unsigned long long *const *fold = L.totals;  // set: the tiles' sums go straight to the callers' totals (slots unused)
     if (L.pad && L.w8) {
         const size_t lds = (size_t)(THREADS * ITEMS + BM_PAD_ROOM);
         BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, true, true>), lds));
         hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, true, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
                            h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, h->bd_tend.as<unsigned>(),
-                           h->bd_fb.as<unsigned long long>(), h->bd_fb_host, fold);
+                           h->bd_fb.as<unsigned long long>(), h->bd_fb_host);
     } else if (L.pad) {
         const size_t lds = (size_t)(THREADS * ITEMS + BM_PAD_ROOM) * sizeof(unsigned short);
         BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, true>), lds));
         hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
-                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, h->bd_tend.as<unsigned>(),
-                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, fold);
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, h->bd_tend.as<unsigned>());
     } else {
         const size_t lds = (size_t)THREADS * ITEMS * sizeof(unsigned short);
         BXMI_TRY(allow_big_lds((bd_unpermute_kernel<THREADS, ITEMS, false>), lds));
         hipLaunchKernelGGL((bd_unpermute_kernel<THREADS, ITEMS, false>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, h->bd_cnt16.as<unsigned short>(),
-                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, (const unsigned *)nullptr,
-                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, fold);
+                           h->bm_slots.as<unsigned short>(), L.segs, L.tile_seg, slots, L.gate, (const unsigned *)nullptr);
     }
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
@@ -3211,8 +3207,12 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
                        tile_log2, h->bm_runT.as<unsigned>(), ntp, h->bm_grpcnt.as<unsigned>(), unsorted);
     hipLaunchKernelGGL(sl_unit_sums_kernel, dim3((unsigned)ngroups), dim3(1024), 0, st, h->bm_grpcnt.as<unsigned>(), L.segs, L.tile_seg,
                        h->sl_unitcnt.as<unsigned>(), unsorted);
-    hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg, chunk,
-                       h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
+    if (n <= BD_PLAN_SEGS)  // (the one-workgroup plan: 11 us where bm_plan_kernel<2> takes 37 on configs[4]'s 1526 tiles)
+        hipLaunchKernelGGL(bd_plan_kernel, dim3(1), dim3(1024), 0, st, h->sl_unitcnt.as<unsigned>(), n, L.segs, chunk, h->bm_items.as<int4>() + 1,
+                           h->bm_items.as<int>(), unsorted);
+    else
+        hipLaunchKernelGGL(bm_plan_kernel<2>, dim3(BM_PLAN_BLOCKS), dim3(BM_PLAN_THREADS), 0, st, h->sl_unitcnt.as<unsigned>(), ngroups, L.segs, L.tile_seg,
+                           chunk, h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     }
     BXMI_LAUNCH_CHECK();
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
@@ -3232,20 +3232,16 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     } else
         BXMI_TRY(bd_launch_search(L, sgrid, cells ? 1 : 0, any_blocks, st));
     unsigned *loff = fx ? h->sl_loff.as<unsigned>() : nullptr;
-    // No sorted-batch kernels in front (they leave partial totals of their own): the un-permute kernel adds every tile's sum straight
-    // to the caller's total of its segment and the probe has reported to the host itself -- nothing is left to fold.
-    const bool direct_totals = dense && !fxsub && !unsorted;
-    L.totals = direct_totals && any_total ? reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes) : nullptr;
     if (dense && !fxsub) {
         if (variant == 2)
-            BXMI_TRY((bd_launch_unpermute<1024, 32>(L, direct_totals ? nullptr : tslots, st)));
+            BXMI_TRY((bd_launch_unpermute<1024, 32>(L, tslots, st)));
         else
-            BXMI_TRY((bd_launch_unpermute<1024, 16>(L, direct_totals ? nullptr : tslots, st)));
+            BXMI_TRY((bd_launch_unpermute<1024, 16>(L, tslots, st)));
     } else if (variant == 2)
         BXMI_TRY((bm_launch_unpermute<1024, 32>(L, tslots, st, search_out, loff, fxsub ? (fx->direct ? 3 : 2) : 0)));
     else
         BXMI_TRY((bm_launch_unpermute<1024, 16>(L, tslots, st, search_out, loff, fxsub ? (fx->direct ? 3 : 2) : 0)));
-    if (any_total && !direct_totals) {
+    if (any_total) {
         hipLaunchKernelGGL(bm_fold_totals_kernel, dim3((unsigned)n), dim3(64), 0, st, slots,
                            reinterpret_cast<unsigned long long *const *>(h->bm_params.as<unsigned char>() + seg_bytes));
         BXMI_LAUNCH_CHECK();
