@@ -31,6 +31,11 @@
 // extern "C" entry points (bxmi_ivl_*), DESIGN.md 3 has the measurements.
 #include <climits>
 #include <vector>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "primitives.hpp"
 
@@ -2137,6 +2142,8 @@ static int64_t g_opt_bd_table_from = 0;  // dense images: overflow entries from 
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
 static int64_t g_opt_bd_w8 = -1;      // 8-bit counts out of place: -1 = by index and feedback, 0 = never, 1 = whenever the layout allows
 static int64_t g_opt_order_skip = -1;  // -1 = stop launching the order check after two batches in a row were not sorted (a probe of 8192 starts rides on the parameter kernel then), 0 = always check
+static int64_t g_opt_host_chunk = 8 << 20;  // queries per chunk of the host-pointer count (upload of chunk k+1 / pass on k / download of k-1 at once); 0 = one piece
+static int64_t g_opt_host_touchers = 2;  // host threads that touch the output array's pages ahead of the downloads (0 = the download faults them in)
 static int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
 
 // The option table: every knob of the interval path, its variable and how a value is normalised.  bxmi_set_option writes through
@@ -2175,6 +2182,8 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.bd_table_from", &g_opt_bd_table_from, [](int64_t value) -> int64_t { return value < 1 || value > 64 ? 0 : value; }},
     {"ivl.bd_w8", &g_opt_bd_w8, nullptr},
     {"ivl.order_skip", &g_opt_order_skip, nullptr},
+    {"ivl.host_chunk", &g_opt_host_chunk, [](int64_t value) -> int64_t { return value <= 0 ? 0 : ((value + 4095) & ~(int64_t)4095); }},
+    {"ivl.host_touchers", &g_opt_host_touchers, [](int64_t value) -> int64_t { return value < 0 ? 0 : (value > 16 ? 16 : value); }},
     {"ivl.bd_unit_log2", &g_opt_bd_unit_log2, [](int64_t value) -> int64_t { return value < 12 || value > BD_UNIT_LOG2 ? 0 : value; }},
 };
 constexpr int IVL_NOPTS = (int)(sizeof(IVL_OPTS) / sizeof(IVL_OPTS[0]));
@@ -2268,6 +2277,7 @@ struct bxmi_ivl {
     int32_t *one_buf = nullptr;  // host-visible result of bxmi_ivl_find_one: [n:int64][ONE_CAP hits][completion word:int64]
     unsigned long long one_seq = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_up = nullptr, stream_down = nullptr;  // the host-pointer entry points' copies either side of the pass (ivl_count_host_chunks)
     int device = 0;
 };
 
@@ -3459,6 +3469,8 @@ extern "C" int bxmi_ivl_destroy(bxmi_ivl_t *h)
 {
     if (!h) return BXMI_OK;
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream_up) (void)hipStreamDestroy(h->stream_up);
+    if (h->stream_down) (void)hipStreamDestroy(h->stream_down);
     if (h->one_buf) (void)hipHostFree(h->one_buf);
     if (h->bd_fb_host) (void)hipHostFree(h->bd_fb_host);
     delete h;
@@ -3807,6 +3819,140 @@ static int upload_queries(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     return BXMI_OK;
 }
 
+// The host-pointer count in chunks: while the pass runs on chunk k (the handle's stream), chunk k+1 is on its way up (stream_up,
+// this thread) and the counts of chunk k-1 on their way down (stream_down, a second host thread: a copy from or to pageable
+// memory holds its caller until the runtime has staged it, and PCIe carries both directions at once only if two threads ask).
+// tools/micro/pcie_probe.hip on the round's box: 56 GB/s either way alone, 47 + 47 GB/s together -- a 100 M batch is bounded by its
+// 0.8 GB upload (~17 ms); one piece after the other (upload, pass, download) took 42-74 ms.
+struct HostChunks {
+    bxmi_ivl *h;
+    int32_t *counts;
+    int64_t nq, chunk;
+    int nchunks;
+    std::vector<hipEvent_t> done;  // chunk k's pass has finished (recorded on the handle's stream)
+    std::mutex mu;
+    std::condition_variable cv;
+    int launched = 0;   // chunks whose pass has been launched and whose event is recorded
+    std::atomic<bool> stop{false};  // the launching thread failed: nothing more will come
+    int rc = BXMI_OK;
+    std::string err;
+    // the output array's pages, touched chunk by chunk ahead of the downloads (a fresh 400 MB array costs the download 10-16 ms
+    // of page faults otherwise: 32 ms per 100 M against 16 into touched memory)
+    int touchers = 0;
+    std::vector<std::atomic<int>> touched;  // [chunk]: touchers done with it
+};
+
+// Thread j of c->touchers: its share of every chunk's pages, in chunk order.  A page is read and written back (the array is the
+// call's output: nobody else holds it, and chunk k's download waits until its touchers are done).
+static void host_chunks_touch(HostChunks *c, int j)
+{
+    for (int k = 0; k < c->nchunks; k++) {
+        const int64_t o = (int64_t)k * c->chunk, m = std::min(c->chunk, c->nq - o);
+        volatile char *b = reinterpret_cast<volatile char *>(c->counts + o);
+        const int64_t bytes = m * 4, lo = bytes * j / c->touchers, hi = bytes * (j + 1) / c->touchers;
+        if (c->stop.load()) return;
+        for (int64_t x = lo; x < hi; x += 4096) b[x] = b[x];
+        if (hi > lo) b[hi - 1] = b[hi - 1];
+        c->touched[k].fetch_add(1, std::memory_order_release);
+    }
+}
+
+static int host_chunks_download_one(HostChunks *c, int k)
+{
+    bxmi_ivl *h = c->h;
+    const int64_t o = (int64_t)k * c->chunk, m = std::min(c->chunk, c->nq - o);
+    while (c->touched[k].load(std::memory_order_acquire) < c->touchers && !c->stop.load()) std::this_thread::yield();
+    BXMI_HIP(hipStreamWaitEvent(h->stream_down, c->done[k], 0));
+    BXMI_HIP(hipMemcpyAsync(c->counts + o, h->q_cnt.as<int32_t>() + o, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream_down));
+    return BXMI_OK;
+}
+
+static void host_chunks_download(HostChunks *c)
+{
+    if (hipSetDevice(c->h->device) != hipSuccess) {
+        c->rc = BXMI_EHIP, c->err = "hipSetDevice in the download thread failed";
+        return;
+    }
+    for (int k = 0; k < c->nchunks; k++) {
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv.wait(lk, [&] { return c->launched > k || c->stop; });
+            if (c->launched <= k) return;
+        }
+        const int rc = host_chunks_download_one(c, k);
+        if (rc != BXMI_OK) {
+            c->rc = rc, c->err = last_error();  // (last_error() is per thread: carried over to the caller's)
+            return;
+        }
+    }
+    if (hipStreamSynchronize(c->h->stream_down) != hipSuccess) c->rc = BXMI_EHIP, c->err = "hipStreamSynchronize(stream_down) failed";
+}
+
+static int ivl_count_host_chunks(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total)
+{
+    if (!h->stream_up) BXMI_HIP(hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking));
+    if (!h->stream_down) BXMI_HIP(hipStreamCreateWithFlags(&h->stream_down, hipStreamNonBlocking));
+    HostChunks c;
+    c.h = h, c.counts = counts, c.nq = nq, c.chunk = g_opt_host_chunk, c.nchunks = (int)div_up(nq, g_opt_host_chunk);
+    BXMI_TRY(h->q_s.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->q_e.reserve((size_t)(nq + 4) * 4));
+    if (counts) BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
+    BXMI_TRY(h->q_total.reserve(64));
+    BXMI_HIP(hipMemsetAsync(h->q_total.p, 0, 8, h->stream));
+    c.done.assign((size_t)c.nchunks, nullptr);
+    std::vector<hipEvent_t> up((size_t)c.nchunks, nullptr);
+    auto drop_events = [&] {
+        for (hipEvent_t e : c.done) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
+    };
+    for (int k = 0; k < c.nchunks; k++)
+        if (hipEventCreateWithFlags(&c.done[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&up[k], hipEventDisableTiming) != hipSuccess) {
+            drop_events();
+            return fail(BXMI_EHIP, "bxmi_ivl_count: hipEventCreate failed");
+        }
+    std::thread down;
+    std::vector<std::thread> touch;
+    if (counts) {
+        c.touchers = (int)g_opt_host_touchers;
+        c.touched = std::vector<std::atomic<int>>((size_t)c.nchunks);
+        for (auto &t : c.touched) t.store(0);
+        for (int j = 0; j < c.touchers; j++) touch.emplace_back(host_chunks_touch, &c, j);
+        down = std::thread(host_chunks_download, &c);
+    }
+    auto one = [&](int k) -> int {
+        const int64_t o = (int64_t)k * c.chunk, m = std::min(c.chunk, nq - o);
+        BXMI_HIP(hipMemcpyAsync(h->q_s.as<int32_t>() + o, qs + o, (size_t)m * 4, hipMemcpyHostToDevice, h->stream_up));
+        BXMI_HIP(hipMemcpyAsync(h->q_e.as<int32_t>() + o, qe + o, (size_t)m * 4, hipMemcpyHostToDevice, h->stream_up));
+        BXMI_HIP(hipEventRecord(up[k], h->stream_up));
+        BXMI_HIP(hipStreamWaitEvent(h->stream, up[k], 0));
+        BXMI_TRY(bxmi_ivl_count_dev(h, h->q_s.as<int32_t>() + o, h->q_e.as<int32_t>() + o, m, counts ? h->q_cnt.as<int32_t>() + o : nullptr,
+                                    h->q_total.as<int64_t>(), h->stream));  // (the chunks' totals add up in the one word)
+        BXMI_HIP(hipEventRecord(c.done[k], h->stream));
+        return BXMI_OK;
+    };
+    int rc = BXMI_OK;
+    for (int k = 0; k < c.nchunks && rc == BXMI_OK; k++) {
+        rc = one(k);
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (rc == BXMI_OK) c.launched = k + 1;
+        else c.stop = true;
+        c.cv.notify_one();
+    }
+    int64_t t = 0;
+    if (rc == BXMI_OK) {
+        hipError_t e = hipMemcpyAsync(&t, h->q_total.p, 8, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(BXMI_EHIP, "bxmi_ivl_count: reading the total: %s", hipGetErrorString(e));
+    } else
+        (void)hipStreamSynchronize(h->stream);  // nothing of this call stays in flight behind its return
+    if (down.joinable()) down.join();
+    for (auto &t : touch) t.join();
+    drop_events();
+    if (rc == BXMI_OK && c.rc != BXMI_OK) rc = fail(c.rc, "%s", c.err.c_str());
+    if (rc == BXMI_OK && total) *total = t;
+    return rc;
+}
+
 extern "C" int bxmi_ivl_count(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total)
 {
     BXMI_TRY(need_sealed(h, "bxmi_ivl_count"));
@@ -3815,6 +3961,7 @@ extern "C" int bxmi_ivl_count(bxmi_ivl_t *h, const int32_t *qs, const int32_t *q
     if (nq == 0) return BXMI_OK;
     BXMI_TRY(ivl_stream(h));
     hipStream_t st = h->stream;
+    if (g_opt_host_chunk > 0 && nq >= 2 * g_opt_host_chunk) return ivl_count_host_chunks(h, qs, qe, nq, counts, total);
     BXMI_TRY(upload_queries(h, qs, qe, nq, st));
     BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->q_total.reserve(64));

@@ -11,7 +11,7 @@ Only inputs + expected outputs are written (data, never reference source).
 
 --scale additionally runs the 10M-target / 1M-query-subsample point of cfg 2
 through the reference treap (about 5 minutes, ~2 GB) and records its hash.
---only genome | join | calibration | bitsets_genome add, to tests/golden/scale.json, the per-chromosome
+--only genome | join | calibration | bitsets_genome | bitsets_genome_default add, to tests/golden/scale.json, the per-chromosome
 hashes of configs[3] (synth.cfg4), the hit-list hash of configs[4] at 50M targets
 (~10 GB, ~30 min), the reference-vs-port timing BASELINE.md 4 asks for, and the per-chromosome popcounts /
 run-list hashes of configs[2] (two hg19-sized dicts of BinnedBitSets) from the real bx.bitset.
@@ -488,6 +488,53 @@ def bitsets_genome_point():
                 source="bx.bitset.BinnedBitSet (reference 0.14.0): set_range, ior, iand, count_range, next_set / next_clear", chroms=out)
 
 
+def bitsets_genome_default_point():
+    """BASELINE configs[2] with the size the reference's own builders give every chromosome when no `lens` is passed
+    (lib/bx/bitset_builders.py:31-45 -> BinnedBitSet() = MAX = 512 Mi bits, bitset.pyx:196-203): a different bin_size
+    (float32, binBits.c:36) and so different ALL_ONE arithmetic after invert().  Per chromosome through the real bx.bitset:
+    bin_size, popcounts of A, B, A & B, A | B over the whole set, the number of runs of A & B with the sha256 of its run list,
+    and -- on the INVERTED A & B -- count_range over the whole set, over [0, chromosome length) and over eight windows that
+    start and end inside bins (the first-bin / last-bin arithmetic of binBits.c:140-170)."""
+    ra, rb_ = synth.genome_ranges(1_500_000, 301), synth.genome_ranges(1_500_000, 302)
+    out = {}
+    MAX = rb.MAX
+    for chrom, size in synth.HG19_SIZES.items():
+        sets = []
+        for r in (ra, rb_, ra):
+            bs = rb.BinnedBitSet()
+            sr = bs.set_range
+            for s, n in zip(r[chrom][0].tolist(), r[chrom][1].tolist()):
+                sr(s, n)
+            sets.append(bs)
+        a, b, a2 = sets
+        assert a.size == MAX
+        ca, cb = a.count_range(0, MAX), b.count_range(0, MAX)
+        a2.ior(b)
+        c_or = a2.count_range(0, MAX)
+        a.iand(b)
+        c_and = a.count_range(0, MAX)
+        starts, ends = [], []
+        end = 0
+        while True:
+            start = a.next_set(end)
+            if start == MAX:
+                break
+            end = a.next_clear(start)
+            starts.append(start), ends.append(end)
+        runs = np.concatenate([np.array(starts, dtype=np.int64), np.array(ends, dtype=np.int64)])
+        a.invert()
+        rngw = np.random.default_rng(size)
+        ws = rngw.integers(0, MAX - 1, size=8)
+        wn = np.minimum(rngw.integers(1, 50_000_000, size=8), MAX - ws)
+        windows = [[int(s), int(n), int(a.count_range(int(s), int(n)))] for s, n in zip(ws, wn)]
+        out[chrom] = dict(size=MAX, chrom_len=size, bin_size=int(a.bin_size), pop_a=ca, pop_b=cb, pop_and=c_and, pop_or=c_or, n_runs=len(starts),
+                          runs_sha256=sha(runs), inverted_and_count_all=int(a.count_range(0, MAX)),
+                          inverted_and_count_chrom=int(a.count_range(0, size)), inverted_and_windows=windows)
+        print(chrom, out[chrom], flush=True)
+    return dict(workload="synth.genome_ranges(1_500_000, 301) / (.., 302): one BinnedBitSet() (MAX = 512 Mi bits) per hg19 chromosome and set",
+                source="bx.bitset.BinnedBitSet (reference 0.14.0): set_range, ior, iand, invert, count_range, next_set / next_clear", chroms=out)
+
+
 def gen_extra(which):
     path = os.path.join(GOLD, "scale.json")
     doc = json.load(open(path))
@@ -499,10 +546,13 @@ def gen_extra(which):
         doc["calibration"] = calibration_point()
     elif which == "bitsets_genome":
         doc["cfg3_bitsets"] = bitsets_genome_point()
+    elif which == "bitsets_genome_default":
+        doc["cfg3_bitsets_default_max"] = bitsets_genome_default_point()
     # another generator may have rewritten the file meanwhile: merge on the freshest copy
     fresh = json.load(open(path))
-    for k in ("cfg4_genome", "cfg5_join", "calibration", "cfg3_bitsets"):
-        if k in doc and (k == {"genome": "cfg4_genome", "join": "cfg5_join", "calibration": "calibration", "bitsets_genome": "cfg3_bitsets"}[which]):
+    for k in ("cfg4_genome", "cfg5_join", "calibration", "cfg3_bitsets", "cfg3_bitsets_default_max"):
+        if k in doc and (k == {"genome": "cfg4_genome", "join": "cfg5_join", "calibration": "calibration", "bitsets_genome": "cfg3_bitsets",
+                               "bitsets_genome_default": "cfg3_bitsets_default_max"}[which]):
             fresh[k] = doc[k]
     dump("scale.json", fresh)
 
@@ -540,6 +590,6 @@ if __name__ == "__main__":
         gen_cli_crlf()
     if "scale" in todo:
         gen_scale(a.scale)
-    for which in ("genome", "join", "calibration", "bitsets_genome"):  # --only genome | join | calibration | bitsets_genome: long-running extras of scale.json
+    for which in ("genome", "join", "calibration", "bitsets_genome", "bitsets_genome_default"):  # --only genome | join | calibration | bitsets_genome: long-running extras of scale.json
         if which in todo and a.only:
             gen_extra(which)

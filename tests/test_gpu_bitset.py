@@ -398,6 +398,73 @@ def _runs_sha(rs, re):
     return hashlib.sha256(np.concatenate([np.asarray(rs, dtype=np.int64), np.asarray(re, dtype=np.int64)]).tobytes()).hexdigest()
 
 
+def test_cfg3_genome_default_max_sizes(golden_scale_doc):
+    """BASELINE configs[2] the way the reference's builders size it when no `lens` is given (lib/bx/bitset_builders.py:31-45:
+    BinnedBitSet() = MAX = 512 Mi bits per chromosome, bitset.pyx:196-203; the variant bench.py quotes as
+    bitset.default_MAX_sizes).  EVERY chromosome against the real bx.bitset (tests/golden/scale.json
+    "cfg3_bitsets_default_max", oracle/gen_golden.py --only bitsets_genome_default): bin_size, popcounts of A, B, A & B, A | B,
+    the run list of A & B, and count_range on the INVERTED intersection (whole set, the chromosome's length, eight windows that
+    start and end inside bins) -- through the per-set calls, then popcounts / iand / ior through BitSetGroup."""
+    from bxmi.bitset import MAX, BitSetGroup, DeviceBitSet
+
+    g = golden_scale_doc.get("cfg3_bitsets_default_max")
+    assert g, "tests/golden/scale.json has no cfg3_bitsets_default_max point: the reference check must not vanish silently"
+    gold = g["chroms"]
+    assert list(gold) == list(synth.HG19_SIZES)
+    ra = synth.genome_ranges(1_500_000, 301)
+    rb = synth.genome_ranges(1_500_000, 302)
+    chroms = list(synth.HG19_SIZES)
+    A, B, A2 = [], [], []
+    for chrom in chroms:
+        want = gold[chrom]
+        assert want["size"] == MAX
+        a, b, a2 = DeviceBitSet(), DeviceBitSet(), DeviceBitSet()
+        assert (a.size, a.bin_size) == (MAX, want["bin_size"])
+        a.set_ranges(*ra[chrom]), b.set_ranges(*rb[chrom]), a2.set_ranges(*ra[chrom])
+        A.append(a), B.append(b), A2.append(a2)
+    # one launch per genome first (the sets are still the plain A and B)
+    gA, gB, gA2 = BitSetGroup(A), BitSetGroup(B), BitSetGroup(A2)
+    assert gA.popcounts().tolist() == [gold[c]["pop_a"] for c in chroms]
+    assert gB.popcounts().tolist() == [gold[c]["pop_b"] for c in chroms]
+    gA2.ior(gB)
+    assert gA2.popcounts().tolist() == [gold[c]["pop_or"] for c in chroms]
+    for a2 in A2:  # back to A for the per-set pass below
+        a2.close()
+    # per-set calls of the drop-in classes
+    for chrom, a, b in zip(chroms, A, B):
+        want = gold[chrom]
+        assert (a.count_range(0, MAX), b.count_range(0, MAX)) == (want["pop_a"], want["pop_b"]), chrom
+        a2 = DeviceBitSet()
+        a2.set_ranges(*ra[chrom])
+        a2.ior(b)
+        assert a2.count_range(0, MAX) == want["pop_or"], chrom
+        a2.iand(a)  # (A | B) & A == A
+        assert a2.count_range(0, MAX) == want["pop_a"], chrom
+        a2.iand(b)  # ... & B == A & B, through the per-set iand
+        assert a2.count_range(0, MAX) == want["pop_and"], chrom
+        rs, re = a2.runs()
+        assert len(rs) == want["n_runs"] and _runs_sha(rs, re) == want["runs_sha256"], chrom
+        a2.invert()
+        assert a2.count_range(0, MAX) == want["inverted_and_count_all"], chrom
+        assert a2.count_range(0, want["chrom_len"]) == want["inverted_and_count_chrom"], chrom
+        w = np.array(want["inverted_and_windows"], dtype=np.int64)
+        assert a2.count_ranges(w[:, 0], w[:, 1]).tolist() == w[:, 2].tolist(), chrom
+        for s, n, c in want["inverted_and_windows"][:2]:
+            assert a2.count_range(s, n) == c, (chrom, s, n)
+        a2.close()
+    # the group iand with counts, then the run lists and the inverted counts of what it left
+    assert gA.iand(gB, want_counts=True).tolist() == [gold[c]["pop_and"] for c in chroms]
+    assert gB.popcounts().tolist() == [gold[c]["pop_b"] for c in chroms]
+    for chrom, a in zip(chroms, A):
+        want = gold[chrom]
+        rs, re = a.runs()
+        assert len(rs) == want["n_runs"] and _runs_sha(rs, re) == want["runs_sha256"], chrom
+        a.invert()
+        assert a.count_range(0, want["chrom_len"]) == want["inverted_and_count_chrom"], chrom
+    for d in A + B:
+        d.close()
+
+
 def test_cfg3_genome_scale_properties(O, golden_scale_doc):
     """BASELINE configs[2]: two hg19-sized (3.1 Gbp, 24 chromosomes) bitsets, iand + count_range.
     EVERY chromosome against the real bx.bitset.BinnedBitSet (tests/golden/scale.json "cfg3_bitsets", made by

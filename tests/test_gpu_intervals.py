@@ -1041,6 +1041,49 @@ def test_total_only_batches(O, IntervalIndex):
         reset_opts()
 
 
+def test_host_count_in_chunks(O, IntervalIndex):
+    """bxmi_ivl_count on host arrays, the chunked pipeline (upload of chunk k+1 / pass on k / download of k-1 at once,
+    ivl_count_host_chunks): the same counts and total as the oracle whatever the chunk size and however many threads touch
+    the output's pages -- ragged last chunk, chunks below and above the batch-pass threshold, shuffled and sorted, counts
+    wanted or the total only, into a fresh and into a written output array (the touchers must leave neither zeros nor stale
+    values behind).  intersection.pyx:400-406 per query."""
+    import ctypes as C
+
+    from bxmi import _ffi
+
+    rng = np.random.default_rng(4242)
+    span = 40_000_000
+    s = rng.integers(0, span, size=300_000).astype(np.int32)
+    e = (s + rng.integers(1, 2000, size=len(s))).astype(np.int32)
+    ix = make_index(IntervalIndex, s, e)
+    t = O.OracleIntervalTree()
+    t.insert_many_arrays(s, e)
+    nq = 5 * 1_000_000 + 12_345
+    qs = rng.integers(-1000, span + 1000, size=nq).astype(np.int32)
+    qe = (qs + rng.integers(0, 3000, size=nq)).astype(np.int32)
+    try:
+        for order in ("shuffled", "sorted"):
+            if order == "sorted":
+                o = np.argsort(qs, kind="stable")
+                qs, qe = np.ascontiguousarray(qs[o]), np.ascontiguousarray(qe[o])
+            want_counts, want_total = t.count_batch(qs, qe)
+            for chunk, touchers in ((4096, 2), (1 << 20, 0), (1 << 20, 3), (2_500_000, 1), (0, 2)):
+                reset_opts()
+                set_opt("ivl.host_chunk", chunk)
+                set_opt("ivl.host_touchers", touchers)
+                for fresh in (True, False):
+                    counts = np.empty(nq, dtype=np.int32) if fresh else np.full(nq, -3, dtype=np.int32)
+                    total = C.c_int64(-1)
+                    _ffi.call("bxmi_ivl_count", ix._h, _ffi.ptr(qs), _ffi.ptr(qe), nq, _ffi.ptr(counts), C.byref(total))
+                    assert total.value == want_total, (order, chunk, touchers, fresh)
+                    assert np.array_equal(counts, want_counts), (order, chunk, touchers, fresh, np.nonzero(counts != want_counts)[0][:8])
+                total = C.c_int64(-1)
+                _ffi.call("bxmi_ivl_count", ix._h, _ffi.ptr(qs), _ffi.ptr(qe), nq, None, C.byref(total))
+                assert total.value == want_total, (order, chunk, touchers, "total only")
+    finally:
+        reset_opts()
+
+
 def test_count_width_feedback(O, IntervalIndex):
     """8-bit counts between the search and the un-permute kernel of the flat walk.  The index is sparse as a whole (the host
     starts with 8 bits) but 150 000 of its targets crowd into 400 000 coordinates; queries elsewhere have small counts,
@@ -1357,6 +1400,13 @@ scale = int(sys.argv[2])
 g = json.load(open(os.path.join(sys.argv[1], "tests", "golden", "scale.json")))["cfg4_genome"]
 chroms = list(synth.HG19_SIZES)
 weights = {c: synth.cfg4_sizes(10_000_000 // scale)[c] + synth.cfg4_sizes(100_000_000 // scale)[c] for c in chroms}
+if len(sys.argv) > 3 and sys.argv[3] == "heaviest-of-8":
+    # only the chromosomes the 8-rank deal hands its heaviest rank, dealt again to the two ranks of this test
+    deal8 = shard.lpt_assign(weights, 8)
+    heavy = max(deal8, key=lambda cs: sum(weights[c] for c in cs))
+    chroms = [c for c in chroms if c in heavy]
+    weights = {c: weights[c] for c in chroms}
+    assert len(chroms) >= 2, chroms
 mine = shard.lpt_assign(weights, world)[rank]
 tg = {c: synth.cfg4_chrom(c, 10_000_000 // scale, 100_000_000 // scale)[0] for c in mine}
 qr = {c: synth.cfg4_chrom(c, 10_000_000 // scale, 100_000_000 // scale)[1] for c in mine}
@@ -1379,7 +1429,7 @@ full = {}
 for d in obj: full.update(d)
 assert totals == {c: full[c] for c in chroms}, (rank, totals, full)
 dist.barrier(); dist.destroy_process_group()
-sys.stdout.write("rank%d-ok %d chromosomes %d overlaps\n" % (rank, len(mine), sum(totals.values())))
+sys.stdout.write("rank%d-ok %d chromosomes %d overlaps hashes-checked=%d\n" % (rank, len(mine), sum(totals.values()), len(mine) if scale == 1 else 0))
 """
 
 
@@ -1397,6 +1447,26 @@ def test_genome_two_ranks_real_engine(tmp_path):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     assert "rank0-ok" in p.stdout and "rank1-ok" in p.stdout, p.stdout[-2000:]
+
+
+def test_genome_two_ranks_full_size_heaviest_share(tmp_path):
+    """The same two-rank run at FULL size (scale 1) on the chromosomes the 8-rank LPT deal hands its heaviest rank
+    (bxmi/shard.py; scripts/interval_join.py:21-28 is the dict of per-chromosome trees being dealt): every 100th count of each
+    chromosome against the reference treap's hash (tests/golden/scale.json "cfg4_genome") on the count_genome path, totals
+    all-reduced across the two ranks."""
+    import re
+    import subprocess
+    import sys as _sys
+
+    script = tmp_path / "genome_worker.py"
+    script.write_text(GENOME_WORKER)
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29543",
+           str(script), root, "1", "heaviest-of-8"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    checked = [int(x) for x in re.findall(r"rank\d-ok \d+ chromosomes \d+ overlaps hashes-checked=(\d+)", p.stdout)]
+    assert len(checked) == 2 and min(checked) >= 1 and sum(checked) >= 2, p.stdout[-2000:]
 
 
 def test_find_on_sorted_batches_flat_fill(O, IntervalIndex):

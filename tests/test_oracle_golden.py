@@ -191,6 +191,37 @@ def test_binnedbitset_genome_scale_vectors(golden_scale_doc):
         assert hashlib.sha256(runs.tobytes()).hexdigest() == want["runs_sha256"]
 
 
+def test_binnedbitset_genome_default_max_vectors(golden_scale_doc):
+    """The same genome with every chromosome a BinnedBitSet() of the default MAX = 512 Mi bits (what
+    lib/bx/bitset_builders.py:31-45 builds when no `lens` is given; a different float32 bin_size, binBits.c:36): the
+    restatement against the real bx.bitset on chr21 and chrY (tests/golden/scale.json "cfg3_bitsets_default_max", made by
+    oracle/gen_golden.py --only bitsets_genome_default), including count_range on the INVERTED intersection."""
+    g = golden_scale_doc.get("cfg3_bitsets_default_max")
+    assert g, "tests/golden/scale.json has no cfg3_bitsets_default_max point"
+    ra, rb = synth.genome_ranges(1_500_000, 301), synth.genome_ranges(1_500_000, 302)
+    for chrom in ("chr21", "chrY"):
+        want = g["chroms"][chrom]
+        size = want["size"]
+        assert size == 512 * 1024 * 1024 and want["chrom_len"] == synth.HG19_SIZES[chrom]
+        a, b, a2 = O.OracleBinnedBitSet(size), O.OracleBinnedBitSet(size), O.OracleBinnedBitSet(size)
+        assert a.bin_size == want["bin_size"]
+        a.set_ranges(*ra[chrom]), b.set_ranges(*rb[chrom]), a2.set_ranges(*ra[chrom])
+        assert (a.count_range(0, size), b.count_range(0, size)) == (want["pop_a"], want["pop_b"])
+        a2.ior(b)
+        assert a2.count_range(0, size) == want["pop_or"]
+        a.iand(b)
+        assert a.count_range(0, size) == want["pop_and"]
+        rs, re = a.runs()
+        assert len(rs) == want["n_runs"]
+        runs = np.concatenate([np.asarray(rs, dtype=np.int64), np.asarray(re, dtype=np.int64)])
+        assert hashlib.sha256(runs.tobytes()).hexdigest() == want["runs_sha256"]
+        a.invert()
+        assert a.count_range(0, size) == want["inverted_and_count_all"]
+        assert a.count_range(0, want["chrom_len"]) == want["inverted_and_count_chrom"]
+        for s, n, c in want["inverted_and_windows"]:
+            assert a.count_range(s, n) == c, (chrom, s, n)
+
+
 def test_binnedbitset_big_sizes(golden_bitsets):
     for case in golden_bitsets["big"]:
         replay(case, O.OracleBinnedBitSet, check_final=False)
