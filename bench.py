@@ -237,6 +237,7 @@ def bench_find(torch, reps=3):
     out = {"workload": "configs[4]: %d x %d join, G=2e9, len U[1,200], CSR (int64 offsets, int32 hits) in HBM" % (nq, nt)}
     d_ts, d_te = torch.from_numpy(ts).cuda(), torch.from_numpy(te).cuda()
     qs, qe = torch.from_numpy(qs_h).cuda(), torch.from_numpy(qe_h).cuda()
+    host = None
     for label in ("generated_order", "sorted_by_start"):
         if label == "sorted_by_start":
             o = torch.argsort(qs, stable=True)
@@ -266,6 +267,20 @@ def bench_find(torch, reps=3):
                           frac_of_hbm_peak=round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), every_hit_overlaps=every_hit_overlaps,
                           counts_match_count_path=counts_match)
         del h, rep, counts
+        if label == "generated_order":
+            # the same join through the HOST-pointer entry point (bxmi_ivl_find on numpy arrays: what the Cython binding of
+            # INTEGRATION.md 1b and the CLI counterparts call): 0.4 GB up, 0.4 GB of offsets + 1 GB of hits down into fresh arrays
+            ix.find(qs_h[:1 << 20], qe_h[:1 << 20])
+            ho, hh = ix.find(qs_h, qe_h, cap_hint=6 * nq)  # (sizes the handle's staging)
+            del ho, hh
+            t0 = time.perf_counter()
+            ho, hh = ix.find(qs_h, qe_h, cap_hint=6 * nq)
+            dt = time.perf_counter() - t0
+            host = dict(ms=round(dt * 1e3, 2), m_queries_per_s=round(nq / dt / 1e6, 1),
+                        same_csr=bool(np.array_equal(ho, offs.cpu().numpy()) and np.array_equal(hh, hits[:total].cpu().numpy())),
+                        note="bxmi_ivl_find on pageable numpy arrays, fresh output arrays; host threads touch the outputs' pages ahead of the copies")
+            del ho, hh
+    out["host_pointers_generated_order"] = host
     return out
 
 

@@ -3819,6 +3819,76 @@ static int upload_queries(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     return BXMI_OK;
 }
 
+// Host threads that touch the pages of an OUTPUT array chunk by chunk, ahead of the downloads into it.  A copy into fresh pageable
+// memory (numpy.empty) pays for its page faults on the copying thread: 400 MB cost the download 10-16 ms, 32 ms per 100 M
+// counts against 16 into touched memory.  A page is read and written back; the array is the call's output -- nobody else holds
+// it -- and chunk k's download waits (wait_chunk) until its touchers are done with it, so a touch never lands on copied data.
+struct PageToucher {
+    char *base = nullptr;
+    size_t bytes = 0, chunk = 0;
+    int nchunks = 0, nthreads = 0;
+    std::vector<std::atomic<int>> done;  // [chunk]: threads done with it
+    std::atomic<bool> stop{false};
+    std::vector<std::thread> threads;
+    void start(void *p, size_t n, size_t chunk_bytes, int nthr)
+    {
+        base = static_cast<char *>(p), bytes = n, chunk = chunk_bytes, nthreads = nthr;
+        nchunks = (int)((n + chunk_bytes - 1) / chunk_bytes);
+        done = std::vector<std::atomic<int>>((size_t)nchunks);
+        for (auto &d : done) d.store(0);
+        for (int j = 0; j < nthreads; j++) threads.emplace_back([this, j] { run(j); });
+    }
+    void run(int j)
+    {
+        for (int k = 0; k < nchunks && !stop.load(); k++) {
+            const size_t o = (size_t)k * chunk, m = std::min(chunk, bytes - o);
+            volatile char *b = base + o;
+            const size_t lo = m * (size_t)j / (size_t)nthreads, hi = m * (size_t)(j + 1) / (size_t)nthreads;
+            for (size_t x = lo; x < hi; x += 4096) b[x] = b[x];
+            if (hi > lo) b[hi - 1] = b[hi - 1];
+            done[(size_t)k].fetch_add(1, std::memory_order_release);
+        }
+    }
+    void wait_chunk(int k)
+    {
+        while (nthreads && done[(size_t)k].load(std::memory_order_acquire) < nthreads && !stop.load()) std::this_thread::yield();
+    }
+    void join()
+    {
+        for (auto &t : threads) t.join();
+        threads.clear();
+    }
+    ~PageToucher()
+    {
+        stop.store(true);
+        join();
+    }
+};
+
+// Device memory -> a pageable host array the caller has not touched yet, at the link's rate: chunks of 32 MB, the touchers one
+// or more chunks ahead of the copies.  `t` may be running already (started while the device was still computing); NULL = start here.
+static int download_touched(void *dst, const void *src_dev, size_t bytes, hipStream_t st, PageToucher *t = nullptr)
+{
+    constexpr size_t CH = (size_t)32 << 20;
+    if (bytes == 0) return BXMI_OK;
+    PageToucher own;
+    if (!t && bytes >= 2 * CH && g_opt_host_touchers > 0) own.start(dst, bytes, CH, (int)g_opt_host_touchers), t = &own;
+    if (!t) {
+        BXMI_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        return BXMI_OK;
+    }
+    for (int k = 0; k < t->nchunks; k++) {
+        const size_t o = (size_t)k * t->chunk, m = std::min(t->chunk, bytes - o);
+        t->wait_chunk(k);
+        const hipError_t e = hipMemcpyAsync(static_cast<char *>(dst) + o, static_cast<const char *>(src_dev) + o, m, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) {
+            t->stop.store(true);
+            return fail(BXMI_EHIP, "download: %s", hipGetErrorString(e));
+        }
+    }
+    return BXMI_OK;
+}
+
 // The host-pointer count in chunks: while the pass runs on chunk k (the handle's stream), chunk k+1 is on its way up (stream_up,
 // this thread) and the counts of chunk k-1 on their way down (stream_down, a second host thread: a copy from or to pageable
 // memory holds its caller until the runtime has staged it, and PCIe carries both directions at once only if two threads ask).
@@ -3836,32 +3906,14 @@ struct HostChunks {
     std::atomic<bool> stop{false};  // the launching thread failed: nothing more will come
     int rc = BXMI_OK;
     std::string err;
-    // the output array's pages, touched chunk by chunk ahead of the downloads (a fresh 400 MB array costs the download 10-16 ms
-    // of page faults otherwise: 32 ms per 100 M against 16 into touched memory)
-    int touchers = 0;
-    std::vector<std::atomic<int>> touched;  // [chunk]: touchers done with it
+    PageToucher touch;  // the output array's pages, chunk by chunk ahead of the downloads
 };
-
-// Thread j of c->touchers: its share of every chunk's pages, in chunk order.  A page is read and written back (the array is the
-// call's output: nobody else holds it, and chunk k's download waits until its touchers are done).
-static void host_chunks_touch(HostChunks *c, int j)
-{
-    for (int k = 0; k < c->nchunks; k++) {
-        const int64_t o = (int64_t)k * c->chunk, m = std::min(c->chunk, c->nq - o);
-        volatile char *b = reinterpret_cast<volatile char *>(c->counts + o);
-        const int64_t bytes = m * 4, lo = bytes * j / c->touchers, hi = bytes * (j + 1) / c->touchers;
-        if (c->stop.load()) return;
-        for (int64_t x = lo; x < hi; x += 4096) b[x] = b[x];
-        if (hi > lo) b[hi - 1] = b[hi - 1];
-        c->touched[k].fetch_add(1, std::memory_order_release);
-    }
-}
 
 static int host_chunks_download_one(HostChunks *c, int k)
 {
     bxmi_ivl *h = c->h;
     const int64_t o = (int64_t)k * c->chunk, m = std::min(c->chunk, c->nq - o);
-    while (c->touched[k].load(std::memory_order_acquire) < c->touchers && !c->stop.load()) std::this_thread::yield();
+    c->touch.wait_chunk(k);
     BXMI_HIP(hipStreamWaitEvent(h->stream_down, c->done[k], 0));
     BXMI_HIP(hipMemcpyAsync(c->counts + o, h->q_cnt.as<int32_t>() + o, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream_down));
     return BXMI_OK;
@@ -3911,12 +3963,8 @@ static int ivl_count_host_chunks(bxmi_ivl *h, const int32_t *qs, const int32_t *
             return fail(BXMI_EHIP, "bxmi_ivl_count: hipEventCreate failed");
         }
     std::thread down;
-    std::vector<std::thread> touch;
     if (counts) {
-        c.touchers = (int)g_opt_host_touchers;
-        c.touched = std::vector<std::atomic<int>>((size_t)c.nchunks);
-        for (auto &t : c.touched) t.store(0);
-        for (int j = 0; j < c.touchers; j++) touch.emplace_back(host_chunks_touch, &c, j);
+        if (g_opt_host_touchers > 0) c.touch.start(counts, (size_t)nq * 4, (size_t)c.chunk * 4, (int)g_opt_host_touchers);
         down = std::thread(host_chunks_download, &c);
     }
     auto one = [&](int k) -> int {
@@ -3935,7 +3983,7 @@ static int ivl_count_host_chunks(bxmi_ivl *h, const int32_t *qs, const int32_t *
         rc = one(k);
         std::lock_guard<std::mutex> lk(c.mu);
         if (rc == BXMI_OK) c.launched = k + 1;
-        else c.stop = true;
+        else c.stop = true, c.touch.stop.store(true);
         c.cv.notify_one();
     }
     int64_t t = 0;
@@ -3946,7 +3994,7 @@ static int ivl_count_host_chunks(bxmi_ivl *h, const int32_t *qs, const int32_t *
     } else
         (void)hipStreamSynchronize(h->stream);  // nothing of this call stays in flight behind its return
     if (down.joinable()) down.join();
-    for (auto &t : touch) t.join();
+    c.touch.join();
     drop_events();
     if (rc == BXMI_OK && c.rc != BXMI_OK) rc = fail(c.rc, "%s", c.err.c_str());
     if (rc == BXMI_OK && total) *total = t;
@@ -4094,6 +4142,13 @@ extern "C" int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe
         if (total) *total = 0;
         return BXMI_OK;
     }
+    // BLOCKS until offsets / hits are written.  Large batches: host threads touch the pages of `offsets` while the queries go up and
+    // the device works, those of `hits` (the part the total says will be written) while the offsets come down (PageToucher).
+    constexpr size_t TOUCH_CHUNK = (size_t)32 << 20;
+    const size_t off_bytes = (size_t)(nq + 1) * 8;
+    PageToucher t_off, t_hits;
+    const bool touch = g_opt_host_touchers > 0 && off_bytes >= 2 * TOUCH_CHUNK;
+    if (touch) t_off.start(offsets, off_bytes, TOUCH_CHUNK, (int)g_opt_host_touchers);
     BXMI_TRY(upload_queries(h, qs, qe, nq, st));
     BXMI_TRY(h->q_off.reserve((size_t)(nq + 2) * 8));
     BXMI_TRY(h->q_hits.reserve((size_t)(cap + 4) * 4));
@@ -4102,8 +4157,11 @@ extern "C" int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe
                                &tot, st);
     if (total) *total = tot;
     if (rc != BXMI_OK && rc != BXMI_ERANGE) return rc;
-    BXMI_HIP(hipMemcpyAsync(offsets, h->q_off.p, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost, st));
-    if (rc == BXMI_OK && tot > 0) BXMI_HIP(hipMemcpyAsync(hits, h->q_hits.p, (size_t)tot * 4, hipMemcpyDeviceToHost, st));
+    const bool want_hits = rc == BXMI_OK && tot > 0;
+    const bool touch_hits = want_hits && g_opt_host_touchers > 0 && (size_t)tot * 4 >= 2 * TOUCH_CHUNK;
+    if (touch_hits) t_hits.start(hits, (size_t)tot * 4, TOUCH_CHUNK, (int)g_opt_host_touchers);
+    BXMI_TRY(download_touched(offsets, h->q_off.p, off_bytes, st, touch ? &t_off : nullptr));
+    if (want_hits) BXMI_TRY(download_touched(hits, h->q_hits.p, (size_t)tot * 4, st, touch_hits ? &t_hits : nullptr));
     BXMI_HIP(hipStreamSynchronize(st));
     return rc;
 }

@@ -175,7 +175,11 @@ int bxmi_ivl_order_state(const bxmi_ivl_t *h, int *skipping, int64_t *answers_se
 /* IntervalTree.find for a batch, as CSR: offsets[nq+1] (int64) and, for query
  * i, hits[offsets[i]..offsets[i+1]) = insertion indices in the reference's
  * result order.  If the hit list needs more than `cap` entries the call
- * returns BXMI_ERANGE with offsets and *total valid and hits untouched. */
+ * returns BXMI_ERANGE with offsets and *total valid and hits untouched.
+ * Host arrays; BLOCKS until offsets / hits are written.  From 8 Mi queries (or 16 Mi hits) on, ivl.host_touchers (default 2)
+ * host threads touch the pages of `offsets` while the queries go up and the device works, those of `hits` while the
+ * offsets come down; they are joined before the call returns.  configs[4] (50 M x 50 M, 250 M hits) into fresh numpy
+ * arrays: 39 ms against 67 without them (0.4 GB up + 1.4 GB down at 56 GB/s is 32). */
 int bxmi_ivl_find(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets,
                   int32_t *hits, int64_t cap, int64_t *total);
 /* bxmi_ivl_find_dev: device pointers of any natural alignment (4 bytes for qs / qe / hits, 8 for offsets) are legal; the

@@ -59,3 +59,28 @@ for cfg in os.environ.get("CHUNKS", "0 8:0 8:1 8:2 8:4 16:2 4:2").split():
     print("chunk %-5s: fresh %s  touched %s  total-only %s  ok=%s" % (cfg, out[cfg]["fresh_out_ms"], out[cfg]["touched_out_ms"],
                                                                       out[cfg]["total_only_ms"], ok), flush=True)
 print(json.dumps(out))
+
+# ---- find() on host arrays (configs[4]: 50 M x 50 M, ~250 M hits): upload, find, 0.4 GB of offsets + 1 GB of hits down
+if os.environ.get("FIND", "1") == "1":
+    del ix, ref_counts, qs, qe
+    from bxmi import synth
+
+    NF = int(os.environ.get("NF", 50_000_000))
+    (ts, te), (qs, qe) = synth.cfg5(NF, NF)
+    ix = IntervalIndex()
+    ix.append(ts, te)
+    ix.seal()
+    off0, hits0 = ix.find(qs, qe, cap_hint=6 * NF)
+    fout = {}
+    for touchers in (0, 2, 4):
+        call("bxmi_set_option", b"ivl.host_touchers", touchers)
+        ms = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            off, hits = ix.find(qs, qe, cap_hint=6 * NF)
+            ms.append(round((time.perf_counter() - t0) * 1e3, 2))
+            same = bool(np.array_equal(off, off0) and np.array_equal(hits, hits0))
+            del off, hits
+        fout["touchers_%d" % touchers] = dict(ms=ms, same=same)
+        print("find host, %d touchers: %s ms  same=%s  (%d hits)" % (touchers, ms, same, len(hits0)), flush=True)
+    print(json.dumps(dict(find_host=fout)))
