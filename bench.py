@@ -583,8 +583,8 @@ def source_stamps():
         return h.hexdigest()[:16]
 
     csrc = os.path.join(ROOT, "bx-python_amd", "csrc")
-    kernels = [os.path.join(csrc, f) for f in ("common.hpp", "primitives.hpp", "count_bitmap.hpp", "count_slices.hpp", "count_dense.hpp",
-                                               "offset_cells.hpp", "intervals.hip")]  # what the count pass is made of
+    kernels = [os.path.join(csrc, f) for f in ("common.hpp", "primitives.hpp", "count_direct.hpp", "count_bitmap.hpp", "count_slices.hpp",
+                                               "count_dense.hpp", "offset_cells.hpp", "intervals.hip")]  # what the count pass is made of
     return dict(bench_sha16=sha([os.path.join(ROOT, "bench.py")]), kernel_sha16=sha(kernels))
 
 
@@ -879,7 +879,7 @@ def main():
         same = bool(ht == local_total and np.array_equal(hc, counts.cpu().numpy()))
         pcie = dict(value=round(nq / dt / 1e6, 1), unit="M queries/s", seconds=round(dt, 4), first_call_seconds=round(dt_first, 4), same_counts=same,
                     note="bxmi_ivl_count on pageable numpy arrays, fresh output array: 0.8 GB H2D + 0.4 GB D2H in chunks of 8 Mi queries, "
-                         "upload of chunk k+1 / pass on k / download of k-1 at once (csrc/intervals.hip: ivl_count_host_chunks)")
+                         "upload of chunk k+1 / pass on k / download of k-1 at once (csrc/host_pipeline.hpp: ivl_count_host_chunks)")
         del hc
 
     # the same queries sorted by start (how BED files usually arrive): libbxmi notices on the device and answers in one

@@ -13,8 +13,10 @@ if [ "$(cat "$OBJ/.flags" 2>/dev/null)" != "$FLAGS" ]; then rm -f "$OBJ"/*.o; ec
 pids=()
 for f in core intervals bitset bedparse comm; do
   src="$HERE/$f.hip"; [ -f "$src" ] || src="$HERE/$f.cpp"
-  if [ ! -f "$OBJ/$f.o" ] || [ "$src" -nt "$OBJ/$f.o" ] || [ "$HERE/common.hpp" -nt "$OBJ/$f.o" ] \
-     || [ "$HERE/primitives.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_bitmap.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_slices.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/count_dense.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/find_exchange.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/offset_cells.hpp" -nt "$OBJ/$f.o" ] || [ "$HERE/../../include/bxmi.h" -nt "$OBJ/$f.o" ]; then
+  stale=0
+  [ -f "$OBJ/$f.o" ] || stale=1
+  for dep in "$src" "$HERE"/*.hpp "$HERE/../../include/bxmi.h"; do [ "$dep" -nt "$OBJ/$f.o" ] && stale=1; done
+  if [ $stale = 1 ]; then
     $HIPCC $FLAGS -c "$src" -o "$OBJ/$f.o" &
     pids+=($!)
   fi

@@ -1,0 +1,512 @@
+// find_sorted.hpp -- find() on bucketed and on sorted batches: window + count per query, offsets carried to bucket order, the fills (part_fill_kernel, part_fill_flat_kernel), slice bounds.  intersection.pyx:180-189 (hit order), :400-406.
+// Included by intervals.hip (one translation unit; the kernels share its constants and device helpers).
+#pragma once
+
+namespace bxmi {
+
+// ---- partitioned find: window + count per query in bucket order, offsets carried to bucket order ----
+// For every query of [q_begin, q_end): hi = #{start < qe}, lo = #{prefix-max <= qs} and the number of hits in the
+// window [lo, hi) of the tree-ordered arrays.  Ranks come from LDS trees one lane per query; the window is then
+// scanned by 8 lanes per query with 16-byte loads (a per-lane serial scan would issue 8 scattered requests per query).
+struct WindowSlices {
+    int sLo, nS, kS, strideS;  // staged slice of the starts (tree order)
+    int pLo, nP, kP, strideP;  // staged slice of the prefix-max array
+    int qeLo, qeHi;            // rank_lt(starts, qe) may use the slice iff qeLo <= qe <= qeHi
+};
+
+template <int THREADS>
+__device__ __forceinline__ void window_stage(const IndexDev &ix, const WindowSlices &w, int32_t *lds, int32_t *&treeP, int32_t *&treeS)
+{
+    treeP = lds, treeS = lds + (1 << w.kP);
+    const int total = (1 << w.kP) + (1 << w.kS);
+    for (int i = threadIdx.x; i < total; i += THREADS) lds[i] = INT_MAX;
+    __syncthreads();
+    part_stage_tree<THREADS>(treeP, w.kP, ix.pm + w.pLo, w.nP, w.strideP);
+    part_stage_tree<THREADS>(treeS, w.kS, ix.s_ord + w.sLo, w.nS, w.strideS);
+    __syncthreads();
+}
+
+template <int THREADS, bool PAIRS /* qs_arr is an array of (qs, qe) pairs, qe_arr unused */,
+          bool PER_LANE /* neighbouring queries have neighbouring windows (sorted batch): one lane scans one window */>
+__device__ __forceinline__ void window_queries(const IndexDev &ix, const WindowSlices &w, const int32_t *treeP, const int32_t *treeS,
+                                               int64_t q_begin, int64_t q_end, const int32_t *__restrict__ qs_arr,
+                                               const int32_t *__restrict__ qe_arr, int32_t *__restrict__ win_lo,
+                                               int32_t *__restrict__ win_hi, int32_t *__restrict__ counts)
+{
+    for (int64_t i0 = q_begin + threadIdx.x; i0 - threadIdx.x < q_end; i0 += THREADS) {
+        const bool live = i0 < q_end;
+        int qs = 0, qe = 0;
+        if (PAIRS) {
+            const int2 v = live ? reinterpret_cast<const int2 *>(qs_arr)[i0] : make_int2(0, 0);
+            qs = v.x, qe = v.y;
+        } else if (live) {
+            qs = qs_arr[i0], qe = qe_arr[i0];
+        }
+        int rS = 1, rP = 1;
+        for (int it = 0; it < w.kS; it++) rS = 2 * rS + (treeS[rS] < qe);
+        for (int it = 0; it < w.kP; it++) rP = 2 * rP + (treeP[rP] <= qs && qs != INT_MAX);
+        rS = (rS - (1 << w.kS)) * w.strideS;
+        rP = (rP - (1 << w.kP)) * w.strideP;
+        if (w.strideS > 1) rS = group_rank_lt(ix.s_ord + w.sLo, rS, rS + w.strideS < w.nS ? rS + w.strideS : w.nS, qe);
+        if (w.strideP > 1 && qs != INT_MAX)
+            rP = group_rank_lt(ix.pm + w.pLo, rP, rP + w.strideP < w.nP ? rP + w.strideP : w.nP, qs + 1);
+        const bool in_slice = qe >= w.qeLo && qe <= w.qeHi;
+        int hi = in_slice ? w.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe);
+        int lo = qs == INT_MAX ? ix.n : w.pLo + rP;
+        if (!live) lo = hi = 0;
+        int mine = 0;
+        if (PER_LANE) {
+            // window scan, one lane per query (see part_fill_lane_kernel); a long window is counted by the whole wave
+            const bool wide = hi - lo > LANE_WINDOW;
+            if (!wide) {
+                for (int k = lo; k < hi; k++) mine += ix.e_ord[k] > qs;
+            }
+            unsigned long long wm = __ballot(wide);
+            while (wm) {
+                const int src = __ffsll((long long)wm) - 1;
+                wm &= wm - 1;
+                const int L = __shfl(lo, src, 64), H = __shfl(hi, src, 64), S = __shfl(qs, src, 64);
+                int c = 0;
+                for (int k = L + lane_id(); k < H; k += 64) c += ix.e_ord[k] > S;
+    #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+                if (lane_id() == src) mine = c;
+            }
+        } else {
+            const int sub = threadIdx.x & 7, gbase = lane_id() & ~7;
+            // cooperative window scan: the 8 lanes of a group take their 8 queries one after the other; the first
+            // 32-candidate step of all 8 windows is loaded up front (one dependent round trip instead of eight)
+            int wl[8], wh[8], wk[8];
+            int4 v[8];
+    #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                wl[r] = __shfl(lo, gbase + r, 64);
+                wh[r] = __shfl(hi, gbase + r, 64);
+                wk[r] = __shfl(qs, gbase + r, 64);
+                v[r] = wl[r] < wh[r] ? *reinterpret_cast<const int4 *>(ix.e_ord + (wl[r] & ~(FAN - 1)) + sub * 4) : make_int4(0, 0, 0, 0);
+            }
+    #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                int c = 0;
+                if (wl[r] < wh[r]) {
+                    const int k0 = wl[r] & ~(FAN - 1), kb = k0 + sub * 4;
+                    c += (kb + 0 >= wl[r] && kb + 0 < wh[r] && v[r].x > wk[r]);
+                    c += (kb + 1 >= wl[r] && kb + 1 < wh[r] && v[r].y > wk[r]);
+                    c += (kb + 2 >= wl[r] && kb + 2 < wh[r] && v[r].z > wk[r]);
+                    c += (kb + 3 >= wl[r] && kb + 3 < wh[r] && v[r].w > wk[r]);
+                    c = group8_sum_dpp(c);
+                    if (k0 + FAN < wh[r]) c += window_count<true>(ix.e_ord, k0 + FAN, wh[r], wk[r], sub);  // long window: the rest
+                }
+                if (sub == r) mine = c;
+            }
+        }
+        if (live) {
+            win_lo[i0] = lo;
+            win_hi[i0] = hi;
+            counts[i0] = mine;
+        }
+    }
+}
+
+__global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, const SliceBound *__restrict__ bounds,
+                                                                 const int32_t *__restrict__ wg_first,
+                                                                 const unsigned *__restrict__ table,
+                                                                 const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
+                                                                 int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
+                                                                 int32_t *__restrict__ counts)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    __shared__ int s_bucket;
+    int b;
+    int64_t q_begin, q_end;
+    if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end)) return;
+    const SliceBound sb = bounds[b];
+    const WindowSlices w = {sb.sLo, sb.sHi - sb.sLo, sb.kS, sb.strideS, sb.pLo, sb.pHi - sb.pLo, sb.kP, sb.strideP, sb.qeLo, sb.qeHi};
+    int32_t *treeP, *treeS;
+    window_stage<PT_THREADS>(ix, w, lds, treeP, treeS);
+    window_queries<PT_THREADS, true, false>(ix, w, treeP, treeS, q_begin, q_end, reinterpret_cast<const int32_t *>(pairs), nullptr, win_lo, win_hi, counts);
+}
+
+// Are the starts non-decreasing?  (find path: decided on the host before anything else is launched)
+__global__ void ivl_sorted_check_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ unsorted)
+{
+    bool descent = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < nq; i += (int64_t)gridDim.x * blockDim.x)
+        descent |= qs[i] > qs[i + 1];
+    if (__ballot(descent) && lane_id() == 0 && *unsorted == 0) *unsorted = 1;
+}
+
+// Values in query order -> bucket order (the inverse of part_gather_kernel): a workgroup drops its tile's
+// values into LDS at the slots the scatter recorded, then streams the tile's runs out, one per bucket.
+__global__ __launch_bounds__(PT_THREADS) void part_permute_i64_kernel(const long long *__restrict__ values,
+                                                                      const unsigned short *__restrict__ lpos,
+                                                                      const unsigned *__restrict__ tile_table, int64_t ntiles,
+                                                                      int64_t nq, long long *__restrict__ bucketed)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    long long *vals = reinterpret_cast<long long *>(dyn);                           // [PT_TILE]
+    unsigned short *toff = reinterpret_cast<unsigned short *>(vals + PT_TILE);      // [PT_NB + 2]
+    unsigned *gbase = reinterpret_cast<unsigned *>(toff + PT_NB + 2);               // [PT_NB]
+    __shared__ unsigned scan_tmp[16];
+    const int64_t tile = part_tile_of_block(ntiles);
+    if (tile >= ntiles) return;
+    const int64_t base = tile * PT_TILE;
+    const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
+    {
+        const bool last_tile = tile + 1 == ntiles;
+        const unsigned *row = tile_table + tile * PT_NB;
+        const unsigned *next = last_tile ? tile_table : row + PT_NB;
+        unsigned c[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            int b = 2 * threadIdx.x + u;
+            unsigned lo = row[b];
+            unsigned hi = !last_tile ? next[b] : (b + 1 < PT_NB ? next[b + 1] : (unsigned)nq);
+            gbase[b] = lo;
+            c[u] = hi - lo;
+        }
+        unsigned tot;
+        unsigned exc = block_exclusive_scan(c[0] + c[1], OpSum(), 0u, scan_tmp, &tot);
+        toff[2 * threadIdx.x] = (unsigned short)exc;
+        toff[2 * threadIdx.x + 1] = (unsigned short)(exc + c[0]);
+    }
+    for (int k = threadIdx.x; k < n; k += PT_THREADS) vals[lpos[base + k]] = values[base + k];
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    for (int b = threadIdx.x >> 3; b < PT_NB; b += PT_THREADS / 8) {
+        unsigned o = toff[b], len = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o, gb = gbase[b];
+        for (unsigned r = sub; r < len; r += 8) bucketed[gb + r] = vals[o + r];
+    }
+}
+
+// One 32-candidate step of a window: compact the hits of this step behind `base` (CSR order = tree order).
+__device__ __forceinline__ int fill_step(int4 v, int4 id, int kb, int lo, int hi, int qs, int64_t base, int32_t *__restrict__ hits,
+                                         int gshift, unsigned below)
+{
+    bool f0 = kb + 0 >= lo && kb + 0 < hi && v.x > qs;
+    bool f1 = kb + 1 >= lo && kb + 1 < hi && v.y > qs;
+    bool f2 = kb + 2 >= lo && kb + 2 < hi && v.z > qs;
+    bool f3 = kb + 3 >= lo && kb + 3 < hi && v.w > qs;
+    unsigned b0 = (unsigned)(__ballot(f0) >> gshift) & 0xffu;
+    unsigned b1 = (unsigned)(__ballot(f1) >> gshift) & 0xffu;
+    unsigned b2 = (unsigned)(__ballot(f2) >> gshift) & 0xffu;
+    unsigned b3 = (unsigned)(__ballot(f3) >> gshift) & 0xffu;
+    if (f0 | f1 | f2 | f3) {
+        int64_t pos = base + __popc(b0 & below) + __popc(b1 & below) + __popc(b2 & below) + __popc(b3 & below);
+        if (f0) hits[pos++] = id.x;
+        if (f1) hits[pos++] = id.y;
+        if (f2) hits[pos++] = id.z;
+        if (f3) hits[pos++] = id.w;
+    }
+    return __popc(b0) + __popc(b1) + __popc(b2) + __popc(b3);
+}
+
+// Fill pass in bucket order: the window reads stay inside the bucket's lines (L2) instead of touching two random
+// lines per query, and each 8-lane group keeps FILL_Q queries in flight (metadata and the first step of every
+// window are loaded before any of them is compacted: the chain load-meta -> load-window -> store is latency bound).
+constexpr int FILL_Q = 4;
+__global__ __launch_bounds__(FIND_THREADS) void part_fill_kernel(IndexDev ix, const int32_t *__restrict__ qs_arr, int qs_stride /* 2: (qs, qe) pairs */,
+                                                                int64_t nq,
+                                                                const int32_t *__restrict__ win_lo,
+                                                                const int32_t *__restrict__ win_hi,
+                                                                const int32_t *__restrict__ cnt,
+                                                                const long long *__restrict__ boffs,
+                                                                int32_t *__restrict__ hits)
+{
+    const int lane = lane_id();
+    const int sub = lane & 7, gshift = lane & ~7;
+    const unsigned below = (1u << sub) - 1u;
+    // contiguous block of queries per workgroup, XCD-aware: neighbours in bucket order share lines
+    const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
+    const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
+    for (int64_t qb = q0 + (int64_t)(threadIdx.x >> 3) * FILL_Q; qb < q1; qb += (FIND_THREADS / 8) * FILL_Q) {
+        int lo[FILL_Q], hi[FILL_Q], qs[FILL_Q];
+        int64_t base[FILL_Q];
+#pragma unroll
+        for (int j = 0; j < FILL_Q; j++) {
+            const int64_t q = qb + j;
+            const bool live = q < q1 && cnt[q] != 0;
+            lo[j] = live ? win_lo[q] : 0;
+            hi[j] = live ? win_hi[q] : 0;
+            qs[j] = live ? qs_arr[q * qs_stride] : 0;
+            base[j] = live ? boffs[q] : 0;
+        }
+        int4 ve[FILL_Q], vi[FILL_Q];
+#pragma unroll
+        for (int j = 0; j < FILL_Q; j++) {
+            const int kb = (lo[j] & ~(FAN - 1)) + sub * 4;
+            if (lo[j] < hi[j]) {
+                ve[j] = *reinterpret_cast<const int4 *>(ix.e_ord + kb);
+                vi[j] = *reinterpret_cast<const int4 *>(ix.idx + kb);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FILL_Q; j++) {
+            if (lo[j] >= hi[j]) continue;
+            int k0 = lo[j] & ~(FAN - 1);
+            base[j] += fill_step(ve[j], vi[j], k0 + sub * 4, lo[j], hi[j], qs[j], base[j], hits, gshift, below);
+            for (k0 += FAN; k0 < hi[j]; k0 += FAN) {
+                const int kb = k0 + sub * 4;
+                int4 v = *reinterpret_cast<const int4 *>(ix.e_ord + kb);
+                int4 id = *reinterpret_cast<const int4 *>(ix.idx + kb);
+                base[j] += fill_step(v, id, kb, lo[j], hi[j], qs[j], base[j], hits, gshift, below);
+            }
+        }
+    }
+}
+
+// The same walk with both of its memory sides made FLAT (round 4).  The kernel above reads the pairs and writes the hits one
+// lane at a time: a wave's 64 queries own one contiguous stretch of the CSR list (~320 hits) and one contiguous window of the
+// pairs (~100), but every store instruction scatters 64 4-byte pieces over the stretch's ten lines and every load is a lane's own
+// dependent step.  Here a wave first copies the window [wbase, kmax) of the pairs into LDS (coalesced 512-byte loads), the
+// lanes walk down inside LDS and drop their hits into an LDS image of the wave's stretch, and the stretch goes out as whole
+// 256-byte stores, lane i taking positions i, i + 64, ...  A batch whose stretch is longer than FF_HITS (queries on a pile) or
+// whose lanes leave the staged window keeps the direct loads / stores for those accesses: exact either way.
+// (measured on configs[4] sorted by start, find() end to end: the kernel above 2.42 ms; FF_HITS / FF_PAIRS = 1024 / 256: 1.81 ms,
+// 768 / 256: 1.71, 512 / 128: 1.64 -- less LDS per wave, more workgroups per CU)
+constexpr int FF_HITS = 512;    // hits of a wave's 64 queries staged in LDS (mean 320 on configs[4])
+constexpr int FF_PAIRS = 128;   // pairs below the wave's highest `hi` staged in LDS
+
+// The pairs a wave's 64 queries will walk: [wbase, kmax) = the FF_PAIRS ranks below the highest `hi` of the wave, requested into
+// registers ahead of time -- all at once (round 4 issued them one after the other behind a branch each: two dependent round trips
+// to HBM per batch, after two more for the queries' numbers; the kernel's time was those four latencies), and by the callers one
+// batch EARLY, while the batch before is being walked.
+struct FfStage {
+    int2 pv[FF_PAIRS / 64];
+    int wbase, kmax;
+};
+__device__ __forceinline__ void ff_load(const int2 *__restrict__ eid /* at index 0 */, int c, int hi, FfStage &S)
+{
+    const int lane = lane_id();
+    S.kmax = wave_max_i32(c ? hi : 0);
+    S.wbase = S.kmax > FF_PAIRS ? S.kmax - FF_PAIRS : 0;
+    const int last = S.kmax > 0 ? S.kmax - 1 : 0;
+#pragma unroll
+    for (int j = 0; j < FF_PAIRS / 64; j++) {
+        const int kk = S.wbase + 64 * j + lane;
+        S.pv[j] = eid[kk < S.kmax ? kk : last];  // (a valid address: no branch around the loads)
+    }
+}
+
+// One wave, 64 consecutive queries (a lane each: `c` hits to find below rank `hi`, its CSR offset `off`): see the kernel below.
+// wp / wh: the wave's LDS images of the pairs and of its stretch of the list; S: what ff_load brought for these queries.
+__device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *__restrict__ eid /* at index 0 */, const FfStage &S, int c, const int hi,
+                                             const int qs, const long long off, int32_t *__restrict__ hits)
+{
+    const int lane = lane_id();
+    int k = hi - 1;
+    // the wave's stretch of the list: from its first query's offset, as long as the sum of its counts
+    const long long base_off = __shfl(off, 0, 64);
+    long long total64 = c;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) total64 += __shfl_xor(total64, d, 64);
+    if (total64 == 0) return;  // (wave-uniform)
+    const bool flat = total64 <= FF_HITS;
+    const int total = flat ? (int)total64 : 0;
+    const int rel = flat ? (int)(off - base_off) : 0;
+    int32_t *__restrict__ dst = hits + off;
+    // the window of the pairs: FF_PAIRS below the highest hi of the wave
+    const int kmax = S.kmax, wbase = S.wbase;
+#pragma unroll
+    for (int j = 0; j < FF_PAIRS / 64; j++) {
+        const int kk = wbase + 64 * j + lane;
+        if (kk < kmax) wp[64 * j + lane] = S.pv[j];
+    }
+    // (lanes read what OTHER lanes staged: wave-level release + barrier, not just in-order DS issue)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto pair_at = [&](int kk) -> int2 { return kk >= wbase ? wp[kk - wbase] : eid[kk]; };
+    auto take = [&](const int2 p) {
+        if (p.x > qs) {
+            --c;
+            if (flat)
+                wh[rel + c] = p.y;
+            else
+                dst[c] = p.y;
+        }
+    };
+    for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
+        // (two self-contained arms: where an LDS read and an HBM load meet in one value the compiler waits for ALL outstanding
+        // memory operations at every step -- the next batch's numbers and pairs included)
+        if (__all(k >= wbase))
+            take(wp[k - wbase]);
+        else
+            take(pair_at(k));
+    }
+    unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        int C = __shfl(c, src, 64), K = __shfl(k, src, 64);
+        const int S = __shfl(qs, src, 64);
+        const int R = __shfl(rel, src, 64);
+        int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
+        while (C > 0 && K >= 0) {
+            const int kk = K - lane;
+            int2 p = make_int2(INT_MIN, 0);
+            if (kk >= 0) p = pair_at(kk);
+            const bool f = kk >= 0 && p.x > S;
+            const unsigned long long fm = __ballot(f);
+            // hits at higher indices come later in the list: lane 0 (the highest index of the step) takes the last free slot
+            const int before = __popcll(fm & ((1ull << lane) - 1ull));
+            if (f && before < C) {
+                if (flat)
+                    wh[R + C - 1 - before] = p.y;
+                else
+                    D[C - 1 - before] = p.y;
+            }
+            C -= __popcll(fm);
+            K -= 64;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < total; i += 64) hits[base_off + i] = wh[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next batch overwrites both images)
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2 *__restrict__ eid /* at index 0 */, const int32_t *__restrict__ qs_arr,
+                                                                     int64_t nq, const int32_t *__restrict__ his, const int32_t *__restrict__ cnt,
+                                                                     const long long *__restrict__ offs, int32_t *__restrict__ hits)
+{
+    __shared__ int2 s_pairs[FIND_THREADS / 64][FF_PAIRS];
+    __shared__ int32_t s_hits[FIND_THREADS / 64][FF_HITS];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
+    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
+    const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
+    struct Q {
+        int c, hi, qs;
+        long long off;
+    };
+    auto load_q = [&](int64_t qb, Q &x) {  // (independent loads: one round trip)
+        const int64_t q = qb + lane;
+        const bool live = q < q1;
+        const int64_t qa = live ? q : q1 - 1;  // (a dead lane: valid addresses, no hits; its offset is the one behind the stretch's last query)
+        x.c = cnt[qa], x.hi = his[qa], x.qs = qs_arr[qa], x.off = offs[qa];
+        if (!live) x.c = 0;
+    };
+    if (q0 + 64 * wave >= q1) return;
+    Q cur;
+    load_q(q0 + 64 * wave, cur);
+    for (int64_t qb = q0 + 64 * wave; qb < q1; qb += FIND_THREADS) {  // (waves are on their own: no workgroup barrier in here)
+        FfStage S;
+        ff_load(eid, cur.c, cur.hi, S);
+        Q nxt = cur;
+        if (qb + FIND_THREADS < q1) load_q(qb + FIND_THREADS, nxt);  // the next batch's numbers travel while this one is walked
+        ff_wave_fill(s_pairs[wave], s_hits[wave], eid, S, cur.c, cur.hi, cur.qs, cur.off, hits);
+        cur = nxt;
+    }
+}
+
+// CSR offsets of a sorted find(): offsets[q] = chunk_base[chunk of q] + the exclusive prefix of the chunk's counts -- one read of
+// the counts, one write of the offsets (the three-kernel scan read the counts twice and took 0.25 ms per 50 M).
+// (Tried on top, round 5: the fill making the offsets itself -- a workgroup per run of chunks, a block scan per batch of 512 queries,
+// no offsets kernel and no 8 bytes per query read back: 1.75 ms against 1.53 with this kernel + part_fill_flat_kernel, whose waves
+// run free of barriers; forced to 8 waves per SIMD it spilled and took 1.86.  Not kept.)
+__global__ __launch_bounds__(LC_THREADS) void lf_offsets_kernel(const int32_t *__restrict__ cnt, const long long *__restrict__ chunk_base, int64_t nq,
+                                                                long long *__restrict__ offsets)
+{
+    __shared__ long long lds[16];
+    const int64_t base = (int64_t)blockIdx.x * LC_CHUNK + (int64_t)threadIdx.x * LC_ITEMS;
+    int c[LC_ITEMS];
+    if (base + LC_ITEMS <= nq) {
+        const int4 a = *reinterpret_cast<const int4 *>(cnt + base), b = *reinterpret_cast<const int4 *>(cnt + base + 4);
+        c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < LC_ITEMS; j++) c[j] = base + j < nq ? cnt[base + j] : 0;
+    }
+    long long run = 0;
+#pragma unroll
+    for (int j = 0; j < LC_ITEMS; j++) run += c[j];
+    long long total;
+    long long off = chunk_base[blockIdx.x] + block_exclusive_scan(run, OpSum(), 0ll, lds, &total);
+    static_assert(LC_ITEMS == 8, "eight consecutive counts per thread");
+    if (base + LC_ITEMS <= nq) {
+        long long o[LC_ITEMS];
+#pragma unroll
+        for (int j = 0; j < LC_ITEMS; j++) {
+            o[j] = off;
+            off += c[j];
+        }
+#pragma unroll
+        for (int j = 0; j < LC_ITEMS; j += 2)
+            *reinterpret_cast<longlong2 *>(offsets + base + j) = make_longlong2(o[j], o[j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < LC_ITEMS; j++) {
+            if (base + j < nq) offsets[base + j] = off;
+            off += c[j];
+        }
+    }
+}
+
+// (Round 5's fused variant -- count, CSR offsets by decoupled look-back and fill in ONE kernel -- measured 2.65 ms against 1.45 for the
+// stages: the count half is a chain of dependent loads that lives on four workgroups per CU, the fused kernel's registers left two.
+// Removed in round 6; HISTORY.md has its design.)
+__global__ void part_fold_total_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
+{
+    unsigned long long v = threadIdx.x < PT_SLOTS ? slots[threadIdx.x] : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0 && v) atomicAdd(total, v);
+}
+
+// Slice bounds of every bucket; depends only on the sealed index, so it is built once at seal().
+__global__ void part_bounds_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted,
+                                   const int32_t *__restrict__ pm, int n, PartGeom g, SliceBound *__restrict__ out)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= PT_NB) return;
+    const long long W = 1ll << g.shift;
+    const long long lo = b == 0 ? (long long)INT_MIN - 1 : (long long)g.cmin + (long long)b * W;          // qs >= lo
+    const long long hi = b == PT_NB - 1 ? (long long)INT_MAX + 1 : (long long)g.cmin + (long long)(b + 1) * W;  // qs < hi
+    auto rank_lt64 = [n](const int32_t *a, long long x) {
+        int l = 0, h = n;
+        while (l < h) {
+            int mid = (int)(((unsigned)l + (unsigned)h) >> 1);
+            if ((long long)a[mid] < x)
+                l = mid + 1;
+            else
+                h = mid;
+        }
+        return l;
+    };
+    SliceBound sb;
+    // ends: keys qs+1 lie in [lo+1, hi]
+    sb.eLo = rank_lt64(e_sorted, lo + 1);
+    sb.eHi = rank_lt64(e_sorted, hi + 1);
+    // Each slice becomes a perfect tree of at most 2^13 - 1 keys (two trees = 64 KiB of LDS, two workgroups per
+    // CU); a longer slice is sampled with the smallest stride that fits.
+    const int nE = sb.eHi - sb.eLo;
+    sb.sLo = rank_lt64(s_ord, lo);
+    long long x = hi + (W >> 3) + 1;  // starts: keys qe of ordinary queries lie in [lo, hi + W/8]
+    sb.sHi = rank_lt64(s_ord, x);
+    const int nS = sb.sHi - sb.sLo;
+    constexpr int TREE_KEYS = (1 << 13) - 1;
+    sb.strideE = nE / TREE_KEYS + 1;
+    sb.strideS = nS / TREE_KEYS + 1;
+    int kE = 0, kS = 0;
+    while ((1 << kE) - 1 < nE / sb.strideE) kE++;
+    while ((1 << kS) - 1 < nS / sb.strideS) kS++;
+    sb.kE = kE;
+    sb.kS = kS;
+    // prefix max of ends in tree order (monotone): #{pm <= qs} for qs in [lo, hi) lies in [#{pm < lo}, #{pm < hi}]
+    sb.pLo = rank_lt64(pm, lo);
+    sb.pHi = rank_lt64(pm, hi);
+    const int nP = sb.pHi - sb.pLo;
+    sb.strideP = nP / TREE_KEYS + 1;
+    int kP = 0;
+    while ((1 << kP) - 1 < nP / sb.strideP) kP++;
+    sb.kP = kP;
+    sb.qeLo = lo < INT_MIN ? INT_MIN : (int32_t)lo;
+    sb.qeHi = x > INT_MAX ? INT_MAX : (int32_t)x;
+    out[b] = sb;
+}
+
+}  // namespace bxmi

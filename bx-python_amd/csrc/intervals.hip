@@ -39,2078 +39,17 @@
 
 #include "primitives.hpp"
 
-namespace bxmi {
-
-constexpr int MAXLEV = 7;          // 32^7 > 2^31
-constexpr int FAN = 32;            // keys per node (128 B)
-constexpr int LDS_TREE_INTS = 18688;  // per tree: 73 KiB, two trees + scratch < 160 KiB
-constexpr int CNT_THREADS = 1024;  // one workgroup per CU, 16 waves
-constexpr int CNT_Q = 4;           // queries in flight per 8-lane group
-constexpr int FIND_THREADS = 512;
-constexpr int FIND_Q = 2;
-
-struct TreeDev {
-    const int32_t *lev[MAXLEV];  // lev[0] = leaves (the sorted array, padded with INT_MAX)
-    int32_t lds_off[MAXLEV];     // offset (ints) of the level inside this tree's LDS region
-    int32_t lev_ints[MAXLEV];    // ints in the level (32 * nodes)
-    int32_t nlev;
-    int32_t lds_from;            // levels >= lds_from live in LDS
-    int32_t lds_ints;            // total ints staged
-};
-
-struct IndexDev {
-    const int32_t *s_ord, *e_ord, *idx, *pm;
-    int32_t n;
-    int32_t has_reversed;
-};
-
-// ---------------------------------------------------------------------------
-// build kernels
-// ---------------------------------------------------------------------------
-// 64-bit sort key: biased start in the high word, then the tie rule of
-// intersection.pyx:112-116 -- on equal starts, intervals with end <= start go
-// LEFT (so they come first, newest first), the others go right (oldest first).
-__global__ void ivl_make_keys_kernel(const int32_t *__restrict__ start, const int32_t *__restrict__ end, int64_t n,
-                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ end_keys,
-                                     unsigned *__restrict__ n_reversed)
-{
-    unsigned rev = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int32_t s = start[i], e = end[i];
-        uint32_t sub = (e <= s) ? (0x7fffffffu - (uint32_t)i) : (0x80000000u | (uint32_t)i);
-        keys[i] = ((unsigned long long)((uint32_t)s ^ 0x80000000u) << 32) | sub;
-        end_keys[i] = (uint32_t)e ^ 0x80000000u;
-        rev += (e < s);
-    }
-    unsigned long long m = __ballot(rev != 0);
-    if (m && lane_id() == (int)__ffsll((long long)m) - 1) {
-        // one atomic per wave is plenty: we only need "zero or not"
-        atomicAdd(n_reversed, 1u);
-    }
-}
-
-__global__ void ivl_unpack_kernel(const unsigned long long *__restrict__ keys, const int32_t *__restrict__ end,
-                                  int64_t n, int64_t n_pad, int32_t *__restrict__ s_ord, int32_t *__restrict__ e_ord,
-                                  int32_t *__restrict__ idx)
-{
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_pad; k += (int64_t)gridDim.x * blockDim.x) {
-        if (k < n) {
-            unsigned long long key = keys[k];
-            uint32_t sub = (uint32_t)key;
-            int32_t i = (sub & 0x80000000u) ? (int32_t)(sub & 0x7fffffffu) : (int32_t)(0x7fffffffu - sub);
-            s_ord[k] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
-            idx[k] = i;
-            e_ord[k] = end[i];
-        } else {  // padding up to a whole node
-            s_ord[k] = INT_MAX;
-            e_ord[k] = INT_MIN;
-            idx[k] = -1;
-        }
-    }
-}
-
-__global__ void ivl_unbias_kernel(const uint32_t *__restrict__ in, int64_t n, int64_t n_pad, int32_t *__restrict__ out)
-{
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_pad; k += (int64_t)gridDim.x * blockDim.x)
-        out[k] = k < n ? (int32_t)(in[k] ^ 0x80000000u) : INT_MAX;
-}
-
-__global__ void ivl_pad_kernel(int32_t *__restrict__ a, int64_t n, int64_t n_pad, int32_t v)
-{
-    int64_t k = n + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_pad) a[k] = v;
-}
-
-// Level l+1 of a search tree: entry j = last key of child node j, except that
-// the LAST child (and every padding slot) gets INT_MAX, a fence no key is
-// greater than.  With the fence, "number of entries < key" is always a valid
-// child index and no clamping is needed on the way down.
-__global__ void ivl_tree_level_kernel(const int32_t *__restrict__ below, int64_t nodes_below,
-                                      int32_t *__restrict__ out, int64_t out_ints)
-{
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < out_ints; j += (int64_t)gridDim.x * blockDim.x)
-        out[j] = (j < nodes_below - 1) ? below[j * FAN + (FAN - 1)] : INT_MAX;
-}
-
-// ---------------------------------------------------------------------------
-// device-side search
-// ---------------------------------------------------------------------------
-template <bool DPP>
-__device__ __forceinline__ int node_count_lt(int4 v, int key)
-{
-    int c = (v.x < key) + (v.y < key) + (v.z < key) + (v.w < key);
-    return DPP ? group8_sum_dpp(c) : group8_sum_shfl(c);
-}
-
-__device__ __forceinline__ void stage_tree(const TreeDev &t, int32_t *lds)
-{
-    for (int l = t.nlev - 1; l >= t.lds_from; --l) {
-        const int4 *src = reinterpret_cast<const int4 *>(t.lev[l]);
-        int4 *dst = reinterpret_cast<int4 *>(lds + t.lds_off[l]);
-        int n4 = t.lev_ints[l] >> 2;
-        for (int i = threadIdx.x; i < n4; i += blockDim.x) dst[i] = src[i];
-    }
-}
-
-// rank_lt for NQ independent keys at once (ILP): returns #{a[i] < key}.
-// Two separate loops so the staged levels compile to ds_read_b128 and the lower
-// ones to global_load_dwordx4 (one merged loop makes hipcc fall back to flat_load
-// with a full vmcnt+lgkmcnt drain per level).
-template <bool DPP, int NQ>
-__device__ __forceinline__ void tree_rank_lt(const TreeDev &t, const int32_t *lds, const int (&key)[NQ], int (&rank)[NQ],
-                                             int sub)
-{
-#pragma unroll
-    for (int j = 0; j < NQ; j++) rank[j] = 0;
-    int l = t.nlev - 1;
-    for (; l >= t.lds_from; --l) {
-        const int4 *b = reinterpret_cast<const int4 *>(lds + t.lds_off[l]) + sub;
-        int4 v[NQ];
-#pragma unroll
-        for (int j = 0; j < NQ; j++) v[j] = b[rank[j] * (FAN / 4)];
-#pragma unroll
-        for (int j = 0; j < NQ; j++) rank[j] = rank[j] * FAN + node_count_lt<DPP>(v[j], key[j]);
-    }
-    for (; l >= 0; --l) {
-        const int4 *b = reinterpret_cast<const int4 *>(t.lev[l]) + sub;
-        int4 v[NQ];
-#pragma unroll
-        for (int j = 0; j < NQ; j++) v[j] = b[(int64_t)rank[j] * (FAN / 4)];
-#pragma unroll
-        for (int j = 0; j < NQ; j++) rank[j] = rank[j] * FAN + node_count_lt<DPP>(v[j], key[j]);
-    }
-}
-
-// One key per 8-lane group, each group walking ONE of two trees of the same depth (global levels only): the walks of the
-// sorted-batch kernels' slice bounds -- two keys in each of two trees -- are four groups of one wave side by side, instead of
-// one tree after the other (a chunk's set-up is a chain of dependent loads: twelve of them became six).
-template <bool DPP>
-__device__ __forceinline__ int tree_rank_lt_either(const TreeDev &a, const TreeDev &b, bool use_b, int key, int sub)
-{
-    int rank = 0;
-    for (int l = a.nlev - 1; l >= 0; --l) {  // (a.nlev == b.nlev: the caller's business)
-        // (both pointers as scalars first: a select between the two STRUCTS' members sends the structs to scratch memory)
-        const int32_t *pa = a.lev[l], *pb = b.lev[l];
-        const int4 *lev = reinterpret_cast<const int4 *>(use_b ? pb : pa) + sub;
-        const int4 v = lev[(int64_t)rank * (FAN / 4)];
-        rank = rank * FAN + node_count_lt<DPP>(v, key);
-    }
-    return rank;
-}
-
-// Plain lower bound on the monotone prefix-max array: first k with pm[k] > qs.
-__device__ __forceinline__ int first_pm_gt(const int32_t *__restrict__ pm, int n, int qs)
-{
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-        if (pm[mid] > qs)
-            hi = mid;
-        else
-            lo = mid + 1;
-    }
-    return lo;
-}
-
-// #{k in [lo,hi) : e_ord[k] > qs}, 8 lanes x int4 per 32-element step, aligned.
-template <bool DPP>
-__device__ __forceinline__ int window_count(const int32_t *__restrict__ e_ord, int lo, int hi, int qs, int sub)
-{
-    int c = 0;
-    for (int k0 = lo & ~(FAN - 1); k0 < hi; k0 += FAN) {
-        int kb = k0 + sub * 4;
-        int4 v = *reinterpret_cast<const int4 *>(e_ord + kb);
-        c += (kb + 0 >= lo && kb + 0 < hi && v.x > qs);
-        c += (kb + 1 >= lo && kb + 1 < hi && v.y > qs);
-        c += (kb + 2 >= lo && kb + 2 < hi && v.z > qs);
-        c += (kb + 3 >= lo && kb + 3 < hi && v.w > qs);
-    }
-    return DPP ? group8_sum_dpp(c) : group8_sum_shfl(c);
-}
-
-// ---------------------------------------------------------------------------
-// count kernel (the headline path: 100M queries x 10M targets)
-// ---------------------------------------------------------------------------
-template <bool DPP>
-__global__ __launch_bounds__(CNT_THREADS) void ivl_count_kernel(TreeDev S, TreeDev E, IndexDev ix,
-                                                               const int32_t *__restrict__ qs_arr,
-                                                               const int32_t *__restrict__ qe_arr, int64_t nq,
-                                                               int32_t *__restrict__ counts,
-                                                               unsigned long long *__restrict__ total)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    int32_t *ldsS = lds, *ldsE = lds + S.lds_ints;
-    long long *red = reinterpret_cast<long long *>(lds + S.lds_ints + E.lds_ints);  // 16 slots after the staged levels
-    stage_tree(S, ldsS);
-    stage_tree(E, ldsE);
-    __syncthreads();
-
-    const int sub = threadIdx.x & 7;
-    const int64_t group = (int64_t)blockIdx.x * (CNT_THREADS / 8) + (threadIdx.x >> 3);
-    const int64_t ngroups = (int64_t)gridDim.x * (CNT_THREADS / 8);
-    long long acc = 0;
-
-    for (int64_t q0 = group * CNT_Q; q0 < nq; q0 += ngroups * CNT_Q) {
-        int qs[CNT_Q], qe[CNT_Q];
-        if (q0 + CNT_Q <= nq) {
-            int4 a = *reinterpret_cast<const int4 *>(qs_arr + q0);
-            int4 b = *reinterpret_cast<const int4 *>(qe_arr + q0);
-            qs[0] = a.x, qs[1] = a.y, qs[2] = a.z, qs[3] = a.w;
-            qe[0] = b.x, qe[1] = b.y, qe[2] = b.z, qe[3] = b.w;
-        } else {
-#pragma unroll
-            for (int j = 0; j < CNT_Q; j++) {
-                bool ok = q0 + j < nq;
-                qs[j] = ok ? qs_arr[q0 + j] : 0;
-                qe[j] = ok ? qe_arr[q0 + j] : 0;  // (0,0): zero-length, handled below, result discarded
-            }
-        }
-        // rank_lt(starts, qe) and rank_le(ends, qs) = rank_lt(ends, qs+1)
-        int kE[CNT_Q], rS[CNT_Q], rE[CNT_Q];
-#pragma unroll
-        for (int j = 0; j < CNT_Q; j++) kE[j] = qs[j] == INT_MAX ? INT_MAX : qs[j] + 1;
-        tree_rank_lt<DPP, CNT_Q>(S, ldsS, qe, rS, sub);
-        tree_rank_lt<DPP, CNT_Q>(E, ldsE, kE, rE, sub);
-
-        int cnt[CNT_Q];
-#pragma unroll
-        for (int j = 0; j < CNT_Q; j++) {
-            bool regular = (qs[j] < qe[j]) && !ix.has_reversed;
-            if (regular) {
-                cnt[j] = rS[j] - (qs[j] == INT_MAX ? ix.n : rE[j]);
-            } else {
-                // exact predicate over the candidate window (uniform inside the 8-lane group)
-                int lo = first_pm_gt(ix.pm, ix.n, qs[j]);
-                cnt[j] = lo < rS[j] ? window_count<DPP>(ix.e_ord, lo, rS[j], qs[j], sub) : 0;
-            }
-        }
-        if (sub == 0) {
-            if (q0 + CNT_Q <= nq) {
-                if (counts) *reinterpret_cast<int4 *>(counts + q0) = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
-                acc += (long long)cnt[0] + cnt[1] + cnt[2] + cnt[3];
-            } else {
-#pragma unroll
-                for (int j = 0; j < CNT_Q; j++)
-                    if (q0 + j < nq) {
-                        if (counts) counts[q0 + j] = cnt[j];
-                        acc += cnt[j];
-                    }
-            }
-        }
-    }
-    if (total) block_accumulate_i64(acc, red, total);
-}
-
-
-// ---------------------------------------------------------------------------
-// partitioned count path (large batches)
-// ---------------------------------------------------------------------------
-// The direct kernel above is instruction-issue bound (rocprof: ~27 wave
-// instructions per query, SIMDs 100 % busy) and pulls ~350 B/query through the
-// fabric because random queries touch random leaves.  For big batches we make
-// the accesses local instead:
-//   1. bucket the queries by coordinate (2048 buckets over the targets' span):
-//      histogram -> scan -> scatter (LDS atomics give the in-tile ranks);
-//   2. one workgroup per (bucket, chunk): the bucket's slice of the sorted
-//      ends/starts (a few thousand keys) is staged in LDS and every lane does
-//      two plain binary searches there -- ~3 wave instructions per query, and
-//      the targets are read from HBM once, coalesced;
-//   3. counts come back in bucket order and are gathered into query order.
-// Everything stays exact: slices are chosen so that ranks outside them are
-// known, and anything that falls outside (very long / reversed queries) takes
-// a per-lane global search.  rocprofv3 numbers for each step: DESIGN.md 3.1.
-constexpr int PT_NB_LOG2 = 11;
-constexpr int PT_NB = 1 << PT_NB_LOG2;      // coordinate buckets
-constexpr int PT_THREADS = 1024;
-#ifndef BXMI_PT_ITEMS
-#define BXMI_PT_ITEMS 16
-#endif
-constexpr int PT_ITEMS = BXMI_PT_ITEMS;
-constexpr int PT_TILE = PT_THREADS * PT_ITEMS;  // 16384 queries per partition tile (staged whole in LDS)
-#ifndef BXMI_PT_CHUNK
-#define BXMI_PT_CHUNK 65536
-#endif
-constexpr int PT_CHUNK = BXMI_PT_CHUNK;     // queries per search workgroup
-constexpr int PT_LDS_INTS = 19456;          // 76 KiB of slices per workgroup -> two workgroups per CU
-constexpr int PT_SLOTS = 64;                // spread the total over 64 counters (one atomic per workgroup)
-constexpr int PT_ILP = 4;                   // queries in flight per lane in the search kernel
-constexpr int LANE_WINDOW = 24;             // find(): windows up to this long are scanned by their own lane, longer ones by the whole wave
-
-struct PartGeom {
-    int32_t cmin;   // smallest coordinate of the bucket grid
-    int32_t shift;  // bucket width = 1 << shift
-};
-
-struct SliceBound {
-    int32_t eLo, eHi;    // staged slice of the sorted ends    [eLo, eHi)
-    int32_t sLo, sHi;    // staged slice of the sorted starts  [sLo, sHi)
-    int32_t qeLo, qeHi;  // rank_lt(starts, qe) may use the slice iff qeLo <= qe <= qeHi
-    int32_t kE, kS;      // the slices are staged as perfect search trees of 2^k - 1 keys ...
-    int32_t strideE, strideS;  // ... over every stride-th key (stride 1 = all of them: the tree alone gives the rank)
-    int32_t pLo, pHi, kP, strideP;  // same for the prefix-max array (window start of find): ranks of pm <= qs
-};
-
-__device__ __forceinline__ int part_bucket(int qs, PartGeom g)
-{
-    if (qs < g.cmin) return 0;
-    unsigned b = ((unsigned)qs - (unsigned)g.cmin) >> g.shift;
-    return b < (unsigned)(PT_NB - 1) ? (int)b : PT_NB - 1;
-}
-
-// Workgroup -> tile, XCD-aware.  Workgroup w runs on XCD w % 8 (observed dispatch order; used for
-// speed only).  Giving each XCD a CONTIGUOUS range of tiles means the four (tile, bucket) runs that
-// share one 128-byte line of the bucketed arrays are written / read by the same XCD close in time,
-// so its L2 merges them: measured 1.7x write and 3x read amplification without this.
-__device__ __forceinline__ int64_t part_tile_of_block(int64_t ntiles)
-{
-    const int64_t per_xcd = (ntiles + 7) >> 3;
-    return (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-}
-
-// Histogram pass.  The LDS atomics that count a tile's buckets also hand every query its rank inside its (tile,
-// bucket) run, and after one block scan the workgroup knows where each bucket starts inside the tile -- so the
-// query's slot in the tile's sorted order (`lpos`, 16 bits) is written right here and the scatter needs no atomics
-// of its own (LDS atomics run at ~1 lane/clk/CU: 0.16 ms per 100M, paid once instead of twice).
-__global__ __launch_bounds__(PT_THREADS) void part_hist_kernel(const int32_t *__restrict__ qs, int64_t nq, PartGeom g,
-                                                               unsigned *__restrict__ table /* [ntiles][PT_NB] */, int64_t ntiles,
-                                                               unsigned short *__restrict__ lpos, unsigned *__restrict__ unsorted /* may be NULL */)
-{
-    __shared__ unsigned cnt[PT_NB];
-    __shared__ unsigned short toff[PT_NB];
-    __shared__ unsigned scan_tmp[16];
-    const int64_t tile = part_tile_of_block(ntiles);
-    if (tile >= ntiles) return;
-    for (int i = threadIdx.x; i < PT_NB; i += PT_THREADS) cnt[i] = 0;
-    __syncthreads();
-    const int64_t base = tile * PT_TILE;
-    const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
-    // While the starts stream by, notice whether they are already non-decreasing (a sorted BED file): such a batch
-    // needs no bucketing at all and is answered by ivl_local_count_kernel instead (see there).
-    bool descent = false;
-    unsigned br[PT_ITEMS];  // bucket << 16 | rank inside the (tile, bucket) run
-    if (n == PT_TILE) {
-        // full tile: 4 x 16-byte loads in flight per lane before the first atomic
-        const int4 *q4 = reinterpret_cast<const int4 *>(qs + base);
-        int4 v[PT_ITEMS / 4];
-        int nxt[PT_ITEMS / 4];
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS / 4; j++) {
-            v[j] = q4[j * PT_THREADS + threadIdx.x];
-            int64_t k = base + 4 * (int64_t)(j * PT_THREADS + threadIdx.x) + 4;
-            nxt[j] = unsorted && k < nq ? qs[k] : INT_MAX;
-        }
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS / 4; j++) {
-            descent |= v[j].x > v[j].y || v[j].y > v[j].z || v[j].z > v[j].w || v[j].w > nxt[j];
-            const unsigned bx = part_bucket(v[j].x, g), by = part_bucket(v[j].y, g), bz = part_bucket(v[j].z, g), bw = part_bucket(v[j].w, g);
-            // Sorted input puts the wave's 256 consecutive queries in one bucket, and 256 same-address LDS atomics
-            // serialize (measured 4.4x on a sorted batch): one lane adds for the whole wave then.
-            const unsigned b0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bx);
-            if (__all(bx == b0 && by == b0 && bz == b0 && bw == b0)) {
-                unsigned r0 = 0;
-                if (lane_id() == 0) r0 = atomicAdd(&cnt[b0], 256u);
-                r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)r0) + 4u * (unsigned)lane_id();
-                br[4 * j + 0] = (b0 << 16) | (r0 + 0);
-                br[4 * j + 1] = (b0 << 16) | (r0 + 1);
-                br[4 * j + 2] = (b0 << 16) | (r0 + 2);
-                br[4 * j + 3] = (b0 << 16) | (r0 + 3);
-            } else {
-                br[4 * j + 0] = (bx << 16) | atomicAdd(&cnt[bx], 1u);
-                br[4 * j + 1] = (by << 16) | atomicAdd(&cnt[by], 1u);
-                br[4 * j + 2] = (bz << 16) | atomicAdd(&cnt[bz], 1u);
-                br[4 * j + 3] = (bw << 16) | atomicAdd(&cnt[bw], 1u);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS; j++) {
-            const int k = j * PT_THREADS + threadIdx.x;
-            if (k < n) {
-                int a = qs[base + k];
-                descent |= base + k + 1 < nq && a > qs[base + k + 1];
-                unsigned b = (unsigned)part_bucket(a, g);
-                br[j] = (b << 16) | atomicAdd(&cnt[b], 1u);
-            }
-        }
-    }
-    if (unsorted && __ballot(descent) && lane_id() == 0 && *unsorted == 0) *unsorted = 1;
-    __syncthreads();
-    {
-        unsigned a = cnt[2 * threadIdx.x], b = cnt[2 * threadIdx.x + 1];
-        unsigned tot;
-        unsigned exc = block_exclusive_scan(a + b, OpSum(), 0u, scan_tmp, &tot);
-        toff[2 * threadIdx.x] = (unsigned short)exc;
-        toff[2 * threadIdx.x + 1] = (unsigned short)(exc + a);
-        *reinterpret_cast<uint2 *>(table + tile * PT_NB + 2 * threadIdx.x) = make_uint2(a, b);
-    }
-    __syncthreads();
-    if (n == PT_TILE) {
-        uint2 *l4 = reinterpret_cast<uint2 *>(lpos + base);  // four 16-bit slots per 8-byte store
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS / 4; j++) {
-            unsigned s0 = toff[br[4 * j + 0] >> 16] + (br[4 * j + 0] & 0xffffu), s1 = toff[br[4 * j + 1] >> 16] + (br[4 * j + 1] & 0xffffu);
-            unsigned s2 = toff[br[4 * j + 2] >> 16] + (br[4 * j + 2] & 0xffffu), s3 = toff[br[4 * j + 3] >> 16] + (br[4 * j + 3] & 0xffffu);
-            l4[j * PT_THREADS + threadIdx.x] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS; j++) {
-            const int k = j * PT_THREADS + threadIdx.x;
-            if (k < n) lpos[base + k] = (unsigned short)(toff[br[j] >> 16] + (br[j] & 0xffffu));
-        }
-    }
-}
-
-// The table is tile-major ([tile][bucket], every workgroup reads/writes its own 8 KiB row coalesced).
-// Destination of (tile t, bucket b) = sum of all counts of buckets < b, plus counts of bucket b in
-// tiles < t: a scan DOWN the columns after a scan ACROSS the column totals, in three small kernels.
-__global__ __launch_bounds__(PT_THREADS) void part_colsum_kernel(const unsigned *__restrict__ table, int64_t ntiles, int rows_per_block,
-                                                                 unsigned *__restrict__ partial /* [nblocks][PT_NB] */,
-                                                                 const unsigned *__restrict__ gate)
-{
-    if (gate && *gate == 0) return;  // sorted batch: the bucketed path is skipped
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = r0 + rows_per_block < ntiles ? r0 + rows_per_block : ntiles;
-    unsigned s0 = 0, s1 = 0;
-    int64_t r = r0;
-    for (; r + 16 <= r1; r += 16) {  // 32 loads in flight: the kernel is a chain of round trips otherwise
-        unsigned v0[16], v1[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            v0[i] = table[(r + i) * PT_NB + threadIdx.x];
-            v1[i] = table[(r + i) * PT_NB + PT_THREADS + threadIdx.x];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) s0 += v0[i], s1 += v1[i];
-    }
-    for (; r < r1; r++) {
-        s0 += table[r * PT_NB + threadIdx.x];
-        s1 += table[r * PT_NB + PT_THREADS + threadIdx.x];
-    }
-    partial[(int64_t)blockIdx.x * PT_NB + threadIdx.x] = s0;
-    partial[(int64_t)blockIdx.x * PT_NB + PT_THREADS + threadIdx.x] = s1;
-}
-
-__global__ __launch_bounds__(PT_THREADS) void part_colbase_kernel(unsigned *__restrict__ partial, int nblocks, int64_t nq,
-                                                                  int32_t *__restrict__ wg_first /* [PT_NB + 1] */,
-                                                                  const unsigned *__restrict__ gate)
-{
-    __shared__ unsigned scan_tmp[16];
-    if (gate && *gate == 0) return;
-    __shared__ int scan_tmp_i[16];
-    // thread t owns the adjacent columns 2t and 2t+1 (so that one block scan orders all 2048 buckets)
-    const int c0 = 2 * threadIdx.x, c1 = c0 + 1;
-    unsigned t0 = 0, t1 = 0;
-    {
-        int r = 0;
-        for (; r + 16 <= nblocks; r += 16) {
-            uint2 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = *reinterpret_cast<const uint2 *>(partial + (int64_t)(r + i) * PT_NB + c0);
-#pragma unroll
-            for (int i = 0; i < 16; i++) t0 += v[i].x, t1 += v[i].y;
-        }
-        for (; r < nblocks; r++) {
-            uint2 v = *reinterpret_cast<const uint2 *>(partial + (int64_t)r * PT_NB + c0);
-            t0 += v.x;
-            t1 += v.y;
-        }
-    }
-    unsigned tot;
-    unsigned base0 = block_exclusive_scan(t0 + t1, OpSum(), 0u, scan_tmp, &tot);
-    unsigned base1 = base0 + t0;
-    // search-workgroup plan: bucket b gets ceil(n_b / PT_CHUNK) workgroups
-    int ch0 = (int)((t0 + PT_CHUNK - 1) / PT_CHUNK), ch1 = (int)((t1 + PT_CHUNK - 1) / PT_CHUNK);
-    int chtot;
-    int w0 = block_exclusive_scan(ch0 + ch1, OpSum(), 0, scan_tmp_i, &chtot);
-    wg_first[c0] = w0;
-    wg_first[c1] = w0 + ch0;
-    if (threadIdx.x == 0) wg_first[PT_NB] = chtot;
-    unsigned run0 = base0, run1 = base1;
-    {
-        int r = 0;
-        for (; r + 16 <= nblocks; r += 16) {
-            uint2 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = *reinterpret_cast<const uint2 *>(partial + (int64_t)(r + i) * PT_NB + c0);
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                *reinterpret_cast<uint2 *>(partial + (int64_t)(r + i) * PT_NB + c0) = make_uint2(run0, run1);
-                run0 += v[i].x;
-                run1 += v[i].y;
-            }
-        }
-        for (; r < nblocks; r++) {
-            uint2 *cell = reinterpret_cast<uint2 *>(partial + (int64_t)r * PT_NB + c0);
-            uint2 v = *cell;
-            *cell = make_uint2(run0, run1);
-            run0 += v.x;
-            run1 += v.y;
-        }
-    }
-}
-
-__global__ __launch_bounds__(PT_THREADS) void part_colscan_kernel(unsigned *__restrict__ table, int64_t ntiles, int rows_per_block,
-                                                                  const unsigned *__restrict__ partial,
-                                                                  const unsigned *__restrict__ gate)
-{
-    if (gate && *gate == 0) return;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = r0 + rows_per_block < ntiles ? r0 + rows_per_block : ntiles;
-    unsigned run0 = partial[(int64_t)blockIdx.x * PT_NB + threadIdx.x];
-    unsigned run1 = partial[(int64_t)blockIdx.x * PT_NB + PT_THREADS + threadIdx.x];
-    int64_t r = r0;
-    for (; r + 16 <= r1; r += 16) {
-        unsigned v0[16], v1[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            v0[i] = table[(r + i) * PT_NB + threadIdx.x];
-            v1[i] = table[(r + i) * PT_NB + PT_THREADS + threadIdx.x];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            table[(r + i) * PT_NB + threadIdx.x] = run0;
-            table[(r + i) * PT_NB + PT_THREADS + threadIdx.x] = run1;
-            run0 += v0[i];
-            run1 += v1[i];
-        }
-    }
-    for (; r < r1; r++) {
-        unsigned v0 = table[r * PT_NB + threadIdx.x], v1 = table[r * PT_NB + PT_THREADS + threadIdx.x];
-        table[r * PT_NB + threadIdx.x] = run0;
-        table[r * PT_NB + PT_THREADS + threadIdx.x] = run1;
-        run0 += v0;
-        run1 += v1;
-    }
-}
-
-// One workgroup moves one tile of 16384 queries into bucket order.  A scattered 4-byte store
-// costs a whole L2 request, so the tile is ordered INSIDE LDS first ((qs,qe) pairs written to the
-// slot of the tile's sorted order that the histogram pass recorded in `lpos`) and then streamed
-// out: consecutive lanes store to consecutive addresses, one request per (tile, bucket) run.
-__global__ __launch_bounds__(PT_THREADS) void part_scatter_kernel(const int32_t *__restrict__ qs, const int32_t *__restrict__ qe,
-                                                                  int64_t nq, PartGeom g,
-                                                                  const unsigned *__restrict__ tile_table /* [ntiles][PT_NB] */,
-                                                                  int64_t ntiles, int2 *__restrict__ pairs_out /* (qs, qe) in bucket order */,
-                                                                  const unsigned short *__restrict__ lpos,
-                                                                  const unsigned *__restrict__ gate)
-{
-    // LDS: the whole tile of (qs, qe) pairs (128 KiB) + one 2048-entry table (8 KiB).  The tile's pairs and slots live
-    // in registers (102 VGPRs), so ONE workgroup runs per CU whatever the LDS footprint; staging half a tile at a time
-    // (80 KiB) measured 4 % slower, and keeping only the slots in registers and re-reading the pairs (64 VGPRs, two
-    // workgroups per CU) measured 0.61 ms against 0.46 ms -- more tiles in flight spread the runs that share a
-    // 128-byte line further apart in time.  A persistent grid (one workgroup per CU looping over its tiles, next tile's
-    // loads issued before the current one is streamed out) measured +23 % on the whole pass: the workgroups march in
-    // step and the load and store bursts stop overlapping.
-    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    int2 *staged = reinterpret_cast<int2 *>(dyn);                    // [PT_TILE] (qs, qe) in bucket order
-    unsigned *delta = reinterpret_cast<unsigned *>(dyn + 2 * PT_TILE);   // [PT_NB] global base of the (tile, bucket) run - its offset in the tile
-    unsigned *scan_tmp = reinterpret_cast<unsigned *>(dyn);           // the staging area is idle during the scan
-    const int64_t tile = part_tile_of_block(ntiles);
-    if (tile >= ntiles) return;
-    const unsigned go = gate ? *gate : 1u;  // 0 = sorted batch, answered elsewhere
-    const int64_t base = tile * PT_TILE;
-    const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
-    int s[PT_ITEMS], e[PT_ITEMS];
-    unsigned slot[PT_ITEMS];
-    if (go == 0) return;
-#pragma unroll
-    for (int j = 0; j < PT_ITEMS; j++) {
-        int k = j * PT_THREADS + threadIdx.x;
-        if (k < n) {
-            s[j] = qs[base + k];
-            e[j] = qe[base + k];
-            slot[j] = lpos[base + k];
-        }
-    }
-    {
-        // Tile counts = distance to the next entry of the (linear, bucket-major) exclusive scan: the next
-        // tile's entry for the same bucket, or -- for the last tile -- tile 0's entry of the next bucket.
-        const bool last_tile = tile + 1 == ntiles;
-        const unsigned *row = tile_table + tile * PT_NB;
-        const unsigned *next = last_tile ? tile_table : row + PT_NB;
-        unsigned c[2], lo[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            int b = 2 * threadIdx.x + u;
-            lo[u] = row[b];
-            unsigned hi = !last_tile ? next[b] : (b + 1 < PT_NB ? next[b + 1] : (unsigned)nq);
-            c[u] = hi - lo[u];
-        }
-        unsigned tot;
-        unsigned exc = block_exclusive_scan(c[0] + c[1], OpSum(), 0u, scan_tmp, &tot);
-        delta[2 * threadIdx.x] = lo[0] - exc;
-        delta[2 * threadIdx.x + 1] = lo[1] - (exc + c[0]);
-    }
-    __syncthreads();  // table ready, scan scratch free
-#pragma unroll
-    for (int j = 0; j < PT_ITEMS; j++) {
-        int k = j * PT_THREADS + threadIdx.x;
-        if (k < n) staged[slot[j]] = make_int2(s[j], e[j]);
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int p = threadIdx.x; p < n; p += PT_THREADS) {
-        int2 v = staged[p];
-        unsigned d = delta[part_bucket(v.x, g)] + (unsigned)p;  // global base of the run + offset inside it
-        pairs_out[d] = v;  // one 8-byte store: a (tile, bucket) run is 64 contiguous bytes
-    }
-}
-
-// Finish a sampled-tree rank inside one group of `stride` keys: short groups are counted with independent loads
-// (one round trip, usually one line); long ones fall back to a binary search.
-__device__ __forceinline__ int group_rank_lt(const int32_t *__restrict__ a, int lo, int hi, int key);
-
-__device__ __forceinline__ int global_rank_lt(const int32_t *__restrict__ a, int lo, int hi, int key)
-{
-    while (lo < hi) {
-        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-        if (a[mid] < key)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
-// Counts travel back to query order as 16 bits when they fit: 0xFFFF says "ask again" and the gather recomputes
-// that query from the index (exact; only pile-ups of >= 65535 overlapping targets ever take it).  Halves the bytes of
-// the counts' round trip (0.4 GB of the pass at 100M queries).
-constexpr unsigned COUNT_ESCAPE = 0xFFFFu;
-__device__ __forceinline__ void store_count(int32_t *p, int64_t i, int c) { p[i] = c; }
-__device__ __forceinline__ void store_count(unsigned short *p, int64_t i, int c)
-{
-    p[i] = (unsigned short)((unsigned)c < COUNT_ESCAPE ? (unsigned)c : COUNT_ESCAPE);
-}
-
-// One query straight from the sealed index (global binary searches): the escape path of the 16-bit counts.
-__device__ __forceinline__ int count_one_global(const IndexDev &ix, const int32_t *__restrict__ e_sorted, int qs, int qe);
-
-// Which bucket / which queries does this search workgroup own?  (shared prologue of the count and window kernels)
-__device__ __forceinline__ bool part_chunk_of_block(const int32_t *__restrict__ wg_first, const unsigned *__restrict__ table,
-                                                    int64_t nq, int *s_bucket, int &b, int64_t &q_begin, int64_t &q_end)
-{
-    if (threadIdx.x == 0) *s_bucket = -1;
-    __syncthreads();
-    const int w = (int)blockIdx.x;
-#pragma unroll
-    for (int u = 0; u < PT_NB / PT_THREADS; u++) {
-        int c = u * PT_THREADS + threadIdx.x;
-        if (wg_first[c] <= w && w < wg_first[c + 1]) *s_bucket = c;
-    }
-    __syncthreads();
-    b = __builtin_amdgcn_readfirstlane(*s_bucket);  // uniform: everything derived from it lives in SGPRs
-    if (b < 0) return false;
-    const int64_t q_lo = table[b];
-    const int64_t q_hi = b + 1 < PT_NB ? (int64_t)table[b + 1] : nq;
-    q_begin = q_lo + (int64_t)(w - wg_first[b]) * PT_CHUNK;
-    q_end = q_begin + PT_CHUNK < q_hi ? q_begin + PT_CHUNK : q_hi;
-    return true;
-}
-
-// Stage `m = n / stride` samples of a sorted slice as a perfect Eytzinger tree of 2^k slots (slot 0 unused).
-template <int THREADS>
-__device__ __forceinline__ void part_stage_tree(int32_t *tree, int k, const int32_t *__restrict__ src, int n, int stride)
-{
-    const int m = n / stride;
-    for (int r = threadIdx.x; r < m; r += THREADS) {
-        int tpos = r + 1, z = __ffs(tpos) - 1;  // in-order number and height of the node holding sample r
-        tree[(tpos >> (z + 1)) + (1 << (k - 1 - z))] = src[(r + 1) * stride - 1];
-    }
-}
-
-__device__ __forceinline__ int group_rank_lt(const int32_t *__restrict__ a, int lo, int hi, int key)
-{
-    if (hi - lo > 8) return global_rank_lt(a, lo, hi, key);
-    int c = lo;
-#pragma unroll
-    for (int u = 0; u < 8; u++) c += (lo + u < hi) && a[lo + u < hi ? lo + u : lo] < key;
-    return c;
-}
-
-__device__ __forceinline__ int wave_min_i32(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        int o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        int o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
-// ---- the same search with direct addressing instead of trees (default) ----
-// Inside one bucket the keys are close to uniform, so most of a binary search is wasted: the bucket's coordinate
-// range is cut into 4096 (+512 for the starts, whose keys reach W/8 past the bucket) equal cells, `cs[c]` = number of
-// slice keys whose cell is below c (16 bits), and a rank is  cs[cell(key)] + (a 2-4 step search among the cell's
-// own keys)  -- the step count is the bit length of the fullest cell, found while staging, so dense or clumped
-// buckets just take more steps and stay exact.  cell() is monotone (clamped), hence keys in lower cells are smaller
-// and keys in higher cells larger than the probe whatever the clamping does.  ~20 lane-instructions per rank
-// instead of ~52 for the 13-level tree.
-constexpr int PC_CELLS_LOG2 = 12;
-constexpr int PC_NC = (1 << PC_CELLS_LOG2) + (1 << (PC_CELLS_LOG2 - 3));  // 4608
-constexpr int PC_CS_INTS = (PC_NC + 2) / 2;                                // one 16-bit table, in ints
-#ifndef BXMI_PC_ILP
-#define BXMI_PC_ILP 4
-#endif
-constexpr int PC_ILP = BXMI_PC_ILP;  // queries in flight per lane
-constexpr int PC_PAD = 64;                                                 // INT_MAX fence after each slice: searches of <= 6 steps need no bound check
-constexpr int PC_KEYS = (PT_LDS_INTS - 2 * PC_CS_INTS - 2 * PC_PAD) / 2;  // keys (or samples) per staged slice: 7 359
-
-struct CellMap {
-    int lo, hi;  // coordinates of the first cell's first and the last cell's last position
-    int cshift;  // cell width = 1 << cshift
-};
-__device__ __forceinline__ int cell_of(int x, CellMap m)
-{
-    x = x < m.lo ? m.lo : x;  // (a v_med3_i32)
-    x = x > m.hi ? m.hi : x;
-    return (int)(((unsigned)x - (unsigned)m.lo) >> m.cshift);
-}
-__device__ __forceinline__ CellMap cell_map_of(int b, PartGeom g)
-{
-    CellMap cm;
-    long long lo = (long long)g.cmin + ((long long)b << g.shift);
-    cm.lo = lo > INT_MAX ? INT_MAX : (int)lo;
-    cm.cshift = g.shift > PC_CELLS_LOG2 ? g.shift - PC_CELLS_LOG2 : 0;
-    long long hi = (long long)cm.lo + ((long long)PC_NC << cm.cshift) - 1;
-    cm.hi = hi > INT_MAX ? INT_MAX : (int)hi;
-    return cm;
-}
-typedef __attribute__((address_space(3))) const int32_t *lds_i32p;
-typedef __attribute__((address_space(3))) const unsigned short *lds_u16p;
-
-// Stage m = n / stride samples of a sorted slice linearly (arr[m] = INT_MAX fence) and build its cell table.
-// Returns the number of search steps: the bit length of the fullest cell.
-__device__ __forceinline__ int cells_stage(int32_t *arr, unsigned short *cs, const int32_t *__restrict__ src, int n, int stride, CellMap cm,
-                                           int *s_red /* [16] */)
-{
-    const int m = n / stride;
-    for (int r = threadIdx.x; r < m; r += PT_THREADS) arr[r] = src[(r + 1) * stride - 1];
-    if (threadIdx.x < PC_PAD) arr[m + threadIdx.x] = INT_MAX;
-    __syncthreads();
-    // element r opens every cell in (cell(arr[r-1]), cell(arr[r])]; the virtual element m closes the table
-    for (int r = threadIdx.x; r <= m; r += PT_THREADS) {
-        const int cp = r == 0 ? -1 : cell_of(arr[r - 1], cm);
-        const int cr = r == m ? PC_NC - 1 : cell_of(arr[r], cm);
-        for (int c = cp + 1; c <= cr; c++) cs[c] = (unsigned short)r;
-    }
-    __syncthreads();
-    int pop = 0;
-    for (int c = threadIdx.x; c < PC_NC; c += PT_THREADS) {
-        int p = (c + 1 < PC_NC ? (int)cs[c + 1] : m) - (int)cs[c];
-        pop = p > pop ? p : pop;
-    }
-    pop = wave_max_i32(pop);
-    if (lane_id() == 0) s_red[threadIdx.x >> 6] = pop;
-    __syncthreads();
-    pop = 0;
-#pragma unroll
-    for (int i = 0; i < PT_THREADS / 64; i++) pop = s_red[i] > pop ? s_red[i] : pop;
-    __syncthreads();
-    return 32 - __clz(pop);  // 0 for an empty slice
-}
-
-// What a search workgroup needs of its bucket, ready to be copied into LDS: [csE][csS][arrE + fence][arrS + fence].
-// It depends only on the sealed index, so it is built once per bucket (part_cells_image_kernel, on the first large batch) and the search
-// kernel starts with one streaming copy instead of two gathers, two table builds and eight barriers (measured ~25 us
-// per workgroup, a quarter of the kernel).
-struct CellsMeta {
-    int mE, mS;            // staged keys (or samples) of the ends / starts slice
-    int strideE, strideS;  // 1 = every key
-    int stepsE, stepsS;    // search steps inside a cell
-    int used_ints;         // ints of the image in use
-    int pad;
-};
-
-__global__ __launch_bounds__(PT_THREADS) void part_cells_image_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
-                                                                      const SliceBound *__restrict__ bounds, PartGeom g,
-                                                                      int32_t *__restrict__ images /* [PT_NB][PT_LDS_INTS] */,
-                                                                      CellsMeta *__restrict__ meta)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    __shared__ int s_red[PT_THREADS / 64];
-    const int b = blockIdx.x;
-    const SliceBound sb = bounds[b];
-    const int nE = sb.eHi - sb.eLo, nS = sb.sHi - sb.sLo;
-    // strides chosen for the tree kernel may be finer than this layout holds: widen if needed
-    const int strideE = nE / sb.strideE > PC_KEYS ? nE / PC_KEYS + 1 : sb.strideE;
-    const int strideS = nS / sb.strideS > PC_KEYS ? nS / PC_KEYS + 1 : sb.strideS;
-    const int mE = nE / strideE, mS = nS / strideS;
-    const CellMap cm = cell_map_of(b, g);
-    unsigned short *csE = reinterpret_cast<unsigned short *>(lds), *csS = reinterpret_cast<unsigned short *>(lds + PC_CS_INTS);
-    int32_t *arrE = lds + 2 * PC_CS_INTS, *arrS = arrE + mE + PC_PAD;
-    const int stepsE = cells_stage(arrE, csE, e_sorted + sb.eLo, nE, strideE, cm, s_red);
-    const int stepsS = cells_stage(arrS, csS, ix.s_ord + sb.sLo, nS, strideS, cm, s_red);
-    const int used = ((2 * PC_CS_INTS + mE + mS + 2 * PC_PAD) + 3) & ~3;
-    __syncthreads();
-    int4 *dst = reinterpret_cast<int4 *>(images + (int64_t)b * PT_LDS_INTS);
-    for (int i = threadIdx.x; i < used / 4; i += PT_THREADS) dst[i] = reinterpret_cast<const int4 *>(lds)[i];
-    if (threadIdx.x == 0) meta[b] = CellsMeta{mE, mS, strideE, strideS, stepsE, stepsS, used, 0};
-}
-
-template <typename CT>
-__global__ __launch_bounds__(PT_THREADS) void part_count_cells_kernel(IndexDev ix, const int32_t *__restrict__ e_sorted,
-                                                                      const SliceBound *__restrict__ bounds,
-                                                                      const int32_t *__restrict__ images, const CellsMeta *__restrict__ meta,
-                                                                      const int32_t *__restrict__ wg_first,
-                                                                      const unsigned *__restrict__ table /* row 0 = bucket offsets */,
-                                                                      const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
-                                                                      PartGeom g,
-                                                                      CT *__restrict__ counts /* bucket order, may be NULL */,
-                                                                      unsigned long long *__restrict__ total_slots,
-                                                                      const unsigned *__restrict__ gate)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    __shared__ int s_bucket;
-    __shared__ long long red[PT_THREADS / 64];
-    int b;
-    int64_t q_begin, q_end;
-    const unsigned go = gate ? *gate : 1u;  // 0 = sorted batch, answered by ivl_local_count_kernel
-    if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end) || go == 0) return;
-    const SliceBound sb = bounds[b];
-    const CellsMeta cmeta = meta[b];
-    const int nE = sb.eHi - sb.eLo, nS = sb.sHi - sb.sLo;
-    const int strideE = cmeta.strideE, strideS = cmeta.strideS, mE = cmeta.mE, mS = cmeta.mS;
-    const int stepsE = cmeta.stepsE, stepsS = cmeta.stepsS;
-    const CellMap cm = cell_map_of(b, g);
-    {
-        const int4 *src = reinterpret_cast<const int4 *>(images + (int64_t)b * PT_LDS_INTS);
-        for (int i = threadIdx.x; i < cmeta.used_ints / 4; i += PT_THREADS) reinterpret_cast<int4 *>(lds)[i] = src[i];
-    }
-    __syncthreads();
-    unsigned short *csE = reinterpret_cast<unsigned short *>(lds), *csS = reinterpret_cast<unsigned short *>(lds + PC_CS_INTS);
-    int32_t *arrE = lds + 2 * PC_CS_INTS, *arrS = arrE + mE + PC_PAD;
-    // positions are LDS pointers to "the last key known to be below the probe" (one add + one read per step)
-    const lds_i32p aE = (lds_i32p)arrE, aS = (lds_i32p)arrS;
-    const lds_u16p cE = (lds_u16p)csE, cS = (lds_u16p)csS;
-    const bool fenced = stepsE <= 6 && stepsS <= 6;  // every probe stays inside the INT_MAX fence
-    // The common case -- an ordinary query (qs < qe, qe inside the staged slice) against unsampled slices -- is kept
-    // lean: 32-bit offsets from the chunk's base, count = (pS - pE) + constant, one test per round for "anything unusual".
-    const unsigned nch = (unsigned)(q_end - q_begin);
-    const int2 *__restrict__ qb = pairs + q_begin;
-    CT *__restrict__ cb = counts ? counts + q_begin : nullptr;
-    const bool unsampled = strideS == 1 && strideE == 1;
-    const int cconst = (sb.sLo - sb.eLo) - (int)(aS - aE);
-    const unsigned qe_span = (unsigned)sb.qeHi - (unsigned)sb.qeLo;
-    long long acc = 0;
-    for (unsigned u0 = threadIdx.x; u0 < nch; u0 += PT_THREADS * PC_ILP) {
-        int qs[PC_ILP], qe[PC_ILP];
-        lds_i32p pS[PC_ILP], pE[PC_ILP];
-#pragma unroll
-        for (int j = 0; j < PC_ILP; j++) {
-            unsigned u = u0 + (unsigned)j * PT_THREADS;
-            u = u < nch ? u : nch - 1;  // a valid address: no branch around the loads
-            const int2 v = qb[u];
-            qs[j] = v.x;
-            qe[j] = v.y;
-        }
-#pragma unroll
-        for (int j = 0; j < PC_ILP; j++) {
-            pS[j] = aS + cS[cell_of(qe[j], cm)] - 1;
-            pE[j] = aE + cE[cell_of(qs[j], cm)] - 1;
-        }
-        // only keys of the probe's own cell can still qualify, everything in later cells is larger, the fence stops the walk
-        if (fenced) {
-            for (int st = stepsS - 1; st >= 0; st--) {
-#pragma unroll
-                for (int j = 0; j < PC_ILP; j++) {
-                    const lds_i32p t = pS[j] + (1 << st);
-                    pS[j] = *t < qe[j] ? t : pS[j];
-                }
-            }
-            for (int st = stepsE - 1; st >= 0; st--) {
-#pragma unroll
-                for (int j = 0; j < PC_ILP; j++) {
-                    const lds_i32p t = pE[j] + (1 << st);
-                    pE[j] = *t <= qs[j] ? t : pE[j];  // (qs == INT_MAX passes the fence: handled below)
-                }
-            }
-        } else {
-            const lds_i32p endS = aS + mS, endE = aE + mE;
-            for (int st = stepsS - 1; st >= 0; st--) {
-#pragma unroll
-                for (int j = 0; j < PC_ILP; j++) {
-                    lds_i32p t = pS[j] + (1 << st);
-                    t = t < endS ? t : endS;
-                    pS[j] = *t < qe[j] ? t : pS[j];
-                }
-            }
-            for (int st = stepsE - 1; st >= 0; st--) {
-#pragma unroll
-                for (int j = 0; j < PC_ILP; j++) {
-                    lds_i32p t = pE[j] + (1 << st);
-                    t = t < endE ? t : endE;
-                    pE[j] = *t <= qs[j] ? t : pE[j];
-                }
-            }
-        }
-        int c[PC_ILP];
-        bool odd = !unsampled;
-#pragma unroll
-        for (int j = 0; j < PC_ILP; j++) {
-            c[j] = (int)(pS[j] - pE[j]) + cconst;  // (sLo + #starts < qe) - (eLo + #ends <= qs)
-            odd |= !(qs[j] < qe[j]) | ((unsigned)qe[j] - (unsigned)sb.qeLo > qe_span);
-        }
-        if (odd) {
-#pragma unroll
-            for (int j = 0; j < PC_ILP; j++) {
-                const bool in_slice = (unsigned)qe[j] - (unsigned)sb.qeLo <= qe_span;
-                if (unsampled && qs[j] < qe[j] && in_slice) continue;
-                // sampled slices: finish each rank inside its group; qe outside the slice: global search;
-                // zero-length / reversed query: exact predicate over the candidate window
-                int rS = ((int)(pS[j] - aS) + 1) * strideS, rE = ((int)(pE[j] - aE) + 1) * strideE;
-                if (strideS > 1) rS = group_rank_lt(ix.s_ord + sb.sLo, rS, rS + strideS < nS ? rS + strideS : nS, qe[j]);
-                if (strideE > 1 && qs[j] != INT_MAX) rE = group_rank_lt(e_sorted + sb.eLo, rE, rE + strideE < nE ? rE + strideE : nE, qs[j] + 1);
-                const int s_rank = in_slice ? sb.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe[j]);
-                if (qs[j] < qe[j]) {
-                    c[j] = s_rank - (sb.eLo + rE);  // (qs < qe rules out qs == INT_MAX)
-                } else {
-                    int lo = first_pm_gt(ix.pm, ix.n, qs[j]);
-                    int cc = 0;
-                    for (int k = lo; k < s_rank; k++) cc += ix.e_ord[k] > qs[j];
-                    c[j] = cc;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PC_ILP; j++) {
-            const unsigned u = u0 + (unsigned)j * PT_THREADS;
-            if (u < nch) {
-                if (cb) store_count(cb, (int64_t)u, c[j]);
-                acc += c[j];
-            }
-        }
-    }
-    if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
-}
-
-// ---- sorted batches: no bucketing at all ----
-// When the query starts are already non-decreasing (the usual BED file), 16384 consecutive queries touch one short
-// stretch of the sorted ends / starts.  One workgroup takes such a chunk as it lies: min/max of its keys (block
-// reduction), the four slice boundaries (8-lane walks of the index's 32-ary trees by the first wave), the slices
-// staged as LDS search trees exactly as in part_count_kernel, counts stored straight back in query order: 8 B read
-// and 4 B written per query, no scratch.  Nothing in here relies on the order for correctness -- an unsorted chunk
-// would just get long (sampled) slices and be slow -- the flag computed by part_hist_kernel only decides which of
-// the two paths does the work.
-#ifndef LC_THREADS_V
-#define LC_THREADS_V 512
-#endif
-constexpr int LC_THREADS = LC_THREADS_V;
-constexpr int LC_ITEMS = 8;
-constexpr int LC_CHUNK = LC_THREADS * LC_ITEMS;  // 4096 consecutive queries per workgroup
-#ifndef LC_WALK_BOTH
-#define LC_WALK_BOTH 1  // the slice bounds of a chunk: both trees walked side by side (0: one after the other)
-#endif
-#ifndef LC_TREE_LOG2
-#define LC_TREE_LOG2 12
-#endif
-constexpr int LC_TREE_KEYS = (1 << LC_TREE_LOG2) - 1;  // two trees of 4096 slots = 32 KiB of LDS: four workgroups per CU
-
-// One chunk of LC_CHUNK consecutive queries from `base` on: the workgroup's queries are k = j * LC_THREADS + thread, and
-// emit(j, k, live, count, #{start < qe}, qs) is called once per (thread, j) with j a compile-time constant after unrolling.
-template <typename Emit>
-__device__ __forceinline__ void lc_chunk_counts(const TreeDev &S, const TreeDev &E, const IndexDev &ix, const int32_t *__restrict__ e_sorted,
-                                                const int32_t *__restrict__ qs_arr, const int32_t *__restrict__ qe_arr, int64_t base, int n, int32_t *lds,
-                                                int (*s_mm)[LC_THREADS / 64], int *s_slice, Emit emit)
-{
-    int qs[LC_ITEMS], qe[LC_ITEMS];
-    int mn = INT_MAX, mx = INT_MIN, emx = INT_MIN;
-#pragma unroll
-    for (int j = 0; j < LC_ITEMS; j++) {
-        int k = j * LC_THREADS + threadIdx.x;
-        bool live = k < n;
-        qs[j] = live ? qs_arr[base + k] : 0;
-        qe[j] = live ? qe_arr[base + k] : 0;
-        if (live) {
-            mn = qs[j] < mn ? qs[j] : mn;
-            mx = qs[j] > mx ? qs[j] : mx;
-            emx = qe[j] > emx ? qe[j] : emx;
-        }
-    }
-    mn = wave_min_i32(mn), mx = wave_max_i32(mx), emx = wave_max_i32(emx);
-    if (lane_id() == 0) s_mm[0][threadIdx.x >> 6] = mn, s_mm[1][threadIdx.x >> 6] = mx, s_mm[2][threadIdx.x >> 6] = emx;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        int a = INT_MAX, b = INT_MIN, c = INT_MIN;
-#pragma unroll
-        for (int i = 0; i < LC_THREADS / 64; i++) {
-            a = s_mm[0][i] < a ? s_mm[0][i] : a;
-            b = s_mm[1][i] > b ? s_mm[1][i] : b;
-            c = s_mm[2][i] > c ? s_mm[2][i] : c;
-        }
-        // ends: #{end <= qs} for qs in [a, b] lies in [#{end <= a}, #{end <= b}].  starts: the keys qe of ordinary
-        // queries lie in [a, max qe]; a lone far-away qe must not blow the slice up, so the key range is capped at
-        // a few chunk spans and whatever falls outside takes a global search.
-        long long cap = (long long)b + 4 * ((long long)b - (long long)a) + 65536;
-        if (cap > INT_MAX) cap = INT_MAX;
-        int s_hi_key = (long long)c < cap ? c : (int)cap;
-        if (s_hi_key < a) s_hi_key = a;
-        const int sub = threadIdx.x & 7, upper = (threadIdx.x >> 3) & 1;
-        const int qs_key = upper ? b : a;
-#if LC_WALK_BOTH
-        {   // (both trees stand on n keys: the same depth) groups 0 / 1: the ends' bounds, 2 / 3: the starts', side by side
-            const bool starts = ((threadIdx.x >> 4) & 1) != 0;
-            const int key = starts ? (upper ? s_hi_key : a) : (qs_key == INT_MAX ? INT_MAX : qs_key + 1);
-            int r = tree_rank_lt_either<true>(E, S, starts, key, sub);
-            if (!starts && qs_key == INT_MAX) r = ix.n;  // every end is <= INT_MAX
-            if (sub == 0 && threadIdx.x < 32) {
-                s_slice[(starts ? 2 : 0) + upper] = r;
-                if (starts) s_slice[4 + upper] = upper ? s_hi_key : a;
-            }
-        }
-#else
-        int keyE[1] = {qs_key == INT_MAX ? INT_MAX : qs_key + 1};
-        int keyS[1] = {upper ? s_hi_key : a};
-        int rE[1], rS[1];
-        tree_rank_lt<true, 1>(E, lds, keyE, rE, sub);
-        tree_rank_lt<true, 1>(S, lds, keyS, rS, sub);
-        if (qs_key == INT_MAX) rE[0] = ix.n;  // every end is <= INT_MAX
-        if (sub == 0 && threadIdx.x < 16) {
-            s_slice[0 + upper] = rE[0];
-            s_slice[2 + upper] = rS[0];
-            s_slice[4 + upper] = upper ? s_hi_key : a;
-        }
-#endif
-    }
-    __syncthreads();
-    const int eLo = s_slice[0], eHi = s_slice[1], sLo = s_slice[2], sHi = s_slice[3], qeLo = s_slice[4], qeHi = s_slice[5];
-    const int nE = eHi - eLo, nS = sHi - sLo;
-    const int strideE = nE / LC_TREE_KEYS + 1, strideS = nS / LC_TREE_KEYS + 1;
-    int kE = 0, kS = 0;
-    while ((1 << kE) - 1 < nE / strideE) kE++;
-    while ((1 << kS) - 1 < nS / strideS) kS++;
-    int32_t *treeE = lds, *treeS = lds + (1 << kE);
-    {
-        const int total = (1 << kE) + (1 << kS);
-        for (int i = threadIdx.x; i < total; i += LC_THREADS) lds[i] = INT_MAX;
-        __syncthreads();
-        part_stage_tree<LC_THREADS>(treeE, kE, e_sorted + eLo, nE, strideE);
-        part_stage_tree<LC_THREADS>(treeS, kS, ix.s_ord + sLo, nS, strideS);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j0 = 0; j0 < LC_ITEMS; j0 += PT_ILP) {
-        int rS[PT_ILP], rE[PT_ILP];
-#pragma unroll
-        for (int j = 0; j < PT_ILP; j++) rS[j] = rE[j] = 1;
-        for (int it = 0; it < kS; it++) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) rS[j] = 2 * rS[j] + (treeS[rS[j]] < qe[j0 + j]);
-        }
-        for (int it = 0; it < kE; it++) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) rE[j] = 2 * rE[j] + (treeE[rE[j]] <= qs[j0 + j] && qs[j0 + j] != INT_MAX);
-        }
-#pragma unroll
-        for (int j = 0; j < PT_ILP; j++) {
-            rS[j] = (rS[j] - (1 << kS)) * strideS;
-            rE[j] = (rE[j] - (1 << kE)) * strideE;
-        }
-        if (strideS > 1) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) {
-                int hi = rS[j] + strideS < nS ? rS[j] + strideS : nS;
-                rS[j] = group_rank_lt(ix.s_ord + sLo, rS[j], hi, qe[j0 + j]);
-            }
-        }
-        if (strideE > 1) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) {
-                int hi = rE[j] + strideE < nE ? rE[j] + strideE : nE;
-                rE[j] = qs[j0 + j] == INT_MAX ? 0 : group_rank_lt(e_sorted + eLo, rE[j], hi, qs[j0 + j] + 1);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PT_ILP; j++) {
-            const int k = (j0 + j) * LC_THREADS + threadIdx.x;
-            const bool live = k < n;
-            int c = 0, s_rank = 0;
-            const int s = qs[j0 + j], e = qe[j0 + j];
-            if (live) {
-                const bool in_slice = e >= qeLo && e <= qeHi;
-                s_rank = in_slice ? sLo + rS[j] : global_rank_lt(ix.s_ord, 0, ix.n, e);
-                if (s < e) {
-                    const int e_rank = s == INT_MAX ? ix.n : eLo + rE[j];
-                    c = s_rank - e_rank;
-                } else {  // zero-length / reversed query: exact predicate over the candidate window
-                    int lo = first_pm_gt(ix.pm, ix.n, s);
-                    for (int t = lo; t < s_rank; t++) c += ix.e_ord[t] > s;
-                }
-            }
-            emit(j0 + j, k, live, c, s_rank, s);
-        }
-    }
-}
-
-// (eight waves per SIMD = four workgroups per CU: the kernel lives on the chunks it keeps in flight -- said out loud, the compiler
-// took 70 registers for a build that needed 64)
-__global__ __launch_bounds__(LC_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
-                                                                     const int32_t *__restrict__ qs_arr,
-                                                                     const int32_t *__restrict__ qe_arr, int64_t nq,
-                                                                     int32_t *__restrict__ counts /* may be NULL */,
-                                                                     unsigned long long *__restrict__ total_slots,
-                                                                     const unsigned *__restrict__ gate,
-                                                                     int32_t *__restrict__ his = nullptr /* find(): #{start < qe} of every query */,
-                                                                     unsigned long long *__restrict__ order_host = nullptr, unsigned long long seq = 0,
-                                                                     unsigned long long *__restrict__ chunk_tot = nullptr /* find(): the sum of every chunk's counts */)
-{
-    __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
-    __shared__ int s_mm[3][LC_THREADS / 64];
-    __shared__ int s_slice[6];  // eLo, eHi, sLo, sHi, qeLo, qeHi
-    __shared__ long long red[LC_THREADS / 64];
-    __shared__ long long red2[LC_THREADS / 64];
-    // what the order check found, into host memory: the host picks the shape of THIS kernel for later batches by it
-    // (bm_count_segments; pass number << 1 | 1 = not sorted)
-    if (order_host && blockIdx.x == 0 && threadIdx.x == 0) *order_host = (seq << 1) | (gate && *gate != 0 ? 1ull : 0ull);
-    if (gate && *gate != 0) return;  // unsorted batch: the bucketed path answers it
-    long long acc = 0;
-    {
-        const int64_t chunk = blockIdx.x;
-        const int64_t base = chunk * LC_CHUNK;
-        const int n = (int)(nq - base < LC_CHUNK ? nq - base : LC_CHUNK);
-        long long cacc = 0;
-        lc_chunk_counts(S, E, ix, e_sorted, qs_arr, qe_arr, base, n, lds, s_mm, s_slice, [&](int, int k, bool live, int c, int s_rank, int) {
-            if (!live) return;
-            if (counts) counts[base + k] = c;
-            if (his) his[base + k] = s_rank;
-            cacc += c;
-        });
-        acc += cacc;
-        if (chunk_tot) {  // (find(): the CSR offsets are then one scan over the CHUNKS away, ivl_find_local)
-            const long long w = wave_sum_i64(cacc);
-            if (lane_id() == 0) red2[threadIdx.x >> 6] = w;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                long long t = 0;
-                for (int i = 0; i < LC_THREADS / 64; i++) t += red2[i];
-                chunk_tot[chunk] = (unsigned long long)t;
-            }
-        }
-    }
-    if (total_slots) block_accumulate_i64(acc, red, total_slots + (blockIdx.x & (PT_SLOTS - 1)));
-}
-
-// Counts come back in bucket order.  One workgroup per partition tile pulls the tile's runs
-// (one per bucket, contiguous in the bucketed array) into LDS in the tile's sorted order, then
-// every query picks its count through the 16-bit slot remembered by the scatter: all global
-// traffic is coalesced, the random access happens in LDS.
-template <typename CT /* int32_t, or unsigned short with COUNT_ESCAPE */>
-__global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void part_gather_kernel(const CT *__restrict__ bucketed,
-                                                                 const unsigned short *__restrict__ lpos,
-                                                                 const unsigned *__restrict__ tile_table /* [ntiles][PT_NB] */,
-                                                                 int64_t ntiles, int64_t nq, int32_t *__restrict__ out,
-                                                                 const unsigned *__restrict__ gate, IndexDev ix,
-                                                                 const int32_t *__restrict__ e_sorted, const int32_t *__restrict__ qs_arr,
-                                                                 const int32_t *__restrict__ qe_arr /* the four: escape path only */)
-{
-    __shared__ CT vals[PT_TILE];
-    __shared__ unsigned short toff[PT_NB + 2];
-    __shared__ unsigned gbase[PT_NB];
-    __shared__ unsigned scan_tmp[16];
-    const int64_t tile = part_tile_of_block(ntiles);
-    if (tile >= ntiles || (gate && *gate == 0)) return;
-    const int64_t base = tile * PT_TILE;
-    const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
-    {
-        // Tile counts = distance to the next entry of the (linear, bucket-major) exclusive scan: the next
-        // tile's entry for the same bucket, or -- for the last tile -- tile 0's entry of the next bucket.
-        const bool last_tile = tile + 1 == ntiles;
-        const unsigned *row = tile_table + tile * PT_NB;
-        const unsigned *next = last_tile ? tile_table : row + PT_NB;
-        unsigned c[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            int b = 2 * threadIdx.x + u;
-            unsigned lo = row[b];
-            unsigned hi = !last_tile ? next[b] : (b + 1 < PT_NB ? next[b + 1] : (unsigned)nq);
-            gbase[b] = lo;
-            c[u] = hi - lo;
-        }
-        unsigned tot;
-        unsigned exc = block_exclusive_scan(c[0] + c[1], OpSum(), 0u, scan_tmp, &tot);
-        toff[2 * threadIdx.x] = (unsigned short)exc;
-        toff[2 * threadIdx.x + 1] = (unsigned short)(exc + c[0]);
-        if (threadIdx.x == 0) toff[PT_NB] = (unsigned short)tot;  // tot == n <= 16384
-    }
-    __syncthreads();
-    // 8 lanes per bucket run (runs average 8 queries).  A lane's 16 runs are handled eight at a time with all loads
-    // of a round issued before the first LDS write: the loop "per run: load, store" is one dependent round trip per
-    // run (measured 29 us per tile, nearly all of it latency).
-    const unsigned sub = threadIdx.x & 7;
-    constexpr int RUNS = PT_NB / (PT_THREADS / 8);  // 16 runs per lane
-#pragma unroll
-    for (int round = 0; round < 2; round++) {  // elements sub and sub + 8 of all 16 runs: two round trips in all
-        const unsigned r = sub + 8u * round;
-        CT v[RUNS];
-        unsigned short at[RUNS];
-        unsigned live = 0;
-#pragma unroll
-        for (int i = 0; i < RUNS; i++) {
-            const int b = (int)(threadIdx.x >> 3) + i * (PT_THREADS / 8);
-            const unsigned o = toff[b], len = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o;
-            const bool ok = r < len;
-            live |= (unsigned)ok << i;
-            at[i] = (unsigned short)(o + r);
-            v[i] = ok ? bucketed[gbase[b] + r] : (CT)0;
-        }
-#pragma unroll
-        for (int i = 0; i < RUNS; i++)
-            if (live >> i & 1) vals[at[i]] = v[i];
-    }
-#pragma unroll 1
-    for (int i = 0; i < RUNS; i++) {  // runs longer than 16 (rare; the whole tile for a sorted batch): the whole wave copies them
-        const int b = (int)(threadIdx.x >> 3) + i * (PT_THREADS / 8);
-        const unsigned o = toff[b], len = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o, gb = gbase[b];
-        unsigned long long m = __ballot(sub == 0 && len > 16);
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const unsigned oo = __shfl(o, src, 64), ll = __shfl(len, src, 64), gg = __shfl(gb, src, 64);
-            for (unsigned q = 16 + lane_id(); q < ll; q += 64) vals[oo + q] = bucketed[gg + q];
-        }
-    }
-    __syncthreads();
-    constexpr bool ESC = sizeof(CT) == 2;
-    if (n == PT_TILE) {
-        // a lane takes 4 consecutive queries: 8-byte loads of the slots, 16-byte stores of the counts, all loads first
-        const uint2 *l4 = reinterpret_cast<const uint2 *>(lpos + base);
-        int4 *o4 = reinterpret_cast<int4 *>(out + base);
-        uint2 sl[PT_ITEMS / 4];
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS / 4; j++) sl[j] = l4[j * PT_THREADS + threadIdx.x];
-#pragma unroll
-        for (int j = 0; j < PT_ITEMS / 4; j++) {
-            int c[4] = {(int)vals[sl[j].x & 0xffffu], (int)vals[sl[j].x >> 16], (int)vals[sl[j].y & 0xffffu], (int)vals[sl[j].y >> 16]};
-            if (ESC && ((unsigned)c[0] == COUNT_ESCAPE || (unsigned)c[1] == COUNT_ESCAPE || (unsigned)c[2] == COUNT_ESCAPE ||
-                        (unsigned)c[3] == COUNT_ESCAPE)) {
-                const int64_t k0 = base + 4 * (int64_t)(j * PT_THREADS + threadIdx.x);
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if ((unsigned)c[u] == COUNT_ESCAPE) c[u] = count_one_global(ix, e_sorted, qs_arr[k0 + u], qe_arr[k0 + u]);
-            }
-            o4[j * PT_THREADS + threadIdx.x] = make_int4(c[0], c[1], c[2], c[3]);
-        }
-    } else {
-        for (int k = threadIdx.x; k < n; k += PT_THREADS) {
-            int c = (int)vals[lpos[base + k]];
-            if (ESC && (unsigned)c == COUNT_ESCAPE) c = count_one_global(ix, e_sorted, qs_arr[base + k], qe_arr[base + k]);
-            out[base + k] = c;
-        }
-    }
-}
-
-__device__ __forceinline__ int count_one_global(const IndexDev &ix, const int32_t *__restrict__ e_sorted, int qs, int qe)
-{
-    const int s_rank = global_rank_lt(ix.s_ord, 0, ix.n, qe);
-    if (qs < qe) return s_rank - global_rank_lt(e_sorted, 0, ix.n, qs + 1);  // (qs < qe rules out qs == INT_MAX)
-    const int lo = first_pm_gt(ix.pm, ix.n, qs);  // zero-length / reversed query: exact predicate over the candidate window
-    int c = 0;
-    for (int k = lo; k < s_rank; k++) c += ix.e_ord[k] > qs;
-    return c;
-}
-
-}  // namespace bxmi
+#include "count_direct.hpp"
+#include "count_parts.hpp"
 #include "count_bitmap.hpp"
 #include "count_slices.hpp"
 #include "find_exchange.hpp"
 #include "count_dense.hpp"
+#include "find_sorted.hpp"
+#include "find_direct.hpp"
+#include "cluster.hpp"
+
 namespace bxmi {
-
-// ---- partitioned find: window + count per query in bucket order, offsets carried to bucket order ----
-// For every query of [q_begin, q_end): hi = #{start < qe}, lo = #{prefix-max <= qs} and the number of hits in the
-// window [lo, hi) of the tree-ordered arrays.  Ranks come from LDS trees one lane per query; the window is then
-// scanned by 8 lanes per query with 16-byte loads (a per-lane serial scan would issue 8 scattered requests per query).
-struct WindowSlices {
-    int sLo, nS, kS, strideS;  // staged slice of the starts (tree order)
-    int pLo, nP, kP, strideP;  // staged slice of the prefix-max array
-    int qeLo, qeHi;            // rank_lt(starts, qe) may use the slice iff qeLo <= qe <= qeHi
-};
-
-template <int THREADS>
-__device__ __forceinline__ void window_stage(const IndexDev &ix, const WindowSlices &w, int32_t *lds, int32_t *&treeP, int32_t *&treeS)
-{
-    treeP = lds, treeS = lds + (1 << w.kP);
-    const int total = (1 << w.kP) + (1 << w.kS);
-    for (int i = threadIdx.x; i < total; i += THREADS) lds[i] = INT_MAX;
-    __syncthreads();
-    part_stage_tree<THREADS>(treeP, w.kP, ix.pm + w.pLo, w.nP, w.strideP);
-    part_stage_tree<THREADS>(treeS, w.kS, ix.s_ord + w.sLo, w.nS, w.strideS);
-    __syncthreads();
-}
-
-template <int THREADS, bool PAIRS /* qs_arr is an array of (qs, qe) pairs, qe_arr unused */,
-          bool PER_LANE /* neighbouring queries have neighbouring windows (sorted batch): one lane scans one window */>
-__device__ __forceinline__ void window_queries(const IndexDev &ix, const WindowSlices &w, const int32_t *treeP, const int32_t *treeS,
-                                               int64_t q_begin, int64_t q_end, const int32_t *__restrict__ qs_arr,
-                                               const int32_t *__restrict__ qe_arr, int32_t *__restrict__ win_lo,
-                                               int32_t *__restrict__ win_hi, int32_t *__restrict__ counts)
-{
-    for (int64_t i0 = q_begin + threadIdx.x; i0 - threadIdx.x < q_end; i0 += THREADS) {
-        const bool live = i0 < q_end;
-        int qs = 0, qe = 0;
-        if (PAIRS) {
-            const int2 v = live ? reinterpret_cast<const int2 *>(qs_arr)[i0] : make_int2(0, 0);
-            qs = v.x, qe = v.y;
-        } else if (live) {
-            qs = qs_arr[i0], qe = qe_arr[i0];
-        }
-        int rS = 1, rP = 1;
-        for (int it = 0; it < w.kS; it++) rS = 2 * rS + (treeS[rS] < qe);
-        for (int it = 0; it < w.kP; it++) rP = 2 * rP + (treeP[rP] <= qs && qs != INT_MAX);
-        rS = (rS - (1 << w.kS)) * w.strideS;
-        rP = (rP - (1 << w.kP)) * w.strideP;
-        if (w.strideS > 1) rS = group_rank_lt(ix.s_ord + w.sLo, rS, rS + w.strideS < w.nS ? rS + w.strideS : w.nS, qe);
-        if (w.strideP > 1 && qs != INT_MAX)
-            rP = group_rank_lt(ix.pm + w.pLo, rP, rP + w.strideP < w.nP ? rP + w.strideP : w.nP, qs + 1);
-        const bool in_slice = qe >= w.qeLo && qe <= w.qeHi;
-        int hi = in_slice ? w.sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, qe);
-        int lo = qs == INT_MAX ? ix.n : w.pLo + rP;
-        if (!live) lo = hi = 0;
-        int mine = 0;
-        if (PER_LANE) {
-            // window scan, one lane per query (see part_fill_lane_kernel); a long window is counted by the whole wave
-            const bool wide = hi - lo > LANE_WINDOW;
-            if (!wide) {
-                for (int k = lo; k < hi; k++) mine += ix.e_ord[k] > qs;
-            }
-            unsigned long long wm = __ballot(wide);
-            while (wm) {
-                const int src = __ffsll((long long)wm) - 1;
-                wm &= wm - 1;
-                const int L = __shfl(lo, src, 64), H = __shfl(hi, src, 64), S = __shfl(qs, src, 64);
-                int c = 0;
-                for (int k = L + lane_id(); k < H; k += 64) c += ix.e_ord[k] > S;
-    #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-                if (lane_id() == src) mine = c;
-            }
-        } else {
-            const int sub = threadIdx.x & 7, gbase = lane_id() & ~7;
-            // cooperative window scan: the 8 lanes of a group take their 8 queries one after the other; the first
-            // 32-candidate step of all 8 windows is loaded up front (one dependent round trip instead of eight)
-            int wl[8], wh[8], wk[8];
-            int4 v[8];
-    #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                wl[r] = __shfl(lo, gbase + r, 64);
-                wh[r] = __shfl(hi, gbase + r, 64);
-                wk[r] = __shfl(qs, gbase + r, 64);
-                v[r] = wl[r] < wh[r] ? *reinterpret_cast<const int4 *>(ix.e_ord + (wl[r] & ~(FAN - 1)) + sub * 4) : make_int4(0, 0, 0, 0);
-            }
-    #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                int c = 0;
-                if (wl[r] < wh[r]) {
-                    const int k0 = wl[r] & ~(FAN - 1), kb = k0 + sub * 4;
-                    c += (kb + 0 >= wl[r] && kb + 0 < wh[r] && v[r].x > wk[r]);
-                    c += (kb + 1 >= wl[r] && kb + 1 < wh[r] && v[r].y > wk[r]);
-                    c += (kb + 2 >= wl[r] && kb + 2 < wh[r] && v[r].z > wk[r]);
-                    c += (kb + 3 >= wl[r] && kb + 3 < wh[r] && v[r].w > wk[r]);
-                    c = group8_sum_dpp(c);
-                    if (k0 + FAN < wh[r]) c += window_count<true>(ix.e_ord, k0 + FAN, wh[r], wk[r], sub);  // long window: the rest
-                }
-                if (sub == r) mine = c;
-            }
-        }
-        if (live) {
-            win_lo[i0] = lo;
-            win_hi[i0] = hi;
-            counts[i0] = mine;
-        }
-    }
-}
-
-__global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, const SliceBound *__restrict__ bounds,
-                                                                 const int32_t *__restrict__ wg_first,
-                                                                 const unsigned *__restrict__ table,
-                                                                 const int2 *__restrict__ pairs /* (qs, qe), bucket order */, int64_t nq,
-                                                                 int32_t *__restrict__ win_lo, int32_t *__restrict__ win_hi,
-                                                                 int32_t *__restrict__ counts)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    __shared__ int s_bucket;
-    int b;
-    int64_t q_begin, q_end;
-    if (!part_chunk_of_block(wg_first, table, nq, &s_bucket, b, q_begin, q_end)) return;
-    const SliceBound sb = bounds[b];
-    const WindowSlices w = {sb.sLo, sb.sHi - sb.sLo, sb.kS, sb.strideS, sb.pLo, sb.pHi - sb.pLo, sb.kP, sb.strideP, sb.qeLo, sb.qeHi};
-    int32_t *treeP, *treeS;
-    window_stage<PT_THREADS>(ix, w, lds, treeP, treeS);
-    window_queries<PT_THREADS, true, false>(ix, w, treeP, treeS, q_begin, q_end, reinterpret_cast<const int32_t *>(pairs), nullptr, win_lo, win_hi, counts);
-}
-
-// Are the starts non-decreasing?  (find path: decided on the host before anything else is launched)
-__global__ void ivl_sorted_check_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ unsorted)
-{
-    bool descent = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < nq; i += (int64_t)gridDim.x * blockDim.x)
-        descent |= qs[i] > qs[i + 1];
-    if (__ballot(descent) && lane_id() == 0 && *unsorted == 0) *unsorted = 1;
-}
-
-// Values in query order -> bucket order (the inverse of part_gather_kernel): a workgroup drops its tile's
-// values into LDS at the slots the scatter recorded, then streams the tile's runs out, one per bucket.
-__global__ __launch_bounds__(PT_THREADS) void part_permute_i64_kernel(const long long *__restrict__ values,
-                                                                      const unsigned short *__restrict__ lpos,
-                                                                      const unsigned *__restrict__ tile_table, int64_t ntiles,
-                                                                      int64_t nq, long long *__restrict__ bucketed)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
-    long long *vals = reinterpret_cast<long long *>(dyn);                           // [PT_TILE]
-    unsigned short *toff = reinterpret_cast<unsigned short *>(vals + PT_TILE);      // [PT_NB + 2]
-    unsigned *gbase = reinterpret_cast<unsigned *>(toff + PT_NB + 2);               // [PT_NB]
-    __shared__ unsigned scan_tmp[16];
-    const int64_t tile = part_tile_of_block(ntiles);
-    if (tile >= ntiles) return;
-    const int64_t base = tile * PT_TILE;
-    const int n = (int)(nq - base < PT_TILE ? nq - base : PT_TILE);
-    {
-        const bool last_tile = tile + 1 == ntiles;
-        const unsigned *row = tile_table + tile * PT_NB;
-        const unsigned *next = last_tile ? tile_table : row + PT_NB;
-        unsigned c[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            int b = 2 * threadIdx.x + u;
-            unsigned lo = row[b];
-            unsigned hi = !last_tile ? next[b] : (b + 1 < PT_NB ? next[b + 1] : (unsigned)nq);
-            gbase[b] = lo;
-            c[u] = hi - lo;
-        }
-        unsigned tot;
-        unsigned exc = block_exclusive_scan(c[0] + c[1], OpSum(), 0u, scan_tmp, &tot);
-        toff[2 * threadIdx.x] = (unsigned short)exc;
-        toff[2 * threadIdx.x + 1] = (unsigned short)(exc + c[0]);
-    }
-    for (int k = threadIdx.x; k < n; k += PT_THREADS) vals[lpos[base + k]] = values[base + k];
-    __syncthreads();
-    const int sub = threadIdx.x & 7;
-    for (int b = threadIdx.x >> 3; b < PT_NB; b += PT_THREADS / 8) {
-        unsigned o = toff[b], len = (b + 1 < PT_NB ? toff[b + 1] : (unsigned)n) - o, gb = gbase[b];
-        for (unsigned r = sub; r < len; r += 8) bucketed[gb + r] = vals[o + r];
-    }
-}
-
-// One 32-candidate step of a window: compact the hits of this step behind `base` (CSR order = tree order).
-__device__ __forceinline__ int fill_step(int4 v, int4 id, int kb, int lo, int hi, int qs, int64_t base, int32_t *__restrict__ hits,
-                                         int gshift, unsigned below)
-{
-    bool f0 = kb + 0 >= lo && kb + 0 < hi && v.x > qs;
-    bool f1 = kb + 1 >= lo && kb + 1 < hi && v.y > qs;
-    bool f2 = kb + 2 >= lo && kb + 2 < hi && v.z > qs;
-    bool f3 = kb + 3 >= lo && kb + 3 < hi && v.w > qs;
-    unsigned b0 = (unsigned)(__ballot(f0) >> gshift) & 0xffu;
-    unsigned b1 = (unsigned)(__ballot(f1) >> gshift) & 0xffu;
-    unsigned b2 = (unsigned)(__ballot(f2) >> gshift) & 0xffu;
-    unsigned b3 = (unsigned)(__ballot(f3) >> gshift) & 0xffu;
-    if (f0 | f1 | f2 | f3) {
-        int64_t pos = base + __popc(b0 & below) + __popc(b1 & below) + __popc(b2 & below) + __popc(b3 & below);
-        if (f0) hits[pos++] = id.x;
-        if (f1) hits[pos++] = id.y;
-        if (f2) hits[pos++] = id.z;
-        if (f3) hits[pos++] = id.w;
-    }
-    return __popc(b0) + __popc(b1) + __popc(b2) + __popc(b3);
-}
-
-// Fill pass in bucket order: the window reads stay inside the bucket's lines (L2) instead of touching two random
-// lines per query, and each 8-lane group keeps FILL_Q queries in flight (metadata and the first step of every
-// window are loaded before any of them is compacted: the chain load-meta -> load-window -> store is latency bound).
-constexpr int FILL_Q = 4;
-__global__ __launch_bounds__(FIND_THREADS) void part_fill_kernel(IndexDev ix, const int32_t *__restrict__ qs_arr, int qs_stride /* 2: (qs, qe) pairs */,
-                                                                int64_t nq,
-                                                                const int32_t *__restrict__ win_lo,
-                                                                const int32_t *__restrict__ win_hi,
-                                                                const int32_t *__restrict__ cnt,
-                                                                const long long *__restrict__ boffs,
-                                                                int32_t *__restrict__ hits)
-{
-    const int lane = lane_id();
-    const int sub = lane & 7, gshift = lane & ~7;
-    const unsigned below = (1u << sub) - 1u;
-    // contiguous block of queries per workgroup, XCD-aware: neighbours in bucket order share lines
-    const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
-    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
-    const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
-    for (int64_t qb = q0 + (int64_t)(threadIdx.x >> 3) * FILL_Q; qb < q1; qb += (FIND_THREADS / 8) * FILL_Q) {
-        int lo[FILL_Q], hi[FILL_Q], qs[FILL_Q];
-        int64_t base[FILL_Q];
-#pragma unroll
-        for (int j = 0; j < FILL_Q; j++) {
-            const int64_t q = qb + j;
-            const bool live = q < q1 && cnt[q] != 0;
-            lo[j] = live ? win_lo[q] : 0;
-            hi[j] = live ? win_hi[q] : 0;
-            qs[j] = live ? qs_arr[q * qs_stride] : 0;
-            base[j] = live ? boffs[q] : 0;
-        }
-        int4 ve[FILL_Q], vi[FILL_Q];
-#pragma unroll
-        for (int j = 0; j < FILL_Q; j++) {
-            const int kb = (lo[j] & ~(FAN - 1)) + sub * 4;
-            if (lo[j] < hi[j]) {
-                ve[j] = *reinterpret_cast<const int4 *>(ix.e_ord + kb);
-                vi[j] = *reinterpret_cast<const int4 *>(ix.idx + kb);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < FILL_Q; j++) {
-            if (lo[j] >= hi[j]) continue;
-            int k0 = lo[j] & ~(FAN - 1);
-            base[j] += fill_step(ve[j], vi[j], k0 + sub * 4, lo[j], hi[j], qs[j], base[j], hits, gshift, below);
-            for (k0 += FAN; k0 < hi[j]; k0 += FAN) {
-                const int kb = k0 + sub * 4;
-                int4 v = *reinterpret_cast<const int4 *>(ix.e_ord + kb);
-                int4 id = *reinterpret_cast<const int4 *>(ix.idx + kb);
-                base[j] += fill_step(v, id, kb, lo[j], hi[j], qs[j], base[j], hits, gshift, below);
-            }
-        }
-    }
-}
-
-// The same walk with both of its memory sides made FLAT (round 4).  The kernel above reads the pairs and writes the hits one
-// lane at a time: a wave's 64 queries own one contiguous stretch of the CSR list (~320 hits) and one contiguous window of the
-// pairs (~100), but every store instruction scatters 64 4-byte pieces over the stretch's ten lines and every load is a lane's own
-// dependent step.  Here a wave first copies the window [wbase, kmax) of the pairs into LDS (coalesced 512-byte loads), the
-// lanes walk down inside LDS and drop their hits into an LDS image of the wave's stretch, and the stretch goes out as whole
-// 256-byte stores, lane i taking positions i, i + 64, ...  A batch whose stretch is longer than FF_HITS (queries on a pile) or
-// whose lanes leave the staged window keeps the direct loads / stores for those accesses: exact either way.
-// (measured on configs[4] sorted by start, find() end to end: the kernel above 2.42 ms; FF_HITS / FF_PAIRS = 1024 / 256: 1.81 ms,
-// 768 / 256: 1.71, 512 / 128: 1.64 -- less LDS per wave, more workgroups per CU)
-constexpr int FF_HITS = 512;    // hits of a wave's 64 queries staged in LDS (mean 320 on configs[4])
-constexpr int FF_PAIRS = 128;   // pairs below the wave's highest `hi` staged in LDS
-
-// The pairs a wave's 64 queries will walk: [wbase, kmax) = the FF_PAIRS ranks below the highest `hi` of the wave, requested into
-// registers ahead of time -- all at once (round 4 issued them one after the other behind a branch each: two dependent round trips
-// to HBM per batch, after two more for the queries' numbers; the kernel's time was those four latencies), and by the callers one
-// batch EARLY, while the batch before is being walked.
-struct FfStage {
-    int2 pv[FF_PAIRS / 64];
-    int wbase, kmax;
-};
-__device__ __forceinline__ void ff_load(const int2 *__restrict__ eid /* at index 0 */, int c, int hi, FfStage &S)
-{
-    const int lane = lane_id();
-    S.kmax = wave_max_i32(c ? hi : 0);
-    S.wbase = S.kmax > FF_PAIRS ? S.kmax - FF_PAIRS : 0;
-    const int last = S.kmax > 0 ? S.kmax - 1 : 0;
-#pragma unroll
-    for (int j = 0; j < FF_PAIRS / 64; j++) {
-        const int kk = S.wbase + 64 * j + lane;
-        S.pv[j] = eid[kk < S.kmax ? kk : last];  // (a valid address: no branch around the loads)
-    }
-}
-
-// One wave, 64 consecutive queries (a lane each: `c` hits to find below rank `hi`, its CSR offset `off`): see the kernel below.
-// wp / wh: the wave's LDS images of the pairs and of its stretch of the list; S: what ff_load brought for these queries.
-__device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *__restrict__ eid /* at index 0 */, const FfStage &S, int c, const int hi,
-                                             const int qs, const long long off, int32_t *__restrict__ hits)
-{
-    const int lane = lane_id();
-    int k = hi - 1;
-    // the wave's stretch of the list: from its first query's offset, as long as the sum of its counts
-    const long long base_off = __shfl(off, 0, 64);
-    long long total64 = c;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) total64 += __shfl_xor(total64, d, 64);
-    if (total64 == 0) return;  // (wave-uniform)
-    const bool flat = total64 <= FF_HITS;
-    const int total = flat ? (int)total64 : 0;
-    const int rel = flat ? (int)(off - base_off) : 0;
-    int32_t *__restrict__ dst = hits + off;
-    // the window of the pairs: FF_PAIRS below the highest hi of the wave
-    const int kmax = S.kmax, wbase = S.wbase;
-#pragma unroll
-    for (int j = 0; j < FF_PAIRS / 64; j++) {
-        const int kk = wbase + 64 * j + lane;
-        if (kk < kmax) wp[64 * j + lane] = S.pv[j];
-    }
-    // (lanes read what OTHER lanes staged: wave-level release + barrier, not just in-order DS issue)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    auto pair_at = [&](int kk) -> int2 { return kk >= wbase ? wp[kk - wbase] : eid[kk]; };
-    auto take = [&](const int2 p) {
-        if (p.x > qs) {
-            --c;
-            if (flat)
-                wh[rel + c] = p.y;
-            else
-                dst[c] = p.y;
-        }
-    };
-    for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
-        // (two self-contained arms: where an LDS read and an HBM load meet in one value the compiler waits for ALL outstanding
-        // memory operations at every step -- the next batch's numbers and pairs included)
-        if (__all(k >= wbase))
-            take(wp[k - wbase]);
-        else
-            take(pair_at(k));
-    }
-    unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
-    while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        int C = __shfl(c, src, 64), K = __shfl(k, src, 64);
-        const int S = __shfl(qs, src, 64);
-        const int R = __shfl(rel, src, 64);
-        int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
-        while (C > 0 && K >= 0) {
-            const int kk = K - lane;
-            int2 p = make_int2(INT_MIN, 0);
-            if (kk >= 0) p = pair_at(kk);
-            const bool f = kk >= 0 && p.x > S;
-            const unsigned long long fm = __ballot(f);
-            // hits at higher indices come later in the list: lane 0 (the highest index of the step) takes the last free slot
-            const int before = __popcll(fm & ((1ull << lane) - 1ull));
-            if (f && before < C) {
-                if (flat)
-                    wh[R + C - 1 - before] = p.y;
-                else
-                    D[C - 1 - before] = p.y;
-            }
-            C -= __popcll(fm);
-            K -= 64;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < total; i += 64) hits[base_off + i] = wh[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next batch overwrites both images)
-    __builtin_amdgcn_wave_barrier();
-}
-
-__global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2 *__restrict__ eid /* at index 0 */, const int32_t *__restrict__ qs_arr,
-                                                                     int64_t nq, const int32_t *__restrict__ his, const int32_t *__restrict__ cnt,
-                                                                     const long long *__restrict__ offs, int32_t *__restrict__ hits)
-{
-    __shared__ int2 s_pairs[FIND_THREADS / 64][FF_PAIRS];
-    __shared__ int32_t s_hits[FIND_THREADS / 64][FF_HITS];
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    const int64_t per_xcd = ((int64_t)gridDim.x + 7) >> 3;
-    const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
-    const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
-    struct Q {
-        int c, hi, qs;
-        long long off;
-    };
-    auto load_q = [&](int64_t qb, Q &x) {  // (independent loads: one round trip)
-        const int64_t q = qb + lane;
-        const bool live = q < q1;
-        const int64_t qa = live ? q : q1 - 1;  // (a dead lane: valid addresses, no hits; its offset is the one behind the stretch's last query)
-        x.c = cnt[qa], x.hi = his[qa], x.qs = qs_arr[qa], x.off = offs[qa];
-        if (!live) x.c = 0;
-    };
-    if (q0 + 64 * wave >= q1) return;
-    Q cur;
-    load_q(q0 + 64 * wave, cur);
-    for (int64_t qb = q0 + 64 * wave; qb < q1; qb += FIND_THREADS) {  // (waves are on their own: no workgroup barrier in here)
-        FfStage S;
-        ff_load(eid, cur.c, cur.hi, S);
-        Q nxt = cur;
-        if (qb + FIND_THREADS < q1) load_q(qb + FIND_THREADS, nxt);  // the next batch's numbers travel while this one is walked
-        ff_wave_fill(s_pairs[wave], s_hits[wave], eid, S, cur.c, cur.hi, cur.qs, cur.off, hits);
-        cur = nxt;
-    }
-}
-
-// CSR offsets of a sorted find(): offsets[q] = chunk_base[chunk of q] + the exclusive prefix of the chunk's counts -- one read of
-// the counts, one write of the offsets (the three-kernel scan read the counts twice and took 0.25 ms per 50 M).
-// (Tried on top, round 5: the fill making the offsets itself -- a workgroup per run of chunks, a block scan per batch of 512 queries,
-// no offsets kernel and no 8 bytes per query read back: 1.75 ms against 1.53 with this kernel + part_fill_flat_kernel, whose waves
-// run free of barriers; forced to 8 waves per SIMD it spilled and took 1.86.  Not kept.)
-__global__ __launch_bounds__(LC_THREADS) void lf_offsets_kernel(const int32_t *__restrict__ cnt, const long long *__restrict__ chunk_base, int64_t nq,
-                                                                long long *__restrict__ offsets)
-{
-    __shared__ long long lds[16];
-    const int64_t base = (int64_t)blockIdx.x * LC_CHUNK + (int64_t)threadIdx.x * LC_ITEMS;
-    int c[LC_ITEMS];
-    if (base + LC_ITEMS <= nq) {
-        const int4 a = *reinterpret_cast<const int4 *>(cnt + base), b = *reinterpret_cast<const int4 *>(cnt + base + 4);
-        c[0] = a.x, c[1] = a.y, c[2] = a.z, c[3] = a.w, c[4] = b.x, c[5] = b.y, c[6] = b.z, c[7] = b.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < LC_ITEMS; j++) c[j] = base + j < nq ? cnt[base + j] : 0;
-    }
-    long long run = 0;
-#pragma unroll
-    for (int j = 0; j < LC_ITEMS; j++) run += c[j];
-    long long total;
-    long long off = chunk_base[blockIdx.x] + block_exclusive_scan(run, OpSum(), 0ll, lds, &total);
-    static_assert(LC_ITEMS == 8, "eight consecutive counts per thread");
-    if (base + LC_ITEMS <= nq) {
-        long long o[LC_ITEMS];
-#pragma unroll
-        for (int j = 0; j < LC_ITEMS; j++) {
-            o[j] = off;
-            off += c[j];
-        }
-#pragma unroll
-        for (int j = 0; j < LC_ITEMS; j += 2)
-            *reinterpret_cast<longlong2 *>(offsets + base + j) = make_longlong2(o[j], o[j + 1]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < LC_ITEMS; j++) {
-            if (base + j < nq) offsets[base + j] = off;
-            off += c[j];
-        }
-    }
-}
-
-// (Round 5's fused variant -- count, CSR offsets by decoupled look-back and fill in ONE kernel -- measured 2.65 ms against 1.45 for the
-// stages: the count half is a chain of dependent loads that lives on four workgroups per CU, the fused kernel's registers left two.
-// Removed in round 6; HISTORY.md has its design.)
-__global__ void part_fold_total_kernel(unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
-{
-    unsigned long long v = threadIdx.x < PT_SLOTS ? slots[threadIdx.x] : 0ull;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (threadIdx.x == 0 && v) atomicAdd(total, v);
-}
-
-// Slice bounds of every bucket; depends only on the sealed index, so it is built once at seal().
-__global__ void part_bounds_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted,
-                                   const int32_t *__restrict__ pm, int n, PartGeom g, SliceBound *__restrict__ out)
-{
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= PT_NB) return;
-    const long long W = 1ll << g.shift;
-    const long long lo = b == 0 ? (long long)INT_MIN - 1 : (long long)g.cmin + (long long)b * W;          // qs >= lo
-    const long long hi = b == PT_NB - 1 ? (long long)INT_MAX + 1 : (long long)g.cmin + (long long)(b + 1) * W;  // qs < hi
-    auto rank_lt64 = [n](const int32_t *a, long long x) {
-        int l = 0, h = n;
-        while (l < h) {
-            int mid = (int)(((unsigned)l + (unsigned)h) >> 1);
-            if ((long long)a[mid] < x)
-                l = mid + 1;
-            else
-                h = mid;
-        }
-        return l;
-    };
-    SliceBound sb;
-    // ends: keys qs+1 lie in [lo+1, hi]
-    sb.eLo = rank_lt64(e_sorted, lo + 1);
-    sb.eHi = rank_lt64(e_sorted, hi + 1);
-    // Each slice becomes a perfect tree of at most 2^13 - 1 keys (two trees = 64 KiB of LDS, two workgroups per
-    // CU); a longer slice is sampled with the smallest stride that fits.
-    const int nE = sb.eHi - sb.eLo;
-    sb.sLo = rank_lt64(s_ord, lo);
-    long long x = hi + (W >> 3) + 1;  // starts: keys qe of ordinary queries lie in [lo, hi + W/8]
-    sb.sHi = rank_lt64(s_ord, x);
-    const int nS = sb.sHi - sb.sLo;
-    constexpr int TREE_KEYS = (1 << 13) - 1;
-    sb.strideE = nE / TREE_KEYS + 1;
-    sb.strideS = nS / TREE_KEYS + 1;
-    int kE = 0, kS = 0;
-    while ((1 << kE) - 1 < nE / sb.strideE) kE++;
-    while ((1 << kS) - 1 < nS / sb.strideS) kS++;
-    sb.kE = kE;
-    sb.kS = kS;
-    // prefix max of ends in tree order (monotone): #{pm <= qs} for qs in [lo, hi) lies in [#{pm < lo}, #{pm < hi}]
-    sb.pLo = rank_lt64(pm, lo);
-    sb.pHi = rank_lt64(pm, hi);
-    const int nP = sb.pHi - sb.pLo;
-    sb.strideP = nP / TREE_KEYS + 1;
-    int kP = 0;
-    while ((1 << kP) - 1 < nP / sb.strideP) kP++;
-    sb.kP = kP;
-    sb.qeLo = lo < INT_MIN ? INT_MIN : (int32_t)lo;
-    sb.qeHi = x > INT_MAX ? INT_MAX : (int32_t)x;
-    out[b] = sb;
-}
-
-// ---------------------------------------------------------------------------
-// find kernels: window + count, then ballot-compacted fill
-// ---------------------------------------------------------------------------
-
-template <bool DPP>
-__global__ __launch_bounds__(FIND_THREADS) void ivl_find_count_kernel(TreeDev S, TreeDev P, IndexDev ix,
-                                                                     const int32_t *__restrict__ qs_arr,
-                                                                     const int32_t *__restrict__ qe_arr, int64_t nq,
-                                                                     int32_t *__restrict__ win_lo,
-                                                                     int32_t *__restrict__ win_hi,
-                                                                     int32_t *__restrict__ counts)
-{
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    int32_t *ldsS = lds, *ldsP = lds + S.lds_ints;
-    stage_tree(S, ldsS);
-    stage_tree(P, ldsP);
-    __syncthreads();
-    const int sub = threadIdx.x & 7;
-    const int64_t group = (int64_t)blockIdx.x * (FIND_THREADS / 8) + (threadIdx.x >> 3);
-    const int64_t ngroups = (int64_t)gridDim.x * (FIND_THREADS / 8);
-    for (int64_t q0 = group * FIND_Q; q0 < nq; q0 += ngroups * FIND_Q) {
-        int qs[FIND_Q], qe[FIND_Q], kP[FIND_Q], hi[FIND_Q], lo[FIND_Q];
-#pragma unroll
-        for (int j = 0; j < FIND_Q; j++) {
-            bool ok = q0 + j < nq;
-            qs[j] = ok ? qs_arr[q0 + j] : 0;
-            qe[j] = ok ? qe_arr[q0 + j] : 0;
-            kP[j] = qs[j] == INT_MAX ? INT_MAX : qs[j] + 1;
-        }
-        tree_rank_lt<DPP, FIND_Q>(S, ldsS, qe, hi, sub);  // #{start < qe}
-        tree_rank_lt<DPP, FIND_Q>(P, ldsP, kP, lo, sub);  // #{pm <= qs} = first k with pm[k] > qs
-#pragma unroll
-        for (int j = 0; j < FIND_Q; j++) {
-            if (qs[j] == INT_MAX) lo[j] = ix.n;
-            int c = lo[j] < hi[j] ? window_count<DPP>(ix.e_ord, lo[j], hi[j], qs[j], sub) : 0;
-            if (sub == 0 && q0 + j < nq) {
-                win_lo[q0 + j] = lo[j];
-                win_hi[q0 + j] = hi[j];
-                counts[q0 + j] = c;
-            }
-        }
-    }
-}
-
-// One 8-lane group per query; every 32-element step is compacted with four
-// wave ballots: the byte of this group in ballot j tells which of its lanes
-// hit in slot j, so a lane's output position is a handful of popcounts.
-__global__ __launch_bounds__(FIND_THREADS) void ivl_find_fill_kernel(IndexDev ix, const int32_t *__restrict__ qs_arr,
-                                                                    int64_t nq, const int32_t *__restrict__ win_lo,
-                                                                    const int32_t *__restrict__ win_hi,
-                                                                    const int64_t *__restrict__ offsets,
-                                                                    int32_t *__restrict__ hits)
-{
-    const int lane = lane_id();
-    const int sub = lane & 7, gshift = lane & ~7;
-    const unsigned below = (1u << sub) - 1u;
-    const int64_t group = (int64_t)blockIdx.x * (FIND_THREADS / 8) + (threadIdx.x >> 3);
-    const int64_t ngroups = (int64_t)gridDim.x * (FIND_THREADS / 8);
-    for (int64_t q = group; q < nq; q += ngroups) {
-        int lo = win_lo[q], hi = win_hi[q], qs = qs_arr[q];
-        int64_t base = offsets[q];
-        if (offsets[q + 1] == base) continue;
-        for (int k0 = lo & ~(FAN - 1); k0 < hi; k0 += FAN) {
-            int kb = k0 + sub * 4;
-            int4 v = *reinterpret_cast<const int4 *>(ix.e_ord + kb);
-            bool f0 = kb + 0 >= lo && kb + 0 < hi && v.x > qs;
-            bool f1 = kb + 1 >= lo && kb + 1 < hi && v.y > qs;
-            bool f2 = kb + 2 >= lo && kb + 2 < hi && v.z > qs;
-            bool f3 = kb + 3 >= lo && kb + 3 < hi && v.w > qs;
-            unsigned b0 = (unsigned)(__ballot(f0) >> gshift) & 0xffu;
-            unsigned b1 = (unsigned)(__ballot(f1) >> gshift) & 0xffu;
-            unsigned b2 = (unsigned)(__ballot(f2) >> gshift) & 0xffu;
-            unsigned b3 = (unsigned)(__ballot(f3) >> gshift) & 0xffu;
-            int step = __popc(b0) + __popc(b1) + __popc(b2) + __popc(b3);
-            if (f0 | f1 | f2 | f3) {
-                int64_t pos = base + __popc(b0 & below) + __popc(b1 & below) + __popc(b2 & below) + __popc(b3 & below);
-                int4 id = *reinterpret_cast<const int4 *>(ix.idx + kb);
-                if (f0) hits[pos++] = id.x;
-                if (f1) hits[pos++] = id.y;
-                if (f2) hits[pos++] = id.z;
-                if (f3) hits[pos++] = id.w;
-            }
-            base += step;
-        }
-    }
-}
-
-
-// ---- one query, one launch: the latency path behind the per-call find() of the drop-in classes ----
-// A single workgroup: 8 lanes walk the two search trees (all levels from L2), then the whole workgroup scans the
-// window and compacts the hits with wave ballots straight into host-visible memory: launch + one stream sync.
-constexpr int ONE_THREADS = 256;
-__global__ __launch_bounds__(ONE_THREADS) void ivl_find_one_kernel(TreeDev S, TreeDev P, IndexDev ix, int qs, int qe,
-                                                                  int32_t *__restrict__ out /* [0] = n (64-bit), hits from [2] */,
-                                                                  int cap, unsigned long long seq)
-{
-    __shared__ int s_lo, s_hi;
-    __shared__ int wave_tot[ONE_THREADS / 64];
-    if (threadIdx.x < 8) {
-        int key_s[1] = {qe}, key_p[1] = {qs == INT_MAX ? INT_MAX : qs + 1}, r_s[1], r_p[1];
-        tree_rank_lt<true, 1>(S, nullptr, key_s, r_s, (int)threadIdx.x);
-        tree_rank_lt<true, 1>(P, nullptr, key_p, r_p, (int)threadIdx.x);
-        if (threadIdx.x == 0) {
-            s_hi = r_s[0];
-            s_lo = qs == INT_MAX ? ix.n : r_p[0];
-        }
-    }
-    __syncthreads();
-    const int lo = s_lo, hi = s_hi;
-    long long run = 0;
-    for (int b = lo; b < hi; b += ONE_THREADS) {
-        const int k = b + (int)threadIdx.x;
-        const bool f = k < hi && ix.e_ord[k] > qs;
-        const unsigned long long m = __ballot(f);
-        const int w = threadIdx.x >> 6;
-        if (lane_id() == 0) wave_tot[w] = __popcll(m);
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int i = 0; i < ONE_THREADS / 64; i++) {
-            if (i < w) woff += wave_tot[i];
-            tot += wave_tot[i];
-        }
-        const long long pos = run + woff + __popcll(m & lanemask_lt());
-        if (f && pos < cap) out[2 + pos] = ix.idx[k];
-        run += tot;
-        __syncthreads();
-    }
-    // Every wave's hits must have LEFT the GPU before the completion word goes out: the barrier orders the waves, but a
-    // workgroup-scope barrier does not wait for the other waves' stores to host memory, and thread 0's release only
-    // covers its own wave's (seen as a rare wrong hit list in a per-line script).  So each wave drains its stores first.
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *reinterpret_cast<long long *>(out) = run;
-        publish_to_host(reinterpret_cast<unsigned long long *>(out + 2 + cap), seq);
-    }
-}
-
-// before()/after() candidate filter over a window of the in-order arrays
-// (single query, one workgroup): keeps k in [lo,hi) with vlo <= val[k] < vhi.
-__global__ __launch_bounds__(256) void ivl_filter_window_kernel(const int32_t *__restrict__ val,
-                                                               const int32_t *__restrict__ idx, int lo, int hi,
-                                                               long long vlo, long long vhi, int reverse,
-                                                               int32_t *__restrict__ out, int64_t cap,
-                                                               unsigned long long *__restrict__ n_out)
-{
-    __shared__ int wave_tot[4];
-    __shared__ long long run;
-    if (threadIdx.x == 0) run = 0;
-    __syncthreads();
-    int span = hi - lo;
-    for (int b = 0; b < span; b += 256) {
-        int t = b + threadIdx.x;
-        int k = reverse ? hi - 1 - t : lo + t;
-        bool ok = t < span;
-        bool f = false;
-        if (ok) {
-            long long v = val[k];
-            f = v >= vlo && v < vhi;
-        }
-        unsigned long long m = __ballot(f);
-        int w = threadIdx.x >> 6;
-        if (lane_id() == 0) wave_tot[w] = __popcll(m);
-        __syncthreads();
-        int woff = 0, tot = 0;
-        for (int i = 0; i < 4; i++) {
-            if (i < w) woff += wave_tot[i];
-            tot += wave_tot[i];
-        }
-        long long pos = run + woff + __popcll(m & lanemask_lt());
-        if (f && pos < cap) out[pos] = idx[k];
-        __syncthreads();
-        if (threadIdx.x == 0) run += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *n_out = (unsigned long long)run;
-}
-
-// ---------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------
-struct Tree {
-    DevBuf upper;  // levels 1.. (level 0 is the caller's padded sorted array)
-    TreeDev dev{};
-    int build(const int32_t *leaves, int64_t n, hipStream_t st)
-    {
-        dev = TreeDev{};
-        int64_t nodes[MAXLEV];
-        nodes[0] = n > 0 ? div_up(n, FAN) : 1;
-        int nlev = 1;
-        while (nodes[nlev - 1] > 1) {
-            nodes[nlev] = div_up(nodes[nlev - 1], FAN);
-            nlev++;
-        }
-        int64_t upper_ints = 0;
-        for (int l = 1; l < nlev; l++) upper_ints += nodes[l] * FAN;
-        BXMI_TRY(upper.reserve((size_t)(upper_ints + 4) * sizeof(int32_t)));
-        int32_t *p = upper.as<int32_t>();
-        dev.lev[0] = leaves;
-        dev.lev_ints[0] = (int32_t)(nodes[0] * FAN);
-        for (int l = 1; l < nlev; l++) {
-            int64_t ints = nodes[l] * FAN;
-            hipLaunchKernelGGL(ivl_tree_level_kernel, dim3(stream_grid(ints, 256)), dim3(256), 0, st, dev.lev[l - 1], nodes[l - 1],
-                               p, ints);
-            dev.lev[l] = p;
-            dev.lev_ints[l] = (int32_t)ints;
-            p += ints;
-        }
-        BXMI_LAUNCH_CHECK();
-        dev.nlev = nlev;
-        set_lds_budget(LDS_TREE_INTS);
-        return BXMI_OK;
-    }
-    // Stage as many top levels as fit in `budget` ints.
-    void set_lds_budget(int64_t budget)
-    {
-        int64_t used = 0;
-        int from = dev.nlev;
-        for (int l = dev.nlev - 1; l >= 0; --l) {
-            if (used + dev.lev_ints[l] > budget) break;
-            dev.lds_off[l] = (int32_t)used;
-            used += dev.lev_ints[l];
-            from = l;
-        }
-        dev.lds_from = from;
-        dev.lds_ints = (int32_t)used;
-    }
-};
-
-// ---------------------------------------------------------------------------
-// distance clustering (ClusterTree)
-// ---------------------------------------------------------------------------
-// The reference keeps a treap of clusters and merges on insert (src/cluster.c:226-260, fix-ups :112-147); for
-// max_dist >= 0 the outcome does not depend on the insertion order: walking the intervals by start, a new cluster
-// begins exactly where  start - max_dist > (largest end so far)  -- verified against the reference's extension on
-// 20 000 random trees.  The sealed index already holds the starts in order and the prefix maximum of the ends, so a
-// cluster boundary is one comparison per interval.
-// (*empty = 1 when some interval has end <= start: what decides whether max_dist = -1 has an answer, see bxmi_ivl_clusters)
-__global__ void cluster_flag_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_ord, const int32_t *__restrict__ pm, int n,
-                                    int max_dist, int32_t *__restrict__ flag, int32_t *__restrict__ empty)
-{
-    bool mine = false;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        flag[i] = i == 0 || (long long)s_ord[i] - (long long)max_dist > (long long)pm[i - 1];
-        mine |= e_ord[i] <= s_ord[i];
-    }
-    if (__any(mine) && lane_id() == 0) *empty = 1;  // (ordinary stores of one value: visible at the kernel's end)
-}
-
-// cluster id of every interval (inclusive scan of the flags, minus one) -> sort key (cluster, id), and the first position
-// and start coordinate of each cluster
-__global__ void cluster_keys_kernel(const int32_t *__restrict__ cid_incl, const int32_t *__restrict__ flag,
-                                    const int32_t *__restrict__ s_ord, const int32_t *__restrict__ idx,
-                                    const int32_t *__restrict__ ids /* per insertion index, may be NULL */, int n,
-                                    unsigned long long *__restrict__ keys, int32_t *__restrict__ c_start,
-                                    long long *__restrict__ c_off)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int c = cid_incl[i] - 1;
-        const int id = ids ? ids[idx[i]] : idx[i];
-        keys[i] = ((unsigned long long)(unsigned)c << 32) | (unsigned long long)((uint32_t)id ^ 0x80000000u);
-        if (flag[i]) {
-            c_start[c] = s_ord[i];
-            c_off[c] = i;
-        }
-    }
-}
-
-__global__ void cluster_finish_kernel(const unsigned long long *__restrict__ keys_sorted, const int32_t *__restrict__ pm,
-                                      long long *__restrict__ c_off, int nclusters, int n, int32_t *__restrict__ c_end,
-                                      int32_t *__restrict__ members)
-{
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        members[i] = (int32_t)((uint32_t)keys_sorted[i] ^ 0x80000000u);
-        if (i < nclusters) {
-            const long long last = (i + 1 < nclusters ? c_off[i + 1] : (long long)n) - 1;
-            c_end[i] = pm[last];  // max_dist >= 0: every earlier cluster ends before this one starts
-        }
-        if (i == 0) c_off[nclusters] = n;
-    }
-}
 
 static int64_t g_opt_partition = -1;  // -1 = auto (large batches), 0 = never, 1 = always
 static int64_t g_opt_partition_min = 4 << 20;  // auto: partition batches of at least this many queries
@@ -3819,187 +1758,7 @@ static int upload_queries(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     return BXMI_OK;
 }
 
-// Host threads that touch the pages of an OUTPUT array chunk by chunk, ahead of the downloads into it.  A copy into fresh pageable
-// memory (numpy.empty) pays for its page faults on the copying thread: 400 MB cost the download 10-16 ms, 32 ms per 100 M
-// counts against 16 into touched memory.  A page is read and written back; the array is the call's output -- nobody else holds
-// it -- and chunk k's download waits (wait_chunk) until its touchers are done with it, so a touch never lands on copied data.
-struct PageToucher {
-    char *base = nullptr;
-    size_t bytes = 0, chunk = 0;
-    int nchunks = 0, nthreads = 0;
-    std::vector<std::atomic<int>> done;  // [chunk]: threads done with it
-    std::atomic<bool> stop{false};
-    std::vector<std::thread> threads;
-    void start(void *p, size_t n, size_t chunk_bytes, int nthr)
-    {
-        base = static_cast<char *>(p), bytes = n, chunk = chunk_bytes, nthreads = nthr;
-        nchunks = (int)((n + chunk_bytes - 1) / chunk_bytes);
-        done = std::vector<std::atomic<int>>((size_t)nchunks);
-        for (auto &d : done) d.store(0);
-        for (int j = 0; j < nthreads; j++) threads.emplace_back([this, j] { run(j); });
-    }
-    void run(int j)
-    {
-        for (int k = 0; k < nchunks && !stop.load(); k++) {
-            const size_t o = (size_t)k * chunk, m = std::min(chunk, bytes - o);
-            volatile char *b = base + o;
-            const size_t lo = m * (size_t)j / (size_t)nthreads, hi = m * (size_t)(j + 1) / (size_t)nthreads;
-            for (size_t x = lo; x < hi; x += 4096) b[x] = b[x];
-            if (hi > lo) b[hi - 1] = b[hi - 1];
-            done[(size_t)k].fetch_add(1, std::memory_order_release);
-        }
-    }
-    void wait_chunk(int k)
-    {
-        while (nthreads && done[(size_t)k].load(std::memory_order_acquire) < nthreads && !stop.load()) std::this_thread::yield();
-    }
-    void join()
-    {
-        for (auto &t : threads) t.join();
-        threads.clear();
-    }
-    ~PageToucher()
-    {
-        stop.store(true);
-        join();
-    }
-};
-
-// Device memory -> a pageable host array the caller has not touched yet, at the link's rate: chunks of 32 MB, the touchers one
-// or more chunks ahead of the copies.  `t` may be running already (started while the device was still computing); NULL = start here.
-static int download_touched(void *dst, const void *src_dev, size_t bytes, hipStream_t st, PageToucher *t = nullptr)
-{
-    constexpr size_t CH = (size_t)32 << 20;
-    if (bytes == 0) return BXMI_OK;
-    PageToucher own;
-    if (!t && bytes >= 2 * CH && g_opt_host_touchers > 0) own.start(dst, bytes, CH, (int)g_opt_host_touchers), t = &own;
-    if (!t) {
-        BXMI_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, st));
-        return BXMI_OK;
-    }
-    for (int k = 0; k < t->nchunks; k++) {
-        const size_t o = (size_t)k * t->chunk, m = std::min(t->chunk, bytes - o);
-        t->wait_chunk(k);
-        const hipError_t e = hipMemcpyAsync(static_cast<char *>(dst) + o, static_cast<const char *>(src_dev) + o, m, hipMemcpyDeviceToHost, st);
-        if (e != hipSuccess) {
-            t->stop.store(true);
-            return fail(BXMI_EHIP, "download: %s", hipGetErrorString(e));
-        }
-    }
-    return BXMI_OK;
-}
-
-// The host-pointer count in chunks: while the pass runs on chunk k (the handle's stream), chunk k+1 is on its way up (stream_up,
-// this thread) and the counts of chunk k-1 on their way down (stream_down, a second host thread: a copy from or to pageable
-// memory holds its caller until the runtime has staged it, and PCIe carries both directions at once only if two threads ask).
-// tools/micro/pcie_probe.hip on the round's box: 56 GB/s either way alone, 47 + 47 GB/s together -- a 100 M batch is bounded by its
-// 0.8 GB upload (~17 ms); one piece after the other (upload, pass, download) took 42-74 ms.
-struct HostChunks {
-    bxmi_ivl *h;
-    int32_t *counts;
-    int64_t nq, chunk;
-    int nchunks;
-    std::vector<hipEvent_t> done;  // chunk k's pass has finished (recorded on the handle's stream)
-    std::mutex mu;
-    std::condition_variable cv;
-    int launched = 0;   // chunks whose pass has been launched and whose event is recorded
-    std::atomic<bool> stop{false};  // the launching thread failed: nothing more will come
-    int rc = BXMI_OK;
-    std::string err;
-    PageToucher touch;  // the output array's pages, chunk by chunk ahead of the downloads
-};
-
-static int host_chunks_download_one(HostChunks *c, int k)
-{
-    bxmi_ivl *h = c->h;
-    const int64_t o = (int64_t)k * c->chunk, m = std::min(c->chunk, c->nq - o);
-    c->touch.wait_chunk(k);
-    BXMI_HIP(hipStreamWaitEvent(h->stream_down, c->done[k], 0));
-    BXMI_HIP(hipMemcpyAsync(c->counts + o, h->q_cnt.as<int32_t>() + o, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream_down));
-    return BXMI_OK;
-}
-
-static void host_chunks_download(HostChunks *c)
-{
-    if (hipSetDevice(c->h->device) != hipSuccess) {
-        c->rc = BXMI_EHIP, c->err = "hipSetDevice in the download thread failed";
-        return;
-    }
-    for (int k = 0; k < c->nchunks; k++) {
-        {
-            std::unique_lock<std::mutex> lk(c->mu);
-            c->cv.wait(lk, [&] { return c->launched > k || c->stop; });
-            if (c->launched <= k) return;
-        }
-        const int rc = host_chunks_download_one(c, k);
-        if (rc != BXMI_OK) {
-            c->rc = rc, c->err = last_error();  // (last_error() is per thread: carried over to the caller's)
-            return;
-        }
-    }
-    if (hipStreamSynchronize(c->h->stream_down) != hipSuccess) c->rc = BXMI_EHIP, c->err = "hipStreamSynchronize(stream_down) failed";
-}
-
-static int ivl_count_host_chunks(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total)
-{
-    if (!h->stream_up) BXMI_HIP(hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking));
-    if (!h->stream_down) BXMI_HIP(hipStreamCreateWithFlags(&h->stream_down, hipStreamNonBlocking));
-    HostChunks c;
-    c.h = h, c.counts = counts, c.nq = nq, c.chunk = g_opt_host_chunk, c.nchunks = (int)div_up(nq, g_opt_host_chunk);
-    BXMI_TRY(h->q_s.reserve((size_t)(nq + 4) * 4));
-    BXMI_TRY(h->q_e.reserve((size_t)(nq + 4) * 4));
-    if (counts) BXMI_TRY(h->q_cnt.reserve((size_t)(nq + 4) * 4));
-    BXMI_TRY(h->q_total.reserve(64));
-    BXMI_HIP(hipMemsetAsync(h->q_total.p, 0, 8, h->stream));
-    c.done.assign((size_t)c.nchunks, nullptr);
-    std::vector<hipEvent_t> up((size_t)c.nchunks, nullptr);
-    auto drop_events = [&] {
-        for (hipEvent_t e : c.done) if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
-    };
-    for (int k = 0; k < c.nchunks; k++)
-        if (hipEventCreateWithFlags(&c.done[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&up[k], hipEventDisableTiming) != hipSuccess) {
-            drop_events();
-            return fail(BXMI_EHIP, "bxmi_ivl_count: hipEventCreate failed");
-        }
-    std::thread down;
-    if (counts) {
-        if (g_opt_host_touchers > 0) c.touch.start(counts, (size_t)nq * 4, (size_t)c.chunk * 4, (int)g_opt_host_touchers);
-        down = std::thread(host_chunks_download, &c);
-    }
-    auto one = [&](int k) -> int {
-        const int64_t o = (int64_t)k * c.chunk, m = std::min(c.chunk, nq - o);
-        BXMI_HIP(hipMemcpyAsync(h->q_s.as<int32_t>() + o, qs + o, (size_t)m * 4, hipMemcpyHostToDevice, h->stream_up));
-        BXMI_HIP(hipMemcpyAsync(h->q_e.as<int32_t>() + o, qe + o, (size_t)m * 4, hipMemcpyHostToDevice, h->stream_up));
-        BXMI_HIP(hipEventRecord(up[k], h->stream_up));
-        BXMI_HIP(hipStreamWaitEvent(h->stream, up[k], 0));
-        BXMI_TRY(bxmi_ivl_count_dev(h, h->q_s.as<int32_t>() + o, h->q_e.as<int32_t>() + o, m, counts ? h->q_cnt.as<int32_t>() + o : nullptr,
-                                    h->q_total.as<int64_t>(), h->stream));  // (the chunks' totals add up in the one word)
-        BXMI_HIP(hipEventRecord(c.done[k], h->stream));
-        return BXMI_OK;
-    };
-    int rc = BXMI_OK;
-    for (int k = 0; k < c.nchunks && rc == BXMI_OK; k++) {
-        rc = one(k);
-        std::lock_guard<std::mutex> lk(c.mu);
-        if (rc == BXMI_OK) c.launched = k + 1;
-        else c.stop = true, c.touch.stop.store(true);
-        c.cv.notify_one();
-    }
-    int64_t t = 0;
-    if (rc == BXMI_OK) {
-        hipError_t e = hipMemcpyAsync(&t, h->q_total.p, 8, hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) rc = fail(BXMI_EHIP, "bxmi_ivl_count: reading the total: %s", hipGetErrorString(e));
-    } else
-        (void)hipStreamSynchronize(h->stream);  // nothing of this call stays in flight behind its return
-    if (down.joinable()) down.join();
-    c.touch.join();
-    drop_events();
-    if (rc == BXMI_OK && c.rc != BXMI_OK) rc = fail(c.rc, "%s", c.err.c_str());
-    if (rc == BXMI_OK && total) *total = t;
-    return rc;
-}
+#include "host_pipeline.hpp"
 
 extern "C" int bxmi_ivl_count(bxmi_ivl_t *h, const int32_t *qs, const int32_t *qe, int64_t nq, int32_t *counts, int64_t *total)
 {
