@@ -46,7 +46,19 @@ Rccl &rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        // First choice: the librccl that sits beside the HIP runtime libbxmi itself is bound to.  A process can hold two HIP
+        // runtimes (a PyTorch wheel brings its own libamdhip64 and librccl; libbxmi links against /opt/rocm's): a communicator
+        // and the streams / buffers handed to it must belong to the same one, and a bare dlopen("librccl.so") returns whichever
+        // copy the process loaded first (found by the round-6 GPU suite: torch imported before libbxmi -> "unhandled cuda error").
+        std::string beside;
+        Dl_info info;
+        if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            beside = info.dli_fname;
+            const size_t slash = beside.rfind('/');
+            beside = slash == std::string::npos ? std::string() : beside.substr(0, slash + 1) + "librccl.so";
+        }
+        for (const char *name : {beside.c_str(), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            if (!*name) continue;
             r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.lib) break;
         }

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void bd_transpose_kernel(const unsigned short 
 // counts written through as agent-scope atomics -- 21.5 us against 8.2 + 10.3 for one index: every workgroup waits for its
 // stores and a returning atomic, and the planner reads the counts from beyond the L2.  With __threadfence() instead: 153 us --
 // an agent-scope release writes the XCD's whole L2 back.)
-constexpr int BD_PLAN_SEGS = 16;
+constexpr int BD_PLAN_SEGS = 32;  // (a genome of 24 chromosomes on one GPU: 12 us where bm_plan_kernel<2> took 27)
 __global__ __launch_bounds__(1024) void bd_plan_kernel(const unsigned *__restrict__ unitcnt /* [ngroups][BM_NB] */, int n_segs, const BmSeg *__restrict__ segs,
                                                        int chunk, int4 *__restrict__ items, int *__restrict__ n_items, const unsigned *__restrict__ gate)
 {

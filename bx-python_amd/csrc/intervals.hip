@@ -52,7 +52,7 @@
 namespace bxmi {
 
 static int64_t g_opt_partition = -1;  // -1 = auto (large batches), 0 = never, 1 = always
-static int64_t g_opt_partition_min = 4 << 20;  // auto: partition batches of at least this many queries
+constexpr int64_t g_opt_partition_min = 4 << 20;  // auto: partition batches of at least this many queries
 constexpr int PT_MAX_SUB = 1;  // scratch regions are addressed per sub-batch; one region since sub-batch pipelining was dropped
 constexpr int PT_SLOT_STRIDE = PT_SLOTS + 8;  // per sub-batch: the partial totals, then the "unsorted" flag
 static int64_t g_opt_sorted_path = 1;  // 1 = batches whose starts are already sorted skip the bucketing (detected on the device)
@@ -64,16 +64,16 @@ static int64_t g_opt_fx_direct = -1;   // find() through the exchange: 1 = the f
 static int64_t g_opt_find_sliced = 1;  // large unsorted find() batches through the exchange (count_slices.hpp) where the slice stage fits; 0 = the bucketed find
 static int64_t g_opt_slice = -1;       // search stage on staged key slices (count_slices.hpp): -1 = where the images do not pay or fit, 0 = never, 1 = wherever it fits
 static int64_t g_opt_sl_f = -1;        // buckets per slice unit = 2^f: -1 = by run length and LDS, else forced (tests)
-static int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_CHUNK, twice that for bucket pairs)
+constexpr int64_t g_opt_bm_chunk = 0;     // queries per search work item (0 = BM_CHUNK, twice that for bucket pairs)
 static int64_t g_opt_sl_run_cap = 160;  // a slice unit grows only while its expected (tile, unit) run stays within this many records
 static int64_t g_opt_sl_flat = 1;      // 1 = count-only passes on key slices take the flat 16-byte walk of count_dense.hpp (16-bit counts, unit run table), 0 = the 16 / 64 lanes-per-run kernels of count_slices.hpp
-static int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
+constexpr int64_t g_opt_sl_rbits = 20;    // a slice unit's offsets take at most this many bits of the 32-bit record (the rest holds the length)
 static int64_t g_opt_sl_lanes = 0;     // lanes per (tile, unit) run: 0 = by expected run length, 16 or 64, -1 (set as 1) = the flat walk for long runs
 static int64_t g_opt_bm_hard_ppm = 2000;  // an index qualifies while its hard cells stay below this many per million cells
 static int64_t g_opt_flat = -1;       // the flat 16-byte walk on cell images of 2^18-coordinate units (count_dense.hpp, bp_*): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
 static int64_t g_opt_sparse = -1;     // offset-cell images for sparse indexes (offset_cells.hpp; the persistent walk): -1 = sparse indexes that qualify, batches that bring enough queries per unit; 0 = never; 1 = whatever the batch size
 static int64_t g_opt_bo_cell_log2 = 0;  // their cell width: 0 = from the index's density, 6..8 = forced
-static int64_t g_opt_bo_min_per_unit = 4096;  // queries per unit image a batch must bring (an image is 72 KB to load whatever the batch)
+constexpr int64_t g_opt_bo_min_per_unit = 4096;  // queries per unit image a batch must bring (an image is 72 KB to load whatever the batch)
 static int64_t g_opt_sorted_cells = 1;  // sorted batches on indexes with cell images: 1 = answered from the images stretch by stretch (bs_*), 0 = the first-generation kernel for sorted batches
 static int64_t g_opt_dense = -1;      // search stage on dense unit images (count_dense.hpp): -1 = dense indexes that qualify, 0 = never, 1 = every index that qualifies
 static int64_t g_opt_bd_chunk = 0;    // queries per search work item of the dense stage (0 = 256 Ki: one item per unit on a uniform 100 M batch)
@@ -83,7 +83,7 @@ static int64_t g_opt_bd_w8 = -1;      // 8-bit counts out of place: -1 = by inde
 static int64_t g_opt_order_skip = -1;  // -1 = stop launching the order check after two batches in a row were not sorted (a probe of 8192 starts rides on the parameter kernel then), 0 = always check
 static int64_t g_opt_host_chunk = 8 << 20;  // queries per chunk of the host-pointer count (upload of chunk k+1 / pass on k / download of k-1 at once); 0 = one piece
 static int64_t g_opt_host_touchers = 2;  // host threads that touch the output array's pages ahead of the downloads (0 = the download faults them in)
-static int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
+constexpr int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
 
 // The option table: every knob of the interval path, its variable and how a value is normalised.  bxmi_set_option writes through
 // it, bxmi_get_option / bxmi_option_at read it back -- the tests take their "defaults" from the library at import instead of
@@ -96,7 +96,6 @@ struct IvlOpt {
 static const IvlOpt IVL_OPTS[] = {
     {"ivl.partition", &g_opt_partition, nullptr},
     {"ivl.sorted_path", &g_opt_sorted_path, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.partition_min", &g_opt_partition_min, nullptr},
     {"ivl.bitmap_min", &g_opt_bitmap_min, nullptr},
     {"ivl.bitmap", &g_opt_bitmap, nullptr},
     {"ivl.bm_variant", &g_opt_bm_variant, [](int64_t value) -> int64_t { return value < 0 || value > 2 ? -1 : value; }},
@@ -104,10 +103,8 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.fx_direct", &g_opt_fx_direct, [](int64_t value) -> int64_t { return value < 0 ? -1 : value != 0; }},
     {"ivl.slice", &g_opt_slice, nullptr},
     {"ivl.sl_f", &g_opt_sl_f, [](int64_t value) -> int64_t { return value > SL_MAX_F ? SL_MAX_F : value; }},
-    {"ivl.bm_chunk", &g_opt_bm_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
     {"ivl.sl_run_cap", &g_opt_sl_run_cap, [](int64_t value) -> int64_t { return value < 8 ? 8 : value; }},
     {"ivl.sl_flat", &g_opt_sl_flat, [](int64_t value) -> int64_t { return value != 0; }},
-    {"ivl.sl_rbits", &g_opt_sl_rbits, [](int64_t value) -> int64_t { return value < 17 ? 17 : (value > 24 ? 24 : value); }},
     {"ivl.sl_lanes", &g_opt_sl_lanes, [](int64_t value) -> int64_t { return value == 16 || value == 64 ? value : (value == 1 ? -1 : 0); /* 1 = the flat walk */ }},
     {"ivl.bm_hard_ppm", &g_opt_bm_hard_ppm, nullptr},
     {"ivl.flat", &g_opt_flat, nullptr},
@@ -115,7 +112,6 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.sparse", &g_opt_sparse, nullptr},
     {"ivl.sorted_cells", &g_opt_sorted_cells, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.bo_cell_log2", &g_opt_bo_cell_log2, [](int64_t value) -> int64_t { return value < BO_MIN_K || value > BO_MAX_K ? 0 : value; }},
-    {"ivl.bo_min_per_unit", &g_opt_bo_min_per_unit, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
     {"ivl.bd_chunk", &g_opt_bd_chunk, [](int64_t value) -> int64_t { return value < 0 ? 0 : value; }},
     {"ivl.bd_blocks", &g_opt_bd_blocks, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.bd_table_from", &g_opt_bd_table_from, [](int64_t value) -> int64_t { return value < 1 || value > 64 ? 0 : value; }},
@@ -123,7 +119,6 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.order_skip", &g_opt_order_skip, nullptr},
     {"ivl.host_chunk", &g_opt_host_chunk, [](int64_t value) -> int64_t { return value <= 0 ? 0 : ((value + 4095) & ~(int64_t)4095); }},
     {"ivl.host_touchers", &g_opt_host_touchers, [](int64_t value) -> int64_t { return value < 0 ? 0 : (value > 16 ? 16 : value); }},
-    {"ivl.bd_unit_log2", &g_opt_bd_unit_log2, [](int64_t value) -> int64_t { return value < 12 || value > BD_UNIT_LOG2 ? 0 : value; }},
 };
 constexpr int IVL_NOPTS = (int)(sizeof(IVL_OPTS) / sizeof(IVL_OPTS[0]));
 

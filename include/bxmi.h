@@ -64,8 +64,7 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
 /* Tuning / A-B knobs (process-wide), key -> value.  Results never depend on them (the GPU tests run both sides).  The
  * authoritative list with the defaults is what bxmi_option_at enumerates (the IVL_OPTS table of csrc/intervals.hip);
  * the ones a caller may want:
- *   ivl.partition      -1 auto (batches >= ivl.partition_min queries take the large-batch passes), 0 never, 1 always
- *   ivl.partition_min  threshold of the auto mode (default 4 Mi queries)
+ *   ivl.partition      -1 auto (batches >= 4 Mi queries take the large-batch passes), 0 never, 1 always
  *   ivl.sorted_path    1 (default): a batch whose starts are already non-decreasing is answered as it lies
  *   ivl.sorted_cells   1 (default): ... from the cell images, stretch by stretch (count_dense.hpp, bs_*); 0: first-generation kernel
  *   ivl.bitmap         -1 (default): large batches take the exchange (tile sort -> search on unit images -> un-permute)
@@ -73,18 +72,19 @@ int bxmi_memset(void *dst_dev, int value, size_t bytes);
  *   ivl.bitmap_min     smallest batch that takes the exchange (default 2 Mi queries)
  *   ivl.flat / ivl.dense / ivl.slice / ivl.sparse   force (1), forbid (0) or leave to the index's shape (-1, default) the
  *                      search stage: bitmap-cell images / dense unit images / staged key slices / offset-cell images
- *   ivl.bo_cell_log2, ivl.bo_min_per_unit   offset cells: coordinates per cell (6..8, 0 = from the density) and the
- *                      queries per unit image a batch must bring before the images pay
+ *   ivl.bo_cell_log2   offset cells: coordinates per cell (6..8, 0 = from the density)
  *   ivl.bm_variant     tile shape of the exchange (-1 auto, 0 = 512 x 32, 1 = 1024 x 16, 2 = 1024 x 32 queries per tile)
- *   ivl.bm_chunk, ivl.bd_chunk   queries per search work item (0 = default)
+ *   ivl.bd_chunk       queries per search work item (0 = default)
  *   ivl.bd_w8          8-bit counts between the search and the un-permute kernel (-1 auto from the density + feedback)
  *   ivl.order_skip     1 (default): the exact order check is dropped after two shuffled batches (a probe stands in)
  *   ivl.find_sliced    1 (default): find() on large unsorted batches goes through the exchange (count_slices.hpp)
  *   ivl.fx_direct      the exchange's fill writes straight into the CSR list (1) or into scratch, followed by a copy (0); -1 (default):
  *                      straight while the list the handle expects (hits per query of its previous batch) stays under 400 MB
- *   ivl.sl_f, ivl.sl_lanes, ivl.sl_flat, ivl.sl_rbits, ivl.sl_run_cap   geometry of the slice stage (tests, A/B tools)
+ *   ivl.sl_f, ivl.sl_lanes, ivl.sl_flat, ivl.sl_run_cap   geometry of the slice stage (tests, A/B tools)
  *   ivl.bd_table_from  dense images: duplicated coordinates from which a cell gets a rank table (0 = 2 where the LDS has the room, else 6)
- *   ivl.bm_hard_ppm, ivl.bd_unit_log2, ivl.bd_blocks   thresholds / shapes of the unit images (tests)
+ *   ivl.bm_hard_ppm, ivl.bd_blocks   thresholds / shapes of the unit images (tests)
+ *   ivl.host_chunk, ivl.host_touchers   the host-pointer count: queries per chunk of its pipeline (default 8 Mi; 0 = one piece) and
+ *                      the host threads that touch an output array's pages ahead of the downloads (default 2; bxmi_ivl_find too)
  *   bits.grid          grid of the per-bitset kernels
  *   core.poll          1 (default): the one-call paths (bxmi_ivl_find_one, short bxmi_bits_count_range) poll a completion
  *                      word their kernel writes to host memory; 0: they wait for the stream
@@ -158,7 +158,7 @@ int bxmi_ivl_flat_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells);
  * density, holds the offsets of up to five keys; units of up to 2^20 coordinates on the same persistent walk, two workgroups per CU): *state = 0
  * not decided yet, 1 = usable, -1 = the index does not qualify (too dense, reversed targets, too many cells with more than
  * five keys: *hard_cells of them); *cell_log2 = k when usable.  A sparse index takes this stage when a batch brings enough
- * queries per unit image (ivl.bo_min_per_unit), key slices otherwise.  Introspection only. */
+ * queries per unit image (4096), key slices otherwise.  Introspection only. */
 int bxmi_ivl_sparse_state(const bxmi_ivl_t *h, int *state, int64_t *hard_cells, int *cell_log2);
 /* The width of the counts a flat-walk pass over cell images hands from its search to its un-permute kernel: *bits = 8
  * while the index is sparse enough for small counts (fewer than 128 targets per 2048 coordinates) and fewer than one count

@@ -58,9 +58,9 @@ def test_bench_launches_its_own_ranks_dry_two():
 
 
 def test_bench_refuses_more_ranks_than_devices_on_the_gpu_box():
-    import torch
+    from bxmi import _ffi  # (not torch: its bundled HIP runtime would become this process's first, and libbxmi's RCCL binding a mix of two)
 
-    n = torch.cuda.device_count() + 7
+    n = _ffi.device_count() + 7
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600, env=_env())
     assert p.returncode != 0 and "refusing to run fewer ranks than asked" in p.stderr, p.stderr[-2000:]

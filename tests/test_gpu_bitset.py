@@ -294,11 +294,13 @@ def test_thousands_of_default_sized_sets_stay_small(O, B):
     runs, iand / ior between sets of different extents, reads far beyond anything set."""
     import ctypes
 
-    hip = ctypes.CDLL("libamdhip64.so")  # (the runtime libbxmi already runs on; torch's own copy is not brought in here)
+    from bxmi import _ffi
 
     def free_bytes():
-        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
-        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        # through the C ABI, i.e. the HIP runtime libbxmi itself is bound to (a dlopen of "libamdhip64.so" by name brings a SECOND
+        # runtime into the process when torch's bundled copy was loaded first -- it sees no device)
+        free = ctypes.c_int64(0)
+        _ffi.call("bxmi_mem_info", ctypes.byref(free), None)
         return free.value
 
     import gc
