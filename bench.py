@@ -648,6 +648,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bitset", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer (PCIe-inclusive) side measurement: its chunked passes would mix into a kernel profile")
     ap.add_argument("--no-find", action="store_true", help="skip the configs[4] CSR-join side measurement")
     ap.add_argument("--no-sorted", action="store_true", help="skip the sorted-queries side measurement (profiling runs: its launches "
                     "dismiss the bucketed kernels at once and would halve their average durations)")
@@ -867,7 +868,7 @@ def main():
 
     # the same batch through the HOST-pointer entry point (pageable numpy buffers over PCIe): reported, never `value`
     pcie = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_pcie:
         ix.count(qs_h[:1 << 20], qe_h[:1 << 20])
         t1 = time.perf_counter()
         hc, ht = ix.count(qs_h, qe_h)  # the handle's first batch of this size: its 1.2 GB of device staging are allocated here

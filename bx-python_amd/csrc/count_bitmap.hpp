@@ -314,7 +314,10 @@ constexpr int BM_PAD_ROOM = 4096 + 544;
 #define BM_TS_EXP 0
 #endif
 
-template <int THREADS, int ITEMS, bool PAD = false, int SUB = 1>
+// TOT (a batch that wants its overlap TOTAL only, on cell images: bm_count_segments): nobody will put counts back into query
+// order, so the slots are not written (2 of the kernel's 14 bytes per query), and `tesc[tile]` says whether the tile holds a
+// query the images cannot answer (an escape record: bm_escape_totals_kernel then reads that tile's queries again).
+template <int THREADS, int ITEMS, bool PAD = false, int SUB = 1, bool TOT = false>
 __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
                                                                unsigned *__restrict__ recs /* [ntiles][TILE (+ BM_PAD_ROOM)], tile-sorted */,
                                                                unsigned short *__restrict__ slots /* [nq] slot of every query in its tile */,
@@ -322,10 +325,12 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
                                                                const unsigned *__restrict__ gate /* NULL, or 0 = sorted batch: stand down */,
                                                                unsigned *__restrict__ tend /* PAD: [ntiles] slots used */,
                                                                unsigned short *__restrict__ tbl2 /* SUB = 2: [ntiles][2 * BM_NB] first slot of every half bucket */,
-                                                               const BmSegChunk par, const int npar /* 0: segs / tile_seg are in memory already */, const BmParOut po)
+                                                               const BmSegChunk par, const int npar /* 0: segs / tile_seg are in memory already */, const BmParOut po,
+                                                               unsigned *__restrict__ tesc = nullptr /* TOT: [ntiles] 1 = the tile holds an escape record */)
 {
     constexpr int TILE = THREADS * ITEMS;
     if (gate && *gate == 0) return;
+    static_assert(!TOT || (PAD && SUB == 1), "total-only batches: the persistent walk on padded runs");
     constexpr int NBK = BM_NB * SUB;     // sort keys: buckets, or half buckets
     constexpr int BPT = NBK / THREADS;   // keys per thread in the scan
     static_assert(NBK % THREADS == 0 && (BPT == 2 || BPT == 4), "2 or 4 buckets per thread");
@@ -462,6 +467,7 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
         }
     }
     __syncthreads();
+    bool esc = false;  // TOT: one of this thread's queries became an escape record
     if (n == TILE) {
         uint2 *l4 = reinterpret_cast<uint2 *>(slots + base);  // four 16-bit slots per 8-byte store
 #pragma unroll
@@ -472,11 +478,13 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
                 if ((s0 ^ s1 ^ s2 ^ s3 ^ (unsigned)vs[j].x ^ (unsigned)ve[j].y) == 0x9e3779b9u) staged[0] = s0;
                 continue;
             }
-            staged[s0] = bm_record_of(vs[j].x, ve[j].x, g);
-            staged[s1] = bm_record_of(vs[j].y, ve[j].y, g);
-            staged[s2] = bm_record_of(vs[j].z, ve[j].z, g);
-            staged[s3] = bm_record_of(vs[j].w, ve[j].w, g);
-            l4[j * THREADS + threadIdx.x] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+            const unsigned r0 = bm_record_of(vs[j].x, ve[j].x, g), r1 = bm_record_of(vs[j].y, ve[j].y, g);
+            const unsigned r2 = bm_record_of(vs[j].z, ve[j].z, g), r3 = bm_record_of(vs[j].w, ve[j].w, g);
+            staged[s0] = r0, staged[s1] = r1, staged[s2] = r2, staged[s3] = r3;
+            if (TOT)
+                esc |= r0 == BM_REC_ESC || r1 == BM_REC_ESC || r2 == BM_REC_ESC || r3 == BM_REC_ESC;
+            else
+                l4[j * THREADS + threadIdx.x] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
         }
     } else {
 #pragma unroll
@@ -484,12 +492,21 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
             const int k = j * THREADS + threadIdx.x;
             if (k < n) {
                 const unsigned s = toff[br[j] >> 16] + (br[j] & 0xffffu);
-                staged[s] = bm_record_of(qs[base + k], qe[base + k], g);
-                slots[base + k] = (unsigned short)s;
+                const unsigned r = bm_record_of(qs[base + k], qe[base + k], g);
+                staged[s] = r;
+                if (TOT)
+                    esc |= r == BM_REC_ESC;
+                else
+                    slots[base + k] = (unsigned short)s;
             }
         }
     }
-    __syncthreads();
+    if (TOT) {
+        const int any = __syncthreads_or(esc ? 1 : 0);
+        if (threadIdx.x == 0) tesc[tile] = (unsigned)(any != 0);
+    } else {
+        __syncthreads();
+    }
     int4 *out = reinterpret_cast<int4 *>(recs + base);
     const int n4 = BM_TS_EXP == 2 ? 0 : (n_out + 3) >> 2;  // (the scratch is padded to whole tiles)
     for (int i = threadIdx.x; i < n4; i += THREADS) out[i] = reinterpret_cast<const int4 *>(staged)[i];
@@ -685,6 +702,39 @@ __device__ __forceinline__ int bm_escape_count(const IndexDev &ix, const int32_t
 {
     if (qs < qe && (qe <= g.cmin || qs >= g.cmax)) return 0;
     return count_one_global(ix, e_sorted, qs, qe);
+}
+
+// A total-only batch on cell images (the search keeps the totals itself, nothing is put back into query order): the queries the
+// images cannot answer -- improper, off the grid, longer than a record holds -- are answered here from the sealed index, tile by
+// tile; a tile the tile sort found no escape record in (tesc[tile] == 0: every tile of an ordinary batch) costs one load.
+__global__ __launch_bounds__(1024) void bm_escape_totals_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
+                                                                const unsigned *__restrict__ tesc, int64_t ntp, int tile_log2,
+                                                                unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS] */,
+                                                                const unsigned *__restrict__ gate)
+{
+    __shared__ long long red[1024 / 64];
+    if (gate && *gate == 0) return;
+    const int64_t tile = blockIdx.x;  // (a workgroup per tile: the rare tile with an escape is read at full width, 16 bytes per lane and load)
+    const int seg = tile_seg[tile];
+    const BmSeg &sg = segs[seg];
+    const int64_t ltile = tile - sg.tile0;
+    if (ltile >= sg.ntiles || tesc[tile] == 0u) return;  // (uniform)
+    const BmGeom g = sg.g;
+    const int64_t q0 = ltile << tile_log2;
+    const int64_t left = sg.nq - q0;
+    const int n = (int)(left < ((int64_t)1 << tile_log2) ? left : (int64_t)1 << tile_log2);
+    long long acc = 0;
+    auto one = [&](int s, int e) {
+        if (bm_record_of(s, e, g) == BM_REC_ESC) acc += (long long)bm_escape_count(sg.ix, sg.e_sorted, g, s, e);
+    };
+    const int n4 = n >> 2;  // (the query arrays are 16-byte aligned and a tile starts on a multiple of its size)
+    const int4 *__restrict__ s4 = reinterpret_cast<const int4 *>(sg.qs + q0), *__restrict__ e4 = reinterpret_cast<const int4 *>(sg.qe + q0);
+    for (int k = threadIdx.x; k < n4; k += 1024) {
+        const int4 vs = s4[k], ve = e4[k];
+        one(vs.x, ve.x), one(vs.y, ve.y), one(vs.z, ve.z), one(vs.w, ve.w);
+    }
+    for (int k = 4 * n4 + (int)threadIdx.x; k < n; k += 1024) one(sg.qs[q0 + k], sg.qe[q0 + k]);
+    block_accumulate_i64(acc, red, total_slots + (int64_t)seg * PT_SLOTS + (tile & (PT_SLOTS - 1)));
 }
 
 // FIND: also leave loff[tile-sorted position] = exclusive prefix of the counts inside the tile, in tile-sorted order

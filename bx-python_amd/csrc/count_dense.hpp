@@ -702,7 +702,8 @@ __device__ __forceinline__ int bp_hard_rank(const BdImage &I, lds_cell_p cells, 
     return bm_hard_rank(cells, rel, a, slice_lo, I.lo);
 }
 
-// the count of one record (16 bits, 0xFFFF = ask the index again)
+// the count of one record (16 bits, 0xFFFF = ask the index again; RAW: all 32 bits, an escape record counts 0)
+template <bool RAW = false>
 __device__ __forceinline__ unsigned bp_count_record(const BdImage &I, unsigned rec)
 {
     const unsigned off = rec & I.off_mask, len = rec >> BP_RSHIFT;
@@ -717,6 +718,7 @@ __device__ __forceinline__ unsigned bp_count_record(const BdImage &I, unsigned r
         if ((mS >> 25) == (unsigned)BM_HARD) hS = bp_hard_rank(I, I.cS, relS, I.s_ord, I.sLo);
         c = (unsigned)(I.bias + (hS - hE));
     }
+    if (RAW) return rec == BM_REC_ESC ? 0u : c;
     c = c < 0xFFFFu ? c : 0xFFFFu;
     return rec == BM_REC_ESC ? 0xFFFFu : c;
 }
@@ -1156,6 +1158,9 @@ __device__ __forceinline__ unsigned bw_wave_inclusive_sum(unsigned v)
 
 // the four counts of a slot from a cell image (16 bits each, 0xFFFF = ask the index again); all eight cells are read
 // before the first is used, hard cells are noticed once per slot
+// RAW (total-only batches: the walk sums what it finds): the counts' 32 bits as they are, escape records (the runs' padding, and
+// the queries bm_escape_totals_kernel answers) count 0
+template <bool RAW = false>
 __device__ __forceinline__ void bp_count_slot(const BdImage &I, bd_v4u v, unsigned (&c)[4])
 {
     const unsigned rec[4] = {v.x, v.y, v.z, v.w};
@@ -1185,13 +1190,17 @@ __device__ __forceinline__ void bp_count_slot(const BdImage &I, bd_v4u v, unsign
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const unsigned mE = __builtin_bit_cast(bd_v2u, cellE[j]).y, mS = __builtin_bit_cast(bd_v2u, cellS[j]).y;
-            if ((mE > mS ? mE : mS) >= ((unsigned)BM_HARD << 25)) c[j] = bp_count_record(I, rec[j]);
+            if ((mE > mS ? mE : mS) >= ((unsigned)BM_HARD << 25)) c[j] = bp_count_record<RAW>(I, rec[j]);
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        c[j] = c[j] < 0xFFFFu ? c[j] : 0xFFFFu;
-        c[j] = rec[j] == BM_REC_ESC ? 0xFFFFu : c[j];
+        if (RAW) {
+            c[j] = rec[j] == BM_REC_ESC ? 0u : c[j];
+        } else {
+            c[j] = c[j] < 0xFFFFu ? c[j] : 0xFFFFu;
+            c[j] = rec[j] == BM_REC_ESC ? 0xFFFFu : c[j];
+        }
     }
 }
 
@@ -1212,7 +1221,8 @@ __device__ __forceinline__ int bo_hard_rank(const BdImage &I, lds_cell_p cells, 
     return global_rank_lt(a, slice_lo + (int)base, slice_lo + (int)next, (int)key) - slice_lo;
 }
 
-// the count of one record whose cells may be hard (16 bits, 0xFFFF = ask the index again)
+// the count of one record whose cells may be hard (16 bits, 0xFFFF = ask the index again; RAW: see bp_count_slot)
+template <bool RAW = false>
 __device__ __forceinline__ unsigned bo_count_record(const BdImage &I, unsigned rec)
 {
     const unsigned off = rec & I.off_mask, len = rec >> I.rshift;
@@ -1221,11 +1231,13 @@ __device__ __forceinline__ unsigned bo_count_record(const BdImage &I, unsigned r
     const int rE = ce.y >= BO_HARD ? bo_hard_rank(I, I.cE, relE, I.e_sorted, I.eLo) : (int)bo_rank(ce.x, ce.y, relE & I.cell_mask);
     const int rS = cs.y >= BO_HARD ? bo_hard_rank(I, I.cS, relS, I.s_ord, I.sLo) : (int)bo_rank(cs.x, cs.y, relS & I.cell_mask);
     unsigned c = (unsigned)(I.bias + (rS - rE));
+    if (RAW) return rec == BM_REC_ESC ? 0u : c;
     c = c < 0xFFFFu ? c : 0xFFFFu;
     return rec == BM_REC_ESC ? 0xFFFFu : c;
 }
 
 // the four counts of a slot: all eight cells read before the first is used, hard cells noticed once per slot (bp_count_slot's shape)
+template <bool RAW = false>
 __device__ __forceinline__ void bo_count_slot(const BdImage &I, bd_v4u v, unsigned (&c)[4])
 {
     const unsigned rec[4] = {v.x, v.y, v.z, v.w};
@@ -1251,13 +1263,17 @@ __device__ __forceinline__ void bo_count_slot(const BdImage &I, bd_v4u v, unsign
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const unsigned mE = __builtin_bit_cast(bd_v2u, cellE[j]).y, mS = __builtin_bit_cast(bd_v2u, cellS[j]).y;
-            if ((mE > mS ? mE : mS) >= BO_HARD) c[j] = bo_count_record(I, rec[j]);
+            if ((mE > mS ? mE : mS) >= BO_HARD) c[j] = bo_count_record<RAW>(I, rec[j]);
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        c[j] = c[j] < 0xFFFFu ? c[j] : 0xFFFFu;
-        c[j] = rec[j] == BM_REC_ESC ? 0xFFFFu : c[j];
+        if (RAW) {
+            c[j] = rec[j] == BM_REC_ESC ? 0u : c[j];
+        } else {
+            c[j] = c[j] < 0xFFFFu ? c[j] : 0xFFFFu;
+            c[j] = rec[j] == BM_REC_ESC ? 0xFFFFu : c[j];
+        }
     }
 }
 
@@ -1283,15 +1299,24 @@ __device__ __forceinline__ void bw_store_slot(unsigned short *__restrict__ out, 
 // THREADS: 1024 = one workgroup per CU (bitmap cells: a unit's image is 147 KB); 512 = two per CU (offset cells: 72 KB) -- one
 // loads its next image while the other looks records up.  (Measured on configs[3] with one workgroup per CU and units of 2^21:
 // 13.7 us of every 41 us item were image load, ring start and drain, with the vector units idle.)
-template <bool W8, int DEPTH, bool WIDE = false, int THREADS = BD_THREADS>
+// TOT: the batch wants its overlap TOTAL only (every segment's counts == NULL).  The walk then sums what it finds -- the counts'
+// full 32 bits, escape records 0 (bp_count_slot<RAW>) -- and adds the sum to its segment's partial totals when the segment
+// changes and at the end; no count is stored, no un-permute kernel follows (16 bytes of HBM traffic per query instead of 26).
+// The ring keeps its shape: where a pass stored its counts it stores to the slot nobody owns.  `out` is still the count array
+// (that slot lies in it).  The queries behind real escape records are bm_escape_totals_kernel's.
+template <bool W8, int DEPTH, bool WIDE = false, int THREADS = BD_THREADS, bool TOT = false>
 __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                const int *__restrict__ n_items, const unsigned short *__restrict__ unitT, int64_t ntp,
                                                                const unsigned *__restrict__ recs /* tile-sorted records, padded runs */,
                                                                unsigned short *__restrict__ out /* their counts, same order */, int tile_log2,
-                                                               const unsigned *__restrict__ gate, unsigned *__restrict__ xcd_next /* [8], zero */)
+                                                               const unsigned *__restrict__ gate, unsigned *__restrict__ xcd_next /* [8], zero */,
+                                                               unsigned long long *__restrict__ total_slots = nullptr /* TOT: [segments][PT_SLOTS] */)
 {
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
+    __shared__ long long s_red[TOT ? THREADS / 64 : 1];
+    unsigned long long acc = 0ull;  // TOT: this lane's share of the current segment's total
+    int acc_seg = -1;
     constexpr int LONG_CAP = THREADS == BD_THREADS ? BD_LONG_CAP : BD_LONG_CAP / 2;
     constexpr int PF = THREADS == BD_THREADS ? BW_PF : 10;  // 16-byte pieces per thread of an image (10 x 512 x 16 = 80 KB)
     __shared__ uint2 s_long[LONG_CAP];  // {first record, length} of the long runs met during the walk
@@ -1313,6 +1338,13 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
         const int4 item = items[it];
         const int unit = item.x & 0xffff, t0 = item.y, t1 = item.z;
         const BmSeg &sg = segs[item.x >> 16];
+        if (TOT && (item.x >> 16) != acc_seg) {  // (item-uniform) the totals are per segment
+            if (acc_seg >= 0) {
+                block_accumulate_i64((long long)acc, s_red, total_slots + (int64_t)acc_seg * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)));
+                __syncthreads();
+            }
+            acc = 0ull, acc_seg = item.x >> 16;
+        }
         const BmGeom g = sg.g;
         const int cell_log2 = WIDE ? 5 + g.dshift : 5;
         const BpLayout LP = bp_layout(g.shift + g.f, cell_log2);
@@ -1409,6 +1441,15 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
                     const unsigned first = ((unsigned)t * tile_slots << 2) + a;
                     if (k < LONG_CAP) {
                         s_long[k] = make_uint2(first, e - a);
+                    } else if (TOT) {  // (a full list, and nobody to ask again: the lane walks its run itself)
+                        for (unsigned q = first >> 2; q < ((first + (e - a) + 3u) >> 2); q++) {
+                            unsigned c[4];
+                            if (WIDE)
+                                bo_count_slot<true>(I, reinterpret_cast<const bd_v4u *>(recs)[q], c);
+                            else
+                                bp_count_slot<true>(I, reinterpret_cast<const bd_v4u *>(recs)[q], c);
+                            acc += (unsigned long long)c[0] + c[1] + c[2] + c[3];
+                        }
                     } else {  // (a full list: the run's counts say "ask the index again" -- exactness never depends on the list)
                         const unsigned esc[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu};
                         for (unsigned q = first >> 2; q < ((first + (e - a) + 3u) >> 2); q++) bw_store_slot<W8>(out, q, esc);
@@ -1485,12 +1526,14 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
                         if (BW_EXP & 1)
                             c[0] = rv.x & 0xffu, c[1] = rv.y & 0xffu, c[2] = rv.z & 0xffu, c[3] = rv.w & 0xffu;
                         else if (WIDE)
-                            bo_count_slot(I, rv, c);
+                            bo_count_slot<TOT>(I, rv, c);
                         else
-                            bp_count_slot(I, rv, c);
-                        if (!(BW_EXP & 2) || (c[0] & c[1] & c[2] & c[3]) == 0x12345u) bw_store_slot<W8>(out, ring_idx[d], c);
+                            bp_count_slot<TOT>(I, rv, c);
+                        if (TOT) acc += (unsigned long long)c[0] + c[1] + c[2] + c[3];
+                        else if (!(BW_EXP & 2) || (c[0] & c[1] & c[2] & c[3]) == 0x12345u) bw_store_slot<W8>(out, ring_idx[d], c);
                         else bd_dummy_store(reinterpret_cast<unsigned short *>(nobody));
                     }
+                    if (TOT) bd_dummy_store(reinterpret_cast<unsigned short *>(nobody));  // (every lane of the pass: one memory operation, as a count store would be)
                 } else {
                     bd_dummy_store(reinterpret_cast<unsigned short *>(nobody));
                 }
@@ -1510,16 +1553,18 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
                 for (unsigned q = threadIdx.x; q < nq4; q += THREADS) {
                     unsigned c[4];
                     if (WIDE)
-                        bo_count_slot(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
+                        bo_count_slot<TOT>(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
                     else
-                        bp_count_slot(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
-                    bw_store_slot<W8>(out, q0 + q, c);
+                        bp_count_slot<TOT>(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
+                    if (TOT) acc += (unsigned long long)c[0] + c[1] + c[2] + c[3];
+                    else bw_store_slot<W8>(out, q0 + q, c);
                 }
             }
         }
         __syncthreads();
         it = it_nx;
     }
+    if (TOT && acc_seg >= 0) block_accumulate_i64((long long)acc, s_red, total_slots + (int64_t)acc_seg * PT_SLOTS + (blockIdx.x & (PT_SLOTS - 1)));
 }
 
 // ---------------------------------------------------------------------------

@@ -1012,8 +1012,20 @@ __global__ __launch_bounds__(PT_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 
 __device__ __forceinline__ int count_one_global(const IndexDev &ix, const int32_t *__restrict__ e_sorted, int qs, int qe)
 {
+    if (qs < qe) {  // (qs < qe rules out qs == INT_MAX)
+        // #{start < qe} - #{end <= qs}: both searches step together (the arrays have one length), two independent loads per step --
+        // a lone escape is a chain of dependent loads from HBM, and a total-only pass waits for the slowest one (bm_escape_totals_kernel)
+        const int n = ix.n, keyE = qs + 1;
+        int pS = -1, pE = -1;  // the last element below the key
+        for (int step = n > 0 ? 1 << (31 - __clz(n)) : 0; step > 0; step >>= 1) {
+            const int nS = pS + step, nE = pE + step;
+            const int vS = nS < n ? ix.s_ord[nS] : INT_MAX, vE = nE < n ? e_sorted[nE] : INT_MAX;
+            if (nS < n && vS < qe) pS = nS;
+            if (nE < n && vE < keyE) pE = nE;
+        }
+        return pS - pE;
+    }
     const int s_rank = global_rank_lt(ix.s_ord, 0, ix.n, qe);
-    if (qs < qe) return s_rank - global_rank_lt(e_sorted, 0, ix.n, qs + 1);  // (qs < qe rules out qs == INT_MAX)
     const int lo = first_pm_gt(ix.pm, ix.n, qs);  // zero-length / reversed query: exact predicate over the candidate window
     int c = 0;
     for (int k = lo; k < s_rank; k++) c += ix.e_ord[k] > qs;

@@ -81,6 +81,7 @@ static int64_t g_opt_bd_table_from = 0;  // dense images: overflow entries from 
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
 static int64_t g_opt_bd_w8 = -1;      // 8-bit counts out of place: -1 = by index and feedback, 0 = never, 1 = whenever the layout allows
 static int64_t g_opt_order_skip = -1;  // -1 = stop launching the order check after two batches in a row were not sorted (a probe of 8192 starts rides on the parameter kernel then), 0 = always check
+static int64_t g_opt_tot_walk = 1;     // total-only batches on cell images: 1 = the walk keeps the totals itself (no slots, no count stores, no un-permute kernel), 0 = the counts pass without its stores
 static int64_t g_opt_host_chunk = 8 << 20;  // queries per chunk of the host-pointer count (upload of chunk k+1 / pass on k / download of k-1 at once); 0 = one piece
 static int64_t g_opt_host_touchers = 2;  // host threads that touch the output array's pages ahead of the downloads (0 = the download faults them in)
 constexpr int64_t g_opt_bd_unit_log2 = 0;   // coordinates per unit of the dense images (read when an index is prepared): 0 = 19 if the duplicated coordinates fit its 12 KiB of overflow, else 18 (64 KiB: rank tables of clumped cells); 12 .. 19 = forced
@@ -117,6 +118,7 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.bd_table_from", &g_opt_bd_table_from, [](int64_t value) -> int64_t { return value < 1 || value > 64 ? 0 : value; }},
     {"ivl.bd_w8", &g_opt_bd_w8, nullptr},
     {"ivl.order_skip", &g_opt_order_skip, nullptr},
+    {"ivl.tot_walk", &g_opt_tot_walk, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.host_chunk", &g_opt_host_chunk, [](int64_t value) -> int64_t { return value <= 0 ? 0 : ((value + 4095) & ~(int64_t)4095); }},
     {"ivl.host_touchers", &g_opt_host_touchers, [](int64_t value) -> int64_t { return value < 0 ? 0 : (value > 16 ? 16 : value); }},
 };
@@ -169,7 +171,7 @@ struct bxmi_ivl {
     DevBuf slice_bounds, cell_images, cell_meta, p_hist, p_table, p_pairs, p_dest, p_cnt, p_plan, p_slots, p_lo, p_hi, p_boffs;
     // second-generation count pass (count_bitmap.hpp)
     int32_t cmax = 0;            // largest end of the sealed index
-    DevBuf bm_recs, bm_slots, bm_tbl, bm_runT, bm_grpcnt, bm_items, bm_params;
+    DevBuf bm_recs, bm_slots, bm_tbl, bm_runT, bm_grpcnt, bm_items, bm_params, bm_tesc;
     // slice search (count_slices.hpp)
     int sl_state = 0;            // 0 = not decided yet, 1 = boundary table built and a single bucket's keys fit the LDS, -1 = they do not
     unsigned sl_need[SL_MAX_F + 1] = {0, 0, 0, 0, 0, 0, 0};  // most keys a unit of 2^f buckets stages
@@ -635,6 +637,8 @@ struct BmLaunch {
     bool pad = false;  // the units' runs on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): tile stride TILE + BM_PAD_ROOM
     bool w8 = false;   // 8-bit counts between the search and the un-permute kernel (padded layout, cell images)
     bool wide = false; // the cell images are offset cells (sparse indexes)
+    bool tot = false;  // total-only batch on cell images: the walk keeps the totals, no slots, no counts, no un-permute (bw_search_kernel<.., TOT>)
+    unsigned long long *tot_slots = nullptr;  // ... its partial totals [segments][PT_SLOTS]
     unsigned *descent = nullptr;  // no order check in this pass: bm_params_kernel's probe raises this word when it sees a descent
     unsigned *xcd_next = nullptr;  // eight item counters of the persistent search, zeroed with the partial totals
     // the parameter block written by the tile sort's first workgroup (count_bitmap.hpp: bm_write_params) instead of bm_params_kernel
@@ -661,7 +665,13 @@ static int bm_launch_tiles(const BmLaunch &L, hipStream_t st, bool sub = false)
         BXMI_LAUNCH_CHECK();
         return BXMI_OK;
     }
-    if (L.pad) {
+    if (L.pad && L.tot) {
+        const size_t lds = (size_t)(TILE + 3 * THREADS) * 4 + BM_NB * 4 + BM_NB * 2 + 64;
+        BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, true, 1, true>), lds));
+        hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, true, 1, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
+                           h->bm_recs.as<unsigned>(), h->bm_slots.as<unsigned short>(), h->bm_tbl.as<unsigned short>(), L.gate, h->bd_tend.as<unsigned>(),
+                           (unsigned short *)nullptr, L.par, L.npar, L.par_out, h->bm_tesc.as<unsigned>());
+    } else if (L.pad) {
         const size_t lds = (size_t)(TILE + 3 * THREADS) * 4 + BM_NB * 4 + BM_NB * 2 + 64;
         BXMI_TRY(allow_big_lds((bm_tile_sort_kernel<THREADS, ITEMS, true>), lds));
         hipLaunchKernelGGL((bm_tile_sort_kernel<THREADS, ITEMS, true>), dim3((unsigned)L.ntp), dim3(THREADS), lds, st, L.segs, L.tile_seg,
@@ -764,16 +774,16 @@ static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
 }
 
 // the persistent walk on cell images (count_dense.hpp, bw_*): one workgroup per CU, items handed out per XCD
-template <bool W8, bool WIDE>
+template <bool W8, bool WIDE, bool TOT = false>
 static int bw_launch_search(const BmLaunch &L, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
     constexpr int THREADS = WIDE ? BD_THREADS / 2 : BD_THREADS;  // offset cells: two workgroups per CU
     constexpr int DEPTH = 3;  // (offset cells with rings of 2 / 3 / 4: genome pass 0.719 / 0.722 / 0.705 ms, an eighth of it 0.150 / 0.150 / 0.152)
-    BXMI_TRY(allow_big_lds((bw_search_kernel<W8, DEPTH, WIDE, THREADS>), L.search_lds));
-    hipLaunchKernelGGL((bw_search_kernel<W8, DEPTH, WIDE, THREADS>), dim3(WIDE ? 512 : 256), dim3(THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+    BXMI_TRY(allow_big_lds((bw_search_kernel<W8, DEPTH, WIDE, THREADS, TOT>), L.search_lds));
+    hipLaunchKernelGGL((bw_search_kernel<W8, DEPTH, WIDE, THREADS, TOT>), dim3(WIDE ? 512 : 256), dim3(THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
                        h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(), h->bd_cnt16.as<unsigned short>(),
-                       L.tile_log2, L.gate, L.xcd_next);
+                       L.tile_log2, L.gate, L.xcd_next, L.tot_slots);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
 }
@@ -787,6 +797,7 @@ static int bd_launch_search(const BmLaunch &L, unsigned grid, int fmt /* 0 dense
 {
     if (fmt == 1) {
         if (!L.pad) return fail(BXMI_ESTATE, "bd_launch_search: cell images on packed runs");
+        if (L.tot) return L.wide ? bw_launch_search<false, true, true>(L, st) : bw_launch_search<false, false, true>(L, st);
         if (L.wide) return L.w8 ? bw_launch_search<true, true>(L, st) : bw_launch_search<false, true>(L, st);
         return L.w8 ? bw_launch_search<true, false>(L, st) : bw_launch_search<false, false>(L, st);
     }
@@ -927,6 +938,10 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     bool pad = kind == 3 || cells;
     for (int i = 0; i < n && pad; i++) pad = (1 << segs[(size_t)i].g.f) >= (variant == 0 ? 4 : 2);
     const int64_t tile_stride = tile + (pad ? BM_PAD_ROOM : 0);
+    // nobody wants counts, only totals, and the persistent walk serves the batch: it keeps the totals itself (bw_search_kernel<.., TOT>)
+    bool tot_walk = g_opt_tot_walk != 0 && cells && pad && !fx && any_total;
+    for (int i = 0; i < n && tot_walk; i++) tot_walk = counts[i] == nullptr;
+    if (tot_walk) BXMI_TRY(h->bm_tesc.reserve((size_t)ntp * 4));
     BXMI_TRY(h->bm_recs.reserve((size_t)ntp * tile_stride * 4));
     if (pad) BXMI_TRY(h->bd_tend.reserve((size_t)ntp * 4));
     BXMI_TRY(h->bm_slots.reserve((size_t)ntp * tile * 2));
@@ -1043,6 +1058,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.wide = wide;
     L.xcd_next = reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS + 4);
     L.n_segs = n;
+    L.tot = tot_walk, L.tot_slots = slots;
     // 8-bit counts (0xFF = recomputed by the un-permute kernel, exact either way): half the bytes of the second exchange
     // when the counts are small.  Cell images only serve indexes without piled-up coordinates, so the density says what to
     // expect: fewer than 128 targets per 2048 coordinates (configs[1]: 82; a count of 255 needs a query of ~6000).  What the
@@ -1051,7 +1067,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.w8 = false;
     // (a batch over several indexes -- a genome -- keeps the feedback with its first index: every index has to be sparse enough,
     // none may have switched the narrow counts off)
-    if (pad && cells && g_opt_bd_w8 != 0) {
+    if (pad && cells && g_opt_bd_w8 != 0 && !tot_walk) {  // (a total-only walk stores no counts at all)
         BXMI_TRY(ensure_feedback(h, st));
         const unsigned long long wide_counts = *reinterpret_cast<volatile unsigned long long *>(h->bd_fb_host);
         if ((int64_t)wide_counts * 64 > h->w8_queries && wide_counts > 4096) h->w8_off = true;
@@ -1159,6 +1175,11 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
                            chunk, h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     }
     BXMI_LAUNCH_CHECK();
+    if (tot_walk) {  // the queries behind escape records: answered from the index, tile by tile (none in an ordinary batch)
+        hipLaunchKernelGGL(bm_escape_totals_kernel, dim3((unsigned)ntp), dim3(1024), 0, st, L.segs, L.tile_seg, h->bm_tesc.as<unsigned>(), ntp,
+                           tile_log2, slots, unsorted);
+        BXMI_LAUNCH_CHECK();
+    }
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
     if (slices_flat)
         BXMI_TRY(bd_launch_search(L, sgrid, 2, false, st));
@@ -1176,7 +1197,9 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     } else
         BXMI_TRY(bd_launch_search(L, sgrid, cells ? 1 : 0, any_blocks, st));
     unsigned *loff = fx ? h->sl_loff.as<unsigned>() : nullptr;
-    if (dense && !fxsub) {
+    if (tot_walk) {
+        // (the walk has added every tile's share to the partial totals: nothing to put back into query order)
+    } else if (dense && !fxsub) {
         if (variant == 2)
             BXMI_TRY((bd_launch_unpermute<1024, 32>(L, tslots, st)));
         else

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs only the count kernel a few times (profiling target).  MODE=random|sorted|bucket8, NQ, REPS; NOTOTAL=1: no overlap total asked for."""
+"""Runs only the count kernel a few times (profiling target).  MODE=random|sorted|bucket8, NQ, REPS; NOTOTAL=1: no overlap total asked for; NOCOUNTS=1: the total only."""
 import os
 import sys
 
@@ -34,12 +34,13 @@ counts = torch.empty(NQ, dtype=torch.int32, device="cuda")
 total = torch.zeros(1, dtype=torch.int64, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 tptr = None if os.environ.get("NOTOTAL") else total.data_ptr()
+cptr = None if os.environ.get("NOCOUNTS") else counts.data_ptr()  # NOCOUNTS=1: a total-only batch
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-ix.count_dev(qs.data_ptr(), qe.data_ptr(), NQ, counts.data_ptr(), tptr, stream)
+ix.count_dev(qs.data_ptr(), qe.data_ptr(), NQ, cptr, tptr, stream)
 torch.cuda.synchronize()
 e0.record()
 for _ in range(REPS):
-    ix.count_dev(qs.data_ptr(), qe.data_ptr(), NQ, counts.data_ptr(), tptr, stream)
+    ix.count_dev(qs.data_ptr(), qe.data_ptr(), NQ, cptr, tptr, stream)
 e1.record()
 torch.cuda.synchronize()
 print("MODE=%s NQ=%d  %.3f ms/launch  total=%d" % (MODE, NQ, e0.elapsed_time(e1) / REPS, int(total.item()) // (REPS + 1)))

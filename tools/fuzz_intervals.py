@@ -85,6 +85,14 @@ for r in range(rounds):
         opt("ivl.sl_lanes", knobs["lanes"])
         opt("ivl.sorted_path", knobs["sorted_path"])
         got_c, got_t = ix.count(qs, qe)
+        # the same batch asking for the TOTAL only (counts = NULL): on cell images the walk keeps the totals itself (ivl.tot_walk)
+        opt("ivl.tot_walk", int(rng.integers(0, 2)))
+        only_t = ix.count(qs, qe, want_counts=False)[1]
+        opt("ivl.tot_walk", 1)
+        if only_t != want_t:
+            print("TOTAL-ONLY MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells, bitmap=bitmap, slices=slices, flat=flat,
+                                                       dense=dense, sparse=sparse, **knobs), ix.flat_state(), ix.sparse_state(), only_t, want_t)
+            sys.exit(1)
         if not np.array_equal(got_c, want_c) or got_t != want_t:
             bad = np.nonzero(got_c != want_c)[0][:5]
             print("MISMATCH round", r, dict(n=n, nq=nq, span=span, lmax=lmax, clump=clump, part=part, cells=cells, bitmap=bitmap, slices=slices, flat=flat, dense=dense,

@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 REPO=$PWD
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps ${BENCH_STEPS:-5} --warmup 2 --no-cpu-baseline --no-sorted --no-find --no-bitset --no-genome"
+CMD="python $REPO/bench.py --steps ${BENCH_STEPS:-5} --warmup 2 --no-cpu-baseline --no-sorted --no-find --no-bitset --no-genome --no-pcie"
 export PROFILE_CMD="${CMD/$REPO\//}"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/prof_stats -o stats --output-format csv -- $CMD > $REPO/gpurun_out/prof_stats.json 2> $REPO/gpurun_out/prof_stats.err
