@@ -704,9 +704,41 @@ __device__ __forceinline__ int bm_escape_count(const IndexDev &ix, const int32_t
     return count_one_global(ix, e_sorted, qs, qe);
 }
 
+// #{a[i] < key}, a sorted, by ALL 64 lanes of a wave together (uniform arguments): 64 probes per step narrow the range 65-fold, so
+// 10 M keys are three steps and a last look at <= 64 neighbours -- four round trips to HBM where a lane's own binary search
+// is twenty-four.  Two arrays of one length side by side (their loads travel together).
+__device__ __forceinline__ void bm_wave_rank2_lt(const int32_t *__restrict__ a, int keyA, const int32_t *__restrict__ b, int keyB, int n, int &rankA, int &rankB)
+{
+    const int lane = lane_id();
+    int loA = 0, hiA = n, loB = 0, hiB = n;  // everything below lo is < key, everything from hi on is >= key
+    while (hiA - loA > 64 || hiB - loB > 64) {
+        const int stepA = (hiA - loA + 64) / 65, stepB = (hiB - loB + 64) / 65;
+        const long long pA = (long long)loA + (long long)(lane + 1) * stepA - 1, pB = (long long)loB + (long long)(lane + 1) * stepB - 1;
+        const bool inA = hiA - loA > 64 && pA < hiA, inB = hiB - loB > 64 && pB < hiB;
+        const int vA = inA ? a[pA] : INT_MAX, vB = inB ? b[pB] : INT_MAX;
+        const int kA = __popcll(__ballot(inA && vA < keyA)), kB = __popcll(__ballot(inB && vB < keyB));  // (sorted: the first k probes)
+        if (hiA - loA > 64) {
+            const long long probe_k = (long long)loA + (long long)(kA + 1) * stepA - 1;  // the first probe that is not below the key, if it lies in the range
+            if (probe_k < hiA) hiA = (int)probe_k;
+            loA += kA * stepA;
+        }
+        if (hiB - loB > 64) {
+            const long long probe_k = (long long)loB + (long long)(kB + 1) * stepB - 1;
+            if (probe_k < hiB) hiB = (int)probe_k;
+            loB += kB * stepB;
+        }
+    }
+    const bool ltA = loA + lane < hiA && a[loA + lane] < keyA, ltB = loB + lane < hiB && b[loB + lane] < keyB;
+    rankA = loA + __popcll(__ballot(ltA)), rankB = loB + __popcll(__ballot(ltB));
+}
+
 // A total-only batch on cell images (the search keeps the totals itself, nothing is put back into query order): the queries the
 // images cannot answer -- improper, off the grid, longer than a record holds -- are answered here from the sealed index, tile by
 // tile; a tile the tile sort found no escape record in (tesc[tile] == 0: every tile of an ordinary batch) costs one load.
+// A handful of escapes (a uniform batch: the queries that start below the first target) are answered one by one by the whole
+// wave (bm_wave_rank2_lt); a wave that meets many, or an improper query (a window scan), lets every lane answer its own.
+// (Tried in round 6: the same work at the end of the tile sort itself, on the queries still in registers -- the registers cost the
+// kernel 280 -> 378 us; out of line and re-reading the tile -- the call's spills 404 us.)
 __global__ __launch_bounds__(1024) void bm_escape_totals_kernel(const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,
                                                                 const unsigned *__restrict__ tesc, int64_t ntp, int tile_log2,
                                                                 unsigned long long *__restrict__ total_slots /* [segments][PT_SLOTS] */,
@@ -720,20 +752,50 @@ __global__ __launch_bounds__(1024) void bm_escape_totals_kernel(const BmSeg *__r
     const int64_t ltile = tile - sg.tile0;
     if (ltile >= sg.ntiles || tesc[tile] == 0u) return;  // (uniform)
     const BmGeom g = sg.g;
+    const IndexDev ix = sg.ix;
+    const int32_t *__restrict__ e_sorted = sg.e_sorted;
     const int64_t q0 = ltile << tile_log2;
     const int64_t left = sg.nq - q0;
     const int n = (int)(left < ((int64_t)1 << tile_log2) ? left : (int64_t)1 << tile_log2);
     long long acc = 0;
-    auto one = [&](int s, int e) {
-        if (bm_record_of(s, e, g) == BM_REC_ESC) acc += (long long)bm_escape_count(sg.ix, sg.e_sorted, g, s, e);
+    // every lane of the wave comes here together (`live` says whether the lane holds a query): ballots and shuffles inside
+    auto one = [&](bool live, int s, int e) {
+        const bool esc = live && bm_record_of(s, e, g) == BM_REC_ESC;
+        const unsigned long long m = __ballot(esc);
+        if (m == 0ull) return;
+        if (__popcll(m) > 8 || __any(esc && s >= e)) {  // many, or a zero-length / reversed query: lane by lane
+            if (esc) acc += (long long)bm_escape_count(ix, e_sorted, g, s, e);
+            return;
+        }
+        for (unsigned long long rest = m; rest; rest &= rest - 1ull) {
+            const int src = __ffsll((long long)rest) - 1;
+            const int S = __shfl(s, src, 64), E = __shfl(e, src, 64);
+            if (E <= g.cmin || S >= g.cmax) continue;  // (bm_escape_count: nothing out there)
+            int rS, rE;
+            bm_wave_rank2_lt(ix.s_ord, E, e_sorted, S + 1, ix.n, rS, rE);  // (S < E: S is not INT_MAX)
+            if (lane_id() == 0) acc += (long long)(rS - rE);
+        }
     };
     const int n4 = n >> 2;  // (the query arrays are 16-byte aligned and a tile starts on a multiple of its size)
     const int4 *__restrict__ s4 = reinterpret_cast<const int4 *>(sg.qs + q0), *__restrict__ e4 = reinterpret_cast<const int4 *>(sg.qe + q0);
-    for (int k = threadIdx.x; k < n4; k += 1024) {
-        const int4 vs = s4[k], ve = e4[k];
-        one(vs.x, ve.x), one(vs.y, ve.y), one(vs.z, ve.z), one(vs.w, ve.w);
+    for (int k0 = 0; k0 < n4; k0 += 8 * 1024) {  // (a tile of 32768 queries: one round, all sixteen loads of a lane in flight together)
+        int4 vs[8], ve[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int k = k0 + u * 1024 + (int)threadIdx.x;
+            vs[u] = s4[k < n4 ? k : 0], ve[u] = e4[k < n4 ? k : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const bool live = k0 + u * 1024 + (int)threadIdx.x < n4;
+            one(live, vs[u].x, ve[u].x), one(live, vs[u].y, ve[u].y), one(live, vs[u].z, ve[u].z), one(live, vs[u].w, ve[u].w);
+        }
     }
-    for (int k = 4 * n4 + (int)threadIdx.x; k < n; k += 1024) one(sg.qs[q0 + k], sg.qe[q0 + k]);
+    for (int k0 = 4 * n4; k0 < n; k0 += 1024) {  // (uniform trip count: the lanes past the end come along "not live")
+        const int k = k0 + (int)threadIdx.x;
+        const bool live = k < n;
+        one(live, live ? sg.qs[q0 + k] : 0, live ? sg.qe[q0 + k] : 0);
+    }
     block_accumulate_i64(acc, red, total_slots + (int64_t)seg * PT_SLOTS + (tile & (PT_SLOTS - 1)));
 }
 

@@ -1147,6 +1147,14 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         BXMI_TRY((bm_launch_tiles<1024, 16>(L, st, fxsub)));
     else
         BXMI_TRY((bm_launch_tiles<512, 32>(L, st)));
+    if (tot_walk) {
+        // the queries behind escape records, answered from the index tile by tile (none in most batches): behind the tile sort, which
+        // flags the tiles and whose first workgroup has zeroed the partial totals.  (On a stream of its own between the tile sort
+        // and the fold, beside the run table, the plan and the walk: 0.499 against 0.503 ms per pass -- not worth a second stream.)
+        hipLaunchKernelGGL(bm_escape_totals_kernel, dim3((unsigned)ntp), dim3(1024), 0, st, L.segs, L.tile_seg, h->bm_tesc.as<unsigned>(), ntp, tile_log2, slots,
+                           unsorted);
+        BXMI_LAUNCH_CHECK();
+    }
     if (fxsub) {  // the half-bucket run table, half-major (nobody needs its group counts: the fill has its own plan)
         hipLaunchKernelGGL(bm_transpose_kernel<FX_NBK>, dim3((unsigned)ngroups, FX_NBK / 64), dim3(256), 0, st, h->fx_tbl2.as<unsigned short>(), L.segs,
                            L.tile_seg, tile_log2, h->fx_runT2.as<unsigned>(), ntp, (unsigned *)nullptr, unsorted);
@@ -1175,11 +1183,6 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
                            chunk, h->bm_items.as<int4>() + 1, h->bm_items.as<int>(), unsorted);
     }
     BXMI_LAUNCH_CHECK();
-    if (tot_walk) {  // the queries behind escape records: answered from the index, tile by tile (none in an ordinary batch)
-        hipLaunchKernelGGL(bm_escape_totals_kernel, dim3((unsigned)ntp), dim3(1024), 0, st, L.segs, L.tile_seg, h->bm_tesc.as<unsigned>(), ntp,
-                           tile_log2, slots, unsorted);
-        BXMI_LAUNCH_CHECK();
-    }
     const unsigned sgrid = (unsigned)(div_up(max_items, 8) * 8);
     if (slices_flat)
         BXMI_TRY(bd_launch_search(L, sgrid, 2, false, st));

@@ -60,6 +60,19 @@ for world in [int(w) for w in os.environ.get("WORLDS", "1,2,4,8").split(",")]:
 
     ms = timed(step)
     out[world] = dict(chromosomes=len(mine), queries=int(sum(x.numel() for x in qs)), ms=round(ms, 4))
+
+    def step_total():  # the per-chromosome TOTALS only (configs[3]: "RCCL all-reduce on counts"): nothing stored per query
+        IntervalIndex.count_multi_dev(ixs, [x.data_ptr() for x in qs], [x.data_ptr() for x in qe], [x.numel() for x in qs], [None] * len(mine),
+                                      [tot[i:].data_ptr() for i in range(len(mine))], stream)
+
+    tot.zero_()
+    step()
+    want = tot.clone()
+    tot.zero_()
+    step_total()
+    torch.cuda.synchronize()
+    assert torch.equal(tot, want), (tot, want)
+    out[world]["ms_total_only"] = round(timed(step_total), 4)
     if os.environ.get("PLAIN_ONLY"):  # (profiling runs: only the shuffled share's steady-state passes in the kernel list)
         for ix in ixs:
             ix.close()
@@ -94,4 +107,5 @@ for w in out:
     if "ms_with_allreduce_world_of_one" in out[w]:
         out[w]["speedup_with_allreduce_world_of_one"] = round(base / out[w]["ms_with_allreduce_world_of_one"], 2)
     out[w]["speedup_sorted_vs_sorted"] = round(out[min(out)]["ms_sorted_queries"] / out[w]["ms_sorted_queries"], 2)
+    out[w]["speedup_total_only"] = round(out[min(out)]["ms_total_only"] / out[w]["ms_total_only"], 2)
 print(json.dumps(out))
