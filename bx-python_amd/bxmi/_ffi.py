@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbxmi.so")
+LIB_PATH = os.environ.get("BXMI_LIB") or os.path.join(_HERE, "libbxmi.so")  # (BXMI_LIB: another build of the same library, A/B runs of experiments)
 
 OK, EINVAL, ENOMEM, EHIP, ESTATE, ERANGE = 0, 1, 2, 3, 4, 5
 

@@ -3,8 +3,8 @@
 # hipcc cross-compiles without a GPU; the .so travels to the GPU box with gpurun.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="$HERE/../bxmi/libbxmi.so"
-OBJ="$HERE/_obj"
+OUT="${BXMI_OUT:-$HERE/../bxmi/libbxmi.so}"   # BXMI_OUT + BXMI_DEFS: an experiment's build beside the shipped one (objects under _obj_<name>)
+OBJ="$HERE/_obj${BXMI_OBJ_SUFFIX:-}"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 ${BXMI_DEFS:-} -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${BXMI_EXTRA_FLAGS:-}"
 mkdir -p "$OBJ"

@@ -715,7 +715,86 @@ constexpr int LC_CHUNK = LC_THREADS * LC_ITEMS;  // 4096 consecutive queries per
 #ifndef LC_TREE_LOG2
 #define LC_TREE_LOG2 12
 #endif
-constexpr int LC_TREE_KEYS = (1 << LC_TREE_LOG2) - 1;  // two trees of 4096 slots = 32 KiB of LDS: four workgroups per CU
+constexpr int LC_TREE_KEYS = (1 << LC_TREE_LOG2) - 1;  // (round 5's layout: two Eytzinger trees of 4096 slots = 32 KiB of LDS, four workgroups per CU)
+#ifndef LC_EXP
+#define LC_EXP 0  // diagnostics (compile time, wrong results): bit 0 = no walks inside the cells, 1 = no interior table fill, 2 = no pop pass, 3 = no head / tail fill
+#endif
+// Round 6: the chunk's two slices lie in LDS as they are (sorted, an INT_MAX fence behind each) under a table of LC_NC equal
+// coordinate cells -- cs[c] = keys in the cells below c -- so a rank is one table read and a walk of as many steps as the fullest
+// cell's bit length (three or four at one key per cell) where the tree took twelve dependent reads: the searches were 300 of the
+// kernel's 470 us on configs[4] (LC_EXP = 1).  The idea is this file's own direct addressing (cells_stage), built per chunk.
+#ifndef LC_KEYS_V
+#define LC_KEYS_V 4352
+#endif
+#ifndef LC_NC_LOG2_V
+#define LC_NC_LOG2_V 10
+#endif
+#ifndef LC_WAVES_V
+#define LC_WAVES_V 8
+#endif
+constexpr int LC_KEYS = LC_KEYS_V;                 // keys (or samples) of one staged slice, at most
+constexpr int LC_NC_LOG2 = LC_NC_LOG2_V;
+constexpr int LC_NC = (1 << LC_NC_LOG2) + (1 << (LC_NC_LOG2 - 3));  // cells per table (a map's width is rounded up to a power of two: the tail is room)
+constexpr int LC_CS_INTS = (LC_NC + 2) / 2;        // one 16-bit table, in ints
+constexpr int LC_LDS_INTS = 2 * (LC_KEYS + PC_PAD) + 2 * LC_CS_INTS;  // 39.4 KiB: four workgroups per CU (4608 keys + 2304 cells, three per CU: 398 us against 332)
+
+// cells_stage for a chunk's TWO slices at once (LC_THREADS threads, LC_NC cells each): m = n / stride samples of each linearly with an
+// INT_MAX fence behind them -- all loads of both slices in flight together -- then cs[c] = samples in the cells below c; the bit
+// lengths of the two fullest cells (= the steps of a walk inside a cell) come back in stepsE / stepsS.  Four barriers
+// (slice by slice, as cells_stage does it for a bucket image, the chunk paid ten and two round trips to HBM: 26 us per chunk).
+__device__ __forceinline__ void lc_cells_stage2(int32_t *arrE, unsigned short *csE, const int32_t *__restrict__ srcE, int nE, int strideE, CellMap cmE,
+                                                int32_t *arrS, unsigned short *csS, const int32_t *__restrict__ srcS, int nS, int strideS, CellMap cmS,
+                                                int *s_red /* [2][LC_THREADS / 64] */, int &stepsE, int &stepsS)
+{
+    const int mE = nE / strideE, mS = nS / strideS;
+    for (int r = threadIdx.x; r < mE; r += LC_THREADS) arrE[r] = srcE[(r + 1) * strideE - 1];
+    for (int r = threadIdx.x; r < mS; r += LC_THREADS) arrS[r] = srcS[(r + 1) * strideS - 1];
+    if (threadIdx.x < PC_PAD) arrE[mE + threadIdx.x] = INT_MAX, arrS[mS + threadIdx.x] = INT_MAX;
+    __syncthreads();
+    // element r opens every cell in (cell(arr[r-1]), cell(arr[r])]; the cells up to the first key's and behind the last key's --
+    // a map's width is a power of two: up to half the table -- are filled by everybody (one thread walking them alone was
+    // 10 us of every chunk)
+    {
+        const int firstE = mE ? cell_of(arrE[0], cmE) : LC_NC - 1, lastE = mE ? cell_of(arrE[mE - 1], cmE) : LC_NC - 1;
+        const int firstS = mS ? cell_of(arrS[0], cmS) : LC_NC - 1, lastS = mS ? cell_of(arrS[mS - 1], cmS) : LC_NC - 1;
+        for (int c = threadIdx.x; c < ((LC_EXP & 8) ? 0 : LC_NC); c += LC_THREADS) {
+            if (c <= firstE) csE[c] = 0;
+            else if (c > lastE) csE[c] = (unsigned short)mE;
+            if (c <= firstS) csS[c] = 0;
+            else if (c > lastS) csS[c] = (unsigned short)mS;
+        }
+    }
+    // (measured and not kept: a thread's LDS reads of this pass issued together, the element before r from the neighbouring lane --
+    // the registers spill and the walks pay: 335 -> 452 us for the kernel)
+    for (int r = 1 + (int)threadIdx.x; r < ((LC_EXP & 2) ? 0 : mE); r += LC_THREADS) {
+        const int cp = cell_of(arrE[r - 1], cmE), cr = cell_of(arrE[r], cmE);
+        for (int c = cp + 1; c <= cr; c++) csE[c] = (unsigned short)r;
+    }
+    for (int r = 1 + (int)threadIdx.x; r < ((LC_EXP & 2) ? 0 : mS); r += LC_THREADS) {
+        const int cp = cell_of(arrS[r - 1], cmS), cr = cell_of(arrS[r], cmS);
+        for (int c = cp + 1; c <= cr; c++) csS[c] = (unsigned short)r;
+    }
+    __syncthreads();
+    if (LC_EXP & 4) {
+        stepsE = stepsS = 4;
+        return;
+    }
+    int popE = 0, popS = 0;
+    for (int c = threadIdx.x; c < LC_NC; c += LC_THREADS) {
+        const int pE = (c + 1 < LC_NC ? (int)csE[c + 1] : mE) - (int)csE[c], pS = (c + 1 < LC_NC ? (int)csS[c + 1] : mS) - (int)csS[c];
+        popE = pE > popE ? pE : popE, popS = pS > popS ? pS : popS;
+    }
+    popE = wave_max_i32(popE), popS = wave_max_i32(popS);
+    if (lane_id() == 0) s_red[threadIdx.x >> 6] = popE, s_red[LC_THREADS / 64 + (threadIdx.x >> 6)] = popS;
+    __syncthreads();
+    popE = popS = 0;
+#pragma unroll
+    for (int i = 0; i < LC_THREADS / 64; i++) {
+        popE = s_red[i] > popE ? s_red[i] : popE;
+        popS = s_red[LC_THREADS / 64 + i] > popS ? s_red[LC_THREADS / 64 + i] : popS;
+    }
+    stepsE = 32 - __clz(popE), stepsS = 32 - __clz(popS);  // 0 for an empty slice
+}
 
 // One chunk of LC_CHUNK consecutive queries from `base` on: the workgroup's queries are k = j * LC_THREADS + thread, and
 // emit(j, k, live, count, #{start < qe}, qs) is called once per (thread, j) with j a compile-time constant after unrolling.
@@ -767,6 +846,7 @@ __device__ __forceinline__ void lc_chunk_counts(const TreeDev &S, const TreeDev 
             if (sub == 0 && threadIdx.x < 32) {
                 s_slice[(starts ? 2 : 0) + upper] = r;
                 if (starts) s_slice[4 + upper] = upper ? s_hi_key : a;
+                if (!starts && upper) s_slice[6] = b;  // the chunk's largest qs: the ends' slice reaches that far
             }
         }
 #else
@@ -780,82 +860,114 @@ __device__ __forceinline__ void lc_chunk_counts(const TreeDev &S, const TreeDev 
             s_slice[0 + upper] = rE[0];
             s_slice[2 + upper] = rS[0];
             s_slice[4 + upper] = upper ? s_hi_key : a;
+            if (upper) s_slice[6] = b;
         }
 #endif
     }
     __syncthreads();
-    const int eLo = s_slice[0], eHi = s_slice[1], sLo = s_slice[2], sHi = s_slice[3], qeLo = s_slice[4], qeHi = s_slice[5];
+    const int eLo = s_slice[0], eHi = s_slice[1], sLo = s_slice[2], sHi = s_slice[3], qeLo = s_slice[4], qeHi = s_slice[5], qsHi = s_slice[6];
     const int nE = eHi - eLo, nS = sHi - sLo;
-    const int strideE = nE / LC_TREE_KEYS + 1, strideS = nS / LC_TREE_KEYS + 1;
-    int kE = 0, kS = 0;
-    while ((1 << kE) - 1 < nE / strideE) kE++;
-    while ((1 << kS) - 1 < nS / strideS) kS++;
-    int32_t *treeE = lds, *treeS = lds + (1 << kE);
-    {
-        const int total = (1 << kE) + (1 << kS);
-        for (int i = threadIdx.x; i < total; i += LC_THREADS) lds[i] = INT_MAX;
-        __syncthreads();
-        part_stage_tree<LC_THREADS>(treeE, kE, e_sorted + eLo, nE, strideE);
-        part_stage_tree<LC_THREADS>(treeS, kS, ix.s_ord + sLo, nS, strideS);
-    }
-    __syncthreads();
+    const int strideE = nE / LC_KEYS + 1, strideS = nS / LC_KEYS + 1;
+    const int mE = nE / strideE, mS = nS / strideS;
+    // the ends of the slice lie in (qeLo, qsHi], the starts in [qeLo, qeHi): one map each, cells of a power of two
+    auto map_of = [](int lo, int hi) {
+        CellMap cm;
+        cm.lo = lo;
+        const unsigned span = (unsigned)hi - (unsigned)lo;
+        cm.cshift = span >> LC_NC_LOG2 ? 32 - __clz(span >> LC_NC_LOG2) : 0;
+        const long long top = (long long)lo + ((long long)LC_NC << cm.cshift) - 1;
+        cm.hi = top > INT_MAX ? INT_MAX : (int)top;
+        return cm;
+    };
+    const CellMap cmE = map_of(qeLo, qsHi), cmS = map_of(qeLo, qeHi);
+    unsigned short *csE = reinterpret_cast<unsigned short *>(lds), *csS = reinterpret_cast<unsigned short *>(lds + LC_CS_INTS);
+    int32_t *arrE = lds + 2 * LC_CS_INTS, *arrS = arrE + mE + PC_PAD;
+    int stepsE, stepsS;
+    lc_cells_stage2(arrE, csE, e_sorted + eLo, nE, strideE, cmE, arrS, csS, ix.s_ord + sLo, nS, strideS, cmS, &s_mm[0][0], stepsE, stepsS);
+    const lds_i32p aE = (lds_i32p)arrE, aS = (lds_i32p)arrS;
+    const lds_u16p cE = (lds_u16p)csE, cS = (lds_u16p)csS;
+    const bool fenced = stepsE <= 6 && stepsS <= 6;  // every probe stays inside the INT_MAX fence
+    const bool unsampled = strideS == 1 && strideE == 1;
+    const int cconst = (sLo - eLo) - (int)(aS - aE);
+    const unsigned qe_span = (unsigned)qeHi - (unsigned)qeLo;
 #pragma unroll
     for (int j0 = 0; j0 < LC_ITEMS; j0 += PT_ILP) {
-        int rS[PT_ILP], rE[PT_ILP];
-#pragma unroll
-        for (int j = 0; j < PT_ILP; j++) rS[j] = rE[j] = 1;
-        for (int it = 0; it < kS; it++) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) rS[j] = 2 * rS[j] + (treeS[rS[j]] < qe[j0 + j]);
-        }
-        for (int it = 0; it < kE; it++) {
-#pragma unroll
-            for (int j = 0; j < PT_ILP; j++) rE[j] = 2 * rE[j] + (treeE[rE[j]] <= qs[j0 + j] && qs[j0 + j] != INT_MAX);
-        }
+        lds_i32p pS[PT_ILP], pE[PT_ILP];
 #pragma unroll
         for (int j = 0; j < PT_ILP; j++) {
-            rS[j] = (rS[j] - (1 << kS)) * strideS;
-            rE[j] = (rE[j] - (1 << kE)) * strideE;
+            pS[j] = aS + cS[cell_of(qe[j0 + j], cmS)] - 1;  // the last key known to be below the probe
+            pE[j] = aE + cE[cell_of(qs[j0 + j], cmE)] - 1;
         }
-        if (strideS > 1) {
+        if ((LC_EXP & 1) == 0) {
+            // only keys of the probe's own cell can still qualify, everything in later cells is larger, the fence stops the walk
+            if (fenced) {
+                for (int st = stepsS - 1; st >= 0; st--) {
 #pragma unroll
-            for (int j = 0; j < PT_ILP; j++) {
-                int hi = rS[j] + strideS < nS ? rS[j] + strideS : nS;
-                rS[j] = group_rank_lt(ix.s_ord + sLo, rS[j], hi, qe[j0 + j]);
-            }
-        }
-        if (strideE > 1) {
+                    for (int j = 0; j < PT_ILP; j++) {
+                        const lds_i32p t = pS[j] + (1 << st);
+                        pS[j] = *t < qe[j0 + j] ? t : pS[j];
+                    }
+                }
+                for (int st = stepsE - 1; st >= 0; st--) {
 #pragma unroll
-            for (int j = 0; j < PT_ILP; j++) {
-                int hi = rE[j] + strideE < nE ? rE[j] + strideE : nE;
-                rE[j] = qs[j0 + j] == INT_MAX ? 0 : group_rank_lt(e_sorted + eLo, rE[j], hi, qs[j0 + j] + 1);
+                    for (int j = 0; j < PT_ILP; j++) {
+                        const lds_i32p t = pE[j] + (1 << st);
+                        pE[j] = *t <= qs[j0 + j] ? t : pE[j];  // (qs == INT_MAX passes the fence: handled below)
+                    }
+                }
+            } else {
+                const lds_i32p endS = aS + mS, endE = aE + mE;
+                for (int st = stepsS - 1; st >= 0; st--) {
+#pragma unroll
+                    for (int j = 0; j < PT_ILP; j++) {
+                        lds_i32p t = pS[j] + (1 << st);
+                        t = t < endS ? t : endS;
+                        pS[j] = *t < qe[j0 + j] ? t : pS[j];
+                    }
+                }
+                for (int st = stepsE - 1; st >= 0; st--) {
+#pragma unroll
+                    for (int j = 0; j < PT_ILP; j++) {
+                        lds_i32p t = pE[j] + (1 << st);
+                        t = t < endE ? t : endE;
+                        pE[j] = *t <= qs[j0 + j] ? t : pE[j];
+                    }
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < PT_ILP; j++) {
             const int k = (j0 + j) * LC_THREADS + threadIdx.x;
             const bool live = k < n;
-            int c = 0, s_rank = 0;
             const int s = qs[j0 + j], e = qe[j0 + j];
-            if (live) {
-                const bool in_slice = e >= qeLo && e <= qeHi;
-                s_rank = in_slice ? sLo + rS[j] : global_rank_lt(ix.s_ord, 0, ix.n, e);
+            int rS = (int)(pS[j] - aS) + 1, rE = (int)(pE[j] - aE) + 1;  // staged keys (samples) below the probe
+            int c = (int)(pS[j] - pE[j]) + cconst;                        // (sLo + #starts < qe) - (eLo + #ends <= qs)
+            int s_rank = sLo + rS;
+            const bool in_slice = (unsigned)e - (unsigned)qeLo <= qe_span;
+            if (live && !(unsampled && s < e && in_slice)) {
+                // sampled slices: each rank finished inside its group; qe outside the slice: a global search;
+                // a zero-length / reversed query: the exact predicate over the candidate window
+                rS *= strideS, rE *= strideE;
+                if (strideS > 1) rS = group_rank_lt(ix.s_ord + sLo, rS, rS + strideS < nS ? rS + strideS : nS, e);
+                if (strideE > 1 && s != INT_MAX) rE = group_rank_lt(e_sorted + eLo, rE, rE + strideE < nE ? rE + strideE : nE, s + 1);
+                s_rank = in_slice ? sLo + rS : global_rank_lt(ix.s_ord, 0, ix.n, e);
                 if (s < e) {
-                    const int e_rank = s == INT_MAX ? ix.n : eLo + rE[j];
-                    c = s_rank - e_rank;
-                } else {  // zero-length / reversed query: exact predicate over the candidate window
-                    int lo = first_pm_gt(ix.pm, ix.n, s);
+                    c = s_rank - (eLo + rE);  // (s < e rules out s == INT_MAX)
+                } else {
+                    const int lo = first_pm_gt(ix.pm, ix.n, s);
+                    c = 0;
                     for (int t = lo; t < s_rank; t++) c += ix.e_ord[t] > s;
                 }
             }
+            if (!live) c = 0, s_rank = 0;
+            if (LC_EXP & 1) c = 0, s_rank = sLo;  // (diagnostics: nothing found, every rank inside the index)
             emit(j0 + j, k, live, c, s_rank, s);
         }
     }
 }
 
-// (eight waves per SIMD = four workgroups per CU: the kernel lives on the chunks it keeps in flight -- said out loud, the compiler
-// took 70 registers for a build that needed 64)
-__global__ __launch_bounds__(LC_THREADS) __attribute__((amdgpu_waves_per_eu(8))) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
+// (eight waves per SIMD = four workgroups per CU: the kernel lives on the chunks it keeps in flight; 62 registers)
+__global__ __launch_bounds__(LC_THREADS) __attribute__((amdgpu_waves_per_eu(LC_WAVES_V))) void ivl_local_count_kernel(TreeDev S, TreeDev E, IndexDev ix, const int32_t *__restrict__ e_sorted,
                                                                      const int32_t *__restrict__ qs_arr,
                                                                      const int32_t *__restrict__ qe_arr, int64_t nq,
                                                                      int32_t *__restrict__ counts /* may be NULL */,
@@ -865,9 +977,9 @@ __global__ __launch_bounds__(LC_THREADS) __attribute__((amdgpu_waves_per_eu(8)))
                                                                      unsigned long long *__restrict__ order_host = nullptr, unsigned long long seq = 0,
                                                                      unsigned long long *__restrict__ chunk_tot = nullptr /* find(): the sum of every chunk's counts */)
 {
-    __shared__ __attribute__((aligned(16))) int32_t lds[2 * (LC_TREE_KEYS + 1)];
+    __shared__ __attribute__((aligned(16))) int32_t lds[LC_LDS_INTS];
     __shared__ int s_mm[3][LC_THREADS / 64];
-    __shared__ int s_slice[6];  // eLo, eHi, sLo, sHi, qeLo, qeHi
+    __shared__ int s_slice[8];  // eLo, eHi, sLo, sHi, qeLo, qeHi, the largest qs
     __shared__ long long red[LC_THREADS / 64];
     __shared__ long long red2[LC_THREADS / 64];
     // what the order check found, into host memory: the host picks the shape of THIS kernel for later batches by it
