@@ -278,7 +278,9 @@ struct BpLayout {
 
 // cell_log2: 5 = bitmap cells; 6..8 = offset cells (offset_cells.hpp: same 8 bytes per cell, same header, a smaller overflow
 // area; the starts' margin is the longest query the record format holds)
-__host__ __device__ inline BpLayout bp_layout(int unit_log2, int cell_log2 = 5)
+// bytes16 (offset cells only): the image's size in 16-byte pieces when the index keeps RANK TABLES for its hard cells in a large
+// overflow area ("clumped" offset cells, bo_image_kernel<.., TABLES>: duplicate-heavy data); 0 = the standard overflow area
+__host__ __device__ inline BpLayout bp_layout(int unit_log2, int cell_log2 = 5, int bytes16 = 0)
 {
     BpLayout L;
     const int UW = 1 << unit_log2;
@@ -290,6 +292,7 @@ __host__ __device__ inline BpLayout bp_layout(int unit_log2, int cell_log2 = 5)
     L.hdr = (L.cellsS + L.ncs * 8 + 15) & ~15;  // header: [0] eLo, [1] sLo, [2..3] first coordinate of the unit (int64)
     L.ov = L.hdr + 16;                          // the hard cells' tables, 64 bytes each
     L.bytes = L.ov + (cell_log2 == 5 ? BP_TABLES : BO_TABLES) * 64;
+    if (bytes16 && cell_log2 != 5) L.bytes = bytes16 << 4;
     return L;
 }
 
@@ -400,6 +403,14 @@ __global__ __launch_bounds__(BD_THREADS) void bp_image_kernel(const int32_t *__r
 // every cell counted with LDS atomics, a block scan for the cells' bases, then every cell packs its (at most five) keys
 // straight from the sorted array; cells with more keys get a list in the overflow area while it has room.
 // stats: [0] hard cells, [1] units whose slice holds 2^20 keys or more
+// TABLES ("clumped" offset cells, round 6): every hard cell gets a RANK TABLE in the image's overflow area -- T[p] = keys of the cell
+// below position p, a byte each (16 bits each for a cell of 256 keys and more) -- instead of a list of <= 64 offsets: a rank in a
+// hard cell is then one more LDS read whatever the cell holds, and duplicate-heavy indexes (everything around a few thousand
+// hot spots: hundreds of keys in a cell) can take the persistent walk.  The area is as large as the LDS allows (g.stride carries
+// the image's size); stats[2] counts the cells that found no room -- such an index does not qualify.
+// low word of a hard cell: byte offset of its table | BO_TABLE (| BO_TABLE_WIDE: 16-bit entries).
+constexpr unsigned BO_TABLE = 0x40000000u, BO_TABLE_WIDE = 0x80000000u;
+template <bool TABLES = false>
 __global__ __launch_bounds__(BD_THREADS) void bo_image_kernel(const int32_t *__restrict__ s_ord, const int32_t *__restrict__ e_sorted, int n,
                                                               BmGeom g, unsigned char *__restrict__ images, unsigned *__restrict__ stats)
 {
@@ -411,11 +422,11 @@ __global__ __launch_bounds__(BD_THREADS) void bo_image_kernel(const int32_t *__r
     const int unit = blockIdx.x;
     const int k = 5 + g.dshift;
     const int ulog = g.shift + g.f;
-    const BpLayout L = bp_layout(ulog, k);
+    const BpLayout L = bp_layout(ulog, k, TABLES ? g.stride : 0);
     const long long UW = 1ll << ulog;
     const long long lo = (long long)g.cmin + (long long)unit * UW;
     unsigned char *__restrict__ img = images + (size_t)unit * L.bytes;
-    unsigned hard = 0;
+    unsigned hard = 0, homeless = 0;
     int r0s[2];
     for (int arr = 0; arr < 2; arr++) {
         const int32_t *__restrict__ A = arr == 0 ? e_sorted : s_ord;
@@ -452,7 +463,24 @@ __global__ __launch_bounds__(BD_THREADS) void bo_image_kernel(const int32_t *__r
             } else {
                 hard++;
                 lo_w = BP_NO_TABLE, hi_w = ((unsigned)base & 0xFFFFFu) | BO_HARD;
-                if (m <= BO_LIST) {
+                if (TABLES) {
+                    const bool wide = m >= 256;
+                    const int bytes = (wide ? 2 : 1) << k;  // (a multiple of 64: the area stays 16-byte aligned)
+                    const int at = m <= 65535 ? atomicAdd(&s_ntab, bytes) : L.bytes;  // (a table's entries are 16 bits at most: a bigger pile finds no room)
+                    if (L.ov + at + bytes <= L.bytes) {
+                        lo_w = (unsigned)(L.ov + at) | BO_TABLE | (wide ? BO_TABLE_WIDE : 0u);
+                        int i = 0;
+                        for (int p = 0; p < (1 << k); p++) {
+                            while (i < m && (long long)keys[i] - cell0 < (long long)p) i++;
+                            if (wide)
+                                reinterpret_cast<unsigned short *>(img + L.ov + at)[p] = (unsigned short)i;
+                            else
+                                img[L.ov + at + p] = (unsigned char)i;
+                        }
+                    } else {
+                        homeless++;
+                    }
+                } else if (m <= BO_LIST) {
                     const int slot = atomicAdd(&s_ntab, 1);
                     if (slot < BO_TABLES) {
                         lo_w = (unsigned)(L.ov + slot * 64);
@@ -468,6 +496,7 @@ __global__ __launch_bounds__(BD_THREADS) void bo_image_kernel(const int32_t *__r
         __syncthreads();
     }
     if (hard) atomicAdd(&stats[0], hard);
+    if (homeless) atomicAdd(&stats[2], homeless);
     if (threadIdx.x == 0) {
         unsigned *hdr = reinterpret_cast<unsigned *>(img + L.hdr);
         hdr[0] = (unsigned)r0s[0], hdr[1] = (unsigned)r0s[1];
@@ -1211,6 +1240,10 @@ __device__ __forceinline__ int bo_hard_rank(const BdImage &I, lds_cell_p cells, 
     const unsigned ci = rel >> I.cell_log2, p = rel & I.cell_mask;
     const bd_v2u c = __builtin_bit_cast(bd_v2u, cells[ci]);
     const unsigned base = c.y & 0xFFFFFu, next = (unsigned)(cells[ci + 1u] >> 32) & 0xFFFFFu;  // (every cell carries its base, hard or not)
+    if (c.x != BP_NO_TABLE && (c.x & BO_TABLE)) {  // a rank table (clumped offset cells): one read
+        const unsigned at = c.x & 0x3FFFFFFFu;
+        return (int)(base + ((c.x & BO_TABLE_WIDE) ? (unsigned)I.img16[(at >> 1) + p] : (unsigned)I.img8[at + p]));
+    }
     if (c.x != BP_NO_TABLE) {
         unsigned r = base;
         for (unsigned i = 0; i < next - base; i++) r += (unsigned)I.img8[c.x + i] < p ? 1u : 0u;
@@ -1238,7 +1271,7 @@ __device__ __forceinline__ unsigned bo_count_record(const BdImage &I, unsigned r
 
 // the four counts of a slot: all eight cells read before the first is used, hard cells noticed once per slot (bp_count_slot's shape)
 template <bool RAW = false>
-__device__ __forceinline__ void bo_count_slot(const BdImage &I, bd_v4u v, unsigned (&c)[4])
+__device__ __forceinline__ void bo_count_slot_lists(const BdImage &I, bd_v4u v, unsigned (&c)[4])
 {
     const unsigned rec[4] = {v.x, v.y, v.z, v.w};
     unsigned relE[4], relS[4];
@@ -1265,6 +1298,63 @@ __device__ __forceinline__ void bo_count_slot(const BdImage &I, bd_v4u v, unsign
             const unsigned mE = __builtin_bit_cast(bd_v2u, cellE[j]).y, mS = __builtin_bit_cast(bd_v2u, cellS[j]).y;
             if ((mE > mS ? mE : mS) >= BO_HARD) c[j] = bo_count_record<RAW>(I, rec[j]);
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (RAW) {
+            c[j] = rec[j] == BM_REC_ESC ? 0u : c[j];
+        } else {
+            c[j] = c[j] < 0xFFFFu ? c[j] : 0xFFFFu;
+            c[j] = rec[j] == BM_REC_ESC ? 0xFFFFu : c[j];
+        }
+    }
+}
+
+// TAB: the image is in the clumped layout (hard cells carry rank tables); the standard layout keeps round 5's shape (bo_count_slot_lists)
+template <bool RAW = false, bool TAB = false>
+__device__ __forceinline__ void bo_count_slot(const BdImage &I, bd_v4u v, unsigned (&c)[4])
+{
+    if (!TAB) {
+        bo_count_slot_lists<RAW>(I, v, c);
+        return;
+    }
+    const unsigned rec[4] = {v.x, v.y, v.z, v.w};
+    unsigned relE[4], relS[4];
+    unsigned long long cellE[4], cellS[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const unsigned off = rec[j] & I.off_mask;
+        relE[j] = off + 1u, relS[j] = off + (rec[j] >> I.rshift);
+        cellE[j] = I.cE[relE[j] >> I.cell_log2];
+        cellS[j] = I.cS[relS[j] >> I.cell_log2];
+    }
+    // a hard cell with a RANK TABLE (clumped layout: the rule around a hot spot) is answered in line -- one more LDS read, no second
+    // pass over the record; what is left for the slow path are lists and cells without room (standard layout: rare)
+    auto rank_of = [&](bd_v2u cell, unsigned p, bool &slow) -> unsigned {
+        unsigned r = bo_rank(cell.x, cell.y, p);
+        const bool hard = cell.y >= BO_HARD;
+        const bool tab = hard && cell.x != BP_NO_TABLE && (cell.x & BO_TABLE) != 0u;
+        if (tab) {
+            const unsigned at = cell.x & 0x3FFFFFFFu;
+            r = (cell.y & 0xFFFFFu) + ((cell.x & BO_TABLE_WIDE) ? (unsigned)I.img16[(at >> 1) + p] : (unsigned)I.img8[at + p]);
+        }
+        slow |= hard && !tab;
+        return r;
+    };
+    bool any_slow = false;
+    bool slow[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const bd_v2u ce = __builtin_bit_cast(bd_v2u, cellE[j]), cs = __builtin_bit_cast(bd_v2u, cellS[j]);
+        slow[j] = false;
+        const unsigned rE = rank_of(ce, relE[j] & I.cell_mask, slow[j]), rS = rank_of(cs, relS[j] & I.cell_mask, slow[j]);
+        c[j] = (unsigned)I.bias + (rS - rE);
+        any_slow |= slow[j];
+    }
+    if (any_slow) {  // a list or a cell without room among the eight: those records again, one by one
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (slow[j]) c[j] = bo_count_record<true>(I, rec[j]);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -1347,7 +1437,7 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
         }
         const BmGeom g = sg.g;
         const int cell_log2 = WIDE ? 5 + g.dshift : 5;
-        const BpLayout LP = bp_layout(g.shift + g.f, cell_log2);
+        const BpLayout LP = bp_layout(g.shift + g.f, cell_log2, WIDE ? g.stride : 0);
         const unsigned short *__restrict__ runs0 = unitT + (int64_t)unit * ntp;
         const unsigned short *__restrict__ runs1 = runs0 + ntp;  // (the next unit's first slots, or the row behind the last unit)
         int B = BW_B;
@@ -1445,7 +1535,7 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
                         for (unsigned q = first >> 2; q < ((first + (e - a) + 3u) >> 2); q++) {
                             unsigned c[4];
                             if (WIDE)
-                                bo_count_slot<true>(I, reinterpret_cast<const bd_v4u *>(recs)[q], c);
+                                bo_count_slot<true, THREADS == BD_THREADS>(I, reinterpret_cast<const bd_v4u *>(recs)[q], c);
                             else
                                 bp_count_slot<true>(I, reinterpret_cast<const bd_v4u *>(recs)[q], c);
                             acc += (unsigned long long)c[0] + c[1] + c[2] + c[3];
@@ -1526,7 +1616,7 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
                         if (BW_EXP & 1)
                             c[0] = rv.x & 0xffu, c[1] = rv.y & 0xffu, c[2] = rv.z & 0xffu, c[3] = rv.w & 0xffu;
                         else if (WIDE)
-                            bo_count_slot<TOT>(I, rv, c);
+                            bo_count_slot<TOT, THREADS == BD_THREADS>(I, rv, c);
                         else
                             bp_count_slot<TOT>(I, rv, c);
                         if (TOT) acc += (unsigned long long)c[0] + c[1] + c[2] + c[3];
@@ -1553,7 +1643,7 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
                 for (unsigned q = threadIdx.x; q < nq4; q += THREADS) {
                     unsigned c[4];
                     if (WIDE)
-                        bo_count_slot<TOT>(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
+                        bo_count_slot<TOT, THREADS == BD_THREADS>(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
                     else
                         bp_count_slot<TOT>(I, reinterpret_cast<const bd_v4u *>(recs)[q0 + q], c);
                     if (TOT) acc += (unsigned long long)c[0] + c[1] + c[2] + c[3];
@@ -1709,7 +1799,7 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(const BmSeg *__restric
         const BmSeg &sg = segs[seg];
         const BmGeom g = sg.g;
         const int cell_log2 = WIDE ? 5 + g.dshift : 5;
-        const BpLayout LP = bp_layout(g.shift + g.f, cell_log2);
+        const BpLayout LP = bp_layout(g.shift + g.f, cell_log2, WIDE ? g.stride : 0);
         if (threadIdx.x == 0) s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
         if (unit >= 0 && ((seg << 16) | unit) != loaded) {  // (the barrier at the end of the item before: nobody reads the old image any more)
             const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.pimages + (size_t)unit * LP.bytes);
@@ -1777,7 +1867,7 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(const BmSeg *__restric
                     rec.x = bm_record_of(s[u][0], e[u][0], g), rec.y = bm_record_of(s[u][1], e[u][1], g);
                     rec.z = bm_record_of(s[u][2], e[u][2], g), rec.w = bm_record_of(s[u][3], e[u][3], g);
                     if (WIDE)
-                        bo_count_slot(I, rec, c);
+                        bo_count_slot<false, THREADS == BD_THREADS>(I, rec, c);
                     else
                         bp_count_slot(I, rec, c);
                 } else {

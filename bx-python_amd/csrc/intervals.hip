@@ -81,6 +81,7 @@ static int64_t g_opt_bd_table_from = 0;  // dense images: overflow entries from 
 static int64_t g_opt_bd_blocks = 0;   // 1 = dense images with block-relative ranks even where unit-relative ones fit (tests)
 static int64_t g_opt_bd_w8 = -1;      // 8-bit counts out of place: -1 = by index and feedback, 0 = never, 1 = whenever the layout allows
 static int64_t g_opt_order_skip = -1;  // -1 = stop launching the order check after two batches in a row were not sorted (a probe of 8192 starts rides on the parameter kernel then), 0 = always check
+static int64_t g_opt_clumped = -1;     // offset cells with a rank table per hard cell for duplicate-heavy indexes: -1 / 1 = where bitmap cells do not qualify and the tables fit, 0 = never (dense unit images)
 static int64_t g_opt_tot_walk = 1;     // total-only batches on cell images: 1 = the walk keeps the totals itself (no slots, no count stores, no un-permute kernel), 0 = the counts pass without its stores
 static int64_t g_opt_host_chunk = 8 << 20;  // queries per chunk of the host-pointer count (upload of chunk k+1 / pass on k / download of k-1 at once); 0 = one piece
 static int64_t g_opt_host_touchers = 2;  // host threads that touch the output array's pages ahead of the downloads (0 = the download faults them in)
@@ -118,6 +119,7 @@ static const IvlOpt IVL_OPTS[] = {
     {"ivl.bd_table_from", &g_opt_bd_table_from, [](int64_t value) -> int64_t { return value < 1 || value > 64 ? 0 : value; }},
     {"ivl.bd_w8", &g_opt_bd_w8, nullptr},
     {"ivl.order_skip", &g_opt_order_skip, nullptr},
+    {"ivl.clumped", &g_opt_clumped, nullptr},
     {"ivl.tot_walk", &g_opt_tot_walk, [](int64_t value) -> int64_t { return value != 0; }},
     {"ivl.host_chunk", &g_opt_host_chunk, [](int64_t value) -> int64_t { return value <= 0 ? 0 : ((value + 4095) & ~(int64_t)4095); }},
     {"ivl.host_touchers", &g_opt_host_touchers, [](int64_t value) -> int64_t { return value < 0 ? 0 : (value > 16 ? 16 : value); }},
@@ -192,7 +194,9 @@ struct bxmi_ivl {
     int64_t bp_hard_cells = 0;
     BmGeom bp_geom{0, 0, 0, 0, 0, 0, 0, BP_RSHIFT, 0};
     DevBuf bp_images, bp_stats;
-    int bo_state = 0;            // offset-cell images of units (sparse indexes): 0 = not decided yet, 1 = built and the index qualifies, -1 = it does not
+    int bo_state = 0;            // offset-cell images of units: 0 = not decided yet, 1 = built (standard layout: sparse indexes) and the index qualifies, 2 = built
+                                 // with a rank table per hard cell (clumped layout: duplicate-heavy indexes), -1 = neither
+    bool bo_tried_clumped = false;
     int64_t bo_hard_cells = 0;
     BmGeom bo_geom{0, 0, 0, 0, 0, 0, 0, BP_RSHIFT, 0};  // dshift = cell width - 5
     DevBuf bo_images;
@@ -478,12 +482,17 @@ static int bp_prepare_index(bxmi_ivl *h, hipStream_t st)
 
 // Offset-cell images (offset_cells.hpp) for a sparse index: the cell width from the density, units of 4096 cells (fewer when the
 // span is small: a unit is at most 2^BD_MAX_F buckets), built once per sealed index.
-static int bo_prepare_index(bxmi_ivl *h, hipStream_t st)
+// Offset-cell images of an index, once per sealed index.  Two layouts:
+//   standard  sparse indexes (about one key per cell): 72 KB per unit, hard cells (> 5 keys) rare and kept as lists -- bo_state = 1;
+//   clumped   (round 6) duplicate-heavy indexes that bitmap cells refuse: cells of 64 coordinates, EVERY hard cell with a rank
+//             table, the overflow area as large as one CU's LDS allows (a unit image of 147 KB, one 1024-thread workgroup per
+//             CU) -- bo_state = 2 when every hard cell found room.
+static int bo_prepare_index(bxmi_ivl *h, hipStream_t st, bool clumped = false)
 {
     h->bo_state = -1;
     const int shift = h->geom.shift;
     int64_t span = (int64_t)h->cmax - (int64_t)h->geom.cmin + 1;
-    const int k = g_opt_bo_cell_log2 ? (int)g_opt_bo_cell_log2 : bo_cell_log2_for(span, h->n);
+    const int k = g_opt_bo_cell_log2 ? (int)g_opt_bo_cell_log2 : (clumped ? BO_MIN_K : bo_cell_log2_for(span, h->n));
     // (units of at least two buckets, as for bitmap cells: the tile sort can then start every unit's run on a whole slot)
     if (h->has_reversed || h->n < 4096 || k == 0 || shift > bo_rshift(k) - 1 || shift < BM_MIN_SHIFT) return BXMI_OK;
     BmGeom g;
@@ -494,7 +503,9 @@ static int bo_prepare_index(bxmi_ivl *h, hipStream_t st)
     g.f = f > BD_MAX_F ? BD_MAX_F : f;
     g.rshift = bo_rshift(k);
     g.dshift = k - 5;
-    const BpLayout L = bp_layout(g.shift + g.f, k);
+    const int big16 = BW_PF * BD_THREADS;  // what the 1024-thread walk loads: 9 x 1024 pieces of 16 bytes
+    const BpLayout L = bp_layout(g.shift + g.f, k, clumped ? big16 : 0);
+    if (clumped && L.ov + 4096 > L.bytes) return BXMI_OK;  // (no room for tables worth the name)
     g.nce = L.nce, g.ncs = L.ncs;
     g.stride = L.bytes >> 4;
     const int units = BM_NB >> g.f;
@@ -502,17 +513,26 @@ static int bo_prepare_index(bxmi_ivl *h, hipStream_t st)
     BXMI_TRY(h->bp_stats.reserve(64));
     BXMI_HIP(hipMemsetAsync(h->bp_stats.p, 0, 64, st));
     const size_t lds = (size_t)L.ncs * sizeof(int32_t);
-    BXMI_TRY(allow_big_lds(bo_image_kernel, lds));
-    hipLaunchKernelGGL(bo_image_kernel, dim3((unsigned)units), dim3(BD_THREADS), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n, g,
-                       h->bo_images.as<unsigned char>(), h->bp_stats.as<unsigned>());
+    if (clumped) {
+        BXMI_TRY(allow_big_lds(bo_image_kernel<true>, lds));
+        hipLaunchKernelGGL(bo_image_kernel<true>, dim3((unsigned)units), dim3(BD_THREADS), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n, g,
+                           h->bo_images.as<unsigned char>(), h->bp_stats.as<unsigned>());
+    } else {
+        BXMI_TRY(allow_big_lds(bo_image_kernel<false>, lds));
+        hipLaunchKernelGGL(bo_image_kernel<false>, dim3((unsigned)units), dim3(BD_THREADS), lds, st, h->s_ord.as<int32_t>(), h->e_sorted.as<int32_t>(), (int)h->n, g,
+                           h->bo_images.as<unsigned char>(), h->bp_stats.as<unsigned>());
+    }
     BXMI_LAUNCH_CHECK();
-    unsigned stats[2] = {0, 0};
+    unsigned stats[3] = {0, 0, 0};
     BXMI_HIP(hipMemcpyAsync(stats, h->bp_stats.p, sizeof(stats), hipMemcpyDeviceToHost, st));
     BXMI_HIP(hipStreamSynchronize(st));
     h->bo_geom = g;
     h->bo_hard_cells = stats[0];
     const int64_t cells = 2 * ((span >> k) + 1);  // cells that queries can land in: the span of the index, ends and starts
-    if (stats[1] == 0 && (int64_t)stats[0] * 1000000 <= cells * g_opt_bm_hard_ppm) h->bo_state = 1;
+    if (clumped) {
+        if (stats[1] == 0 && stats[2] == 0) h->bo_state = 2;
+    } else if (stats[1] == 0 && (int64_t)stats[0] * 1000000 <= cells * g_opt_bm_hard_ppm)
+        h->bo_state = 1;
     return BXMI_OK;
 }
 
@@ -637,6 +657,7 @@ struct BmLaunch {
     bool pad = false;  // the units' runs on whole 16-byte slots (bm_tile_sort_kernel<.., PAD>): tile stride TILE + BM_PAD_ROOM
     bool w8 = false;   // 8-bit counts between the search and the un-permute kernel (padded layout, cell images)
     bool wide = false; // the cell images are offset cells (sparse indexes)
+    bool big = false;  // ... in the clumped layout (a unit image beyond 80 KB: one 1024-thread workgroup per CU)
     bool tot = false;  // total-only batch on cell images: the walk keeps the totals, no slots, no counts, no un-permute (bw_search_kernel<.., TOT>)
     unsigned long long *tot_slots = nullptr;  // ... its partial totals [segments][PT_SLOTS]
     unsigned *descent = nullptr;  // no order check in this pass: bm_params_kernel's probe raises this word when it sees a descent
@@ -774,14 +795,14 @@ static int bd_launch_search_t(const BmLaunch &L, unsigned grid, hipStream_t st)
 }
 
 // the persistent walk on cell images (count_dense.hpp, bw_*): one workgroup per CU, items handed out per XCD
-template <bool W8, bool WIDE, bool TOT = false>
+template <bool W8, bool WIDE, bool TOT = false, bool BIG = false>
 static int bw_launch_search(const BmLaunch &L, hipStream_t st)
 {
     bxmi_ivl *h = L.owner;
-    constexpr int THREADS = WIDE ? BD_THREADS / 2 : BD_THREADS;  // offset cells: two workgroups per CU
+    constexpr int THREADS = WIDE && !BIG ? BD_THREADS / 2 : BD_THREADS;  // offset cells: two workgroups per CU (the clumped layout: one)
     constexpr int DEPTH = 3;  // (offset cells with rings of 2 / 3 / 4: genome pass 0.719 / 0.722 / 0.705 ms, an eighth of it 0.150 / 0.150 / 0.152)
     BXMI_TRY(allow_big_lds((bw_search_kernel<W8, DEPTH, WIDE, THREADS, TOT>), L.search_lds));
-    hipLaunchKernelGGL((bw_search_kernel<W8, DEPTH, WIDE, THREADS, TOT>), dim3(WIDE ? 512 : 256), dim3(THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
+    hipLaunchKernelGGL((bw_search_kernel<W8, DEPTH, WIDE, THREADS, TOT>), dim3(WIDE && !BIG ? 512 : 256), dim3(THREADS), L.search_lds, st, L.segs, h->bm_items.as<int4>() + 1,
                        h->bm_items.as<int>(), h->bd_unitT.as<unsigned short>(), L.ntp, h->bm_recs.as<unsigned>(), h->bd_cnt16.as<unsigned short>(),
                        L.tile_log2, L.gate, L.xcd_next, L.tot_slots);
     BXMI_LAUNCH_CHECK();
@@ -797,13 +818,18 @@ static int bd_launch_search(const BmLaunch &L, unsigned grid, int fmt /* 0 dense
 {
     if (fmt == 1) {
         if (!L.pad) return fail(BXMI_ESTATE, "bd_launch_search: cell images on packed runs");
+        if (L.tot && L.big) return bw_launch_search<false, true, true, true>(L, st);
         if (L.tot) return L.wide ? bw_launch_search<false, true, true>(L, st) : bw_launch_search<false, false, true>(L, st);
+        if (L.big) return L.w8 ? bw_launch_search<true, true, false, true>(L, st) : bw_launch_search<false, true, false, true>(L, st);
         if (L.wide) return L.w8 ? bw_launch_search<true, true>(L, st) : bw_launch_search<false, true>(L, st);
         return L.w8 ? bw_launch_search<true, false>(L, st) : bw_launch_search<false, false>(L, st);
     }
     if (fmt == 2) return bd_launch_search_t<2, false, 0, 2, false>(L, grid, st);  // (never padded: see bm_count_segments)
-    if (L.pad) return blocks ? bd_launch_search_t<0, true, 0, 3, true, true>(L, grid, st) : bd_launch_search_t<0, false, 0, 3, true, true>(L, grid, st);
-    return blocks ? bd_launch_search_t<0, true, 0, 4, true>(L, grid, st) : bd_launch_search_t<0, false, 0, 4, true>(L, grid, st);
+#ifndef BD_EXP_V
+#define BD_EXP_V 0  // diagnostics (compile time, wrong results): 1 = the dense walk without its look-ups
+#endif
+    if (L.pad) return blocks ? bd_launch_search_t<0, true, BD_EXP_V, 3, true, true>(L, grid, st) : bd_launch_search_t<0, false, BD_EXP_V, 3, true, true>(L, grid, st);
+    return blocks ? bd_launch_search_t<0, true, BD_EXP_V, 4, true>(L, grid, st) : bd_launch_search_t<0, false, BD_EXP_V, 4, true>(L, grid, st);
 }
 
 template <int THREADS, int ITEMS>
@@ -1059,6 +1085,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
     L.xcd_next = reinterpret_cast<unsigned *>(slots + (size_t)n * PT_SLOTS + 4);
     L.n_segs = n;
     L.tot = tot_walk, L.tot_slots = slots;
+    L.big = wide && max_stride * 16 > (size_t)10 * (BD_THREADS / 2) * 16;  // (beyond what the 512-thread walk loads: 80 KB)
     // 8-bit counts (0xFF = recomputed by the un-permute kernel, exact either way): half the bytes of the second exchange
     // when the counts are small.  Cell images only serve indexes without piled-up coordinates, so the density says what to
     // expect: fewer than 128 targets per 2048 coordinates (configs[1]: 82; a count of 255 needs a query of ~6000).  What the
@@ -1075,6 +1102,7 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
         for (int i = 0; i < n; i++) {
             const int64_t span = (int64_t)hs[i]->cmax - (int64_t)hs[i]->geom.cmin + 1;
             narrow = narrow && !hs[i]->w8_off && (int64_t)hs[i]->n * 2048 < span * 128;
+            if (wide && hs[i]->bo_state == 2) narrow = false;  // (the clumped layout: hundreds of targets around every hot spot -- its first pass on 8-bit counts recomputed all of them: 24 ms)
         }
         L.w8 = g_opt_bd_w8 > 0 || narrow;
         if (L.w8) h->w8_queries += nq_all;
@@ -1099,7 +1127,11 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
             BXMI_HIP(hipMemsetAsync(n_sorted, 0, sizeof(int), st));
             hipLaunchKernelGGL(bs_check_multi_kernel, dim3((unsigned)(ntp < 2048 ? ntp : 2048)), dim3(256), 0, st, L.segs, L.tile_seg, ntp, tile_log2, unsorted, bounds_all);
             hipLaunchKernelGGL(bs_plan_multi_kernel, dim3((unsigned)n), dim3(1024), 0, st, L.segs, bounds_all, chunk, sorted_items, n_sorted, unsorted);
-            if (wide) {
+            if (wide && L.big) {
+                BXMI_TRY(allow_big_lds((bs_walk_kernel<true, BD_THREADS>), L.search_lds));
+                hipLaunchKernelGGL((bs_walk_kernel<true, BD_THREADS>), dim3(256), dim3(BD_THREADS), L.search_lds, st, L.segs, sorted_items, n_sorted, tslots,
+                                   unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
+            } else if (wide) {
                 BXMI_TRY(allow_big_lds((bs_walk_kernel<true, BD_THREADS / 2>), L.search_lds));
                 hipLaunchKernelGGL((bs_walk_kernel<true, BD_THREADS / 2>), dim3(512), dim3(BD_THREADS / 2), L.search_lds, st, L.segs, sorted_items, n_sorted, tslots,
                                    unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
@@ -1121,7 +1153,11 @@ static int bm_count_segments(bxmi_ivl *const *hs, int n, const int32_t *const *q
             int4 *sorted_items = reinterpret_cast<int4 *>(h->bs_plan.as<unsigned char>() + (((size_t)(units + 2) * 4 + 16 + 15) & ~(size_t)15));
             hipLaunchKernelGGL(bm_sorted_check_kernel<true>, dim3(2048), dim3(256), 0, st, qs[0], nq[0], unsorted, B);
             hipLaunchKernelGGL(bs_plan_kernel, dim3(1), dim3(1024), 0, st, B.bounds, units, (unsigned)nq[0], chunk, sorted_items, n_sorted, unsorted);
-            if (wide) {
+            if (wide && L.big) {
+                BXMI_TRY(allow_big_lds((bs_walk_kernel<true, BD_THREADS>), L.search_lds));
+                hipLaunchKernelGGL((bs_walk_kernel<true, BD_THREADS>), dim3(256), dim3(BD_THREADS), L.search_lds, st, L.segs, sorted_items, n_sorted, tslots,
+                                   unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
+            } else if (wide) {
                 BXMI_TRY(allow_big_lds((bs_walk_kernel<true, BD_THREADS / 2>), L.search_lds));
                 hipLaunchKernelGGL((bs_walk_kernel<true, BD_THREADS / 2>), dim3(512), dim3(BD_THREADS / 2), L.search_lds, st, L.segs, sorted_items, n_sorted, tslots,
                                    unsorted, L.xcd_next, h->bd_fb_host + 1, order_seq);
@@ -1378,6 +1414,21 @@ static int bm_choose_stage(bxmi_ivl *h, hipStream_t st, int *kind, int64_t nq)
             }
         }
     }
+    // duplicate-heavy indexes (bitmap cells refuse them): offset cells with a rank table per hard cell, if the tables fit the LDS
+    // (ivl.clumped: -1 = where bitmap cells do not qualify and no knob forces or forbids another stage, 0 = never, 1 = ahead of
+    // every other stage but the sparse one)
+    auto try_clumped = [&]() -> int {
+        if (h->bo_state == 0 || (h->bo_state == -1 && !h->bo_tried_clumped)) {
+            h->bo_tried_clumped = true;
+            BXMI_TRY(bo_prepare_index(h, st, true));
+        }
+        if (h->bo_state == 2) *kind = 5;
+        return BXMI_OK;
+    };
+    if (g_opt_clumped > 0 && g_opt_dense != 1) {
+        BXMI_TRY(try_clumped());
+        if (*kind) return BXMI_OK;
+    }
     const bool slices_first = g_opt_dense != 1 && g_opt_flat != 1 && (g_opt_slice == 1 || (g_opt_slice < 0 && (span / h->n >= 64 || h->geom.shift > BD_MAX_SHIFT)));
     if (slices_first) {
         if (h->sl_state == 0) BXMI_TRY(sl_prepare_index(h, st));
@@ -1393,6 +1444,8 @@ static int bm_choose_stage(bxmi_ivl *h, hipStream_t st, int *kind, int64_t nq)
             return BXMI_OK;
         }
     }
+    if (g_opt_clumped < 0 && g_opt_flat != 0 && h->bp_state == -1 && g_opt_dense < 0 && g_opt_sparse != 0 && g_opt_slice < 1) BXMI_TRY(try_clumped());
+    if (*kind) return BXMI_OK;
     if (g_opt_dense != 0) {
         if (h->bd_state == 0) BXMI_TRY(bd_prepare_index(h, st));
         if (h->bd_state == 1) {
@@ -1555,7 +1608,7 @@ extern "C" int bxmi_ivl_seal(bxmi_ivl_t *h, void *stream)
         h->fx_state = 0, h->fx_pieces_f = -1;
         h->bd_state = 0;
         h->bp_state = 0;
-        h->bo_state = 0;
+        h->bo_state = 0, h->bo_tried_clumped = false;
         h->w8_off = false, h->w8_queries = 0;  // (the feedback of the 8-bit counts belongs to the index that was)
         if (h->bd_fb_host) {
             BXMI_HIP(hipMemsetAsync(h->bd_fb.p, 0, 64, st));
@@ -1609,7 +1662,7 @@ extern "C" int bxmi_ivl_sparse_state(const bxmi_ivl_t *h, int *state, int64_t *h
     BXMI_TRY(need_sealed(h, "bxmi_ivl_sparse_state"));
     if (state) *state = h->bo_state;
     if (hard_cells) *hard_cells = h->bo_hard_cells;
-    if (cell_log2) *cell_log2 = h->bo_state == 1 ? 5 + h->bo_geom.dshift : 0;
+    if (cell_log2) *cell_log2 = h->bo_state >= 1 ? 5 + h->bo_geom.dshift : 0;
     return BXMI_OK;
 }
 

@@ -460,7 +460,7 @@ def test_incremental_append_reseals(O, IntervalIndex):
         assert np.array_equal(ix.find(qs, qe)[1], t.find_batch(qs, qe)[1])
 
 
-@pytest.mark.parametrize("stage", ["slices", "dense", "flat", "sparse"])
+@pytest.mark.parametrize("stage", ["slices", "dense", "flat", "sparse", "clumped"])
 @pytest.mark.parametrize("shape", ["uniform", "sorted", "one_bucket", "messy", "ragged_tail", "dups"])
 def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
     """The large-batch count pass (count_bitmap.hpp, and its search stages count_slices.hpp and count_dense.hpp) against the oracle
@@ -536,6 +536,27 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
                 assert got_total == want_total
             if shape == "dups":
                 assert (state[1][1] > 100) if stage == "dense" else (state[1] > 0)  # overflow entries / hard cells
+            return
+        if stage == "clumped":
+            # offset cells in the CLUMPED layout (round 6: cells of 64 coordinates, every hard cell with a rank table -- bytes, or 16
+            # bits for the two piled-up cells of "dups" -- one 1024-thread workgroup per CU): tile shapes, work items of every
+            # size, both count widths, totals only
+            set_opt("ivl.clumped", 1)
+            set_opt("ivl.flat", 0)
+            for k, (variant, chunk, w8) in enumerate(((0, 0, 0), (1, 4096, 0), (2, 1 << 20, 1), (-1, 20000, -1), (2, 0, -1), (1, 65536, 1))):
+                set_opt("ivl.sorted_path", k % 2)
+                set_opt("ivl.bm_variant", variant)
+                set_opt("ivl.bd_chunk", chunk)
+                set_opt("ivl.bd_w8", w8)
+                got, got_total = ix.count(qs, qe)
+                state = ix.sparse_state()
+                assert state[0] == 2 and state[2] == 6 and ix.slice_state()[0] == 0 and ix.dense_state()[0] == 0, (state, ix.slice_state(), ix.dense_state())
+                bad = np.nonzero(got != want)[0]
+                assert len(bad) == 0, (shape, stage, variant, chunk, w8, state, bad[:8], qs[bad[:8]], qe[bad[:8]], got[bad[:8]], want[bad[:8]])
+                assert got_total == want_total
+                assert ix.count(qs, qe, want_counts=False)[1] == want_total
+            if shape == "dups":
+                assert state[1] > 0  # hard cells: every one of them tabled
             return
         if stage == "sparse":
             # offset-cell images (one target per 333 coordinates: cells of 256 by the density; narrower ones forced): tile shapes,
@@ -1142,9 +1163,9 @@ def test_count_width_feedback(O, IntervalIndex):
 
 def test_clustered_distribution_differential(O, IntervalIndex):
     """bxmi.synth.clustered (everything around hot spots, heavily duplicated coordinates) at 4 M queries x 1 M targets
-    against the oracle treap, through whatever large-batch stage serves such an index (the images refuse it -- too many
-    duplicated coordinates per cell -- key slices on the flat walk take it), in generated order and sorted by start, and
-    through the first-generation pass."""
+    against the oracle treap, through whatever large-batch stage serves such an index (bitmap cells refuse it -- too many
+    duplicated coordinates per cell; offset cells in the clumped layout take it since round 6, the dense unit images with
+    ivl.clumped = 0), in generated order and sorted by start, and through the first-generation pass."""
     (ts, te), (qs, qe) = synth.clustered(1_000_000, 4_000_000, hot_spots=2_000, genome=25_000_000)
     t = O.OracleIntervalTree()
     t.insert_many_arrays(ts, te)
@@ -1154,18 +1175,23 @@ def test_clustered_distribution_differential(O, IntervalIndex):
     want, _ = t.count_batch(qs[pick], qe[pick])
     ix = make_index(IntervalIndex, ts, te)
     got, got_total = ix.count(qs, qe)
-    stages = (ix.flat_state()[0], ix.dense_state()[0], 0, ix.slice_state()[0])
+    stages = (ix.flat_state()[0], ix.dense_state()[0], ix.sparse_state()[0], ix.slice_state()[0])
     bad = np.nonzero(got[pick] != want)[0]
     assert len(bad) == 0 and got_total == int(got.sum(dtype=np.int64)), (stages, bad[:8], qs[pick][bad[:8]], qe[pick][bad[:8]], got[pick][bad[:8]], want[bad[:8]])
-    assert stages[3] == 1 or stages[0] == 1 or stages[1] == 1, stages  # one of the exchange's search stages served it
+    # one of the exchange's search stages served it (round 6: offset cells in the clumped layout -- a rank table per hard cell)
+    assert stages[3] == 1 or stages[0] == 1 or stages[1] == 1 or stages[2] == 2, stages
     o = np.argsort(qs, kind="stable")
     got_s, got_s_total = ix.count(qs[o], qe[o])
     assert np.array_equal(got_s, got[o]) and got_s_total == got_total, "sorted by start"
-    set_opt("ivl.bitmap", 0)
     try:
+        set_opt("ivl.clumped", 0)
+        got_d, got_d_total = ix.count(qs, qe)
+        assert ix.dense_state()[0] == 1 or ix.slice_state()[0] == 1, (ix.dense_state(), ix.slice_state())
+        set_opt("ivl.bitmap", 0)
         got_1, got_1_total = ix.count(qs, qe)
     finally:
         reset_opts()
+    assert np.array_equal(got_d, got) and got_d_total == got_total, "dense unit images / key slices"
     assert np.array_equal(got_1, got) and got_1_total == got_total, "first-generation pass"
 
 
