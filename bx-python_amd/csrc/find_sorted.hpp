@@ -292,12 +292,34 @@ __device__ __forceinline__ void ff_load(const int2 *__restrict__ eid /* at index
 
 // One wave, 64 consecutive queries (a lane each: `c` hits to find below rank `hi`, its CSR offset `off`): see the kernel below.
 // wp / wh: the wave's LDS images of the pairs and of its stretch of the list; S: what ff_load brought for these queries.
+#ifndef FF_EARLY_FILL
+#define FF_EARLY_FILL 0  // 1: the fill of a sorted find() is launched before the host has read the total (intervals.hip: ivl_find_local)
+#endif
+#ifndef FF_WAVE_OFFS
+#define FF_WAVE_OFFS 0   // 1: a wave reads ONE CSR offset (its first query's) and scans its own counts; 0: every lane reads its query's offset
+#endif
+// `off`: FF_WAVE_OFFS = 0 the lane's own CSR offset; 1 the offset of the wave's FIRST query in every lane (one broadcast load) -- a
+// lane's place in the stretch is the prefix of the wave's counts, and only a stretch that does not fit the LDS image reads the
+// lanes' own offsets (`offs_q` = &offsets[this lane's query], dead lanes: any valid address).
 __device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *__restrict__ eid /* at index 0 */, const FfStage &S, int c, const int hi,
-                                             const int qs, const long long off, int32_t *__restrict__ hits)
+                                             const int qs, long long off, int32_t *__restrict__ hits, const long long *__restrict__ offs_q = nullptr)
 {
     const int lane = lane_id();
     int k = hi - 1;
     // the wave's stretch of the list: from its first query's offset, as long as the sum of its counts
+#if FF_WAVE_OFFS
+    const long long base_off = off;
+    // (counts clamped to "does not fit": 64 of them cannot overflow 32 bits, and a sum that fits is exact)
+    const unsigned nc = (unsigned)c <= (unsigned)FF_HITS ? (unsigned)c : (unsigned)FF_HITS + 1u;
+    const unsigned incl = wave_inclusive_sum_dpp(nc);
+    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    if (tot == 0u) return;  // (wave-uniform)
+    const bool flat = tot <= (unsigned)FF_HITS;
+    const int total = flat ? (int)tot : 0;
+    const int rel = flat ? (int)(incl - nc) : 0;
+    off = flat ? base_off + rel : *offs_q;  // (wave-uniform choice)
+    int32_t *__restrict__ dst = hits + off;
+#else
     const long long base_off = __shfl(off, 0, 64);
     long long total64 = c;
 #pragma unroll
@@ -307,6 +329,7 @@ __device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *
     const int total = flat ? (int)total64 : 0;
     const int rel = flat ? (int)(off - base_off) : 0;
     int32_t *__restrict__ dst = hits + off;
+#endif
     // the window of the pairs: FF_PAIRS below the highest hi of the wave
     const int kmax = S.kmax, wbase = S.wbase;
 #pragma unroll
@@ -370,8 +393,9 @@ __device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *
 
 __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2 *__restrict__ eid /* at index 0 */, const int32_t *__restrict__ qs_arr,
                                                                      int64_t nq, const int32_t *__restrict__ his, const int32_t *__restrict__ cnt,
-                                                                     const long long *__restrict__ offs, int32_t *__restrict__ hits)
+                                                                     const long long *__restrict__ offs, int32_t *__restrict__ hits, long long cap)
 {
+    if (offs[nq] > cap) return;  // (launched before the host knows the total, FF_EARLY_FILL: a list that does not fit is not written)
     __shared__ int2 s_pairs[FIND_THREADS / 64][FF_PAIRS];
     __shared__ int32_t s_hits[FIND_THREADS / 64][FF_HITS];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
@@ -387,7 +411,11 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
         const int64_t q = qb + lane;
         const bool live = q < q1;
         const int64_t qa = live ? q : q1 - 1;  // (a dead lane: valid addresses, no hits; its offset is the one behind the stretch's last query)
+#if FF_WAVE_OFFS
+        x.c = cnt[qa], x.hi = his[qa], x.qs = qs_arr[qa], x.off = offs[qb < q1 ? qb : q1 - 1];  // (one address for the wave: a broadcast)
+#else
         x.c = cnt[qa], x.hi = his[qa], x.qs = qs_arr[qa], x.off = offs[qa];
+#endif
         if (!live) x.c = 0;
     };
     if (q0 + 64 * wave >= q1) return;
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
         ff_load(eid, cur.c, cur.hi, S);
         Q nxt = cur;
         if (qb + FIND_THREADS < q1) load_q(qb + FIND_THREADS, nxt);  // the next batch's numbers travel while this one is walked
-        ff_wave_fill(s_pairs[wave], s_hits[wave], eid, S, cur.c, cur.hi, cur.qs, cur.off, hits);
+        ff_wave_fill(s_pairs[wave], s_hits[wave], eid, S, cur.c, cur.hi, cur.qs, cur.off, hits, offs + (qb + lane < q1 ? qb + lane : q1 - 1));
         cur = nxt;
     }
 }

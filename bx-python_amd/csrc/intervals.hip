@@ -381,6 +381,21 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
         BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
                                                                reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
     int64_t total = 0;
+#if FF_EARLY_FILL
+    // The fill is launched BEHIND the offsets without waiting for the host to learn the total (a round trip of ~25 us with the
+    // device idle): it reads the total itself and leaves the list alone when it does not fit the caller's buffer.
+    if (hits && cap > 0) {
+        BXMI_TRY(sl_ensure_eid(h, st));
+        hipLaunchKernelGGL(part_fill_flat_kernel, dim3(device_props().cus * 8), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq,
+                           h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (long long)cap);
+        BXMI_LAUNCH_CHECK();
+    }
+    BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
+    BXMI_HIP(hipStreamSynchronize(st));
+    if (total_host) *total_host = total;
+    if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
+    return BXMI_OK;
+#else
     BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
     BXMI_HIP(hipStreamSynchronize(st));
     if (total_host) *total_host = total;
@@ -388,9 +403,10 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     if (total == 0) return BXMI_OK;
     BXMI_TRY(sl_ensure_eid(h, st));
     hipLaunchKernelGGL(part_fill_flat_kernel, dim3(device_props().cus * 8), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq,
-                       h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits);
+                       h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (long long)cap);
     BXMI_LAUNCH_CHECK();
     return BXMI_OK;
+#endif
 }
 
 // Partitioned find(): same bucketing as the count path, then window+count per query in bucket order, counts gathered

@@ -29,6 +29,8 @@ rounds = int(os.environ.get("ROUNDS", 20))
 MAX_HITS = 20_000_000
 checked = 0
 sparse_served = 0
+clumped_served = 0
+was_clumped = False
 for r in range(rounds):
     n = int(rng.choice([5000, 20000, 100000, 400000]))
     nq = int(rng.choice([3000, 20000, 70000]))
@@ -43,7 +45,13 @@ for r in range(rounds):
     s = rng.integers(-span // 2, span // 2, size=n)
     if clump:  # a tenth of the targets piled on a small stretch (queries there see all of them)
         s[: n // 10] = rng.integers(0, max(span // 1000, 2), size=n // 10)
+    dups = not clump and rng.random() < 0.25
+    if dups:  # duplicate-heavy targets (what real BED tracks look like): starts drawn from n / 8 coordinates around hot spots
+        pool = np.sort(rng.integers(-span // 2, span // 2, size=max(n // 8, 16)))
+        s = pool[rng.integers(0, len(pool), size=n)]
     ln = rng.integers(0, lmax + 1, size=n)
+    if dups:
+        ln = rng.integers(0, lmax + 1, size=12)[rng.integers(0, 12, size=n)]  # a dozen lengths: the ends pile up too
     e = np.minimum(s + ln, 2**31 - 1)
     qs = rng.integers(-span // 2 - 10, span // 2 + 10, size=nq)
     qe = np.minimum(qs + rng.integers(0, 2 * lmax + 2, size=nq), 2**31 - 1)
@@ -63,11 +71,21 @@ for r in range(rounds):
     # on images first / slices first / slices only, each with random tile shapes, unit sizes and run widths
     # sparse = 1: offset-cell images whatever the density (with ivl.bm_hard_ppm opened up: cells with more than five keys, their
     # lists and the searches behind them are then the rule, not the exception)
+    # sparse = 2: offset cells in the CLUMPED layout (ivl.clumped = 1: a rank table per hard cell) wherever the tables fit the LDS
     for part, cells, bitmap, slices, flat, dense, sparse in ((0, 1, 0, 0, -1, -1, -1), (1, 1, 0, 0, -1, -1, -1), (1, 0, 0, 0, -1, -1, -1), (1, 1, -1, 0, 1, 1, -1),
                                                              (1, 1, -1, 0, 0, 1, -1), (1, 1, -1, -1, -1, -1, -1), (1, 1, -1, 1, 0, 0, -1), (1, 1, -1, 1, 0, 0, -1),
-                                                             (1, 1, -1, -1, 1, 1, -1), (1, 1, -1, -1, -1, -1, 1), (1, 1, -1, -1, -1, -1, 1)):
+                                                             (1, 1, -1, -1, 1, 1, -1), (1, 1, -1, -1, -1, -1, 1), (1, 1, -1, -1, -1, -1, 1),
+                                                             (1, 1, -1, -1, 0, -1, 2), (1, 1, -1, -1, -1, -1, 2)):
         knobs = dict(variant=int(rng.integers(-1, 3)), f=int(rng.integers(-1, 7)), lanes=int(rng.choice([0, 16, 64, 1])),
                      sorted_path=int(rng.integers(0, 2)), cell_log2=int(rng.choice([0, 6, 7, 8])))
+        opt("ivl.clumped", 1 if sparse == 2 else -1)
+        if sparse == 2:
+            sparse = -1
+            ix.seal()  # (the offset-cell images of a sealed index are built once, in one layout)
+            was_clumped = True
+        elif was_clumped:
+            ix.seal()
+            was_clumped = False
         opt("ivl.sparse", sparse)
         opt("ivl.bo_cell_log2", knobs["cell_log2"] if sparse == 1 else 0)
         opt("ivl.bm_hard_ppm", 1000000 if sparse == 1 and rng.random() < 0.7 else 2000)
@@ -85,6 +103,7 @@ for r in range(rounds):
         opt("ivl.sl_lanes", knobs["lanes"])
         opt("ivl.sorted_path", knobs["sorted_path"])
         got_c, got_t = ix.count(qs, qe)
+        clumped_served += ix.sparse_state()[0] == 2
         # the same batch asking for the TOTAL only (counts = NULL): on cell images the walk keeps the totals itself (ivl.tot_walk)
         opt("ivl.tot_walk", int(rng.integers(0, 2)))
         only_t = ix.count(qs, qe, want_counts=False)[1]
@@ -101,7 +120,7 @@ for r in range(rounds):
             sys.exit(1)
     opt("ivl.bitmap", -1)
     opt("ivl.flat", -1), opt("ivl.dense", -1), opt("ivl.bd_w8", -1), opt("ivl.bd_chunk", 0)
-    opt("ivl.sparse", -1), opt("ivl.bo_cell_log2", 0), opt("ivl.bm_hard_ppm", 2000)
+    opt("ivl.sparse", -1), opt("ivl.bo_cell_log2", 0), opt("ivl.bm_hard_ppm", 2000), opt("ivl.clumped", -1)
     sparse_served += ix.sparse_state()[0] == 1
     m = min(nq, 20000)
     w_off, w_hits = t.find_batch(qs[:m], qe[:m])
@@ -127,4 +146,4 @@ for r in range(rounds):
         opt(k, v)
     checked += 1
     ix.close()
-print("fuzz: %d rounds (%d with offset-cell images), all counts and hit lists equal the oracle" % (checked, sparse_served))
+print("fuzz: %d rounds (%d with offset-cell images, %d batches on the clumped layout), all counts and hit lists equal the oracle" % (checked, sparse_served, clumped_served))
