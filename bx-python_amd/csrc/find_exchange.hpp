@@ -73,8 +73,10 @@ struct FxPiece {
 // Exclusive scan of the tiles' hit totals (one workgroup): tile_base[t] = hits of the tiles before t, tile_base[ntp] = all
 // hits, also written to the caller's offsets[nq].
 __global__ __launch_bounds__(1024) void fx_tile_scan_kernel(const unsigned long long *__restrict__ tile_tot, int64_t ntp, long long *__restrict__ tile_base,
-                                                            long long *__restrict__ grand_total, long long *__restrict__ max_tile = nullptr)
+                                                            long long *__restrict__ grand_total, long long *__restrict__ max_tile = nullptr,
+                                                            const unsigned *__restrict__ gate = nullptr)
 {
+    if (gate && *gate != 0) return;  // (the sorted find's chain on a batch that turned out not to be sorted)
     __shared__ long long lds[16];
     __shared__ unsigned long long s_max;
     if (threadIdx.x == 0) s_max = 0ull;

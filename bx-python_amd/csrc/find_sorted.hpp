@@ -1,4 +1,4 @@
-// find_sorted.hpp -- find() on bucketed and on sorted batches: window + count per query, offsets carried to bucket order, the fills (part_fill_kernel, part_fill_flat_kernel), slice bounds.  intersection.pyx:180-189 (hit order), :400-406.
+// find_sorted.hpp -- find() on bucketed and on sorted batches: window + count per query, offsets carried to bucket order, the fills (part_fill_kernel, part_fill_pipe_kernel), slice bounds.  intersection.pyx:180-189 (hit order), :400-406.
 // Included by intervals.hip (one translation unit; the kernels share its constants and device helpers).
 #pragma once
 
@@ -270,17 +270,61 @@ constexpr int FF_HITS = 512;    // hits of a wave's 64 queries staged in LDS (me
 constexpr int FF_PAIRS = 128;   // pairs below the wave's highest `hi` staged in LDS
 
 // The pairs a wave's 64 queries will walk: [wbase, kmax) = the FF_PAIRS ranks below the highest `hi` of the wave, requested into
-// registers ahead of time -- all at once (round 4 issued them one after the other behind a branch each: two dependent round trips
-// to HBM per batch, after two more for the queries' numbers; the kernel's time was those four latencies), and by the callers one
-// batch EARLY, while the batch before is being walked.
+// registers all at once, one batch EARLY, while the batch before is being walked.
 struct FfStage {
     int2 pv[FF_PAIRS / 64];
     int wbase, kmax;
 };
-__device__ __forceinline__ void ff_load(const int2 *__restrict__ eid /* at index 0 */, int c, int hi, FfStage &S)
+
+// part_fill_pipe_kernel (round 6): the walk above as a software pipeline.  Round 5's kernel (part_fill_flat_kernel, 0.72 ms on
+// configs[4]) was a chain per batch of 64 queries: the pairs requested when the batch starts and waited for at once, and -- memory
+// operations retire in order, stores included -- the wait for the next batch's numbers at the top of the loop also waited for this
+// batch's hit stores to be acknowledged by the L2; worse, where an LDS access and a global one met in one value (a pair inside or
+// below the staged window, a hit into the image or straight into the list) the compiler made FLAT instructions of both and
+// drained every outstanding memory operation at every step of the walk.  Here
+//   * a wave reads ONE CSR offset per batch (its first query's, a broadcast) and scans its own counts (-8 B per query: 0.72 -> 0.66 ms);
+//   * every batch issues EXACTLY FF_HITS / 64 store instructions, straight line (lanes beyond the stretch store to a word
+//     nobody reads), so the compiler can count them: the wait at the top of a batch is `vmcnt(10)` -- all but the last batch's
+//     stores and two younger loads -- and what it lands was requested a whole batch earlier: the numbers of batch i + 1 and, older,
+//     the pairs of batch i.  Then the pairs of batch i + 1 and the numbers of batch i + 2 are requested and batch i is walked in LDS;
+//   * the loop is unrolled by two with the register sets swapped: no register is copied while a load is on its way to it;
+//   * the rare global accesses of the walk are hand-issued, so the walk is LDS-only as far as the compiler's counting goes.
+// 0.72 -> 0.57-0.59 ms; sorted find 1.38 -> 1.21-1.24 ms with the chain launched without waiting for the host (ivl_find_local).
+__device__ __forceinline__ int wave_max_nonneg_dpp(int x)
+{
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));  // row_shr:1
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));  // row_shr:2
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));  // row_shr:4
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));  // row_shr:8
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
+// Hand-issued global accesses of the pipelined fill's rare paths (see the walk in part_fill_pipe_kernel).
+typedef int ffp_v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int2 ffp_global_pair(const int2 *p)
+{
+    ffp_v2i v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_int2(v.x, v.y);
+}
+__device__ __forceinline__ long long ffp_global_offset(const long long *p)
+{
+    long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ffp_global_store(int32_t *p, int v)
+{
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+
+__device__ __forceinline__ void ffp_load(const int2 *__restrict__ eid /* at index 0 */, int c, int hi, FfStage &S)
 {
     const int lane = lane_id();
-    S.kmax = wave_max_i32(c ? hi : 0);
+    S.kmax = wave_max_nonneg_dpp(c ? hi : 0);
     S.wbase = S.kmax > FF_PAIRS ? S.kmax - FF_PAIRS : 0;
     const int last = S.kmax > 0 ? S.kmax - 1 : 0;
 #pragma unroll
@@ -290,112 +334,14 @@ __device__ __forceinline__ void ff_load(const int2 *__restrict__ eid /* at index
     }
 }
 
-// One wave, 64 consecutive queries (a lane each: `c` hits to find below rank `hi`, its CSR offset `off`): see the kernel below.
-// wp / wh: the wave's LDS images of the pairs and of its stretch of the list; S: what ff_load brought for these queries.
-#ifndef FF_EARLY_FILL
-#define FF_EARLY_FILL 0  // 1: the fill of a sorted find() is launched before the host has read the total (intervals.hip: ivl_find_local)
-#endif
-#ifndef FF_WAVE_OFFS
-#define FF_WAVE_OFFS 0   // 1: a wave reads ONE CSR offset (its first query's) and scans its own counts; 0: every lane reads its query's offset
-#endif
-// `off`: FF_WAVE_OFFS = 0 the lane's own CSR offset; 1 the offset of the wave's FIRST query in every lane (one broadcast load) -- a
-// lane's place in the stretch is the prefix of the wave's counts, and only a stretch that does not fit the LDS image reads the
-// lanes' own offsets (`offs_q` = &offsets[this lane's query], dead lanes: any valid address).
-__device__ __forceinline__ void ff_wave_fill(int2 *wp, int32_t *wh, const int2 *__restrict__ eid /* at index 0 */, const FfStage &S, int c, const int hi,
-                                             const int qs, long long off, int32_t *__restrict__ hits, const long long *__restrict__ offs_q = nullptr)
-{
-    const int lane = lane_id();
-    int k = hi - 1;
-    // the wave's stretch of the list: from its first query's offset, as long as the sum of its counts
-#if FF_WAVE_OFFS
-    const long long base_off = off;
-    // (counts clamped to "does not fit": 64 of them cannot overflow 32 bits, and a sum that fits is exact)
-    const unsigned nc = (unsigned)c <= (unsigned)FF_HITS ? (unsigned)c : (unsigned)FF_HITS + 1u;
-    const unsigned incl = wave_inclusive_sum_dpp(nc);
-    const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    if (tot == 0u) return;  // (wave-uniform)
-    const bool flat = tot <= (unsigned)FF_HITS;
-    const int total = flat ? (int)tot : 0;
-    const int rel = flat ? (int)(incl - nc) : 0;
-    off = flat ? base_off + rel : *offs_q;  // (wave-uniform choice)
-    int32_t *__restrict__ dst = hits + off;
-#else
-    const long long base_off = __shfl(off, 0, 64);
-    long long total64 = c;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) total64 += __shfl_xor(total64, d, 64);
-    if (total64 == 0) return;  // (wave-uniform)
-    const bool flat = total64 <= FF_HITS;
-    const int total = flat ? (int)total64 : 0;
-    const int rel = flat ? (int)(off - base_off) : 0;
-    int32_t *__restrict__ dst = hits + off;
-#endif
-    // the window of the pairs: FF_PAIRS below the highest hi of the wave
-    const int kmax = S.kmax, wbase = S.wbase;
-#pragma unroll
-    for (int j = 0; j < FF_PAIRS / 64; j++) {
-        const int kk = wbase + 64 * j + lane;
-        if (kk < kmax) wp[64 * j + lane] = S.pv[j];
-    }
-    // (lanes read what OTHER lanes staged: wave-level release + barrier, not just in-order DS issue)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    auto pair_at = [&](int kk) -> int2 { return kk >= wbase ? wp[kk - wbase] : eid[kk]; };
-    auto take = [&](const int2 p) {
-        if (p.x > qs) {
-            --c;
-            if (flat)
-                wh[rel + c] = p.y;
-            else
-                dst[c] = p.y;
-        }
-    };
-    for (int step = 0; step < LANE_WINDOW && c > 0 && k >= 0; step++, k--) {
-        // (two self-contained arms: where an LDS read and an HBM load meet in one value the compiler waits for ALL outstanding
-        // memory operations at every step -- the next batch's numbers and pairs included)
-        if (__all(k >= wbase))
-            take(wp[k - wbase]);
-        else
-            take(pair_at(k));
-    }
-    unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
-    while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        int C = __shfl(c, src, 64), K = __shfl(k, src, 64);
-        const int S = __shfl(qs, src, 64);
-        const int R = __shfl(rel, src, 64);
-        int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
-        while (C > 0 && K >= 0) {
-            const int kk = K - lane;
-            int2 p = make_int2(INT_MIN, 0);
-            if (kk >= 0) p = pair_at(kk);
-            const bool f = kk >= 0 && p.x > S;
-            const unsigned long long fm = __ballot(f);
-            // hits at higher indices come later in the list: lane 0 (the highest index of the step) takes the last free slot
-            const int before = __popcll(fm & ((1ull << lane) - 1ull));
-            if (f && before < C) {
-                if (flat)
-                    wh[R + C - 1 - before] = p.y;
-                else
-                    D[C - 1 - before] = p.y;
-            }
-            C -= __popcll(fm);
-            K -= 64;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < total; i += 64) hits[base_off + i] = wh[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next batch overwrites both images)
-    __builtin_amdgcn_wave_barrier();
-}
-
-__global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2 *__restrict__ eid /* at index 0 */, const int32_t *__restrict__ qs_arr,
+// (70 registers = 7 waves per SIMD; held to 64 / 8 waves it is no faster: 605 against 593 us on configs[4])
+__global__ __launch_bounds__(FIND_THREADS) void part_fill_pipe_kernel(const int2 *__restrict__ eid /* at index 0 */, const int32_t *__restrict__ qs_arr,
                                                                      int64_t nq, const int32_t *__restrict__ his, const int32_t *__restrict__ cnt,
-                                                                     const long long *__restrict__ offs, int32_t *__restrict__ hits, long long cap)
+                                                                     const long long *__restrict__ offs, int32_t *__restrict__ hits, long long cap,
+                                                                     int32_t *__restrict__ nobody /* a word nobody reads */, const unsigned *__restrict__ gate)
 {
-    if (offs[nq] > cap) return;  // (launched before the host knows the total, FF_EARLY_FILL: a list that does not fit is not written)
+    if (gate && *gate != 0) return;  // (the batch turned out not to be sorted: the numbers behind it were never written)
+    if (offs[nq] > cap) return;  // (launched before the host knows the total: a list that does not fit is not written)
     __shared__ int2 s_pairs[FIND_THREADS / 64][FF_PAIRS];
     __shared__ int32_t s_hits[FIND_THREADS / 64][FF_HITS];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
@@ -403,31 +349,130 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
     const int64_t wg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int64_t per_wg = (nq + gridDim.x - 1) / gridDim.x;
     const int64_t q0 = wg * per_wg, q1 = q0 + per_wg < nq ? q0 + per_wg : nq;
+    if (q0 + 64 * wave >= q1) return;
+    int2 *const wp = s_pairs[wave];
+    int32_t *const wh = s_hits[wave];
     struct Q {
         int c, hi, qs;
-        long long off;
+        long long off;  // the CSR offset of the batch's FIRST query (one address for the wave: a broadcast)
     };
-    auto load_q = [&](int64_t qb, Q &x) {  // (independent loads: one round trip)
+    auto load_q = [&](int64_t qb, Q &x) {  // (independent loads: one round trip; past the stretch: valid addresses, the counts masked when they are used)
         const int64_t q = qb + lane;
-        const bool live = q < q1;
-        const int64_t qa = live ? q : q1 - 1;  // (a dead lane: valid addresses, no hits; its offset is the one behind the stretch's last query)
-#if FF_WAVE_OFFS
-        x.c = cnt[qa], x.hi = his[qa], x.qs = qs_arr[qa], x.off = offs[qb < q1 ? qb : q1 - 1];  // (one address for the wave: a broadcast)
-#else
-        x.c = cnt[qa], x.hi = his[qa], x.qs = qs_arr[qa], x.off = offs[qa];
-#endif
-        if (!live) x.c = 0;
+        const int64_t qa = q < q1 ? q : q1 - 1;
+        x.c = cnt[qa], x.hi = his[qa], x.qs = qs_arr[qa], x.off = offs[qb < q1 ? qb : q1 - 1];
     };
-    if (q0 + 64 * wave >= q1) return;
-    Q cur;
-    load_q(q0 + 64 * wave, cur);
-    for (int64_t qb = q0 + 64 * wave; qb < q1; qb += FIND_THREADS) {  // (waves are on their own: no workgroup barrier in here)
-        FfStage S;
-        ff_load(eid, cur.c, cur.hi, S);
-        Q nxt = cur;
-        if (qb + FIND_THREADS < q1) load_q(qb + FIND_THREADS, nxt);  // the next batch's numbers travel while this one is walked
-        ff_wave_fill(s_pairs[wave], s_hits[wave], eid, S, cur.c, cur.hi, cur.qs, cur.off, hits, offs + (qb + lane < q1 ? qb + lane : q1 - 1));
-        cur = nxt;
+    auto stores = [&](const long long base_off, const int total) {  // FF_HITS / 64 store instructions whatever `total` is
+#pragma unroll
+        for (int j = 0; j < FF_HITS / 64; j++) {
+            const int i = 64 * j + lane;
+            int32_t *const d = i < total ? hits + base_off + i : nobody;
+            *d = wh[i];
+        }
+    };
+    // One batch: `cur` = its numbers (landed a batch ago), Scur = its pairs (requested a batch ago), `nxt` = the next batch's
+    // numbers (requested a batch ago, landed here), Snxt = where the next batch's pairs go; the numbers of the batch after that
+    // are requested into `cur`, whose values have moved to working registers by then.  Called with the two sets swapped every
+    // other batch (the loop is unrolled by two): no register is copied while a load is on its way to it.
+    auto step = [&](Q &cur, Q &nxt, FfStage &Scur, FfStage &Snxt, const int64_t qb) {
+        int c = qb + lane < q1 ? cur.c : 0;
+        const int hi = cur.hi, qs = cur.qs;
+        const long long base_off = cur.off;
+        ffp_load(eid, qb + FIND_THREADS + lane < q1 ? nxt.c : 0, nxt.hi, Snxt);
+        load_q(qb + 2 * FIND_THREADS, cur);
+        // (counts clamped to "does not fit": 64 of them cannot overflow 32 bits, and a sum that fits is exact)
+        const unsigned nc = (unsigned)c <= (unsigned)FF_HITS ? (unsigned)c : (unsigned)FF_HITS + 1u;
+        const unsigned incl = wave_inclusive_sum_dpp(nc);
+        const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        const bool flat = tot <= (unsigned)FF_HITS;
+        const int rel = (int)(incl - nc);
+        if (tot != 0u) {
+            int k = hi - 1;
+            const int kmax = Scur.kmax, wbase = Scur.wbase;
+#pragma unroll
+            for (int j = 0; j < FF_PAIRS / 64; j++) {
+                const int kk = wbase + 64 * j + lane;
+                if (kk < kmax) wp[64 * j + lane] = Scur.pv[j];
+            }
+            // (lanes read what OTHER lanes staged: wave-level release + barrier, not just in-order DS issue)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // The walk, as the compiler sees it, touches LDS only.  The rare accesses to HBM -- a pair below the staged window, the
+            // hits of a stretch that does not fit the image -- are hand-issued (ffp_global_pair waits for its own load, the stores
+            // are not waited for): where an LDS access and a global one meet in one value the compiler makes FLAT instructions of
+            // both and drains every outstanding memory operation around them, at every step of every batch.
+            const int64_t q = qb + lane;
+            int32_t *dst = hits;
+            if (!flat) dst = hits + ffp_global_offset(offs + (q < q1 ? q : q1 - 1));  // (a wave-uniform branch)
+            auto pair_at = [&](int kk) -> int2 {
+                int2 p;
+                if (kk >= wbase)
+                    p = wp[kk - wbase];
+                else
+                    p = ffp_global_pair(eid + kk);
+                return p;
+            };
+            auto put = [&](int at, int v) {  // hit number `at` of this lane's query
+                if (flat)
+                    wh[rel + at] = v;
+                else
+                    ffp_global_store(dst + at, v);
+            };
+            for (int st = 0; st < LANE_WINDOW && c > 0 && k >= 0; st++, k--) {
+                int2 p;
+                if (__all(k >= wbase))
+                    p = wp[k - wbase];
+                else
+                    p = pair_at(k);
+                if (p.x > qs) put(--c, p.y);
+            }
+            unsigned long long m = __ballot(c > 0);  // long walks (a few long targets far below hi): the wave takes them one by one
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                int C = __shfl(c, src, 64), K = __shfl(k, src, 64);
+                const int S = __shfl(qs, src, 64);
+                const int R = __shfl(rel, src, 64);
+                int32_t *D = reinterpret_cast<int32_t *>(__shfl((long long)reinterpret_cast<uintptr_t>(dst), src, 64));
+                while (C > 0 && K >= 0) {
+                    const int kk = K - lane;
+                    int2 p = make_int2(INT_MIN, 0);
+                    if (kk >= 0) p = pair_at(kk);
+                    const bool f = kk >= 0 && p.x > S;
+                    const unsigned long long fm = __ballot(f);
+                    // hits at higher indices come later in the list: lane 0 (the highest index of the step) takes the last free slot
+                    const int before = __popcll(fm & ((1ull << lane) - 1ull));
+                    if (f && before < C) {
+                        if (flat)
+                            wh[R + C - 1 - before] = p.y;
+                        else
+                            ffp_global_store(D + (C - 1 - before), p.y);
+                    }
+                    C -= __popcll(fm);
+                    K -= 64;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        stores(base_off, flat ? (int)tot : 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next batch overwrites both images)
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int64_t first = q0 + 64 * wave;
+    Q X, Y;
+    FfStage SX, SY;
+    load_q(first, X);
+    load_q(first + FIND_THREADS, Y);
+    ffp_load(eid, first + lane < q1 ? X.c : 0, X.hi, SX);
+    {
+        int zero;  // (not to the compiler: as many store instructions behind Y's loads on the way into the loop as around it)
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+        stores(0, zero);
+    }
+    for (int64_t qb = first; qb < q1; qb += 2 * FIND_THREADS) {  // (waves are on their own: no workgroup barrier in here)
+        step(X, Y, SX, SY, qb);
+        if (qb + FIND_THREADS >= q1) break;
+        step(Y, X, SY, SX, qb + FIND_THREADS);
     }
 }
 
@@ -437,8 +482,9 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_flat_kernel(const int2
 // no offsets kernel and no 8 bytes per query read back: 1.75 ms against 1.53 with this kernel + part_fill_flat_kernel, whose waves
 // run free of barriers; forced to 8 waves per SIMD it spilled and took 1.86.  Not kept.)
 __global__ __launch_bounds__(LC_THREADS) void lf_offsets_kernel(const int32_t *__restrict__ cnt, const long long *__restrict__ chunk_base, int64_t nq,
-                                                                long long *__restrict__ offsets)
+                                                                long long *__restrict__ offsets, const unsigned *__restrict__ gate = nullptr)
 {
+    if (gate && *gate != 0) return;
     __shared__ long long lds[16];
     const int64_t base = (int64_t)blockIdx.x * LC_CHUNK + (int64_t)threadIdx.x * LC_ITEMS;
     int c[LC_ITEMS];

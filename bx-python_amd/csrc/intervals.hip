@@ -352,8 +352,10 @@ static int sl_ensure_eid(bxmi_ivl *h, hipStream_t st)
 }
 
 // find() on a batch with sorted starts: windows in query order -> scan -> fill, no bucketing.
+// `gate`: the word the order check -- launched just before, not waited for -- raises when the starts descend
+// somewhere; every kernel of the chain stands down on it, and *stood_down tells the caller to take the exchange instead.
 static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_t nq, int64_t *offsets, int32_t *hits, int64_t cap,
-                          int64_t *total_host, hipStream_t st)
+                          int64_t *total_host, hipStream_t st, const unsigned *gate = nullptr, bool *stood_down = nullptr)
 {
     BXMI_TRY(h->p_lo.reserve((size_t)(nq + 4) * 4));
     BXMI_TRY(h->p_hi.reserve((size_t)(nq + 4) * 4));
@@ -366,14 +368,14 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
         const int64_t nchunks = div_up(nq, LC_CHUNK);
         if (chunk_scan) BXMI_TRY(h->lf_state.reserve((size_t)(2 * nchunks + 4) * 8));
         hipLaunchKernelGGL(ivl_local_count_kernel, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, S, E, index_dev(h),
-                           h->e_sorted.as<int32_t>(), qs, qe, nq, h->q_cnt.as<int32_t>(), (unsigned long long *)nullptr, (const unsigned *)nullptr,
+                           h->e_sorted.as<int32_t>(), qs, qe, nq, h->q_cnt.as<int32_t>(), (unsigned long long *)nullptr, gate,
                            h->p_hi.as<int32_t>(), (unsigned long long *)nullptr, 0ull, chunk_scan ? h->lf_state.as<unsigned long long>() : nullptr);
         if (chunk_scan) {
             long long *chunk_base = h->lf_state.as<long long>() + nchunks;  // [nchunks + 1]
             hipLaunchKernelGGL(fx_tile_scan_kernel, dim3(1), dim3(1024), 0, st, h->lf_state.as<unsigned long long>(), nchunks, chunk_base,
-                               reinterpret_cast<long long *>(offsets) + nq);
+                               reinterpret_cast<long long *>(offsets) + nq, (long long *)nullptr, gate);
             hipLaunchKernelGGL(lf_offsets_kernel, dim3((unsigned)nchunks), dim3(LC_THREADS), 0, st, h->q_cnt.as<int32_t>(), chunk_base, nq,
-                               reinterpret_cast<long long *>(offsets));
+                               reinterpret_cast<long long *>(offsets), gate);
         }
     }
     BXMI_LAUNCH_CHECK();
@@ -381,32 +383,27 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
         BXMI_TRY((device_scan<int32_t, long long, OpSum, false>(h->q_cnt.as<int32_t>(), reinterpret_cast<long long *>(offsets), nq, 0ll,
                                                                reinterpret_cast<long long *>(offsets) + nq, h->scan_scratch, st)));
     int64_t total = 0;
-#if FF_EARLY_FILL
     // The fill is launched BEHIND the offsets without waiting for the host to learn the total (a round trip of ~25 us with the
     // device idle): it reads the total itself and leaves the list alone when it does not fit the caller's buffer.
     if (hits && cap > 0) {
         BXMI_TRY(sl_ensure_eid(h, st));
-        hipLaunchKernelGGL(part_fill_flat_kernel, dim3(device_props().cus * 8), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq,
-                           h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (long long)cap);
+        BXMI_TRY(h->fx_work.reserve(64));
+        hipLaunchKernelGGL(part_fill_pipe_kernel, dim3(device_props().cus * 8), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq,
+                           h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (long long)cap,
+                           h->fx_work.as<int32_t>() + 12, gate);
         BXMI_LAUNCH_CHECK();
     }
+    unsigned gate_host = 0;
+    if (gate) BXMI_HIP(hipMemcpyAsync(&gate_host, gate, sizeof(unsigned), hipMemcpyDeviceToHost, st));
     BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
     BXMI_HIP(hipStreamSynchronize(st));
+    if (gate_host) {  // (the starts descend somewhere: nothing was written that the exchange does not write again)
+        if (stood_down) *stood_down = true;
+        return BXMI_OK;
+    }
     if (total_host) *total_host = total;
     if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
     return BXMI_OK;
-#else
-    BXMI_HIP(hipMemcpyAsync(&total, offsets + nq, 8, hipMemcpyDeviceToHost, st));
-    BXMI_HIP(hipStreamSynchronize(st));
-    if (total_host) *total_host = total;
-    if (total > cap) return fail(BXMI_ERANGE, "bxmi_ivl_find: %lld hits need a larger buffer than cap=%lld", (long long)total, (long long)cap);
-    if (total == 0) return BXMI_OK;
-    BXMI_TRY(sl_ensure_eid(h, st));
-    hipLaunchKernelGGL(part_fill_flat_kernel, dim3(device_props().cus * 8), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq,
-                       h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (long long)cap);
-    BXMI_LAUNCH_CHECK();
-    return BXMI_OK;
-#endif
 }
 
 // Partitioned find(): same bucketing as the count path, then window+count per query in bucket order, counts gathered
@@ -1906,8 +1903,17 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
             if (!unsorted) {
                 BXMI_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
                 hipLaunchKernelGGL(ivl_sorted_check_kernel, dim3(stream_grid(nq, 256)), dim3(256), 0, st, qs, nq, flag);
-                BXMI_HIP(hipMemcpyAsync(&unsorted, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-                BXMI_HIP(hipStreamSynchronize(st));
+                // the whole chain of the sorted find behind the check, every kernel gated on the check's word: one round trip to the
+                // host (flag and total together) instead of three
+                if (((uintptr_t)offsets & 15) == 0) {
+                    bool stood_down = false;
+                    BXMI_TRY(ivl_find_local(h, qs, qe, nq, offsets, hits, cap, total_host, st, flag, &stood_down));
+                    if (!stood_down) return BXMI_OK;
+                    unsorted = 1;
+                } else {
+                    BXMI_HIP(hipMemcpyAsync(&unsorted, flag, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                    BXMI_HIP(hipStreamSynchronize(st));
+                }
             }
             if (!unsorted) return ivl_find_local(h, qs, qe, nq, offsets, hits, cap, total_host, st);
         }
