@@ -23,6 +23,13 @@
 //      Two consecutive queries per lane (fx_hits_copy2_kernel): twice the gathers in flight per wave.
 //   5. Lists that fit the memory-side cache skip the scratch and the copy (ivl.fx_direct): the un-permute kernel leaves prefixes
 //      in QUERY order (FIND = 3), the fill writes straight into the CSR list, fx_offsets_kernel turns the prefixes into offsets.
+//   6. (round 6) The passes of the fill are a software pipeline with a COUNTED number of stores: every pass of 64 records issues
+//      exactly FX_SQ 16-byte and three 4-byte store instructions (lanes with nothing to store write to words nobody reads), so the
+//      wait for a pass's records is `vmcnt(6)` = "all but the last pass's stores" where round 5's loop drained everything the
+//      wave had sent, the acknowledgements of its own stores included, at the top of every pass; the pass loop is unrolled by two
+//      with swapped register sets (no register copied while a load is on its way to it), a batch's run words are used as loaded
+//      (round 5 computed from them where they were requested: a wait), the rare global accesses of the walk are hand-issued (no
+//      FLAT instructions), and the walk reads four candidates per round trip to the LDS: 1.13-1.15 -> 1.04 ms on configs[4].
 // A record whose walk leaves the staged window (long targets far below, piles larger than the window) reads the pairs from HBM
 // as before: exact either way.
 #pragma once
@@ -36,20 +43,14 @@ constexpr int FX_HCAP = 512;          // hits a wave collects in LDS per pass of
 #ifndef FX_BT_V
 #define FX_BT_V 32
 #endif
-#ifndef FX_FL_V
-#define FX_FL_V 6
-#endif
 constexpr int FX_BT = FX_BT_V;       // tiles of a wave's batch (one run per lane; 64 left 16 waves with 24 batches on configs[4])
 constexpr int FX_THREADS = 1024;
 constexpr int FX_NW = FX_THREADS / 64;
 constexpr size_t FX_LDS_BYTES = (size_t)FX_CAPW * 8 + (size_t)FX_NW * (FX_HCAP * 4 + 64 * 4);
-// (experiments of round 5, compile time)
-#ifndef FX_STORE4
-#define FX_STORE4 0   // 1: the hits leave as 4-byte stores
-#endif
-#ifndef FX_EXP
-#define FX_EXP 0      // diagnostics (wrong results): bit 0 = the hits are not stored, bit 1 = no walk (nothing to store either), bit 2 = no window staging
-                      // (configs[4], round 5: 1.16 ms whole, 0.78 without the stores, 0.36 without the walk as well, 0.32 without the staging too)
+// (round 5's diagnostic builds on configs[4]: 1.16 ms whole, 0.78 without the stores, 0.36 without the walk as well, 0.32 without the
+// window staging too)
+#ifndef FX_SQ
+#define FX_SQ 3       // 16-byte stores every pass issues per lane (records of up to 4 FX_SQ + 3 hits; longer ones: a rare loop behind)
 #endif
 #ifndef FX_XCD
 #define FX_XCD 1      // 1: neighbouring pieces are handed out on ONE XCD (eight counters), 0: one counter for the chip
@@ -103,6 +104,32 @@ __global__ __launch_bounds__(1024) void fx_tile_scan_kernel(const unsigned long 
 
 typedef int fx_v4a4 __attribute__((ext_vector_type(4), aligned(4)));
 
+// Hand-issued global accesses of the fill's rare paths : not seen by the compiler's count of outstanding operations.
+typedef int fxp_v2i __attribute__((ext_vector_type(2)));
+typedef int fxp_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int2 fxp_global_pair(const int2 *p)
+{
+    fxp_v2i v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_int2(v.x, v.y);
+}
+__device__ __forceinline__ unsigned fxp_global_u32(const unsigned *p)
+{
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void fxp_global_store(int32_t *p, int v)
+{
+    asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void fxp_global_store4(int32_t *p, fx_v4a4 v)
+{
+    fxp_v4i w;
+    w.x = v.x, w.y = v.y, w.z = v.z, w.w = v.w;
+    asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(w) : "memory");
+}
+
 // #{i in [0, 64) : ends[i] <= s}, ends non-decreasing (a wave's inclusive prefix sums in LDS): six halvings.
 __device__ __forceinline__ unsigned fx_locate(const unsigned *ends, unsigned s)
 {
@@ -122,7 +149,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                                                             const unsigned *__restrict__ cnt, const unsigned *__restrict__ loff,
                                                             const long long *__restrict__ tile_base, const int2 *__restrict__ eid /* at index 0 */,
                                                             const int2 *__restrict__ meta2, int32_t *__restrict__ tmp_hits, int tile_log2,
-                                                            unsigned *__restrict__ work_counter)
+                                                            unsigned *__restrict__ work_counter, int32_t *__restrict__ nobody /* 16 bytes nobody reads */)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t dyn[];
     __shared__ int s_work;
@@ -161,7 +188,7 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
             constexpr int ROUNDS = (FX_CAPW + 2 * FX_THREADS - 1) / (2 * FX_THREADS);
             sl_v4a8 v[ROUNDS];
 #pragma unroll
-            for (int r = 0; r < ((FX_EXP & 4) ? 0 : ROUNDS); r++) {
+            for (int r = 0; r < ROUNDS; r++) {
                 const int i = 2 * ((int)threadIdx.x + r * FX_THREADS);
                 // (the pair behind the window's last one is read with it when the window's length is odd: the pair array ends
                 // with SL_WALK spare entries... in front; behind, a valid address is all that is needed -- clamp)
@@ -184,28 +211,25 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
         // A wave takes FX_BT tiles at a time (one run per lane), and the kernel is a chain of dependent loads -- run table ->
         // records -> stores -- on ONE workgroup per CU: the next batch's runs and the next pass's records are requested before
         // the current ones are worked on.
-        struct Run {
-            unsigned a, rlen;
+        struct Run {  // (as loaded: nothing is computed from a run's words before its batch starts -- that would be a wait where they are requested)
+            unsigned r0, r1;
             long long tbase;
         };
-        auto load_run = [&](int tb, Run &R) {  // the piece's records of tile tb + lane
+        auto load_run = [&](int tb, Run &R) {  // the piece's records of tile tb + lane (past t1: a valid address, the words unused)
             const int t = tb + lane;
-            R.a = 0u, R.rlen = 0u, R.tbase = 0;
-            if (lane < FX_BT && t < t1) {
-                const unsigned r0 = runs0[t], r1 = runs1[t];
-                R.a = r0 & 0xffffu;
-                R.rlen = (r1 & 0xffffu) + (r1 >> 16) - R.a;
-                R.tbase = tile_base[t];
-            }
+            const int ta = lane < FX_BT && t < t1 ? t : t0;
+            R.r0 = runs0[ta], R.r1 = runs1[ta], R.tbase = tile_base[ta];
         };
         Run cur_run;
         load_run(t0 + FX_BT * wave, cur_run);
         for (int tb = t0 + FX_BT * wave; tb < t1; tb += FX_BT * FX_NW) {
             Run next_run;
             load_run(tb + FX_BT * FX_NW, next_run);  // (past t1: nothing is loaded)
-            const unsigned a = cur_run.a, rlen = cur_run.rlen;
-            const long long tbase = cur_run.tbase;
             const int t = tb + lane;
+            const bool live_run = lane < FX_BT && t < t1;
+            const unsigned a = live_run ? cur_run.r0 & 0xffffu : 0u;
+            const unsigned rlen = live_run ? (cur_run.r1 & 0xffffu) + (cur_run.r1 >> 16) - a : 0u;
+            const long long tbase = cur_run.tbase;
             const unsigned rincl = wave_inclusive_sum_dpp(rlen);
             const unsigned T = (unsigned)__builtin_amdgcn_readlane((int)rincl, 63);
             const unsigned rdelta = ((unsigned)t << tile_log2) + a - (rincl - rlen);  // + s = the tile-sorted position of the batch's record s
@@ -228,31 +252,62 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                 R.at = R.act ? rd_r + s : ((unsigned)tb << tile_log2);
                 R.rec = recs[(size_t)R.at], R.h = hc[(size_t)R.at], R.lo = loff[(size_t)R.at];
             };
-            Rec nxt;
-            if (T) fetch(0u, nxt);
-            for (unsigned p0 = 0; p0 < T; p0 += 64u) {
-                Rec R = nxt;
-                // (the pass's records must have ARRIVED before the next pass's are requested: the counter of outstanding memory
-                // operations retires in order, so a wait placed after the new requests would wait for them as well)
-                asm volatile("; records of the pass %0 %1 %2" : "+v"(R.rec), "+v"(R.h), "+v"(R.lo) : : "memory");
-                if (p0 + 64u < T) fetch(p0 + 64u, nxt);  // (wave-uniform)
+            // One pass of 64 records.  R: its records (requested a pass ago), N: where the next pass's records go -- the loop below is
+            // unrolled by two with the sets swapped, so no register is copied while a load is on its way to it.  Every pass issues
+            // EXACTLY FX_SQ 16-byte and three 4-byte store instructions, straight line (a lane with nothing to store writes to words
+            // nobody reads), so the compiler can count them: the wait for a pass's records is "all but the last pass's stores", not
+            // a drain of everything the wave has sent (memory operations retire in order, stores included; round 5's loop of
+            // `while any lane has hits left` stores made every pass wait for the acknowledgement of the pass before).  The rare
+            // global accesses of the walk are hand-issued: where an LDS access and a global one meet in one value the compiler makes
+            // FLAT instructions of both and drains both counters around every one.
+            auto static_stores = [&](const unsigned nn, const unsigned my_off, int32_t *dst) {
+                const unsigned quads = nn >> 2, tail0 = nn & ~3u;
+#pragma unroll
+                for (unsigned q = 0; q < (unsigned)FX_SQ; q++) {
+                    const bool ok = q < quads;
+                    const unsigned s = ok ? my_off + 4u * q : 0u;
+                    fx_v4a4 v;
+                    v.x = st[s], v.y = st[s + 1u], v.z = st[s + 2u], v.w = st[s + 3u];
+                    fx_v4a4 *d = ok ? reinterpret_cast<fx_v4a4 *>(dst + 4u * q) : reinterpret_cast<fx_v4a4 *>(nobody);
+                    *d = v;
+                }
+#pragma unroll
+                for (unsigned u = 0; u < 3u; u++) {
+                    const bool ok = tail0 + u < nn;
+                    int32_t *d = ok ? dst + tail0 + u : nobody;
+                    *d = st[ok ? my_off + tail0 + u : 0u];
+                }
+                if (__any(quads > (unsigned)FX_SQ)) {  // records with more hits than the static stores cover: rare, not counted (never waited for)
+                    for (unsigned q = (unsigned)FX_SQ; __any(q < quads); q++)
+                        if (q < quads) {
+                            const unsigned s = my_off + 4u * q;
+                            fx_v4a4 v;
+                            v.x = st[s], v.y = st[s + 1u], v.z = st[s + 2u], v.w = st[s + 3u];
+                            fxp_global_store4(dst + 4u * q, v);
+                        }
+                }
+            };
+            auto pair_far = [&](int k) -> int2 { return (k >= wlo && k < whi) ? s_win[k - wlo] : fxp_global_pair(eid + k); };
+            auto pass = [&](Rec &R, Rec &N, const unsigned p0) {
                 const bool act = R.act;
                 const unsigned at = R.at, rec = R.rec, h = R.h, lo = R.lo;
                 const long long tb_r = R.tb_r;
+                fetch(p0 + 64u, N);  // (past the batch's records: valid addresses, the words unused -- every pass issues the same operations)
                 const bool esc = (lo >> 31) != 0u;
-                unsigned n = act && !esc && !(FX_EXP & 2) ? (h & 0xffffu) : 0u;
-                if (n == 0xffffu) n = cnt[(size_t)at];  // (a count that did not fit the packed word)
+                unsigned n = act && !esc ? (h & 0xffffu) : 0u;
+                if (__any(n == 0xffffu)) {  // (a count that did not fit the packed word: rare)
+                    if (n == 0xffffu) n = fxp_global_u32(cnt + (size_t)at);
+                }
                 const int hi = sLo + (int)(h >> 16);
                 const int qs = (int)(lo_u + (long long)(rec & omask));
-                int32_t *__restrict__ dst = tmp_hits + tb_r + (long long)(lo & 0x7FFFFFFFu);
+                int32_t *dst = tmp_hits + tb_r + (long long)(lo & 0x7FFFFFFFu);
                 // (prefix sums of the counts clamped to "does not fit": a pile's counts cannot overflow them, and what fits is exact)
                 const unsigned nc = n <= (unsigned)FX_HCAP ? n : (unsigned)FX_HCAP + 1u;
                 const unsigned hincl = wave_inclusive_sum_dpp(nc);
-                if (__builtin_amdgcn_readlane((int)hincl, 63) == 0) continue;  // (wave-uniform: nothing to emit in this pass)
                 // sub-batches of lanes whose hits fit the wave's LDS image together (normally: all 64 at once)
                 int first = 0;
                 unsigned hbase = 0u;
-                while (first < 64) {
+                do {
                     const bool fits = lane >= first && hincl - hbase <= (unsigned)FX_HCAP;
                     const int k = __popcll(__ballot(fits));  // (hincl is monotone: the lanes that fit are first .. first + k - 1)
                     const bool direct = k == 0;              // lane `first` alone has more hits than the image holds: straight to HBM
@@ -261,29 +316,34 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                     const unsigned my_off = hincl - nc - hbase;
                     int c = in ? (int)n : 0;
                     int kk = hi - 1;
-                    if (!direct) {
+                    if (!direct && __any(c > 0)) {
                         auto take = [&](const int2 p) {
                             if (p.x > qs) {
                                 --c;
                                 st[my_off + (unsigned)c] = p.y;
                             }
                         };
-                        // The kernel is bound by vector instructions as much as by memory (402 per pass of 64 records, measured:
-                        // profiles/r05_find_pmc.txt), half of them this loop: when every lane's first LANE_WINDOW candidates lie
-                        // inside the window -- the rule -- the steps carry no bounds checks at all.
                         if (__all(c <= 0 || (hi <= whi && hi - LANE_WINDOW >= wlo))) {
+                            // (four candidates per round trip to the LDS: one read and one wait per candidate made the walk a chain of
+                            // ~8 dependent LDS latencies per pass on four waves per SIMD; what a lane reads beyond its last hit is inside
+                            // the window by the condition above)
+                            static_assert(LANE_WINDOW % 4 == 0, "the walk reads four candidates at a time");
                             const int2 *wp = s_win + (c > 0 ? kk - wlo : LANE_WINDOW);
-                            int step = 0;
-                            for (; step < LANE_WINDOW && c > 0; step++) take(wp[-step]);
-                            kk -= step;
+                            int used = 0;
+                            for (int step = 0; step < LANE_WINDOW && __any(c > 0); step += 4) {
+                                const int2 pa = wp[-step], pb = wp[-step - 1], pc = wp[-step - 2], pd = wp[-step - 3];
+                                if (c > 0) take(pa), used++;
+                                if (c > 0) take(pb), used++;
+                                if (c > 0) take(pc), used++;
+                                if (c > 0) take(pd), used++;
+                            }
+                            kk -= used;
                         } else {
                             for (int step = 0; step < LANE_WINDOW && c > 0 && kk >= 0; step++, kk--) {
-                                // (two self-contained arms: where an LDS read and an HBM load meet in one value the compiler waits
-                                // for ALL outstanding memory operations at every step -- the next pass's records included)
                                 if (__all(kk >= wlo && kk < whi))
                                     take(s_win[kk - wlo]);
                                 else
-                                    take(pair_at(kk));
+                                    take(pair_far(kk));
                             }
                         }
                     }
@@ -298,14 +358,14 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                         while (C > 0 && K >= 0) {
                             const int kx = K - lane;
                             int2 p = make_int2(INT_MIN, 0);
-                            if (kx >= 0) p = pair_at(kx);
+                            if (kx >= 0) p = pair_far(kx);
                             const bool f = kx >= 0 && p.x > S;
                             const unsigned long long fm = __ballot(f);
                             // hits at higher ranks come later in the list: lane 0 (the highest rank of the step) takes the last free slot
                             const int before = __popcll(fm & ((1ull << lane) - 1ull));
                             if (f && before < C) {
                                 if (direct)
-                                    D[C - 1 - before] = p.y;
+                                    fxp_global_store(D + (C - 1 - before), p.y);
                                 else
                                     st[Rr + (unsigned)(C - 1 - before)] = p.y;
                             }
@@ -313,29 +373,26 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
                             K -= 64;
                         }
                     }
-                    // (Round 6 tried the image leaving as ONE flat sequence instead -- consecutive lanes on consecutive words of the
-                    // scratch list, a run's ~160 bytes in two or three write requests instead of one per record and 16 bytes: 1.25 ms
-                    // against 1.20 for the kernel.  The write requests are not what it waits for.)
-                    if (!direct) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        // every record's hits as 16-byte stores (its place in the caller's list is only 4-byte aligned)
-                        const unsigned nn = in ? n : 0u;
-                        for (unsigned j = 0; !(FX_EXP & 1) && __any(j < nn); j += 4u) {
-                            if (!FX_STORE4 && j + 4u <= nn) {
-                                fx_v4a4 v;
-                                v.x = st[my_off + j], v.y = st[my_off + j + 1u], v.z = st[my_off + j + 2u], v.w = st[my_off + j + 3u];
-                                *reinterpret_cast<fx_v4a4 *>(dst + j) = v;
-                            } else if (j < nn) {
-                                for (unsigned u = j; u < nn && u < j + 4u; u++) dst[u] = st[my_off + u];
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next sub-batch / pass overwrites the image)
-                        __builtin_amdgcn_wave_barrier();
-                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    static_stores(in && !direct ? n : 0u, my_off, dst);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next sub-batch / pass overwrites the image)
+                    __builtin_amdgcn_wave_barrier();
                     first += cntl;
                     hbase = (unsigned)__builtin_amdgcn_readlane((int)hincl, first - 1);
-                }
+                } while (first < 64 && hbase < (unsigned)__builtin_amdgcn_readlane((int)hincl, 63));
+            };
+            Rec RA, RB;
+            {
+                fetch(0u, RA);
+                int zero;  // (not to the compiler: as many stores behind the first pass's records as behind every other pass's)
+                asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+                static_stores((unsigned)zero, 0u, nobody);
+            }
+            for (unsigned p0 = 0; p0 < T; p0 += 128u) {
+                pass(RA, RB, p0);
+                if (p0 + 64u >= T) break;
+                pass(RB, RA, p0 + 64u);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (`re` is rewritten by the next batch)
             __builtin_amdgcn_wave_barrier();

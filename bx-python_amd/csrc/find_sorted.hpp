@@ -417,7 +417,22 @@ __global__ __launch_bounds__(FIND_THREADS) void part_fill_pipe_kernel(const int2
                 else
                     ffp_global_store(dst + at, v);
             };
-            for (int st = 0; st < LANE_WINDOW && c > 0 && k >= 0; st++, k--) {
+            if (__all(c <= 0 || k - (LANE_WINDOW - 1) >= wbase)) {
+                // (four candidates per round trip to the LDS instead of one read and one wait per candidate; what a lane reads beyond
+                // its last hit is inside the staged window by the condition above)
+                static_assert(LANE_WINDOW % 4 == 0, "the walk reads four candidates at a time");
+                const int2 *wq = wp + (c > 0 ? k - wbase : LANE_WINDOW);
+                int used = 0;
+                for (int st = 0; st < LANE_WINDOW && __any(c > 0); st += 4) {
+                    const int2 pa = wq[-st], pb = wq[-st - 1], pc = wq[-st - 2], pd = wq[-st - 3];
+                    if (c > 0) { if (pa.x > qs) put(--c, pa.y); used++; }
+                    if (c > 0) { if (pb.x > qs) put(--c, pb.y); used++; }
+                    if (c > 0) { if (pc.x > qs) put(--c, pc.y); used++; }
+                    if (c > 0) { if (pd.x > qs) put(--c, pd.y); used++; }
+                }
+                k -= used;
+            } else
+                for (int st = 0; st < LANE_WINDOW && c > 0 && k >= 0; st++, k--) {
                 int2 p;
                 if (__all(k >= wbase))
                     p = wp[k - wbase];

@@ -387,7 +387,7 @@ static int ivl_find_local(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int
     // device idle): it reads the total itself and leaves the list alone when it does not fit the caller's buffer.
     if (hits && cap > 0) {
         BXMI_TRY(sl_ensure_eid(h, st));
-        BXMI_TRY(h->fx_work.reserve(64));
+        BXMI_TRY(h->fx_work.reserve(128));
         hipLaunchKernelGGL(part_fill_pipe_kernel, dim3(device_props().cus * 8), dim3(FIND_THREADS), 0, st, h->sl_eid.as<int2>() + SL_WALK, qs, nq,
                            h->p_hi.as<int32_t>(), h->q_cnt.as<int32_t>(), reinterpret_cast<const long long *>(offsets), hits, (long long)cap,
                            h->fx_work.as<int32_t>() + 12, gate);
@@ -1275,7 +1275,7 @@ static int fx_prepare_index(bxmi_ivl *h, hipStream_t st)
     h->fx_state = -1;
     if (h->has_reversed || h->n < 1 || h->geom.shift < 1) return BXMI_OK;
     BXMI_TRY(h->fx_meta2.reserve((size_t)(FX_NBK + 1) * sizeof(int2)));
-    BXMI_TRY(h->fx_work.reserve(64));
+    BXMI_TRY(h->fx_work.reserve(128));  // (eight work counters, a word and sixteen bytes nobody reads)
     hipLaunchKernelGGL(fx_meta_kernel, dim3((FX_NBK + 1 + 255) / 256), dim3(256), 0, st, h->s_ord.as<int32_t>(), (int)h->n, h->geom.cmin, h->geom.shift,
                        h->fx_meta2.as<int2>());
     BXMI_LAUNCH_CHECK();
@@ -1389,7 +1389,7 @@ static int ivl_find_fx(bxmi_ivl *h, const int32_t *qs, const int32_t *qe, int64_
     hipLaunchKernelGGL(fx_fill_kernel, dim3((unsigned)device_props().cus), dim3(FX_THREADS), FX_LDS_BYTES, st, fx.L.segs, h->fx_pieces.as<FxPiece>(), npieces,
                        (int)nchunks, (int)tiles_per_chunk, h->fx_runT2.as<unsigned>(), ntp, h->bm_recs.as<unsigned>(), h->fx_hc.as<unsigned>(),
                        h->sl_cnt.as<unsigned>(), h->sl_loff.as<unsigned>(), h->fx_tile_base.as<long long>(), h->sl_eid.as<int2>() + SL_WALK,
-                       h->fx_meta2.as<int2>(), fx.direct ? hits : h->sl_hits.as<int32_t>(), fx.L.tile_log2, h->fx_work.as<unsigned>());
+                       h->fx_meta2.as<int2>(), fx.direct ? hits : h->sl_hits.as<int32_t>(), fx.L.tile_log2, h->fx_work.as<unsigned>(), h->fx_work.as<int32_t>() + 16);
     BXMI_LAUNCH_CHECK();
     if (fx.direct) return BXMI_OK;  // (every record's hits went where the CSR offsets say)
     const unsigned cgrid = (unsigned)(div_up(ntp, 8) * 8 * (((int64_t)1 << fx.L.tile_log2) / BM_PART_Q));
