@@ -519,8 +519,10 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_group_kernel(const GroupSeg
             seg++;
         }
         const GroupSeg A = sa[seg];
-        ulonglong2 *va = reinterpret_cast<ulonglong2 *>(A.words);
-        const ulonglong2 *vb = OP == 3 ? nullptr : reinterpret_cast<const ulonglong2 *>(sb[seg].words);
+        // (the members' word arrays come out of a table in memory: as_global, common.hpp -- global_load / global_store with counted
+        // waits instead of FLAT instructions)
+        u64x2 BX_GLOBAL *va = reinterpret_cast<u64x2 BX_GLOBAL *>(as_global(A.words));
+        const u64x2 BX_GLOBAL *vb = OP == 3 ? nullptr : reinterpret_cast<const u64x2 BX_GLOBAL *>(as_global(sb[seg].words));
         const int64_t p0 = (c - A.chunk_first) * MB_CHUNK_PAIRS;
         const int64_t p1 = p0 + MB_CHUNK_PAIRS < A.npairs ? p0 + MB_CHUNK_PAIRS : A.npairs;
         const int64_t full_words = A.size_bits >> 6;
@@ -528,12 +530,12 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_group_kernel(const GroupSeg
         // 4 x 16-byte loads per operand in flight per lane before the first store (a chunk is 16 pairs per lane)
         constexpr int U = 4;
         for (int64_t pb = p0 + threadIdx.x; pb < p1; pb += (int64_t)BITS_THREADS * U) {
-            ulonglong2 x[U], y[U];
+            u64x2 x[U], y[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int64_t p = pb + (int64_t)u * BITS_THREADS;
-                x[u] = p < p1 ? va[p] : make_ulonglong2(0, 0);
-                if (OP != 3) y[u] = p < p1 ? vb[p] : make_ulonglong2(0, 0);
+                x[u] = p < p1 ? va[p] : u64x2{0, 0};
+                if (OP != 3) y[u] = p < p1 ? vb[p] : u64x2{0, 0};
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(BITS_THREADS) void bits_group_kernel(const GroupSeg
                         x[u].x |= y[u].x;
                         x[u].y |= y[u].y;
                     }
-                    store_pair_nt(va + p, x[u]);
+                    __builtin_nontemporal_store(x[u], va + p);
                 }
                 if (COUNT) {
                     int64_t w = p * 2;

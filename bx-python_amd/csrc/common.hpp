@@ -102,6 +102,29 @@ inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // ---- wave64 device helpers --------------------------------------------------
 #define BXMI_WAVE 64
 
+// Pointers the kernels LOAD FROM MEMORY (the members of BmSeg / IndexDev in a segment table) are generic to the compiler: every
+// access through them becomes a FLAT instruction, which counts against the vector-memory AND the LDS counter and may complete
+// out of order between the two -- the compiler then waits for `vmcnt(0) lgkmcnt(0)` wherever it waits at all, and every LDS wait
+// drains the loads and stores in flight.  (Kernel ARGUMENTS are known to be global.)  as_global() types such a pointer as what it
+// is -- address space 1 -- and the accesses through the result are global_load / global_store with counted waits.
+#define BX_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ T BX_GLOBAL *as_global(T *p)
+{
+    return (T BX_GLOBAL *)p;
+}
+// (int4 is a class: it cannot be copied out of or into another address space -- 16-byte accesses go through the built-in vector type)
+typedef int bx_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 load_int4(const int32_t BX_GLOBAL *p)
+{
+    const bx_v4i v = *reinterpret_cast<const bx_v4i BX_GLOBAL *>(p);
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store_int4(int32_t BX_GLOBAL *p, int a, int b, int c, int d)
+{
+    *reinterpret_cast<bx_v4i BX_GLOBAL *>(p) = bx_v4i{a, b, c, d};
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // DPP controls (gfx9 DPP16 encodings).

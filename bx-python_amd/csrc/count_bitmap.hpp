@@ -344,7 +344,7 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
     unsigned *scan_tmp = reinterpret_cast<unsigned *>(toff + NBK);                 // [16]
     const int64_t tile = blockIdx.x;
     BmGeom g;
-    const int32_t *__restrict__ qs, *__restrict__ qe;  // this tile's queries
+    const int32_t BX_GLOBAL *__restrict__ qs, *__restrict__ qe;  // this tile's queries (as_global: common.hpp)
     int64_t nq, ltile, ntiles_seg;
     if (npar) {
         if (blockIdx.x == 0) bm_write_params(par, npar, po);  // (nothing below depends on it: later kernels read the block)
@@ -352,13 +352,13 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
         while (i + 1 < npar && tile >= par.seg[i].tile_end) i++;
         g = par.seg[i].g;
         ltile = tile - par.seg[i].tile0, ntiles_seg = par.seg[i].ntiles;
-        qs = par.seg[i].qs + ltile * TILE, qe = par.seg[i].qe + ltile * TILE;
+        qs = as_global(par.seg[i].qs) + ltile * TILE, qe = as_global(par.seg[i].qe) + ltile * TILE;
         nq = par.seg[i].nq - ltile * TILE;
     } else {
         const BmSeg &sg = segs[tile_seg[tile]];
         g = sg.g;
         ltile = tile - sg.tile0, ntiles_seg = sg.ntiles;
-        qs = sg.qs + ltile * TILE, qe = sg.qe + ltile * TILE;
+        qs = as_global(sg.qs) + ltile * TILE, qe = as_global(sg.qe) + ltile * TILE;
         nq = sg.nq - ltile * TILE;
     }
     if (ltile >= ntiles_seg) return;  // padding up to the next plan group
@@ -371,11 +371,10 @@ __global__ __launch_bounds__(THREADS) void bm_tile_sort_kernel(const BmSeg *__re
     unsigned br[ITEMS];  // bucket << 16 | rank inside the (tile, bucket) run
     int4 vs[ITEMS / 4], ve[ITEMS / 4];
     if (n == TILE) {
-        const int4 *s4 = reinterpret_cast<const int4 *>(qs + base), *e4 = reinterpret_cast<const int4 *>(qe + base);
 #pragma unroll
-        for (int j = 0; j < ITEMS / 4; j++) vs[j] = s4[j * THREADS + threadIdx.x];
+        for (int j = 0; j < ITEMS / 4; j++) vs[j] = load_int4(qs + base + 4 * (j * THREADS + (int)threadIdx.x));
 #pragma unroll
-        for (int j = 0; j < ITEMS / 4; j++) ve[j] = e4[j * THREADS + threadIdx.x];
+        for (int j = 0; j < ITEMS / 4; j++) ve[j] = load_int4(qe + base + 4 * (j * THREADS + (int)threadIdx.x));
 #pragma unroll
         for (int j = 0; j < ITEMS / 4; j++) {
             const unsigned bx = bm_sort_key_of<SUB>(vs[j].x, g), by = bm_sort_key_of<SUB>(vs[j].y, g), bz = bm_sort_key_of<SUB>(vs[j].z, g),
@@ -838,8 +837,8 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
     const IndexDev ix = sg.ix;
     const BmGeom g = sg.g;
     const int32_t *__restrict__ e_sorted = sg.e_sorted;
-    const int32_t *__restrict__ qs_arr = sg.qs + ltile * TILE, *__restrict__ qe_arr = sg.qe + ltile * TILE;  // escapes only
-    int32_t *__restrict__ out = sg.counts + ltile * TILE;
+    const int32_t BX_GLOBAL *__restrict__ qs_arr = as_global(sg.qs) + ltile * TILE, *__restrict__ qe_arr = as_global(sg.qe) + ltile * TILE;  // escapes only
+    int32_t BX_GLOBAL *__restrict__ out = as_global(sg.counts) + ltile * TILE;  // (as_global: common.hpp)
     cnt += tile * TILE, slots += tile * TILE;  // scratch is laid out by the batch's tile numbering
     const int64_t nq = sg.nq - ltile * TILE;
     const int64_t base = 0;
@@ -861,7 +860,7 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
     long long acc = 0;
     if (n == TILE) {
         const uint2 *l4 = reinterpret_cast<const uint2 *>(slots + base);
-        int4 *o4 = reinterpret_cast<int4 *>(out + base);
+        int32_t BX_GLOBAL *o4 = out + base;
         uint2 sl[ITEMS / 4];
 #pragma unroll
         for (int j = 0; j < ITEMS / 4; j++) sl[j] = l4[j * THREADS + threadIdx.x];
@@ -874,7 +873,7 @@ __global__ __launch_bounds__(THREADS) void bm_unpermute_kernel(const unsigned *_
                 for (int u = 0; u < 4; u++)
                     if (c[u] == BM_REC_ESC) c[u] = (unsigned)bm_escape_count(ix, e_sorted, g, qs_arr[k0 + u], qe_arr[k0 + u]);
             }
-            if (sg.counts) o4[j * THREADS + threadIdx.x] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);  // (NULL: the caller wants the total only)
+            if (sg.counts) store_int4(o4 + 4 * (j * THREADS + (int)threadIdx.x), (int)c[0], (int)c[1], (int)c[2], (int)c[3]);  // (NULL: the caller wants the total only)
             acc += (long long)c[0] + c[1] + c[2] + c[3];
             if (FIND >= 2) {  // the four queries 4 (j THREADS + t) ..: part 4 j + t / 256 -- one part per wave and j
                 unsigned long long ws = (unsigned long long)c[0] + c[1] + c[2] + c[3];

@@ -963,7 +963,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
         I.g = g;
     } else {
         // the image (streams through L2 once: non-temporal loads); every load of a lane issued before its first LDS store
-        const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.dimages + (size_t)unit * image_bytes);
+        const bm_v4i BX_GLOBAL *src = reinterpret_cast<const bm_v4i BX_GLOBAL *>(as_global(sg.dimages) + (size_t)unit * image_bytes);
         const int n4 = L.ov >> 4;  // (the overflow area follows, as much of it as is used)
         constexpr int SWEEPS = 5;
         for (int i0 = 0; i0 < n4; i0 += SWEEPS * BD_THREADS) {
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(BD_THREADS) void bd_search_kernel(const BmSeg *__re
     }
     __syncthreads();
     if (FMT == 0) {
-        const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.dimages + (size_t)unit * image_bytes + L.ov);
+        const bm_v4i BX_GLOBAL *src = reinterpret_cast<const bm_v4i BX_GLOBAL *>(as_global(sg.dimages) + (size_t)unit * image_bytes + L.ov);
         const int used = (int)reinterpret_cast<const unsigned *>(reinterpret_cast<unsigned char *>(dyn) + L.hdr)[12];  // overflow entries of this unit
         const int n4 = (used * 2 + 15) >> 4;
         for (int i = threadIdx.x; i < n4; i += BD_THREADS) reinterpret_cast<bm_v4i *>(reinterpret_cast<unsigned char *>(dyn) + L.ov)[i] = __builtin_nontemporal_load(src + i);
@@ -1470,7 +1470,7 @@ __global__ __launch_bounds__(THREADS) void bw_search_kernel(const BmSeg *__restr
             // the loads travel while the slower waves finish: the 36 registers are live across the loop's back edge and the
             // allocator spills five of the nine pieces beside the 1024-thread walk's 127 -- search 204 -> 245 us on configs[1];
             // the 512-thread walk keeps them (126 registers) and gains 0.5-2 %: its CU's other workgroup hides the load already.)
-            const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.pimages + (size_t)unit * LP.bytes);
+            const bm_v4i BX_GLOBAL *src = reinterpret_cast<const bm_v4i BX_GLOBAL *>(as_global(sg.pimages) + (size_t)unit * LP.bytes);
             const int n4 = LP.bytes >> 4;
             bm_v4i v[PF];
 #pragma unroll
@@ -1802,7 +1802,7 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(const BmSeg *__restric
         const BpLayout LP = bp_layout(g.shift + g.f, cell_log2, WIDE ? g.stride : 0);
         if (threadIdx.x == 0) s_item_next = it_lo + (int)atomicAdd(&xcd_next[xcd], 1u);
         if (unit >= 0 && ((seg << 16) | unit) != loaded) {  // (the barrier at the end of the item before: nobody reads the old image any more)
-            const bm_v4i *src = reinterpret_cast<const bm_v4i *>(sg.pimages + (size_t)unit * LP.bytes);
+            const bm_v4i BX_GLOBAL *src = reinterpret_cast<const bm_v4i BX_GLOBAL *>(as_global(sg.pimages) + (size_t)unit * LP.bytes);
             const int n4 = LP.bytes >> 4;
             bm_v4i v[PF];
 #pragma unroll
@@ -1846,14 +1846,14 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(const BmSeg *__restric
                 const int64_t q = qb + (int64_t)u * THREADS, k0 = 4 * q;
                 whole[u] = q < q1 && k0 >= lo && k0 + 4 <= hi;  // (hi <= nq: a whole group never reads past the arrays)
                 if (whole[u]) {
-                    const int4 vs = reinterpret_cast<const int4 *>(sg.qs)[q], ve = reinterpret_cast<const int4 *>(sg.qe)[q];
+                    const int4 vs = load_int4(as_global(sg.qs) + 4 * q), ve = load_int4(as_global(sg.qe) + 4 * q);
                     s[u][0] = vs.x, s[u][1] = vs.y, s[u][2] = vs.z, s[u][3] = vs.w;
                     e[u][0] = ve.x, e[u][1] = ve.y, e[u][2] = ve.z, e[u][3] = ve.w;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const bool in = q < q1 && k0 + j >= lo && k0 + j < hi;
-                        s[u][j] = in ? sg.qs[k0 + j] : 0, e[u][j] = in ? sg.qe[k0 + j] : 0;
+                        s[u][j] = in ? as_global(sg.qs)[k0 + j] : 0, e[u][j] = in ? as_global(sg.qe)[k0 + j] : 0;
                     }
                 }
             }
@@ -1884,11 +1884,11 @@ __global__ __launch_bounds__(THREADS) void bs_walk_kernel(const BmSeg *__restric
                 }
                 if (sg.counts) {
                     if (whole[u]) {
-                        reinterpret_cast<int4 *>(sg.counts)[q] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);
+                        store_int4(as_global(sg.counts) + 4 * q, (int)c[0], (int)c[1], (int)c[2], (int)c[3]);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            if (k0 + j >= lo && k0 + j < hi) sg.counts[k0 + j] = (int)c[j];
+                            if (k0 + j >= lo && k0 + j < hi) as_global(sg.counts)[k0 + j] = (int)c[j];
                     }
                 }
                 acc += (long long)c[0] + c[1] + c[2] + c[3];
@@ -1933,8 +1933,8 @@ __device__ __forceinline__ void bd_unpermute_tile(const unsigned short *__restri
     const IndexDev ix = sg.ix;
     const BmGeom g = sg.g;
     const int32_t *__restrict__ e_sorted = sg.e_sorted;
-    const int32_t *__restrict__ qs_arr = sg.qs + ltile * TILE, *__restrict__ qe_arr = sg.qe + ltile * TILE;  // escapes only
-    int32_t *__restrict__ out = sg.counts + ltile * TILE;
+    const int32_t BX_GLOBAL *__restrict__ qs_arr = as_global(sg.qs) + ltile * TILE, *__restrict__ qe_arr = as_global(sg.qe) + ltile * TILE;  // escapes only
+    int32_t BX_GLOBAL *__restrict__ out = as_global(sg.counts) + ltile * TILE;  // (as_global: common.hpp)
     static_assert(!W8 || PAD, "8-bit counts come with the padded layout");
     const unsigned char *vals8 = reinterpret_cast<const unsigned char *>(dyn);
     cnt = W8 ? reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned char *>(cnt) + tile * STRIDE) : cnt + tile * STRIDE;
@@ -2004,7 +2004,7 @@ __device__ __forceinline__ void bd_unpermute_tile(const unsigned short *__restri
     }
     if (n == TILE) {
         const uint2 *l4 = reinterpret_cast<const uint2 *>(slots);
-        int4 *o4 = reinterpret_cast<int4 *>(out);
+        int32_t BX_GLOBAL *o4 = out;
         uint2 sl[ITEMS / 4];
 #pragma unroll
         for (int j = 0; j < ITEMS / 4; j++) sl[j] = l4[j * THREADS + threadIdx.x];
@@ -2027,7 +2027,7 @@ __device__ __forceinline__ void bd_unpermute_tile(const unsigned short *__restri
             }
             // (no counts array: the caller asked for the total only -- the 4 bytes per query of this store are 0.4 of the kernel's
             // 0.71 GB per 100 M queries)
-            if (sg.counts) o4[j * THREADS + threadIdx.x] = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);
+            if (sg.counts) store_int4(o4 + 4 * (j * THREADS + (int)threadIdx.x), (int)c[0], (int)c[1], (int)c[2], (int)c[3]);
             acc += (long long)c[0] + c[1] + c[2] + c[3];
         }
     } else {
@@ -2056,6 +2056,8 @@ __device__ __forceinline__ void bd_unpermute_tile(const unsigned short *__restri
     }
 }
 
+// (66-68 registers = seven waves per SIMD = one 1024-thread workgroup per CU; held to eight waves, and with the staging loads below
+// requested together, the pass is no faster: 0.662-0.672 against 0.668-0.669 ms, round 6)
 template <int THREADS, int ITEMS, bool PAD = false, bool W8 = false>
 __global__ __launch_bounds__(THREADS) void bd_unpermute_kernel(const unsigned short *__restrict__ cnt, const unsigned short *__restrict__ slots,
                                                                const BmSeg *__restrict__ segs, const unsigned short *__restrict__ tile_seg,

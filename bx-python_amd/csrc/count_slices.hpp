@@ -127,7 +127,7 @@ __device__ __forceinline__ SlUnit sl_stage_unit(const BmSeg &sg, int unit, int32
     const int n_max = U.nS > U.nE ? U.nS : U.nE;
     if (n_max <= 2 * 4 * SL_THREADS) {  // small slices (sparse index): a key per thread and step, nothing issued in vain
         for (int arr = 0; arr < 2; arr++) {
-            const int32_t *__restrict__ A = arr == 0 ? sg.ix.s_ord + U.sLo : sg.e_sorted + U.eLo;
+            const int32_t BX_GLOBAL *__restrict__ A = arr == 0 ? as_global(sg.ix.s_ord) + U.sLo : as_global(sg.e_sorted) + U.eLo;  // (as_global: common.hpp)
             const int n = arr == 0 ? U.nS : U.nE;
             unsigned short *low = arr == 0 ? lowS : lowE, *dir = arr == 0 ? dirS : dirE;
             for (int i = threadIdx.x; i < n; i += SL_THREADS) {
@@ -143,13 +143,13 @@ __device__ __forceinline__ SlUnit sl_stage_unit(const BmSeg &sg, int unit, int32
         int pv[2][SL_STAGE_V];
 #pragma unroll
         for (int arr = 0; arr < 2; arr++) {
-            const int32_t *__restrict__ A = arr == 0 ? sg.ix.s_ord + U.sLo : sg.e_sorted + U.eLo;
+            const int32_t BX_GLOBAL *__restrict__ A = arr == 0 ? as_global(sg.ix.s_ord) + U.sLo : as_global(sg.e_sorted) + U.eLo;  // (as_global: common.hpp)
             const int n = arr == 0 ? U.nS : U.nE;
 #pragma unroll
             for (int k = 0; k < SL_STAGE_V; k++) {
                 const int i = base + (k * SL_THREADS + (int)threadIdx.x) * 4;
                 // (the index arrays are padded past n: a vector that starts below n may read up to 3 keys beyond it)
-                v[arr][k] = *reinterpret_cast<const sl_v4a4 *>(A + (i < n ? i : 0));
+                v[arr][k] = *reinterpret_cast<const sl_v4a4 BX_GLOBAL *>(A + (i < n ? i : 0));
                 pv[arr][k] = A[i > 0 && i < n ? i - 1 : 0];
             }
         }

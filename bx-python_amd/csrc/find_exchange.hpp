@@ -449,14 +449,14 @@ __global__ __launch_bounds__(BM_PART_Q / QPL) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int u = 0; u < QPL; u++) c[u] = 0u, sv[u] = 0u;
     if (k + QPL <= n) {
-        const fx_vqu cv = __builtin_nontemporal_load(reinterpret_cast<const fx_vqu *>(sg.counts + q));
+        const fx_vqu cv = __builtin_nontemporal_load(reinterpret_cast<const fx_vqu BX_GLOBAL *>(as_global(sg.counts) + q));
         const fx_vqu sq = __builtin_nontemporal_load(reinterpret_cast<const fx_vqu *>(svq + q));
 #pragma unroll
         for (int u = 0; u < QPL; u++) c[u] = cv[u], sv[u] = sq[u];
     } else {
 #pragma unroll
         for (int u = 0; u < QPL; u++)
-            if (k + u < n) c[u] = (unsigned)sg.counts[q + u], sv[u] = svq[q + u];
+            if (k + u < n) c[u] = (unsigned)as_global(sg.counts)[q + u], sv[u] = svq[q + u];
     }
     long long mine = 0;
 #pragma unroll
