@@ -496,6 +496,10 @@ __global__ __launch_bounds__(BM_PART_Q / QPL) __attribute__((amdgpu_waves_per_eu
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // (Round 6 made the gathers and stores of a turn unconditional -- a fixed number per turn, so that the compiler counts them and
+    // every store waits for its own gather only, vmcnt(9), where behind these wave-uniform branches each one waits for everything
+    // before it: 811 -> 902 us.  The kernel is bound by the requests it sends (one per query's stretch of the scratch list), not by
+    // the chain; the dummy accesses of the rows beyond the wave's hits are requests too.  Not kept.)
     constexpr int FL = FX_FL2_V;
     for (unsigned s0 = 0; s0 < wtotal; s0 += 64u * FL) {
         unsigned dst[FL];
