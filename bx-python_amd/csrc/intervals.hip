@@ -1904,8 +1904,9 @@ extern "C" int bxmi_ivl_find_dev(bxmi_ivl_t *h, const int32_t *qs, const int32_t
                 BXMI_HIP(hipMemsetAsync(flag, 0, sizeof(unsigned), st));
                 hipLaunchKernelGGL(ivl_sorted_check_kernel, dim3(stream_grid(nq, 256)), dim3(256), 0, st, qs, nq, flag);
                 // the whole chain of the sorted find behind the check, every kernel gated on the check's word: one round trip to the
-                // host (flag and total together) instead of three
-                if (((uintptr_t)offsets & 15) == 0) {
+                // host (flag and total together) instead of three -- for batches the probe has looked at (a smaller batch that is
+                // NOT sorted would pay four launches that stand down before it takes the other path)
+                if (((uintptr_t)offsets & 15) == 0 && nq >= (1 << 20)) {
                     bool stood_down = false;
                     BXMI_TRY(ivl_find_local(h, qs, qe, nq, offsets, hits, cap, total_host, st, flag, &stood_down));
                     if (!stood_down) return BXMI_OK;

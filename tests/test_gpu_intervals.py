@@ -1511,7 +1511,7 @@ def test_genome_two_ranks_full_size_heaviest_share(tmp_path):
 
 def test_find_on_sorted_batches_flat_fill(O, IntervalIndex):
     """find() on a batch sorted by start: the fill that stages a wave's window of pairs and its stretch of the hit list in LDS
-    (part_fill_flat_kernel) against the oracle's hit lists --
+    (part_fill_pipe_kernel) against the oracle's hit lists --
     ordinary stretches, queries on a pile (a wave's stretch beyond the LDS image: direct stores), a few very long targets far
     below the queries' windows (lanes that leave the staged pairs, walks handed to the whole wave), queries without hits."""
     rng = np.random.default_rng(4242)
@@ -1545,6 +1545,41 @@ def test_find_on_sorted_batches_flat_fill(O, IntervalIndex):
         assert np.array_equal(got[0], w_off) and np.array_equal(got[1], w_hits)
     finally:
         reset_opts()
+
+
+def test_find_almost_sorted_batch_stands_down(IntervalIndex):
+    """A large batch that passes the order PROBE (two stretches of 4096 starts) and fails the exact check: the sorted find's chain
+    is launched behind the check without waiting for the host (round 6), every kernel of it stands down on the check's word, and the
+    batch is answered through the exchange -- same lists as the sorted batch's, with the two swapped queries' lists swapped."""
+    rng = np.random.default_rng(777)
+    n, span = 300_000, 30_000_000
+    s = rng.integers(0, span, size=n)
+    e = s + rng.integers(1, 400, size=n)
+    nq = (1 << 21) + 77
+    qs = np.sort(rng.integers(0, span, size=nq))
+    qe = qs + rng.integers(1, 300, size=nq)
+    s, e, qs, qe = (a.astype(np.int32) for a in (s, e, qs, qe))
+    ix = make_index(IntervalIndex, s, e)
+    off_s, hits_s = ix.find(qs, qe)
+    for at in (5, nq - 9):  # far from the probe's stretches (at nq / 3 and 2 nq / 3)
+        assert qs[at] < qs[at + 1]
+        q2s, q2e = qs.copy(), qe.copy()
+        q2s[[at, at + 1]] = q2s[[at + 1, at]]
+        q2e[[at, at + 1]] = q2e[[at + 1, at]]
+        off_w, hits_w = ix.find(q2s, q2e)
+        cnt_s, cnt_w = np.diff(off_s), np.diff(off_w)
+        want = cnt_s.copy()
+        want[[at, at + 1]] = want[[at + 1, at]]
+        assert np.array_equal(cnt_w, want) and off_w[-1] == off_s[-1]
+        lo = off_s[at]
+        assert np.array_equal(hits_w[:lo], hits_s[:lo]) and np.array_equal(hits_w[off_s[at + 2]:], hits_s[off_s[at + 2]:])
+        assert np.array_equal(hits_w[off_w[at]:off_w[at + 1]], hits_s[off_s[at + 1]:off_s[at + 2]])
+        assert np.array_equal(hits_w[off_w[at + 1]:off_w[at + 2]], hits_s[off_s[at]:off_s[at + 1]])
+    # and the sorted batch again behind it: the same lists as before
+    off_a, hits_a = ix.find(qs, qe)
+    assert np.array_equal(off_a, off_s) and np.array_equal(hits_a, hits_s)
+    c, total = ix.count(qs, qe)
+    assert np.array_equal(c, np.diff(off_s)) and total == off_s[-1]
 
 
 def test_find_join_scale_properties(IntervalIndex):
