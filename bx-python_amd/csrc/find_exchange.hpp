@@ -30,6 +30,10 @@
 //      with swapped register sets (no register copied while a load is on its way to it), a batch's run words are used as loaded
 //      (round 5 computed from them where they were requested: a wait), the rare global accesses of the walk are hand-issued (no
 //      FLAT instructions), and the walk reads four candidates per round trip to the LDS: 1.13-1.15 -> 1.04 ms on configs[4].
+//      (Measured on top and not kept, round 6: a record's hits in whole 16-byte SLOTS of the scratch list -- the un-permute kernel
+//      scanning the counts rounded up to four, the tiles' stretches from a scan of the padded totals, every store of the fill one
+//      aligned 16-byte request, -28 % write requests: fill 1092 -> 1025 us, copy 807 -> 836 (its gathers meet sparser lines), find
+//      2.93-2.96 ms either way.)
 // A record whose walk leaves the staged window (long targets far below, piles larger than the window) reads the pairs from HBM
 // as before: exact either way.
 #pragma once
