@@ -611,15 +611,17 @@ def test_bitmap_pass_differential(O, IntervalIndex, shape, stage):
         reset_opts()
 
 
-@pytest.mark.parametrize("shape", ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target", "pile"])
+@pytest.mark.parametrize("shape", ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target", "pile", "pile70k"])
 def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
     """find() on large unsorted batches (count_slices.hpp: count half; find_exchange.hpp: CSR offsets, the fill on LDS windows of
     half-bucket pieces, hits back to query order) against the oracle treap's find: same
     offsets, same hits in the same order.  Escapes (zero-length / reversed / off-grid / over-long queries), duplicated
     coordinates (queries with more hits than a wave's LDS image holds), a tile that is not full, one target spanning
     everything (walks that leave the staged window), a pile of targets larger than a piece's window, all tile shapes, unit
-    sizes and run widths, with and without the copy; and the bucketed find of the first generation on the same input."""
-    shapes = ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target", "pile"]
+    sizes and run widths, with and without the copy; and the bucketed find of the first generation on the same input.
+    pile70k: 70 000 long targets under every query, 65535 hits and more per query -- the count does not fit the word the count half packs for the fill (0xFFFF: read again
+    from the 32-bit counts, a hand-issued load since round 6)."""
+    shapes = ["uniform", "sorted", "messy", "ragged_tail", "dups", "long_target", "pile", "pile70k"]
     rng = np.random.default_rng(70 + shapes.index(shape))
     n, span = 100_000, 30_000_000
     s = rng.integers(1000, span, size=n)
@@ -629,12 +631,18 @@ def test_find_through_the_exchange_differential(O, IntervalIndex, shape):
     if shape == "pile":
         s[:25_000] = rng.integers(5_001_000, 5_003_000, size=25_000)  # one half bucket holds more pairs than an LDS window
     e = s + rng.integers(0, 1200, size=n)
+    if shape == "pile70k":  # 70 000 long targets that every query meets
+        s[:70_000] = rng.integers(1000, 2_000_000, size=70_000)
+        e[:70_000] = s[:70_000] + rng.integers(27_000_000, 28_000_000, size=70_000)
     if shape == "long_target":
         s[0], e[0] = 2000, span - 5  # every query meets it, and the walk down from hi passes thousands of candidates
         s[1], e[1] = 15_000_000, 15_400_000
-    nq = {"ragged_tail": 16384 * 2 + 311}.get(shape, 50_000)
+    nq = {"ragged_tail": 16384 * 2 + 311, "pile70k": 260}.get(shape, 50_000)
     qs = rng.integers(0, span + 2000, size=nq)
     qe = qs + rng.integers(1, 2500, size=nq)
+    if shape == "pile70k":
+        qs = rng.integers(3_000_000, 26_000_000, size=nq)
+        qe = qs + rng.integers(1, 2500, size=nq)
     if shape == "pile":
         qs[:300] = rng.integers(4_999_000, 5_004_000, size=300)
         qe[:300] = qs[:300] + rng.integers(1, 400, size=300)
