@@ -337,6 +337,10 @@ __device__ __forceinline__ void sl_count_slot(const SlUnit &U, const BmGeom &g, 
 // compiler drains the memory pipe between a round's stores and the next round's loads (genome search 0.68 -> 0.80 ms).
 // (8 waves per SIMD = at most 64 VGPRs: two workgroups per CU when the unit's keys leave room, so that one stages its
 // unit while the other searches -- sparse indexes have small units and many work items)
+// (Round 6, after the fills: the run table's words kept as loaded and a COUNTED number of stores per round -- six straight-line stores,
+// lanes without a record writing to a word nobody reads, so that the waits for the next round's runs and records are vmcnt(6..9)
+// instead of drains, HISTORY 11 -- measured 474 -> 489 us on configs[4]: this kernel is bound by its vector instructions, not by
+// those waits.  Not kept.)
 template <int L, int U, bool APART>
 __global__ __launch_bounds__(SL_THREADS) __attribute__((amdgpu_waves_per_eu(APART ? 4 : 8, APART ? 4 : 8))) void sl_search_pipe_kernel(const BmSeg *__restrict__ segs, const int4 *__restrict__ items,
                                                                     const int *__restrict__ n_items, const unsigned *__restrict__ runT, int64_t ntp,
