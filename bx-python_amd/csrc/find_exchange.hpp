@@ -221,7 +221,6 @@ __global__ __launch_bounds__(FX_THREADS) void fx_fill_kernel(const BmSeg *__rest
             }
         }
         __syncthreads();
-        auto pair_at = [&](int k) -> int2 { return (k >= wlo && k < whi) ? s_win[k - wlo] : eid[k]; };
         const unsigned *__restrict__ runs0 = runT2 + (int64_t)pc.sb0 * ntp;
         const unsigned *__restrict__ runs1 = runT2 + (int64_t)(pc.sb1 - 1) * ntp;
         // A wave takes FX_BT tiles at a time (one run per lane), and the kernel is a chain of dependent loads -- run table ->
